@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference/src).
+
+Runs only in the build container (the reference does not travel to the GPU box); the committed
+.npz files are data: inputs + the reference's outputs.  No reference source is copied.
+
+Harness-side shims (they do not modify the reference):
+  * transformer.decoder.pad_list -> utils.utils.pad_list(...)[0]   (decoder.py:54-56 vs utils.py:14)
+  * torch.Tensor.cuda -> identity                                   (cif_model.py:47-100, decoder.py:361)
+  * utils.utils.get_non_pad_mask injected for ctcModel/encoder.py:5
+Usage:  python tests/golden/make_fixtures.py
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from weights import crc_of, make_state_dict, names_shapes_to_json  # noqa: E402
+
+REF = "/root/reference/src"
+sys.path.insert(0, REF)
+import utils.utils as uu  # noqa: E402
+
+uu.get_non_pad_mask = lambda x, input_lengths: uu.sequence_mask(input_lengths).unsqueeze(-1)
+torch.Tensor.cuda = lambda self, *a, **k: self
+import transformer.decoder as tdec  # noqa: E402
+
+tdec.pad_list = lambda xs, v: uu.pad_list(xs, v)[0]
+from transformer.transformer import Conv_CTC_Transformer, CTC_Transformer  # noqa: E402
+from transformer.cif_model import CIF_Model  # noqa: E402
+from transformer.encoder import Encoder  # noqa: E402
+from transformer.decoder import Decoder  # noqa: E402
+from transformer.loss import cal_ctc_ce_loss, cal_ctc_qua_ce_loss, cal_ce_loss  # noqa: E402
+from transformer.optimizer import TransformerOptimizer  # noqa: E402
+from ctcModel.ctc_model import CTC_Model  # noqa: E402
+from ctcModel.encoder import Encoder as CtcEncoder  # noqa: E402
+from ctcModel.decoder import Decoder as CtcDecoder  # noqa: E402
+from ctcModel.loss import cal_loss as ctc_cal_loss  # noqa: E402
+
+S0 = dict(d_input=80, LFR_m=1, d_model=64, n_conv_layers=2, n_layers_enc=2, n_head=2, d_inner=128,
+          dropout=0.0, sos_id=2, eos_id=3, vocab_size=50, n_layers_dec=2, spec_aug_cfg=None,
+          d_assigner_hidden=32, w_context=3, n_assigner_layers=2)
+
+
+def s0_batch(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(4, 100, 80, generator=g)
+    lens = torch.tensor([100, 90, 77, 64])
+    tg = torch.randint(4, 49, (4, 7), generator=g)
+    tg[1, 5:] = 0
+    tg[2, 3:] = 0
+    tg[3, 6:] = 0
+    # a repeated label pair in row 0 exercises the CTC no-skip rule
+    tg[0, 3] = tg[0, 2]
+    return x, lens, tg
+
+
+def load_seeded(model, seed):
+    ns = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    sd = make_state_dict(ns, seed)
+    full = {k: torch.from_numpy(v) for k, v in sd.items()}
+    missing = model.load_state_dict(full, strict=False)
+    assert all(k.endswith("positional_encoding.pe") for k in missing.missing_keys), missing
+    return ns, sd
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def cfg_arrays():
+    return {f"cfg_{k}": np.asarray(v) for k, v in S0.items() if isinstance(v, (int, float))}
+
+
+def g0_conv_ctc_transformer():
+    args = argparse.Namespace(**S0)
+    model = Conv_CTC_Transformer.create_model(args).eval()
+    ns, sd = load_seeded(model, seed=100)
+    x, lens, tg = s0_batch()
+    conv_out, len_seq = model.conv_encoder(x, lens)
+    enc_out = model.encoder(conv_out, len_seq)
+    ctc_logits, l, logits, teos = model(x, lens, tg)
+    ctc, ce = cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+    ce0 = cal_ce_loss(logits, teos, 0.0)
+    model.zero_grad()
+    (ctc + ce).backward()
+    grads = {k: npy(p.grad) for k, p in model.named_parameters()}
+    keep = ["ctc_fc.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight", "conv_encoder.conv.subsample/conv0.weight",
+            "decoder.tgt_word_emb.weight", "decoder.layer_stack.1.enc_attn.fc.bias",
+            "encoder.layer_norm_in.weight", "conv_encoder.affine.weight"]
+    out = dict(names_shapes=names_shapes_to_json(ns), seed=100, crc=crc_of(sd),
+               x=npy(x), lens=npy(lens), targets=npy(tg), conv_out=npy(conv_out), conv_len=npy(len_seq),
+               enc_out=npy(enc_out), ctc_logits=npy(ctc_logits), ctc_len=npy(l), logits=npy(logits),
+               targets_eos=npy(teos), ctc_loss=npy(ctc), ce_loss_s01=npy(ce), ce_loss_s0=npy(ce0),
+               pe_head=npy(model.encoder.positional_encoding.pe[0, :128]),
+               grad_norms=np.array([np.linalg.norm(grads[k]) for k in sorted(grads)], dtype=np.float64),
+               grad_names="|".join(sorted(grads)), **cfg_arrays())
+    for k in keep:
+        out["grad:" + k] = grads[k]
+
+    # G6: one optimizer step exactly as the harness does it (solver.py:88-93, optimizer.py:19-29, train.py:166-170)
+    opt = TransformerOptimizer(torch.optim.Adam(model.parameters(), betas=(0.9, 0.98), eps=1e-9), 0.2, S0["d_model"], 4000)
+    before = {k: npy(p).copy() for k, p in model.named_parameters()}
+    opt.step()
+    out["lr_step1"] = np.float64(opt.optimizer.param_groups[0]["lr"])
+    for k in ["ctc_fc.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight"]:
+        out["delta:" + k] = dict(model.named_parameters())[k].detach().numpy() - before[k]
+    lrs = []
+    for n in (1, 4000, 10000):
+        o = TransformerOptimizer(torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))]), 0.2, 256, 4000)
+        o.step_num = n - 1
+        o._update_lr()
+        lrs.append(o.optimizer.param_groups[0]["lr"])
+    out["noam_k0.2_d256_w4000_steps_1_4000_10000"] = np.array(lrs, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "g0_conv_ctc_transformer.npz"), **out)
+    print("G0 ctc", float(ctc), "ce", float(ce), "ce0", float(ce0))
+
+
+def g1_ctc_transformer():
+    enc = Encoder(80, 2, 2, 64, 128, dropout=0.0)
+    dec = Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.0)
+    model = CTC_Transformer(enc, dec).eval()
+    ns, sd = load_seeded(model, seed=101)
+    x, lens, tg = s0_batch(seed=1)
+    x = x[:, :40].contiguous()
+    lens = torch.tensor([40, 33, 25, 12])
+    l, ctc_logits, (logits, teos) = model(x, lens, tg)
+    enc_out = model.encoder(x, lens)
+    ctc, ce = cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+    np.savez_compressed(os.path.join(HERE, "g1_ctc_transformer.npz"), names_shapes=names_shapes_to_json(ns), seed=101,
+                        crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), enc_out=npy(enc_out),
+                        ctc_logits=npy(ctc_logits), ctc_len=npy(l), logits=npy(logits), targets_eos=npy(teos),
+                        ctc_loss=npy(ctc), ce_loss_s01=npy(ce), **cfg_arrays())
+    print("G1 ctc", float(ctc), "ce", float(ce))
+
+
+def g2_ctc():
+    """Known-answer set for torch 2.10 CPU F.ctc_loss as the reference calls it (loss.py:41-43)."""
+    out = {}
+    cases = {"a": (25, 4, 7, 50), "b": (60, 3, 20, 11), "c": (8, 2, 4, 5)}
+    g = torch.Generator().manual_seed(7)
+    for name, (T, B, U, V) in cases.items():
+        logits = torch.randn(B, T, V, generator=g, requires_grad=True)
+        tg = torch.randint(1, V - 1, (B, U), generator=g)
+        in_len = torch.full((B,), T, dtype=torch.int64)
+        if name == "a":
+            tg[0, 1] = tg[0, 0]; tg[0, 4] = tg[0, 3]          # repeats
+            tg[1, 1:] = 0                                     # U = 1
+            tg[2, 5:] = 0
+            in_len = torch.tensor([25, 20, 13, 25])           # ragged
+        if name == "b":
+            tg[1, 10:] = 0
+            in_len = torch.tensor([60, 41, 47])
+        if name == "c":
+            tg[0] = torch.tensor([1, 1, 2, 2])                # needs T >= 4 + 2 repeats = 6
+            in_len = torch.tensor([6, 8])                     # row 0 sits exactly on the feasibility edge
+        tgt_len = tg.ne(0).int().sum(1)
+        lp = F.log_softmax(logits, dim=-1).transpose(0, 1)
+        nll = F.ctc_loss(lp, tg, in_len, tgt_len, blank=V - 1, reduction="none")
+        mean = F.ctc_loss(lp, tg, in_len, tgt_len, blank=V - 1)
+        mean.backward()
+        out.update({f"{name}_logits": npy(logits), f"{name}_targets": npy(tg), f"{name}_in_len": npy(in_len),
+                    f"{name}_nll": npy(nll), f"{name}_mean": npy(mean), f"{name}_grad": npy(logits.grad)})
+    # infeasible alignment -> inf (zero_infinity=False is the reference default)
+    logits = torch.randn(2, 5, 6, generator=g)
+    tg = torch.tensor([[1, 1, 1, 2], [3, 0, 0, 0]])
+    in_len = torch.tensor([5, 5])
+    tgt_len = tg.ne(0).int().sum(1)
+    nll = F.ctc_loss(F.log_softmax(logits, -1).transpose(0, 1), tg, in_len, tgt_len, blank=5, reduction="none")
+    out.update(d_logits=npy(logits), d_targets=npy(tg), d_in_len=npy(in_len), d_nll=npy(nll))
+    np.savez_compressed(os.path.join(HERE, "g2_ctc.npz"), **out)
+    print("G2", {k: v for k, v in out.items() if k.endswith("_nll")})
+
+
+def g3_cif():
+    out = {}
+    thr = 0.95
+    f = np.float32
+    # hand-built rows, T=12, H=4.  Row 5 carries a large sum so max round(sum alpha) admits every row's fires.
+    rows = np.zeros((6, 12), dtype=np.float32)
+    rows[0, :4] = [f(0.95), 0.0, 1e-7, 0.5]                 # exact tie at thr (no fire), then tiny step over it
+    rows[1, :5] = [1.7, 0.5, 0.1, 0.9, 0.2]                 # alpha > 1: one fire per frame even when crossing twice
+    rows[2, :6] = [0.5, 0.46, 0.5, 0.46, 0.5, 0.4]          # fires = round(sum)-1 style boundary
+    rows[3, :3] = [0.3, 0.3, 0.3]                           # never fires, zero tail
+    rows[4, :] = 0.0                                        # empty row
+    rows[5, :] = [0.9, 0.8, 0.7, 0.99, 0.97, 0.6, 0.5, 0.96, 0.4, 0.3, 0.95, 0.94]
+    g = torch.Generator().manual_seed(3)
+    hid = torch.randn(6, 12, 4, generator=g, requires_grad=True)
+    al = torch.from_numpy(rows).clone().requires_grad_(True)
+    o = CIF_Model.cif(None, hid, al, thr)
+    w = torch.randn(o.shape, generator=g)
+    (o * w).sum().backward()
+    out.update(h_alpha=rows, h_hidden=npy(hid), h_out=npy(o), h_w=npy(w), h_galpha=npy(al.grad), h_ghidden=npy(hid.grad))
+    # random rows, the S3 recipe scaled down: sum alpha_b = U_b + U(-.5,.5)
+    B, T, H = 8, 60, 16
+    a = torch.sigmoid(torch.randn(B, T, generator=g))
+    lens = torch.tensor([60, 60, 55, 50, 41, 33, 60, 20])
+    a = a * uu.sequence_mask(lens)
+    U = torch.tensor([9, 7, 8, 5, 6, 4, 9, 3]).float()
+    a = a * ((U + torch.rand(B, generator=g) - 0.5) / a.sum(-1))[:, None]
+    a = a.detach().clone().requires_grad_(True)
+    hid = torch.randn(B, T, H, generator=g, requires_grad=True)
+    o = CIF_Model.cif(None, hid, a, thr)
+    w = torch.randn(o.shape, generator=g)
+    (o * w).sum().backward()
+    out.update(r_alpha=npy(a), r_hidden=npy(hid), r_out=npy(o), r_w=npy(w), r_galpha=npy(a.grad), r_ghidden=npy(hid.grad),
+               r_round_sum=npy(torch.round(a.sum(-1)).int()))
+    np.savez_compressed(os.path.join(HERE, "g3_cif.npz"), **out)
+    print("G3 out shapes", out["h_out"].shape, out["r_out"].shape)
+
+
+def g4_cif_model():
+    args = argparse.Namespace(**S0)
+    model = CIF_Model.create_model(args).eval()
+    ns, sd = load_seeded(model, seed=104)
+    x, lens, tg = s0_batch(seed=4)
+    # record the noise the reference will draw at cif_model.py:47, then replay the same RNG state
+    torch.manual_seed(1234)
+    noise = torch.rand(4)
+    torch.manual_seed(1234)
+    ctc_logits, l, _num, num, logits = model(x, lens, tg)
+    qua, ctc, ce = cal_ctc_qua_ce_loss(ctc_logits, l, _num, num, logits, tg, smoothing=0.1)
+    # intermediates
+    conv_out, len_seq = model.conv_encoder(x, lens)
+    enc_out = model.encoder(conv_out, len_seq)
+    alpha0 = model.assigner(enc_out, len_seq)
+    alpha = alpha0 * ((num + noise - 0.5) / alpha0.sum(-1))[:, None]
+    cif_out = model.cif(enc_out, alpha, 0.95)
+    np.savez_compressed(os.path.join(HERE, "g4_cif_model.npz"), names_shapes=names_shapes_to_json(ns), seed=104,
+                        crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), noise=npy(noise),
+                        ctc_logits=npy(ctc_logits), ctc_len=npy(l), num_pred=npy(_num), num=npy(num), logits=npy(logits),
+                        alpha_raw=npy(alpha0), alpha=npy(alpha), cif_out=npy(cif_out), enc_out=npy(enc_out),
+                        qua_loss=npy(qua), ctc_loss=npy(ctc), ce_loss_s01=npy(ce), **cfg_arrays())
+    print("G4 qua", float(qua), "ctc", float(ctc), "ce", float(ce), "cif_out", tuple(cif_out.shape))
+
+
+def g5_ctc_model():
+    enc = CtcEncoder(80, 2, 2, 64, 64, 64, 128, dropout=0.0, pe_maxlen=5000)
+    dec = CtcDecoder(50, 64)
+    model = CTC_Model(enc, dec).eval()
+    ns, sd = load_seeded(model, seed=105)
+    x, lens, tg = s0_batch(seed=5)
+    x = x[:, :40].contiguous()
+    lens = torch.tensor([40, 31, 22, 17])
+    logits, l = model(x, lens)
+    loss = ctc_cal_loss(logits, l, tg)
+    np.savez_compressed(os.path.join(HERE, "g5_ctc_model.npz"), names_shapes=names_shapes_to_json(ns), seed=105,
+                        crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), logits=npy(logits), len=npy(l),
+                        loss=npy(loss), **cfg_arrays())
+    print("G5 loss", float(loss))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    g0_conv_ctc_transformer()
+    g1_ctc_transformer()
+    g2_ctc()
+    g3_cif()
+    g4_cif_model()
+    g5_ctc_model()
