@@ -1,0 +1,88 @@
+// Shared device/host helpers for libasr_hip.so (gfx950 / CDNA4 only: wave = 64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/asr_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define ASR_WAVE 64
+
+// ---- error plumbing (thread-local message, no exceptions across the ABI) ------------------------------------
+void asr_set_error(const char* fmt, ...);
+#define ASR_REQUIRE(cond, code, ...)      \
+    do {                                  \
+        if (!(cond)) {                    \
+            asr_set_error(__VA_ARGS__);   \
+            return (code);                \
+        }                                 \
+    } while (0)
+#define ASR_LAUNCH_CHECK(name)                                          \
+    do {                                                                \
+        hipError_t e__ = hipGetLastError();                             \
+        if (e__ != hipSuccess) {                                        \
+            asr_set_error("%s: %s", name, hipGetErrorString(e__));      \
+            return (int)e__;                                            \
+        }                                                               \
+    } while (0)
+
+static inline bool asr_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---- device helpers ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// online (max, sum-exp) pair combine
+__device__ __forceinline__ void lse_combine(float& m, float& s, float m2, float s2) {
+    float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { s = 0.f; m = mn; return; }
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+template <typename T> struct DType;
+template <> struct DType<float> { static constexpr int code = ASR_F32; };
+template <> struct DType<bf16_t> { static constexpr int code = ASR_BF16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// ---- MFMA 16x16 step over one 4-chunk group of K (a 64-byte slice of K per row) -----------------------------
+// Each lane supplies the 16-byte chunk (lane>>4) of row (lane&15) for both operands.  bf16: one
+// v_mfma_f32_16x16x32_bf16;  f32: four exact v_mfma_f32_16x16x4_f32 (element j of each lane's float4 pairs up).
+// D[row][col]: row index comes from operand `a`, col from operand `b`; lane holds col = lane&15, rows (lane>>4)*4+reg.
+template <typename CT> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], c, 0, 0, 0);
+    }
+};
+

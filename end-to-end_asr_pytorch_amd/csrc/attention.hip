@@ -1,0 +1,288 @@
+// Fused scaled-dot-product attention forward for gfx950 (replaces attention.py:76-84 + the permutes of :47-57).
+//
+// bf16 path (the product path): flash-style, one workgroup = NW waves x 32 query rows of one (batch, head).
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16_bf16 (A = K tile rows from LDS, B = Q rows held in registers), so the
+//     query index sits on the LANE and the 32 keys of a half-tile sit in the 16 accumulator registers x 2 lane
+//     halves: the online-softmax row max / row sum are 16 in-register ops + one cross-half shuffle, and the
+//     running rescale of O is a per-lane scalar.
+//   * P^T feeds the PV MFMA directly from those registers as the B operand (O^T = V^T.P^T); the k-order
+//     permutation this implies is absorbed by how the A operand (V^T) is read from LDS.
+//   * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] live in LDS, XOR-swizzled so the ds_read_b128 (K) and
+//     ds_read_b64 (V^T) fragment reads are bank-conflict free; V is transposed on the way in (4x4 register
+//     transpose + ds_write_b64); global loads for tile t+1 are issued before the MFMAs of tile t.
+//   * masks come from lengths (key j masked iff j >= k_len[b] or causal && j > i); no mask tensor is read.
+// fp32 path: one wave per query row, plain VALU, exact fp32 - the parity/debug mode, not a performance path.
+#include "asr_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 reference-precision kernel
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                           const float* __restrict__ V, float* __restrict__ ctx,
+                                                           float* __restrict__ lse, int B, int h, int Lq, int Lk,
+                                                           const int32_t* __restrict__ k_len, int causal) {
+    __shared__ float qs[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    if (gw >= (int64_t)B * h * Lq) return;
+    const int i = (int)(gw % Lq);
+    const int bh = (int)(gw / Lq);
+    const int b = bh / h, hd = bh - b * h;
+    int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int kend = causal ? min(kl, i + 1) : kl;
+    qs[wave][lane] = Q[((int64_t)bh * Lq + i) * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    float m = -INFINITY, l = 0.f, acc = 0.f;
+    for (int j0 = 0; j0 < kend; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < kend;
+        float s = -INFINITY;
+        if (valid) {
+            const float* kr = K + ((int64_t)bh * Lk + j) * 64;
+            float d = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < 64; dd += 4) {
+                const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + dd);
+                d = fmaf(qs[wave][dd], kv[0], d);
+                d = fmaf(qs[wave][dd + 1], kv[1], d);
+                d = fmaf(qs[wave][dd + 2], kv[2], d);
+                d = fmaf(qs[wave][dd + 3], kv[3], d);
+            }
+            s = d;
+        }
+        const float mc = wave_max(s);
+        const float mn = fmaxf(m, mc);
+        const float sc = (m == -INFINITY) ? 0.f : expf(m - mn);
+        const float p = valid ? expf(s - mn) : 0.f;
+        l = l * sc + wave_sum(p);
+        acc *= sc;
+        const int cnt = min(64, kend - j0);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float pj = __shfl(p, jj, 64);
+            acc = fmaf(pj, V[((int64_t)bh * Lk + j0 + jj) * 64 + lane], acc);
+        }
+        m = mn;
+    }
+    ctx[((int64_t)b * Lq + i) * (h * 64) + hd * 64 + lane] = acc / l;
+    if (lse && lane == 0) lse[(int64_t)bh * Lq + i] = m + logf(l);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 MFMA flash kernel
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+
+template <int NW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                   const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
+                                                                   float* __restrict__ lse, int h, int Lq, int Lk,
+                                                                   const int32_t* __restrict__ k_len, int q_tiles) {
+    constexpr int NTHR = NW * 64;
+    constexpr int QB = NW * 32;            // query rows per workgroup
+    constexpr int KCH = 512 / NTHR;        // 16-byte K chunks per thread per tile
+    constexpr int VBL = 256 / NTHR;        // 4x4 V blocks per thread per tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 8192];
+    unsigned char* Ks = smem;
+    unsigned char* Vt = smem + 8192;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qt = blockIdx.x % q_tiles;
+    const int bh = blockIdx.x / q_tiles;
+    const int b = bh / h, hd = bh - b * h;
+    const int q0 = qt * QB;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
+    const int ntiles = (kmax + 63) >> 6;
+    const int qrow = q0 + wave * 32 + r;
+    const int wave_qlast = q0 + wave * 32 + 31;
+
+    const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
+    const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
+
+    u32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = (qrow < Lq) ? *reinterpret_cast<const u32x4*>(Q + ((int64_t)bh * Lq + qrow) * 64 + 16 * s + 8 * hh)
+                            : u32x4{0, 0, 0, 0};
+
+    u32x4 kreg[KCH];
+    u32x2 vreg[VBL][4];
+    auto gload = [&](int t) {
+        const int key0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int id = tid + NTHR * i;
+            const int row = id >> 3, c = id & 7;
+            const int key = key0 + row;
+            kreg[i] = (key < kl) ? *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * 64 + c * 8) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < VBL; ++i) {
+            const int id = tid + NTHR * i;
+            const int dg = id & 15, kg = id >> 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int key = key0 + 4 * kg + kk;
+                vreg[i][kk] = (key < kl) ? *reinterpret_cast<const u32x2*>(Vb + (int64_t)key * 64 + 4 * dg) : u32x2{0, 0};
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int id = tid + NTHR * i;
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4*>(Ks + row * 128 + swz_chunk(row, c)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VBL; ++i) {
+            const int id = tid + NTHR * i;
+            const int dg = id & 15, kg = id >> 4;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int w = dd >> 1, sh = (dd & 1) * 16;
+                const unsigned e0 = (vreg[i][0][w] >> sh) & 0xffffu, e1 = (vreg[i][1][w] >> sh) & 0xffffu;
+                const unsigned e2 = (vreg[i][2][w] >> sh) & 0xffffu, e3 = (vreg[i][3][w] >> sh) & 0xffffu;
+                const int row = 4 * dg + dd;  // d index
+                const int off = row * 128 + swz_chunk(row, kg >> 1) + (((kg & 1) ^ ((row >> 4) & 1)) << 3);
+                *reinterpret_cast<u32x2*>(Vt + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+            }
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    if (ntiles > 0) gload(0);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (t + 1 < ntiles) gload(t + 1);
+        const int key0 = t * 64;
+        if (CAUSAL && key0 > wave_qlast) continue;  // wave-uniform: whole tile in this wave's future
+
+        // ---- S^T = K . Q^T : two 32-key halves --------------------------------------------------------
+        f32x16 st[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) st[hf][i] = 0.f;
+            const int row = hf * 32 + r;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + row * 128 + swz_chunk(row, 2 * s + hh));
+                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                 __builtin_bit_cast(bf16x8, qf[s]), st[hf], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (query on the lane) ------------------------------------------------
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const bool bad = key >= kl || (CAUSAL && key > qrow);
+                st[hf][i] = bad ? -INFINITY : st[hf][i];
+                mloc = fmaxf(mloc, st[hf][i]);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mn = fmaxf(m, mloc);
+        const float mbase = (mn == -INFINITY) ? 0.f : mn;
+        const float alpha = __expf(m - mbase);  // m = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __expf(st[hf][i] - mbase);
+                st[hf][i] = p;
+                rs += p;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+
+        // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[hf][8 * s2 + j];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int row = dt * 32 + r;
+                    const int sub = (hh ^ ((row >> 4) & 1)) << 3;
+                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(Vt + row * 128 + swz_chunk(row, hf * 4 + 2 * s2) + sub);
+                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(Vt + row * 128 + swz_chunk(row, hf * 4 + 2 * s2 + 1) + sub);
+                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+                    if (dt == 0)
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
+                    else
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
+                }
+            }
+    }
+
+    if (qrow < Lq) {
+        const float inv = 1.f / l;
+        bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * hh;
+            bf16x4 a = {(bf16_t)(o0[4 * g] * inv), (bf16_t)(o0[4 * g + 1] * inv), (bf16_t)(o0[4 * g + 2] * inv),
+                        (bf16_t)(o0[4 * g + 3] * inv)};
+            bf16x4 c = {(bf16_t)(o1[4 * g] * inv), (bf16_t)(o1[4 * g + 1] * inv), (bf16_t)(o1[4 * g + 2] * inv),
+                        (bf16_t)(o1[4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(op + d) = a;
+            *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
+        }
+        if (lse && hh == 0) lse[(int64_t)bh * Lq + qrow] = m + logf(l);
+    }
+}
+
+template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B,
+                                  int h, int Lq, int Lk, const int32_t* k_len, int causal) {
+    const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);
+    dim3 grid(B * h * q_tiles), block(NW * 64);
+    if (causal)
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<NW, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
+    else
+        hipLaunchKernelGGL((attn_fwd_bf16_kernel<NW, false>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
+    ASR_LAUNCH_CHECK("attention_fwd_bf16");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
+                                 int B, int h, int Lq, int Lk, const int32_t* k_len, int causal) {
+    ASR_REQUIRE(q && k && v && ctx, ASR_ERR_ARG, "attention: null pointer");
+    ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention: B=%d h=%d Lq=%d Lk=%d", B, h, Lq, Lk);
+    ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(ctx, 16), ASR_ERR_ALIGN,
+                "attention: q/k/v/ctx must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ASR_F32) {
+        const int64_t rows = (int64_t)B * h * Lq;
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)q,
+                           (const float*)k, (const float*)v, (float*)ctx, lse, B, h, Lq, Lk, k_len, causal);
+        ASR_LAUNCH_CHECK("attention_fwd_f32");
+        return 0;
+    }
+    ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
+    if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal);
+    if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal);
+    return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal);
+}

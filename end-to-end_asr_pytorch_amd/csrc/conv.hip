@@ -1,0 +1,182 @@
+// Conv2dSubsample (conv_encoder.py:101-108) for gfx950.
+//
+// Layout: activations between conv layers are channel-LAST [B,T,F,32] so the 32 input channels of one tap are a
+// contiguous 64-byte (bf16) / 128-byte (f32) MFMA K-slice.  Only the region of each layer that the final crop
+// (freq[:ceil(D/2)], time[:ceil(T/2^n)]) can see is produced: the reference computes 86 frequency columns in the
+// last layer and keeps 40.
+//   layer 0 (1 -> 32 ch, K = 9): VALU, one thread per output position, weights in LDS, implicit zero right-pad.
+//   layer i >= 1 (32 -> 32 ch): implicit GEMM on MFMA, K = 9 taps x 32 channels.  Weights (A operand, rows =
+//     c_out) are gathered once per wave into registers; the B operand (16 consecutive output positions x 32 c_in)
+//     is read straight from global/L2 per tap - neighbouring taps/positions hit the same lines in L1.
+//     D[c_out][position] puts 4 consecutive output channels of one position in each lane.
+#include "asr_common.h"
+
+namespace {
+
+template <typename CT>
+__global__ __launch_bounds__(256) void conv_sub0_kernel(const float* __restrict__ feats, const float* __restrict__ w0,
+                                                        const float* __restrict__ b0, CT* __restrict__ y, int B, int T, int D,
+                                                        int T1, int F1) {
+    __shared__ float ws[9][32];
+    __shared__ float bs[32];
+    for (int i = threadIdx.x; i < 288; i += 256) ws[i % 9][i / 9] = w0[i];  // w0[c][0][kh][kw] -> ws[tap][c]
+    if (threadIdx.x < 32) bs[threadIdx.x] = b0[threadIdx.x];
+    __syncthreads();
+    const int64_t total = (int64_t)B * T1 * F1;
+    const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= total) return;
+    const int f = (int)(pos % F1);
+    const int t1 = (int)((pos / F1) % T1);
+    const int b = (int)(pos / ((int64_t)F1 * T1));
+    float x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tt = 2 * t1 + kh, ff = f + kw;
+            x[kh * 3 + kw] = (tt < T && ff < D) ? feats[((int64_t)b * T + tt) * D + ff] : 0.f;
+        }
+    CT* yp = y + pos * 32;
+#pragma unroll
+    for (int c0 = 0; c0 < 32; c0 += 4) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = bs[c0 + i];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc = fmaf(ws[tap][c0 + i], x[tap], acc);
+            o[i] = fmaxf(acc, 0.f);
+        }
+        if constexpr (sizeof(CT) == 4) {
+            *reinterpret_cast<f32x4*>(yp + c0) = o;
+        } else {
+            bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            *reinterpret_cast<bf16x4*>(yp + c0) = ob;
+        }
+    }
+}
+
+template <typename CT> struct ConvK {  // 16-byte chunks per 32-channel tap slice
+    static constexpr int CH = 16 / sizeof(CT);      // elements per chunk
+    static constexpr int GROUPS = 32 / (4 * CH);    // 4-chunk MFMA groups per tap: bf16 1, f32 2
+};
+
+template <typename CT>
+__global__ __launch_bounds__(256) void conv_sub1_kernel(const CT* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, CT* __restrict__ y, int B, int Tin,
+                                                        int Fin, int Tout, int Fout, int last, int n_tiles) {
+    constexpr int CH = ConvK<CT>::CH, G = ConvK<CT>::GROUPS;
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int gwave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+
+    // weights as the MFMA row operand: wf[tap][ct][g] = chunk (g*4+q4) of w[c_out = ct*16 + r16][c_in][tap]
+    u32x4 wf[9][2][G];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int co = ct * 16 + r16;
+                const int ci0 = (g * 4 + q4) * CH;
+                if constexpr (sizeof(CT) == 4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = w[(co * 32 + ci0 + j) * 9 + tap];
+                    wf[tap][ct][g] = __builtin_bit_cast(u32x4, v);
+                } else {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)w[(co * 32 + ci0 + j) * 9 + tap];
+                    wf[tap][ct][g] = __builtin_bit_cast(u32x4, v);
+                }
+            }
+    f32x4 bv[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) bv[ct] = *reinterpret_cast<const f32x4*>(bias + ct * 16 + q4 * 4);
+
+    const int64_t total = (int64_t)B * Tout * Fout;
+    for (int tile = gwave; tile < n_tiles; tile += nwaves) {
+        int64_t pos = (int64_t)tile * 16 + r16;
+        const bool ok = pos < total;
+        if (!ok) pos = total - 1;
+        const int f = (int)(pos % Fout);
+        const int t = (int)((pos / Fout) % Tout);
+        const int b = (int)(pos / ((int64_t)Fout * Tout));
+        f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const CT* xp = x + (((int64_t)b * Tin + 2 * t + kh) * Fin + f + kw) * 32;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const u32x4 xv = *reinterpret_cast<const u32x4*>(xp + (g * 4 + q4) * CH);
+                    Mma<CT>::run(wf[kh * 3 + kw][0][g], xv, acc[0]);
+                    Mma<CT>::run(wf[kh * 3 + kw][1][g], xv, acc[1]);
+                }
+            }
+        if (!ok) continue;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            f32x4 o = acc[ct] + bv[ct];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = fmaxf(o[i], 0.f);
+            const int c0 = ct * 16 + q4 * 4;
+            if (last) {
+                CT* yp = y + ((int64_t)b * Tout + t) * (32 * Fout) + f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) yp[(int64_t)(c0 + i) * Fout] = from_f32<CT>(o[i]);
+            } else {
+                CT* yp = y + pos * 32 + c0;
+                if constexpr (sizeof(CT) == 4) {
+                    *reinterpret_cast<f32x4*>(yp) = o;
+                } else {
+                    bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                    *reinterpret_cast<bf16x4*>(yp) = ob;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int asr_conv_sub0_fwd(void* stream, const float* feats, const float* w0, const float* b0, void* y, int dtype, int B, int T,
+                                 int D, int T1, int F1) {
+    ASR_REQUIRE(feats && w0 && b0 && y, ASR_ERR_ARG, "conv_sub0: null pointer");
+    ASR_REQUIRE(B > 0 && T > 0 && D > 0 && T1 > 0 && F1 > 0, ASR_ERR_ARG, "conv_sub0: bad sizes");
+    ASR_REQUIRE(asr_aligned(y, 16), ASR_ERR_ALIGN, "conv_sub0: y alignment");
+    const int64_t total = (int64_t)B * T1 * F1;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ASR_F32)
+        hipLaunchKernelGGL(conv_sub0_kernel<float>, grid, block, 0, s, feats, w0, b0, (float*)y, B, T, D, T1, F1);
+    else
+        hipLaunchKernelGGL(conv_sub0_kernel<bf16_t>, grid, block, 0, s, feats, w0, b0, (bf16_t*)y, B, T, D, T1, F1);
+    ASR_LAUNCH_CHECK("conv_sub0");
+    return 0;
+}
+
+extern "C" int asr_conv_sub1_fwd(void* stream, const void* x, const float* w, const float* b, void* y, int dtype, int B, int Tin,
+                                 int Fin, int Tout, int Fout, int last) {
+    ASR_REQUIRE(x && w && b && y, ASR_ERR_ARG, "conv_sub1: null pointer");
+    ASR_REQUIRE(B > 0 && Tout > 0 && Fout > 0 && Tin >= 2 * Tout + 1 && Fin >= Fout + 2, ASR_ERR_ARG,
+                "conv_sub1: input region [%d,%d] too small for output [%d,%d]", Tin, Fin, Tout, Fout);
+    ASR_REQUIRE(asr_aligned(x, 16) && asr_aligned(y, 16) && asr_aligned(b, 16), ASR_ERR_ALIGN, "conv_sub1: alignment");
+    const int64_t total = (int64_t)B * Tout * Fout;
+    const int n_tiles = (int)((total + 15) / 16);
+    int blocks = (n_tiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == ASR_F32)
+        hipLaunchKernelGGL(conv_sub1_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, w, b, (float*)y, B, Tin, Fin,
+                           Tout, Fout, last, n_tiles);
+    else
+        hipLaunchKernelGGL(conv_sub1_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, w, b, (bf16_t*)y, B, Tin, Fin,
+                           Tout, Fout, last, n_tiles);
+    ASR_LAUNCH_CHECK("conv_sub1");
+    return 0;
+}

@@ -1,0 +1,271 @@
+// MFMA projection GEMM for gfx950:  C[M,N] = epi(A[M,K] . W[N,K]^T)   ("NT": both operands K-contiguous).
+//
+// Tile 128x128, K-step = 128 bytes of K per LDS row (64 bf16 / 32 f32), 4 waves as 2(M) x 2(N), each wave a 64x64
+// sub-tile = 4x4 MFMA 16x16 accumulators (v_mfma_f32_16x16x32_bf16, or the exact v_mfma_f32_16x16x4_f32 for the
+// fp32 parity mode).  LDS rows are XOR-swizzled on the 16-byte chunk index (chunk ^ (row & 7)) so the ds_read_b128
+// fragment reads (16 rows x one chunk per lane group) are bank-conflict free.  Global->LDS goes through registers
+// (loads of tile k+1 are issued before the MFMAs of tile k) because M/N/K tails need guards and the f32->bf16
+// conversion of activations happens on the way in.  blockIdx is remapped so each XCD walks a contiguous run of
+// tiles (A row-panels are re-read from that XCD's L2 across the N tiles).
+#include "asr_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128, NT = 256;
+
+template <typename CT> struct KTraits;
+template <> struct KTraits<bf16_t> { static constexpr int KT = 64, CH = 8; };
+template <> struct KTraits<float> { static constexpr int KT = 32, CH = 4; };
+
+// raw registers for one 16-byte LDS chunk's worth of source data
+template <typename AT, typename CT> struct Chunk;
+template <typename T> struct Chunk<T, T> {
+    u32x4 v;
+    __device__ __forceinline__ void load(const T* p, bool ok) {
+        v = ok ? *reinterpret_cast<const u32x4*>(p) : u32x4{0, 0, 0, 0};
+    }
+    __device__ __forceinline__ u32x4 get() const { return v; }
+};
+template <> struct Chunk<float, bf16_t> {
+    f32x4 lo, hi;
+    __device__ __forceinline__ void load(const float* p, bool ok) {
+        if (ok) {
+            lo = *reinterpret_cast<const f32x4*>(p);
+            hi = *reinterpret_cast<const f32x4*>(p + 4);
+        } else {
+            lo = f32x4{0, 0, 0, 0};
+            hi = lo;
+        }
+    }
+    __device__ __forceinline__ u32x4 get() const {
+        bf16x8 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[i] = (bf16_t)lo[i];
+            r[4 + i] = (bf16_t)hi[i];
+        }
+        return __builtin_bit_cast(u32x4, r);
+    }
+};
+
+// ---- epilogues: receive 4 consecutive output columns n0..n0+3 of row m --------------------------------------
+struct EpiDense {
+    void* C;
+    int c_dtype;
+    int64_t ldc;
+    const float* bias;
+    unsigned flags;
+    int M, N;
+    __device__ __forceinline__ void store4(int m, int n0, f32x4 v) const {
+        if (m >= M || n0 >= N) return;
+        const int nv = min(4, N - n0);
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nv) v[i] += bias[n0 + i];
+        }
+        if (flags & ASR_GEMM_RELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        const int64_t off = (int64_t)m * ldc + n0;
+        if (c_dtype == ASR_F32) {
+            float* p = reinterpret_cast<float*>(C) + off;
+            if (nv == 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                *reinterpret_cast<f32x4*>(p) = v;
+            } else if (nv == 4 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) {
+                *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+                *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nv) p[i] = v[i];
+            }
+        } else {
+            bf16_t* p = reinterpret_cast<bf16_t*>(C) + off;
+            if (nv == 4 && ((reinterpret_cast<uintptr_t>(p) & 7) == 0)) {
+                bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                *reinterpret_cast<bf16x4*>(p) = o;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nv) p[i] = (bf16_t)v[i];
+            }
+        }
+    }
+};
+
+template <typename CT> struct EpiHeads {
+    CT* out;
+    int64_t proj_stride;
+    const float* bias;
+    int L, h, M, N;
+    float scale_first;
+    __device__ __forceinline__ void store4(int m, int n0, f32x4 v) const {
+        if (m >= M || n0 >= N) return;  // N is a multiple of 64
+        if (bias) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
+            v += bv;
+        }
+        const int hd = h * 64;
+        const int which = n0 / hd;
+        const int rem = n0 - which * hd;
+        const int head = rem >> 6, d = rem & 63;
+        if (which == 0) v *= scale_first;
+        const int b = m / L, t = m - b * L;
+        CT* p = out + which * proj_stride + (((int64_t)b * h + head) * L + t) * 64 + d;
+        if constexpr (sizeof(CT) == 4) {
+            *reinterpret_cast<f32x4*>(p) = v;
+        } else {
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(p) = o;
+        }
+    }
+};
+
+template <typename AT, typename CT, typename Epi>
+__global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A, int64_t lda, const CT* __restrict__ W,
+                                                        int64_t ldw, int M, int N, int K, int tiles_n, int nwg, Epi epi) {
+    constexpr int KT = KTraits<CT>::KT, CH = KTraits<CT>::CH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * ROWB;
+
+    // XCD-aware bijective remap (8 XCDs, blocks dealt round-robin): each XCD gets a contiguous tile range.
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, q4 = lane >> 4;
+
+    Chunk<AT, CT> ra[4];
+    Chunk<CT, CT> rb[4];
+    const int nk = (K + KT - 1) / KT;
+
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + NT * i;
+            const int row = id >> 3, c = id & 7;
+            const int k = kt * KT + c * CH;
+            const int gm = m0 + row, gn = n0 + row;
+            ra[i].load(A + (int64_t)gm * lda + k, gm < M && k < K);
+            rb[i].load(W + (int64_t)gn * ldw + k, gn < N && k < K);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + NT * i;
+            const int row = id >> 3, c = id & 7;
+            const int off = row * ROWB + ((c ^ (row & 7)) << 4);
+            *reinterpret_cast<u32x4*>(As + off) = ra[i].get();
+            *reinterpret_cast<u32x4*>(Bs + off) = rb[i].get();
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = g * 4 + q4;
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int arow = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                const int brow = wn * 64 + i * 16 + r16;
+                b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * ROWB + ((chunk ^ (brow & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<CT>::run(b[j], a[i], acc[i][j]);  // D[n_local][m_local]
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + q4 * 4;
+            epi.store4(m, n, acc[i][j]);
+        }
+    }
+}
+
+template <typename AT, typename CT, typename Epi>
+int launch_gemm(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const Epi& epi) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_nt_kernel<AT, CT, Epi>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const AT*>(A), lda,
+                       reinterpret_cast<const CT*>(W), ldw, M, N, K, tiles_n, nwg, epi);
+    ASR_LAUNCH_CHECK("gemm_nt");
+    return 0;
+}
+
+int check_operands(const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw, int K) {
+    ASR_REQUIRE(A && W, ASR_ERR_ARG, "gemm: null operand");
+    ASR_REQUIRE((a_dtype == ASR_F32 || a_dtype == ASR_BF16) && (w_dtype == ASR_F32 || w_dtype == ASR_BF16), ASR_ERR_ARG,
+                "gemm: bad dtype code");
+    ASR_REQUIRE(!(a_dtype == ASR_BF16 && w_dtype == ASR_F32), ASR_ERR_UNSUPPORTED, "gemm: bf16 activations with f32 weights");
+    const int ch = (w_dtype == ASR_BF16) ? 8 : 4;
+    ASR_REQUIRE(K % ch == 0 && lda % ch == 0 && ldw % ch == 0, ASR_ERR_ALIGN,
+                "gemm: K=%d lda=%lld ldw=%lld must be multiples of %d", K, (long long)lda, (long long)ldw, ch);
+    ASR_REQUIRE(asr_aligned(A, 16) && asr_aligned(W, 16), ASR_ERR_ALIGN, "gemm: A/W must be 16-byte aligned");
+    return 0;
+}
+
+template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype,
+                                     int64_t ldw, int M, int N, int K, const Epi& epi) {
+    if (w_dtype == ASR_F32) return launch_gemm<float, float>(s, A, lda, W, ldw, M, N, K, epi);
+    if (a_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
+    return launch_gemm<bf16_t, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
+}
+
+}  // namespace
+
+extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
+                           const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags) {
+    ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm: M=%d N=%d K=%d C=%p", M, N, K, C);
+    ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm: bad c_dtype");
+    if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
+    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N};
+    return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
+}
+
+extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t ldx, const void* W, int w_dtype, int64_t ldw,
+                              const float* bias, void* out, int64_t proj_stride, int n_proj, int B, int L, int h, int K,
+                              float scale_first) {
+    ASR_REQUIRE(B > 0 && L > 0 && h > 0 && n_proj > 0 && K > 0 && out, ASR_ERR_ARG, "proj_heads: bad sizes");
+    if (int rc = check_operands(X, x_dtype, ldx, W, w_dtype, ldw, K)) return rc;
+    ASR_REQUIRE(asr_aligned(out, 16) && (proj_stride % 8 == 0), ASR_ERR_ALIGN, "proj_heads: out alignment");
+    ASR_REQUIRE(!bias || asr_aligned(bias, 16), ASR_ERR_ALIGN, "proj_heads: bias must be 16-byte aligned");
+    const int M = B * L, N = n_proj * h * 64;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (w_dtype == ASR_F32) {
+        EpiHeads<float> epi{reinterpret_cast<float*>(out), proj_stride, bias, L, h, M, N, scale_first};
+        return launch_gemm<float, float>(s, X, ldx, W, ldw, M, N, K, epi);
+    }
+    EpiHeads<bf16_t> epi{reinterpret_cast<bf16_t*>(out), proj_stride, bias, L, h, M, N, scale_first};
+    if (x_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
+    return launch_gemm<bf16_t, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
+}

@@ -1,0 +1,176 @@
+// HBM-bound row kernels: residual-add + LayerNorm (+PE, +length mask), embedding + PE, casts, row masks,
+// assigner tail.  One 64-lane wave owns one row (D <= 1024), 16-byte accesses, reductions by cross-lane shuffles.
+#include "asr_common.h"
+
+namespace {
+
+constexpr int LN_MAXJ = 4;  // D <= 1024
+
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ pe, const int32_t* __restrict__ row_len,
+                                                                float* __restrict__ y32, bf16_t* __restrict__ y16,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                int M, int L, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int b = (int)(row / L), t = (int)(row - (int64_t)b * L);
+    const float* xr = x + row * D;
+    f32x4 v[LN_MAXJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+            v[j] = *reinterpret_cast<const f32x4*>(xr + c);
+            if (res) v[j] += *reinterpret_cast<const f32x4*>(res + row * D + c);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+            const f32x4 d = v[j] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+    const bool keep = row_len ? (t < row_len[b]) : true;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o = (v[j] - mean) * rstd * g + bt;
+            if (pe) o += *reinterpret_cast<const f32x4*>(pe + (int64_t)t * D + c);
+            if (!keep) o = f32x4{0, 0, 0, 0};
+            *reinterpret_cast<f32x4*>(y32 + row * D + c) = o;
+            if (y16) {
+                bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                *reinterpret_cast<bf16x4*>(y16 + row * D + c) = ob;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
+                                                           const float* __restrict__ pe, float* __restrict__ y32,
+                                                           bf16_t* __restrict__ y16, int M, int U, int D, int V) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int u = (int)(row % U);
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // torch would raise; clamp keeps the kernel memory-safe
+    for (int c = lane * 4; c < D; c += 256) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(emb + id * D + c) + *reinterpret_cast<const f32x4*>(pe + (int64_t)u * D + c);
+        *reinterpret_cast<f32x4*>(y32 + row * D + c) = o;
+        if (y16) {
+            bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            *reinterpret_cast<bf16x4*>(y16 + row * D + c) = ob;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n4,
+                                                            int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(y + i * 4) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) y[n4 * 4 + threadIdx.x] = (bf16_t)x[n4 * 4 + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int32_t* __restrict__ len, int L, int V) {
+    const int row = blockIdx.x;  // b*L + t
+    const int b = row / L, t = row - b * L;
+    if (t < len[b]) return;
+    float* p = x + (int64_t)row * V;
+    for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void assigner_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const int32_t* __restrict__ len,
+                                                            int M, int L, int Dh, float* __restrict__ alpha) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane; c < Dh; c += 64) s = fmaf(x[row * Dh + c], w[c], s);
+    s = wave_sum(s) + bias[0];
+    const int b = (int)(row / L), t = (int)(row - (int64_t)b * L);
+    const float a = 1.0f / (1.0f + expf(-s));
+    if (lane == 0) alpha[row] = (t < len[b]) ? a : 0.f;
+}
+
+}  // namespace
+
+extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                                     const float* pe, const int32_t* row_len, float* y32, void* y16, float* mean, float* rstd,
+                                     int B, int L, int D, float eps) {
+    ASR_REQUIRE(x && gamma && beta && y32, ASR_ERR_ARG, "layernorm: null pointer");
+    ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 256 * LN_MAXJ && D % 4 == 0, ASR_ERR_UNSUPPORTED,
+                "layernorm: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXJ);
+    ASR_REQUIRE(asr_aligned(x, 16) && asr_aligned(y32, 16) && asr_aligned(gamma, 16) && asr_aligned(beta, 16) &&
+                    (!residual || asr_aligned(residual, 16)) && (!pe || asr_aligned(pe, 16)) && (!y16 || asr_aligned(y16, 8)),
+                ASR_ERR_ALIGN, "layernorm: 16-byte alignment required");
+    const int M = B * L;
+    hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, residual,
+                       gamma, beta, pe, row_len, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, M, L, D, eps);
+    ASR_LAUNCH_CHECK("add_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16, int B,
+                                int U, int D, int V) {
+    ASR_REQUIRE(ids && emb && pe && y32, ASR_ERR_ARG, "embed: null pointer");
+    ASR_REQUIRE(B > 0 && U > 0 && D > 0 && D % 4 == 0 && V > 0, ASR_ERR_ARG, "embed: bad sizes");
+    ASR_REQUIRE(asr_aligned(emb, 16) && asr_aligned(pe, 16) && asr_aligned(y32, 16), ASR_ERR_ALIGN, "embed: alignment");
+    const int M = B * U;
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ids, emb, pe, y32,
+                       reinterpret_cast<bf16_t*>(y16), M, U, D, V);
+    ASR_LAUNCH_CHECK("embed_pe_fwd");
+    return 0;
+}
+
+extern "C" int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t n) {
+    ASR_REQUIRE(x && y && n > 0, ASR_ERR_ARG, "cast: bad args");
+    ASR_REQUIRE(asr_aligned(x, 16) && asr_aligned(y, 8), ASR_ERR_ALIGN, "cast: alignment");
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       reinterpret_cast<bf16_t*>(y), n4, n);
+    ASR_LAUNCH_CHECK("cast_f32_bf16");
+    return 0;
+}
+
+extern "C" int asr_mask_rows(void* stream, float* x, const int32_t* len, int B, int L, int V) {
+    ASR_REQUIRE(x && len && B > 0 && L > 0 && V > 0, ASR_ERR_ARG, "mask_rows: bad args");
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(B * L), dim3(256), 0, static_cast<hipStream_t>(stream), x, len, L, V);
+    ASR_LAUNCH_CHECK("mask_rows");
+    return 0;
+}
+
+extern "C" int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const float* b, const int32_t* len, int B, int L,
+                                     int Dh, float* alpha) {
+    ASR_REQUIRE(x && w && b && len && alpha && B > 0 && L > 0 && Dh > 0, ASR_ERR_ARG, "assigner_tail: bad args");
+    const int M = B * L;
+    hipLaunchKernelGGL(assigner_tail_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, w, b, len, M, L,
+                       Dh, alpha);
+    ASR_LAUNCH_CHECK("assigner_tail");
+    return 0;
+}

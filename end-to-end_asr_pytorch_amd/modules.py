@@ -1,0 +1,585 @@
+"""nn.Module mirrors of the reference's model classes, running on libasr_hip.so.
+
+Constructor signatures, forward signatures / return tuples and state_dict keys follow the reference
+(each class cites its reference file:line), so a reference checkpoint's `state_dict`
+loads unchanged.  What differs is the execution: masks are never materialised (kernels take lengths),
+Q/K/V projections are one head-major GEMM, attention is a flash-style MFMA kernel, residual+LayerNorm+
+length-mask is one row kernel, and the attention-probability tensor the reference returns (and every
+caller discards) is not produced (`None` is returned in its place).
+
+Precision: "bf16" (default; bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / losses) or "f32"
+(exact-fp32 MFMA, the parity mode).  Select with `set_precision()` or the `precision(...)` context.
+Dropout: the kernels implement p = 0 (eval / parity runs); constructing with dropout > 0 is accepted for
+signature compatibility and is a no-op in this round (DESIGN.md "out of scope").
+"""
+import contextlib
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_PRECISION = os.environ.get("ASR_AMD_PRECISION", "bf16")
+
+
+def set_precision(p):
+    global _PRECISION
+    assert p in ("bf16", "f32")
+    _PRECISION = p
+
+
+def get_precision():
+    return _PRECISION
+
+
+@contextlib.contextmanager
+def precision(p):
+    old = get_precision()
+    set_precision(p)
+    try:
+        yield
+    finally:
+        set_precision(old)
+
+
+def _cdtype():
+    return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+
+
+class _Cached(nn.Module):
+    """Derived weights (concatenated / re-laid-out / bf16 copies) cached against parameter versions."""
+
+    def _derived(self, key, params, build):
+        cache = self.__dict__.setdefault("_wcache", {})
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (_PRECISION,)
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                hit = (ver, build())
+            cache[key] = hit
+        return hit[1]
+
+    def _w(self, key, params, dim=0):
+        """Compute-dtype copy of (the concatenation of) weight matrices."""
+        def build():
+            w = params[0] if len(params) == 1 else torch.cat(list(params), dim)
+            w = w.detach().contiguous()
+            return ops.cast_bf16(w) if _PRECISION == "bf16" else w.float()
+        return self._derived(key, params, build)
+
+    def _b(self, key, params):
+        def build():
+            b = params[0] if len(params) == 1 else torch.cat(list(params), 0)
+            return b.detach().float().contiguous()
+        return self._derived(key, params, build)
+
+
+class Act:
+    """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
+    __slots__ = ("f32", "b16", "B", "L")
+
+    def __init__(self, f32, b16, B, L):
+        self.f32, self.b16, self.B, self.L = f32, b16, B, L
+
+    def mma(self):
+        return self.b16 if (self.b16 is not None and _PRECISION == "bf16") else self.f32
+
+    def view3(self):
+        return self.f32.view(self.B, self.L, -1)
+
+
+def _act(x):
+    B, L, D = x.shape
+    return Act(x.contiguous().float().view(B * L, D), None, B, L)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class PositionalEncoding(nn.Module):
+    """src/transformer/module.py:7-32 — `pe` is a state_dict buffer (1, max_len, d_model)."""
+
+    def __init__(self, d_model, max_len=5000):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model, requires_grad=False)
+        position = torch.arange(0, max_len).unsqueeze(1).float()
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, input):
+        return self.pe[:, :input.size(1)]
+
+    def rows(self, length):
+        return self.pe[0, :length].contiguous()
+
+
+class MultiheadAttention(_Cached):
+    """src/transformer/attention.py:6-62 (with ScaledDotProductAttention :65-86 fused in)."""
+
+    def __init__(self, d_model, n_head, d_k=64, d_v=64, dropout=0.1):
+        super().__init__()
+        if d_k != 64 or d_v != 64:
+            raise NotImplementedError("the MFMA attention kernel is specialised for d_k = d_v = 64 "
+                                      "(the only head width the reference ever constructs, SURVEY.md)")
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.w_qs = nn.Linear(d_model, n_head * d_k)
+        self.w_ks = nn.Linear(d_model, n_head * d_k)
+        self.w_vs = nn.Linear(d_model, n_head * d_v)
+        nn.init.normal_(self.w_qs.weight, mean=0, std=math.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_ks.weight, mean=0, std=math.sqrt(2.0 / (d_model + d_k)))
+        nn.init.normal_(self.w_vs.weight, mean=0, std=math.sqrt(2.0 / (d_model + d_v)))
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        nn.init.xavier_normal_(self.fc.weight)
+        self.dropout_rate = dropout
+
+    def _impl(self, xq, xkv, k_len, causal, row_len):
+        """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act."""
+        h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
+        scale = 1.0 / math.sqrt(self.d_k)
+        if xkv is xq:
+            W = self._w("qkv", (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight))
+            bias = self._b("bqkv", (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias))
+            qkv = ops.proj_heads(xq.mma(), W, bias, 3, B, Lq, h, scale)
+            q, k, v = qkv[0], qkv[1], qkv[2]
+        else:
+            q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, scale)[0]
+            kv = ops.proj_heads(xkv.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)),
+                                self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
+            k, v = kv[0], kv[1]
+        ctx, _ = ops.attention_fwd(q, k, v, k_len, causal)
+        o = ops.gemm_nt(ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,)), self._b("bfc", (self.fc.bias,)))
+        y32, y16, _, _ = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
+                                           want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps)
+        return Act(y32, y16, B, Lq)
+
+    def forward(self, q, k, v, mask=None, k_len=None, causal=False):
+        """Reference signature + length-based masking: `k_len` (int [B]) / `causal`.  A bool `mask` [B,Lq,Lk] is
+        accepted when it is a key-padding mask (tail padding): it is reduced to k_len.  Returns (output, None)."""
+        if mask is not None and k_len is None:
+            k_len = (~mask[:, -1, :].bool()).sum(-1)
+        xq = _act(q)
+        xkv = xq if (k is q and v is q) else _act(k)
+        if k is not v:
+            raise NotImplementedError("key and value must be the same tensor (all reference call sites)")
+        kl = None if k_len is None else ops.as_i32(k_len, q.device)
+        out = self._impl(xq, xkv, kl, causal, None)
+        return out.view3(), None
+
+
+class PositionwiseFeedForward(_Cached):
+    """src/transformer/module.py:35-53."""
+
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.dropout_rate = dropout
+
+    def _impl(self, x, row_len):
+        hdt = _cdtype()
+        hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
+        o = ops.gemm_nt(hid, self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)))
+        y32, y16, _, _ = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
+                                           want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps)
+        return Act(y32, y16, x.B, x.L)
+
+    def forward(self, x):
+        return self._impl(_act(x), None).view3()
+
+
+class EncoderLayer(nn.Module):
+    """src/transformer/encoder.py:61-79."""
+
+    def __init__(self, d_model, d_inner, n_head, dropout=0.1):
+        super().__init__()
+        self.slf_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def _impl(self, x, lens, causal=False):
+        x = self.slf_attn._impl(x, x, lens, causal, lens)   # `*= non_pad_mask` fused into the LN kernel
+        return self.pos_ffn._impl(x, lens)
+
+    def forward(self, enc_input, non_pad_mask=None, slf_attn_mask=None, lengths=None):
+        if lengths is None and non_pad_mask is not None:
+            lengths = non_pad_mask.reshape(non_pad_mask.shape[0], -1).sum(-1)
+        lens = None if lengths is None else ops.as_i32(lengths, enc_input.device)
+        return self._impl(_act(enc_input), lens).view3()
+
+
+class Encoder(_Cached):
+    """src/transformer/encoder.py:8-58."""
+
+    def __init__(self, d_input, n_layers, n_head, d_model, d_inner, dropout=0.1):
+        super().__init__()
+        self.d_input, self.n_layers, self.n_head = d_input, n_layers, n_head
+        self.d_model, self.d_output, self.d_inner, self.dropout_rate = d_model, d_model, d_inner, dropout
+        self.linear_in = nn.Linear(d_input, d_model)
+        self.layer_norm_in = nn.LayerNorm(d_model)
+        self.positional_encoding = PositionalEncoding(d_model)
+        self.layer_stack = nn.ModuleList([EncoderLayer(d_model, d_inner, n_head, dropout=dropout) for _ in range(n_layers)])
+
+    def _impl(self, x, lens):
+        B, L = x.B, x.L
+        o = ops.gemm_nt(x.mma(), self._w("lin", (self.linear_in.weight,)), self._b("blin", (self.linear_in.bias,)))
+        y32, y16, _, _ = ops.add_layernorm(o, None, self.layer_norm_in.weight, self.layer_norm_in.bias, B, L,
+                                           pe=self.positional_encoding.rows(L), want_bf16=(_PRECISION == "bf16"),
+                                           eps=self.layer_norm_in.eps)
+        x = Act(y32, y16, B, L)
+        for layer in self.layer_stack:
+            x = layer._impl(x, lens)
+        return x
+
+    def forward(self, padded_input, input_lengths):
+        lens = ops.as_i32(input_lengths, padded_input.device)
+        return self._impl(_act(padded_input), lens).view3()
+
+
+class Conv2dSubsample(_Cached):
+    """src/transformer/conv_encoder.py:81-126 (pad='same')."""
+
+    def __init__(self, d_input, d_model, n_layers=2, pad="same"):
+        super().__init__()
+        assert n_layers >= 1
+        if pad != "same":
+            raise NotImplementedError("only pad='same' (the reference default, never overridden)")
+        self.n_layers, self.d_input, self.pad = n_layers, d_input, pad
+        from collections import OrderedDict
+        layers = [("subsample/conv0", nn.Conv2d(1, 32, 3, (2, 1))), ("subsample/relu0", nn.ReLU())]
+        for i in range(n_layers - 1):
+            layers += [("subsample/conv{}".format(i + 1), nn.Conv2d(32, 32, 3, (2, 1))),
+                       ("subsample/relu{}".format(i + 1), nn.ReLU())]
+        self.conv = nn.Sequential(OrderedDict(layers))  # parameter container only; compute is in conv.hip
+        self.d_conv_out = int(math.ceil(d_input / 2))
+        self.affine = nn.Linear(32 * self.d_conv_out, d_model)
+
+    def _conv_params(self, i):
+        m = getattr(self.conv, "subsample/conv{}".format(i))
+        return m.weight, m.bias
+
+    def _impl(self, feats, feat_lengths):
+        B, T, D = feats.shape
+        n = self.n_layers
+        tl = T
+        for _ in range(n):
+            tl = int(math.ceil(tl / 2.0))
+        tneed, fneed = [0] * n, [0] * n
+        tneed[n - 1], fneed[n - 1] = tl, self.d_conv_out
+        for i in range(n - 2, -1, -1):
+            tneed[i], fneed[i] = 2 * tneed[i + 1] + 1, fneed[i + 1] + 2
+        w0, b0 = self._conv_params(0)
+        y = ops.conv_sub0(feats.float(), w0.detach().float().contiguous(), b0.detach().float().contiguous(), _cdtype(),
+                          tneed[0], fneed[0])
+        if n == 1:
+            y = y.permute(0, 1, 3, 2).reshape(B, tl, 32 * self.d_conv_out).contiguous()
+        for i in range(1, n):
+            w, b = self._conv_params(i)
+            y = ops.conv_sub1(y, w.detach().float().contiguous(), b.detach().float().contiguous(), tneed[i], fneed[i],
+                              last=(i == n - 1))
+        out = ops.gemm_nt(y.view(B * tl, 32 * self.d_conv_out), self._w("aff", (self.affine.weight,)),
+                          self._b("baff", (self.affine.bias,)))
+        lens = feat_lengths.to(feats.device)
+        for _ in range(n):
+            lens = torch.div(lens + 1, 2, rounding_mode="floor")  # == ceil(len / 2) for non-negative ints
+        return Act(out, None, B, tl), lens.to(torch.int32)
+
+    def forward(self, feats, feat_lengths):
+        a, lens = self._impl(feats, feat_lengths)
+        return a.view3(), lens
+
+
+class Conv1d(_Cached):
+    """src/transformer/conv_encoder.py:9-49 (pad='same').  k=w valid convs expressed as GEMMs over overlapping
+    row windows (lda = C, K = w*C) of a right-zero-padded [B, L + n*w, C] buffer."""
+
+    def __init__(self, d_input, d_hidden, n_layers, w_context, pad="same", name=""):
+        super().__init__()
+        assert n_layers >= 1
+        self.n_layers, self.d_input, self.d_hidden, self.w_context, self.pad, self.name = (
+            n_layers, d_input, d_hidden, w_context, pad, name)
+        from collections import OrderedDict
+        layers = [("{}/conv1d_0".format(name), nn.Conv1d(d_input, d_hidden, w_context, 1)), ("{}/relu_0".format(name), nn.ReLU())]
+        for i in range(n_layers - 1):
+            layers += [("{}/conv1d_{}".format(name, i + 1), nn.Conv1d(d_hidden, d_hidden, w_context, 1)),
+                       ("{}/relu_{}".format(name, i + 1), nn.ReLU())]
+        self.conv = nn.Sequential(OrderedDict(layers))
+
+    def _impl(self, x):
+        """x: Act [B*L, C] -> f32 tensor [B, L, d_hidden]"""
+        B, L, w, n = x.B, x.L, self.w_context, self.n_layers
+        Lp = L + n * w
+        C = x.f32.shape[1]
+        cd = _cdtype()
+        buf = torch.zeros((B * Lp + w, C), device=x.f32.device, dtype=cd)
+        src = x.mma() if x.mma().dtype == cd else (ops.cast_bf16(x.f32) if cd == torch.bfloat16 else x.f32)
+        buf[:B * Lp].view(B, Lp, C)[:, :L].copy_(src.view(B, L, C))
+        for i in range(n):
+            m = getattr(self.conv, "{}/conv1d_{}".format(self.name, i))
+            Wg = self._derived("w%d" % i, (m.weight,), lambda m=m: (
+                ops.cast_bf16(m.weight.detach().permute(0, 2, 1).reshape(m.weight.shape[0], -1).contiguous())
+                if _PRECISION == "bf16" else m.weight.detach().permute(0, 2, 1).reshape(m.weight.shape[0], -1).contiguous().float()))
+            last = i == n - 1
+            out = torch.zeros((B * Lp + w, self.d_hidden), device=buf.device, dtype=torch.float32 if last else cd)
+            ops.gemm_nt_raw(buf, B * Lp, w * buf.shape[1], buf.shape[1], Wg, m.bias.detach().float().contiguous(), relu=True,
+                            out=out, ldc=self.d_hidden)
+            buf = out
+        return buf[:B * Lp].view(B, Lp, self.d_hidden)[:, :L].contiguous()
+
+    def forward(self, feats, feat_lengths):
+        return self._impl(_act(feats)), feat_lengths
+
+
+class Attention_Assigner(nn.Module):
+    """src/transformer/attentionAssigner.py:8-40."""
+
+    def __init__(self, d_input, d_hidden, w_context, n_layers, dropout=0.1):
+        super().__init__()
+        self.d_input, self.d_hidden, self.n_layers, self.w_context = d_input, d_hidden, n_layers, w_context
+        self.conv = Conv1d(d_input, d_hidden, n_layers, w_context, pad="same", name="assigner")
+        self.linear = nn.Linear(d_hidden, 1)
+        self.dropout_rate = dropout
+
+    def _impl(self, x, lens):
+        hcv = self.conv._impl(x)
+        return ops.assigner_tail(hcv, self.linear.weight.detach().float().contiguous().view(-1),
+                                 self.linear.bias.detach().float().contiguous(), lens, x.B, x.L)
+
+    def forward(self, padded_input, input_lengths):
+        return self._impl(_act(padded_input), ops.as_i32(input_lengths, padded_input.device))
+
+
+# ------------------------------------------------------------------------------------------------------------
+class DecoderLayer(nn.Module):
+    """src/transformer/decoder.py:618-639."""
+
+    def __init__(self, d_model, d_inner, n_head, dropout=0.1):
+        super().__init__()
+        self.slf_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
+        self.enc_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def _impl(self, x, enc, dec_len, enc_len):
+        x = self.slf_attn._impl(x, x, dec_len, True, dec_len)
+        x = self.enc_attn._impl(x, enc, enc_len, False, dec_len)
+        return self.pos_ffn._impl(x, dec_len)
+
+
+def _compact_targets(targets):
+    """rows with zeros stripped (decoder.py:46) -> (compacted [B,U], count [B])"""
+    nz = targets != 0
+    n = nz.sum(1)
+    order = torch.argsort((~nz).to(torch.int8), dim=1, stable=True)
+    comp = torch.gather(targets, 1, order)
+    comp = comp * (torch.arange(targets.shape[1], device=targets.device)[None, :] < n[:, None])
+    return comp, n
+
+
+class Decoder(_Cached):
+    """src/transformer/decoder.py:13-96 (forward path; decode loops are out of scope)."""
+
+    def __init__(self, sos_id, eos_id, n_tgt_vocab, n_layers, n_head, d_model, d_inner, dropout=0.1):
+        super().__init__()
+        self.sos_id, self.eos_id, self.n_tgt_vocab = sos_id, eos_id, n_tgt_vocab
+        self.d_word_vec, self.n_layers, self.n_head = d_model, n_layers, n_head
+        self.d_model, self.d_inner, self.d_output, self.dropout_rate = d_model, d_inner, n_tgt_vocab, dropout
+        self.tgt_word_emb = nn.Embedding(n_tgt_vocab, d_model)
+        self.positional_encoding = PositionalEncoding(d_model)
+        self.layer_stack = nn.ModuleList([DecoderLayer(d_model, d_inner, n_head, dropout=dropout) for _ in range(n_layers)])
+        self.tgt_word_prj = nn.Linear(d_model, n_tgt_vocab, bias=False)
+        nn.init.xavier_normal_(self.tgt_word_prj.weight)
+
+    def preprocess(self, targets):
+        """decoder.py:42-58 — strip pad(0), prepend <sos> / append <eos>, re-pad with 0."""
+        comp, n = _compact_targets(targets)
+        umax = int(n.max().item())
+        ys = comp[:, :umax]
+        B = targets.shape[0]
+        ys_in = torch.cat([torch.full((B, 1), self.sos_id, dtype=targets.dtype, device=targets.device), ys], 1)
+        ys_out = torch.cat([ys, torch.zeros((B, 1), dtype=targets.dtype, device=targets.device)], 1)
+        ys_out.scatter_(1, n[:, None], self.eos_id)
+        return ys_in, ys_out
+
+    def _impl(self, targets, enc, enc_len):
+        ys_in, ys_out = self.preprocess(targets)
+        B, U = ys_in.shape
+        dec_len = ((ys_in > 0).sum(1)).to(torch.int32)
+        x32, x16 = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U),
+                                want_bf16=(_PRECISION == "bf16"))
+        x = Act(x32, x16, B, U)
+        for layer in self.layer_stack:
+            x = layer._impl(x, enc, dec_len, enc_len)
+        logits = ops.gemm_nt(x.mma(), self._w("prj", (self.tgt_word_prj.weight,)), None)
+        return logits.view(B, U, self.n_tgt_vocab), ys_out
+
+    def forward(self, targets, encoder_padded_outputs, encoder_input_lengths):
+        enc = _act(encoder_padded_outputs)
+        return self._impl(targets, enc, ops.as_i32(encoder_input_lengths, encoder_padded_outputs.device))
+
+
+class Decoder_CIF(_Cached):
+    """src/transformer/decoder.py:327-399 (forward path)."""
+
+    def __init__(self, sos_id, n_tgt_vocab, n_layers, n_head, d_model, d_inner, dropout=0.1):
+        super().__init__()
+        self.sos_id, self.n_tgt_vocab, self.d_word_vec = sos_id, n_tgt_vocab, d_model
+        self.n_layers, self.n_head, self.d_model, self.d_inner = n_layers, n_head, d_model, d_inner
+        self.d_output, self.dropout_rate = n_tgt_vocab, dropout
+        self.tgt_word_emb = nn.Embedding(n_tgt_vocab, d_model)
+        self.positional_encoding = PositionalEncoding(d_model)
+        self.layer_stack = nn.ModuleList([EncoderLayer(d_model, d_inner, n_head, dropout=dropout) for _ in range(n_layers)])
+        self.input_affine = nn.Linear(2 * d_model, d_model, bias=False)
+        self.tgt_word_prj = nn.Linear(2 * d_model, n_tgt_vocab, bias=False)
+        nn.init.xavier_normal_(self.tgt_word_prj.weight)
+
+    def preprocess(self, target):
+        pad_mask = (target > 0).long()
+        sos = torch.full((target.size(0), 1), self.sos_id, dtype=torch.long, device=target.device)
+        return torch.cat([sos, target[:, :-1]], 1) * pad_mask
+
+    def forward(self, encoded_attentioned, target):
+        B, U, D = encoded_attentioned.shape
+        ys_in = self.preprocess(target)
+        dec_len = (target > 0).sum(1).to(torch.int32)          # tail padding (every reference data path)
+        cif32 = encoded_attentioned.contiguous().float().view(B * U, D)
+        e32, _ = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U))
+        x = ops.gemm_nt(torch.cat([cif32, e32], -1), self._w("inaff", (self.input_affine.weight,)), None)
+        a = Act(x, None, B, U)
+        for layer in self.layer_stack:
+            a = layer._impl(a, dec_len, causal=True)
+        logits = ops.gemm_nt(torch.cat([cif32, a.f32], -1), self._w("prj", (self.tgt_word_prj.weight,)), None)
+        return logits.view(B, U, self.n_tgt_vocab)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _xavier_all(model):
+    for p in model.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class Transformer(nn.Module):
+    """src/transformer/transformer.py:7-35."""
+
+    def __init__(self, encoder, decoder, spec_aug_cfg=None):
+        super().__init__()
+        self.encoder, self.decoder, self.spec_aug_cfg = encoder, decoder, spec_aug_cfg
+        if spec_aug_cfg:
+            raise NotImplementedError("spec_aug is a train-time augmentation outside the hot path (SURVEY.md §2 row 9)")
+        _xavier_all(self)
+
+    def forward(self, features, len_features, padded_target):
+        lens = ops.as_i32(len_features, features.device)
+        enc = self.encoder._impl(_act(features), lens)
+        logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
+        return logits, targets_eos
+
+
+class CTC_Transformer(Transformer):
+    """src/transformer/transformer.py:100-124 — returns (ctc_len, ctc_logits, (logits, targets_eos))."""
+
+    def __init__(self, encoder, decoder, spec_aug_cfg=None):
+        super().__init__(encoder, decoder, spec_aug_cfg)
+        self.ctc_fc = nn.Linear(encoder.d_output, decoder.d_output, bias=False)
+
+    def _ctc_logits(self, enc):
+        def build():
+            w = self.ctc_fc.weight.detach().contiguous()
+            return ops.cast_bf16(w) if _PRECISION == "bf16" else w.float()
+        cache = self.__dict__.setdefault("_wcache", {})
+        ver = (self.ctc_fc.weight.data_ptr(), self.ctc_fc.weight._version, _PRECISION)
+        if cache.get("v") != ver:
+            cache["v"], cache["w"] = ver, build()
+        return ops.gemm_nt(enc.mma(), cache["w"], None).view(enc.B, enc.L, -1)
+
+    def forward(self, features, len_features, padded_target):
+        lens = ops.as_i32(len_features, features.device)
+        enc = self.encoder._impl(_act(features), lens)
+        ctc_pred = self._ctc_logits(enc)
+        pred = self.decoder._impl(padded_target, enc, lens)
+        return len_features, ctc_pred, pred
+
+
+class Conv_CTC_Transformer(CTC_Transformer):
+    """src/transformer/transformer.py:127-153 — returns (ctc_logits, len, logits, targets_eos)."""
+
+    def __init__(self, conv_encoder, encoder, decoder, spec_aug_cfg=None):
+        super().__init__(encoder, decoder, spec_aug_cfg)
+        self.conv_encoder = conv_encoder
+
+    def forward(self, features, len_features, targets, spec_aug_cfg=False):
+        conv, len_sequence = self.conv_encoder._impl(features, len_features)
+        enc = self.encoder._impl(conv, len_sequence)
+        ctc_logits = self._ctc_logits(enc)
+        logits, targets_eos = self.decoder._impl(targets, enc, len_sequence)
+        return ctc_logits, len_sequence, logits, targets_eos
+
+    @classmethod
+    def create_model(cls, args):
+        """transformer.py:188-214."""
+        conv_encoder = Conv2dSubsample(d_input=args.d_input * args.LFR_m, d_model=args.d_model, n_layers=args.n_conv_layers)
+        encoder = Encoder(d_input=args.d_model, n_layers=args.n_layers_enc, n_head=args.n_head, d_model=args.d_model,
+                          d_inner=args.d_inner, dropout=args.dropout)
+        decoder = Decoder(sos_id=args.sos_id, eos_id=args.eos_id, n_tgt_vocab=args.vocab_size, n_layers=args.n_layers_dec,
+                          n_head=args.n_head, d_model=args.d_model, d_inner=args.d_inner, dropout=args.dropout)
+        return cls(conv_encoder, encoder, decoder, spec_aug_cfg=args.spec_aug_cfg)
+
+
+def cif_forward(hidden, alphas, threshold, max_label_len=None):
+    """cif_model.py:57-106 on cif.hip.  Returns (out [B,Umax,H], (fire_idx, n_fire, n_label)).
+    One host sync (the reference has the same one: `.max()` used as a tensor size) unless max_label_len is given."""
+    cur, rem, fire_idx, n_fire, n_label = ops.cif_scan(alphas.float(), threshold)
+    if max_label_len is None:
+        stats = torch.stack([n_label.max(), n_fire.max()]).tolist()
+        max_label_len = stats[0]
+        if stats[1] > max_label_len:
+            raise RuntimeError("cif: a row fires %d times but max round(sum alpha) is %d "
+                               "(the reference fails here too, cif_model.py:100)" % (stats[1], max_label_len))
+    out = ops.cif_gather(hidden.float(), cur, rem, fire_idx, n_fire, int(max_label_len))
+    return out, (fire_idx, n_fire, n_label)
+
+
+class CIF_Model(_Cached):
+    """src/transformer/cif_model.py:8-106 — returns (ctc_logits, len, _num, num, logits)."""
+
+    def __init__(self, conv_encoder, encoder, assigner, decoder, spec_aug_cfg=None):
+        super().__init__()
+        self.conv_encoder, self.encoder, self.assigner, self.decoder = conv_encoder, encoder, assigner, decoder
+        self.spec_aug_cfg = spec_aug_cfg
+        if spec_aug_cfg:
+            raise NotImplementedError("spec_aug is outside the hot path")
+        self.ctc_fc = nn.Linear(encoder.d_output, decoder.d_output, bias=False)
+        _xavier_all(self)
+
+    def forward(self, features, len_features, targets, threshold=0.95, noise=None):
+        conv, len_sequence = self.conv_encoder._impl(features, len_features)
+        enc = self.encoder._impl(conv, len_sequence)
+        ctc_logits = ops.gemm_nt(enc.mma(), self._w("ctc", (self.ctc_fc.weight,)), None).view(enc.B, enc.L, -1)
+        alpha = self.assigner._impl(enc, len_sequence)
+        _num = alpha.sum(-1)
+        num = (targets > 0).float().sum(-1)
+        if noise is None:
+            noise = torch.rand(alpha.size(0), device=alpha.device)     # cif_model.py:47
+        alpha = alpha * ((num + noise - 0.5) / _num)[:, None]
+        l = self.cif(enc.view3(), alpha, threshold=threshold)
+        logits = self.decoder(l, targets)
+        return ctc_logits, len_sequence, _num, num, logits
+
+    def cif(self, hidden, alphas, threshold, log=False, max_label_len=None):
+        """cif_model.py:57-106."""
+        out, self.last_fire = cif_forward(hidden, alphas, threshold, max_label_len)
+        return out
+
+    @classmethod
+    def create_model(cls, args):
+        """cif_model.py:133-163."""
+        conv_encoder = Conv2dSubsample(d_input=args.d_input * args.LFR_m, d_model=args.d_model, n_layers=args.n_conv_layers)
+        encoder = Encoder(d_input=args.d_model, n_layers=args.n_layers_enc, n_head=args.n_head, d_model=args.d_model,
+                          d_inner=args.d_inner, dropout=args.dropout)
+        assigner = Attention_Assigner(d_input=args.d_model, d_hidden=args.d_assigner_hidden, w_context=args.w_context,
+                                      n_layers=args.n_assigner_layers)
+        decoder = Decoder_CIF(sos_id=args.sos_id, n_tgt_vocab=args.vocab_size, n_layers=args.n_layers_dec, n_head=args.n_head,
+                              d_model=args.d_model, d_inner=args.d_inner, dropout=args.dropout)
+        return cls(conv_encoder, encoder, assigner, decoder, args.spec_aug_cfg)

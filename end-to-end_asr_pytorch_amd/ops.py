@@ -1,0 +1,249 @@
+"""Thin tensor-level wrappers over the C-ABI (include/asr_hip.h).
+
+Every function here takes torch CUDA tensors, passes raw device pointers + torch's current HIP stream to
+libasr_hip.so and returns torch tensors that own the outputs.  torch is plumbing only (allocation, streams);
+no arithmetic on the product path is done by torch ops.  There is no CPU fallback: CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+F32, BF16 = 0, 1
+GEMM_RELU = 1
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("asr_amd: unsupported dtype %s" % t.dtype)
+
+
+def torch_dtype(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("asr_amd: tensor is on %s - the MI355X path has no CPU fallback" % t.device)
+
+
+def as_i32(t, device=None):
+    t = t.to(device=device if device is not None else t.device, dtype=torch.int32)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------
+def gemm_nt_raw(a, M, K, lda, w, bias=None, out_dtype=torch.float32, relu=False, out=None, ldc=None):
+    """C[M,N] = act(A . W^T + bias) where A is addressed as rows of K elements with stride lda inside tensor `a`."""
+    _req_cuda(a, w, bias)
+    N = w.shape[0]
+    assert w.dim() == 2 and w.shape[1] == K and w.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+        ldc = N
+    check(lib().asr_gemm_nt(_stream(), _p(a), dtype_code(a), lda, _p(w), dtype_code(w), K, _p(bias), _p(out), dtype_code(out),
+                            ldc if ldc is not None else N, M, N, K, GEMM_RELU if relu else 0), "asr_gemm_nt")
+    return out
+
+
+def gemm_nt(a2d, w, bias=None, out_dtype=torch.float32, relu=False):
+    assert a2d.dim() == 2 and a2d.is_contiguous()
+    return gemm_nt_raw(a2d, a2d.shape[0], a2d.shape[1], a2d.shape[1], w, bias, out_dtype, relu)
+
+
+def proj_heads(x2d, w, bias, n_proj, B, L, h, scale_first=1.0):
+    """-> tensor [n_proj, B, h, L, 64] in w.dtype (head-major), projection 0 scaled by scale_first."""
+    _req_cuda(x2d, w, bias)
+    assert x2d.is_contiguous() and w.is_contiguous() and x2d.shape[0] == B * L and w.shape[0] == n_proj * h * 64
+    K = x2d.shape[1]
+    out = torch.empty((n_proj, B, h, L, 64), device=x2d.device, dtype=w.dtype)
+    check(lib().asr_proj_heads(_stream(), _p(x2d), dtype_code(x2d), K, _p(w), dtype_code(w), K, _p(bias), _p(out),
+                               B * h * L * 64, n_proj, B, L, h, K, float(scale_first)), "asr_proj_heads")
+    return out
+
+
+def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False):
+    """q [B,h,Lq,64] (pre-scaled), k/v [B,h,Lk,64] -> ctx [B,Lq,h*64] (same dtype), lse [B,h,Lq] or None."""
+    _req_cuda(q, k, v, k_len)
+    B, h, Lq, dk = q.shape
+    Lk = k.shape[2]
+    assert dk == 64 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    ctx = torch.empty((B, Lq, h * 64), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32) if need_lse else None
+    check(lib().asr_attention_fwd(_stream(), _p(q), _p(k), _p(v), dtype_code(q), _p(ctx), _p(lse), B, h, Lq, Lk, _p(k_len),
+                                  1 if causal else 0), "asr_attention_fwd")
+    return ctx, lse
+
+
+def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False):
+    """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd)."""
+    _req_cuda(x, residual, gamma, beta, pe, row_len)
+    D = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == B * L * D
+    y32 = torch.empty((B * L, D), device=x.device, dtype=torch.float32)
+    y16 = torch.empty((B * L, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
+    mean = torch.empty(B * L, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(B * L, device=x.device, dtype=torch.float32) if save_stats else None
+    check(lib().asr_add_layernorm_fwd(_stream(), _p(x), _p(residual), _p(gamma), _p(beta), _p(pe), _p(row_len), _p(y32), _p(y16),
+                                      _p(mean), _p(rstd), B, L, D, float(eps)), "asr_add_layernorm_fwd")
+    return y32, y16, mean, rstd
+
+
+def embed_pe(ids, emb, pe, want_bf16=False):
+    _req_cuda(ids, emb, pe)
+    B, U = ids.shape
+    V, D = emb.shape
+    ids = ids.contiguous()
+    y32 = torch.empty((B * U, D), device=emb.device, dtype=torch.float32)
+    y16 = torch.empty((B * U, D), device=emb.device, dtype=torch.bfloat16) if want_bf16 else None
+    check(lib().asr_embed_pe_fwd(_stream(), _p(ids), _p(emb), _p(pe), _p(y32), _p(y16), B, U, D, V), "asr_embed_pe_fwd")
+    return y32, y16
+
+
+def conv_sub0(feats, w0, b0, dtype, T1, F1):
+    _req_cuda(feats, w0, b0)
+    B, T, D = feats.shape
+    y = torch.empty((B, T1, F1, 32), device=feats.device, dtype=dtype)
+    check(lib().asr_conv_sub0_fwd(_stream(), _p(feats.contiguous()), _p(w0), _p(b0), _p(y), dtype_code(y), B, T, D, T1, F1),
+          "asr_conv_sub0_fwd")
+    return y
+
+
+def conv_sub1(x, w, b, Tout, Fout, last):
+    _req_cuda(x, w, b)
+    B, Tin, Fin, C = x.shape
+    assert C == 32 and x.is_contiguous()
+    shape = (B, Tout, 32 * Fout) if last else (B, Tout, Fout, 32)
+    y = torch.empty(shape, device=x.device, dtype=x.dtype)
+    check(lib().asr_conv_sub1_fwd(_stream(), _p(x), _p(w), _p(b), _p(y), dtype_code(x), B, Tin, Fin, Tout, Fout, 1 if last else 0),
+          "asr_conv_sub1_fwd")
+    return y
+
+
+def cast_bf16(x):
+    _req_cuda(x)
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib().asr_cast_f32_bf16(_stream(), _p(x), _p(y), x.numel()), "asr_cast_f32_bf16")
+    return y
+
+
+def mask_rows_(x, lens):
+    B, L, V = x.shape
+    assert x.is_contiguous()
+    check(lib().asr_mask_rows(_stream(), _p(x), _p(lens), B, L, V), "asr_mask_rows")
+    return x
+
+
+def assigner_tail(x, w, b, lens, B, L):
+    Dh = x.shape[-1]
+    alpha = torch.empty((B, L), device=x.device, dtype=torch.float32)
+    check(lib().asr_assigner_tail_fwd(_stream(), _p(x), _p(w), _p(b), _p(lens), B, L, Dh, _p(alpha)), "asr_assigner_tail_fwd")
+    return alpha
+
+
+# ------------------------------------------------------------------------------------------------------------
+class CtcState:
+    """Workspaces saved between asr_ctc_loss_fwd and asr_ctc_loss_bwd."""
+    __slots__ = ("logits", "ldl", "in_len", "targets", "B", "L", "V", "Umax", "blank", "lse", "lp_ext", "alpha", "nll",
+                 "tgt_len")
+
+
+def ctc_loss_fwd(logits, in_len, targets, blank=None):
+    """logits f32 [B,L,V] (last dim contiguous, rows may be strided), in_len int32 [B], targets int64 [B,Umax].
+    -> (loss scalar tensor [1], nll [B], state)"""
+    _req_cuda(logits, in_len, targets)
+    B, L, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(2) == 1 and logits.stride(0) == L * logits.stride(1)
+    Umax = targets.shape[1]
+    st = CtcState()
+    st.logits, st.ldl, st.B, st.L, st.V, st.Umax = logits, logits.stride(1), B, L, V, Umax
+    st.blank = V - 1 if blank is None else blank
+    st.in_len = as_i32(in_len)
+    st.targets = targets.to(torch.int64).contiguous()
+    S = 2 * Umax + 1
+    dev = logits.device
+    st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
+    st.lp_ext = torch.empty((B, L, S), device=dev, dtype=torch.float32)
+    st.alpha = torch.empty((B, L, S), device=dev, dtype=torch.float32)
+    st.nll = torch.empty(B, device=dev, dtype=torch.float32)
+    st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
+    check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
+                                 _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len)), "asr_ctc_loss_fwd")
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
+    return loss, st.nll, st
+
+
+def ctc_loss_bwd(st, gout):
+    """-> grad wrt logits [B,L,V] (dense).  Consumes st.alpha."""
+    grad = torch.empty((st.B, st.L, st.V), device=st.logits.device, dtype=torch.float32)
+    gout = gout.reshape(1).to(torch.float32).contiguous()
+    check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax, st.blank,
+                                 _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad), st.V),
+          "asr_ctc_loss_bwd")
+    return grad
+
+
+def ce_loss_fwd(logits2d, targets1d, smoothing):
+    """-> (loss[2] = (mean, n_word), row_loss [N], lse [N])"""
+    _req_cuda(logits2d, targets1d)
+    N, V = logits2d.shape
+    assert logits2d.stride(1) == 1 and logits2d.dtype == torch.float32
+    targets1d = targets1d.to(torch.int64).contiguous()
+    row_loss = torch.empty(N, device=logits2d.device, dtype=torch.float32)
+    lse = torch.empty(N, device=logits2d.device, dtype=torch.float32)
+    check(lib().asr_ce_loss_fwd(_stream(), _p(logits2d), logits2d.stride(0), _p(targets1d), N, V, float(smoothing), _p(row_loss),
+                                _p(lse)), "asr_ce_loss_fwd")
+    loss = torch.empty(2, device=logits2d.device, dtype=torch.float32)
+    check(lib().asr_ce_mean(_stream(), _p(row_loss), _p(targets1d), N, _p(loss)), "asr_ce_mean")
+    return loss, row_loss, lse, targets1d
+
+
+def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout):
+    N, V = logits2d.shape
+    grad = torch.empty((N, V), device=logits2d.device, dtype=torch.float32)
+    gout = gout.reshape(1).to(torch.float32).contiguous()
+    n_word = loss2[1:2]
+    check(lib().asr_ce_loss_bwd(_stream(), _p(logits2d), logits2d.stride(0), _p(targets1d), N, V, float(smoothing), _p(lse),
+                                _p(n_word), _p(gout), _p(grad), V), "asr_ce_loss_bwd")
+    return grad
+
+
+def cif_scan(alpha, threshold):
+    """alpha f32 [B,L] -> cur, rem [B,L], fire_idx int32 [B,L], n_fire [B], n_label [B]"""
+    _req_cuda(alpha)
+    alpha = alpha.contiguous()
+    B, L = alpha.shape
+    dev = alpha.device
+    cur = torch.empty((B, L), device=dev, dtype=torch.float32)
+    rem = torch.empty((B, L), device=dev, dtype=torch.float32)
+    fire_idx = torch.zeros((B, L), device=dev, dtype=torch.int32)
+    n_fire = torch.empty(B, device=dev, dtype=torch.int32)
+    n_label = torch.empty(B, device=dev, dtype=torch.int32)
+    check(lib().asr_cif_scan_fwd(_stream(), _p(alpha), B, L, float(threshold), _p(cur), _p(rem), _p(fire_idx), _p(n_fire), _p(n_label)),
+          "asr_cif_scan_fwd")
+    return cur, rem, fire_idx, n_fire, n_label
+
+
+def cif_gather(hidden, cur, rem, fire_idx, n_fire, Umax):
+    _req_cuda(hidden)
+    hidden = hidden.contiguous()
+    B, L, H = hidden.shape
+    out = torch.empty((B, Umax, H), device=hidden.device, dtype=torch.float32)
+    check(lib().asr_cif_gather_fwd(_stream(), _p(hidden), _p(cur), _p(rem), _p(fire_idx), _p(n_fire), B, L, H, Umax, _p(out)),
+          "asr_cif_gather_fwd")
+    return out

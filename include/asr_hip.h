@@ -1,0 +1,150 @@
+/*
+ * asr_hip.h — C-ABI of libasr_hip.so: the MI355X (gfx950) Speech-Transformer / CTC / CIF forward+loss path.
+ *
+ * The reference (eastonYi/end-to-end_asr_pytorch) has no FFI / plugin boundary: it is 100 % Python calling stock
+ * aten ops.  Each entry point below replaces one aten call site (cited as `src/...:line`, paths
+ * relative to the reference tree) so that the Python host code in end-to-end_asr_pytorch_amd/ can mirror the
+ * reference's nn.Module classes one-to-one.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types cross the boundary.
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the library never allocates or frees device
+ *     memory and keeps no state besides its loaded code objects and a thread-local error string.
+ *   - `stream` is a hipStream_t (torch's current stream).  Calls are asynchronous, never synchronise, and are
+ *     capturable into a hipGraph.
+ *   - return value: 0 = ok, <0 = invalid argument (ASR_ERR_*), >0 = hipError_t.  asr_last_error() gives text.
+ *   - dtype codes: ASR_F32 = 0 (exact-fp32 MFMA path), ASR_BF16 = 1 (bf16 MFMA inputs, fp32 accumulate).
+ *   - lengths / indices on device: int32 lengths, int64 token ids (the reference's dtypes).
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_F32 0
+#define ASR_BF16 1
+
+#define ASR_ERR_ARG (-1)       /* null pointer / non-positive size */
+#define ASR_ERR_ALIGN (-2)     /* pointer or leading dimension not aligned as documented */
+#define ASR_ERR_UNSUPPORTED (-3)
+
+/* GEMM epilogue flags */
+#define ASR_GEMM_RELU 1u
+
+int asr_version(void);
+const char* asr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Dense projection  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N])          (nn.Linear; W is [out,in] row-major)
+ * replaces: encoder.py:49 linear_in, conv_encoder.py:124 affine, module.py:50 w_1 / w_2, attention.py:59 fc,
+ *           transformer.py:148 ctc_fc, decoder.py:94 tgt_word_prj, decoder.py:387,397 (CIF), ctcModel/decoder.py:32.
+ * A: a_dtype (f32 is converted on load when w_dtype is bf16);  W: w_dtype = the MFMA compute type;
+ * bias: f32 or NULL;  C: c_dtype.  lda/ldw/ldc in elements.  16-byte alignment of A/W rows required
+ * (K, lda, ldw multiples of 8 for bf16, 4 for f32); C may have any ldc.
+ */
+int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
+                const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags);
+
+/* Head-major projection (attention.py:43-49: w_qs/w_ks/w_vs + view/permute/contiguous fused).
+ * X[M = B*L, K] . W[n_proj*h*64, K]^T + bias -> out[p][B][h][L][64] for p < n_proj, out_dtype = w_dtype.
+ * `proj_stride` = elements between consecutive projections' buffers.  If scale_first != 1, projection 0 (Q) is
+ * multiplied by it (the 1/sqrt(d_k) of attention.py:77 folded in; exact for powers of two).
+ */
+int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t ldx, const void* W, int w_dtype, int64_t ldw,
+                   const float* bias, void* out, int64_t proj_stride, int n_proj, int B, int L, int h, int K,
+                   float scale_first);
+
+/* Fused scaled-dot-product attention (attention.py:76-84 bmm -> /sqrt(dk) -> masked_fill(-inf) -> softmax -> bmm,
+ * plus the un-permute of attention.py:56-57).  q (pre-scaled) [B,h,Lq,64], k,v [B,h,Lk,64] in `dtype`;
+ * ctx [B,Lq,h*64] in `dtype`.  Masks are expressed by lengths, not tensors: key j of batch b is masked iff
+ * j >= k_len[b] (utils.py:157-165 / :146-154) or (causal && j > i) (utils.py:135-143).  k_len may be NULL.
+ * lse (f32 [B,h,Lq], natural log of the softmax denominator incl. max) is written when non-NULL (for backward).
+ */
+int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
+                      int B, int h, int Lq, int Lk, const int32_t* k_len, int causal);
+
+/* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
+ * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.
+ * mean/rstd (f32 [M]) optional saves for backward.
+ */
+int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
+                          const float* pe, const int32_t* row_len, float* y32, void* y16, float* mean, float* rstd,
+                          int B, int L, int D, float eps);
+
+/* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = emb[ids[b,u],:] + pe[u,:]. */
+int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16,
+                     int B, int U, int D, int V);
+
+/* Conv2dSubsample (conv_encoder.py:101-108).  Layer 0: feats f32 [B,T,D] with the implicit zero right-pad of
+ * conv_encoder.py:104 -> relu(conv 1->32, 3x3, stride (2,1)) -> y [B,T1,F1,32] channel-last in `dtype`; only the
+ * T1 x F1 region later layers need is produced.  w0 f32 [32,1,3,3], b0 f32 [32].
+ */
+int asr_conv_sub0_fwd(void* stream, const float* feats, const float* w0, const float* b0, void* y, int dtype,
+                      int B, int T, int D, int T1, int F1);
+/* Layer i>=1: x [B,Tin,Fin,32] channel-last -> relu(conv 32->32, 3x3, stride (2,1)).  If last != 0 the output is
+ * written as [B,Tout,32*Fout] with column c*Fout+f (the permute/view of conv_encoder.py:108), else channel-last.
+ * w f32 [32,32,3,3], b f32 [32].
+ */
+int asr_conv_sub1_fwd(void* stream, const void* x, const float* w, const float* b, void* y, int dtype,
+                      int B, int Tin, int Fin, int Tout, int Fout, int last);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CTC loss (loss.py:41-43 / ctcModel/loss.py:9-11: F.log_softmax(dim=-1) -> F.ctc_loss(blank=V-1)).
+ * logits f32 [B,L,V] with row stride ldl (elements) and batch stride L*ldl; in_len int32 [B]; targets int64
+ * [B,Umax] zero-padded; target length = number of non-zero ids per row (loss.py:40).
+ * Workspaces (caller-owned): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L,S]; S = 2*Umax+1.
+ * Outputs: nll f32 [B] (inf for infeasible rows, zero_infinity=False), tgt_len int32 [B].
+ */
+int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
+                     int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
+                     int32_t* tgt_len);
+/* mean_b(nll_b / max(tgt_len_b,1))  — reduction='mean' of F.ctc_loss.  loss: f32 [1]. */
+int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_len, int B, float* loss);
+/* Gradient wrt logits of gout * mean-reduced loss: g[b,t,v] = gout/(B*max(tgt_len_b,1)) * (softmax - occupancy),
+ * zero for t >= in_len[b].  Consumes (and overwrites) alpha with the occupancies.  grad f32, row stride ldg.
+ */
+int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
+                     int B, int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
+                     const float* nll, const int32_t* tgt_len, const float* gout, float* grad, int64_t ldg);
+
+/* Label-smoothed cross entropy (loss.py:5-31).  logits f32 [N,V] (row stride ldl), targets int64 [N] (0 = pad).
+ * row_loss f32 [N] (0 on pad rows), lse f32 [N];  asr_ce_mean: loss[0] = sum(row_loss) / n_word, loss[1] = n_word
+ * = count(target != 0) (f32 [2]);  asr_ce_loss_bwd: grad of gout * loss wrt logits, n_word = &loss[1].
+ */
+int asr_ce_loss_fwd(void* stream, const float* logits, int64_t ldl, const int64_t* targets, int N, int V,
+                    float smoothing, float* row_loss, float* lse);
+int asr_ce_mean(void* stream, const float* row_loss, const int64_t* targets, int N, float* loss);
+int asr_ce_loss_bwd(void* stream, const float* logits, int64_t ldl, const int64_t* targets, int N, int V,
+                    float smoothing, const float* lse, const float* n_word, const float* gout, float* grad, int64_t ldg);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CIF (cif_model.py:57-106).  asr_cif_scan_fwd runs the integrate-and-fire recurrence in the reference's exact fp32
+ * operation order (one wavefront per utterance): cur/rem f32 [B,L] weights, fire_idx int32 [B,L] (frame index of
+ * each fire, in order), n_fire int32 [B], n_label int32 [B] = round(sum alpha) (cif_model.py:95).
+ * asr_cif_gather_fwd forms out[b,u,:] (f32 [B,Umax,H], zero-padded rows u >= n_fire[b]) as the same ordered
+ * fp32 sum the reference accumulates.
+ */
+int asr_cif_scan_fwd(void* stream, const float* alpha, int B, int L, float threshold, float* cur, float* rem,
+                     int32_t* fire_idx, int32_t* n_fire, int32_t* n_label);
+int asr_cif_gather_fwd(void* stream, const float* hidden, const float* cur, const float* rem, const int32_t* fire_idx,
+                       const int32_t* n_fire, int B, int L, int H, int Umax, float* out);
+
+/* Attention_Assigner tail (attentionAssigner.py:37-40): alpha = sigmoid(x . w + b) * (t < len). x f32 [B,L,Dh]. */
+int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const float* b, const int32_t* len,
+                          int B, int L, int Dh, float* alpha);
+/* Conv1d k=w stride 1 valid + ReLU over time with implicit zero right-pad (conv_encoder.py:33-43) is expressed by
+ * the caller as w_context shifted GEMMs through asr_gemm_nt; no dedicated entry point. */
+
+/* Utility: dtype cast f32 -> bf16 (weights / activations entering the bf16 MFMA path). n elements. */
+int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t n);
+/* logits *= (t < len)  (ctcModel/decoder.py:33-36), in place, f32 [B,L,V] dense. */
+int asr_mask_rows(void* stream, float* x, const int32_t* len, int B, int L, int V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */

@@ -1,0 +1,425 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, called through the C-ABI, against
+(1) the numpy oracle, (2) the committed golden fixtures generated from the reference, and (3) for floating-point
+kernels a plain PyTorch fp32 CPU reference of the same op.
+
+Tolerances (stated per SURVEY.md §8d):
+  fp32 kernels (CTC, CE, CIF, LayerNorm, fp32-MFMA GEMM/attention): abs <= 1e-4 on O(1) values; CTC nll rel 1e-5;
+  CIF firing index lists exactly equal, fired frames abs <= 1e-6.
+  bf16-MFMA path vs fp32 oracle: abs <= 3e-2 + rel 2e-2 on logits at S0.
+"""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+from oracle import asr_oracle as O
+from weights import make_state_dict, names_shapes_from_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"])) if "names_shapes" in z else None
+    cfg = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")}
+    return z, sd, cfg
+
+
+def load_sd(model, sd):
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert all(k.endswith("positional_encoding.pe") for k in missing.missing_keys)
+    return model.to(DEV).eval()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N_,K", [(300, 4234, 80), (128, 128, 64), (1000, 256, 2048), (77, 50, 1280), (5, 7, 8)])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gemm_nt(M, N_, K, prec):
+    g = torch.Generator().manual_seed(M * 7 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N_, K, generator=g) / K ** 0.5
+    b = torch.randn(N_, generator=g)
+    if prec == "f32":
+        ref = torch.relu(a @ w.t() + b)
+        out = ops.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+        np.testing.assert_allclose(N(out), ref.numpy(), atol=1e-4, rtol=1e-5)
+    else:
+        ab, wb = a.bfloat16().float(), w.bfloat16().float()
+        ref = torch.relu(ab @ wb.t() + b)
+        # f32 activations converted on load
+        out = ops.gemm_nt(a.to(DEV), w.to(DEV).bfloat16(), b.to(DEV), relu=True)
+        np.testing.assert_allclose(N(out), ref.numpy(), atol=2e-3, rtol=2e-3)
+        # bf16 activations, bf16 output
+        out16 = ops.gemm_nt(a.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV), out_dtype=torch.bfloat16, relu=True)
+        np.testing.assert_allclose(N(out16), ref.numpy(), atol=3e-2, rtol=1e-2)
+
+
+def test_gemm_asymmetric_identity():
+    # A = I with an asymmetric W catches a transposed C write (cdna guide §3)
+    K = 64
+    a = torch.eye(K)
+    w = torch.arange(K * K, dtype=torch.float32).reshape(K, K) / 100.0
+    out = ops.gemm_nt(a.to(DEV), w.to(DEV))
+    np.testing.assert_allclose(N(out), w.t().numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_proj_heads_layout(prec):
+    B, L, h, K = 3, 37, 2, 64
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B * L, K, generator=g)
+    w = torch.randn(3 * h * 64, K, generator=g) / 8
+    b = torch.randn(3 * h * 64, generator=g)
+    dt = torch.float32 if prec == "f32" else torch.bfloat16
+    out = ops.proj_heads(x.to(DEV), w.to(DEV).to(dt), b.to(DEV), 3, B, L, h, 0.125)
+    xr, wr = (x, w) if prec == "f32" else (x.bfloat16().float(), w.bfloat16().float())
+    y = (xr @ wr.t() + b).view(B, L, 3, h, 64).permute(2, 0, 3, 1, 4).clone()
+    y[0] *= 0.125
+    tol = 1e-4 if prec == "f32" else 3e-2
+    np.testing.assert_allclose(N(out), y.numpy(), atol=tol, rtol=tol)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------
+def ref_attention(q, k, v, k_len, causal):
+    B, h, Lq, _ = q.shape
+    Lk = k.shape[2]
+    s = q @ k.transpose(-1, -2)
+    mask = torch.zeros(B, 1, Lq, Lk, dtype=torch.bool)
+    if k_len is not None:
+        mask |= (torch.arange(Lk)[None, :] >= k_len[:, None])[:, None, None, :]
+    if causal:
+        mask |= torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1)[None, None]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B, Lq, h * 64)
+    return ctx, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("B,h,Lq,Lk,causal,ragged", [
+    (2, 2, 25, 25, False, True), (3, 4, 200, 200, False, True), (2, 2, 8, 8, True, True), (2, 2, 51, 51, True, True),
+    (2, 4, 51, 250, False, True), (1, 1, 130, 130, True, False), (2, 2, 300, 300, False, False), (1, 2, 1000, 1000, False, True)])
+def test_attention_fwd(prec, B, h, Lq, Lk, causal, ragged):
+    g = torch.Generator().manual_seed(B * 1000 + Lq)
+    q = torch.randn(B, h, Lq, 64, generator=g) * 0.5
+    k = torch.randn(B, h, Lk, 64, generator=g)
+    v = torch.randn(B, h, Lk, 64, generator=g)
+    k_len = None
+    if ragged:
+        k_len = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+        k_len[0] = Lk
+    dt = torch.float32 if prec == "f32" else torch.bfloat16
+    qd, kd, vd = (t.to(DEV).to(dt) for t in (q, k, v))
+    ctx, lse = ops.attention_fwd(qd, kd, vd, None if k_len is None else k_len.to(DEV).int(), causal, need_lse=True)
+    qr, kr, vr = (qd.float().cpu(), kd.float().cpu(), vd.float().cpu())
+    rctx, rlse = ref_attention(qr, kr, vr, k_len, causal)
+    tol = 2e-5 if prec == "f32" else 2e-2
+    np.testing.assert_allclose(N(ctx), rctx.numpy(), atol=tol, rtol=tol)
+    np.testing.assert_allclose(N(lse), rlse.numpy(), atol=1e-4 if prec == "f32" else 2e-2, rtol=1e-4)
+
+
+def test_attention_online_softmax_rescale_branch():
+    # a spike late in the key sequence forces the running-max rescale (cdna guide rule 26)
+    B, h, L = 1, 1, 256
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, h, L, 64, generator=g) * 0.3
+    k = torch.randn(B, h, L, 64, generator=g) * 0.3
+    v = torch.randn(B, h, L, 64, generator=g)
+    k[0, 0, 200] = q[0, 0, 17] * 40.0
+    for dt, tol in ((torch.float32, 5e-5), (torch.bfloat16, 3e-2)):
+        qd, kd, vd = (t.to(DEV).to(dt) for t in (q, k, v))
+        ctx, _ = ops.attention_fwd(qd, kd, vd, None, False)
+        rctx, _ = ref_attention(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), None, False)
+        np.testing.assert_allclose(N(ctx), rctx.numpy(), atol=tol, rtol=tol)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# row kernels
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D", [64, 256, 512])
+def test_add_layernorm(D):
+    B, L = 3, 21
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(B * L, D, generator=g)
+    r = torch.randn(B * L, D, generator=g)
+    gam = torch.randn(D, generator=g)
+    bet = torch.randn(D, generator=g)
+    pe = torch.randn(L, D, generator=g)
+    lens = torch.tensor([21, 10, 1], dtype=torch.int32)
+    y32, y16, mean, rstd = ops.add_layernorm(x.to(DEV), r.to(DEV), gam.to(DEV), bet.to(DEV), B, L, pe=pe.to(DEV),
+                                             row_len=lens.to(DEV), want_bf16=True, save_stats=True)
+    ref = torch.nn.functional.layer_norm(x + r, (D,), gam, bet).view(B, L, D) + pe[None]
+    ref = ref * (torch.arange(L)[None, :] < lens[:, None])[:, :, None]
+    np.testing.assert_allclose(N(y32).reshape(B, L, D), ref.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(N(y16).reshape(B, L, D), ref.numpy(), atol=3e-2, rtol=1e-2)
+    np.testing.assert_allclose(N(mean), (x + r).mean(-1).numpy(), atol=1e-5)
+
+
+def test_embed_pe():
+    B, U, D, V = 4, 9, 64, 50
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, V, (B, U), generator=g)
+    emb = torch.randn(V, D, generator=g)
+    pe = torch.randn(U, D, generator=g)
+    y32, y16 = ops.embed_pe(ids.to(DEV), emb.to(DEV), pe.to(DEV), want_bf16=True)
+    ref = emb[ids] + pe[None]
+    np.testing.assert_allclose(N(y32).reshape(B, U, D), ref.numpy(), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# conv front-end
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_layers", [1, 2, 3])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_conv2d_subsample(n_layers, prec):
+    B, T, D, dm = 3, 61, 80, 64
+    conv = asr_amd.Conv2dSubsample(D, dm, n_layers=n_layers)
+    sd = {k: v.detach().numpy().copy() for k, v in conv.state_dict().items()}
+    conv = conv.to(DEV)
+    g = torch.Generator().manual_seed(n_layers)
+    x = torch.randn(B, T, D, generator=g)
+    lens = torch.tensor([61, 40, 7])
+    with asr_amd.precision(prec):
+        out, ol = conv(x.to(DEV), lens.to(DEV))
+    ref, rl = O.conv2d_subsample(sd, "", x.numpy(), lens.numpy(), n_layers)
+    np.testing.assert_array_equal(N(ol).astype(np.int32), rl)
+    tol = 2e-4 if prec == "f32" else 4e-2
+    np.testing.assert_allclose(N(out), ref, atol=tol, rtol=tol)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CTC
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_ctc_golden(golden_dir, case):
+    z, _, _ = load(golden_dir, "g2_ctc.npz")
+    logits = T(z[f"{case}_logits"]).requires_grad_(True)
+    loss, nll = asr_amd.ctc_loss(logits, T(z[f"{case}_in_len"]), T(z[f"{case}_targets"]))
+    np.testing.assert_allclose(N(nll), z[f"{case}_nll"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(float(loss), z[f"{case}_mean"], rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(N(logits.grad), z[f"{case}_grad"], atol=1e-5)
+
+
+def test_ctc_infeasible_is_inf(golden_dir):
+    z, _, _ = load(golden_dir, "g2_ctc.npz")
+    loss, nll = asr_amd.ctc_loss(T(z["d_logits"]), T(z["d_in_len"]), T(z["d_targets"]))
+    nll = N(nll)
+    assert np.isinf(nll[0]) and nll[0] > 0
+    np.testing.assert_allclose(nll[1], z["d_nll"][1], rtol=1e-5)
+    assert np.isinf(float(loss))
+
+
+@pytest.mark.parametrize("B,L,U,V,repeat", [(4, 250, 51, 4234, False), (3, 120, 20, 301, True), (2, 64, 1, 7, False)])
+def test_ctc_vs_torch_cpu(B, L, U, V, repeat):
+    g = torch.Generator().manual_seed(L)
+    logits = torch.randn(B, L, V, generator=g)
+    tg = torch.randint(1, V - 1, (B, U), generator=g)
+    if repeat:
+        tg[:, 1::2] = tg[:, 0::2][:, :tg[:, 1::2].shape[1]]
+    if U > 2:
+        tg[1, U // 2:] = 0
+    in_len = torch.full((B,), L, dtype=torch.int64)
+    in_len[-1] = max(L // 2, 2 * U + 1)
+    lg = logits.clone().requires_grad_(True)
+    tl = tg.ne(0).int().sum(1)
+    lp = torch.nn.functional.log_softmax(lg, -1).transpose(0, 1)
+    ref_nll = torch.nn.functional.ctc_loss(lp, tg, in_len, tl, blank=V - 1, reduction="none")
+    ref = torch.nn.functional.ctc_loss(lp, tg, in_len, tl, blank=V - 1)
+    ref.backward()
+    ld = logits.to(DEV).requires_grad_(True)
+    loss, nll = asr_amd.ctc_loss(ld, in_len.to(DEV), tg.to(DEV))
+    loss.backward()
+    np.testing.assert_allclose(N(nll), ref_nll.detach().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+    np.testing.assert_allclose(N(ld.grad), lg.grad.numpy(), atol=1e-5)
+    # frames past in_len carry exactly zero gradient
+    assert float(ld.grad[-1, int(in_len[-1]):].abs().max()) == 0.0
+
+
+def test_ctc_strided_logits_rows():
+    # logits living in a padded buffer (row stride > V) are consumed in place
+    B, L, V, U = 2, 30, 50, 5
+    g = torch.Generator().manual_seed(9)
+    buf = torch.randn(B, L, 56, generator=g).to(DEV)
+    view = buf[:, :, :V]
+    tg = torch.randint(1, V - 1, (B, U), generator=g).to(DEV)
+    il = torch.tensor([30, 22]).to(DEV)
+    l1, n1 = asr_amd.ctc_loss(view, il, tg)
+    l2, n2 = asr_amd.ctc_loss(view.contiguous(), il, tg)
+    np.testing.assert_array_equal(N(n1), N(n2))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CE
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("smoothing", [0.0, 0.1])
+def test_ce_loss(smoothing):
+    Nrows, V = 37, 4234
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(Nrows, V, generator=g) * 2
+    tg = torch.randint(1, V, (Nrows,), generator=g)
+    tg[::5] = 0
+    ref_l = O.cal_ce_loss(logits.numpy()[None], tg.numpy()[None], smoothing)
+    # torch reference of the same formula for the gradient
+    lg = logits.clone().requires_grad_(True)
+    if smoothing > 0:
+        one_hot = torch.zeros_like(lg).scatter(1, tg.view(-1, 1), 1)
+        one_hot = one_hot * (1 - smoothing) + (1 - one_hot) * smoothing / V
+        lp = torch.nn.functional.log_softmax(lg, 1)
+        npm = tg.ne(0)
+        rl = -(one_hot * lp).sum(1).masked_select(npm).sum() / npm.sum()
+    else:
+        rl = torch.nn.functional.cross_entropy(lg, tg, ignore_index=0)
+    rl.backward()
+    ld = logits.to(DEV).requires_grad_(True)
+    loss = asr_amd.cal_ce_loss(ld.view(1, Nrows, V), tg.to(DEV).view(1, Nrows), smoothing)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(ref_l), rtol=1e-5)
+    np.testing.assert_allclose(float(loss), float(rl), rtol=1e-5)
+    np.testing.assert_allclose(N(ld.grad), lg.grad.numpy(), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CIF
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pfx", ["h", "r"])
+def test_cif_golden_exact_boundaries(golden_dir, pfx):
+    z, _, _ = load(golden_dir, "g3_cif.npz")
+    alpha, hidden = z[f"{pfx}_alpha"], z[f"{pfx}_hidden"]
+    ref_out, ref_idx, ref_nlabel = O.cif(hidden, alpha, 0.95)
+    cur, rem, fire_idx, n_fire, n_label = ops.cif_scan(T(alpha), 0.95)
+    nf = N(n_fire).astype(int)
+    assert list(nf) == [len(i) for i in ref_idx]
+    fi = fire_idx.cpu().numpy()
+    for b in range(len(nf)):
+        np.testing.assert_array_equal(fi[b, :nf[b]], ref_idx[b])          # firing boundaries: exact
+    np.testing.assert_array_equal(N(n_label).astype(np.int32), ref_nlabel)
+    out, _ = asr_amd.modules.cif_forward(T(hidden), T(alpha), 0.95)
+    assert tuple(out.shape) == z[f"{pfx}_out"].shape
+    np.testing.assert_allclose(N(out), z[f"{pfx}_out"], rtol=0, atol=1e-6)   # vs the reference itself
+    np.testing.assert_array_equal(N(out), ref_out)                            # vs the oracle: bit-exact
+
+
+def test_cif_s3_shape_against_oracle():
+    B, L, H = 8, 1000, 256
+    g = torch.Generator().manual_seed(0)
+    a = torch.sigmoid(torch.randn(B, L, generator=g))
+    U = torch.randint(20, 51, (B,), generator=g).float()
+    a = a * ((U + torch.rand(B, generator=g) - 0.5) / a.sum(-1))[:, None]
+    hid = torch.randn(B, L, H, generator=g)
+    ref_out, ref_idx, _ = O.cif(hid.numpy(), a.numpy(), 0.95)
+    out, (fire_idx, n_fire, _) = asr_amd.modules.cif_forward(hid.to(DEV), a.to(DEV), 0.95)
+    nf = N(n_fire).astype(int)
+    assert list(nf) == [len(i) for i in ref_idx]
+    for b in range(B):
+        np.testing.assert_array_equal(fire_idx[b, :nf[b]].cpu().numpy(), ref_idx[b])
+    np.testing.assert_array_equal(N(out), ref_out)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# whole models vs the reference's outputs (golden) and the oracle
+# ---------------------------------------------------------------------------------------------------------
+TOLS = {"f32": dict(atol=5e-4, rtol=1e-3), "bf16": dict(atol=3e-2, rtol=2e-2)}
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_g0_conv_ctc_transformer(golden_dir, prec):
+    z, sd, cfg = load(golden_dir, "g0_conv_ctc_transformer.npz")
+    model = load_sd(asr_amd.Conv_CTC_Transformer.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg)), sd)
+    with asr_amd.precision(prec), torch.no_grad():
+        conv_out, conv_len = model.conv_encoder(T(z["x"]), T(z["lens"]))
+        enc_out = model.encoder(conv_out, conv_len)
+        ctc_logits, l, logits, teos = model(T(z["x"]), T(z["lens"]), T(z["targets"]))
+        ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, 0.1)
+        ce0 = asr_amd.cal_ce_loss(logits, teos, 0.0)
+    tol = TOLS[prec]
+    np.testing.assert_array_equal(N(conv_len).astype(np.int32), z["conv_len"])
+    np.testing.assert_array_equal(teos.cpu().numpy(), z["targets_eos"])
+    np.testing.assert_allclose(N(conv_out), z["conv_out"], **tol)
+    np.testing.assert_allclose(N(enc_out), z["enc_out"], **tol)
+    np.testing.assert_allclose(N(ctc_logits), z["ctc_logits"], **tol)
+    np.testing.assert_allclose(N(logits), z["logits"], **tol)
+    ltol = 1e-4 if prec == "f32" else 5e-3
+    np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=ltol)
+    np.testing.assert_allclose(float(ce), z["ce_loss_s01"], rtol=ltol)
+    np.testing.assert_allclose(float(ce0), z["ce_loss_s0"], rtol=ltol)
+    enc = N(enc_out)
+    for b, n in enumerate(z["conv_len"]):
+        assert np.all(enc[b, n:] == 0)      # padded encoder rows are exact zeros (encoder.py:74,77)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_g1_ctc_transformer(golden_dir, prec):
+    z, sd, cfg = load(golden_dir, "g1_ctc_transformer.npz")
+    model = load_sd(asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=0.0),
+                                            asr_amd.Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.0)), sd)
+    with asr_amd.precision(prec), torch.no_grad():
+        l, ctc_logits, (logits, teos) = model(T(z["x"]), T(z["lens"]), T(z["targets"]))
+        ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, 0.1)
+    tol = TOLS[prec]
+    np.testing.assert_allclose(N(ctc_logits), z["ctc_logits"], **tol)
+    np.testing.assert_allclose(N(logits), z["logits"], **tol)
+    ltol = 1e-4 if prec == "f32" else 5e-3
+    np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=ltol)
+    np.testing.assert_allclose(float(ce), z["ce_loss_s01"], rtol=ltol)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_g4_cif_model(golden_dir, prec):
+    z, sd, cfg = load(golden_dir, "g4_cif_model.npz")
+    model = load_sd(asr_amd.CIF_Model.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg)), sd)
+    with asr_amd.precision(prec), torch.no_grad():
+        ctc_logits, l, _num, num, logits = model(T(z["x"]), T(z["lens"]), T(z["targets"]), noise=T(z["noise"]))
+        qua, ctc, ce = asr_amd.cal_ctc_qua_ce_loss(ctc_logits, l, _num, num, logits, T(z["targets"]), 0.1)
+    tol = TOLS[prec]
+    np.testing.assert_allclose(N(_num), z["num_pred"], rtol=1e-4 if prec == "f32" else 2e-2)
+    np.testing.assert_array_equal(N(num), z["num"])
+    np.testing.assert_allclose(N(ctc_logits), z["ctc_logits"], **tol)
+    if prec == "f32":
+        # CIF firing boundaries equal the reference's: same number of fired (non-zero) rows per utterance
+        fire_idx, n_fire, _ = model.last_fire
+        ref_cnt = (np.abs(z["cif_out"]).sum(-1) > 0).sum(-1)
+        np.testing.assert_array_equal(N(n_fire).astype(int), ref_cnt)
+        np.testing.assert_allclose(N(logits), z["logits"], **tol)
+        np.testing.assert_allclose(float(qua), z["qua_loss"], rtol=1e-4)
+        np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=1e-4)
+        np.testing.assert_allclose(float(ce), z["ce_loss_s01"], rtol=1e-4)
+    else:
+        np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=5e-3)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_g5_ctc_model(golden_dir, prec):
+    from asr_amd.ctc_model import CTC_Model, Decoder, Encoder
+    z, sd, cfg = load(golden_dir, "g5_ctc_model.npz")
+    model = load_sd(CTC_Model(Encoder(80, 2, 2, 64, 64, 64, 128, dropout=0.0, pe_maxlen=5000), Decoder(50, 64)), sd)
+    with asr_amd.precision(prec), torch.no_grad():
+        logits, l = model(T(z["x"]), T(z["lens"]))
+        loss = asr_amd.cal_loss(logits, l, T(z["targets"]))
+    np.testing.assert_allclose(N(logits), z["logits"], **TOLS[prec])
+    np.testing.assert_allclose(float(loss), z["loss"], rtol=1e-4 if prec == "f32" else 5e-3)
+
+
+def test_native_library_is_what_ran():
+    """The .so in-tree is loaded in this process (the round-end check looks for exactly this)."""
+    maps = open("/proc/self/maps").read()
+    assert "libasr_hip.so" in maps
