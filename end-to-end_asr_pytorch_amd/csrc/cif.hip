@@ -10,6 +10,12 @@
 // (non-fused) multiply and add so the fp32 results match the CPU loop bit-for-bit.
 #include "asr_common.h"
 
+// The reference rounds the product and the sum separately (torch: cur[:,None]*hidden, then +=); hipcc contracts
+// a*b+c into v_fma_f32 by default, which changes the last bit.  Contraction is disabled for this whole file (pragma
+// here + -ffp-contract=off in the build; the __fmul_rn/__fadd_rn header inlines keep their own contract flag, so the
+// arithmetic below is written with plain operators).
+#pragma clang fp contract(off)
+
 namespace {
 
 __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ alpha, int L, float thr, float* __restrict__ cur_out,
@@ -30,16 +36,16 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
         for (int i = 0; i < 64; ++i) {
             if (i < cnt) {  // wave-uniform
                 const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), i));
-                const float dc = __fsub_rn(1.0f, integrate);
-                integrate = __fadd_rn(integrate, al);
+                const float dc = 1.0f - integrate;
+                integrate = integrate + al;
                 const bool fire = integrate > thr;
                 if (fire) {
-                    integrate = __fsub_rn(integrate, 1.0f);
+                    integrate = integrate - 1.0f;
                     if (lane == i) fire_idx[(int64_t)b * L + n] = t0 + i;
                     ++n;
                 }
                 const float c = fire ? dc : al;
-                if (lane == i) { my_cur = c; my_rem = __fsub_rn(al, c); }
+                if (lane == i) { my_cur = c; my_rem = al - c; }
             }
         }
         if (t < L) {
@@ -70,8 +76,11 @@ __global__ __launch_bounds__(256) void cif_gather_kernel(const float* __restrict
     const float* cb = cur + (int64_t)b * L;
     const float w0 = (u == 0) ? cb[0] : rem[(int64_t)b * L + t_start];
     for (int c = threadIdx.x; c < H; c += 256) {
-        float frame = __fmul_rn(w0, hb[(int64_t)t_start * H + c]);
-        for (int t = t_start + 1; t <= t_end; ++t) frame = __fadd_rn(frame, __fmul_rn(cb[t], hb[(int64_t)t * H + c]));
+        float frame = w0 * hb[(int64_t)t_start * H + c];
+        for (int t = t_start + 1; t <= t_end; ++t) {
+            const float prod = cb[t] * hb[(int64_t)t * H + c];  // rounded product, then rounded sum (no FMA)
+            frame = frame + prod;
+        }
         o[c] = frame;
     }
 }

@@ -40,6 +40,45 @@ def _req_cuda(*ts):
             raise RuntimeError("asr_amd: tensor is on %s - the MI355X path has no CPU fallback" % t.device)
 
 
+# ---- optional live per-kernel timing (bench.py): HIP events on the launch stream around each C-ABI call ----------
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = {}
+
+
+def profile_stop():
+    """-> {name: dict(calls, ms, work)} ; `work` = algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) summed."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in (prof or {}).items():
+        out[name] = dict(calls=len(recs), ms=sum(a.elapsed_time(b) for a, b, _ in recs), work=sum(w for _, _, w in recs))
+    return out
+
+
+class _timed:
+    __slots__ = ("name", "work", "a")
+
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _PROF.setdefault(self.name, []).append((self.a, b, self.work))
+        return False
+
+
 def as_i32(t, device=None):
     t = t.to(device=device if device is not None else t.device, dtype=torch.int32)
     return t.contiguous()
@@ -54,8 +93,9 @@ def gemm_nt_raw(a, M, K, lda, w, bias=None, out_dtype=torch.float32, relu=False,
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=out_dtype)
         ldc = N
-    check(lib().asr_gemm_nt(_stream(), _p(a), dtype_code(a), lda, _p(w), dtype_code(w), K, _p(bias), _p(out), dtype_code(out),
-                            ldc if ldc is not None else N, M, N, K, GEMM_RELU if relu else 0), "asr_gemm_nt")
+    with _timed("gemm_nt[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
+        check(lib().asr_gemm_nt(_stream(), _p(a), dtype_code(a), lda, _p(w), dtype_code(w), K, _p(bias), _p(out), dtype_code(out),
+                                ldc if ldc is not None else N, M, N, K, GEMM_RELU if relu else 0), "asr_gemm_nt")
     return out
 
 
@@ -70,8 +110,9 @@ def proj_heads(x2d, w, bias, n_proj, B, L, h, scale_first=1.0):
     assert x2d.is_contiguous() and w.is_contiguous() and x2d.shape[0] == B * L and w.shape[0] == n_proj * h * 64
     K = x2d.shape[1]
     out = torch.empty((n_proj, B, h, L, 64), device=x2d.device, dtype=w.dtype)
-    check(lib().asr_proj_heads(_stream(), _p(x2d), dtype_code(x2d), K, _p(w), dtype_code(w), K, _p(bias), _p(out),
-                               B * h * L * 64, n_proj, B, L, h, K, float(scale_first)), "asr_proj_heads")
+    with _timed("proj_heads[%dx%dx%d]" % (B * L, n_proj * h * 64, K), 2.0 * B * L * n_proj * h * 64 * K):
+        check(lib().asr_proj_heads(_stream(), _p(x2d), dtype_code(x2d), K, _p(w), dtype_code(w), K, _p(bias), _p(out),
+                                   B * h * L * 64, n_proj, B, L, h, K, float(scale_first)), "asr_proj_heads")
     return out
 
 
@@ -83,8 +124,9 @@ def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False):
     assert dk == 64 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     ctx = torch.empty((B, Lq, h * 64), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32) if need_lse else None
-    check(lib().asr_attention_fwd(_stream(), _p(q), _p(k), _p(v), dtype_code(q), _p(ctx), _p(lse), B, h, Lq, Lk, _p(k_len),
-                                  1 if causal else 0), "asr_attention_fwd")
+    with _timed("attention_fwd[B%d h%d %dx%d]" % (B, h, Lq, Lk), 4.0 * B * h * 64 * Lq * Lk):
+        check(lib().asr_attention_fwd(_stream(), _p(q), _p(k), _p(v), dtype_code(q), _p(ctx), _p(lse), B, h, Lq, Lk, _p(k_len),
+                                      1 if causal else 0), "asr_attention_fwd")
     return ctx, lse
 
 
@@ -97,8 +139,10 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
     y16 = torch.empty((B * L, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
     mean = torch.empty(B * L, device=x.device, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(B * L, device=x.device, dtype=torch.float32) if save_stats else None
-    check(lib().asr_add_layernorm_fwd(_stream(), _p(x), _p(residual), _p(gamma), _p(beta), _p(pe), _p(row_len), _p(y32), _p(y16),
-                                      _p(mean), _p(rstd), B, L, D, float(eps)), "asr_add_layernorm_fwd")
+    nbytes = B * L * D * (4 + (4 if residual is not None else 0) + 4 + (2 if want_bf16 else 0))
+    with _timed("add_layernorm[%dx%d]" % (B * L, D), float(nbytes)):
+        check(lib().asr_add_layernorm_fwd(_stream(), _p(x), _p(residual), _p(gamma), _p(beta), _p(pe), _p(row_len), _p(y32), _p(y16),
+                                          _p(mean), _p(rstd), B, L, D, float(eps)), "asr_add_layernorm_fwd")
     return y32, y16, mean, rstd
 
 
@@ -181,8 +225,9 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None):
     st.alpha = torch.empty((B, L, S), device=dev, dtype=torch.float32)
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
-    check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
-                                 _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len)), "asr_ctc_loss_fwd")
+    with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
+        check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
+                                     _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len)), "asr_ctc_loss_fwd")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
     return loss, st.nll, st
@@ -192,9 +237,10 @@ def ctc_loss_bwd(st, gout):
     """-> grad wrt logits [B,L,V] (dense).  Consumes st.alpha."""
     grad = torch.empty((st.B, st.L, st.V), device=st.logits.device, dtype=torch.float32)
     gout = gout.reshape(1).to(torch.float32).contiguous()
-    check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax, st.blank,
-                                 _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad), st.V),
-          "asr_ctc_loss_bwd")
+    with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), 8.0 * st.B * st.L * st.V):
+        check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax,
+                                     st.blank, _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad),
+                                     st.V), "asr_ctc_loss_bwd")
     return grad
 
 
