@@ -4,8 +4,10 @@
 // HBM-bound design: the [B,L,V] logits are streamed exactly once forward (row log-sum-exp + gather
 // of the 2U+1 extended-label log-probs into a compact [B,L,S] table) and once backward (softmax recomputed from the
 // saved row lse; gradient written once).  The T-long alpha / beta recursions never touch the V axis: they run on the
-// compact table, one workgroup per utterance, the previous row held in LDS (log-space, -inf aware), the table rows
-// prefetched into registers 4 steps ahead so the dependent chain is LDS + transcendental latency only.
+// compact table, ONE WAVEFRONT per utterance and no LDS / no barriers: lane i owns the (blank, label) state pairs
+// i*NP..i*NP+NP-1, so a time step needs exactly one neighbour value (the previous lane's last label state), fetched
+// with a DPP wave shift; the table is kept in the base-2 log domain so log-sum-exp is v_exp_f32 / v_log_f32 directly;
+// table rows are prefetched 8 steps ahead into registers, leaving ~a dozen dependent VALU ops per step on the chain.
 // Per-label occupancies are scattered into an LDS vector indexed by vocabulary id, so repeated labels need no global
 // atomics and the gradient row is produced by one coalesced stream.
 #include "asr_common.h"
@@ -31,7 +33,17 @@ __global__ void ctc_prep_kernel(const int64_t* __restrict__ targets, int B, int 
     tgt_len[b] = n;
 }
 
-// one workgroup per (b,t) row: online (max,sum-exp) over V, then gather the extended labels' log-probs
+// compact-table row stride: 2U+1 extended states rounded up to 16 floats (64-byte rows; a multiple of every lane's
+// 2*NP-float slice, so a lane is either fully inside a row or fully outside)
+__host__ __device__ __forceinline__ int ctc_row_stride(int Umax) { return ((2 * Umax + 1 + 15) / 16) * 16; }
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// one workgroup per (b,t) row: (max, sum-exp) over V with every load of the row issued up front, then the gather of
+// the extended labels' log-probs (stored base-2: (x - lse) * log2(e)) into the compact table row (stride Sp = 2U+2).
+constexpr int LSE_UNR = 6;  // float4 per thread held in registers: V <= 256*4*6 = 6144 takes the two-pass register path
+
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ logits, int64_t ldl,
                                                              const int32_t* __restrict__ in_len, const int64_t* __restrict__ targets,
                                                              const int32_t* __restrict__ tgt_len, int L, int V, int Umax, int blank,
@@ -44,17 +56,37 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
     float m = -INFINITY, s = 0.f;
     const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
     const int peel = min((4 - mis) & 3, V);
-    if (tid < peel) { m = x[tid]; s = 1.f; }
     const int nv4 = (V - peel) >> 2;
-    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + peel);
-    for (int i = tid; i < nv4; i += 256) {
-        const f32x4 v = x4[i];
-        const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        if (m4 > m) { s *= __expf(m - m4); m = m4; }
-        s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
-    }
     const int tail0 = peel + nv4 * 4;
-    if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + peel);
+    if (nv4 <= 256 * LSE_UNR) {
+        f32x4 v[LSE_UNR];
+#pragma unroll
+        for (int j = 0; j < LSE_UNR; ++j) {
+            const int i = tid + 256 * j;
+            v[j] = (i < nv4) ? x4[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+        float xe = -INFINITY;  // peel / tail element of this thread
+        if (tid < peel) xe = x[tid];
+        else if (tid - peel < V - tail0 && tid >= peel) xe = x[tail0 + tid - peel];
+        m = xe;
+#pragma unroll
+        for (int j = 0; j < LSE_UNR; ++j) m = fmaxf(m, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+        const float ms = (m == -INFINITY) ? 0.f : m;
+        s = __expf(xe - ms);
+#pragma unroll
+        for (int j = 0; j < LSE_UNR; ++j)
+            s += (__expf(v[j][0] - ms) + __expf(v[j][1] - ms)) + (__expf(v[j][2] - ms) + __expf(v[j][3] - ms));
+    } else {
+        if (tid < peel) { m = x[tid]; s = 1.f; }
+        for (int i = tid; i < nv4; i += 256) {
+            const f32x4 v = x4[i];
+            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            if (m4 > m) { s *= __expf(m - m4); m = m4; }
+            s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
+        }
+        if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
+    }
     // wave then block combine
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -74,104 +106,184 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
     }
     __syncthreads();
     const float lse = lse_sh;
-    const int Sfull = 2 * Umax + 1, Sb = 2 * tgt_len[b] + 1;
-    for (int sidx = tid; sidx < Sfull; sidx += 256) {
+    const int Sp = ctc_row_stride(Umax), Sb = 2 * tgt_len[b] + 1;
+    for (int sidx = tid; sidx < Sp; sidx += 256) {
         float v = -INFINITY;
         if (sidx < Sb) {
             const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
-            v = x[lab] - lse;
+            v = (x[lab] - lse) * LOG2E;
         }
-        lp_ext[(int64_t)row * Sfull + sidx] = v;
+        lp_ext[(int64_t)row * Sp + sidx] = v;
     }
 }
 
-// alpha recursion: one workgroup per utterance, thread s owns extended state s.
-template <bool BACKWARD>
-__global__ void ctc_recursion_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
-                                     const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len, int L, int Umax,
-                                     float* __restrict__ alpha, float* __restrict__ nll) {
-    extern __shared__ float sh[];  // 2 x (NTH + 4)
-    const int b = blockIdx.x, s = threadIdx.x, NTH = blockDim.x;
-    const int Sfull = 2 * Umax + 1;
-    const int U = tgt_len[b], Sb = 2 * U + 1;
+__device__ __forceinline__ float l2se2(float a, float b) {
+    const float m = fmaxf(a, b);
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    return ms + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - ms) + __builtin_amdgcn_exp2f(b - ms));
+}
+__device__ __forceinline__ float l2se3(float a, float b, float c) {
+    const float m = fmaxf(fmaxf(a, b), c);
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    return ms + __builtin_amdgcn_logf((__builtin_amdgcn_exp2f(a - ms) + __builtin_amdgcn_exp2f(b - ms)) + __builtin_amdgcn_exp2f(c - ms));
+}
+// occupancy of a state = alpha * beta / y / p(l|x) (beta includes y_t like aten's); dead states (lp = -inf) give 0
+__device__ __forceinline__ float occupancy(float a2, float b2, float lp2, float nll2) {
+    return (lp2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(a2 + b2 - lp2 + nll2);
+}
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {  // lane i <- lane i-1 ; lane 0 <- -inf
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0xff800000, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_next_lane(float v) {  // lane i <- lane i+1 ; lane 63 <- -inf
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0xff800000, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// alpha (forward) / beta+occupancy (backward) recursion: one wavefront per utterance, lane i owns state pairs
+// j = i*NP + p (p < NP): e = state 2j (blank), o = state 2j+1 (label j).  All values are base-2 logs.
+template <int NP, bool BACKWARD>
+__global__ __launch_bounds__(64) void ctc_recursion_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
+                                                           const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
+                                                           int L, int Umax, float* __restrict__ alpha, float* __restrict__ nll) {
+    constexpr int PF = NP <= 2 ? 8 : (NP == 4 ? 4 : 2);  // time steps prefetched per group (register budget)
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int Sp = ctc_row_stride(Umax);
+    const int U = tgt_len[b];
     const int Tb = min(in_len[b], L);
-    const bool live = s < Sb;
-    float* buf0 = sh + 2;             // index -2..NTH+1 valid
-    float* buf1 = sh + (NTH + 4) + 2;
-    if (s < 2) { buf0[-2 + s] = -INFINITY; buf1[-2 + s] = -INFINITY; buf0[NTH + s] = -INFINITY; buf1[NTH + s] = -INFINITY; }
-
-    // skip transitions: forward uses s-2 -> s (ext[s] != blank, ext[s] != ext[s-2]); backward uses s -> s+2.
-    bool skip = false;
-    if (live && (s & 1)) {
-        const int64_t* tg = targets + (int64_t)b * Umax;
-        if (!BACKWARD) skip = (s >= 3) && (tg[s >> 1] != tg[(s >> 1) - 1]);
-        else skip = (s + 2 < Sb) && (tg[s >> 1] != tg[(s >> 1) + 1]);
-    }
-    const float* lp = lp_ext + (int64_t)b * L * Sfull + (live ? s : 0);
-    float* al = alpha + (int64_t)b * L * Sfull + (live ? s : 0);
-
     if (Tb <= 0) {
-        if (!BACKWARD && s == 0) nll[b] = (Sb == 1) ? 0.f : INFINITY;
+        if (!BACKWARD && lane == 0) nll[b] = (U == 0) ? 0.f : INFINITY;
         return;
     }
-    const float my_nll = BACKWARD ? nll[b] : 0.f;
-    float a;
-    if (!BACKWARD) {
-        a = (live && s < 2) ? lp[0] : -INFINITY;
-        if (live) al[0] = a;
-    } else {
-        const float l0 = live ? lp[(int64_t)(Tb - 1) * Sfull] : -INFINITY;
-        a = (live && s >= Sb - 2) ? l0 : -INFINITY;
-        if (live) {
-            float* ap = al + (int64_t)(Tb - 1) * Sfull;
-            *ap = __expf(*ap + a - l0 + my_nll);  // occupancy = exp(alpha + beta - lp + nll)
-        }
-    }
-    buf0[s] = a;
-    __syncthreads();
-    float* cur = buf0;
-    float* nxt = buf1;
-
-    // register prefetch of the compact table, 4 time steps per group
-    float pf[4], pa[4];
-    auto fetch = [&](int step0) {
+    const int j0 = lane * NP;
+    bool skip[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int st = step0 + i;  // step index 1..Tb-1
-            const bool ok = live && st < Tb;
-            const int t = BACKWARD ? (Tb - 1 - st) : st;
-            pf[i] = ok ? lp[(int64_t)t * Sfull] : -INFINITY;
-            if (BACKWARD) pa[i] = ok ? al[(int64_t)t * Sfull] : 0.f;
+    for (int p = 0; p < NP; ++p) {
+        const int j = j0 + p;
+        const int64_t* tg = targets + (int64_t)b * Umax;
+        if (!BACKWARD) skip[p] = (j >= 1 && j < U) && (tg[j] != tg[j - 1]);       // s-2 -> s, s = 2j+1
+        else skip[p] = (j + 1 < U) && (tg[j] != tg[j + 1]);                         // s -> s+2
+    }
+    // this lane's slice of a table row: 2*NP floats at column 2*j0 (clamped so dead lanes stay in bounds)
+    const bool inb = (2 * j0 + 2 * NP <= Sp);
+    const int col = inb ? 2 * j0 : 0;
+    const float* lp = lp_ext + (int64_t)b * L * Sp + col;
+    float* al = alpha + (int64_t)b * L * Sp + col;
+    const float nll2 = BACKWARD ? nll[b] * LOG2E : 0.f;
+
+    auto load_row = [&](const float* base, int t, float (&dst)[2 * NP], float fill) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (inb) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(base + (int64_t)t * Sp + 2 * q);
+                dst[2 * q] = v[0];
+                dst[2 * q + 1] = v[1];
+            } else {
+                dst[2 * q] = fill;
+                dst[2 * q + 1] = fill;
+            }
         }
     };
-    fetch(1);
-    for (int st0 = 1; st0 < Tb; st0 += 4) {
-        float cf[4], ca[4];
+
+    float e[NP], o[NP];
+    {
+        const int t = BACKWARD ? Tb - 1 : 0;
+        float r[2 * NP];
+        load_row(lp, t, r, -INFINITY);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { cf[i] = pf[i]; ca[i] = pa[i]; }
-        if (st0 + 4 < Tb) fetch(st0 + 4);
+        for (int p = 0; p < NP; ++p) {
+            const int j = j0 + p;
+            if (!BACKWARD) {
+                e[p] = (j == 0) ? r[2 * p] : -INFINITY;
+                o[p] = (j == 0) ? r[2 * p + 1] : -INFINITY;     // -inf already when U == 0 (dead state)
+            } else {
+                e[p] = (j == U) ? r[2 * p] : -INFINITY;
+                o[p] = (j == U - 1) ? r[2 * p + 1] : -INFINITY;
+            }
+        }
+        if (inb) {
+            if (!BACKWARD) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int st = st0 + i;
-            if (st < Tb) {  // uniform across the workgroup
-                const float a0 = cur[s];
-                const float a1 = BACKWARD ? cur[s + 1] : cur[s - 1];
-                const float a2 = skip ? (BACKWARD ? cur[s + 2] : cur[s - 2]) : -INFINITY;
-                float v = live ? lse3(a0, a1, a2) + cf[i] : -INFINITY;
-                nxt[s] = v;
-                if (live) {
-                    const int t = BACKWARD ? (Tb - 1 - st) : st;
-                    if (!BACKWARD) al[(int64_t)t * Sfull] = v;
-                    else al[(int64_t)t * Sfull] = __expf(ca[i] + v - cf[i] + my_nll);
-                }
-                __syncthreads();
-                float* tmp = cur; cur = nxt; nxt = tmp;
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) = f32x2{e[p], o[p]};
+            } else {
+                float a[2 * NP];
+                load_row(al, t, a, -INFINITY);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) =
+                        f32x2{occupancy(a[2 * p], e[p], r[2 * p], nll2), occupancy(a[2 * p + 1], o[p], r[2 * p + 1], nll2)};
             }
         }
     }
-    if (!BACKWARD && s == 0) {
-        const float ll = (Sb > 1) ? lse2(cur[Sb - 1], cur[Sb - 2]) : cur[0];
-        nll[b] = -ll;
+
+    float pf[PF][2 * NP], pa[PF][2 * NP];
+    auto fetch = [&](int step0) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int st = min(step0 + i, Tb - 1);  // clamp: extra rows are loaded but never consumed
+            const int t = BACKWARD ? (Tb - 1 - st) : st;
+            load_row(lp, t, pf[i], -INFINITY);
+            if (BACKWARD) load_row(al, t, pa[i], -INFINITY);
+        }
+    };
+    fetch(1);
+    for (int st0 = 1; st0 < Tb; st0 += PF) {
+        float cf[PF][2 * NP], ca[PF][2 * NP];
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+#pragma unroll
+            for (int q = 0; q < 2 * NP; ++q) { cf[i][q] = pf[i][q]; ca[i][q] = BACKWARD ? pa[i][q] : 0.f; }
+        if (st0 + PF < Tb) fetch(st0 + PF);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int st = st0 + i;
+            if (st < Tb) {  // wave-uniform
+                const int t = BACKWARD ? (Tb - 1 - st) : st;
+                float en[NP], on[NP];
+                if (!BACKWARD) {
+                    const float left = dpp_from_prev_lane(o[NP - 1]);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const float ol = (p == 0) ? left : o[p - 1];
+                        en[p] = l2se2(e[p], ol) + cf[i][2 * p];
+                        on[p] = l2se3(o[p], e[p], skip[p] ? ol : -INFINITY) + cf[i][2 * p + 1];
+                    }
+                } else {
+                    const float re = dpp_from_next_lane(e[0]);
+                    const float ro = dpp_from_next_lane(o[0]);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const float er = (p == NP - 1) ? re : e[p + 1];
+                        const float orr = (p == NP - 1) ? ro : o[p + 1];
+                        en[p] = l2se2(e[p], o[p]) + cf[i][2 * p];
+                        on[p] = l2se3(o[p], er, skip[p] ? orr : -INFINITY) + cf[i][2 * p + 1];
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { e[p] = en[p]; o[p] = on[p]; }
+                if (inb) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        if (!BACKWARD)
+                            *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) = f32x2{e[p], o[p]};
+                        else
+                            *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) =
+                                f32x2{occupancy(ca[i][2 * p], e[p], cf[i][2 * p], nll2),
+                                      occupancy(ca[i][2 * p + 1], o[p], cf[i][2 * p + 1], nll2)};
+                    }
+                }
+            }
+        }
+    }
+    if (!BACKWARD) {
+        // log-likelihood = lse(alpha_{T-1}(2U), alpha_{T-1}(2U-1)): e of pair U, o of pair U-1
+        float eU = -INFINITY, oU1 = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (j0 + p == U) eU = e[p];
+            if (j0 + p == U - 1) oU1 = o[p];
+        }
+        eU = wave_max(eU);      // exactly one lane holds a non -inf candidate slot
+        oU1 = wave_max(oU1);
+        if (lane == 0) nll[b] = -l2se2(eU, oU1) * LN2;
     }
 }
 
@@ -190,7 +302,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        float* __restrict__ grad, int64_t ldg) {
     extern __shared__ float corr[];  // V floats
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int Sfull = 2 * Umax + 1, Sb = 2 * tgt_len[b] + 1;
+    const int Sfull = ctc_row_stride(Umax), Sb = 2 * tgt_len[b] + 1;
     const int Tb = min(in_len[b], L);
     const float scale = gout[0] / ((float)B * (float)max(tgt_len[b], 1));
     for (int i = tid; i < V; i += 256) corr[i] = 0.f;
@@ -245,26 +357,37 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
 }
 
-int recursion_threads(int Umax) {
-    const int S = 2 * Umax + 1;
-    return ((S + 63) / 64) * 64;
+template <bool BACKWARD>
+int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, const int64_t* targets, const int32_t* tgt_len, int B,
+                     int L, int Umax, float* alpha, float* nll) {
+    // U <= 64*NP - 1 state pairs + the final blank must fit: pairs 0..U  ->  U + 1 <= 64 * NP
+    if (Umax + 1 <= 64)
+        hipLaunchKernelGGL((ctc_recursion_kernel<1, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
+    else if (Umax + 1 <= 128)
+        hipLaunchKernelGGL((ctc_recursion_kernel<2, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
+    else if (Umax + 1 <= 256)
+        hipLaunchKernelGGL((ctc_recursion_kernel<4, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
+    else
+        hipLaunchKernelGGL((ctc_recursion_kernel<8, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
+    return 0;
 }
 
 }  // namespace
+
+extern "C" int asr_ctc_workspace_stride(int Umax) { return ctc_row_stride(Umax); }
 
 extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                 int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
                                 int32_t* tgt_len) {
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len, ASR_ERR_ARG, "ctc_fwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && blank >= 0 && blank < V && ldl >= V, ASR_ERR_ARG, "ctc_fwd: bad sizes");
-    const int nth = recursion_threads(Umax);
-    ASR_REQUIRE(nth <= 1024, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (2U+1 must be <= 1024)", Umax);
+    ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (U+1 must be <= 512)", Umax);
+    ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd: workspaces must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(ctc_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, targets, B, Umax, tgt_len);
     hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, tgt_len, L, V, Umax, blank,
                        lse, lp_ext);
-    hipLaunchKernelGGL(ctc_recursion_kernel<false>, dim3(B), dim3(nth), 2 * (nth + 4) * sizeof(float), s, lp_ext, in_len, targets,
-                       tgt_len, L, Umax, alpha, nll);
+    launch_recursion<false>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll);
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
 }
@@ -283,11 +406,9 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
                 "ctc_bwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && ldl >= V && ldg >= V, ASR_ERR_ARG, "ctc_bwd: bad sizes");
     ASR_REQUIRE((size_t)V * sizeof(float) <= 64 * 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: V=%d exceeds the LDS occupancy vector", V);
-    const int nth = recursion_threads(Umax);
-    ASR_REQUIRE(nth <= 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: Umax too long");
+    ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_bwd: Umax too long");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(ctc_recursion_kernel<true>, dim3(B), dim3(nth), 2 * (nth + 4) * sizeof(float), s, lp_ext, in_len, targets,
-                       tgt_len, L, Umax, alpha, const_cast<float*>(nll));
+    launch_recursion<true>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, const_cast<float*>(nll));
     int rb = (2048 + B - 1) / B;  // ~2048 workgroups in flight
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;

@@ -218,7 +218,7 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None):
     st.blank = V - 1 if blank is None else blank
     st.in_len = as_i32(in_len)
     st.targets = targets.to(torch.int64).contiguous()
-    S = 2 * Umax + 1
+    S = lib().asr_ctc_workspace_stride(Umax)   # opaque workspace row stride (asr_hip.h)
     dev = logits.device
     st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
     st.lp_ext = torch.empty((B, L, S), device=dev, dtype=torch.float32)

@@ -96,9 +96,11 @@ int asr_conv_sub1_fwd(void* stream, const void* x, const float* w, const float* 
  * CTC loss (loss.py:41-43 / ctcModel/loss.py:9-11: F.log_softmax(dim=-1) -> F.ctc_loss(blank=V-1)).
  * logits f32 [B,L,V] with row stride ldl (elements) and batch stride L*ldl; in_len int32 [B]; targets int64
  * [B,Umax] zero-padded; target length = number of non-zero ids per row (loss.py:40).
- * Workspaces (caller-owned): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L,S]; S = 2*Umax+1.
+ * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L,S] with
+ * S = asr_ctc_workspace_stride(Umax) (the 2*Umax+1 extended states rounded up to 16 floats).
  * Outputs: nll f32 [B] (inf for infeasible rows, zero_infinity=False), tgt_len int32 [B].
  */
+int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
                      int32_t* tgt_len);

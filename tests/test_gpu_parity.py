@@ -229,14 +229,16 @@ def test_ctc_infeasible_is_inf(golden_dir):
     assert np.isinf(float(loss))
 
 
-@pytest.mark.parametrize("B,L,U,V,repeat", [(4, 250, 51, 4234, False), (3, 120, 20, 301, True), (2, 64, 1, 7, False)])
+@pytest.mark.parametrize("B,L,U,V,repeat", [(4, 250, 51, 4234, False), (3, 120, 20, 301, True), (2, 64, 1, 7, False),
+                                             (2, 260, 63, 40, True), (2, 300, 64, 40, False), (2, 420, 100, 33, True),
+                                             (2, 700, 200, 29, False), (1, 900, 300, 21, True)])
 def test_ctc_vs_torch_cpu(B, L, U, V, repeat):
     g = torch.Generator().manual_seed(L)
     logits = torch.randn(B, L, V, generator=g)
     tg = torch.randint(1, V - 1, (B, U), generator=g)
     if repeat:
         tg[:, 1::2] = tg[:, 0::2][:, :tg[:, 1::2].shape[1]]
-    if U > 2:
+    if U > 2 and B > 1:
         tg[1, U // 2:] = 0
     in_len = torch.full((B,), L, dtype=torch.int64)
     in_len[-1] = max(L // 2, 2 * U + 1)
@@ -251,7 +253,9 @@ def test_ctc_vs_torch_cpu(B, L, U, V, repeat):
     loss.backward()
     np.testing.assert_allclose(N(nll), ref_nll.detach().numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
-    np.testing.assert_allclose(N(ld.grad), lg.grad.numpy(), atol=1e-5, rtol=1e-4)
+    # occupancies are exp(alpha + beta - ...) of fp32 log-domain sums of magnitude |alpha| ~ 8*T: both this kernel and
+    # aten's accumulate ~sqrt(T) * ulp(|alpha|) ~ 1e-3 relative error there, so gradients carry rtol 2e-3 (+ 1e-5 abs)
+    np.testing.assert_allclose(N(ld.grad), lg.grad.numpy(), atol=1e-5, rtol=2e-3)
     # frames past in_len carry exactly zero gradient
     assert float(ld.grad[-1, int(in_len[-1]):].abs().max()) == 0.0
 

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Op-level microbenchmarks at the north-star shapes (one JSON line per op).  HIP-event timing on the launch stream.
+Usage: python tools/bench_ops.py [ctc] [cif] [attn] [gemm] [ln]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import asr_amd  # noqa: E402
+from asr_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def bench_ctc():
+    B, L, U, V = 32, 1000, 50, 4234
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(B, L, V, generator=g).to(DEV)
+    tg = torch.randint(1, V - 1, (B, U), generator=g).to(DEV)
+    il = torch.full((B,), L, dtype=torch.int32).to(DEV)
+    gout = torch.ones(1, device=DEV)
+    fwd = timeit(lambda: ops.ctc_loss_fwd(logits, il, tg))
+    def fb():
+        loss, nll, st = ops.ctc_loss_fwd(logits, il, tg)
+        ops.ctc_loss_bwd(st, gout)
+    both = timeit(fb)
+    nb = B * L * V * 4
+    print(json.dumps(dict(op="ctc_loss", shape=[B, L, U, V], fwd_ms=round(fwd, 4), fwd_bwd_ms=round(both, 4),
+                          fwd_GBps=round(nb / fwd / 1e6, 1), fwd_bwd_GBps=round(3 * nb / both / 1e6, 1),
+                          fwd_frac_hbm_peak=round(nb / fwd / 1e6 / 8000, 4), fwd_bwd_frac_hbm_peak=round(3 * nb / both / 1e6 / 8000, 4))))
+
+
+def bench_cif():
+    B, L, H = 32, 1000, 256
+    g = torch.Generator().manual_seed(0)
+    a = torch.sigmoid(torch.randn(B, L, generator=g))
+    U = torch.randint(20, 51, (B,), generator=g).float()
+    a = (a * ((U + torch.rand(B, generator=g) - 0.5) / a.sum(-1))[:, None]).to(DEV)
+    hid = torch.randn(B, L, H, generator=g).to(DEV)
+    t_scan = timeit(lambda: ops.cif_scan(a, 0.95))
+    cur, rem, fi, nf, nl = ops.cif_scan(a, 0.95)
+    t_g = timeit(lambda: ops.cif_gather(hid, cur, rem, fi, nf, 50))
+    nb = B * L * H * 4 + B * L * 4 + B * 50 * H * 4
+    print(json.dumps(dict(op="cif", shape=[B, L, H], scan_us=round(t_scan * 1e3, 2), gather_us=round(t_g * 1e3, 2),
+                          GBps=round(nb / (t_scan + t_g) / 1e6, 1), frac_hbm_peak=round(nb / (t_scan + t_g) / 1e6 / 8000, 4))))
+
+
+def bench_attn():
+    for (B, h, Lq, Lk, causal) in [(32, 4, 1000, 1000, False), (32, 4, 250, 250, False), (32, 4, 51, 1000, False), (32, 4, 51, 51, True)]:
+        q = (torch.randn(B, h, Lq, 64, device=DEV) * 0.5).bfloat16()
+        k = torch.randn(B, h, Lk, 64, device=DEV).bfloat16()
+        v = torch.randn(B, h, Lk, 64, device=DEV).bfloat16()
+        t = timeit(lambda: ops.attention_fwd(q, k, v, None, causal))
+        fl = 4.0 * B * h * 64 * Lq * Lk
+        print(json.dumps(dict(op="attention_fwd", shape=[B, h, Lq, Lk], causal=causal, us=round(t * 1e3, 2),
+                              TFLOPs=round(fl / t / 1e9, 1), frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+
+
+def bench_gemm():
+    for (M, N, K, relu, odt) in [(32000, 2048, 256, True, torch.bfloat16), (32000, 256, 2048, False, torch.float32),
+                                 (32000, 256, 256, False, torch.float32), (32000, 4234, 256, False, torch.float32),
+                                 (8192, 8192, 8192, False, torch.bfloat16)]:
+        a = torch.randn(M, K, device=DEV).bfloat16()
+        w = (torch.randn(N, K, device=DEV) / K ** 0.5).bfloat16()
+        b = torch.randn(N, device=DEV)
+        t = timeit(lambda: ops.gemm_nt(a, w, b, out_dtype=odt, relu=relu))
+        fl = 2.0 * M * N * K
+        print(json.dumps(dict(op="gemm_nt", shape=[M, N, K], us=round(t * 1e3, 2), TFLOPs=round(fl / t / 1e9, 1),
+                              frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+
+
+def bench_ln():
+    B, L, D = 32, 1000, 256
+    x = torch.randn(B * L, D, device=DEV)
+    r = torch.randn(B * L, D, device=DEV)
+    g_, b_ = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    t = timeit(lambda: ops.add_layernorm(x, r, g_, b_, B, L, want_bf16=True))
+    nb = B * L * D * 14
+    print(json.dumps(dict(op="add_layernorm", shape=[B * L, D], us=round(t * 1e3, 2), GBps=round(nb / t / 1e6, 1))))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ctc", "cif", "attn", "gemm", "ln"]
+    for w in which:
+        globals()["bench_" + w]()
