@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd"],
+                    help="train: forward+loss+backward+grad all-reduce+Adam (default); fwd: forward+loss only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,11 +91,15 @@ def main():
     model = build_model(asr_amd, dev)
     x, lens, tg = make_batch(dev, seed=rank)
 
+    trainer = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1) if args.mode == "train" else None
+
     def step():
+        if trainer is not None:
+            return trainer.step(x, lens, tg)
         with torch.no_grad():
             l, ctc_logits, (logits, teos) = model(x, lens, tg)
             ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, 0.1)
-        return ctc, ce, ctc_logits, logits
+        return ctc, ce
 
     def barrier():
         if world > 1:
@@ -129,6 +135,8 @@ def main():
         for name, r in prof.items():
             per_ms = r["ms"] / r["calls"]
             hbm = name.startswith(("add_layernorm", "ctc_loss"))
+            if name.startswith("attention_bwd"):
+                r["work"] = r["work"] * 10.0 / 14.0   # roofline on the 5-product (non-recompute) FLOP count, SURVEY.md §8d
             ach = (r["work"] / r["calls"]) / (per_ms * 1e-3) / (1e9 if hbm else 1e12)
             kernels.append(dict(name=name, calls_per_step=r["calls"] / args.steps, ms_per_call=round(per_ms, 4),
                                 ms_per_step=round(r["ms"] / args.steps, 3), bound="hbm" if hbm else "mfma",
@@ -141,23 +149,30 @@ def main():
                         note="achieved = algorithmic FLOPs (or bytes) per launch / mean launch duration from HIP events "
                              "on the launch stream; PMC traffic is collected by separate rocprofv3 --pmc passes (profiles/)")
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
+        ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
+        what = ("training step: forward + joint CTC/CE loss + backward + grad all-reduce + Adam" if args.mode == "train"
+                else "forward + joint CTC/CE loss")
         result = {
-            "metric": "fbank frames/sec (CTC_Transformer d256 h4 enc12/dec6 forward + joint CTC/CE loss)",
+            "metric": "fbank frames/sec (CTC_Transformer d256 h4 enc12/dec6, %s)" % what,
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "S1: CTC_Transformer d_model=256 h=4 d_inner=2048 enc12/dec6 V=4234, per-GPU B=32 x T=1000 x 80 "
-                                   "fbank, U=50, forward+loss (no backward yet)", "global_batch": world * CFG["B"],
+                                   "fbank, U=50, " + what, "global_batch": world * CFG["B"],
                        "seq_len": CFG["T"], "parallelism": "dp%d" % world},
             "roofline": roofline,
-            "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "achieved_GBps": ctc_k[0]["achieved"],
-                     "frac_of_hbm_peak": round(ctc_k[0]["achieved"] / PEAK_HBM_GBS, 4)} if ctc_k else None),
+            "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "fwd_GBps": ctc_k[0]["achieved"],
+                     "fwd_frac_of_hbm_peak": round(ctc_k[0]["achieved"] / PEAK_HBM_GBS, 4),
+                     "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
+                     "fwd_bwd_GBps": (round(3 * 4.0 * CFG["B"] * CFG["T"] * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
+                                      if ctc_b else None)} if ctc_k else None),
             "kernels": kernels[:12],
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, ref_ctc, ref_ce, ref_ctc_logits, ref_logits = cpu_baseline(model, x, lens, tg, n_utt=1)
             result["cpu_baseline"] = cb
             # sanity: the GPU result on the same utterance agrees with the oracle (bf16 tolerance); not timed
+            # (in train mode the weights have moved since `cb` copied them: cpu_baseline() reads the current weights)
             with torch.no_grad():
                 l1, cl1, (lg1, te1) = model(x[:1], lens[:1], tg[:1])
             import numpy as np

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libasr_hip.so")
-SOURCES = ["common.hip", "gemm.hip", "attention.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
+SOURCES = ["common.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
            "backward.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
@@ -21,9 +21,17 @@ _vp, _i, _i64, _f, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 # every prototype in the header is exported by the .so and listed here.
 SIGNATURES = {
     "asr_gemm_nt": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u],
+    "asr_gemm_nt_ex": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _i64, _vp, _i64],
+    "asr_gemm_nn": [_vp, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp, _i64],
+    "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
+    "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i],
+    "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
+    "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "asr_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f],
     "asr_proj_heads": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f],
     "asr_attention_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i],
-    "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f],
+    "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f],
     "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_conv_sub0_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asr_conv_sub1_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],

@@ -1,0 +1,302 @@
+// Flash-attention backward for gfx950 (bf16 MFMA, fp32 accumulate): gradients of attention.py:76-84 without ever
+// materialising the [Lq, Lk] probabilities.  P is recomputed from Q, K and the forward's row log-sum-exp.
+//
+//   kernel A (dQ):   one workgroup = NW waves x 32 queries, query on the LANE (exactly the forward's geometry):
+//       S^T = K.Q^T,  dP^T = V.dO^T  (A = K / V tile rows from LDS, B = Q / dO rows in registers),
+//       dS^T = P^T o (dP^T - delta[q])   (lse, delta are per-lane scalars),
+//       dQ^T += K^T . dS^T               (A = transposed K tile from LDS, B = dS^T straight from the accumulators).
+//       Also emits delta[q] = rowsum(dO o O) for kernel B.
+//   kernel B (dK,dV): one workgroup = 4 waves x 32 keys, key on the LANE, looping over 64-query tiles:
+//       S = Q.K^T, dP = dO.V^T (A = Q / dO tile rows from LDS, B = K / V rows in registers),
+//       dV^T += dO^T . P,  dK^T += Q^T . dS   (A = transposed dO / Q tiles from LDS, B = P / dS from the accumulators).
+//   Neither kernel needs a cross-workgroup reduction (7 matmuls instead of 5, no float atomics: the dQ atomic
+//   traffic of the single-kernel form would cost more than the two recomputed products at L = 1000, d = 64).
+// Gradients are written token-major ([B*L, ld] with head h at columns h*64..) so they are directly the A operand of
+// the projection GEMMs' backward; dQ carries the 1/sqrt(d_k) that the forward folded into Q.
+#include "asr_common.h"
+
+namespace {
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
+
+// stage a [64 rows][64 bf16] tile row-major (16-byte chunks, swizzled).  src row r at src + r*ld (elements).
+template <int NTHR>
+__device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < 512 / NTHR; ++i) {
+        const int id = tid + NTHR * i;
+        const int row = id >> 3, c = id & 7;
+        const u32x4 v = (row0 + row < nrows) ? *reinterpret_cast<const u32x4*>(src + (int64_t)(row0 + row) * ld + c * 8) : u32x4{0, 0, 0, 0};
+        *reinterpret_cast<u32x4*>(dst + row * 128 + swz(row, c)) = v;
+    }
+}
+// stage the TRANSPOSE of a [64 rows][64 cols] tile: dst[col][row] (8-byte pieces of 4 rows, swizzled like the fwd V^T)
+template <int NTHR>
+__device__ __forceinline__ void stage_transposed(unsigned char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int i = 0; i < 256 / NTHR; ++i) {
+        const int id = tid + NTHR * i;
+        const int cg = id & 15, rg = id >> 4;  // 4-col group, 4-row group
+        u32x2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = row0 + 4 * rg + k;
+            v[k] = (r < nrows) ? *reinterpret_cast<const u32x2*>(src + (int64_t)r * ld + 4 * cg) : u32x2{0, 0};
+        }
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int w = dd >> 1, sh = (dd & 1) * 16;
+            const unsigned e0 = (v[0][w] >> sh) & 0xffffu, e1 = (v[1][w] >> sh) & 0xffffu;
+            const unsigned e2 = (v[2][w] >> sh) & 0xffffu, e3 = (v[3][w] >> sh) & 0xffffu;
+            const int row = 4 * cg + dd;
+            const int off = row * 128 + swz(row, rg >> 1) + (((rg & 1) ^ ((row >> 4) & 1)) << 3);
+            *reinterpret_cast<u32x2*>(dst + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+        }
+    }
+}
+// A-operand fragment (32 rows x 16 k) of a row-major tile: lane (r, hh) reads chunk 2s+hh of row `row`
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* t, int row, int s, int hh) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(t + row * 128 + swz(row, 2 * s + hh)));
+}
+// A-operand fragment of a transposed tile for the "accumulator as B operand" k-order: k-block hf (32), step s2
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* t, int row, int hf, int s2, int hh) {
+    const int sub = (hh ^ ((row >> 4) & 1)) << 3;
+    const u32x2 v0 = *reinterpret_cast<const u32x2*>(t + row * 128 + swz(row, hf * 4 + 2 * s2) + sub);
+    const u32x2 v1 = *reinterpret_cast<const u32x2*>(t + row * 128 + swz(row, hf * 4 + 2 * s2 + 1) + sub);
+    return __builtin_bit_cast(bf16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s2 + j];
+    return r;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// store a [64 d][32 x] accumulator pair (x on the lane) as token-major bf16 rows: 4 consecutive d per 8-byte store
+__device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16& a0, const f32x16& a1, int hh, float scale) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * hh;
+        bf16x4 x = {(bf16_t)(a0[4 * g] * scale), (bf16_t)(a0[4 * g + 1] * scale), (bf16_t)(a0[4 * g + 2] * scale), (bf16_t)(a0[4 * g + 3] * scale)};
+        bf16x4 y = {(bf16_t)(a1[4 * g] * scale), (bf16_t)(a1[4 * g + 1] * scale), (bf16_t)(a1[4 * g + 2] * scale), (bf16_t)(a1[4 * g + 3] * scale)};
+        *reinterpret_cast<bf16x4*>(rowp + d) = x;
+        *reinterpret_cast<bf16x4*>(rowp + 32 + d) = y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <int NW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
+                                                                 const bf16_t* __restrict__ dO, const float* __restrict__ lse,
+                                                                 float* __restrict__ delta, bf16_t* __restrict__ dq_out, int64_t ldq,
+                                                                 int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int q_tiles,
+                                                                 float scale) {
+    constexpr int NTHR = NW * 64, QB = NW * 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 8192];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = smem + 8192;
+    unsigned char* Kt = smem + 16384;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int qt = blockIdx.x % q_tiles, bh = blockIdx.x / q_tiles, b = bh / h, hd = bh - b * h;
+    const int q0 = qt * QB;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
+    const int ntiles = (kmax + 63) >> 6;
+    const int qrow = q0 + wave * 32 + r;
+    const int wave_qlast = q0 + wave * 32 + 31;
+    const bool qok = qrow < Lq;
+    const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
+    const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
+    const int64_t tok = ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;  // token-major row of this lane's query
+
+    bf16x8 qf[4], dof[4];
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 16 * s + 8 * hh;
+        const u32x4 z = {0, 0, 0, 0};
+        qf[s] = __builtin_bit_cast(bf16x8, qok ? *reinterpret_cast<const u32x4*>(Q + ((int64_t)bh * Lq + qrow) * 64 + c) : z);
+        dof[s] = __builtin_bit_cast(bf16x8, qok ? *reinterpret_cast<const u32x4*>(dO + tok + c) : z);
+        const bf16x8 of = __builtin_bit_cast(bf16x8, qok ? *reinterpret_cast<const u32x4*>(O + tok + c) : z);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[j];
+    }
+    dl += __shfl_xor(dl, 32, 64);
+    const float my_lse = qok ? lse[(int64_t)bh * Lq + qrow] : 0.f;
+    if (qok && hh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
+
+    f32x16 a0 = zero16(), a1 = zero16();
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * 64;
+        __syncthreads();
+        stage_rows<NTHR>(Ks, Kb, 64, key0, kl, tid);
+        stage_rows<NTHR>(Vs, Vb, 64, key0, kl, tid);
+        stage_transposed<NTHR>(Kt, Kb, 64, key0, kl, tid);
+        __syncthreads();
+        if (CAUSAL && key0 > wave_qlast) continue;
+        f32x16 st[2], dp[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            st[hf] = zero16();
+            dp[hf] = zero16();
+            const int row = hf * 32 + r;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
+                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const bool bad = key >= kl || (CAUSAL && key > qrow) || !qok;
+                const float p = bad ? 0.f : __expf(st[hf][i] - my_lse);
+                st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
+            }
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(st[hf], s2);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, r, hf, s2, hh), pf, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, 32 + r, hf, s2, hh), pf, a1, 0, 0, 0);
+            }
+    }
+    if (qok) store_T(dq_out + ((int64_t)b * Lq + qrow) * ldq + hd * 64, a0, a1, hh, scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dv_out, int64_t ldkv,
+                                                              int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int k_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 + 512];
+    unsigned char* Qs = smem;
+    unsigned char* dOs = smem + 8192;
+    unsigned char* Qt = smem + 16384;
+    unsigned char* dOt = smem + 24576;
+    float* lse_s = reinterpret_cast<float*>(smem + 32768);
+    float* del_s = lse_s + 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int kt = blockIdx.x % k_tiles, bh = blockIdx.x / k_tiles, b = bh / h, hd = bh - b * h;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int key = kt * 128 + wave * 32 + r;
+    const bool kok = key < kl;
+    const bf16_t* Qb = Q + (int64_t)bh * Lq * 64;
+    const bf16_t* dOb = dO + (int64_t)b * Lq * (h * 64) + hd * 64;   // token-major rows, ld = h*64
+    const int64_t ldo = (int64_t)h * 64;
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 16 * s + 8 * hh;
+        const u32x4 z = {0, 0, 0, 0};
+        kf[s] = __builtin_bit_cast(bf16x8, kok ? *reinterpret_cast<const u32x4*>(K + ((int64_t)bh * Lk + key) * 64 + c) : z);
+        vf[s] = __builtin_bit_cast(bf16x8, kok ? *reinterpret_cast<const u32x4*>(V + ((int64_t)bh * Lk + key) * 64 + c) : z);
+    }
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    const int qt_first = CAUSAL ? (kt * 128) / 64 : 0;   // queries before the first key of this block see none of it
+    const int nqt = (Lq + 63) >> 6;
+    const int wave_kfirst = kt * 128 + wave * 32;
+    for (int t = qt_first; t < nqt; ++t) {
+        const int q0 = t * 64;
+        __syncthreads();
+        stage_rows<256>(Qs, Qb, 64, q0, Lq, tid);
+        stage_rows<256>(dOs, dOb, ldo, q0, Lq, tid);
+        stage_transposed<256>(Qt, Qb, 64, q0, Lq, tid);
+        stage_transposed<256>(dOt, dOb, ldo, q0, Lq, tid);
+        if (tid < 64) {
+            const int q = q0 + tid;
+            lse_s[tid] = (q < Lq) ? lse[(int64_t)bh * Lq + q] : 0.f;
+            del_s[tid] = (q < Lq) ? delta[(int64_t)bh * Lq + q] : 0.f;
+        }
+        __syncthreads();
+        if (CAUSAL && q0 + 63 < wave_kfirst) continue;   // every query of the tile precedes every key of this wave
+        f32x16 sq[2], dp[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            sq[hf] = zero16();
+            dp[hf] = zero16();
+            const int row = hf * 32 + r;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sq[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, row, s, hh), kf[s], sq[hf], 0, 0, 0);
+                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, row, s, hh), vf[s], dp[hf], 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = hf * 32 + 8 * g + 4 * hh;   // 4 consecutive query rows live in regs 4g..4g+3
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ql);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = q0 + ql + i;
+                    const bool bad = !kok || q >= Lq || (CAUSAL && key > q);
+                    const float p = bad ? 0.f : __expf(sq[hf][4 * g + i] - l4[i]);
+                    sq[hf][4 * g + i] = p;                                   // P
+                    dp[hf][4 * g + i] = p * (dp[hf][4 * g + i] - d4[i]);     // dS
+                }
+            }
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(sq[hf], s2), sf = pack8(dp[hf], s2);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOt, r, hf, s2, hh), pf, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOt, 32 + r, hf, s2, hh), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, r, hf, s2, hh), sf, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 32 + r, hf, s2, hh), sf, dk1, 0, 0, 0);
+            }
+    }
+    if (key < Lk) {   // keys in [kl, Lk) get exact zeros
+        const int64_t off = ((int64_t)b * Lk + key) * ldkv + hd * 64;
+        store_T(dk_out + off, dk0, dk1, hh, 1.f);
+        store_T(dv_out + off, dv0, dv1, hh, 1.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                 const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
+                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale) {
+    ASR_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, ASR_ERR_ARG, "attention_bwd: null pointer");
+    ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd: bad sizes");
+    ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(o, 16) && asr_aligned(d_o, 16) &&
+                    asr_aligned(dq, 8) && asr_aligned(dk, 8) && asr_aligned(dv, 8) && ldq % 4 == 0 && ldkv % 4 == 0,
+                ASR_ERR_ALIGN, "attention_bwd: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *O = (const bf16_t*)o, *dO = (const bf16_t*)d_o;
+#define LAUNCH_DQ(NW)                                                                                                            \
+    do {                                                                                                                         \
+        const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);                                                                      \
+        if (causal)                                                                                                              \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, true>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse,  \
+                               delta, (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale);                                       \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, false>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, \
+                               delta, (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale);                                       \
+    } while (0)
+    if (Lq <= 32) LAUNCH_DQ(1);
+    else if (Lq <= 64) LAUNCH_DQ(2);
+    else LAUNCH_DQ(4);
+#undef LAUNCH_DQ
+    const int k_tiles = (Lk + 127) / 128;
+    if (causal)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk,
+                           (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk,
+                           (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles);
+    ASR_LAUNCH_CHECK("attention_bwd");
+    return 0;
+}

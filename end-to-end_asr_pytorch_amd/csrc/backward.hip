@@ -1,0 +1,320 @@
+// Backward-pass kernels other than attention / CTC / CE for gfx950:
+//   gemm_tn      weight gradient  dW[N,K] = sum_m dY[m,n] * X[m,k]   (both operands M-major -> transposing LDS staging)
+//   colsum       bias gradient    db[n]   = sum_m dY[m,n]
+//   layernorm_bwd  d(x+res) of the fused residual + LayerNorm (+mask) kernel, with dgamma / dbeta
+//   embed_bwd    scatter-add of row gradients into the embedding table
+//   adam_step    fused Adam over one flat parameter buffer (train.py:166-170: betas (0.9,0.98), eps 1e-9, no decay)
+#include "asr_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// gemm_tn: C[N,K] += A^T . B over an M-range.  Output tile 128(n) x 128(k); reduction step 64 rows of m.
+// LDS images At[128 n][64 m], Bt[128 k][64 m] in the NT GEMM's swizzled row format (chunk ^ (row & 7)), filled by
+// 4x4 register transposes (8-byte ds_write), so the MFMA inner loop is the NT kernel's.  Split over M (grid.y) with
+// float atomics into the (pre-zeroed) fp32 output: weight-gradient tiles are few (N*K/16384) while M is long.
+template <typename T> __device__ __forceinline__ void load4_bf16(const T* p, bool ok, unsigned& w0, unsigned& w1);
+template <> __device__ __forceinline__ void load4_bf16<bf16_t>(const bf16_t* p, bool ok, unsigned& w0, unsigned& w1) {
+    const u32x2 v = ok ? *reinterpret_cast<const u32x2*>(p) : u32x2{0, 0};
+    w0 = v[0];
+    w1 = v[1];
+}
+template <> __device__ __forceinline__ void load4_bf16<float>(const float* p, bool ok, unsigned& w0, unsigned& w1) {
+    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0, 0, 0, 0};
+    bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    const u32x2 u = __builtin_bit_cast(u32x2, b);
+    w0 = u[0];
+    w1 = u[1];
+}
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TA* __restrict__ A, int64_t lda, const TB* __restrict__ Bm, int64_t ldb,
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K, int tiles_k,
+                                                         int m_per_split) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * 128];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 128 * 128;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int m_begin = blockIdx.y * m_per_split, m_end = min(M, m_begin + m_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // per-thread 4x4 blocks: id -> (cg = 4-column group 0..31, rg = 4-row (m) group 0..15), two ids per operand
+    unsigned ra[2][4][2], rb[2][4][2];
+    auto gload = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i;
+            const int cg = id & 31, rg = id >> 5;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int m = m0 + 4 * rg + kk;
+                load4_bf16<TA>(A + (int64_t)m * lda + n0 + 4 * cg, m < m_end && n0 + 4 * cg < N, ra[i][kk][0], ra[i][kk][1]);
+                load4_bf16<TB>(Bm + (int64_t)m * ldb + k0 + 4 * cg, m < m_end && k0 + 4 * cg < K, rb[i][kk][0], rb[i][kk][1]);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i;
+            const int cg = id & 31, rg = id >> 5;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int w = dd >> 1, sh = (dd & 1) * 16;
+                const int row = 4 * cg + dd;
+                const int off = row * 128 + (((rg >> 1) ^ (row & 7)) << 4) + ((rg & 1) << 3);
+                {
+                    const unsigned e0 = (ra[i][0][w] >> sh) & 0xffffu, e1 = (ra[i][1][w] >> sh) & 0xffffu;
+                    const unsigned e2 = (ra[i][2][w] >> sh) & 0xffffu, e3 = (ra[i][3][w] >> sh) & 0xffffu;
+                    *reinterpret_cast<u32x2*>(As + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+                }
+                {
+                    const unsigned e0 = (rb[i][0][w] >> sh) & 0xffffu, e1 = (rb[i][1][w] >> sh) & 0xffffu;
+                    const unsigned e2 = (rb[i][2][w] >> sh) & 0xffffu, e3 = (rb[i][3][w] >> sh) & 0xffffu;
+                    *reinterpret_cast<u32x2*>(Bs + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+                }
+            }
+        }
+    };
+
+    if (m_begin < m_end) gload(m_begin);
+    for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (m0 + 64 < m_end) gload(m0 + 64);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = g * 4 + q4;
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int arow = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const u32x4*>(As + arow * 128 + ((chunk ^ (arow & 7)) << 4));
+                const int brow = wn * 64 + i * 16 + r16;
+                b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * 128 + ((chunk ^ (brow & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);   // D[k_local][n_local]
+        }
+    }
+    // lane holds n = .. + r16 (one output ROW of C[N,K]) and 4 consecutive k
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wm * 64 + i * 16 + r16;
+        if (n >= N) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + wn * 64 + j * 16 + q4 * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < K) atomicAdd(C + (int64_t)n * ldc + k + e, acc[i][j][e]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, int64_t lda, int M, int N, int rows_per_block,
+                                                     float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += to_f32(A[(int64_t)m * lda + n]);
+    atomicAdd(out + n, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LN_MAXJ = 4;
+constexpr int LNB_ROWS = 32;  // rows per workgroup (8 per wave)
+
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
+                                                                float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int M, int L, int D) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 ag[LN_MAXJ], ab[LN_MAXJ];
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; }
+    const float invD = 1.f / (float)D;
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + rr * 4 + wave;
+        if (row >= M) break;
+        const int b = (int)(row / L), t = (int)(row - (int64_t)b * L);
+        const bool keep = row_len ? (t < row_len[b]) : true;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 g[LN_MAXJ], xh[LN_MAXJ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXJ; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < D) {
+                f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * D + c);
+                if (!keep) d = f32x4{0, 0, 0, 0};
+                xh[j] = (*reinterpret_cast<const f32x4*>(s + row * D + c) - mu) * rs;
+                ag[j] += d * xh[j];
+                ab[j] += d;
+                g[j] = d * *reinterpret_cast<const f32x4*>(gamma + c);
+                s1 += (g[j][0] + g[j][1]) + (g[j][2] + g[j][3]);
+                const f32x4 gx = g[j] * xh[j];
+                s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+            }
+        }
+        s1 = wave_sum(s1) * invD;
+        s2 = wave_sum(s2) * invD;
+#pragma unroll
+        for (int j = 0; j < LN_MAXJ; ++j) {
+            const int c = lane * 4 + 256 * j;
+            if (c < D) {
+                const f32x4 o = (g[j] - s1 - xh[j] * s2) * rs;
+                *reinterpret_cast<f32x4*>(ds + row * D + c) = o;
+                if (ds16) {
+                    bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(ds16) + row * D + c) = ob;
+                }
+            }
+        }
+    }
+    // workgroup reduction of the dgamma / dbeta partials, then one atomic per column
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < D) {
+            *reinterpret_cast<f32x4*>(&red[0][wave][c]) = ag[j];
+            *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab[j];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy, int M, int D,
+                                                        int V, float* __restrict__ demb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    for (int c = lane; c < D; c += 64) atomicAdd(demb + id * D + c, dy[row * D + c]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ p16, int64_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;      // torch.optim.Adam: sqrt(v)/sqrt(bias_correction2) + eps
+        const float pn = p[i] - (lr / bc1) * (mi / denom);
+        p[i] = pn;
+        if (p16) p16[i] = (bf16_t)pn;                          // bf16 MFMA shadow refreshed in the same pass
+    }
+}
+
+template <typename TA, typename TB>
+int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* Bm, int64_t ldb, float* C, int64_t ldc, int M, int N, int K) {
+    const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
+    const int tiles = tiles_n * tiles_k;
+    int splits = (768 + tiles - 1) / tiles;
+    const int max_splits = (M + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
+    splits = (M + m_per_split - 1) / m_per_split;
+    hipLaunchKernelGGL((gemm_tn_kernel<TA, TB>), dim3(tiles, splits), dim3(256), 0, s, (const TA*)A, lda, (const TB*)Bm, ldb, C, ldc, M, N,
+                       K, tiles_k, m_per_split);
+    ASR_LAUNCH_CHECK("gemm_tn");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int b_dtype, int64_t ldb, float* C,
+                           int64_t ldc, int M, int N, int K, int zero_first) {
+    ASR_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, ASR_ERR_ARG, "gemm_tn: bad args");
+    ASR_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= (N + 3) / 4 * 4 && ldb >= (K + 3) / 4 * 4, ASR_ERR_ALIGN,
+                "gemm_tn: lda/ldb must be multiples of 4 covering N/K rounded up to 4 (padded columns are read)");
+    ASR_REQUIRE(asr_aligned(A, a_dtype == ASR_F32 ? 16 : 8) && asr_aligned(Bm, b_dtype == ASR_F32 ? 16 : 8), ASR_ERR_ALIGN,
+                "gemm_tn: operand alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (zero_first) {
+        if (ldc == K) {
+            hipError_t e = hipMemsetAsync(C, 0, (size_t)N * K * sizeof(float), s);
+            if (e != hipSuccess) { asr_set_error("gemm_tn memset: %s", hipGetErrorString(e)); return (int)e; }
+        } else {
+            hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)K * sizeof(float), N, s);
+            if (e != hipSuccess) { asr_set_error("gemm_tn memset2d: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    }
+    if (a_dtype == ASR_F32 && b_dtype == ASR_F32) return launch_tn<float, float>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
+    if (a_dtype == ASR_F32 && b_dtype == ASR_BF16) return launch_tn<float, bf16_t>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
+    if (a_dtype == ASR_BF16 && b_dtype == ASR_F32) return launch_tn<bf16_t, float>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
+    return launch_tn<bf16_t, bf16_t>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
+}
+
+extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first) {
+    ASR_REQUIRE(A && out && M > 0 && N > 0, ASR_ERR_ARG, "colsum: bad args");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+        if (e != hipSuccess) { asr_set_error("colsum memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    const int rows_per_block = 128;
+    dim3 grid((N + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+    if (a_dtype == ASR_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)A, lda, M, N, rows_per_block, out);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)A, lda, M, N, rows_per_block, out);
+    ASR_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
+                                     const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
+                                     int B, int L, int D) {
+    ASR_REQUIRE(dy && s && mean && rstd && gamma && ds && dgamma && dbeta, ASR_ERR_ARG, "layernorm_bwd: null pointer");
+    ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
+    const int M = B * L;
+    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s,
+                       mean, rstd, gamma, row_len, ds, ds16, dgamma, dbeta, M, L, D);
+    ASR_LAUNCH_CHECK("add_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int M, int D, int V, float* demb) {
+    ASR_REQUIRE(ids && dy && demb && M > 0 && D > 0 && V > 0, ASR_ERR_ARG, "embed_bwd: bad args");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ids, dy, M, D, V, demb);
+    ASR_LAUNCH_CHECK("embed_bwd");
+    return 0;
+}
+
+extern "C" int asr_adam_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int step, float grad_scale) {
+    ASR_REQUIRE(p && g && m && v && n > 0 && step >= 1, ASR_ERR_ARG, "adam: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+                       reinterpret_cast<bf16_t*>(p16), n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    ASR_LAUNCH_CHECK("adam_step");
+    return 0;
+}

@@ -56,6 +56,10 @@ struct EpiDense {
     const float* bias;
     unsigned flags;
     int M, N;
+    const float* addend;      // optional f32 [M,N] (ld_add): C += addend  (residual-gradient accumulation)
+    int64_t ld_add;
+    const bf16_t* relu_mask;  // optional bf16 [M,N] (ld_mask): C = relu_mask > 0 ? C : 0  (ReLU backward)
+    int64_t ld_mask;
     __device__ __forceinline__ void store4(int m, int n0, f32x4 v) const {
         if (m >= M || n0 >= N) return;
         const int nv = min(4, N - n0);
@@ -67,6 +71,16 @@ struct EpiDense {
         if (flags & ASR_GEMM_RELU) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nv) v[i] += addend[(int64_t)m * ld_add + n0 + i];
+        }
+        if (relu_mask) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < nv) v[i] = ((float)relu_mask[(int64_t)m * ld_mask + n0 + i] > 0.f) ? v[i] : 0.f;
         }
         const int64_t off = (int64_t)m * ldc + n0;
         if (c_dtype == ASR_F32) {
@@ -212,6 +226,107 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
     }
 }
 
+// ---- NN variant (data gradient): C[M,N] = A[M,Kr] . Bm[Kr,N], Bm row-major as the weight is stored ([out,in] with the
+// reduction over `out`).  Same tile / MFMA loop; only the B staging differs: 4(k) x 4(n) register transposes + 8-byte LDS
+// writes build the K-contiguous Bs[n][k] image, so no transposed weight copy ever exists in HBM.  bf16 MFMA only.
+template <typename AT, typename Epi>
+__global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
+                                                        int64_t ldb, int M, int N, int K, int tiles_n, int nwg, Epi epi) {
+    constexpr int KT = 64, CH = 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + BM * ROWB;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+
+    Chunk<AT, bf16_t> ra[4];
+    u32x2 rb[2][4];
+    const int nk = (K + KT - 1) / KT;
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + NT * i;
+            const int row = id >> 3, c = id & 7;
+            const int k = kt * KT + c * CH;
+            const int gm = m0 + row;
+            ra[i].load(A + (int64_t)gm * lda + k, gm < M && k < K);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + NT * i;
+            const int cg = id & 31, rg = id >> 5;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = kt * KT + 4 * rg + kk, n = n0 + 4 * cg;
+                rb[i][kk] = (k < K && n < N) ? *reinterpret_cast<const u32x2*>(Bm + (int64_t)k * ldb + n) : u32x2{0, 0};
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + NT * i;
+            const int row = id >> 3, c = id & 7;
+            *reinterpret_cast<u32x4*>(As + row * ROWB + ((c ^ (row & 7)) << 4)) = ra[i].get();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + NT * i;
+            const int cg = id & 31, rg = id >> 5;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int w = dd >> 1, sh = (dd & 1) * 16;
+                const unsigned e0 = (rb[i][0][w] >> sh) & 0xffffu, e1 = (rb[i][1][w] >> sh) & 0xffffu;
+                const unsigned e2 = (rb[i][2][w] >> sh) & 0xffffu, e3 = (rb[i][3][w] >> sh) & 0xffffu;
+                const int row = 4 * cg + dd;
+                *reinterpret_cast<u32x2*>(Bs + row * ROWB + (((rg >> 1) ^ (row & 7)) << 4) + ((rg & 1) << 3)) =
+                    u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+            }
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = g * 4 + q4;
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int arow = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                const int brow = wn * 64 + i * 16 + r16;
+                b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * ROWB + ((chunk ^ (brow & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi.store4(m, n0 + wn * 64 + j * 16 + q4 * 4, acc[i][j]);
+    }
+}
+
 template <typename AT, typename CT, typename Epi>
 int launch_gemm(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const Epi& epi) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -248,7 +363,17 @@ extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda
     ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm: M=%d N=%d K=%d C=%p", M, N, K, C);
     ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm: bad c_dtype");
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
-    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N};
+    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, nullptr, 0, nullptr, 0};
+    return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
+}
+
+extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
+                              const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags,
+                              const float* addend, int64_t ld_add, const void* relu_mask, int64_t ld_mask) {
+    ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm_ex: M=%d N=%d K=%d C=%p", M, N, K, C);
+    ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm_ex: bad c_dtype");
+    if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
+    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask};
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -268,4 +393,24 @@ extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t 
     EpiHeads<bf16_t> epi{reinterpret_cast<bf16_t*>(out), proj_stride, bias, L, h, M, N, scale_first};
     if (x_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
+}
+
+extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int64_t ldb, const float* bias, void* C,
+                           int c_dtype, int64_t ldc, int M, int N, int K, const float* addend, int64_t ld_add, const void* relu_mask,
+                           int64_t ld_mask) {
+    ASR_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, ASR_ERR_ARG, "gemm_nn: bad args");
+    ASR_REQUIRE(lda % 8 == 0 && lda >= (K + 7) / 8 * 8 && N % 4 == 0 && ldb % 4 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 8),
+                ASR_ERR_ALIGN, "gemm_nn: lda=%lld must be a multiple of 8 covering K=%d rounded up (pad columns must be zero), N=%d ldb=%lld of 4",
+                (long long)lda, K, N, (long long)ldb);
+    EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask};
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a_dtype == ASR_F32)
+        hipLaunchKernelGGL((gemm_nn_kernel<float, EpiDense>), dim3(nwg), dim3(NT), 0, s, (const float*)A, lda, (const bf16_t*)Bm, ldb, M, N,
+                           K, tiles_n, nwg, epi);
+    else
+        hipLaunchKernelGGL((gemm_nn_kernel<bf16_t, EpiDense>), dim3(nwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N,
+                           K, tiles_n, nwg, epi);
+    ASR_LAUNCH_CHECK("gemm_nn");
+    return 0;
 }

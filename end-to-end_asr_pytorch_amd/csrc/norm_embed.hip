@@ -6,12 +6,12 @@ namespace {
 
 constexpr int LN_MAXJ = 4;  // D <= 1024
 
-__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, const float* __restrict__ res,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 const float* __restrict__ pe, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ y32, bf16_t* __restrict__ y16,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                                int M, int L, int D, float eps) {
+                                                                float* s_out, int M, int L, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* __r
         if (c < D) {
             v[j] = *reinterpret_cast<const f32x4*>(xr + c);
             if (res) v[j] += *reinterpret_cast<const f32x4*>(res + row * D + c);
+            if (s_out) *reinterpret_cast<f32x4*>(s_out + row * D + c) = v[j];   // pre-norm sum for the backward (may alias x)
             s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         }
     }
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void assigner_tail_kernel(const float* __restr
 
 extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
                                      const float* pe, const int32_t* row_len, float* y32, void* y16, float* mean, float* rstd,
-                                     int B, int L, int D, float eps) {
+                                     float* s_out, int B, int L, int D, float eps) {
     ASR_REQUIRE(x && gamma && beta && y32, ASR_ERR_ARG, "layernorm: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 256 * LN_MAXJ && D % 4 == 0, ASR_ERR_UNSUPPORTED,
                 "layernorm: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXJ);
@@ -128,7 +129,7 @@ extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* 
                 ASR_ERR_ALIGN, "layernorm: 16-byte alignment required");
     const int M = B * L;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, residual,
-                       gamma, beta, pe, row_len, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, M, L, D, eps);
+                       gamma, beta, pe, row_len, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, s_out, M, L, D, eps);
     ASR_LAUNCH_CHECK("add_layernorm_fwd");
     return 0;
 }

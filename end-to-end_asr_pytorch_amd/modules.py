@@ -48,6 +48,60 @@ def _cdtype():
     return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
 
 
+# ---- backward tape ---------------------------------------------------------------------------------------------
+# The forward of every block pushes one closure that, run in reverse order, turns the gradient of the block's output Act
+# into parameter gradients (written straight into `p.grad`, which the trainer points into one flat buffer) and input
+# gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
+_TAPE = None
+
+
+class Tape:
+    def __init__(self):
+        self.fns = []
+
+    def push(self, fn, params=()):
+        fn.params = tuple(params)
+        self.fns.append(fn)
+
+    def backward(self, after_each=None):
+        for fn in reversed(self.fns):
+            fn()
+            if after_each is not None:
+                after_each(fn)
+        self.fns = []
+
+
+@contextlib.contextmanager
+def record():
+    global _TAPE
+    if _PRECISION != "bf16":
+        raise RuntimeError("the backward tape runs on the bf16 MFMA path")
+    old, t = _TAPE, Tape()
+    _TAPE = t
+    try:
+        yield t
+    finally:
+        _TAPE = old
+
+
+def _acc(act, g):
+    act.grad = g if act.grad is None else act.grad.add_(g)
+
+
+def _gcat(params):
+    """Gradient view covering adjacent parameters (the trainer lays Q/K/V weights out contiguously)."""
+    if len(params) == 1:
+        return params[0].grad
+    p0 = params[0]
+    off = p0._asr_off
+    n = 0
+    for q in params:
+        assert q._asr_off == off + n, "parameters are not adjacent in the flat buffer"
+        n += q.numel()
+    rows = sum(q.shape[0] for q in params)
+    return p0._asr_gflat[off:off + n].view(rows, *p0.shape[1:])
+
+
 class _Cached(nn.Module):
     """Derived weights (concatenated / re-laid-out / bf16 copies) cached against parameter versions."""
 
@@ -62,7 +116,18 @@ class _Cached(nn.Module):
         return hit[1]
 
     def _w(self, key, params, dim=0):
-        """Compute-dtype copy of (the concatenation of) weight matrices."""
+        """Compute-dtype copy of (the concatenation of) weight matrices.  When the trainer has re-homed the parameters into
+        its flat buffers the bf16 shadow view is returned directly (kept fresh by the fused Adam kernel)."""
+        p0 = params[0]
+        if _PRECISION == "bf16" and getattr(p0, "_asr_flat16", None) is not None:
+            off, n, ok = p0._asr_off, 0, True
+            for q in params:
+                ok = ok and getattr(q, "_asr_off", -1) == off + n
+                n += q.numel()
+            if ok:
+                rows = sum(q.shape[0] for q in params)
+                return p0._asr_flat16[off:off + n].view(rows, *p0.shape[1:])
+
         def build():
             w = params[0] if len(params) == 1 else torch.cat(list(params), dim)
             w = w.detach().contiguous()
@@ -78,10 +143,10 @@ class _Cached(nn.Module):
 
 class Act:
     """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
-    __slots__ = ("f32", "b16", "B", "L")
+    __slots__ = ("f32", "b16", "B", "L", "grad")
 
     def __init__(self, f32, b16, B, L):
-        self.f32, self.b16, self.B, self.L = f32, b16, B, L
+        self.f32, self.b16, self.B, self.L, self.grad = f32, b16, B, L, None
 
     def mma(self):
         return self.b16 if (self.b16 is not None and _PRECISION == "bf16") else self.f32
@@ -149,11 +214,48 @@ class MultiheadAttention(_Cached):
             kv = ops.proj_heads(xkv.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)),
                                 self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
             k, v = kv[0], kv[1]
-        ctx, _ = ops.attention_fwd(q, k, v, k_len, causal)
+        rec = _TAPE is not None
+        ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec)
         o = ops.gemm_nt(ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,)), self._b("bfc", (self.fc.bias,)))
-        y32, y16, _, _ = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
-                                           want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps)
-        return Act(y32, y16, B, Lq)
+        y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
+                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec)
+        y = Act(y32, y16, B, Lq)
+        if rec:
+            self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale)
+        return y
+
+    def _record_bw(self, xq, xkv, q, k, v, ctx, lse, s_sum, mean, rstd, y, k_len, causal, row_len, scale):
+        h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
+        hd = h * 64
+        ln, fc = self.layer_norm, self.fc
+        qkvw = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight)
+        qkvb = (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)
+
+        def bw():
+            ds, ds16 = ops.add_layernorm_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
+                                             want_bf16=True)
+            y.grad = None
+            ops.gemm_tn(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
+            ops.colsum(ds16, out=fc.bias.grad, accumulate=True)
+            d_ctx = ops.gemm_nn(ds16, self._w("fc", (fc.weight,)), out_dtype=torch.bfloat16)
+            if xkv is xq:
+                dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:])
+                ops.gemm_tn(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True)
+                ops.colsum(dqkv, out=_gcat(qkvb), accumulate=True)
+                _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
+            else:
+                dq = torch.empty((B * Lq, hd), device=ds.device, dtype=torch.bfloat16)
+                dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dkv[:, :hd], dkv[:, hd:])
+                ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True)
+                ops.colsum(dq, out=self.w_qs.bias.grad, accumulate=True)
+                _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
+                ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True)
+                ops.colsum(dkv, out=_gcat(qkvb[1:]), accumulate=True)
+                xkv.grad = ops.gemm_nn(dkv, self._w("kv", qkvw[1:]), addend=xkv.grad)
+
+        _TAPE.push(bw, qkvw + qkvb + (fc.weight, fc.bias, ln.weight, ln.bias))
 
     def forward(self, q, k, v, mask=None, k_len=None, causal=False):
         """Reference signature + length-based masking: `k_len` (int [B]) / `causal`.  A bool `mask` [B,Lq,Lk] is
@@ -181,11 +283,28 @@ class PositionwiseFeedForward(_Cached):
 
     def _impl(self, x, row_len):
         hdt = _cdtype()
+        rec = _TAPE is not None
         hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
         o = ops.gemm_nt(hid, self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)))
-        y32, y16, _, _ = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
-                                           want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps)
-        return Act(y32, y16, x.B, x.L)
+        y32, y16, mean, rstd = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
+                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec)
+        y = Act(y32, y16, x.B, x.L)
+        if rec:
+            ln, w1, w2 = self.layer_norm, self.w_1, self.w_2
+
+            def bw():
+                ds, ds16 = ops.add_layernorm_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
+                                                 want_bf16=True)
+                y.grad = None
+                ops.gemm_tn(ds16, hid, out=w2.weight.grad, accumulate=True)
+                ops.colsum(ds16, out=w2.bias.grad, accumulate=True)
+                d_hid = ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid)
+                ops.gemm_tn(d_hid, x.mma(), out=w1.weight.grad, accumulate=True)
+                ops.colsum(d_hid, out=w1.bias.grad, accumulate=True)
+                _acc(x, ops.gemm_nn(d_hid, self._w("w1", (w1.weight,)), addend=ds))
+
+            _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
+        return y
 
     def forward(self, x):
         return self._impl(_act(x), None).view3()
@@ -224,11 +343,27 @@ class Encoder(_Cached):
 
     def _impl(self, x, lens):
         B, L = x.B, x.L
+        rec = _TAPE is not None
+        x_in = x
         o = ops.gemm_nt(x.mma(), self._w("lin", (self.linear_in.weight,)), self._b("blin", (self.linear_in.bias,)))
-        y32, y16, _, _ = ops.add_layernorm(o, None, self.layer_norm_in.weight, self.layer_norm_in.bias, B, L,
-                                           pe=self.positional_encoding.rows(L), want_bf16=(_PRECISION == "bf16"),
-                                           eps=self.layer_norm_in.eps)
+        y32, y16, mean, rstd = ops.add_layernorm(o, None, self.layer_norm_in.weight, self.layer_norm_in.bias, B, L,
+                                                 pe=self.positional_encoding.rows(L), want_bf16=(_PRECISION == "bf16"),
+                                                 eps=self.layer_norm_in.eps, save_stats=rec)
         x = Act(y32, y16, B, L)
+        if rec:
+            y0, ln, lin = x, self.layer_norm_in, self.linear_in
+            need_dx = getattr(x_in, "needs_grad", False)
+
+            def bw():
+                ds, ds16 = ops.add_layernorm_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
+                                                 want_bf16=True)
+                y0.grad = None
+                ops.gemm_tn(ds16, x_in.mma(), out=lin.weight.grad, accumulate=True)
+                ops.colsum(ds16, out=lin.bias.grad, accumulate=True)
+                if need_dx:
+                    _acc(x_in, ops.gemm_nn(ds16, self._w("lin", (lin.weight,))))
+
+            _TAPE.push(bw, (lin.weight, lin.bias, ln.weight, ln.bias))
         for layer in self.layer_stack:
             x = layer._impl(x, lens)
         return x
@@ -367,6 +502,27 @@ class DecoderLayer(nn.Module):
         return self.pos_ffn._impl(x, dec_len)
 
 
+def _vocab_proj(mod, key, weight, x):
+    """logits = x . W^T (no bias).  On the tape the gradient arrives through `mod._grad_slots[key]["g"]`, filled by the
+    trainer from the fused loss backward: a [.., V] view of a zero-padded buffer whose rows are 16-byte aligned."""
+    w16 = mod._w(key, (weight,))
+    logits = ops.gemm_nt(x.mma(), w16, None)
+    if _TAPE is not None:
+        slot = {"g": None}
+        mod.__dict__.setdefault("_grad_slots", {})[key] = slot
+
+        def bw():
+            g = slot["g"]
+            Vp = g.stride(-2)
+            g2 = torch.as_strided(g, (g.numel() // g.shape[-1], g.shape[-1]), (Vp, 1), g.storage_offset())
+            ops.gemm_tn(g2, x.mma(), out=weight.grad, accumulate=True)
+            x.grad = ops.gemm_nn(g2, w16, addend=x.grad)
+            slot["g"] = None
+
+        _TAPE.push(bw, (weight,))
+    return logits
+
+
 def _compact_targets(targets):
     """rows with zeros stripped (decoder.py:46) -> (compacted [B,U], count [B])"""
     nz = targets != 0
@@ -409,9 +565,17 @@ class Decoder(_Cached):
         x32, x16 = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U),
                                 want_bf16=(_PRECISION == "bf16"))
         x = Act(x32, x16, B, U)
+        if _TAPE is not None:
+            x_emb, emb = x, self.tgt_word_emb
+
+            def bw_emb():
+                ops.embed_bwd(ys_in, x_emb.grad, emb.weight.grad)
+                x_emb.grad = None
+
+            _TAPE.push(bw_emb, (emb.weight,))
         for layer in self.layer_stack:
             x = layer._impl(x, enc, dec_len, enc_len)
-        logits = ops.gemm_nt(x.mma(), self._w("prj", (self.tgt_word_prj.weight,)), None)
+        logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, x)
         return logits.view(B, U, self.n_tgt_vocab), ys_out
 
     def forward(self, targets, encoder_padded_outputs, encoder_input_lengths):
@@ -460,7 +624,7 @@ def _xavier_all(model):
             nn.init.xavier_uniform_(p)
 
 
-class Transformer(nn.Module):
+class Transformer(_Cached):
     """src/transformer/transformer.py:7-35."""
 
     def __init__(self, encoder, decoder, spec_aug_cfg=None):
@@ -485,21 +649,14 @@ class CTC_Transformer(Transformer):
         self.ctc_fc = nn.Linear(encoder.d_output, decoder.d_output, bias=False)
 
     def _ctc_logits(self, enc):
-        def build():
-            w = self.ctc_fc.weight.detach().contiguous()
-            return ops.cast_bf16(w) if _PRECISION == "bf16" else w.float()
-        cache = self.__dict__.setdefault("_wcache", {})
-        ver = (self.ctc_fc.weight.data_ptr(), self.ctc_fc.weight._version, _PRECISION)
-        if cache.get("v") != ver:
-            cache["v"], cache["w"] = ver, build()
-        return ops.gemm_nt(enc.mma(), cache["w"], None).view(enc.B, enc.L, -1)
+        return _vocab_proj(self, "ctc", self.ctc_fc.weight, enc)
 
     def forward(self, features, len_features, padded_target):
         lens = ops.as_i32(len_features, features.device)
         enc = self.encoder._impl(_act(features), lens)
         ctc_pred = self._ctc_logits(enc)
         pred = self.decoder._impl(padded_target, enc, lens)
-        return len_features, ctc_pred, pred
+        return len_features, ctc_pred.view(enc.B, enc.L, -1), pred
 
 
 class Conv_CTC_Transformer(CTC_Transformer):
@@ -514,7 +671,7 @@ class Conv_CTC_Transformer(CTC_Transformer):
         enc = self.encoder._impl(conv, len_sequence)
         ctc_logits = self._ctc_logits(enc)
         logits, targets_eos = self.decoder._impl(targets, enc, len_sequence)
-        return ctc_logits, len_sequence, logits, targets_eos
+        return ctc_logits.view(enc.B, enc.L, -1), len_sequence, logits, targets_eos
 
     @classmethod
     def create_model(cls, args):

@@ -131,7 +131,8 @@ def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False):
 
 
 def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False):
-    """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd)."""
+    """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd).
+    With save_stats the pre-norm sum x+residual overwrites x in place (it is what the backward needs)."""
     _req_cuda(x, residual, gamma, beta, pe, row_len)
     D = x.shape[-1]
     assert x.is_contiguous() and x.numel() == B * L * D
@@ -142,7 +143,8 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
     nbytes = B * L * D * (4 + (4 if residual is not None else 0) + 4 + (2 if want_bf16 else 0))
     with _timed("add_layernorm[%dx%d]" % (B * L, D), float(nbytes)):
         check(lib().asr_add_layernorm_fwd(_stream(), _p(x), _p(residual), _p(gamma), _p(beta), _p(pe), _p(row_len), _p(y32), _p(y16),
-                                          _p(mean), _p(rstd), B, L, D, float(eps)), "asr_add_layernorm_fwd")
+                                          _p(mean), _p(rstd), _p(x) if save_stats else None, B, L, D, float(eps)),
+              "asr_add_layernorm_fwd")
     return y32, y16, mean, rstd
 
 
@@ -233,14 +235,22 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None):
     return loss, st.nll, st
 
 
+def _pad8(v):
+    return (v + 7) // 8 * 8
+
+
 def ctc_loss_bwd(st, gout):
-    """-> grad wrt logits [B,L,V] (dense).  Consumes st.alpha."""
-    grad = torch.empty((st.B, st.L, st.V), device=st.logits.device, dtype=torch.float32)
+    """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,roundup(V,8)] buffer (rows 16-byte aligned so the
+    gradient is directly a GEMM operand).  Consumes st.alpha."""
+    Vp = _pad8(st.V)
+    gbuf = torch.zeros((st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32) if Vp != st.V else torch.empty(
+        (st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32)
+    grad = gbuf[:, :, :st.V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
     with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), 8.0 * st.B * st.L * st.V):
         check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax,
                                      st.blank, _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad),
-                                     st.V), "asr_ctc_loss_bwd")
+                                     Vp), "asr_ctc_loss_bwd")
     return grad
 
 
@@ -261,11 +271,14 @@ def ce_loss_fwd(logits2d, targets1d, smoothing):
 
 def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout):
     N, V = logits2d.shape
-    grad = torch.empty((N, V), device=logits2d.device, dtype=torch.float32)
+    Vp = _pad8(V)
+    gbuf = torch.zeros((N, Vp), device=logits2d.device, dtype=torch.float32) if Vp != V else torch.empty(
+        (N, Vp), device=logits2d.device, dtype=torch.float32)
+    grad = gbuf[:, :V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
     n_word = loss2[1:2]
     check(lib().asr_ce_loss_bwd(_stream(), _p(logits2d), logits2d.stride(0), _p(targets1d), N, V, float(smoothing), _p(lse),
-                                _p(n_word), _p(gout), _p(grad), V), "asr_ce_loss_bwd")
+                                _p(n_word), _p(gout), _p(grad), Vp), "asr_ce_loss_bwd")
     return grad
 
 
@@ -293,3 +306,103 @@ def cif_gather(hidden, cur, rem, fire_idx, n_fire, Umax):
     check(lib().asr_cif_gather_fwd(_stream(), _p(hidden), _p(cur), _p(rem), _p(fire_idx), _p(n_fire), B, L, H, Umax, _p(out)),
           "asr_cif_gather_fwd")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# backward-pass ops
+def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=None, relu_mask=None, out=None):
+    """C = A . W^T (+bias) (+addend) (masked by relu_mask > 0).  A [M,K] contiguous; W [N,K]."""
+    _req_cuda(a2d, w, bias, addend, relu_mask)
+    M, K = a2d.shape
+    N = w.shape[0]
+    assert a2d.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    if out is None:
+        out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
+    with _timed("gemm_nt[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
+        check(lib().asr_gemm_nt_ex(_stream(), _p(a2d), dtype_code(a2d), K, _p(w), dtype_code(w), K, _p(bias), _p(out), dtype_code(out),
+                                   N, M, N, K, GEMM_RELU if relu else 0, _p(addend), N, _p(relu_mask), N), "asr_gemm_nt_ex")
+    return out
+
+
+def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=None, K=None):
+    """dX[M,in] = A[M,out] . W[out,in]  (W bf16 as stored).  Optional f32 addend [M,in] and bf16 relu_mask [M,in].
+    `K` (<= a2d.shape[1], rows of W used) and `lda` let A live in a wider / padded buffer."""
+    _req_cuda(a2d, w, addend, relu_mask)
+    M = a2d.shape[0]
+    K = a2d.shape[1] if K is None else K
+    lda = a2d.stride(0) if lda is None else lda
+    N = w.shape[1]
+    assert w.is_contiguous() and w.dtype == torch.bfloat16 and w.shape[0] >= K and a2d.stride(1) == 1
+    out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
+    with _timed("gemm_nn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
+        check(lib().asr_gemm_nn(_stream(), _p(a2d), dtype_code(a2d), lda, _p(w), N, None, _p(out), dtype_code(out), N, M, N, K,
+                                _p(addend), N, _p(relu_mask), N), "asr_gemm_nn")
+    return out
+
+
+def gemm_tn(a2d, b2d, out=None, accumulate=False):
+    """dW[N,K] = A[M,N]^T . B[M,K]  (f32 result).  A/B f32 or bf16; rows may be strided (padded buffers)."""
+    _req_cuda(a2d, b2d)
+    M, N = a2d.shape
+    K = b2d.shape[1]
+    assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and b2d.shape[0] == M
+    if out is None:
+        out = torch.empty((N, K), device=a2d.device, dtype=torch.float32)
+        accumulate = False
+    with _timed("gemm_tn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
+        check(lib().asr_gemm_tn(_stream(), _p(a2d), dtype_code(a2d), a2d.stride(0), _p(b2d), dtype_code(b2d), b2d.stride(0), _p(out),
+                                out.stride(0), M, N, K,
+                                0 if accumulate else 1), "asr_gemm_tn")
+    return out
+
+
+def colsum(a2d, out=None, accumulate=False):
+    _req_cuda(a2d)
+    M, N = a2d.shape
+    assert a2d.stride(1) == 1
+    if out is None:
+        out = torch.empty(N, device=a2d.device, dtype=torch.float32)
+        accumulate = False
+    check(lib().asr_colsum(_stream(), _p(a2d), dtype_code(a2d), a2d.stride(0), M, N, _p(out), 0 if accumulate else 1), "asr_colsum")
+    return out
+
+
+def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, want_bf16=False):
+    """-> (ds f32 [M,D], ds16 or None); dgamma/dbeta accumulated in place."""
+    _req_cuda(dy, s, mean, rstd, gamma, row_len, dgamma, dbeta)
+    D = s.shape[-1]
+    assert dy.is_contiguous() and s.is_contiguous()
+    ds = torch.empty((B * L, D), device=s.device, dtype=torch.float32)
+    ds16 = torch.empty((B * L, D), device=s.device, dtype=torch.bfloat16) if want_bf16 else None
+    nbytes = B * L * D * (4 + 4 + 4 + (2 if want_bf16 else 0))
+    with _timed("add_layernorm_bwd[%dx%d]" % (B * L, D), float(nbytes)):
+        check(lib().asr_add_layernorm_bwd(_stream(), _p(dy), _p(s), _p(mean), _p(rstd), _p(gamma), _p(row_len), _p(ds), _p(ds16),
+                                          _p(dgamma), _p(dbeta), B, L, D), "asr_add_layernorm_bwd")
+    return ds, ds16
+
+
+def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out):
+    """q [B,h,Lq,64], k/v [B,h,Lk,64] bf16; ctx, d_ctx token-major bf16 [B,Lq,h*64]; dq_out / dk_out / dv_out are bf16 views with
+    row stride (elements) dq_out.stride(0) / dk_out.stride(0) into token-major gradient buffers (last dim = h*64)."""
+    _req_cuda(q, k, v, ctx, d_ctx, lse)
+    B, h, Lq, _ = q.shape
+    Lk = k.shape[2]
+    assert q.dtype == torch.bfloat16 and ctx.is_contiguous() and d_ctx.is_contiguous() and d_ctx.dtype == torch.bfloat16
+    assert dk_out.stride(0) == dv_out.stride(0) and dq_out.stride(1) == 1 and dk_out.stride(1) == 1
+    delta = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32)
+    with _timed("attention_bwd[B%d h%d %dx%d]" % (B, h, Lq, Lk), 14.0 * B * h * 64 * Lq * Lk):
+        check(lib().asr_attention_bwd(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(delta), _p(dq_out),
+                                      dq_out.stride(0), _p(dk_out), _p(dv_out), dk_out.stride(0), B, h, Lq, Lk, _p(k_len),
+                                      1 if causal else 0, float(scale)), "asr_attention_bwd")
+
+
+def embed_bwd(ids, dy, demb):
+    M, D = dy.shape
+    check(lib().asr_embed_bwd(_stream(), _p(ids.contiguous()), _p(dy), M, D, demb.shape[0], _p(demb)), "asr_embed_bwd")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None):
+    _req_cuda(p, g, m, v, p16)
+    assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32
+    check(lib().asr_adam_step(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(beta1), float(beta2),
+                              float(eps), int(step), float(grad_scale)), "asr_adam_step")

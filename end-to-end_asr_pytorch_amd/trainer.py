@@ -1,0 +1,175 @@
+"""Data-parallel training step for the hot path.
+
+Mirrors what the reference's harness does per batch (src/transformer/solver.py:83-93, optimizer.py:19-29,
+train.py:166-170) with every piece on the GPU path:
+
+    forward (HIP kernels, backward tape recorded) -> loss = ctc + ce (fused CTC / CE kernels) -> backward (tape: HIP
+    kernels write parameter gradients straight into one flat fp32 buffer) -> RCCL all-reduce of that buffer in
+    buckets, launched as soon as a bucket's last gradient is final so it overlaps the rest of the backward ->
+    Noam learning rate -> fused Adam over the flat buffer (which also refreshes the bf16 MFMA weight shadow).
+
+One process per GPU; utterances are sharded across ranks (each rank owns B_local of them); gradients are averaged
+(sum all-reduce, 1/world folded into the Adam kernel's grad_scale), i.e. DDP semantics: the mean over ranks of the
+per-rank mean losses.  (The reference has no multi-GPU code; DESIGN.md §6 states the exact-vs-DDP denominators.)
+"""
+import math
+
+import torch
+
+from . import modules, ops
+from .loss import cal_ce_loss  # noqa: F401  (API parity)
+
+
+def _param_order(model):
+    """Parameters in forward-execution module order with each attention block's Q,K,V weights (then biases) adjacent, so
+    their concatenations are plain views of the flat buffers."""
+    seen, order = set(), []
+
+    def add(p):
+        if id(p) not in seen:
+            seen.add(id(p))
+            order.append(p)
+
+    for m in model.modules():
+        if isinstance(m, modules.MultiheadAttention):
+            for p in (m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.w_qs.bias, m.w_ks.bias, m.w_vs.bias):
+                add(p)
+        for p in m.parameters(recurse=False):
+            add(p)
+    for p in model.parameters():
+        add(p)
+    return order
+
+
+class FlatParams:
+    """Re-homes every parameter into one flat fp32 buffer, with a flat gradient buffer and a flat bf16 shadow."""
+
+    def __init__(self, model, device):
+        self.params = _param_order(model)
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 7) // 8 * 8 if False else p.numel()   # no padding: Q/K/V must stay adjacent
+        # every parameter here has a multiple-of-8 element count except scalars/biases of odd size; pad the tail only
+        self.numel = n
+        total = (n + 63) // 64 * 64
+        self.flat = torch.zeros(total, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=device, dtype=torch.float32)
+        self.flat16 = torch.zeros(total, device=device, dtype=torch.bfloat16)
+        self.offsets = offs
+        for p, off in zip(self.params, offs):
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1).to(device))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            p._asr_off, p._asr_gflat, p._asr_flat16 = off, self.grad, self.flat16
+        self.sync_shadow()
+
+    def sync_shadow(self):
+        """bf16 shadow <- fp32 master (after init / load_state_dict; the Adam kernel keeps it fresh afterwards)."""
+        self.flat16.copy_(ops.cast_bf16(self.flat))
+
+    def check_alignment(self):
+        for p, off in zip(self.params, self.offsets):
+            if p.dim() >= 2 and off % 8 != 0:
+                raise RuntimeError("parameter of shape %s lands at flat offset %d (not 16-byte aligned for bf16 MFMA loads)"
+                                   % (tuple(p.shape), off))
+
+
+class Trainer:
+    """model: asr_amd.CTC_Transformer (or Transformer-family module that records a tape).  k, warmup: Noam schedule
+    (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
+
+    def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=4,
+                 process_group=None):
+        self.model = model
+        dev = next(model.parameters()).device
+        self.fp = FlatParams(model, dev)
+        self.fp.check_alignment()
+        self.m = torch.zeros_like(self.fp.flat)
+        self.v = torch.zeros_like(self.fp.flat)
+        self.k, self.warmup, self.betas, self.eps = k, warmup_steps, betas, eps
+        self.init_lr = model.encoder.d_model ** (-0.5)
+        self.step_num = 0
+        self.smoothing = label_smoothing
+        self.world = 1
+        self.pg = process_group
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        # buckets = contiguous flat ranges cut at parameter boundaries (forward order); the backward finishes them last-first
+        n = self.fp.numel
+        cuts = [0]
+        for i in range(1, n_buckets):
+            target = n * i // n_buckets
+            off = min(self.fp.offsets, key=lambda o: abs(o - target))
+            if off > cuts[-1]:
+                cuts.append(off)
+        cuts.append(self.fp.flat.numel())
+        self.buckets = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+        self._bucket_of = {}
+        for p, off in zip(self.fp.params, self.fp.offsets):
+            for bi, (a, b) in enumerate(self.buckets):
+                if a <= off < b:
+                    self._bucket_of[id(p)] = bi
+        self._bucket_size = [0] * len(self.buckets)
+        for p in self.fp.params:
+            self._bucket_size[self._bucket_of[id(p)]] += 1
+
+    def lr(self):
+        """optimizer.py:24-29 (step_num already incremented)."""
+        return self.k * self.init_lr * min(self.step_num ** (-0.5), self.step_num * (self.warmup ** (-1.5)))
+
+    def forward_loss(self, feats, lens, targets):
+        """forward + joint loss with the tape recorded; returns (ctc, ce, state for backward)."""
+        model = self.model
+        with torch.no_grad(), modules.record() as tape:
+            out = model(feats, lens, targets)
+            if isinstance(model, modules.Conv_CTC_Transformer):
+                ctc_logits, ctc_len, logits, teos = out
+            else:
+                ctc_len, ctc_logits, (logits, teos) = out
+            ctc, nll, st = ops.ctc_loss_fwd(ctc_logits, ops.as_i32(ctc_len, ctc_logits.device), teos)
+            V = logits.shape[-1]
+            loss2, row_loss, lse, tg1 = ops.ce_loss_fwd(logits.reshape(-1, V), teos.reshape(-1), self.smoothing)
+        return ctc, loss2[0], (tape, st, logits, tg1, lse, loss2)
+
+    def backward(self, state):
+        tape, st, logits, tg1, lse, loss2 = state
+        model = self.model
+        one = torch.ones(1, device=logits.device)
+        with torch.no_grad():
+            # loss = ctc + ce (solver.py:88): both seeds are 1
+            model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one)
+            V = logits.shape[-1]
+            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one)
+            pending = list(self._bucket_size)
+            handles = []
+
+            def after(fn):
+                if self.world == 1:
+                    return
+                for p in fn.params:
+                    bi = self._bucket_of[id(p)]
+                    pending[bi] -= 1
+                    if pending[bi] == 0:
+                        a, b = self.buckets[bi]
+                        handles.append(torch.distributed.all_reduce(self.fp.grad[a:b], group=self.pg, async_op=True))
+
+            tape.backward(after)
+            for h in handles:
+                h.wait()
+            if self.world > 1:
+                assert all(c == 0 for c in pending), "a bucket never became ready: %s" % pending
+
+    def optimizer_step(self):
+        self.step_num += 1
+        ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr(), self.betas[0], self.betas[1], self.eps, self.step_num,
+                      grad_scale=1.0 / self.world, p16=self.fp.flat16)
+
+    def step(self, feats, lens, targets):
+        """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync)."""
+        self.fp.grad.zero_()
+        ctc, ce, state = self.forward_loss(feats, lens, targets)
+        self.backward(state)
+        self.optimizer_step()
+        return ctc, ce

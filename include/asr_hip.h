@@ -49,6 +49,19 @@ const char* asr_last_error(void);
 int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
                 const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags);
 
+/* asr_gemm_nt with two more epilogue terms (backward pass): C += addend (f32 [M,N], ld_add) and, when relu_mask
+ * (bf16 [M,N], ld_mask: the forward's post-ReLU activations) is given, C = relu_mask > 0 ? C : 0.  Either may be NULL. */
+int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
+                   const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags,
+                   const float* addend, int64_t ld_add, const void* relu_mask, int64_t ld_mask);
+
+/* Data gradient  C[M,N] = A[M,K] . Bm[K,N] (+bias) (+addend) (masked by relu_mask > 0): for nn.Linear with weight W [out,in],
+ * dX = dY . W is A = dY [M,out], Bm = W (bf16, as stored: no transposed copy), K = out, N = in.  A f32 or bf16 with lda % 8 == 0
+ * covering K rounded up to 8 (columns K..lda of A must be zero). */
+int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int64_t ldb, const float* bias, void* C,
+                int c_dtype, int64_t ldc, int M, int N, int K, const float* addend, int64_t ld_add, const void* relu_mask,
+                int64_t ld_mask);
+
 /* Head-major projection (attention.py:43-49: w_qs/w_ks/w_vs + view/permute/contiguous fused).
  * X[M = B*L, K] . W[n_proj*h*64, K]^T + bias -> out[p][B][h][L][64] for p < n_proj, out_dtype = w_dtype.
  * `proj_stride` = elements between consecutive projections' buffers.  If scale_first != 1, projection 0 (Q) is
@@ -67,13 +80,42 @@ int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t ldx, const 
 int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
                       int B, int h, int Lq, int Lk, const int32_t* k_len, int causal);
 
+/* Backward of asr_attention_fwd (bf16 only).  q,k,v as in the forward; o = the forward's ctx and d_o = its gradient, both
+ * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 [B,h,Lq] workspace.  Outputs are token-major bf16:
+ * dq[(b*Lq+i)*ldq + head*64 + d] (multiplied by `scale` = the 1/sqrt(d_k) the forward folded into q), dk / dv at
+ * [(b*Lk+j)*ldkv + head*64 + d] - i.e. directly the A operands of the projection GEMMs' backward. */
+int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                      const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
+                      int Lq, int Lk, const int32_t* k_len, int causal, float scale);
+
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.
- * mean/rstd (f32 [M]) optional saves for backward.
+ * mean/rstd (f32 [M]) and s_out (f32 [M,D], the pre-norm sum x+residual; may alias x) are optional saves for backward.
  */
 int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
                           const float* pe, const int32_t* row_len, float* y32, void* y16, float* mean, float* rstd,
-                          int B, int L, int D, float eps);
+                          float* s_out, int B, int L, int D, float eps);
+
+/* Backward of asr_add_layernorm_fwd: s = the pre-norm sum x+residual (f32 [M,D]), mean/rstd from the forward.
+ * ds (f32, optional bf16 copy ds16) = gradient wrt s (= wrt x and wrt residual); rows t >= row_len[b] get zero and do
+ * not contribute.  dgamma/dbeta (f32 [D]) are ACCUMULATED into (caller zeroes them). */
+int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
+                          const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
+                          int B, int L, int D);
+
+/* Weight gradient  C[N,K] (+)= sum_m A[m,n] * B[m,k]  (nn.Linear: A = dY [M,N], B = X [M,K] -> dW).  A, B f32 or bf16
+ * (converted to bf16 MFMA operands on load); C f32.  zero_first != 0 clears C first (the kernel accumulates with
+ * float atomics across M-splits).  lda / ldb multiples of 4 and >= N / K rounded up to 4 (A and B may live in padded buffers). */
+int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int b_dtype, int64_t ldb, float* C,
+                int64_t ldc, int M, int N, int K, int zero_first);
+/* Bias gradient out[n] (+)= sum_m A[m,n]. */
+int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first);
+/* Embedding backward: demb[ids[r], :] += dy[r, :]  (f32 atomics; caller zeroes demb). */
+int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int M, int D, int V, float* demb);
+/* Fused Adam over a flat buffer (torch.optim.Adam semantics, no weight decay): g is multiplied by grad_scale first;
+ * p16 (optional) receives the bf16 copy of the updated parameters (the MFMA operand shadow). */
+int asr_adam_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale);
 
 /* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = emb[ids[b,u],:] + pe[u,:]. */
 int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16,

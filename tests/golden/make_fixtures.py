@@ -132,10 +132,22 @@ def g1_ctc_transformer():
     l, ctc_logits, (logits, teos) = model(x, lens, tg)
     enc_out = model.encoder(x, lens)
     ctc, ce = cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+    # the harness step (solver.py:88-93): loss = ctc + ce, backward, Noam + Adam
+    model.zero_grad()
+    (ctc + ce).backward()
+    grads = {"grad:" + k: npy(p.grad).astype(np.float16 if p.grad.numel() > 20000 else np.float32) for k, p in model.named_parameters()}
+    gnorm = {"gnorm:" + k: np.float64(p.grad.norm()) for k, p in model.named_parameters()}
+    opt = TransformerOptimizer(torch.optim.Adam(model.parameters(), betas=(0.9, 0.98), eps=1e-9), 0.2, 64, 4000)
+    before = {k: npy(p).copy() for k, p in model.named_parameters()}
+    opt.step()
+    deltas = {"delta:" + k: (npy(p) - before[k]) for k, p in model.named_parameters()
+              if k in ("ctc_fc.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight", "decoder.layer_stack.1.enc_attn.w_vs.bias",
+                       "encoder.layer_norm_in.weight", "decoder.tgt_word_emb.weight")}
     np.savez_compressed(os.path.join(HERE, "g1_ctc_transformer.npz"), names_shapes=names_shapes_to_json(ns), seed=101,
                         crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), enc_out=npy(enc_out),
                         ctc_logits=npy(ctc_logits), ctc_len=npy(l), logits=npy(logits), targets_eos=npy(teos),
-                        ctc_loss=npy(ctc), ce_loss_s01=npy(ce), **cfg_arrays())
+                        ctc_loss=npy(ctc), ce_loss_s01=npy(ce), lr_step1=np.float64(opt.optimizer.param_groups[0]["lr"]),
+                        **grads, **gnorm, **deltas, **cfg_arrays())
     print("G1 ctc", float(ctc), "ce", float(ce))
 
 

@@ -1,0 +1,141 @@
+"""GPU parity of the backward-pass kernels against torch autograd on CPU (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (777, 4236, 64), (300, 768, 256), (64, 128, 128)])
+@pytest.mark.parametrize("dts", [("bf16", "bf16"), ("f32", "bf16"), ("f32", "f32")])
+def test_gemm_tn(M, N_, K, dts):
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, N_, generator=g)
+    b = torch.randn(M, K, generator=g)
+    ad = a.to(DEV).to(torch.bfloat16 if dts[0] == "bf16" else torch.float32)
+    bd = b.to(DEV).to(torch.bfloat16 if dts[1] == "bf16" else torch.float32)
+    out = ops.gemm_tn(ad, bd)
+    ref = a.bfloat16().float().t() @ b.bfloat16().float()
+    np.testing.assert_allclose(N(out), ref.numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+    out2 = ops.gemm_tn(ad, bd, out=out, accumulate=True)
+    np.testing.assert_allclose(N(out2), 2 * ref.numpy(), atol=4e-2 * (M / 300) ** 0.5, rtol=2e-3)
+
+
+@pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (300, 80, 256), (77, 256, 768), (500, 256, 4240)])
+def test_gemm_nn(M, N_, K):
+    g = torch.Generator().manual_seed(M + K)
+    dy = torch.randn(M, K, generator=g)
+    w = torch.randn(K, N_, generator=g) / K ** 0.5
+    add = torch.randn(M, N_, generator=g)
+    out = ops.gemm_nn(dy.to(DEV), w.to(DEV).bfloat16(), addend=add.to(DEV))
+    ref = dy.bfloat16().float() @ w.bfloat16().float() + add
+    np.testing.assert_allclose(N(out), ref.numpy(), atol=3e-3, rtol=2e-3)
+    out16 = ops.gemm_nn(dy.to(DEV).bfloat16(), w.to(DEV).bfloat16(), out_dtype=torch.bfloat16)
+    np.testing.assert_allclose(N(out16), (ref - add).numpy(), atol=3e-2, rtol=2e-2)
+
+
+def test_colsum_and_embed_bwd():
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(1000, 300, generator=g)
+    np.testing.assert_allclose(N(ops.colsum(a.to(DEV))), a.sum(0).numpy(), atol=1e-3)
+    np.testing.assert_allclose(N(ops.colsum(a.to(DEV).bfloat16())), a.bfloat16().float().sum(0).numpy(), atol=1e-3)
+    ids = torch.randint(0, 50, (200,), generator=g)
+    dy = torch.randn(200, 64, generator=g)
+    demb = torch.zeros(50, 64, device=DEV)
+    ops.embed_bwd(ids.to(DEV), dy.to(DEV), demb)
+    ref = torch.zeros(50, 64).index_add_(0, ids, dy)
+    np.testing.assert_allclose(N(demb), ref.numpy(), atol=1e-4)
+
+
+def test_gemm_nt_ex_addend_and_relu_mask():
+    g = torch.Generator().manual_seed(1)
+    a, w = torch.randn(300, 128, generator=g), torch.randn(200, 128, generator=g) / 11
+    add = torch.randn(300, 200, generator=g)
+    mask = torch.relu(torch.randn(300, 200, generator=g))
+    out = ops.gemm_nt_ex(a.to(DEV), w.to(DEV), addend=add.to(DEV), relu_mask=mask.to(DEV).bfloat16())
+    ref = (a @ w.t() + add) * (mask.bfloat16().float() > 0)
+    np.testing.assert_allclose(N(out), ref.numpy(), atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("D", [64, 256, 512])
+def test_add_layernorm_bwd(D):
+    B, L = 3, 50
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(B * L, D, generator=g, requires_grad=True)
+    r = torch.randn(B * L, D, generator=g)
+    gam = torch.randn(D, generator=g, requires_grad=True)
+    bet = torch.randn(D, generator=g, requires_grad=True)
+    lens = torch.tensor([50, 31, 1], dtype=torch.int32)
+    dy = torch.randn(B * L, D, generator=g)
+    keep = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1, 1).float()
+    y = torch.nn.functional.layer_norm(x + r, (D,), gam, bet) * keep
+    y.backward(dy)
+    xd = x.detach().to(DEV).clone()
+    y32, _, mean, rstd = ops.add_layernorm(xd, r.to(DEV), gam.detach().to(DEV), bet.detach().to(DEV), B, L, row_len=lens.to(DEV),
+                                           save_stats=True)
+    np.testing.assert_allclose(N(xd), (x + r).detach().numpy(), atol=1e-6)   # pre-norm sum saved in place
+    dgam, dbet = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ds, ds16 = ops.add_layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.detach().to(DEV), lens.to(DEV), B, L, dgam, dbet, want_bf16=True)
+    np.testing.assert_allclose(N(ds), x.grad.numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(N(dgam), gam.grad.numpy(), atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(N(dbet), bet.grad.numpy(), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,h,Lq,Lk,causal,ragged", [(2, 2, 25, 25, False, True), (2, 4, 200, 200, False, True), (2, 2, 51, 51, True, True),
+                                                     (2, 2, 51, 250, False, True), (1, 2, 300, 300, True, False), (1, 1, 1000, 1000, False, True)])
+def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
+    g = torch.Generator().manual_seed(Lq * 3 + Lk)
+    q = (torch.randn(B, h, Lq, 64, generator=g) * 0.4).bfloat16().float().requires_grad_(True)
+    k = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
+    v = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
+    k_len = None
+    if ragged:
+        k_len = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+        k_len[0] = Lk
+    s = q @ k.transpose(-1, -2)
+    mask = torch.zeros(B, 1, Lq, Lk, dtype=torch.bool)
+    if k_len is not None:
+        mask |= (torch.arange(Lk)[None, :] >= k_len[:, None])[:, None, None, :]
+    if causal:
+        mask |= torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1)[None, None]
+    p = torch.softmax(s.masked_fill(mask, float("-inf")), -1)
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(B, Lq, h * 64)
+    dctx = torch.randn(B, Lq, h * 64, generator=g).bfloat16().float()
+    ctx.backward(dctx)
+    qd, kd, vd = (t.detach().to(DEV).bfloat16() for t in (q, k, v))
+    kl = None if k_len is None else k_len.to(DEV).int()
+    ctx_d, lse = ops.attention_fwd(qd, kd, vd, kl, causal, need_lse=True)
+    dq = torch.zeros(B * Lq, h * 64, device=DEV, dtype=torch.bfloat16)
+    dkv = torch.zeros(B * Lk, 2 * h * 64, device=DEV, dtype=torch.bfloat16)
+    ops.attention_bwd(qd, kd, vd, ctx_d, dctx.to(DEV).bfloat16(), lse, kl, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:])
+    to_tok = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0] * t.shape[2], h * 64)
+    # bf16 operands / outputs on sums over up to Lq (dK, dV) or Lk (dQ) terms: the absolute error grows ~ sqrt(L)
+    tol = dict(atol=3e-2 * max(1.0, (max(Lq, Lk) / 250.0) ** 0.5), rtol=3e-2)
+    np.testing.assert_allclose(N(dq), (to_tok(q.grad) * 0.125).numpy(), **tol)
+    np.testing.assert_allclose(N(dkv[:, :h * 64]), to_tok(k.grad).numpy(), **tol)
+    np.testing.assert_allclose(N(dkv[:, h * 64:]), to_tok(v.grad).numpy(), **tol)
+
+
+def test_adam_step_matches_torch():
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(10000, generator=g)
+    tp = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([tp], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    p16 = torch.zeros(10000, device=DEV, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        gr = torch.randn(10000, generator=g)
+        tp.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.to(DEV), m, v, 1e-3, 0.9, 0.98, 1e-9, step, p16=p16)
+    np.testing.assert_allclose(N(p), tp.detach().numpy(), atol=1e-6, rtol=1e-5)
+    np.testing.assert_array_equal(N(p16), N(p.bfloat16()))

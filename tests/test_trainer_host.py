@@ -1,0 +1,45 @@
+"""Host-side trainer logic that needs no GPU: parameter ordering / adjacency, bucket cover, Noam schedule."""
+import numpy as np
+import torch
+
+import asr_amd
+from asr_amd.trainer import _param_order
+from oracle import asr_oracle as O
+
+
+def _model():
+    return asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=0.0), asr_amd.Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.0))
+
+
+def test_param_order_is_a_permutation_with_qkv_adjacent():
+    m = _model()
+    order = _param_order(m)
+    assert sorted(id(p) for p in order) == sorted(id(p) for p in m.parameters())
+    pos = {id(p): i for i, p in enumerate(order)}
+    for mod in m.modules():
+        if isinstance(mod, asr_amd.MultiheadAttention):
+            i = pos[id(mod.w_qs.weight)]
+            assert pos[id(mod.w_ks.weight)] == i + 1 and pos[id(mod.w_vs.weight)] == i + 2
+            j = pos[id(mod.w_qs.bias)]
+            assert pos[id(mod.w_ks.bias)] == j + 1 and pos[id(mod.w_vs.bias)] == j + 2
+    off = 0
+    for p in order:
+        if p.dim() >= 2:
+            assert off % 8 == 0          # bf16 shadow rows start 16-byte aligned
+        off += p.numel()
+
+
+def test_noam_schedule_matches_oracle_and_reference_pins(golden_dir):
+    import os
+    z = np.load(os.path.join(golden_dir, "g0_conv_ctc_transformer.npz"))
+
+    class T:  # the trainer's lr() without building device buffers
+        k, warmup, init_lr = 0.2, 4000, 256 ** (-0.5)
+        lr = asr_amd.Trainer.lr
+    t = T()
+    got = []
+    for n in (1, 4000, 10000):
+        t.step_num = n
+        got.append(t.lr())
+        np.testing.assert_allclose(t.lr(), O.noam_lr(n, 0.2, 256, 4000), rtol=1e-12)
+    np.testing.assert_allclose(got, z["noam_k0.2_d256_w4000_steps_1_4000_10000"], rtol=1e-12)
