@@ -108,30 +108,62 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TA* __restrict__ 
                 for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);   // D[k_local][n_local]
         }
     }
-    // lane holds n = .. + r16 (one output ROW of C[N,K]) and 4 consecutive k
+    // Accumulate into C with float atomics.  In the MFMA layout a lane holds one n-row and 4 k-columns, i.e. a wave
+    // instruction would touch 16 rows x 16-byte pieces (the slow, scattered atomic shape).  The tile is therefore bounced
+    // through LDS per wave (2 passes of 32 rows x 64 columns) so that every atomic wave-instruction adds 256 contiguous bytes.
+    float* wlds = reinterpret_cast<float*>(smem) + wave * (32 * 64);   // 32 rows x 64 floats per wave (8 KB), XOR-swizzled columns
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wm * 64 + i * 16 + r16;
-        if (n >= N) continue;
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + wn * 64 + j * 16 + q4 * 4;
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = pass * 2 + ii;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (k + e < K) atomicAdd(C + (int64_t)n * ldc + k + e, acc[i][j][e]);
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(wlds + (ii * 16 + r16) * 64 + ((j * 16 + q4 * 4) ^ (r16 << 2))) = acc[i][j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int k = k0 + wn * 64 + lane;
+        for (int rr = 0; rr < 32; ++rr) {
+            const int n = n0 + wm * 64 + pass * 32 + rr;
+            const float v = wlds[rr * 64 + (lane ^ ((rr & 15) << 2))];
+            if (n < N && k < K) atomicAdd(C + (int64_t)n * ldc + k, v);
         }
     }
 }
 
+// out[n] += sum_m A[m,n]: a workgroup owns a 256-column chunk (64 lanes x 4 columns per vector load) and a row range; its 4
+// waves stride over the rows, partials meet in LDS, one float atomic per column per workgroup.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, int64_t lda, int M, int N, int rows_per_block,
                                                      float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + lane * 4;
     const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
-    if (n >= N) return;
-    float s = 0.f;
-    for (int m = m0; m < m1; ++m) s += to_f32(A[(int64_t)m * lda + n]);
-    atomicAdd(out + n, s);
+    f32x4 s = {0, 0, 0, 0};
+    if (n < N) {
+        const bool vec = (n + 3 < N) && ((lda & 3) == 0);
+        for (int m = m0 + wave; m < m1; m += 4) {
+            const T* p = A + (int64_t)m * lda + n;
+            if (vec) {
+                if constexpr (sizeof(T) == 4) {
+                    s += *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+                    s += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) s[e] += to_f32(p[e]);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[wave][lane * 4]) = s;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) atomicAdd(out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -142,12 +174,12 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, int M, int L, int D) {
-    __shared__ float red[2][4][1024];
+                                                                float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D) {
+    __shared__ float red[3][4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 ag[LN_MAXJ], ab[LN_MAXJ];
+    f32x4 ag[LN_MAXJ], ab[LN_MAXJ], as[LN_MAXJ];
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; }
+    for (int j = 0; j < LN_MAXJ; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; as[j] = f32x4{0, 0, 0, 0}; }
     const float invD = 1.f / (float)D;
     for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
         const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + rr * 4 + wave;
@@ -179,6 +211,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
             const int c = lane * 4 + 256 * j;
             if (c < D) {
                 const f32x4 o = (g[j] - s1 - xh[j] * s2) * rs;
+                as[j] += o;
                 *reinterpret_cast<f32x4*>(ds + row * D + c) = o;
                 if (ds16) {
                     bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
@@ -194,12 +227,14 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         if (c < D) {
             *reinterpret_cast<f32x4*>(&red[0][wave][c]) = ag[j];
             *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab[j];
+            *reinterpret_cast<f32x4*>(&red[2][wave][c]) = as[j];
         }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
         atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+        if (dbias) atomicAdd(dbias + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
     }
 }
 
@@ -234,8 +269,8 @@ template <typename TA, typename TB>
 int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* Bm, int64_t ldb, float* C, int64_t ldc, int M, int N, int K) {
     const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
     const int tiles = tiles_n * tiles_k;
-    int splits = (768 + tiles - 1) / tiles;
-    const int max_splits = (M + 255) / 256;
+    int splits = (512 + tiles - 1) / tiles;
+    const int max_splits = (M + 511) / 512;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
@@ -278,8 +313,11 @@ extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda,
         hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
         if (e != hipSuccess) { asr_set_error("colsum memset: %s", hipGetErrorString(e)); return (int)e; }
     }
-    const int rows_per_block = 128;
-    dim3 grid((N + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+    const int col_blocks = (N + 255) / 256;
+    int row_blocks = (1024 + col_blocks - 1) / col_blocks;          // ~1024 workgroups
+    if (row_blocks > (M + 31) / 32) row_blocks = (M + 31) / 32;
+    const int rows_per_block = (M + row_blocks - 1) / row_blocks;
+    dim3 grid(col_blocks, (M + rows_per_block - 1) / rows_per_block);
     if (a_dtype == ASR_F32)
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)A, lda, M, N, rows_per_block, out);
     else
@@ -290,12 +328,12 @@ extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda,
 
 extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
                                      const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
-                                     int B, int L, int D) {
+                                     float* dbias, int B, int L, int D) {
     ASR_REQUIRE(dy && s && mean && rstd && gamma && ds && dgamma && dbeta, ASR_ERR_ARG, "layernorm_bwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s,
-                       mean, rstd, gamma, row_len, ds, ds16, dgamma, dbeta, M, L, D);
+                       mean, rstd, gamma, row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D);
     ASR_LAUNCH_CHECK("add_layernorm_bwd");
     return 0;
 }

@@ -73,14 +73,26 @@ struct EpiDense {
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
         }
         if (addend) {
+            const float* ap = addend + (int64_t)m * ld_add + n0;
+            if (nv == 4 && ((reinterpret_cast<uintptr_t>(ap) & 15) == 0)) {
+                v += *reinterpret_cast<const f32x4*>(ap);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nv) v[i] += addend[(int64_t)m * ld_add + n0 + i];
+                for (int i = 0; i < 4; ++i)
+                    if (i < nv) v[i] += ap[i];
+            }
         }
         if (relu_mask) {
+            const bf16_t* mp = relu_mask + (int64_t)m * ld_mask + n0;
+            if (nv == 4 && ((reinterpret_cast<uintptr_t>(mp) & 7) == 0)) {
+                const bf16x4 mk = *reinterpret_cast<const bf16x4*>(mp);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nv) v[i] = ((float)relu_mask[(int64_t)m * ld_mask + n0 + i] > 0.f) ? v[i] : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nv) v[i] = ((float)mp[i] > 0.f) ? v[i] : 0.f;
+            }
         }
         const int64_t off = (int64_t)m * ldc + n0;
         if (c_dtype == ASR_F32) {

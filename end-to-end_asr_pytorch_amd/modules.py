@@ -233,10 +233,9 @@ class MultiheadAttention(_Cached):
 
         def bw():
             ds, ds16 = ops.add_layernorm_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
-                                             want_bf16=True)
+                                             want_bf16=True, dbias=fc.bias.grad)
             y.grad = None
             ops.gemm_tn(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
-            ops.colsum(ds16, out=fc.bias.grad, accumulate=True)
             d_ctx = ops.gemm_nn(ds16, self._w("fc", (fc.weight,)), out_dtype=torch.bfloat16)
             if xkv is xq:
                 dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
@@ -294,10 +293,9 @@ class PositionwiseFeedForward(_Cached):
 
             def bw():
                 ds, ds16 = ops.add_layernorm_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
-                                                 want_bf16=True)
+                                                 want_bf16=True, dbias=w2.bias.grad)
                 y.grad = None
                 ops.gemm_tn(ds16, hid, out=w2.weight.grad, accumulate=True)
-                ops.colsum(ds16, out=w2.bias.grad, accumulate=True)
                 d_hid = ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid)
                 ops.gemm_tn(d_hid, x.mma(), out=w1.weight.grad, accumulate=True)
                 ops.colsum(d_hid, out=w1.bias.grad, accumulate=True)
@@ -356,10 +354,9 @@ class Encoder(_Cached):
 
             def bw():
                 ds, ds16 = ops.add_layernorm_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
-                                                 want_bf16=True)
+                                                 want_bf16=True, dbias=lin.bias.grad)
                 y0.grad = None
                 ops.gemm_tn(ds16, x_in.mma(), out=lin.weight.grad, accumulate=True)
-                ops.colsum(ds16, out=lin.bias.grad, accumulate=True)
                 if need_dx:
                     _acc(x_in, ops.gemm_nn(ds16, self._w("lin", (lin.weight,))))
 

@@ -367,8 +367,8 @@ def colsum(a2d, out=None, accumulate=False):
     return out
 
 
-def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, want_bf16=False):
-    """-> (ds f32 [M,D], ds16 or None); dgamma/dbeta accumulated in place."""
+def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, want_bf16=False, dbias=None):
+    """-> (ds f32 [M,D], ds16 or None); dgamma/dbeta (and dbias += colsum(ds) when given) accumulated in place."""
     _req_cuda(dy, s, mean, rstd, gamma, row_len, dgamma, dbeta)
     D = s.shape[-1]
     assert dy.is_contiguous() and s.is_contiguous()
@@ -377,7 +377,7 @@ def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, wa
     nbytes = B * L * D * (4 + 4 + 4 + (2 if want_bf16 else 0))
     with _timed("add_layernorm_bwd[%dx%d]" % (B * L, D), float(nbytes)):
         check(lib().asr_add_layernorm_bwd(_stream(), _p(dy), _p(s), _p(mean), _p(rstd), _p(gamma), _p(row_len), _p(ds), _p(ds16),
-                                          _p(dgamma), _p(dbeta), B, L, D), "asr_add_layernorm_bwd")
+                                          _p(dgamma), _p(dbeta), _p(dbias), B, L, D), "asr_add_layernorm_bwd")
     return ds, ds16
 
 

@@ -76,6 +76,55 @@ class FlatParams:
                                    % (tuple(p.shape), off))
 
 
+class GradBuckets:
+    """Bucketed gradient all-reduce over one flat buffer, overlapped with the backward.
+
+    Buckets are contiguous ranges of the flat gradient cut at parameter boundaries.  `on_done(params)` is called after each
+    backward closure with the parameters whose gradients just became final; when a bucket's last parameter is done its
+    all-reduce (sum) is launched asynchronously (RCCL on the GPU, gloo in the CPU tests) while the backward keeps running.
+    `finish()` waits for all of them.  Device-agnostic: only torch.distributed + tensor views."""
+
+    def __init__(self, flat_grad, params, offsets, numel, n_buckets=4, group=None):
+        self.flat_grad, self.group = flat_grad, group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(group)
+        cuts = [0]
+        for i in range(1, n_buckets):
+            target = numel * i // n_buckets
+            off = min(offsets, key=lambda o: abs(o - target))
+            if off > cuts[-1]:
+                cuts.append(off)
+        cuts.append(flat_grad.numel())
+        self.ranges = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+        self._bucket_of, self._size = {}, [0] * len(self.ranges)
+        for p, off in zip(params, offsets):
+            for bi, (a, b) in enumerate(self.ranges):
+                if a <= off < b:
+                    self._bucket_of[id(p)] = bi
+                    self._size[bi] += 1
+        self.start()
+
+    def start(self):
+        self._pending, self._handles, self.launch_order = list(self._size), [], []
+
+    def on_done(self, params):
+        for p in params:
+            bi = self._bucket_of[id(p)]
+            self._pending[bi] -= 1
+            if self._pending[bi] == 0:
+                self.launch_order.append(bi)
+                if self.world > 1:
+                    a, b = self.ranges[bi]
+                    self._handles.append(torch.distributed.all_reduce(self.flat_grad[a:b], group=self.group, async_op=True))
+
+    def finish(self):
+        for h in self._handles:
+            h.wait()
+        if any(c != 0 for c in self._pending):
+            raise RuntimeError("gradient bucket(s) never became ready: pending=%s" % self._pending)
+
+
 class Trainer:
     """model: asr_amd.CTC_Transformer (or Transformer-family module that records a tape).  k, warmup: Noam schedule
     (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
@@ -92,28 +141,8 @@ class Trainer:
         self.init_lr = model.encoder.d_model ** (-0.5)
         self.step_num = 0
         self.smoothing = label_smoothing
-        self.world = 1
-        self.pg = process_group
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
-        # buckets = contiguous flat ranges cut at parameter boundaries (forward order); the backward finishes them last-first
-        n = self.fp.numel
-        cuts = [0]
-        for i in range(1, n_buckets):
-            target = n * i // n_buckets
-            off = min(self.fp.offsets, key=lambda o: abs(o - target))
-            if off > cuts[-1]:
-                cuts.append(off)
-        cuts.append(self.fp.flat.numel())
-        self.buckets = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
-        self._bucket_of = {}
-        for p, off in zip(self.fp.params, self.fp.offsets):
-            for bi, (a, b) in enumerate(self.buckets):
-                if a <= off < b:
-                    self._bucket_of[id(p)] = bi
-        self._bucket_size = [0] * len(self.buckets)
-        for p in self.fp.params:
-            self._bucket_size[self._bucket_of[id(p)]] += 1
+        self.buckets = GradBuckets(self.fp.grad, self.fp.params, self.fp.offsets, self.fp.numel, n_buckets, process_group)
+        self.world = self.buckets.world
 
     def lr(self):
         """optimizer.py:24-29 (step_num already incremented)."""
@@ -142,24 +171,9 @@ class Trainer:
             model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one)
             V = logits.shape[-1]
             model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one)
-            pending = list(self._bucket_size)
-            handles = []
-
-            def after(fn):
-                if self.world == 1:
-                    return
-                for p in fn.params:
-                    bi = self._bucket_of[id(p)]
-                    pending[bi] -= 1
-                    if pending[bi] == 0:
-                        a, b = self.buckets[bi]
-                        handles.append(torch.distributed.all_reduce(self.fp.grad[a:b], group=self.pg, async_op=True))
-
-            tape.backward(after)
-            for h in handles:
-                h.wait()
-            if self.world > 1:
-                assert all(c == 0 for c in pending), "a bucket never became ready: %s" % pending
+            self.buckets.start()
+            tape.backward(lambda fn: self.buckets.on_done(fn.params))
+            self.buckets.finish()
 
     def optimizer_step(self):
         self.step_num += 1

@@ -98,10 +98,11 @@ int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, c
 
 /* Backward of asr_add_layernorm_fwd: s = the pre-norm sum x+residual (f32 [M,D]), mean/rstd from the forward.
  * ds (f32, optional bf16 copy ds16) = gradient wrt s (= wrt x and wrt residual); rows t >= row_len[b] get zero and do
- * not contribute.  dgamma/dbeta (f32 [D]) are ACCUMULATED into (caller zeroes them). */
+ * not contribute.  dgamma/dbeta (f32 [D]) are ACCUMULATED into (caller zeroes them); dbias (optional, f32 [D]) likewise
+ * receives colsum(ds) = the bias gradient of the projection whose output was normalised. */
 int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
                           const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
-                          int B, int L, int D);
+                          float* dbias, int B, int L, int D);
 
 /* Weight gradient  C[N,K] (+)= sum_m A[m,n] * B[m,k]  (nn.Linear: A = dY [M,N], B = X [M,K] -> dW).  A, B f32 or bf16
  * (converted to bf16 MFMA operands on load); C f32.  zero_first != 0 clears C first (the kernel accumulates with

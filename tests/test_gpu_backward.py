@@ -47,6 +47,10 @@ def test_colsum_and_embed_bwd():
     a = torch.randn(1000, 300, generator=g)
     np.testing.assert_allclose(N(ops.colsum(a.to(DEV))), a.sum(0).numpy(), atol=1e-3)
     np.testing.assert_allclose(N(ops.colsum(a.to(DEV).bfloat16())), a.bfloat16().float().sum(0).numpy(), atol=1e-3)
+    big = torch.randn(5000, 768, generator=g)
+    np.testing.assert_allclose(N(ops.colsum(big.to(DEV).bfloat16())), big.bfloat16().float().sum(0).numpy(), atol=5e-3)
+    odd = torch.randn(333, 50, generator=g)          # N not a multiple of 4, lda not a multiple of 4
+    np.testing.assert_allclose(N(ops.colsum(odd.to(DEV))), odd.sum(0).numpy(), atol=1e-3)
     ids = torch.randint(0, 50, (200,), generator=g)
     dy = torch.randn(200, 64, generator=g)
     demb = torch.zeros(50, 64, device=DEV)
@@ -83,8 +87,11 @@ def test_add_layernorm_bwd(D):
                                            save_stats=True)
     np.testing.assert_allclose(N(xd), (x + r).detach().numpy(), atol=1e-6)   # pre-norm sum saved in place
     dgam, dbet = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
-    ds, ds16 = ops.add_layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.detach().to(DEV), lens.to(DEV), B, L, dgam, dbet, want_bf16=True)
+    dbias = torch.zeros(D, device=DEV)
+    ds, ds16 = ops.add_layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.detach().to(DEV), lens.to(DEV), B, L, dgam, dbet, want_bf16=True,
+                                     dbias=dbias)
     np.testing.assert_allclose(N(ds), x.grad.numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(N(dbias), x.grad.sum(0).numpy(), atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(N(dgam), gam.grad.numpy(), atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(N(dbet), bet.grad.numpy(), atol=2e-4, rtol=1e-4)
 
