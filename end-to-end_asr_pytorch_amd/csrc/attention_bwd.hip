@@ -103,7 +103,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     unsigned char* Vs = smem + 8192;
     unsigned char* Kt = smem + 16384;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int qt = blockIdx.x % q_tiles, bh = blockIdx.x / q_tiles, b = bh / h, hd = bh - b * h;
+    int qt, bh;   // XCD-aware map (see attention.hip): tiles of one (batch, head) share an XCD and are adjacent in time
+    {
+        const int BH = gridDim.x / q_tiles;
+        if ((BH & 7) == 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            bh = (slot / q_tiles) * 8 + xcd;
+            qt = slot % q_tiles;
+        } else {
+            qt = blockIdx.x % q_tiles;
+            bh = blockIdx.x / q_tiles;
+        }
+    }
+    const int b = bh / h, hd = bh - b * h;
     const int q0 = qt * QB;
     const int kl = k_len ? min(k_len[b], Lk) : Lk;
     const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
         for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[j];
     }
     dl += __shfl_xor(dl, 32, 64);
-    const float my_lse = qok ? lse[(int64_t)bh * Lq + qrow] : 0.f;
+    const float my_lse2 = (qok ? lse[(int64_t)bh * Lq + qrow] : 0.f) * 1.4426950408889634f;
     if (qok && hh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
 
     f32x16 a0 = zero16(), a1 = zero16();
@@ -140,6 +152,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
         stage_transposed<NTHR>(Kt, Kb, 64, key0, kl, tid);
         __syncthreads();
         if (CAUSAL && key0 > wave_qlast) continue;
+        // interior tile: every key valid for every (in-range) query of this wave -> no mask arithmetic (wave-uniform)
+        const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32) && (q0 + wave * 32 + 31 < Lq);
         f32x16 st[2], dp[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -151,12 +165,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                 st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
                 dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
             }
+            if (interior) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const bool bad = key >= kl || (CAUSAL && key > qrow) || !qok;
-                const float p = bad ? 0.f : __expf(st[hf][i] - my_lse);
-                st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -my_lse2));
+                    st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const bool bad = key >= kl || (CAUSAL && key > qrow) || !qok;
+                    const float p = bad ? 0.f : __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -my_lse2));
+                    st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
+                }
             }
         }
 #pragma unroll
@@ -186,7 +208,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     float* lse_s = reinterpret_cast<float*>(smem + 32768);
     float* del_s = lse_s + 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int kt = blockIdx.x % k_tiles, bh = blockIdx.x / k_tiles, b = bh / h, hd = bh - b * h;
+    int kt, bh;   // XCD-aware map: key blocks of one (batch, head) share an XCD (they all stream the same Q / dO)
+    {
+        const int BH = gridDim.x / k_tiles;
+        if ((BH & 7) == 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            bh = (slot / k_tiles) * 8 + xcd;
+            kt = slot % k_tiles;
+        } else {
+            kt = blockIdx.x % k_tiles;
+            bh = blockIdx.x / k_tiles;
+        }
+    }
+    const int b = bh / h, hd = bh - b * h;
     const int kl = k_len ? min(k_len[b], Lk) : Lk;
     const int key = kt * 128 + wave * 32 + r;
     const bool kok = key < kl;
@@ -215,11 +249,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         stage_transposed<256>(dOt, dOb, ldo, q0, Lq, tid);
         if (tid < 64) {
             const int q = q0 + tid;
-            lse_s[tid] = (q < Lq) ? lse[(int64_t)bh * Lq + q] : 0.f;
+            lse_s[tid] = (q < Lq) ? lse[(int64_t)bh * Lq + q] * 1.4426950408889634f : 0.f;   // base-2 for exp2(fma)
             del_s[tid] = (q < Lq) ? delta[(int64_t)bh * Lq + q] : 0.f;
         }
         __syncthreads();
         if (CAUSAL && q0 + 63 < wave_kfirst) continue;   // every query of the tile precedes every key of this wave
+        // interior tile: all 64 queries in range, all 32 keys of the wave valid and (causal) not in any query's future
+        const bool interior = (q0 + 64 <= Lq) && (wave_kfirst + 31 < kl) && (!CAUSAL || wave_kfirst + 31 <= q0);
         f32x16 sq[2], dp[2];
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -239,8 +275,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int q = q0 + ql + i;
-                    const bool bad = !kok || q >= Lq || (CAUSAL && key > q);
-                    const float p = bad ? 0.f : __expf(sq[hf][4 * g + i] - l4[i]);
+                    const bool bad = !interior && (!kok || q >= Lq || (CAUSAL && key > q));
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sq[hf][4 * g + i], 1.4426950408889634f, -l4[i]));
+                    const float p = bad ? 0.f : e;
                     sq[hf][4 * g + i] = p;                                   // P
                     dp[hf][4 * g + i] = p * (dp[hf][4 * g + i] - d4[i]);     // dS
                 }
