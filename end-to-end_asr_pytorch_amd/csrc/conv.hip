@@ -142,7 +142,88 @@ __global__ __launch_bounds__(256) void conv_sub1_kernel(const CT* __restrict__ x
     }
 }
 
+// ---- backward helpers: the conv layers' gradients are expressed as GEMMs over an explicit patch matrix ------------------
+// im2col: col[(b,t,f), tap*C + c] = x[b, 2t+kh, f+kw, c] (zero outside [Tin) x [Fin)); columns 9*C..ldc-1 are zeroed.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void conv_im2col_kernel(const TI* __restrict__ x, TO* __restrict__ col, int C, int Tin, int Fin,
+                                                          int Tout, int Fout, int ldc, int64_t total) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int j = (int)(i % ldc);
+        const int64_t pos = i / ldc;
+        float v = 0.f;
+        if (j < 9 * C) {
+            const int tap = j / C, c = j - tap * C, kh = tap / 3, kw = tap - kh * 3;
+            const int f = (int)(pos % Fout), t = (int)((pos / Fout) % Tout), b = (int)(pos / ((int64_t)Fout * Tout));
+            const int tt = 2 * t + kh, ff = f + kw;
+            if (tt < Tin && ff < Fin) v = to_f32(x[(((int64_t)b * Tin + tt) * Fin + ff) * C + c]);
+        }
+        col[i] = from_f32<TO>(v);
+    }
+}
+
+// col2im (gather form) + ReLU mask: dx[b,ti,fi,c] = (y[b,ti,fi,c] > 0) * sum_{kh,kw} dcol[(b,(ti-kh)/2,fi-kw), tap*32 + c]
+// over taps with (ti-kh) even, 0 <= (ti-kh)/2 < Tout, 0 <= fi-kw < Fout.  One thread per (position, 4 channels).
+__global__ __launch_bounds__(256) void conv_col2im_kernel(const bf16_t* __restrict__ dcol, int ldc, const bf16_t* __restrict__ y,
+                                                          bf16_t* __restrict__ dx, int Tin, int Fin, int Tout, int Fout, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i & 7) * 4;
+    const int64_t pos = i >> 3;
+    const int fi = (int)(pos % Fin), ti = (int)((pos / Fin) % Tin), b = (int)(pos / ((int64_t)Fin * Tin));
+    f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int t2 = ti - kh;
+        if (t2 < 0 || (t2 & 1)) continue;
+        const int t = t2 >> 1;
+        if (t >= Tout) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int f = fi - kw;
+            if (f < 0 || f >= Fout) continue;
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(dcol + (((int64_t)b * Tout + t) * Fout + f) * ldc + (kh * 3 + kw) * 32 + c4);
+            acc += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        }
+    }
+    const bf16x4 yv = *reinterpret_cast<const bf16x4*>(y + pos * 32 + c4);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(((float)yv[e] > 0.f) ? acc[e] : 0.f);
+    *reinterpret_cast<bf16x4*>(dx + pos * 32 + c4) = o;
+}
+
 }  // namespace
+
+extern "C" int asr_conv_im2col(void* stream, const void* x, int x_dtype, int C, void* col, int col_dtype, int ldc, int B, int Tin, int Fin,
+                               int Tout, int Fout) {
+    ASR_REQUIRE(x && col && B > 0 && C > 0 && ldc >= 9 * C && Tout > 0 && Fout > 0, ASR_ERR_ARG, "im2col: bad args");
+    const int64_t total = (int64_t)B * Tout * Fout * ldc;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 g((unsigned)blocks), b(256);
+    if (x_dtype == ASR_F32 && col_dtype == ASR_F32)
+        hipLaunchKernelGGL((conv_im2col_kernel<float, float>), g, b, 0, s, (const float*)x, (float*)col, C, Tin, Fin, Tout, Fout, ldc, total);
+    else if (x_dtype == ASR_F32 && col_dtype == ASR_BF16)
+        hipLaunchKernelGGL((conv_im2col_kernel<float, bf16_t>), g, b, 0, s, (const float*)x, (bf16_t*)col, C, Tin, Fin, Tout, Fout, ldc, total);
+    else if (x_dtype == ASR_BF16 && col_dtype == ASR_BF16)
+        hipLaunchKernelGGL((conv_im2col_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)x, (bf16_t*)col, C, Tin, Fin, Tout, Fout, ldc, total);
+    else
+        ASR_REQUIRE(false, ASR_ERR_UNSUPPORTED, "im2col: dtype combination");
+    ASR_LAUNCH_CHECK("conv_im2col");
+    return 0;
+}
+
+extern "C" int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y, void* dx, int B, int Tin, int Fin, int Tout,
+                                    int Fout) {
+    ASR_REQUIRE(dcol && y && dx && B > 0 && ldc >= 288 && ldc % 4 == 0, ASR_ERR_ARG, "col2im: bad args");
+    const int64_t total = (int64_t)B * Tin * Fin * 8;
+    hipLaunchKernelGGL(conv_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (const bf16_t*)dcol, ldc, (const bf16_t*)y, (bf16_t*)dx, Tin, Fin, Tout, Fout, total);
+    ASR_LAUNCH_CHECK("conv_col2im");
+    return 0;
+}
 
 extern "C" int asr_conv_sub0_fwd(void* stream, const float* feats, const float* w0, const float* b0, void* y, int dtype, int B, int T,
                                  int D, int T1, int F1) {

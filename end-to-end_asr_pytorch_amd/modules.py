@@ -53,6 +53,12 @@ def _cdtype():
 # into parameter gradients (written straight into `p.grad`, which the trainer points into one flat buffer) and input
 # gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
 _TAPE = None
+_PARAM_EPOCH = 0   # bumped by the trainer after each fused Adam step (raw-pointer updates do not bump tensor versions)
+
+
+def bump_param_epoch():
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
 
 
 class Tape:
@@ -107,7 +113,7 @@ class _Cached(nn.Module):
 
     def _derived(self, key, params, build):
         cache = self.__dict__.setdefault("_wcache", {})
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (_PRECISION,)
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (_PRECISION, _PARAM_EPOCH)
         hit = cache.get(key)
         if hit is None or hit[0] != ver:
             with torch.no_grad():
@@ -143,10 +149,10 @@ class _Cached(nn.Module):
 
 class Act:
     """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
-    __slots__ = ("f32", "b16", "B", "L", "grad")
+    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad")
 
     def __init__(self, f32, b16, B, L):
-        self.f32, self.b16, self.B, self.L, self.grad = f32, b16, B, L, None
+        self.f32, self.b16, self.B, self.L, self.grad, self.needs_grad = f32, b16, B, L, None, False
 
     def mma(self):
         return self.b16 if (self.b16 is not None and _PRECISION == "bf16") else self.f32
@@ -350,7 +356,7 @@ class Encoder(_Cached):
         x = Act(y32, y16, B, L)
         if rec:
             y0, ln, lin = x, self.layer_norm_in, self.linear_in
-            need_dx = getattr(x_in, "needs_grad", False)
+            need_dx = x_in.needs_grad
 
             def bw():
                 ds, ds16 = ops.add_layernorm_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
@@ -395,28 +401,76 @@ class Conv2dSubsample(_Cached):
     def _impl(self, feats, feat_lengths):
         B, T, D = feats.shape
         n = self.n_layers
+        F = self.d_conv_out
         tl = T
         for _ in range(n):
             tl = int(math.ceil(tl / 2.0))
         tneed, fneed = [0] * n, [0] * n
-        tneed[n - 1], fneed[n - 1] = tl, self.d_conv_out
+        tneed[n - 1], fneed[n - 1] = tl, F
         for i in range(n - 2, -1, -1):
             tneed[i], fneed[i] = 2 * tneed[i + 1] + 1, fneed[i + 1] + 2
+        feats = feats.float().contiguous()
         w0, b0 = self._conv_params(0)
-        y = ops.conv_sub0(feats.float(), w0.detach().float().contiguous(), b0.detach().float().contiguous(), _cdtype(),
-                          tneed[0], fneed[0])
-        if n == 1:
-            y = y.permute(0, 1, 3, 2).reshape(B, tl, 32 * self.d_conv_out).contiguous()
+        ys = [ops.conv_sub0(feats, w0.detach().float().contiguous(), b0.detach().float().contiguous(), _cdtype(), tneed[0], fneed[0])]
         for i in range(1, n):
             w, b = self._conv_params(i)
-            y = ops.conv_sub1(y, w.detach().float().contiguous(), b.detach().float().contiguous(), tneed[i], fneed[i],
-                              last=(i == n - 1))
-        out = ops.gemm_nt(y.view(B * tl, 32 * self.d_conv_out), self._w("aff", (self.affine.weight,)),
-                          self._b("baff", (self.affine.bias,)))
+            ys.append(ops.conv_sub1(ys[-1], w.detach().float().contiguous(), b.detach().float().contiguous(), tneed[i], fneed[i],
+                                    last=False))
+        # the last layer stays channel-LAST [B,tl,F,32]; the reference's [B,T,C*D] flattening (conv_encoder.py:108, column c*F+f) is
+        # absorbed by permuting the affine weight's columns to f*32+c once (a derived weight)
+        aff = self.affine
+
+        def perm_w():
+            w = aff.weight.detach().view(-1, 32, F).permute(0, 2, 1).reshape(-1, F * 32).contiguous()
+            return ops.cast_bf16(w) if _PRECISION == "bf16" else w.float()
+
+        wp = self._derived("aff_perm", (aff.weight,), perm_w)
+        y_last = ys[-1].view(B * tl, F * 32)
+        out = ops.gemm_nt(y_last, wp, self._b("baff", (aff.bias,)))
         lens = feat_lengths.to(feats.device)
         for _ in range(n):
             lens = torch.div(lens + 1, 2, rounding_mode="floor")  # == ceil(len / 2) for non-negative ints
-        return Act(out, None, B, tl), lens.to(torch.int32)
+        act = Act(out, None, B, tl)
+        act.needs_grad = True
+        if _TAPE is not None:
+            self._record_bw(feats, ys, tneed, fneed, act, wp, y_last)
+        return act, lens.to(torch.int32)
+
+    def _record_bw(self, feats, ys, tneed, fneed, act, wp, y_last):
+        n, F, aff = self.n_layers, self.d_conv_out, self.affine
+        B, T, D = feats.shape
+        convs = [getattr(self.conv, "subsample/conv{}".format(i)) for i in range(n)]
+
+        def bw():
+            d_out = act.grad
+            act.grad = None
+            d = d_out.shape[1]
+            dwp = ops.gemm_tn(d_out, y_last)                                        # [d, F*32] in the permuted column order
+            aff.weight.grad.view(d, 32, F).add_(dwp.view(d, F, 32).permute(0, 2, 1))
+            ops.colsum(d_out, out=aff.bias.grad, accumulate=True)
+            dy = ops.gemm_nn(d_out, wp, out_dtype=torch.bfloat16, relu_mask=y_last)  # [M, F*32] = channel-last d(y_last), ReLU applied
+            for i in range(n - 1, 0, -1):
+                cv = convs[i]
+                tout, fout = tneed[i], fneed[i]
+                dy2 = dy.view(-1, 32)
+                col = ops.conv_im2col(ys[i - 1], 32, tout, fout, 288, torch.bfloat16)
+                dwm = ops.gemm_tn(dy2, col)                                         # [co, tap*32 + ci]
+                cv.weight.grad.add_(dwm.view(32, 9, 32).permute(0, 2, 1).reshape(32, 32, 3, 3))
+                ops.colsum(dy2, out=cv.bias.grad, accumulate=True)
+                wm = self._derived("wm%d" % i, (cv.weight,),
+                                   lambda cv=cv: ops.cast_bf16(cv.weight.detach().permute(0, 2, 3, 1).reshape(32, 288).contiguous()))
+                dcol = ops.gemm_nn(dy2, wm, out_dtype=torch.bfloat16)
+                dy = ops.conv_col2im_relu(dcol, ys[i - 1], tout, fout)              # [B,Tin,Fin,32], masked by relu'(y_{i-1})
+            dy2 = dy.view(-1, 32)
+            col0 = ops.conv_im2col(feats.view(B, T, D, 1), 1, tneed[0], fneed[0], 12, torch.float32)
+            dw0 = ops.gemm_tn(dy2, col0)                                            # [32, 12]; taps in columns 0..8
+            convs[0].weight.grad.view(32, 9).add_(dw0[:, :9])
+            ops.colsum(dy2, out=convs[0].bias.grad, accumulate=True)
+
+        params = [aff.weight, aff.bias]
+        for cv in convs:
+            params += [cv.weight, cv.bias]
+        _TAPE.push(bw, params)
 
     def forward(self, feats, feat_lengths):
         a, lens = self._impl(feats, feat_lengths)

@@ -406,3 +406,20 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None)
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32
     check(lib().asr_adam_step(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(beta1), float(beta2),
                               float(eps), int(step), float(grad_scale)), "asr_adam_step")
+
+
+def conv_im2col(x, C, Tout, Fout, ldc, out_dtype):
+    """x channel-last [B,Tin,Fin,C] (f32 or bf16) -> patch matrix [B*Tout*Fout, ldc] (columns 9*C.. zero)."""
+    _req_cuda(x)
+    B, Tin, Fin = x.shape[0], x.shape[1], x.shape[2]
+    col = torch.empty((B * Tout * Fout, ldc), device=x.device, dtype=out_dtype)
+    check(lib().asr_conv_im2col(_stream(), _p(x), dtype_code(x), C, _p(col), dtype_code(col), ldc, B, Tin, Fin, Tout, Fout), "asr_conv_im2col")
+    return col
+
+
+def conv_col2im_relu(dcol, y, Tout, Fout):
+    """dcol bf16 [B*Tout*Fout, 288(+pad)], y bf16 [B,Tin,Fin,32] (forward output, ReLU mask) -> dx bf16 [B,Tin,Fin,32]."""
+    B, Tin, Fin, _ = y.shape
+    dx = torch.empty_like(y)
+    check(lib().asr_conv_col2im_relu(_stream(), _p(dcol), dcol.stride(0), _p(y), _p(dx), B, Tin, Fin, Tout, Fout), "asr_conv_col2im_relu")
+    return dx

@@ -179,6 +179,7 @@ class Trainer:
         self.step_num += 1
         ops.adam_step(self.fp.flat, self.fp.grad, self.m, self.v, self.lr(), self.betas[0], self.betas[1], self.eps, self.step_num,
                       grad_scale=1.0 / self.world, p16=self.fp.flat16)
+        modules.bump_param_epoch()     # derived (re-laid-out) weights are rebuilt from the new parameters on next use
 
     def step(self, feats, lens, targets):
         """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync)."""

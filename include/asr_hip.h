@@ -135,6 +135,14 @@ int asr_conv_sub0_fwd(void* stream, const float* feats, const float* w0, const f
 int asr_conv_sub1_fwd(void* stream, const void* x, const float* w, const float* b, void* y, int dtype,
                       int B, int Tin, int Fin, int Tout, int Fout, int last);
 
+/* Backward helpers for the conv layers (their gradients run on asr_gemm_tn / asr_gemm_nn over an explicit patch matrix):
+ * im2col: col[(b,t,f), tap*C + c] = x[b, 2t+kh, f+kw, c] for the 3x3 stride-(2,1) conv (zero outside x; pad columns zeroed),
+ * x channel-last [B,Tin,Fin,C];  col2im_relu: dx[b,ti,fi,:] = (y > 0) * gather-sum of dcol (bf16, 32 channels). */
+int asr_conv_im2col(void* stream, const void* x, int x_dtype, int C, void* col, int col_dtype, int ldc, int B, int Tin, int Fin,
+                    int Tout, int Fout);
+int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y, void* dx, int B, int Tin, int Fin, int Tout,
+                         int Fout);
+
 /* ------------------------------------------------------------------------------------------------------------
  * CTC loss (loss.py:41-43 / ctcModel/loss.py:9-11: F.log_softmax(dim=-1) -> F.ctc_loss(blank=V-1)).
  * logits f32 [B,L,V] with row stride ldl (elements) and batch stride L*ldl; in_len int32 [B]; targets int64

@@ -88,3 +88,38 @@ def test_loss_decreases_over_steps(golden_dir):
             first = float(ctc) + float(ce)
     last = float(ctc) + float(ce)
     assert last < 0.7 * first, (first, last)
+
+
+def test_conv_ctc_transformer_gradients_match_reference(golden_dir):
+    """S2-family model (Conv2dSubsample front-end): conv / affine / encoder / decoder gradients vs the reference (G0)."""
+    import argparse
+    z = np.load(os.path.join(golden_dir, "g0_conv_ctc_transformer.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    cfg = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")}
+    model = asr_amd.Conv_CTC_Transformer.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    model = model.to(DEV).eval()
+    asr_amd.set_precision("bf16")
+    tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    tr.fp.grad.zero_()
+    ctc, ce, state = tr.forward_loss(x, lens, tg)
+    tr.backward(state)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=5e-3)
+    np.testing.assert_allclose(float(ce), z["ce_loss_s01"], rtol=5e-3)
+    params = dict(model.named_parameters())
+    for key in [k for k in z.files if k.startswith("grad:")]:
+        name = key[5:]
+        ref, got = z[key], params[name].grad.float().cpu().numpy()
+        err, rn = np.linalg.norm(got - ref), np.linalg.norm(ref)
+        assert err < 6e-2 * rn or err < 5e-3, (name, err, rn)
+    # every parameter's gradient norm (the fixture stores all of them, sorted by name)
+    names = str(z["grad_names"]).split("|")
+    for name, rn in zip(names, z["grad_norms"]):
+        gn = float(params[name].grad.norm())
+        assert abs(gn - rn) < 8e-2 * rn + 5e-3, (name, gn, rn)
+    # and a few optimizer steps run end to end
+    for _ in range(3):
+        c2, e2 = tr.step(x, lens, tg)
+    assert np.isfinite(float(c2)) and np.isfinite(float(e2))
