@@ -559,13 +559,21 @@ def _vocab_proj(mod, key, weight, x):
     w16 = mod._w(key, (weight,))
     logits = ops.gemm_nt(x.mma(), w16, None)
     if _TAPE is not None:
-        slot = {"g": None}
+        slot = {"g": None, "shape": tuple(logits.shape)}
         mod.__dict__.setdefault("_grad_slots", {})[key] = slot
 
         def bw():
             g = slot["g"]
+            V = g.shape[-1]
+            rows = g.numel() // V
+            ok = (g.dtype == torch.float32 and g.stride(-1) == 1 and g.stride(-2) % 8 == 0 and g.data_ptr() % 16 == 0 and
+                  (g.dim() == 2 or g.stride(0) == g.shape[1] * g.stride(1)))
+            if not ok:   # a gradient that did not come from the fused loss kernels: re-home it into a zero-padded, aligned buffer
+                buf = torch.zeros((rows, (V + 7) // 8 * 8), device=g.device, dtype=torch.float32)
+                buf[:, :V].copy_(g.reshape(rows, V))
+                g = buf[:, :V]
             Vp = g.stride(-2)
-            g2 = torch.as_strided(g, (g.numel() // g.shape[-1], g.shape[-1]), (Vp, 1), g.storage_offset())
+            g2 = torch.as_strided(g, (rows, V), (Vp, 1), g.storage_offset())
             ops.gemm_tn(g2, x.mma(), out=weight.grad, accumulate=True)
             x.grad = ops.gemm_nn(g2, w16, addend=x.grad)
             slot["g"] = None
@@ -669,6 +677,65 @@ class Decoder_CIF(_Cached):
 
 
 # ------------------------------------------------------------------------------------------------------------
+class _TapeFn(torch.autograd.Function):
+    """Bridges torch.autograd to the HIP backward tape: forward records the tape; backward seeds the two logits gradients,
+    replays the tape (HIP kernels write into a flat scratch gradient buffer laid out like the trainer's) and returns one
+    gradient per parameter, so `loss.backward()` + any torch optimizer work exactly as with the reference's modules."""
+
+    @staticmethod
+    def forward(ctx, model, run, holder, *params):
+        with torch.no_grad(), record() as tape:
+            ctc2d, logits3d, extra = run()
+        holder["extra"] = extra
+        ctx.model, ctx.tape, ctx.params = model, tape, params
+        outs = tuple(t for t in (ctc2d, logits3d) if t is not None)
+        ctx.has_ctc = ctc2d is not None
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from .trainer import _param_order
+        model, tape, params = ctx.model, ctx.tape, ctx.params
+        gouts = list(gouts)
+        g_ctc = gouts.pop(0) if ctx.has_ctc else None
+        g_log = gouts.pop(0)
+        order = _param_order(model)
+        offs, n = {}, 0
+        for p in order:
+            offs[id(p)] = n
+            n += p.numel()
+        dev = order[0].device
+        scratch = torch.zeros((n + 63) // 64 * 64, device=dev, dtype=torch.float32)
+        saved = []
+        for p in order:
+            saved.append((p, p.grad, getattr(p, "_asr_off", None), getattr(p, "_asr_gflat", None)))
+            off = offs[id(p)]
+            p.grad = scratch[off:off + p.numel()].view(p.shape)
+            p._asr_off, p._asr_gflat = off, scratch
+        try:
+            with torch.no_grad():
+                if ctx.has_ctc:
+                    slot = model._grad_slots["ctc"]
+                    slot["g"] = g_ctc if g_ctc is not None else torch.zeros(slot["shape"], device=dev)
+                slot = model.decoder._grad_slots["prj"]
+                slot["g"] = g_log if g_log is not None else torch.zeros(slot["shape"], device=dev)
+                tape.backward()
+            grads = tuple(p.grad.clone() if False else p.grad for p in params)
+        finally:
+            for p, g, off, gf in saved:
+                p.grad = g
+                if off is None:
+                    del p._asr_off, p._asr_gflat
+                else:
+                    p._asr_off, p._asr_gflat = off, gf
+        return (None, None, None) + grads
+
+
+def _autograd_wanted(model):
+    return (torch.is_grad_enabled() and _TAPE is None and _PRECISION == "bf16" and
+            any(p.requires_grad for p in model.parameters()))
+
+
 def _xavier_all(model):
     for p in model.parameters():
         if p.dim() > 1:
@@ -685,10 +752,24 @@ class Transformer(_Cached):
             raise NotImplementedError("spec_aug is a train-time augmentation outside the hot path (SURVEY.md §2 row 9)")
         _xavier_all(self)
 
+    def _taped(self, run):
+        """run() -> (ctc_logits2d or None, logits3d, extra); returns the same with autograd attached when wanted."""
+        if not _autograd_wanted(self):
+            return run()
+        holder = {}
+        params = [p for p in self.parameters() if p.requires_grad]
+        outs = _TapeFn.apply(self, run, holder, *params)
+        if len(outs) == 2:
+            return outs[0], outs[1], holder["extra"]
+        return None, outs[0], holder["extra"]
+
     def forward(self, features, len_features, padded_target):
-        lens = ops.as_i32(len_features, features.device)
-        enc = self.encoder._impl(_act(features), lens)
-        logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
+        def run():
+            lens = ops.as_i32(len_features, features.device)
+            enc = self.encoder._impl(_act(features), lens)
+            logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
+            return None, logits, targets_eos
+        _, logits, targets_eos = self._taped(run)
         return logits, targets_eos
 
 
@@ -703,11 +784,16 @@ class CTC_Transformer(Transformer):
         return _vocab_proj(self, "ctc", self.ctc_fc.weight, enc)
 
     def forward(self, features, len_features, padded_target):
-        lens = ops.as_i32(len_features, features.device)
-        enc = self.encoder._impl(_act(features), lens)
-        ctc_pred = self._ctc_logits(enc)
-        pred = self.decoder._impl(padded_target, enc, lens)
-        return len_features, ctc_pred.view(enc.B, enc.L, -1), pred
+        B, L = features.shape[0], features.shape[1]
+
+        def run():
+            lens = ops.as_i32(len_features, features.device)
+            enc = self.encoder._impl(_act(features), lens)
+            ctc_pred = self._ctc_logits(enc)
+            logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
+            return ctc_pred, logits, targets_eos
+        ctc_pred, logits, targets_eos = self._taped(run)
+        return len_features, ctc_pred.view(B, L, -1), (logits, targets_eos)
 
 
 class Conv_CTC_Transformer(CTC_Transformer):
@@ -718,11 +804,14 @@ class Conv_CTC_Transformer(CTC_Transformer):
         self.conv_encoder = conv_encoder
 
     def forward(self, features, len_features, targets, spec_aug_cfg=False):
-        conv, len_sequence = self.conv_encoder._impl(features, len_features)
-        enc = self.encoder._impl(conv, len_sequence)
-        ctc_logits = self._ctc_logits(enc)
-        logits, targets_eos = self.decoder._impl(targets, enc, len_sequence)
-        return ctc_logits.view(enc.B, enc.L, -1), len_sequence, logits, targets_eos
+        def run():
+            conv, len_sequence = self.conv_encoder._impl(features, len_features)
+            enc = self.encoder._impl(conv, len_sequence)
+            ctc_logits = self._ctc_logits(enc)
+            logits, targets_eos = self.decoder._impl(targets, enc, len_sequence)
+            return ctc_logits, logits, (targets_eos, len_sequence, enc.B, enc.L)
+        ctc_logits, logits, (targets_eos, len_sequence, B, L) = self._taped(run)
+        return ctc_logits.view(B, L, -1), len_sequence, logits, targets_eos
 
     @classmethod
     def create_model(cls, args):

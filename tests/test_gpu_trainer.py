@@ -123,3 +123,39 @@ def test_conv_ctc_transformer_gradients_match_reference(golden_dir):
     for _ in range(3):
         c2, e2 = tr.step(x, lens, tg)
     assert np.isfinite(float(c2)) and np.isfinite(float(e2))
+
+
+def test_autograd_drop_in_matches_trainer_and_reference(golden_dir):
+    """The reference's own loop shape (solver.py:83-93): model(...) -> cal_ctc_ce_loss -> loss.backward() -> torch optimizer."""
+    z, sd, model = build(golden_dir)
+    asr_amd.set_precision("bf16")
+    model.train()
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    l, ctc_logits, (logits, teos) = model(x, lens, tg)
+    assert ctc_logits.requires_grad and logits.requires_grad
+    ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+    loss = ctc + ce
+    opt.zero_grad()
+    loss.backward()
+    worst = 0.0
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        ref = z["grad:" + name].astype(np.float32)
+        got = p.grad.float().cpu().numpy()
+        err, rn = np.linalg.norm(got - ref), np.linalg.norm(ref)
+        assert err < 6e-2 * rn or err < 5e-3, (name, err, rn)
+        worst = max(worst, err / max(rn, 1e-3))
+    first = float(loss)
+    for _ in range(20):
+        opt.step()
+        l, ctc_logits, (logits, teos) = model(x, lens, tg)
+        ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+        loss = ctc + ce
+        opt.zero_grad()
+        loss.backward()
+    assert float(loss) < 0.8 * first, (first, float(loss))
+    # no_grad / eval inference still takes the plain path
+    with torch.no_grad():
+        l, c2, (lg2, _) = model(x, lens, tg)
+    assert not c2.requires_grad
