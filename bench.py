@@ -24,6 +24,30 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_train_s1.json")   # rocprofv3 --pmc passes, tools/pmc_summary.py
+
+
+def pmc_traffic(op_name):
+    """HBM bytes per launch of the kernel(s) behind a bench op, from the committed PMC summary (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same bench; FETCH doubled per MI355X_MICROARCH.md §HBM).  None when unknown."""
+    if not os.path.exists(PMC_FILE):
+        return None
+    pmc = json.load(open(PMC_FILE))
+    B, T, h = CFG["B"], CFG["T"], CFG["n_head"]
+    table = {
+        "attention_bwd_dq[B%d h%d %dx%d]" % (B, h, T, T): ["attn_bwd_dq_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
+        "attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, T, T): ["attn_bwd_dkv_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
+        "gemm_nn[%dx%dx%d]" % (B * T, CFG["d_inner"], CFG["d_model"]): ["gemm_nn_kernel|grid=%d" % (((B * T + 127) // 128) * (CFG["d_inner"] // 128) * 256)],
+        "gemm_nt[%dx%dx%d]" % (B * T, CFG["d_inner"], CFG["d_model"]): ["gemm_nt_kernel|grid=%d" % (((B * T + 127) // 128) * (CFG["d_inner"] // 128) * 256)],
+        "attention_fwd[B%d h%d %dx%d]" % (B, h, T, T): ["attn_fwd_bf16_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
+        "ctc_loss_bwd[B%d L%d V%d U%d]" % (B, T, CFG["vocab_size"], CFG["U"] + 1): ["ctc_grad_kernel|grid=%d" % (64 * B * 256)],
+    }
+    keys = table.get(op_name)
+    if not keys or any(k not in pmc for k in keys):
+        return None
+    return int(sum(pmc[k]["hbm_bytes"] for k in keys))
+
+
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0            # HBM3E spec peak, same table
 
@@ -135,8 +159,6 @@ def main():
         for name, r in prof.items():
             per_ms = r["ms"] / r["calls"]
             hbm = name.startswith(("add_layernorm", "ctc_loss"))
-            if name.startswith("attention_bwd"):
-                r["work"] = r["work"] * 10.0 / 14.0   # roofline on the 5-product (non-recompute) FLOP count, SURVEY.md §8d
             ach = (r["work"] / r["calls"]) / (per_ms * 1e-3) / (1e9 if hbm else 1e12)
             kernels.append(dict(name=name, calls_per_step=r["calls"] / args.steps, ms_per_call=round(per_ms, 4),
                                 ms_per_step=round(r["ms"] / args.steps, 3), bound="hbm" if hbm else "mfma",
@@ -145,9 +167,10 @@ def main():
         dom = kernels[0]
         peak = PEAK_HBM_GBS if dom["bound"] == "hbm" else PEAK_MFMA_BF16_TFLOPS
         roofline = dict(kernel=dom["name"], bound=dom["bound"], achieved=dom["achieved"], peak=peak, unit=dom["unit"],
-                        frac=round(dom["achieved"] / peak, 4), traffic=None,
+                        frac=round(dom["achieved"] / peak, 4), traffic=pmc_traffic(dom["name"]),
                         note="achieved = algorithmic FLOPs (or bytes) per launch / mean launch duration from HIP events "
-                             "on the launch stream; PMC traffic is collected by separate rocprofv3 --pmc passes (profiles/)")
+                             "on the launch stream; traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
+                             "WRITE_SIZE passes (profiles/r1/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 correction)")
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
         what = ("training step: forward + joint CTC/CE loss + backward + grad all-reduce + Adam" if args.mode == "train"

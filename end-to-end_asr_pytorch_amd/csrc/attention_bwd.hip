@@ -303,14 +303,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 }  // namespace
 
-extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                                 const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
-                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale) {
-    ASR_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, ASR_ERR_ARG, "attention_bwd: null pointer");
-    ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd: bad sizes");
+extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                    const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,
+                                    const int32_t* k_len, int causal, float scale) {
+    ASR_REQUIRE(q && k && v && o && d_o && lse && delta && dq, ASR_ERR_ARG, "attention_bwd_dq: null pointer");
+    ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd_dq: bad sizes");
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(o, 16) && asr_aligned(d_o, 16) &&
-                    asr_aligned(dq, 8) && asr_aligned(dk, 8) && asr_aligned(dv, 8) && ldq % 4 == 0 && ldkv % 4 == 0,
-                ASR_ERR_ALIGN, "attention_bwd: alignment");
+                    asr_aligned(dq, 8) && ldq % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dq: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *O = (const bf16_t*)o, *dO = (const bf16_t*)d_o;
 #define LAUNCH_DQ(NW)                                                                                                            \
@@ -327,6 +326,19 @@ extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, con
     else if (Lq <= 64) LAUNCH_DQ(2);
     else LAUNCH_DQ(4);
 #undef LAUNCH_DQ
+    ASR_LAUNCH_CHECK("attention_bwd_dq");
+    return 0;
+}
+
+extern "C" int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void* v, const void* d_o, const float* lse,
+                                     const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
+                                     const int32_t* k_len, int causal) {
+    ASR_REQUIRE(q && k && v && d_o && lse && delta && dk && dv, ASR_ERR_ARG, "attention_bwd_dkv: null pointer");
+    ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd_dkv: bad sizes");
+    ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(d_o, 16) && asr_aligned(dk, 8) &&
+                    asr_aligned(dv, 8) && ldkv % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dkv: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)d_o;
     const int k_tiles = (Lk + 127) / 128;
     if (causal)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk,
@@ -334,6 +346,13 @@ extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, con
     else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk,
                            (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles);
-    ASR_LAUNCH_CHECK("attention_bwd");
+    ASR_LAUNCH_CHECK("attention_bwd_dkv");
     return 0;
+}
+
+extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                 const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
+                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale) {
+    if (int rc = asr_attention_bwd_dq(stream, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, causal, scale)) return rc;
+    return asr_attention_bwd_dkv(stream, q, k, v, d_o, lse, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, causal);
 }

@@ -4,7 +4,8 @@
 // HBM-bound design: the [B,L,V] logits are streamed exactly once forward (row log-sum-exp + gather
 // of the 2U+1 extended-label log-probs into a compact [B,L,S] table) and once backward (softmax recomputed from the
 // saved row lse; gradient written once).  The T-long alpha / beta recursions never touch the V axis: they run on the
-// compact table, ONE WAVEFRONT per utterance and no LDS / no barriers: lane i owns the (blank, label) state pairs
+// compact table, TWO WAVEFRONTS per utterance (alpha forward, beta backward, meeting in the middle - each dependent chain is T/2
+// long for the loss and T/2 more for the gradient) with no barriers inside the chains: lane i owns the (blank, label) state pairs
 // i*NP..i*NP+NP-1, so a time step needs exactly one neighbour value (the previous lane's last label state), fetched
 // with a DPP wave shift; the table is kept in the base-2 log domain so log-sum-exp is v_exp_f32 / v_log_f32 directly;
 // table rows are prefetched 8 steps ahead into registers, leaving ~a dozen dependent VALU ops per step on the chain.
@@ -33,9 +34,11 @@ __global__ void ctc_prep_kernel(const int64_t* __restrict__ targets, int B, int 
     tgt_len[b] = n;
 }
 
-// compact-table row stride: 2U+1 extended states rounded up to 16 floats (64-byte rows; a multiple of every lane's
-// 2*NP-float slice, so a lane is either fully inside a row or fully outside)
-__host__ __device__ __forceinline__ int ctc_row_stride(int Umax) { return ((2 * Umax + 1 + 15) / 16) * 16; }
+// compact-table row stride = 128 * NP floats, NP = state pairs per lane of the recursion kernel (1, 2, 4 or 8): every lane of the
+// recursion wave owns an in-bounds 2*NP-float slice of each row, so its loads/stores need no predicate and a row is written
+// by one fully coalesced wave store (512 B for NP = 1).  Columns >= 2U+1 hold -inf.
+__host__ __device__ __forceinline__ int ctc_np(int Umax) { return Umax + 1 <= 64 ? 1 : (Umax + 1 <= 128 ? 2 : (Umax + 1 <= 256 ? 4 : 8)); }
+__host__ __device__ __forceinline__ int ctc_row_stride(int Umax) { return 128 * ctc_np(Umax); }
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -117,14 +120,13 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
     }
 }
 
+constexpr float NEG_BIG = -1.0e30f;   // max(m, NEG_BIG) keeps exp2(x - m) = 0 and m + log2(0) = -inf when every input is -inf
 __device__ __forceinline__ float l2se2(float a, float b) {
-    const float m = fmaxf(a, b);
-    const float ms = (m == -INFINITY) ? 0.f : m;
+    const float ms = fmaxf(fmaxf(a, b), NEG_BIG);
     return ms + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - ms) + __builtin_amdgcn_exp2f(b - ms));
 }
 __device__ __forceinline__ float l2se3(float a, float b, float c) {
-    const float m = fmaxf(fmaxf(a, b), c);
-    const float ms = (m == -INFINITY) ? 0.f : m;
+    const float ms = fmaxf(fmaxf(fmaxf(a, b), c), NEG_BIG);
     return ms + __builtin_amdgcn_logf((__builtin_amdgcn_exp2f(a - ms) + __builtin_amdgcn_exp2f(b - ms)) + __builtin_amdgcn_exp2f(c - ms));
 }
 // occupancy of a state = alpha * beta / y / p(l|x) (beta includes y_t like aten's); dead states (lp = -inf) give 0
@@ -138,152 +140,198 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {  // lane i <- lan
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0xff800000, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-// alpha (forward) / beta+occupancy (backward) recursion: one wavefront per utterance, lane i owns state pairs
-// j = i*NP + p (p < NP): e = state 2j (blank), o = state 2j+1 (label j).  All values are base-2 logs.
-template <int NP, bool BACKWARD>
-__global__ __launch_bounds__(64) void ctc_recursion_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
-                                                           const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
-                                                           int L, int Umax, float* __restrict__ alpha, float* __restrict__ nll) {
-    constexpr int PF = NP <= 2 ? 8 : (NP == 4 ? 4 : 2);  // time steps prefetched per group (register budget)
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int Sp = ctc_row_stride(Umax);
-    const int U = tgt_len[b];
-    const int Tb = min(in_len[b], L);
-    if (Tb <= 0) {
-        if (!BACKWARD && lane == 0) nll[b] = (U == 0) ? 0.f : INFINITY;
-        return;
-    }
-    const int j0 = lane * NP;
-    bool skip[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int j = j0 + p;
-        const int64_t* tg = targets + (int64_t)b * Umax;
-        if (!BACKWARD) skip[p] = (j >= 1 && j < U) && (tg[j] != tg[j - 1]);       // s-2 -> s, s = 2j+1
-        else skip[p] = (j + 1 < U) && (tg[j] != tg[j + 1]);                         // s -> s+2
-    }
-    // this lane's slice of a table row: 2*NP floats at column 2*j0 (clamped so dead lanes stay in bounds)
-    const bool inb = (2 * j0 + 2 * NP <= Sp);
-    const int col = inb ? 2 * j0 : 0;
-    const float* lp = lp_ext + (int64_t)b * L * Sp + col;
-    float* al = alpha + (int64_t)b * L * Sp + col;
-    const float nll2 = BACKWARD ? nll[b] * LOG2E : 0.f;
-
-    auto load_row = [&](const float* base, int t, float (&dst)[2 * NP], float fill) {
+// One direction of the recursion as a register-resident chain.  lane i owns state pairs j = i*NP + p: e = state 2j (blank),
+// o = state 2j+1 (label j); all values are base-2 logs.  DIRB = false: alpha (t increasing), true: beta (t decreasing).
+// OCC = false: the new state row is stored;  OCC = true: the OTHER direction's stored row is read and replaced in place by the
+// occupancies exp2(alpha + beta - lp + nll2).  Row t lives at al + row_of(t) * Sp where row_of(special_t) = special_row.
+template <int NP, bool DIRB, bool OCC>
+__device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* __restrict__ al, int t_first, int nsteps, float (&e)[NP],
+                                          float (&o)[NP], const float (&skip_add)[NP], float nll2, int special_t, int special_row) {
+    constexpr int PF = NP <= 2 ? 8 : (NP == 4 ? 4 : 2);
+    constexpr int Sp = 128 * NP;
+    if (nsteps <= 0) return;
+    auto row_of = [&](int t) { return t == special_t ? special_row : t; };
+    auto load_row = [&](const float* base, int64_t row, float (&dst)[2 * NP]) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            if (inb) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(base + (int64_t)t * Sp + 2 * q);
-                dst[2 * q] = v[0];
-                dst[2 * q + 1] = v[1];
-            } else {
-                dst[2 * q] = fill;
-                dst[2 * q + 1] = fill;
-            }
+            const f32x2 v = *reinterpret_cast<const f32x2*>(base + row * Sp + 2 * q);
+            dst[2 * q] = v[0];
+            dst[2 * q + 1] = v[1];
         }
     };
-
-    float e[NP], o[NP];
-    {
-        const int t = BACKWARD ? Tb - 1 : 0;
-        float r[2 * NP];
-        load_row(lp, t, r, -INFINITY);
+    auto step = [&](int t, const float (&cf)[2 * NP], const float (&ca)[2 * NP]) {
+        float en[NP], on[NP];
+        if (!DIRB) {
+            const float left = dpp_from_prev_lane(o[NP - 1]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float ol = (p == 0) ? left : o[p - 1];
+                en[p] = l2se2(e[p], ol) + cf[2 * p];
+                on[p] = l2se3(o[p], e[p], ol + skip_add[p]) + cf[2 * p + 1];
+            }
+        } else {
+            const float re = dpp_from_next_lane(e[0]);
+            const float ro = dpp_from_next_lane(o[0]);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const float er = (p == NP - 1) ? re : e[p + 1];
+                const float orr = (p == NP - 1) ? ro : o[p + 1];
+                en[p] = l2se2(e[p], o[p]) + cf[2 * p];
+                on[p] = l2se3(o[p], er, orr + skip_add[p]) + cf[2 * p + 1];
+            }
+        }
+        float* dst = al + (int64_t)row_of(t) * Sp;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int j = j0 + p;
-            if (!BACKWARD) {
-                e[p] = (j == 0) ? r[2 * p] : -INFINITY;
-                o[p] = (j == 0) ? r[2 * p + 1] : -INFINITY;     // -inf already when U == 0 (dead state)
-            } else {
-                e[p] = (j == U) ? r[2 * p] : -INFINITY;
-                o[p] = (j == U - 1) ? r[2 * p + 1] : -INFINITY;
-            }
-        }
-        if (inb) {
-            if (!BACKWARD) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) = f32x2{e[p], o[p]};
-            } else {
-                float a[2 * NP];
-                load_row(al, t, a, -INFINITY);
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) =
-                        f32x2{occupancy(a[2 * p], e[p], r[2 * p], nll2), occupancy(a[2 * p + 1], o[p], r[2 * p + 1], nll2)};
-            }
-        }
-    }
-
-    float pf[PF][2 * NP], pa[PF][2 * NP];
-    auto fetch = [&](int step0) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int st = min(step0 + i, Tb - 1);  // clamp: extra rows are loaded but never consumed
-            const int t = BACKWARD ? (Tb - 1 - st) : st;
-            load_row(lp, t, pf[i], -INFINITY);
-            if (BACKWARD) load_row(al, t, pa[i], -INFINITY);
+            e[p] = en[p];
+            o[p] = on[p];
+            if (!OCC)
+                *reinterpret_cast<f32x2*>(dst + 2 * p) = f32x2{e[p], o[p]};
+            else
+                *reinterpret_cast<f32x2*>(dst + 2 * p) =
+                    f32x2{occupancy(ca[2 * p], e[p], cf[2 * p], nll2), occupancy(ca[2 * p + 1], o[p], cf[2 * p + 1], nll2)};
         }
     };
-    fetch(1);
-    for (int st0 = 1; st0 < Tb; st0 += PF) {
+    const int dir = DIRB ? -1 : 1;
+    float pf[PF][2 * NP], pa[PF][2 * NP];
+    auto fetch = [&](int k0) {   // steps k0..k0+PF-1, clamped to the chain (over-fetched rows are never consumed)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int k = min(k0 + i, nsteps - 1);
+            const int t = t_first + dir * k;
+            load_row(lp, t, pf[i]);
+            if (OCC) load_row(al, row_of(t), pa[i]);
+        }
+    };
+    fetch(0);
+    int k0 = 0;
+    for (; k0 + PF <= nsteps; k0 += PF) {
         float cf[PF][2 * NP], ca[PF][2 * NP];
 #pragma unroll
         for (int i = 0; i < PF; ++i)
 #pragma unroll
-            for (int q = 0; q < 2 * NP; ++q) { cf[i][q] = pf[i][q]; ca[i][q] = BACKWARD ? pa[i][q] : 0.f; }
-        if (st0 + PF < Tb) fetch(st0 + PF);
+            for (int q = 0; q < 2 * NP; ++q) { cf[i][q] = pf[i][q]; ca[i][q] = OCC ? pa[i][q] : 0.f; }
+        fetch(k0 + PF);
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int st = st0 + i;
-            if (st < Tb) {  // wave-uniform
-                const int t = BACKWARD ? (Tb - 1 - st) : st;
-                float en[NP], on[NP];
-                if (!BACKWARD) {
-                    const float left = dpp_from_prev_lane(o[NP - 1]);
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const float ol = (p == 0) ? left : o[p - 1];
-                        en[p] = l2se2(e[p], ol) + cf[i][2 * p];
-                        on[p] = l2se3(o[p], e[p], skip[p] ? ol : -INFINITY) + cf[i][2 * p + 1];
-                    }
-                } else {
-                    const float re = dpp_from_next_lane(e[0]);
-                    const float ro = dpp_from_next_lane(o[0]);
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const float er = (p == NP - 1) ? re : e[p + 1];
-                        const float orr = (p == NP - 1) ? ro : o[p + 1];
-                        en[p] = l2se2(e[p], o[p]) + cf[i][2 * p];
-                        on[p] = l2se3(o[p], er, skip[p] ? orr : -INFINITY) + cf[i][2 * p + 1];
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < NP; ++p) { e[p] = en[p]; o[p] = on[p]; }
-                if (inb) {
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        if (!BACKWARD)
-                            *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) = f32x2{e[p], o[p]};
-                        else
-                            *reinterpret_cast<f32x2*>(al + (int64_t)t * Sp + 2 * p) =
-                                f32x2{occupancy(ca[i][2 * p], e[p], cf[i][2 * p], nll2),
-                                      occupancy(ca[i][2 * p + 1], o[p], cf[i][2 * p + 1], nll2)};
-                    }
-                }
-            }
-        }
+        for (int i = 0; i < PF; ++i) step(t_first + dir * (k0 + i), cf[i], ca[i]);
     }
-    if (!BACKWARD) {
-        // log-likelihood = lse(alpha_{T-1}(2U), alpha_{T-1}(2U-1)): e of pair U, o of pair U-1
-        float eU = -INFINITY, oU1 = -INFINITY;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (j0 + p == U) eU = e[p];
-            if (j0 + p == U - 1) oU1 = o[p];
+    for (int i = 0; i < PF; ++i) {
+        float ca[2 * NP];
+#pragma unroll
+        for (int q = 0; q < 2 * NP; ++q) ca[q] = OCC ? pa[i][q] : 0.f;
+        if (k0 + i < nsteps) step(t_first + dir * (k0 + i), pf[i], ca);
+    }
+}
+
+// Meet-in-the-middle CTC recursion: one workgroup (2 wavefronts) per utterance.  Wave 0 runs alpha forward, wave 1 runs beta
+// backward, so the T-long dependent chain is cut in half for the loss (PHASE 0: they meet at mid = T/2 and
+// p(l|x) = sum_s alpha_mid(s) beta_mid(s) / y_mid(s)) and again for the gradient (PHASE 1: each wave continues over the other
+// half, turning the stored rows of the opposite direction into occupancies in place).  Workspace rows per utterance: L + 1
+// (rows 0..mid hold alpha, mid+1..T-1 hold beta, row L holds beta_mid).
+template <int NP, int PHASE>
+__global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
+                                                       const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len, int L,
+                                                       int Umax, float* __restrict__ alpha, float* __restrict__ nll) {
+    constexpr int Sp = 128 * NP;
+    __shared__ float xch[64][2 * NP];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int U = tgt_len[b];
+    const int Tb = min(in_len[b], L);
+    if (Tb <= 0) {
+        if (PHASE == 0 && threadIdx.x == 0) nll[b] = (U == 0) ? 0.f : INFINITY;
+        return;
+    }
+    const int mid = Tb >> 1;
+    const int j0 = lane * NP;
+    const int64_t* tg = targets + (int64_t)b * Umax;
+    float skip_f[NP], skip_b[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int j = j0 + p;
+        skip_f[p] = ((j >= 1 && j < U) && (tg[j] != tg[j - 1])) ? 0.f : -INFINITY;   // s-2 -> s, s = 2j+1
+        skip_b[p] = ((j + 1 < U) && (tg[j] != tg[j + 1])) ? 0.f : -INFINITY;         // s -> s+2
+    }
+    const float* lp = lp_ext + (int64_t)b * L * Sp + 2 * j0;
+    float* al = alpha + (int64_t)b * (L + 1) * Sp + 2 * j0;
+    auto load_row = [&](const float* base, int64_t row, float (&ev)[NP], float (&ov)[NP]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(base + row * Sp + 2 * q);
+            ev[q] = v[0];
+            ov[q] = v[1];
         }
-        eU = wave_max(eU);      // exactly one lane holds a non -inf candidate slot
-        oU1 = wave_max(oU1);
-        if (lane == 0) nll[b] = -l2se2(eU, oU1) * LN2;
+    };
+    auto store_row = [&](int64_t row, const float (&ev)[NP], const float (&ov)[NP]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<f32x2*>(al + row * Sp + 2 * q) = f32x2{ev[q], ov[q]};
+    };
+    float e[NP], o[NP], le[NP], lo[NP];
+
+    if (PHASE == 0) {
+        if (wave == 0) {        // alpha: t = 0 .. mid
+            load_row(lp, 0, le, lo);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                e[p] = (j0 + p == 0) ? le[p] : -INFINITY;
+                o[p] = (j0 + p == 0) ? lo[p] : -INFINITY;
+            }
+            store_row(0, e, o);
+            ctc_chain<NP, false, false>(lp, al, 1, mid, e, o, skip_f, 0.f, -1, 0);
+        } else {                // beta: t = Tb-1 .. mid  (beta_mid goes to row L)
+            load_row(lp, Tb - 1, le, lo);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                e[p] = (j0 + p == U) ? le[p] : -INFINITY;
+                o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
+            }
+            store_row((Tb - 1 == mid) ? L : Tb - 1, e, o);
+            ctc_chain<NP, true, false>(lp, al, Tb - 2, Tb - 1 - mid, e, o, skip_b, 0.f, mid, L);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { xch[lane][2 * p] = e[p]; xch[lane][2 * p + 1] = o[p]; }
+        }
+        __syncthreads();
+        if (wave == 0) {        // log p(l|x) = lse_s( alpha_mid(s) + beta_mid(s) - lp_mid(s) )
+            load_row(lp, mid, le, lo);
+            float v[2 * NP], m = -INFINITY;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                v[2 * p] = (le[p] == -INFINITY) ? -INFINITY : e[p] + xch[lane][2 * p] - le[p];
+                v[2 * p + 1] = (lo[p] == -INFINITY) ? -INFINITY : o[p] + xch[lane][2 * p + 1] - lo[p];
+                m = fmaxf(m, fmaxf(v[2 * p], v[2 * p + 1]));
+            }
+            m = wave_max(m);
+            const float ms = fmaxf(m, NEG_BIG);
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2 * NP; ++q) sum += __builtin_amdgcn_exp2f(v[q] - ms);
+            sum = wave_sum(sum);
+            if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
+        }
+    } else {
+        const float nll2 = nll[b] * LOG2E;
+        float ae[NP], ao[NP];
+        if (wave == 0) {
+            load_row(al, mid, e, o);                    // alpha_mid: start state of the forward continuation
+        } else {
+            load_row(al, L, e, o);                      // beta_mid
+            load_row(al, mid, ae, ao);                  // alpha_mid, for the occupancy of row mid
+            load_row(lp, mid, le, lo);
+        }
+        __syncthreads();                                // wave 0 has read row mid before wave 1 overwrites it
+        if (wave == 0) {
+            ctc_chain<NP, false, true>(lp, al, mid + 1, Tb - 1 - mid, e, o, skip_f, nll2, -1, 0);
+        } else {
+            float oe[NP], oo[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                oe[p] = occupancy(ae[p], e[p], le[p], nll2);
+                oo[p] = occupancy(ao[p], o[p], lo[p], nll2);
+            }
+            store_row(mid, oe, oo);
+            ctc_chain<NP, true, true>(lp, al, mid - 1, mid, e, o, skip_b, nll2, -1, 0);
+        }
     }
 }
 
@@ -324,7 +372,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         const float* x = logits + row * ldl;
         for (int sidx = tid; sidx < Sb; sidx += 256) {
             const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
-            atomicAdd(&corr[lab], occ[row * Sfull + sidx]);
+            atomicAdd(&corr[lab], occ[((int64_t)b * (L + 1) + t) * Sfull + sidx]);
         }
         __syncthreads();
         const float l = lse[row];
@@ -357,18 +405,15 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
 }
 
-template <bool BACKWARD>
+template <int PHASE>
 int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, const int64_t* targets, const int32_t* tgt_len, int B,
                      int L, int Umax, float* alpha, float* nll) {
-    // U <= 64*NP - 1 state pairs + the final blank must fit: pairs 0..U  ->  U + 1 <= 64 * NP
-    if (Umax + 1 <= 64)
-        hipLaunchKernelGGL((ctc_recursion_kernel<1, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
-    else if (Umax + 1 <= 128)
-        hipLaunchKernelGGL((ctc_recursion_kernel<2, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
-    else if (Umax + 1 <= 256)
-        hipLaunchKernelGGL((ctc_recursion_kernel<4, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
-    else
-        hipLaunchKernelGGL((ctc_recursion_kernel<8, BACKWARD>), dim3(B), dim3(64), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll);
+    switch (ctc_np(Umax)) {
+        case 1: hipLaunchKernelGGL((ctc_mitm_kernel<1, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
+        case 2: hipLaunchKernelGGL((ctc_mitm_kernel<2, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
+        case 4: hipLaunchKernelGGL((ctc_mitm_kernel<4, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
+        default: hipLaunchKernelGGL((ctc_mitm_kernel<8, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
+    }
     return 0;
 }
 
@@ -387,7 +432,7 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     hipLaunchKernelGGL(ctc_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, targets, B, Umax, tgt_len);
     hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, tgt_len, L, V, Umax, blank,
                        lse, lp_ext);
-    launch_recursion<false>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll);
+    launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll);
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
 }
@@ -408,7 +453,7 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE((size_t)V * sizeof(float) <= 64 * 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: V=%d exceeds the LDS occupancy vector", V);
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_bwd: Umax too long");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_recursion<true>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, const_cast<float*>(nll));
+    launch_recursion<1>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, const_cast<float*>(nll));
     int rb = (2048 + B - 1) / B;  // ~2048 workgroups in flight
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;

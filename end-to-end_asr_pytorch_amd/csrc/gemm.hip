@@ -7,6 +7,8 @@
 // (loads of tile k+1 are issued before the MFMAs of tile k) because M/N/K tails need guards and the f32->bf16
 // conversion of activations happens on the way in.  blockIdx is remapped so each XCD walks a contiguous run of
 // tiles (A row-panels are re-read from that XCD's L2 across the N tiles).
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 namespace {
@@ -64,9 +66,13 @@ struct EpiDense {
         if (m >= M || n0 >= N) return;
         const int nv = min(4, N - n0);
         if (bias) {
+            if (nv == 4 && ((reinterpret_cast<uintptr_t>(bias + n0) & 15) == 0)) {
+                v += *reinterpret_cast<const f32x4*>(bias + n0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < nv) v[i] += bias[n0 + i];
+                for (int i = 0; i < 4; ++i)
+                    if (i < nv) v[i] += bias[n0 + i];
+            }
         }
         if (flags & ASR_GEMM_RELU) {
 #pragma unroll
@@ -238,6 +244,89 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
     }
 }
 
+// ---- LDS-DMA fast path (bf16 x bf16, K % 64 == 0): global_load_lds_dwordx4 writes each 1-KiB piece (8 rows x 128 B) of the
+// A / W tiles straight into LDS - no staging VGPRs, no ds_write - into a DOUBLE-buffered image; the loads of tile k+1 are in
+// flight while tile k is multiplied, and there is one barrier per K-tile.  The DMA destination is lane-linear, so the XOR
+// swizzle is applied to the per-lane SOURCE address (LDS slot p of row r is filled with chunk p ^ (r & 7)) and undone by the
+// same XOR on the fragment reads.  Rows past M / N are clamped to the last valid row (their outputs are never stored).
+template <typename Epi>
+__global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+                                                             int64_t ldw, int M, int N, int K, int tiles_n, int nwg, Epi epi) {
+    constexpr int KT = 64, TILE = BM * ROWB;  // 16 KiB per operand tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];   // [buf][A|B]
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+
+    // per-lane source rows for the 4 pieces this wave stages per operand: piece p = wave*4 + i covers tile rows 8p..8p+7
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (wave * 4 + i) + (lane >> 3);
+        const int c = (lane & 7) ^ (row & 7);
+        asrc[i] = A + (int64_t)min(m0 + row, M - 1) * lda + c * 8;
+        wsrc[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* base = smem + buf * 2 * TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * KT),
+                                             (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + kt * KT),
+                                             (__attribute__((address_space(3))) void*)(base + TILE + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    const int nk = K / KT;
+    stage(0, 0);
+    __syncthreads();   // drains the DMA (vmcnt) and publishes tile 0
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const unsigned char* As = smem + cur * 2 * TILE;
+        const unsigned char* Bs = As + TILE;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = g * 4 + q4;
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int arow = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                const int brow = wn * 64 + i * 16 + r16;
+                b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * ROWB + ((chunk ^ (brow & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
+        }
+        __syncthreads();   // next tile landed (the barrier's fence waits for the outstanding LDS-DMA) and `cur` is free to overwrite
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epi.store4(m, n0 + wn * 64 + j * 16 + q4 * 4, acc[i][j]);
+    }
+}
+
 // ---- NN variant (data gradient): C[M,N] = A[M,Kr] . Bm[Kr,N], Bm row-major as the weight is stored ([out,in] with the
 // reduction over `out`).  Same tile / MFMA loop; only the B staging differs: 4(k) x 4(n) register transposes + 8-byte LDS
 // writes build the K-contiguous Bs[n][k] image, so no transposed weight copy ever exists in HBM.  bf16 MFMA only.
@@ -361,8 +450,21 @@ int check_operands(const void* A, int a_dtype, int64_t lda, const void* W, int w
     return 0;
 }
 
+template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
+                                        const Epi& epi) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
+                       reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, nwg, epi);
+    ASR_LAUNCH_CHECK("gemm_nt_glds");
+    return 0;
+}
+
 template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype,
                                      int64_t ldw, int M, int N, int K, const Epi& epi) {
+    static const bool no_glds = getenv("ASR_AMD_NO_GLDS") != nullptr;   // A/B switch for benchmarking the staging paths
+    // (A/B on one MI355X: LDS-DMA double buffering +26 % at K = 2048, -3 % at K = 256 where only 4 k-steps exist and the 64 KB of
+    // LDS lowers residency, so short-K shapes keep the register-staged kernel)
+    if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= 1024) return launch_glds(s, A, lda, W, ldw, M, N, K, epi);
     if (w_dtype == ASR_F32) return launch_gemm<float, float>(s, A, lda, W, ldw, M, N, K, epi);
     if (a_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
@@ -404,6 +506,7 @@ extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t 
     }
     EpiHeads<bf16_t> epi{reinterpret_cast<bf16_t*>(out), proj_stride, bias, L, h, M, N, scale_first};
     if (x_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
+    if (K % 64 == 0 && K >= 1024 && getenv("ASR_AMD_NO_GLDS") == nullptr) return launch_glds(s, X, ldx, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
 }
 

@@ -224,7 +224,7 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None):
     dev = logits.device
     st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
     st.lp_ext = torch.empty((B, L, S), device=dev, dtype=torch.float32)
-    st.alpha = torch.empty((B, L, S), device=dev, dtype=torch.float32)
+    st.alpha = torch.empty((B, L + 1, S), device=dev, dtype=torch.float32)   # +1 row: beta at the meeting point
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
@@ -390,10 +390,16 @@ def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out
     assert q.dtype == torch.bfloat16 and ctx.is_contiguous() and d_ctx.is_contiguous() and d_ctx.dtype == torch.bfloat16
     assert dk_out.stride(0) == dv_out.stride(0) and dq_out.stride(1) == 1 and dk_out.stride(1) == 1
     delta = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32)
-    with _timed("attention_bwd[B%d h%d %dx%d]" % (B, h, Lq, Lk), 14.0 * B * h * 64 * Lq * Lk):
-        check(lib().asr_attention_bwd(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(delta), _p(dq_out),
-                                      dq_out.stride(0), _p(dk_out), _p(dv_out), dk_out.stride(0), B, h, Lq, Lk, _p(k_len),
-                                      1 if causal else 0, float(scale)), "asr_attention_bwd")
+    # two kernels, timed separately (algorithmic FLOPs on the 5-product count 10*B*h*64*Lq*Lk: dq owns dQ + one of the two
+    # shared recomputed products, dkv owns dV, dK + the other)
+    base = float(B) * h * 64 * Lq * Lk
+    with _timed("attention_bwd_dq[B%d h%d %dx%d]" % (B, h, Lq, Lk), 4.0 * base):
+        check(lib().asr_attention_bwd_dq(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(delta), _p(dq_out),
+                                         dq_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, float(scale)),
+              "asr_attention_bwd_dq")
+    with _timed("attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, Lq, Lk), 6.0 * base):
+        check(lib().asr_attention_bwd_dkv(_stream(), _p(q), _p(k), _p(v), _p(d_ctx), _p(lse), _p(delta), _p(dk_out), _p(dv_out),
+                                          dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0), "asr_attention_bwd_dkv")
 
 
 def embed_bwd(ids, dy, demb):

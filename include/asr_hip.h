@@ -87,6 +87,13 @@ int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v,
 int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
                       int Lq, int Lk, const int32_t* k_len, int causal, float scale);
+/* The two kernels of asr_attention_bwd as separate calls (dq first: it also produces delta, which dkv consumes). */
+int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                         const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,
+                         const int32_t* k_len, int causal, float scale);
+int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void* v, const void* d_o, const float* lse,
+                          const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
+                          const int32_t* k_len, int causal);
 
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.
@@ -147,8 +154,8 @@ int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y,
  * CTC loss (loss.py:41-43 / ctcModel/loss.py:9-11: F.log_softmax(dim=-1) -> F.ctc_loss(blank=V-1)).
  * logits f32 [B,L,V] with row stride ldl (elements) and batch stride L*ldl; in_len int32 [B]; targets int64
  * [B,Umax] zero-padded; target length = number of non-zero ids per row (loss.py:40).
- * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L,S] with
- * S = asr_ctc_workspace_stride(Umax) (the 2*Umax+1 extended states rounded up to 16 floats).
+ * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L+1,S] with
+ * S = asr_ctc_workspace_stride(Umax) (>= 2*Umax+1; one 512-byte wave store per row and 64 labels).
  * Outputs: nll f32 [B] (inf for infeasible rows, zero_infinity=False), tgt_len int32 [B].
  */
 int asr_ctc_workspace_stride(int Umax);
