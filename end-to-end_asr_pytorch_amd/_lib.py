@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libasr_hip.so")
 SOURCES = ["common.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
-           "backward.hip"]
+           "backward.hip", "debug_probe.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
@@ -37,6 +37,7 @@ SIGNATURES = {
     "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_conv_sub0_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asr_conv_sub1_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "asr_debug_probe_tr": [_vp, _vp, _i, _i],
     "asr_conv_im2col": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_conv_col2im_relu": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],

@@ -86,3 +86,14 @@ template <> struct Mma<float> {
     }
 };
 
+
+// ---- 4x4 bf16 register transpose on v_perm_b32 ---------------------------------------------------------------
+// rows r[0..3] hold 4 bf16 each (two dwords); column d of the result is { r0[d], r1[d], r2[d], r3[d] } packed the same way.
+// 8 v_perm_b32 instead of ~30 shift/and/or operations; used by every loader that builds a K-contiguous LDS image from
+// row-major data whose reduction index is the slow dimension (V^T, dgrad / wgrad GEMM operands, attention backward tiles).
+__device__ __forceinline__ void transpose4x4_bf16(const u32x2 (&r)[4], u32x2 (&c)[4]) {
+    c[0] = u32x2{__builtin_amdgcn_perm(r[1][0], r[0][0], 0x05040100u), __builtin_amdgcn_perm(r[3][0], r[2][0], 0x05040100u)};
+    c[1] = u32x2{__builtin_amdgcn_perm(r[1][0], r[0][0], 0x07060302u), __builtin_amdgcn_perm(r[3][0], r[2][0], 0x07060302u)};
+    c[2] = u32x2{__builtin_amdgcn_perm(r[1][1], r[0][1], 0x05040100u), __builtin_amdgcn_perm(r[3][1], r[2][1], 0x05040100u)};
+    c[3] = u32x2{__builtin_amdgcn_perm(r[1][1], r[0][1], 0x07060302u), __builtin_amdgcn_perm(r[3][1], r[2][1], 0x07060302u)};
+}

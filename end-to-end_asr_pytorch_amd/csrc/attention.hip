@@ -153,14 +153,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const bf16_t*
         for (int i = 0; i < VBL; ++i) {
             const int id = tid + NTHR * i;
             const int dg = id & 15, kg = id >> 4;
+            u32x2 ct[4];
+            transpose4x4_bf16(vreg[i], ct);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
-                const int w = dd >> 1, sh = (dd & 1) * 16;
-                const unsigned e0 = (vreg[i][0][w] >> sh) & 0xffffu, e1 = (vreg[i][1][w] >> sh) & 0xffffu;
-                const unsigned e2 = (vreg[i][2][w] >> sh) & 0xffffu, e3 = (vreg[i][3][w] >> sh) & 0xffffu;
                 const int row = 4 * dg + dd;  // d index
                 const int off = row * 128 + swz_chunk(row, kg >> 1) + (((kg & 1) ^ ((row >> 4) & 1)) << 3);
-                *reinterpret_cast<u32x2*>(Vt + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+                *reinterpret_cast<u32x2*>(Vt + off) = ct[dd];
             }
         }
     };

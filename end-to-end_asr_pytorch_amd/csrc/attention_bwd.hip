@@ -43,14 +43,13 @@ __device__ __forceinline__ void stage_transposed(unsigned char* dst, const bf16_
             const int r = row0 + 4 * rg + k;
             v[k] = (r < nrows) ? *reinterpret_cast<const u32x2*>(src + (int64_t)r * ld + 4 * cg) : u32x2{0, 0};
         }
+        u32x2 ct[4];
+        transpose4x4_bf16(v, ct);
 #pragma unroll
         for (int dd = 0; dd < 4; ++dd) {
-            const int w = dd >> 1, sh = (dd & 1) * 16;
-            const unsigned e0 = (v[0][w] >> sh) & 0xffffu, e1 = (v[1][w] >> sh) & 0xffffu;
-            const unsigned e2 = (v[2][w] >> sh) & 0xffffu, e3 = (v[3][w] >> sh) & 0xffffu;
             const int row = 4 * cg + dd;
             const int off = row * 128 + swz(row, rg >> 1) + (((rg & 1) ^ ((row >> 4) & 1)) << 3);
-            *reinterpret_cast<u32x2*>(dst + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+            *reinterpret_cast<u32x2*>(dst + off) = ct[dd];
         }
     }
 }

@@ -4,6 +4,8 @@
 //   layernorm_bwd  d(x+res) of the fused residual + LayerNorm (+mask) kernel, with dgamma / dbeta
 //   embed_bwd    scatter-add of row gradients into the embedding table
 //   adam_step    fused Adam over one flat parameter buffer (train.py:166-170: betas (0.9,0.98), eps 1e-9, no decay)
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 namespace {
@@ -13,18 +15,14 @@ namespace {
 // LDS images At[128 n][64 m], Bt[128 k][64 m] in the NT GEMM's swizzled row format (chunk ^ (row & 7)), filled by
 // 4x4 register transposes (8-byte ds_write), so the MFMA inner loop is the NT kernel's.  Split over M (grid.y) with
 // float atomics into the (pre-zeroed) fp32 output: weight-gradient tiles are few (N*K/16384) while M is long.
-template <typename T> __device__ __forceinline__ void load4_bf16(const T* p, bool ok, unsigned& w0, unsigned& w1);
-template <> __device__ __forceinline__ void load4_bf16<bf16_t>(const bf16_t* p, bool ok, unsigned& w0, unsigned& w1) {
-    const u32x2 v = ok ? *reinterpret_cast<const u32x2*>(p) : u32x2{0, 0};
-    w0 = v[0];
-    w1 = v[1];
+template <typename T> __device__ __forceinline__ u32x2 load4_bf16(const T* p, bool ok);
+template <> __device__ __forceinline__ u32x2 load4_bf16<bf16_t>(const bf16_t* p, bool ok) {
+    return ok ? *reinterpret_cast<const u32x2*>(p) : u32x2{0, 0};
 }
-template <> __device__ __forceinline__ void load4_bf16<float>(const float* p, bool ok, unsigned& w0, unsigned& w1) {
+template <> __device__ __forceinline__ u32x2 load4_bf16<float>(const float* p, bool ok) {
     const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0, 0, 0, 0};
     bf16x4 b = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-    const u32x2 u = __builtin_bit_cast(u32x2, b);
-    w0 = u[0];
-    w1 = u[1];
+    return __builtin_bit_cast(u32x2, b);
 }
 
 template <typename TA, typename TB>
@@ -46,41 +44,48 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TA* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    // per-thread 4x4 blocks: id -> (cg = 4-column group 0..31, rg = 4-row (m) group 0..15), two ids per operand
-    unsigned ra[2][4][2], rb[2][4][2];
+    // per-thread 4x4 blocks: column group cg = tid & 31 (4 columns), m-row groups rg = (tid >> 5) + 8 i (4 rows each), i = 0, 1.
+    // Pointers are hoisted; the loop only adds the m offset.
+    const int cg = tid & 31;
+    const bool aok = n0 + 4 * cg < N, bok = k0 + 4 * cg < K;
+    const TA* ap = A + (int64_t)(4 * (tid >> 5)) * lda + min(n0 + 4 * cg, N - 1);
+    const TB* bp = Bm + (int64_t)(4 * (tid >> 5)) * ldb + min(k0 + 4 * cg, K - 1);
+    u32x2 ra[2][4], rb[2][4];
+    const bool cols_full = (n0 + 128 <= N) && (k0 + 128 <= K);      // block-uniform
     auto gload = [&](int m0) {
+        if (cols_full && m0 + 64 <= m_end) {                         // interior tile: no per-load predicates / branches
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i;
-            const int cg = id & 31, rg = id >> 5;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int m = m0 + 4 * rg + kk;
-                load4_bf16<TA>(A + (int64_t)m * lda + n0 + 4 * cg, m < m_end && n0 + 4 * cg < N, ra[i][kk][0], ra[i][kk][1]);
-                load4_bf16<TB>(Bm + (int64_t)m * ldb + k0 + 4 * cg, m < m_end && k0 + 4 * cg < K, rb[i][kk][0], rb[i][kk][1]);
-            }
+                for (int kk = 0; kk < 4; ++kk) {
+                    ra[i][kk] = load4_bf16<TA>(ap + (int64_t)(m0 + 32 * i + kk) * lda, true);
+                    rb[i][kk] = load4_bf16<TB>(bp + (int64_t)(m0 + 32 * i + kk) * ldb, true);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int mo = 32 * i + kk;
+                    const bool mok = m0 + 4 * (tid >> 5) + mo < m_end;
+                    ra[i][kk] = load4_bf16<TA>(ap + (int64_t)(m0 + mo) * lda, mok && aok);
+                    rb[i][kk] = load4_bf16<TB>(bp + (int64_t)(m0 + mo) * ldb, mok && bok);
+                }
         }
     };
     auto lstore = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i;
-            const int cg = id & 31, rg = id >> 5;
+            const int rg = (tid >> 5) + 8 * i;
+            u32x2 ca[4], cb[4];
+            transpose4x4_bf16(ra[i], ca);
+            transpose4x4_bf16(rb[i], cb);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
-                const int w = dd >> 1, sh = (dd & 1) * 16;
                 const int row = 4 * cg + dd;
                 const int off = row * 128 + (((rg >> 1) ^ (row & 7)) << 4) + ((rg & 1) << 3);
-                {
-                    const unsigned e0 = (ra[i][0][w] >> sh) & 0xffffu, e1 = (ra[i][1][w] >> sh) & 0xffffu;
-                    const unsigned e2 = (ra[i][2][w] >> sh) & 0xffffu, e3 = (ra[i][3][w] >> sh) & 0xffffu;
-                    *reinterpret_cast<u32x2*>(As + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
-                }
-                {
-                    const unsigned e0 = (rb[i][0][w] >> sh) & 0xffffu, e1 = (rb[i][1][w] >> sh) & 0xffffu;
-                    const unsigned e2 = (rb[i][2][w] >> sh) & 0xffffu, e3 = (rb[i][3][w] >> sh) & 0xffffu;
-                    *reinterpret_cast<u32x2*>(Bs + off) = u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
-                }
+                *reinterpret_cast<u32x2*>(As + off) = ca[dd];
+                *reinterpret_cast<u32x2*>(Bs + off) = cb[dd];
             }
         }
     };
@@ -128,6 +133,110 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TA* __restrict__ 
             const int n = n0 + wm * 64 + pass * 32 + rr;
             const float v = wlds[rr * 64 + (lane ^ ((rr & 15) << 2))];
             if (n < N && k < K) atomicAdd(C + (int64_t)n * ldc + k, v);
+        }
+    }
+}
+
+// ---- gemm_tn, LDS-DMA + hardware-transpose form (bf16 x bf16, full tiles): the M-major operand tiles [64 m][128 cols] are
+// copied row-major straight into LDS by global_load_lds_dwordx4 (double-buffered, one barrier per 64-row step, no staging
+// VGPRs, no transposing VALU) and the MFMA operands - 8 consecutive m for one output row/column - are fetched with
+// ds_read_b64_tr_b16 (lane i of 16-lane group g receives column c0+i of rows r0+8g..+3; verified on hardware with
+// tools/probe_tr.py).  A 16-byte chunk c of LDS row r holds global chunk c ^ sw(r), sw(r) = ((r&3)<<1) ^ (((r>>3)&1)<<3): the
+// 8 (row, half-wave group) combinations of one transposing read then land on 8 distinct 32-byte bank segments (conflict-free).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int tr_sw(int row) { return ((row & 3) << 1) ^ (((row >> 3) & 1) << 3); }
+__device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, int col) {
+    // rows row0..row0+3 and row0+4..row0+7 at 4 consecutive columns starting at `col` (this lane's address per the tr rule)
+    const int c = col >> 3, sub = (col & 7) * 2;
+    const unsigned char* p0 = tile + row0 * 256 + ((c ^ tr_sw(row0)) << 4) + sub;
+    const unsigned char* p1 = tile + (row0 + 4) * 256 + ((c ^ tr_sw(row0 + 4)) << 4) + sub;
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    const u32x2 a = __builtin_bit_cast(u32x2, v0), b = __builtin_bit_cast(u32x2, v1);
+    return u32x4{a[0], a[1], b[0], b[1]};
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
+                                                            int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                            int tiles_k, int m_per_split) {
+    constexpr int TILE = 64 * 256;   // 64 rows x 128 bf16
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];   // [buf][A|B]
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const int m_begin = blockIdx.y * m_per_split, m_end = min(M, m_begin + m_per_split);   // multiples of 64 by construction
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+
+    // staging: piece p (4 rows x 256 B) = rows 4p..4p+3; wave w stages pieces 4w..4w+3 of each operand
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * (wave * 4 + i) + (lane >> 4);
+        const int c = (lane & 15) ^ tr_sw(row);
+        asrc[i] = A + (int64_t)row * lda + n0 + c * 8;
+        bsrc[i] = Bm + (int64_t)row * ldb + k0 + c * 8;
+    }
+    auto stage = [&](int buf, int m0) {
+        unsigned char* base = smem + buf * 2 * TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)m0 * lda),
+                                             (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (int64_t)m0 * ldb),
+                                             (__attribute__((address_space(3))) void*)(base + TILE + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    if (m_begin < m_end) stage(0, m_begin);
+    __syncthreads();
+    int cur = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += 64) {
+        if (m0 + 64 < m_end) stage(cur ^ 1, m0 + 64);
+        const unsigned char* At = smem + cur * 2 * TILE;
+        const unsigned char* Bt = At + TILE;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const int row0 = g2 * 32 + 8 * q4 + (r16 >> 2);     // this lane's address row for the transposing read
+            const int csub = 4 * (r16 & 3);
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = tr_frag(At, row0, wm * 64 + i * 16 + csub);
+                b[i] = tr_frag(Bt, row0, wn * 64 + i * 16 + csub);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);   // D[k_local][n_local]
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* wlds = reinterpret_cast<float*>(smem) + wave * (32 * 64);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = pass * 2 + ii;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(wlds + (ii * 16 + r16) * 64 + ((j * 16 + q4 * 4) ^ (r16 << 2))) = acc[i][j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int k = k0 + wn * 64 + lane;
+        for (int rr = 0; rr < 32; ++rr) {
+            const int n = n0 + wm * 64 + pass * 32 + rr;
+            atomicAdd(C + (int64_t)n * ldc + k, wlds[rr * 64 + (lane ^ ((rr & 15) << 2))]);
         }
     }
 }
@@ -299,6 +408,21 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
             hipError_t e = hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)K * sizeof(float), N, s);
             if (e != hipSuccess) { asr_set_error("gemm_tn memset2d: %s", hipGetErrorString(e)); return (int)e; }
         }
+    }
+    static const bool no_tr = getenv("ASR_AMD_NO_TR") != nullptr;   // A/B switch
+    if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 &&
+        ldb % 8 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 16)) {
+        const int tiles_n = N / 128, tiles_k = K / 128, tiles = tiles_n * tiles_k;
+        int splits = (512 + tiles - 1) / tiles;
+        const int max_splits = (M + 511) / 512;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        const int m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
+        splits = (M + m_per_split - 1) / m_per_split;
+        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, C, ldc, M,
+                           N, K, tiles_k, m_per_split);
+        ASR_LAUNCH_CHECK("gemm_tn_tr");
+        return 0;
     }
     if (a_dtype == ASR_F32 && b_dtype == ASR_F32) return launch_tn<float, float>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
     if (a_dtype == ASR_F32 && b_dtype == ASR_BF16) return launch_tn<float, bf16_t>(s, A, lda, Bm, ldb, C, ldc, M, N, K);

@@ -62,6 +62,34 @@ struct EpiDense {
     int64_t ld_add;
     const bf16_t* relu_mask;  // optional bf16 [M,N] (ld_mask): C = relu_mask > 0 ? C : 0  (ReLU backward)
     int64_t ld_mask;
+    bool vec_ok;              // host-checked: every pointer / leading dimension allows 4-wide vector access
+
+    // fast path (kernel-uniform): the tile lies fully inside N and everything is vector-aligned -> no per-element logic
+    struct Row { unsigned char* c; const float* add; const bf16_t* mask; };
+    __device__ __forceinline__ bool fast(int n0_tile) const { return vec_ok && n0_tile + BN <= N; }
+    __device__ __forceinline__ Row row(int m) const {
+        return Row{reinterpret_cast<unsigned char*>(C) + (int64_t)m * ldc * (c_dtype == ASR_F32 ? 4 : 2),
+                   addend ? addend + (int64_t)m * ld_add : nullptr, relu_mask ? relu_mask + (int64_t)m * ld_mask : nullptr};
+    }
+    __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (flags & ASR_GEMM_RELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if (r.add) v += *reinterpret_cast<const f32x4*>(r.add + n);
+        if (r.mask) {
+            const bf16x4 mk = *reinterpret_cast<const bf16x4*>(r.mask + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] : 0.f;
+        }
+        if (c_dtype == ASR_F32) {
+            *reinterpret_cast<f32x4*>(r.c + (int64_t)n * 4) = v;
+        } else {
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(r.c + (int64_t)n * 2) = o;
+        }
+    }
     __device__ __forceinline__ void store4(int m, int n0, f32x4 v) const {
         if (m >= M || n0 >= N) return;
         const int nv = min(4, N - n0);
@@ -133,6 +161,27 @@ template <typename CT> struct EpiHeads {
     const float* bias;
     int L, h, M, N;
     float scale_first;
+    // fast path: N is a multiple of 64 and everything is aligned by construction, so every full tile qualifies.  The row
+    // (b, t) split costs one integer division per ROW instead of per store, the head split one per 64-column wave slice.
+    struct Row { CT* base; };
+    __device__ __forceinline__ bool fast(int n0_tile) const { return n0_tile + BN <= N; }
+    __device__ __forceinline__ Row row(int m) const {
+        const int b = m / L, t = m - b * L;
+        return Row{out + ((int64_t)b * h * L + t) * 64};
+    }
+    __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        const int slot = n >> 6;                       // global head slot = which * h + head
+        const int which = slot / h, head = slot - which * h;
+        if (which == 0) v *= scale_first;
+        CT* p = r.base + which * proj_stride + (int64_t)head * L * 64 + (n & 63);
+        if constexpr (sizeof(CT) == 4) {
+            *reinterpret_cast<f32x4*>(p) = v;
+        } else {
+            bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            *reinterpret_cast<bf16x4*>(p) = o;
+        }
+    }
     __device__ __forceinline__ void store4(int m, int n0, f32x4 v) const {
         if (m >= M || n0 >= N) return;  // N is a multiple of 64
         if (bias) {
@@ -154,6 +203,28 @@ template <typename CT> struct EpiHeads {
         }
     }
 };
+
+template <typename Epi>
+__device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int q4) {
+    if (epi.fast(n0)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + r16;
+            if (m < epi.M) {
+                const auto r = epi.row(m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) epi.store_fast(r, n0 + wn * 64 + j * 16 + q4 * 4, acc[i][j]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + r16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) epi.store4(m, n0 + wn * 64 + j * 16 + q4 * 4, acc[i][j]);
+        }
+    }
+}
 
 template <typename AT, typename CT, typename Epi>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A, int64_t lda, const CT* __restrict__ W,
@@ -181,15 +252,35 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
     Chunk<CT, CT> rb[4];
     const int nk = (K + KT - 1) / KT;
 
-    auto gload = [&](int kt) {
+    // per-thread chunk pointers, hoisted: this thread always stages chunk c = tid & 7 of rows (tid >> 3) + 32 i
+    const int cch = (tid & 7) * CH;
+    const AT* aptr[4];
+    const CT* wptr[4];
+    bool aok[4], wok[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + NT * i;
-            const int row = id >> 3, c = id & 7;
-            const int k = kt * KT + c * CH;
-            const int gm = m0 + row, gn = n0 + row;
-            ra[i].load(A + (int64_t)gm * lda + k, gm < M && k < K);
-            rb[i].load(W + (int64_t)gn * ldw + k, gn < N && k < K);
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        aok[i] = m0 + row < M;
+        wok[i] = n0 + row < N;
+        aptr[i] = A + (int64_t)min(m0 + row, M - 1) * lda + cch;
+        wptr[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + cch;
+    }
+    const bool rows_full = (m0 + BM <= M) && (n0 + BN <= N);   // block-uniform
+    auto gload = [&](int kt) {
+        const int kb = kt * KT;
+        if (rows_full && kb + KT <= K) {                        // interior tile: no per-load predicates / branches
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i].load(aptr[i] + kb, true);
+                rb[i].load(wptr[i] + kb, true);
+            }
+        } else {
+            const bool kok = kb + cch < K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i].load(aptr[i] + kb, aok[i] && kok);
+                rb[i].load(wptr[i] + kb, wok[i] && kok);
+            }
         }
     };
     auto lstore = [&]() {
@@ -233,15 +324,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
         }
     }
 
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + q4 * 4;
-            epi.store4(m, n, acc[i][j]);
-        }
-    }
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
 }
 
 // ---- LDS-DMA fast path (bf16 x bf16, K % 64 == 0): global_load_lds_dwordx4 writes each 1-KiB piece (8 rows x 128 B) of the
@@ -319,12 +402,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
         }
         __syncthreads();   // next tile landed (the barrier's fence waits for the outstanding LDS-DMA) and `cur` is free to overwrite
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) epi.store4(m, n0 + wn * 64 + j * 16 + q4 * 4, acc[i][j]);
-    }
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
 }
 
 // ---- NN variant (data gradient): C[M,N] = A[M,Kr] . Bm[Kr,N], Bm row-major as the weight is stored ([out,in] with the
@@ -350,23 +428,41 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A
     Chunk<AT, bf16_t> ra[4];
     u32x2 rb[2][4];
     const int nk = (K + KT - 1) / KT;
+    const int cch = (tid & 7) * CH;
+    const AT* aptr[4];
+    bool aok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        aok[i] = m0 + row < M;
+        aptr[i] = A + (int64_t)min(m0 + row, M - 1) * lda + cch;
+    }
+    // B blocks: this thread owns column group cg = tid & 31 and k-row groups rg = (tid >> 5) + 8 i
+    const int bn = n0 + 4 * (tid & 31);
+    const bool bnok = bn < N;
+    const bf16_t* bptr = Bm + (int64_t)(4 * (tid >> 5)) * ldb + min(bn, N - 4 < 0 ? 0 : N - 4);
+    const bool rows_full = (m0 + BM <= M) && (n0 + BN <= N);   // block-uniform
     auto gload = [&](int kt) {
+        const int kb = kt * KT;
+        if (rows_full && kb + KT <= K) {                        // interior tile: no per-load predicates / branches
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = tid + NT * i;
-            const int row = id >> 3, c = id & 7;
-            const int k = kt * KT + c * CH;
-            const int gm = m0 + row;
-            ra[i].load(A + (int64_t)gm * lda + k, gm < M && k < K);
-        }
+            for (int i = 0; i < 4; ++i) ra[i].load(aptr[i] + kb, true);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + NT * i;
-            const int cg = id & 31, rg = id >> 5;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = kt * KT + 4 * rg + kk, n = n0 + 4 * cg;
-                rb[i][kk] = (k < K && n < N) ? *reinterpret_cast<const u32x2*>(Bm + (int64_t)k * ldb + n) : u32x2{0, 0};
+                for (int kk = 0; kk < 4; ++kk)
+                    rb[i][kk] = *reinterpret_cast<const u32x2*>(bptr + (int64_t)(kb + 32 * i + kk) * ldb);
+        } else {
+            const bool kok = kb + cch < K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i].load(aptr[i] + kb, aok[i] && kok);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = kb + 4 * (tid >> 5) + 32 * i + kk;
+                    rb[i][kk] = (k < K && bnok) ? *reinterpret_cast<const u32x2*>(bptr + (int64_t)(kb + 32 * i + kk) * ldb) : u32x2{0, 0};
+                }
             }
         }
     };
@@ -381,14 +477,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A
         for (int i = 0; i < 2; ++i) {
             const int id = tid + NT * i;
             const int cg = id & 31, rg = id >> 5;
+            u32x2 ct[4];
+            transpose4x4_bf16(rb[i], ct);
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
-                const int w = dd >> 1, sh = (dd & 1) * 16;
-                const unsigned e0 = (rb[i][0][w] >> sh) & 0xffffu, e1 = (rb[i][1][w] >> sh) & 0xffffu;
-                const unsigned e2 = (rb[i][2][w] >> sh) & 0xffffu, e3 = (rb[i][3][w] >> sh) & 0xffffu;
                 const int row = 4 * cg + dd;
-                *reinterpret_cast<u32x2*>(Bs + row * ROWB + (((rg >> 1) ^ (row & 7)) << 4) + ((rg & 1) << 3)) =
-                    u32x2{e0 | (e1 << 16), e2 | (e3 << 16)};
+                *reinterpret_cast<u32x2*>(Bs + row * ROWB + (((rg >> 1) ^ (row & 7)) << 4) + ((rg & 1) << 3)) = ct[dd];
             }
         }
     };
@@ -420,12 +514,92 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A
                 for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
         }
     }
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
+}
+
+// ---- NN variant, LDS-DMA + hardware-transpose form (bf16 A, K % 64 == 0, N % 128 == 0): the A tile is staged exactly like the
+// glds NT kernel; the weight tile [64 k][128 n] is copied ROW-MAJOR (as stored) by LDS-DMA and its MFMA fragments - 8 consecutive
+// k for one n - come from ds_read_b64_tr_b16 (see backward.hip gemm_tn_tr_kernel for the swizzle / conflict analysis).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int tr_sw(int row) { return ((row & 3) << 1) ^ (((row >> 3) & 1) << 3); }
+__device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, int col) {
+    const int c = col >> 3, sub = (col & 7) * 2;
+    const unsigned char* p0 = tile + row0 * 256 + ((c ^ tr_sw(row0)) << 4) + sub;
+    const unsigned char* p1 = tile + (row0 + 4) * 256 + ((c ^ tr_sw(row0 + 4)) << 4) + sub;
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    const u32x2 a = __builtin_bit_cast(u32x2, v0), b = __builtin_bit_cast(u32x2, v1);
+    return u32x4{a[0], a[1], b[0], b[1]};
+}
+
+template <typename Epi>
+__global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
+                                                           int64_t ldb, int M, int N, int K, int tiles_n, int nwg, Epi epi) {
+    constexpr int KT = 64, TILE = BM * ROWB;   // 16 KiB: A tile [128 m][64 k]; B tile [64 k][128 n]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) epi.store4(m, n0 + wn * 64 + j * 16 + q4 * 4, acc[i][j]);
+        const int arow = 8 * (wave * 4 + i) + (lane >> 3);                   // A piece: 8 rows x 128 B
+        asrc[i] = A + (int64_t)min(m0 + arow, M - 1) * lda + (((lane & 7) ^ (arow & 7)) * 8);
+        const int brow = 4 * (wave * 4 + i) + (lane >> 4);                   // B piece: 4 k-rows x 256 B
+        bsrc[i] = Bm + (int64_t)brow * ldb + n0 + (((lane & 15) ^ tr_sw(brow)) * 8);
     }
+    auto stage = [&](int buf, int kt) {
+        unsigned char* base = smem + buf * 2 * TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = wave * 4 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * KT),
+                                             (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (int64_t)kt * KT * ldb),
+                                             (__attribute__((address_space(3))) void*)(base + TILE + p * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    const int nk = K / KT;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const unsigned char* As = smem + cur * 2 * TILE;
+        const unsigned char* Bt = As + TILE;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int chunk = g * 4 + q4;
+            const int row0 = g * 32 + 8 * q4 + (r16 >> 2), csub = 4 * (r16 & 3);
+            u32x4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int arow = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                b[i] = tr_frag(Bt, row0, wn * 64 + i * 16 + csub);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
 }
 
 template <typename AT, typename CT, typename Epi>
@@ -436,6 +610,13 @@ int launch_gemm(hipStream_t s, const void* A, int64_t lda, const void* W, int64_
                        reinterpret_cast<const CT*>(W), ldw, M, N, K, tiles_n, nwg, epi);
     ASR_LAUNCH_CHECK("gemm_nt");
     return 0;
+}
+
+bool dense_vec_ok(const EpiDense& e) {
+    const size_t ca = e.c_dtype == ASR_F32 ? 16 : 8;
+    return (e.ldc % 4 == 0) && asr_aligned(e.C, ca) && (!e.bias || asr_aligned(e.bias, 16)) &&
+           (!e.addend || (e.ld_add % 4 == 0 && asr_aligned(e.addend, 16))) &&
+           (!e.relu_mask || (e.ld_mask % 4 == 0 && asr_aligned(e.relu_mask, 8)));
 }
 
 int check_operands(const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw, int K) {
@@ -477,7 +658,8 @@ extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda
     ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm: M=%d N=%d K=%d C=%p", M, N, K, C);
     ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm: bad c_dtype");
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
-    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, nullptr, 0, nullptr, 0};
+    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, nullptr, 0, nullptr, 0, false};
+    epi.vec_ok = dense_vec_ok(epi);
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -487,7 +669,8 @@ extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t 
     ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm_ex: M=%d N=%d K=%d C=%p", M, N, K, C);
     ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm_ex: bad c_dtype");
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
-    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask};
+    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask, false};
+    epi.vec_ok = dense_vec_ok(epi);
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -517,9 +700,16 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     ASR_REQUIRE(lda % 8 == 0 && lda >= (K + 7) / 8 * 8 && N % 4 == 0 && ldb % 4 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 8),
                 ASR_ERR_ALIGN, "gemm_nn: lda=%lld must be a multiple of 8 covering K=%d rounded up (pad columns must be zero), N=%d ldb=%lld of 4",
                 (long long)lda, K, N, (long long)ldb);
-    EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask};
+    EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask, false};
+    epi.vec_ok = dense_vec_ok(epi);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
+        hipLaunchKernelGGL((gemm_nn_tr_kernel<EpiDense>), dim3(nwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, K,
+                           tiles_n, nwg, epi);
+        ASR_LAUNCH_CHECK("gemm_nn_tr");
+        return 0;
+    }
     if (a_dtype == ASR_F32)
         hipLaunchKernelGGL((gemm_nn_kernel<float, EpiDense>), dim3(nwg), dim3(NT), 0, s, (const float*)A, lda, (const bf16_t*)Bm, ldb, M, N,
                            K, tiles_n, nwg, epi);

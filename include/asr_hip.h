@@ -199,6 +199,9 @@ int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const fl
 /* Conv1d k=w stride 1 valid + ReLU over time with implicit zero right-pad (conv_encoder.py:33-43) is expressed by
  * the caller as w_context shifted GEMMs through asr_gemm_nt; no dedicated entry point. */
 
+/* Development probe (not on the product path): dumps what each lane receives from ds_read_b64_tr_b16 on a known LDS tile. */
+int asr_debug_probe_tr(void* stream, void* out, int m0, int n0);
+
 /* Utility: dtype cast f32 -> bf16 (weights / activations entering the bf16 MFMA path). n elements. */
 int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t n);
 /* logits *= (t < len)  (ctcModel/decoder.py:33-36), in place, f32 [B,L,V] dense. */

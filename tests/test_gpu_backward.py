@@ -14,7 +14,8 @@ def N(t):
     return t.detach().float().cpu().numpy()
 
 
-@pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (777, 4236, 64), (300, 768, 256), (64, 128, 128)])
+@pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (777, 4236, 64), (300, 768, 256), (64, 128, 128), (1024, 256, 2048), (4096, 768, 256),
+                                    (3200, 2048, 256), (128, 128, 256)])
 @pytest.mark.parametrize("dts", [("bf16", "bf16"), ("f32", "bf16"), ("f32", "f32")])
 def test_gemm_tn(M, N_, K, dts):
     g = torch.Generator().manual_seed(M + K)
@@ -29,7 +30,7 @@ def test_gemm_tn(M, N_, K, dts):
     np.testing.assert_allclose(N(out2), 2 * ref.numpy(), atol=4e-2 * (M / 300) ** 0.5, rtol=2e-3)
 
 
-@pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (300, 80, 256), (77, 256, 768), (500, 256, 4240)])
+@pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (300, 80, 256), (77, 256, 768), (500, 256, 4240), (1000, 2048, 256), (130, 128, 64)])
 def test_gemm_nn(M, N_, K):
     g = torch.Generator().manual_seed(M + K)
     dy = torch.randn(M, K, generator=g)

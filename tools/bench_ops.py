@@ -84,6 +84,24 @@ def bench_gemm():
                               frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
 
 
+def bench_bwdgemm():
+    for (M, N, K) in [(32000, 256, 2048), (32000, 2048, 256), (32000, 768, 256), (32000, 256, 256)]:
+        dy = torch.randn(M, N, device=DEV).bfloat16()
+        x = torch.randn(M, K, device=DEV).bfloat16()
+        out = torch.zeros(N, K, device=DEV)
+        t = timeit(lambda: ops.gemm_tn(dy, x, out=out, accumulate=False))
+        fl = 2.0 * M * N * K
+        print(json.dumps(dict(op="gemm_tn", shape=[M, N, K], us=round(t * 1e3, 2), TFLOPs=round(fl / t / 1e9, 1),
+                              frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+    for (M, N, K) in [(32000, 2048, 256), (32000, 256, 2048), (32000, 256, 768)]:
+        dy = torch.randn(M, K, device=DEV).bfloat16()
+        w = (torch.randn(K, N, device=DEV) / K ** 0.5).bfloat16()
+        t = timeit(lambda: ops.gemm_nn(dy, w, out_dtype=torch.bfloat16))
+        fl = 2.0 * M * N * K
+        print(json.dumps(dict(op="gemm_nn", shape=[M, N, K], us=round(t * 1e3, 2), TFLOPs=round(fl / t / 1e9, 1),
+                              frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+
+
 def bench_ln():
     B, L, D = 32, 1000, 256
     x = torch.randn(B * L, D, device=DEV)
@@ -95,6 +113,6 @@ def bench_ln():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ctc", "cif", "attn", "gemm", "ln"]
+    which = sys.argv[1:] or ["ctc", "cif", "attn", "gemm", "bwdgemm", "ln"]
     for w in which:
         globals()["bench_" + w]()
