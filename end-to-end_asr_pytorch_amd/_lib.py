@@ -27,7 +27,7 @@ SIGNATURES = {
     "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i],
     "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
     "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
-    "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i],
+    "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
     "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "asr_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f],

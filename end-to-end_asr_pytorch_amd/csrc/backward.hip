@@ -158,7 +158,7 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, in
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
                                                             int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                            int tiles_k, int m_per_split) {
+                                                            int tiles_k, int m_per_split, float* __restrict__ colsum) {
     constexpr int TILE = 64 * 256;   // 64 rows x 128 bf16
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];   // [buf][A|B]
     const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
@@ -196,6 +196,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
+    // bias gradient for free: the workgroups of the first K-tile (and the wn = 0 waves) multiply their A fragments by an all-ones
+    // operand as well - every row of that 16x16 product is the column sum of dY over the 32 m just consumed.
+    const bool do_colsum = (colsum != nullptr) && (tk == 0) && (wn == 0);
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // bf16 1.0 x 8
+    f32x4 cs[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+
     if (m_begin < m_end) stage(0, m_begin);
     __syncthreads();
     int cur = 0;
@@ -217,9 +223,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);   // D[k_local][n_local]
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Mma<bf16_t>::run(ones, a[i], cs[i]);        // D[*][n_local] = sum_m A[m][n]
+            }
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if (do_colsum && q4 == 0) {   // rows are identical: lanes 0..15 (row group 0, register 0) hold the 16 column sums of fragment i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(colsum + n0 + wm * 64 + i * 16 + r16, cs[i][0]);
     }
     float* wlds = reinterpret_cast<float*>(smem) + wave * (32 * 64);
 #pragma unroll
@@ -276,50 +290,90 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LN_MAXJ = 4;
-constexpr int LNB_ROWS = 32;  // rows per workgroup (8 per wave)
+constexpr int LNB_RPW = 4;             // rows per wave handled TOGETHER: all loads issued up front, reductions interleaved
+constexpr int LNB_ROWS = 4 * LNB_RPW;  // rows per workgroup
 
+// MAXJ = float4 column groups per lane: 1 for D <= 256 (the model dimension of every shipped config), 4 up to D = 1024.
+template <int MAXJ>
 __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D) {
-    __shared__ float red[3][4][1024];
+    __shared__ float red[3][4][256 * MAXJ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 ag[LN_MAXJ], ab[LN_MAXJ], as[LN_MAXJ];
-#pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) { ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; as[j] = f32x4{0, 0, 0, 0}; }
     const float invD = 1.f / (float)D;
-    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
-        const int64_t row = (int64_t)blockIdx.x * LNB_ROWS + rr * 4 + wave;
-        if (row >= M) break;
-        const int b = (int)(row / L), t = (int)(row - (int64_t)b * L);
-        const bool keep = row_len ? (t < row_len[b]) : true;
-        const float mu = mean[row], rs = rstd[row];
-        f32x4 g[LN_MAXJ], xh[LN_MAXJ];
-        float s1 = 0.f, s2 = 0.f;
+    f32x4 ag[MAXJ], ab[MAXJ], as[MAXJ], gam[MAXJ];
 #pragma unroll
-        for (int j = 0; j < LN_MAXJ; ++j) {
+    for (int j = 0; j < MAXJ; ++j) {
+        ag[j] = f32x4{0, 0, 0, 0}; ab[j] = f32x4{0, 0, 0, 0}; as[j] = f32x4{0, 0, 0, 0};
+        const int c = lane * 4 + 256 * j;
+        gam[j] = (c < D) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0, 0, 0, 0};
+    }
+    // persistent: a bounded number of workgroups stride over the rows keeping the per-column partials in registers, so the
+    // contended dgamma / dbeta / dbias atomics (every workgroup hits the same D addresses) happen once per workgroup, not per 16 rows
+    for (int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS + wave * LNB_RPW; row0 < M; row0 += (int64_t)gridDim.x * LNB_ROWS) {
+    f32x4 d[LNB_RPW][MAXJ], xh[LNB_RPW][MAXJ];
+    float mu[LNB_RPW], rs[LNB_RPW];
+    bool live[LNB_RPW];
+    // phase 1: every load of the wave's rows in flight at once
+#pragma unroll
+    for (int r = 0; r < LNB_RPW; ++r) {
+        const int64_t row = row0 + r;
+        live[r] = row < M;
+        const int64_t rr = live[r] ? row : (int64_t)M - 1;
+        const int b = (int)(rr / L), t = (int)(rr - (int64_t)b * L);
+        const bool keep = live[r] && (row_len ? (t < row_len[b]) : true);
+        mu[r] = mean[rr];
+        rs[r] = rstd[rr];
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
-                f32x4 d = *reinterpret_cast<const f32x4*>(dy + row * D + c);
-                if (!keep) d = f32x4{0, 0, 0, 0};
-                xh[j] = (*reinterpret_cast<const f32x4*>(s + row * D + c) - mu) * rs;
-                ag[j] += d * xh[j];
-                ab[j] += d;
-                g[j] = d * *reinterpret_cast<const f32x4*>(gamma + c);
-                s1 += (g[j][0] + g[j][1]) + (g[j][2] + g[j][3]);
-                const f32x4 gx = g[j] * xh[j];
-                s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+                d[r][j] = keep ? *reinterpret_cast<const f32x4*>(dy + rr * D + c) : f32x4{0, 0, 0, 0};
+                xh[r][j] = *reinterpret_cast<const f32x4*>(s + rr * D + c);
+            } else {
+                d[r][j] = f32x4{0, 0, 0, 0};
+                xh[r][j] = f32x4{0, 0, 0, 0};
             }
         }
-        s1 = wave_sum(s1) * invD;
-        s2 = wave_sum(s2) * invD;
+    }
+    // phase 2: per-row reductions (independent chains) and outputs
+    float s1[LNB_RPW], s2[LNB_RPW];
 #pragma unroll
-        for (int j = 0; j < LN_MAXJ; ++j) {
+    for (int r = 0; r < LNB_RPW; ++r) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            xh[r][j] = (xh[r][j] - mu[r]) * rs[r];
+            ag[j] += d[r][j] * xh[r][j];
+            ab[j] += d[r][j];
+            const f32x4 g = d[r][j] * gam[j];
+            const f32x4 gx = g * xh[r][j];
+            a1 += (g[0] + g[1]) + (g[2] + g[3]);
+            a2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+        }
+        s1[r] = a1;
+        s2[r] = a2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < LNB_RPW; ++r) {
+            s1[r] += __shfl_xor(s1[r], o, 64);
+            s2[r] += __shfl_xor(s2[r], o, 64);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LNB_RPW; ++r) {
+        if (!live[r]) continue;
+        const int64_t row = row0 + r;
+        const float m1 = s1[r] * invD, m2 = s2[r] * invD;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
-                const f32x4 o = (g[j] - s1 - xh[j] * s2) * rs;
+                const f32x4 o = (d[r][j] * gam[j] - m1 - xh[r][j] * m2) * rs[r];
                 as[j] += o;
                 *reinterpret_cast<f32x4*>(ds + row * D + c) = o;
                 if (ds16) {
@@ -329,15 +383,14 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
             }
         }
     }
-    // workgroup reduction of the dgamma / dbeta partials, then one atomic per column
+    }  // row loop
+    // workgroup reduction of the dgamma / dbeta / dbias partials, then one atomic per column
 #pragma unroll
-    for (int j = 0; j < LN_MAXJ; ++j) {
+    for (int j = 0; j < MAXJ; ++j) {
         const int c = lane * 4 + 256 * j;
-        if (c < D) {
-            *reinterpret_cast<f32x4*>(&red[0][wave][c]) = ag[j];
-            *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab[j];
-            *reinterpret_cast<f32x4*>(&red[2][wave][c]) = as[j];
-        }
+        *reinterpret_cast<f32x4*>(&red[0][wave][c]) = ag[j];
+        *reinterpret_cast<f32x4*>(&red[1][wave][c]) = ab[j];
+        *reinterpret_cast<f32x4*>(&red[2][wave][c]) = as[j];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
@@ -392,8 +445,10 @@ int launch_tn(hipStream_t s, const void* A, int64_t lda, const void* Bm, int64_t
 
 }  // namespace
 
+extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first);
+
 extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int b_dtype, int64_t ldb, float* C,
-                           int64_t ldc, int M, int N, int K, int zero_first) {
+                           int64_t ldc, int M, int N, int K, int zero_first, float* colsum) {
     ASR_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, ASR_ERR_ARG, "gemm_tn: bad args");
     ASR_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= (N + 3) / 4 * 4 && ldb >= (K + 3) / 4 * 4, ASR_ERR_ALIGN,
                 "gemm_tn: lda/ldb must be multiples of 4 covering N/K rounded up to 4 (padded columns are read)");
@@ -420,9 +475,12 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
         const int m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
         splits = (M + m_per_split - 1) / m_per_split;
         hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, C, ldc, M,
-                           N, K, tiles_k, m_per_split);
+                           N, K, tiles_k, m_per_split, colsum);
         ASR_LAUNCH_CHECK("gemm_tn_tr");
         return 0;
+    }
+    if (colsum) {   // shapes the fused path does not cover: separate column-sum kernel (accumulating)
+        if (int rc = asr_colsum(stream, A, a_dtype, lda, M, N, colsum, 0)) return rc;
     }
     if (a_dtype == ASR_F32 && b_dtype == ASR_F32) return launch_tn<float, float>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
     if (a_dtype == ASR_F32 && b_dtype == ASR_BF16) return launch_tn<float, bf16_t>(s, A, lda, Bm, ldb, C, ldc, M, N, K);
@@ -456,8 +514,14 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(dy && s && mean && rstd && gamma && ds && dgamma && dbeta, ASR_ERR_ARG, "layernorm_bwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
-    hipLaunchKernelGGL(add_layernorm_bwd_kernel, dim3((M + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s,
-                       mean, rstd, gamma, row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D);
+    int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
+    if (blocks > 256) blocks = 256;
+    if (D <= 256)
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D);
+    else
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D);
     ASR_LAUNCH_CHECK("add_layernorm_bwd");
     return 0;
 }

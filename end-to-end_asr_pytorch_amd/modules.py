@@ -246,18 +246,15 @@ class MultiheadAttention(_Cached):
             if xkv is xq:
                 dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:])
-                ops.gemm_tn(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True)
-                ops.colsum(dqkv, out=_gcat(qkvb), accumulate=True)
+                ops.gemm_tn(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
                 _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
             else:
                 dq = torch.empty((B * Lq, hd), device=ds.device, dtype=torch.bfloat16)
                 dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dkv[:, :hd], dkv[:, hd:])
-                ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True)
-                ops.colsum(dq, out=self.w_qs.bias.grad, accumulate=True)
+                ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
                 _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
-                ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True)
-                ops.colsum(dkv, out=_gcat(qkvb[1:]), accumulate=True)
+                ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True, colsum=_gcat(qkvb[1:]))
                 xkv.grad = ops.gemm_nn(dkv, self._w("kv", qkvw[1:]), addend=xkv.grad)
 
         _TAPE.push(bw, qkvw + qkvb + (fc.weight, fc.bias, ln.weight, ln.bias))
@@ -303,8 +300,7 @@ class PositionwiseFeedForward(_Cached):
                 y.grad = None
                 ops.gemm_tn(ds16, hid, out=w2.weight.grad, accumulate=True)
                 d_hid = ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid)
-                ops.gemm_tn(d_hid, x.mma(), out=w1.weight.grad, accumulate=True)
-                ops.colsum(d_hid, out=w1.bias.grad, accumulate=True)
+                ops.gemm_tn(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
                 _acc(x, ops.gemm_nn(d_hid, self._w("w1", (w1.weight,)), addend=ds))
 
             _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))

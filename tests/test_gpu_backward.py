@@ -23,8 +23,10 @@ def test_gemm_tn(M, N_, K, dts):
     b = torch.randn(M, K, generator=g)
     ad = a.to(DEV).to(torch.bfloat16 if dts[0] == "bf16" else torch.float32)
     bd = b.to(DEV).to(torch.bfloat16 if dts[1] == "bf16" else torch.float32)
-    out = ops.gemm_tn(ad, bd)
+    cs = torch.zeros(N_, device=DEV)
+    out = ops.gemm_tn(ad, bd, colsum=cs)
     ref = a.bfloat16().float().t() @ b.bfloat16().float()
+    np.testing.assert_allclose(N(cs), (a.bfloat16().float() if dts[0] == "bf16" else a).sum(0).numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
     np.testing.assert_allclose(N(out), ref.numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
     out2 = ops.gemm_tn(ad, bd, out=out, accumulate=True)
     np.testing.assert_allclose(N(out2), 2 * ref.numpy(), atol=4e-2 * (M / 300) ** 0.5, rtol=2e-3)

@@ -110,6 +110,11 @@ def bench_ln():
     t = timeit(lambda: ops.add_layernorm(x, r, g_, b_, B, L, want_bf16=True))
     nb = B * L * D * 14
     print(json.dumps(dict(op="add_layernorm", shape=[B * L, D], us=round(t * 1e3, 2), GBps=round(nb / t / 1e6, 1))))
+    y32, _, mean, rstd = ops.add_layernorm(x.clone(), r, g_, b_, B, L, want_bf16=True, save_stats=True)
+    dy = torch.randn(B * L, D, device=DEV)
+    dg, db_, dbias = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    t = timeit(lambda: ops.add_layernorm_bwd(dy, x, mean, rstd, g_, None, B, L, dg, db_, want_bf16=True, dbias=dbias))
+    print(json.dumps(dict(op="add_layernorm_bwd", shape=[B * L, D], us=round(t * 1e3, 2), GBps=round(nb / t / 1e6, 1))))
 
 
 if __name__ == "__main__":
