@@ -12,6 +12,8 @@
 //     transpose + ds_write_b64); global loads for tile t+1 are issued before the MFMAs of tile t.
 //   * masks come from lengths (key j masked iff j >= k_len[b] or causal && j > i); no mask tensor is read.
 // fp32 path: one wave per query row, plain VALU, exact fp32 - the parity/debug mode, not a performance path.
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 namespace {
@@ -272,10 +274,200 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const bf16_t*
     }
 }
 
+// ---- v2: LDS-DMA staging + hardware-transposed V reads -----------------------------------------------------------------------
+// K and V tiles are copied ROW-MAJOR ([64 keys][64 d], 128-byte rows) straight into a double-buffered LDS image by
+// global_load_lds_dwordx4 (no staging VGPRs, no register transposes, one barrier per tile, the next tile's DMA in flight during
+// the MFMAs).  One swizzle serves both access patterns: 16-byte chunk c of row r lives at slot c ^ f(r),
+// f(r) = (((r>>1)&1)<<2) | ((r>>2)&3): conflict-free for the ds_read_b128 row reads of QK^T (16 rows x one chunk) and for the
+// ds_read_b64_tr_b16 transposed reads of PV (4 consecutive keys x 64 bytes).  The DMA destination is lane-linear, so the swizzle is
+// applied to each lane's SOURCE chunk.  Keys past k_len are clamped to the last valid row (their probabilities are masked to 0).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+template <int NW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                      const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
+                                                                      float* __restrict__ lse, int h, int Lq, int Lk,
+                                                                      const int32_t* __restrict__ k_len, int q_tiles) {
+    constexpr int QB = NW * 32, PIECES = 8 / NW;   // 1-KiB pieces (8 rows) per wave per operand tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    int qt, bh;
+    {
+        const int BH = gridDim.x / q_tiles;
+        if ((BH & 7) == 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            bh = (slot / q_tiles) * 8 + xcd;
+            qt = slot % q_tiles;
+        } else {
+            qt = blockIdx.x % q_tiles;
+            bh = blockIdx.x / q_tiles;
+        }
+    }
+    const int b = bh / h, hd = bh - b * h;
+    const int q0 = qt * QB;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
+    const int ntiles = (kmax + 63) >> 6;
+    const int qrow = q0 + wave * 32 + r;
+    const int wave_qlast = q0 + wave * 32 + 31;
+    const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
+    const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
+
+    u32x4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = (qrow < Lq) ? *reinterpret_cast<const u32x4*>(Q + ((int64_t)bh * Lq + qrow) * 64 + 16 * s + 8 * hh)
+                            : u32x4{0, 0, 0, 0};
+
+    // this lane's (row, source chunk) inside each piece it stages: piece p covers tile rows 8p..8p+7
+    const int prow = lane >> 3;
+    auto stage = [&](int buf, int t) {
+        unsigned char* base = smem + buf * 2 * 8192;
+        const int key0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = wave * PIECES + i;
+            const int row = 8 * p + prow;
+            const int c = (lane & 7) ^ swz2(row);
+            const int64_t goff = (int64_t)min(key0 + row, kl - 1) * 64 + c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + goff),
+                                             (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + goff),
+                                             (__attribute__((address_space(3))) void*)(base + 8192 + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+        const unsigned char* Ks = smem + cur * 2 * 8192;
+        const unsigned char* Vs = Ks + 8192;
+        const int key0 = t * 64;
+        if (!(CAUSAL && key0 > wave_qlast)) {   // wave-uniform: otherwise the whole tile lies in this wave's future
+            f32x16 st[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[hf][i] = 0.f;
+                const int row = hf * 32 + r;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + row * 128 + (((2 * s + hh) ^ swz2(row)) << 4));
+                    st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                                     __builtin_bit_cast(bf16x8, qf[s]), st[hf], 0, 0, 0);
+                }
+            }
+            const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32);
+            float mloc = -INFINITY;
+            if (interior) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[hf][i]);
+            } else {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        const bool bad = key >= kl || (CAUSAL && key > qrow);
+                        st[hf][i] = bad ? -INFINITY : st[hf][i];
+                        mloc = fmaxf(mloc, st[hf][i]);
+                    }
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mn = fmaxf(m, mloc);
+            const float mbase = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = __expf(m - mbase);
+            const float mb2 = mbase * 1.4426950408889634f;
+            float rs = 0.f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -mb2));
+                    st[hf][i] = p;
+                    rs += p;
+                }
+            rs += __shfl_xor(rs, 32, 64);
+            l = l * alpha + rs;
+            m = mn;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+
+            // O^T += V^T . P^T : V^T fragments by transposing reads of the row-major V tile.
+            // lane (group g16 = lane>>4, i = lane&15) addresses key row kb + (i>>2), d column dt*32 + 16*(g16&1) + 4*(i&3)
+            const int i16 = lane & 15, g16 = lane >> 4;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[hf][8 * s2 + j];
+                    const int kb = hf * 32 + 16 * s2 + 4 * hh + (i16 >> 2);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const int col = dt * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+                        const int c = col >> 3, sub = (col & 7) * 2;
+                        const unsigned char* p0 = Vs + kb * 128 + ((c ^ swz2(kb)) << 4) + sub;
+                        const unsigned char* p1 = Vs + (kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub;
+                        const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+                        const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+                        const u32x2 a = __builtin_bit_cast(u32x2, v0), bb = __builtin_bit_cast(u32x2, v1);
+                        const u32x4 vf = {a[0], a[1], bb[0], bb[1]};
+                        if (dt == 0)
+                            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
+                        else
+                            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();   // next tile's DMA has landed (barrier fence drains vmcnt) and `cur` may be overwritten
+    }
+
+    if (qrow < Lq) {
+        const float inv = 1.f / l;
+        bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = 8 * g + 4 * hh;
+            bf16x4 a = {(bf16_t)(o0[4 * g] * inv), (bf16_t)(o0[4 * g + 1] * inv), (bf16_t)(o0[4 * g + 2] * inv),
+                        (bf16_t)(o0[4 * g + 3] * inv)};
+            bf16x4 c = {(bf16_t)(o1[4 * g] * inv), (bf16_t)(o1[4 * g + 1] * inv), (bf16_t)(o1[4 * g + 2] * inv),
+                        (bf16_t)(o1[4 * g + 3] * inv)};
+            *reinterpret_cast<bf16x4*>(op + d) = a;
+            *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
+        }
+        if (lse && hh == 0) lse[(int64_t)bh * Lq + qrow] = m + logf(l);
+    }
+}
+
 template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B,
                                   int h, int Lq, int Lk, const int32_t* k_len, int causal) {
     const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);
     dim3 grid(B * h * q_tiles), block(NW * 64);
+    static const bool v1 = getenv("ASR_AMD_ATTN_V1") != nullptr;   // A/B switch: register-staged v1 kernel
+    if (!v1) {
+        if (causal)
+            hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
+        else
+            hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, false>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                               (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
+        ASR_LAUNCH_CHECK("attention_fwd_bf16_v2");
+        return 0;
+    }
     if (causal)
         hipLaunchKernelGGL((attn_fwd_bf16_kernel<NW, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);

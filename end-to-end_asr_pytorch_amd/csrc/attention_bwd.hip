@@ -1,6 +1,8 @@
 // Flash-attention backward for gfx950 (bf16 MFMA, fp32 accumulate): gradients of attention.py:76-84 without ever
 // materialising the [Lq, Lk] probabilities.  P is recomputed from Q, K and the forward's row log-sum-exp.
 //
+//   Tiles are row-major in LDS, filled by LDS-DMA (double-buffered, one barrier per tile); every transposed operand (K^T, Q^T,
+//   dO^T) is fetched with ds_read_b64_tr_b16 from the SAME tile the row reads use (one swizzle serves both, attention.hip v2).
 //   kernel A (dQ):   one workgroup = NW waves x 32 queries, query on the LANE (exactly the forward's geometry):
 //       S^T = K.Q^T,  dP^T = V.dO^T  (A = K / V tile rows from LDS, B = Q / dO rows in registers),
 //       dS^T = P^T o (dP^T - delta[q])   (lse, delta are per-lane scalars),
@@ -88,6 +90,37 @@ __device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16& a0, const f3
     }
 }
 
+// ---- v2 building blocks: row-major tiles by LDS-DMA, one swizzle for row reads and hardware-transposed reads (attention.hip v2)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+// DMA one [64 rows][64 bf16] tile: `pieces` 1-KiB pieces (8 rows each) per wave; rows clamped to nrows-1
+template <int PIECES>
+__device__ __forceinline__ void dma_tile(unsigned char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int p = wave * PIECES + i;
+        const int row = 8 * p + (lane >> 3);
+        const int c = (lane & 7) ^ swz2(row);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)min(row0 + row, nrows - 1) * ld + c * 8),
+                                         (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 frag_rows2(const unsigned char* t, int row, int s, int hh) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(t + row * 128 + (((2 * s + hh) ^ swz2(row)) << 4)));
+}
+// transposed A-operand fragment (32 columns of the tile x 16 tile-rows in the accumulator's k-order) for column block cb (0/1),
+// tile-row block hf (32 rows), k-step s2
+__device__ __forceinline__ bf16x8 frag_tr2(const unsigned char* t, int cb, int hf, int s2, int lane) {
+    const int i16 = lane & 15, g16 = lane >> 4, hh = lane >> 5;
+    const int kb = hf * 32 + 16 * s2 + 4 * hh + (i16 >> 2);
+    const int col = cb * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+    const int c = col >> 3, sub = (col & 7) * 2;
+    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(t + kb * 128 + ((c ^ swz2(kb)) << 4) + sub));
+    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(t + (kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub));
+    const u32x2 a = __builtin_bit_cast(u32x2, v0), b = __builtin_bit_cast(u32x2, v1);
+    return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+}
+
 // ---------------------------------------------------------------------------------------------------------
 template <int NW, bool CAUSAL>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
@@ -96,12 +129,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dq_out, int64_t ldq,
                                                                  int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int q_tiles,
                                                                  float scale) {
-    constexpr int NTHR = NW * 64, QB = NW * 32;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 8192];
-    unsigned char* Ks = smem;
-    unsigned char* Vs = smem + 8192;
-    unsigned char* Kt = smem + 16384;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    constexpr int QB = NW * 32, PIECES = 8 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V], row-major, LDS-DMA filled
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int qt, bh;   // XCD-aware map (see attention.hip): tiles of one (batch, head) share an XCD and are adjacent in time
     {
         const int BH = gridDim.x / q_tiles;
@@ -143,14 +174,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     if (qok && hh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
 
     f32x16 a0 = zero16(), a1 = zero16();
+    auto stage = [&](int buf, int t) {
+        dma_tile<PIECES>(smem + buf * 16384, Kb, 64, t * 64, kl, wave, lane);
+        dma_tile<PIECES>(smem + buf * 16384 + 8192, Vb, 64, t * 64, kl, wave, lane);
+    };
+    if (ntiles > 0) stage(0, 0);
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
-        const int key0 = t * 64;
-        __syncthreads();
-        stage_rows<NTHR>(Ks, Kb, 64, key0, kl, tid);
-        stage_rows<NTHR>(Vs, Vb, 64, key0, kl, tid);
-        stage_transposed<NTHR>(Kt, Kb, 64, key0, kl, tid);
-        __syncthreads();
-        if (CAUSAL && key0 > wave_qlast) continue;
+        const int key0 = t * 64, cur = t & 1;
+        if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
+        const unsigned char* Ks = smem + cur * 16384;
+        const unsigned char* Vs = Ks + 8192;
+        if (CAUSAL && key0 > wave_qlast) { __syncthreads(); continue; }
         // interior tile: every key valid for every (in-range) query of this wave -> no mask arithmetic (wave-uniform)
         const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32) && (q0 + wave * 32 + 31 < Lq);
         f32x16 st[2], dp[2];
@@ -161,8 +196,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
             const int row = hf * 32 + r;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
-                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
+                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
+                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
             }
             if (interior) {
 #pragma unroll
@@ -185,9 +220,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = pack8(st[hf], s2);
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, r, hf, s2, hh), pf, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Kt, 32 + r, hf, s2, hh), pf, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Ks, 0, hf, s2, lane), pf, a0, 0, 0, 0);   // K^T from the same K tile
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Ks, 1, hf, s2, lane), pf, a1, 0, 0, 0);
             }
+        __syncthreads();   // next tile's DMA landed; `cur` may be overwritten
     }
     if (qok) store_T(dq_out + ((int64_t)b * Lq + qrow) * ldq + hd * 64, a0, a1, hh, scale);
 }
@@ -199,14 +235,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dv_out, int64_t ldkv,
                                                               int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int k_tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 + 512];
-    unsigned char* Qs = smem;
-    unsigned char* dOs = smem + 8192;
-    unsigned char* Qt = smem + 16384;
-    unsigned char* dOt = smem + 24576;
-    float* lse_s = reinterpret_cast<float*>(smem + 32768);
-    float* del_s = lse_s + 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 + 1024];   // [buf][Q|dO] row-major + [buf][lse|delta]
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int kt, bh;   // XCD-aware map: key blocks of one (batch, head) share an XCD (they all stream the same Q / dO)
     {
         const int BH = gridDim.x / k_tiles;
@@ -239,20 +270,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int qt_first = CAUSAL ? (kt * 128) / 64 : 0;   // queries before the first key of this block see none of it
     const int nqt = (Lq + 63) >> 6;
     const int wave_kfirst = kt * 128 + wave * 32;
-    for (int t = qt_first; t < nqt; ++t) {
+    auto stage = [&](int buf, int t) {
         const int q0 = t * 64;
-        __syncthreads();
-        stage_rows<256>(Qs, Qb, 64, q0, Lq, tid);
-        stage_rows<256>(dOs, dOb, ldo, q0, Lq, tid);
-        stage_transposed<256>(Qt, Qb, 64, q0, Lq, tid);
-        stage_transposed<256>(dOt, dOb, ldo, q0, Lq, tid);
-        if (tid < 64) {
-            const int q = q0 + tid;
-            lse_s[tid] = (q < Lq) ? lse[(int64_t)bh * Lq + q] * 1.4426950408889634f : 0.f;   // base-2 for exp2(fma)
-            del_s[tid] = (q < Lq) ? delta[(int64_t)bh * Lq + q] : 0.f;
-        }
-        __syncthreads();
-        if (CAUSAL && q0 + 63 < wave_kfirst) continue;   // every query of the tile precedes every key of this wave
+        dma_tile<2>(smem + buf * 16384, Qb, 64, q0, Lq, wave, lane);
+        dma_tile<2>(smem + buf * 16384 + 8192, dOb, ldo, q0, Lq, wave, lane);
+        // per-row scalars of the tile: waves 0 / 1 DMA 64 floats of lse / delta (4 bytes per lane), rows clamped
+        float* sc = reinterpret_cast<float*>(smem + 32768) + buf * 128;
+        const int q = min(q0 + lane, Lq - 1);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + (int64_t)bh * Lq + q),
+                                             (__attribute__((address_space(3))) void*)sc, 4, 0, 0);
+        else if (wave == 1)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + (int64_t)bh * Lq + q),
+                                             (__attribute__((address_space(3))) void*)(sc + 64), 4, 0, 0);
+    };
+    if (qt_first < nqt) stage(0, qt_first);
+    __syncthreads();
+    for (int t = qt_first; t < nqt; ++t) {
+        const int q0 = t * 64, cur = (t - qt_first) & 1;
+        if (t + 1 < nqt) stage(cur ^ 1, t + 1);
+        const unsigned char* Qs = smem + cur * 16384;
+        const unsigned char* dOs = Qs + 8192;
+        const float* lse_s = reinterpret_cast<const float*>(smem + 32768) + cur * 128;
+        const float* del_s = lse_s + 64;
+        if (CAUSAL && q0 + 63 < wave_kfirst) { __syncthreads(); continue; }   // every query of the tile precedes every key of this wave
         // interior tile: all 64 queries in range, all 32 keys of the wave valid and (causal) not in any query's future
         const bool interior = (q0 + 64 <= Lq) && (wave_kfirst + 31 < kl) && (!CAUSAL || wave_kfirst + 31 <= q0);
         f32x16 sq[2], dp[2];
@@ -263,13 +304,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             const int row = hf * 32 + r;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                sq[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qs, row, s, hh), kf[s], sq[hf], 0, 0, 0);
-                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(dOs, row, s, hh), vf[s], dp[hf], 0, 0, 0);
+                sq[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Qs, row, s, hh), kf[s], sq[hf], 0, 0, 0);
+                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(dOs, row, s, hh), vf[s], dp[hf], 0, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = hf * 32 + 8 * g + 4 * hh;   // 4 consecutive query rows live in regs 4g..4g+3
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql) * 1.4426950408889634f;   // base-2 for exp2(fma)
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ql);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -287,11 +328,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = pack8(sq[hf], s2), sf = pack8(dp[hf], s2);
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOt, r, hf, s2, hh), pf, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(dOt, 32 + r, hf, s2, hh), pf, dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, r, hf, s2, hh), sf, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(Qt, 32 + r, hf, s2, hh), sf, dk1, 0, 0, 0);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(dOs, 0, hf, s2, lane), pf, dv0, 0, 0, 0);   // dO^T from the dO tile
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(dOs, 1, hf, s2, lane), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Qs, 0, hf, s2, lane), sf, dk0, 0, 0, 0);    // Q^T from the Q tile
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Qs, 1, hf, s2, lane), sf, dk1, 0, 0, 0);
             }
+        __syncthreads();   // next tile's DMA landed; `cur` may be overwritten
     }
     if (key < Lk) {   // keys in [kl, Lk) get exact zeros
         const int64_t off = ((int64_t)b * Lk + key) * ldkv + hd * 64;
