@@ -34,18 +34,25 @@ def pmc_traffic(op_name):
         return None
     pmc = json.load(open(PMC_FILE))
     B, T, h = CFG["B"], CFG["T"], CFG["n_head"]
+    tiles = lambda m, n: ((m + 127) // 128) * ((n + 127) // 128) * 256
+    M = B * T
     table = {
-        "attention_bwd_dq[B%d h%d %dx%d]" % (B, h, T, T): ["attn_bwd_dq_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
-        "attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, T, T): ["attn_bwd_dkv_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
-        "gemm_nn[%dx%dx%d]" % (B * T, CFG["d_inner"], CFG["d_model"]): ["gemm_nn_kernel|grid=%d" % (((B * T + 127) // 128) * (CFG["d_inner"] // 128) * 256)],
-        "gemm_nt[%dx%dx%d]" % (B * T, CFG["d_inner"], CFG["d_model"]): ["gemm_nt_kernel|grid=%d" % (((B * T + 127) // 128) * (CFG["d_inner"] // 128) * 256)],
-        "attention_fwd[B%d h%d %dx%d]" % (B, h, T, T): ["attn_fwd_bf16_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
-        "ctc_loss_bwd[B%d L%d V%d U%d]" % (B, T, CFG["vocab_size"], CFG["U"] + 1): ["ctc_grad_kernel|grid=%d" % (64 * B * 256)],
+        "attention_bwd_dq[B%d h%d %dx%d]" % (B, h, T, T): [["attn_bwd_dq_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)]],
+        "attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, T, T): [["attn_bwd_dkv_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)]],
+        "attention_fwd[B%d h%d %dx%d]" % (B, h, T, T): [["attn_fwd_bf16_v2_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
+                                                       ["attn_fwd_bf16_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)]],
+        "ctc_loss_bwd[B%d L%d V%d U%d]" % (B, T, CFG["vocab_size"], CFG["U"] + 1): [["ctc_grad_kernel|grid=%d" % (64 * B * 256)]],
+        "gemm_nn[%dx%dx%d]" % (M, CFG["d_inner"], CFG["d_model"]): [["gemm_nn_tr_kernel|grid=%d" % tiles(M, CFG["d_inner"])],
+                                                                    ["gemm_nn_kernel|grid=%d" % tiles(M, CFG["d_inner"])]],
+        "gemm_nt[%dx%dx%d]" % (M, CFG["d_inner"], CFG["d_model"]): [["gemm_nt_glds_kernel|grid=%d" % tiles(M, CFG["d_inner"])],
+                                                                    ["gemm_nt_kernel|grid=%d" % tiles(M, CFG["d_inner"])]],
     }
-    keys = table.get(op_name)
-    if not keys or any(k not in pmc for k in keys):
-        return None
-    return int(sum(pmc[k]["hbm_bytes"] for k in keys))
+    for keys in table.get(op_name, []):
+        if all(k in pmc for k in keys):
+            return int(sum(pmc[k]["hbm_bytes"] for k in keys))
+    return None
+
+
 
 
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
@@ -105,9 +112,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        # nccl (= RCCL over xGMI) is the product backend; ASR_AMD_DIST_BACKEND=gloo + ASR_AMD_DEVICE=0 lets several ranks share one
+        # GPU so the data-parallel step can be exercised on a single-GPU box (test rig only)
+        dist.init_process_group(os.environ.get("ASR_AMD_DIST_BACKEND", "nccl"))
+    dev_index = int(os.environ.get("ASR_AMD_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import asr_amd
     from asr_amd import ops
@@ -204,6 +214,12 @@ def main():
                 "logits": float(np.abs(lg1.float().cpu().numpy() - ref_logits).max())}
         print(json.dumps(result))
     if world > 1:
+        if trainer is not None:   # data-parallel invariant: every rank holds bit-identical parameters after the same steps
+            chk = trainer.fp.flat.double().sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            assert float(lo) == float(hi), "ranks diverged: parameter checksum %r vs %r" % (float(lo), float(hi))
         torch.distributed.destroy_process_group()
 
 

@@ -643,9 +643,11 @@ template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t ld
 template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype,
                                      int64_t ldw, int M, int N, int K, const Epi& epi) {
     static const bool no_glds = getenv("ASR_AMD_NO_GLDS") != nullptr;   // A/B switch for benchmarking the staging paths
-    // (A/B on one MI355X: LDS-DMA double buffering +26 % at K = 2048, -3 % at K = 256 where only 4 k-steps exist and the 64 KB of
-    // LDS lowers residency, so short-K shapes keep the register-staged kernel)
-    if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= 1024) return launch_glds(s, A, lda, W, ldw, M, N, K, epi);
+    // (A/B on one MI355X after the epilogue / addressing diet: LDS-DMA double buffering +10..26 % at K = 2048, roughly neutral at
+    // K = 256 (-7 % on the [32000,2048,256] FFN1 shape, +10 % on the narrow-N ones, whole train step 1-2 % faster), so it is the
+    // default whenever K % 64 == 0; ASR_AMD_GLDS_MINK raises the threshold for experiments)
+    static const int glds_min_k = getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64;
+    if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= glds_min_k) return launch_glds(s, A, lda, W, ldw, M, N, K, epi);
     if (w_dtype == ASR_F32) return launch_gemm<float, float>(s, A, lda, W, ldw, M, N, K, epi);
     if (a_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
@@ -689,7 +691,8 @@ extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t 
     }
     EpiHeads<bf16_t> epi{reinterpret_cast<bf16_t*>(out), proj_stride, bias, L, h, M, N, scale_first};
     if (x_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
-    if (K % 64 == 0 && K >= 1024 && getenv("ASR_AMD_NO_GLDS") == nullptr) return launch_glds(s, X, ldx, W, ldw, M, N, K, epi);
+    if (K % 64 == 0 && K >= (getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64) && getenv("ASR_AMD_NO_GLDS") == nullptr)
+        return launch_glds(s, X, ldx, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
 }
 

@@ -13,10 +13,8 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
-    m = re.search(r"(gemm_nt_kernel|gemm_nn_kernel|gemm_tn_kernel|attn_fwd_bf16_kernel|attn_bwd_dq_kernel|attn_bwd_dkv_kernel|"
-                  r"add_layernorm_fwd_kernel|add_layernorm_bwd_kernel|ctc_\w+_kernel|ce_\w+_kernel|cif_\w+_kernel|colsum_kernel|"
-                  r"adam_kernel|embed_\w+_kernel|cast_f32_bf16_kernel|conv_sub\d_kernel)", name)
-    if not m:
+    m = re.search(r"(?:\d+)?([a-z][a-z0-9_]*_kernel)", name)
+    if not m or m.group(1).startswith("__amd"):
         return None
     k = m.group(1)
     if "EpiHeads" in name:
