@@ -450,8 +450,9 @@ extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda,
 extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int b_dtype, int64_t ldb, float* C,
                            int64_t ldc, int M, int N, int K, int zero_first, float* colsum) {
     ASR_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, ASR_ERR_ARG, "gemm_tn: bad args");
-    ASR_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= (N + 3) / 4 * 4 && ldb >= (K + 3) / 4 * 4, ASR_ERR_ALIGN,
-                "gemm_tn: lda/ldb must be multiples of 4 covering N/K rounded up to 4 (padded columns are read)");
+    // (no `ld >= width` requirement: overlapping row windows - conv1d as a GEMM, lda = C < K = w*C - are legitimate operands; the
+    // caller guarantees that rows may be read 4-element-group-wise up to the rounded-up width)
+    ASR_REQUIRE(lda % 4 == 0 && ldb % 4 == 0, ASR_ERR_ALIGN, "gemm_tn: lda/ldb must be multiples of 4");
     ASR_REQUIRE(asr_aligned(A, a_dtype == ASR_F32 ? 16 : 8) && asr_aligned(Bm, b_dtype == ASR_F32 ? 16 : 8), ASR_ERR_ALIGN,
                 "gemm_tn: operand alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);

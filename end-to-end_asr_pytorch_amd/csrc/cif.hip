@@ -20,7 +20,8 @@ namespace {
 
 __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ alpha, int L, float thr, float* __restrict__ cur_out,
                                                       float* __restrict__ rem_out, int32_t* __restrict__ fire_idx,
-                                                      int32_t* __restrict__ n_fire, int32_t* __restrict__ n_label) {
+                                                      int32_t* __restrict__ n_fire, int32_t* __restrict__ n_label,
+                                                      int32_t* __restrict__ tok_out) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const float* a = alpha + (int64_t)b * L;
     float integrate = 0.f;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
         const float av = (t < L) ? a[t] : 0.f;
         psum += av;
         float my_cur = 0.f, my_rem = 0.f;
+        int my_tok = 0;
         const int cnt = min(64, L - t0);
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
                 const float dc = 1.0f - integrate;
                 integrate = integrate + al;
                 const bool fire = integrate > thr;
+                if (lane == i) my_tok = n | (fire ? (1 << 30) : 0);   // token being accumulated at this frame (+ fire flag)
                 if (fire) {
                     integrate = integrate - 1.0f;
                     if (lane == i) fire_idx[(int64_t)b * L + n] = t0 + i;
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
         if (t < L) {
             cur_out[(int64_t)b * L + t] = my_cur;
             rem_out[(int64_t)b * L + t] = my_rem;
+            if (tok_out) tok_out[(int64_t)b * L + t] = my_tok;
         }
     }
     psum = wave_sum(psum);
@@ -85,13 +89,101 @@ __global__ __launch_bounds__(256) void cif_gather_kernel(const float* __restrict
     }
 }
 
+// ---- backward ------------------------------------------------------------------------------------------------------------
+// out[b,u,:] = sum_t w[u,t] h[b,t,:] with w = cur_t for the frames of token u and rem_f for the fire frame f that opened it.
+// One wave per frame (b,t): d_hidden[t] = cur_t * g(tok_t) (+ rem_t * g(tok_t + 1) on a fire frame), d_cur[t] = <g(tok_t), h_t>,
+// d_rem[t] = <g(tok_t + 1), h_t>, where g(u) = d_out[b,u,:] for emitted tokens (u < n_fire) and 0 otherwise.
+__global__ __launch_bounds__(256) void cif_gather_bwd_kernel(const float* __restrict__ hidden, const float* __restrict__ cur,
+                                                             const float* __restrict__ rem, const int32_t* __restrict__ tok,
+                                                             const int32_t* __restrict__ n_fire, const float* __restrict__ d_out, int M,
+                                                             int L, int H, int Umax, float* __restrict__ d_hidden,
+                                                             float* __restrict__ d_cur, float* __restrict__ d_rem) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int b = (int)(row / L);
+    const int te = tok[row];
+    const int u = te & 0x3fffffff;
+    const bool fire = (te >> 30) & 1;
+    const int nf = min(n_fire[b], Umax);
+    const bool has1 = u < nf, has2 = fire && (u + 1 < nf);
+    const float c = cur[row], rm = rem[row];
+    const float* g1 = d_out + ((int64_t)b * Umax + u) * H;
+    const float* g2 = g1 + H;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane * 4; k < H; k += 256) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(hidden + row * H + k);
+        f32x4 o = {0, 0, 0, 0};
+        if (has1) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(g1 + k);
+            o = a * c;
+            s1 += (a[0] * hv[0] + a[1] * hv[1]) + (a[2] * hv[2] + a[3] * hv[3]);
+        }
+        if (has2) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(g2 + k);
+            o += a * rm;
+            s2 += (a[0] * hv[0] + a[1] * hv[1]) + (a[2] * hv[2] + a[3] * hv[3]);
+        }
+        *reinterpret_cast<f32x4*>(d_hidden + row * H + k) = o;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { d_cur[row] = s1; d_rem[row] = s2; }
+}
+
+// d_alpha from d_cur / d_rem.  Non-fire frame: cur = alpha_t (d_alpha_t += d_cur_t).  Fire frame f: cur_f = 1 - integrate_before_f,
+// rem_f = alpha_f - cur_f, and integrate_before_f = sum_{j<f} alpha_j - (#fires before f): every EARLIER alpha_j receives
+// (d_rem_f - d_cur_f), alpha_f itself receives d_rem_f.  So d_alpha_t = own_t + sum_{fires f > t} (d_rem_f - d_cur_f): a suffix sum,
+// done by one wave per utterance walking 64-frame chunks from the end.
+__global__ __launch_bounds__(64) void cif_scan_bwd_kernel(const float* __restrict__ d_cur, const float* __restrict__ d_rem,
+                                                          const int32_t* __restrict__ tok, int L, float* __restrict__ d_alpha) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float carry = 0.f;   // sum of g over all frames after the current chunk
+    for (int t0 = ((L - 1) / 64) * 64; t0 >= 0; t0 -= 64) {
+        const int t = t0 + lane;
+        const bool ok = t < L;
+        const int64_t idx = (int64_t)b * L + (ok ? t : 0);
+        const bool fire = ok && ((tok[idx] >> 30) & 1);
+        const float dc = ok ? d_cur[idx] : 0.f, dr = ok ? d_rem[idx] : 0.f;
+        const float g = fire ? (dr - dc) : 0.f;
+        float incl = g;                               // inclusive suffix sum within the chunk
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float v = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += v;
+        }
+        const float excl = incl - g + carry;          // sum over frames strictly after t
+        if (ok) d_alpha[idx] = (fire ? dr : dc) + excl;
+        carry += __shfl(incl, 0, 64);
+    }
+}
+
 }  // namespace
 
+extern "C" int asr_cif_gather_bwd(void* stream, const float* hidden, const float* cur, const float* rem, const int32_t* tok,
+                                  const int32_t* n_fire, const float* d_out, int B, int L, int H, int Umax, float* d_hidden, float* d_cur,
+                                  float* d_rem) {
+    ASR_REQUIRE(hidden && cur && rem && tok && n_fire && d_out && d_hidden && d_cur && d_rem, ASR_ERR_ARG, "cif_gather_bwd: null pointer");
+    ASR_REQUIRE(B > 0 && L > 0 && H > 0 && H % 4 == 0 && Umax > 0, ASR_ERR_ARG, "cif_gather_bwd: bad sizes");
+    const int M = B * L;
+    hipLaunchKernelGGL(cif_gather_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), hidden, cur, rem, tok, n_fire,
+                       d_out, M, L, H, Umax, d_hidden, d_cur, d_rem);
+    ASR_LAUNCH_CHECK("cif_gather_bwd");
+    return 0;
+}
+
+extern "C" int asr_cif_scan_bwd(void* stream, const float* d_cur, const float* d_rem, const int32_t* tok, int B, int L, float* d_alpha) {
+    ASR_REQUIRE(d_cur && d_rem && tok && d_alpha && B > 0 && L > 0, ASR_ERR_ARG, "cif_scan_bwd: bad args");
+    hipLaunchKernelGGL(cif_scan_bwd_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), d_cur, d_rem, tok, L, d_alpha);
+    ASR_LAUNCH_CHECK("cif_scan_bwd");
+    return 0;
+}
+
 extern "C" int asr_cif_scan_fwd(void* stream, const float* alpha, int B, int L, float threshold, float* cur, float* rem,
-                                int32_t* fire_idx, int32_t* n_fire, int32_t* n_label) {
+                                int32_t* fire_idx, int32_t* n_fire, int32_t* n_label, int32_t* tok) {
     ASR_REQUIRE(alpha && cur && rem && fire_idx && n_fire && n_label && B > 0 && L > 0, ASR_ERR_ARG, "cif_scan: bad args");
     hipLaunchKernelGGL(cif_scan_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), alpha, L, threshold, cur, rem, fire_idx,
-                       n_fire, n_label);
+                       n_fire, n_label, tok);
     ASR_LAUNCH_CHECK("cif_scan_fwd");
     return 0;
 }

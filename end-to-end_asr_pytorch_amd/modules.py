@@ -489,8 +489,14 @@ class Conv1d(_Cached):
                        ("{}/relu_{}".format(name, i + 1), nn.ReLU())]
         self.conv = nn.Sequential(OrderedDict(layers))
 
-    def _impl(self, x):
-        """x: Act [B*L, C] -> f32 tensor [B, L, d_hidden]"""
+    def _wg(self, i):
+        m = getattr(self.conv, "{}/conv1d_{}".format(self.name, i))
+        return self._derived("w%d" % i, (m.weight,), lambda m=m: (
+            ops.cast_bf16(m.weight.detach().permute(0, 2, 1).reshape(m.weight.shape[0], -1).contiguous())
+            if _PRECISION == "bf16" else m.weight.detach().permute(0, 2, 1).reshape(m.weight.shape[0], -1).contiguous().float()))
+
+    def _impl(self, x, save=False):
+        """x: Act [B*L, C] -> f32 tensor [B, L, d_hidden] (and the per-layer buffers when save=True, for the backward)"""
         B, L, w, n = x.B, x.L, self.w_context, self.n_layers
         Lp = L + n * w
         C = x.f32.shape[1]
@@ -498,17 +504,40 @@ class Conv1d(_Cached):
         buf = torch.zeros((B * Lp + w, C), device=x.f32.device, dtype=cd)
         src = x.mma() if x.mma().dtype == cd else (ops.cast_bf16(x.f32) if cd == torch.bfloat16 else x.f32)
         buf[:B * Lp].view(B, Lp, C)[:, :L].copy_(src.view(B, L, C))
+        bufs, outs = [], []
         for i in range(n):
             m = getattr(self.conv, "{}/conv1d_{}".format(self.name, i))
-            Wg = self._derived("w%d" % i, (m.weight,), lambda m=m: (
-                ops.cast_bf16(m.weight.detach().permute(0, 2, 1).reshape(m.weight.shape[0], -1).contiguous())
-                if _PRECISION == "bf16" else m.weight.detach().permute(0, 2, 1).reshape(m.weight.shape[0], -1).contiguous().float()))
             last = i == n - 1
             out = torch.zeros((B * Lp + w, self.d_hidden), device=buf.device, dtype=torch.float32 if last else cd)
-            ops.gemm_nt_raw(buf, B * Lp, w * buf.shape[1], buf.shape[1], Wg, m.bias.detach().float().contiguous(), relu=True,
+            ops.gemm_nt_raw(buf, B * Lp, w * buf.shape[1], buf.shape[1], self._wg(i), m.bias.detach().float().contiguous(), relu=True,
                             out=out, ldc=self.d_hidden)
+            bufs.append(buf)
+            outs.append(out)
             buf = out
-        return buf[:B * Lp].view(B, Lp, self.d_hidden)[:, :L].contiguous()
+        y = buf[:B * Lp].view(B, Lp, self.d_hidden)[:, :L].contiguous()
+        return (y, (bufs, outs, B, L, Lp)) if save else y
+
+    def _backward(self, saved, d_y):
+        """d_y f32 [B, L, d_hidden] -> d_x f32 [B*L, C]; accumulates the conv weights' / biases' gradients."""
+        bufs, outs, B, L, Lp = saved
+        w, n = self.w_context, self.n_layers
+        rows = B * Lp
+        d = torch.zeros((rows + w, self.d_hidden), device=d_y.device, dtype=torch.float32)
+        d[:rows].view(B, Lp, self.d_hidden)[:, :L].copy_(d_y)
+        for i in range(n - 1, -1, -1):
+            m = getattr(self.conv, "{}/conv1d_{}".format(self.name, i))
+            cin = bufs[i].shape[1]
+            d_pre = (d * (outs[i] > 0)).contiguous()                                  # ReLU backward on a [rows, d_hidden] tensor
+            win = torch.as_strided(bufs[i], (rows, w * cin), (cin, 1))              # the overlapping row windows the forward GEMM read
+            dwg = ops.gemm_tn(d_pre[:rows], win)                                      # [O, w*cin]
+            m.weight.grad.add_(dwg.view(-1, w, cin).permute(0, 2, 1))
+            ops.colsum(d_pre[:rows], out=m.bias.grad, accumulate=True)
+            d_win = ops.gemm_nn(d_pre[:rows], self._wg(i))                            # [rows, w*cin] f32
+            d_in = torch.zeros((rows + w, cin), device=d.device, dtype=torch.float32)
+            for j in range(w):                                                        # overlap-add of the w window slots
+                d_in[j:j + rows].add_(d_win[:, j * cin:(j + 1) * cin])
+            d = d_in
+        return d[:rows].view(B, Lp, -1)[:, :L].reshape(B * L, -1).contiguous()
 
     def forward(self, feats, feat_lengths):
         return self._impl(_act(feats)), feat_lengths
@@ -524,10 +553,33 @@ class Attention_Assigner(nn.Module):
         self.linear = nn.Linear(d_hidden, 1)
         self.dropout_rate = dropout
 
-    def _impl(self, x, lens):
-        hcv = self.conv._impl(x)
-        return ops.assigner_tail(hcv, self.linear.weight.detach().float().contiguous().view(-1),
-                                 self.linear.bias.detach().float().contiguous(), lens, x.B, x.L)
+    def _impl(self, x, lens, slot=None):
+        """-> alpha f32 [B,L].  When the tape is recording, `slot` ({"g": d_alpha}) is read by the pushed backward closure."""
+        rec = _TAPE is not None and slot is not None
+        w = self.linear.weight.detach().float().contiguous().view(-1)
+        if not rec:
+            hcv = self.conv._impl(x)
+            return ops.assigner_tail(hcv, w, self.linear.bias.detach().float().contiguous(), lens, x.B, x.L)
+        hcv, saved = self.conv._impl(x, save=True)
+        alpha = ops.assigner_tail(hcv, w, self.linear.bias.detach().float().contiguous(), lens, x.B, x.L)
+        lin, conv = self.linear, self.conv
+        params = [lin.weight, lin.bias]
+        for i in range(conv.n_layers):
+            cm = getattr(conv.conv, "{}/conv1d_{}".format(conv.name, i))
+            params += [cm.weight, cm.bias]
+
+        def bw():
+            g = slot["g"]
+            dz = (g * alpha * (1.0 - alpha)).reshape(-1)        # sigmoid' (alpha is 0 on masked frames, so is dz); [B*L] glue ops
+            h2 = hcv.view(-1, hcv.shape[-1])
+            lin.weight.grad.add_((dz[None, :] @ h2))
+            lin.bias.grad.add_(dz.sum())
+            d_hcv = dz[:, None] * w[None, :]
+            _acc(x, conv._backward(saved, d_hcv.view(x.B, x.L, -1)))
+            slot["g"] = None
+
+        _TAPE.push(bw, params)
+        return alpha
 
     def forward(self, padded_input, input_lengths):
         return self._impl(_act(padded_input), ops.as_i32(input_lengths, padded_input.device))
@@ -658,48 +710,66 @@ class Decoder_CIF(_Cached):
         sos = torch.full((target.size(0), 1), self.sos_id, dtype=torch.long, device=target.device)
         return torch.cat([sos, target[:, :-1]], 1) * pad_mask
 
-    def forward(self, encoded_attentioned, target):
+    def forward(self, encoded_attentioned, target, cif_slot=None):
+        """cif_slot: {"g": tensor or None} - when the tape is recording, the gradient wrt `encoded_attentioned` is accumulated there."""
         B, U, D = encoded_attentioned.shape
+        rec = _TAPE is not None and cif_slot is not None
         ys_in = self.preprocess(target)
         dec_len = (target > 0).sum(1).to(torch.int32)          # tail padding (every reference data path)
         cif32 = encoded_attentioned.contiguous().float().view(B * U, D)
         e32, _ = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U))
-        x = ops.gemm_nt(torch.cat([cif32, e32], -1), self._w("inaff", (self.input_affine.weight,)), None)
-        a = Act(x, None, B, U)
+        cat1 = torch.cat([cif32, e32], -1)
+        w_in = self._w("inaff", (self.input_affine.weight,))
+        a = Act(ops.gemm_nt(cat1, w_in, None), None, B, U)
+        if rec:
+            a0, emb, aff = a, self.tgt_word_emb, self.input_affine
+
+            def bw_in():
+                ops.gemm_tn(a0.grad, cat1, out=aff.weight.grad, accumulate=True)
+                d_cat = ops.gemm_nn(a0.grad, w_in)
+                a0.grad = None
+                cif_slot["g"] = d_cat[:, :D] if cif_slot["g"] is None else cif_slot["g"] + d_cat[:, :D]
+                ops.embed_bwd(ys_in, d_cat[:, D:].contiguous(), emb.weight.grad)
+
+            _TAPE.push(bw_in, (aff.weight, emb.weight))
         for layer in self.layer_stack:
             a = layer._impl(a, dec_len, causal=True)
-        logits = ops.gemm_nt(torch.cat([cif32, a.f32], -1), self._w("prj", (self.tgt_word_prj.weight,)), None)
+        cat2 = Act(torch.cat([cif32, a.f32], -1), None, B, U)
+        if rec:
+            a_last = a
+
+            def bw_split():   # runs after the vocab projection's closure has produced cat2.grad
+                g = cat2.grad
+                cat2.grad = None
+                cif_slot["g"] = g[:, :D] if cif_slot["g"] is None else cif_slot["g"] + g[:, :D]
+                _acc(a_last, g[:, D:].contiguous())
+
+            _TAPE.push(bw_split, ())
+        logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, cat2)
         return logits.view(B, U, self.n_tgt_vocab)
 
 
 # ------------------------------------------------------------------------------------------------------------
 class _TapeFn(torch.autograd.Function):
-    """Bridges torch.autograd to the HIP backward tape: forward records the tape; backward seeds the two logits gradients,
-    replays the tape (HIP kernels write into a flat scratch gradient buffer laid out like the trainer's) and returns one
-    gradient per parameter, so `loss.backward()` + any torch optimizer work exactly as with the reference's modules."""
+    """Bridges torch.autograd to the HIP backward tape: forward records the tape; backward seeds each differentiable output's
+    gradient slot, replays the tape (HIP kernels write into a flat scratch gradient buffer laid out like the trainer's) and
+    returns one gradient per parameter, so `loss.backward()` + any torch optimizer work exactly as with the reference's modules."""
 
     @staticmethod
     def forward(ctx, model, run, holder, *params):
         with torch.no_grad(), record() as tape:
-            ctc2d, logits3d, extra = run()
+            outs, slots, extra = run()
         holder["extra"] = extra
-        ctx.model, ctx.tape, ctx.params = model, tape, params
-        outs = tuple(t for t in (ctc2d, logits3d) if t is not None)
-        ctx.has_ctc = ctc2d is not None
-        return outs
+        ctx.model, ctx.tape, ctx.params, ctx.slots = model, tape, params, slots
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
-        from .trainer import _param_order
+        from .trainer import _param_order, flat_offsets
         model, tape, params = ctx.model, ctx.tape, ctx.params
-        gouts = list(gouts)
-        g_ctc = gouts.pop(0) if ctx.has_ctc else None
-        g_log = gouts.pop(0)
         order = _param_order(model)
-        offs, n = {}, 0
-        for p in order:
-            offs[id(p)] = n
-            n += p.numel()
+        off_list, n = flat_offsets(order)
+        offs = {id(p): o for p, o in zip(order, off_list)}
         dev = order[0].device
         scratch = torch.zeros((n + 63) // 64 * 64, device=dev, dtype=torch.float32)
         saved = []
@@ -710,13 +780,10 @@ class _TapeFn(torch.autograd.Function):
             p._asr_off, p._asr_gflat = off, scratch
         try:
             with torch.no_grad():
-                if ctx.has_ctc:
-                    slot = model._grad_slots["ctc"]
-                    slot["g"] = g_ctc if g_ctc is not None else torch.zeros(slot["shape"], device=dev)
-                slot = model.decoder._grad_slots["prj"]
-                slot["g"] = g_log if g_log is not None else torch.zeros(slot["shape"], device=dev)
+                for g, slot in zip(gouts, ctx.slots):
+                    slot["g"] = g if g is not None else torch.zeros(slot["shape"], device=dev)
                 tape.backward()
-            grads = tuple(p.grad.clone() if False else p.grad for p in params)
+            grads = tuple(p.grad for p in params)
         finally:
             for p, g, off, gf in saved:
                 p.grad = g
@@ -725,6 +792,22 @@ class _TapeFn(torch.autograd.Function):
                 else:
                     p._asr_off, p._asr_gflat = off, gf
         return (None, None, None) + grads
+
+
+def _taped(model, run):
+    """run() -> (differentiable outputs, their gradient slots, extra).  Attaches the tape-backed autograd node when wanted."""
+    if not _autograd_wanted(model):
+        outs, _, extra = run()
+        return list(outs), extra
+    holder = {}
+    params = [p for p in model.parameters() if p.requires_grad]
+    outs = _TapeFn.apply(model, run, holder, *params)
+    return list(outs), holder["extra"]
+
+
+def _slots(*mods_keys):
+    """gradient slots registered by _vocab_proj while recording: _slots(modA, "keyA", modB, "keyB") (None when not recording)"""
+    return [mods_keys[i].__dict__.get("_grad_slots", {}).get(mods_keys[i + 1]) for i in range(0, len(mods_keys), 2)]
 
 
 def _autograd_wanted(model):
@@ -748,24 +831,13 @@ class Transformer(_Cached):
             raise NotImplementedError("spec_aug is a train-time augmentation outside the hot path (SURVEY.md §2 row 9)")
         _xavier_all(self)
 
-    def _taped(self, run):
-        """run() -> (ctc_logits2d or None, logits3d, extra); returns the same with autograd attached when wanted."""
-        if not _autograd_wanted(self):
-            return run()
-        holder = {}
-        params = [p for p in self.parameters() if p.requires_grad]
-        outs = _TapeFn.apply(self, run, holder, *params)
-        if len(outs) == 2:
-            return outs[0], outs[1], holder["extra"]
-        return None, outs[0], holder["extra"]
-
     def forward(self, features, len_features, padded_target):
         def run():
             lens = ops.as_i32(len_features, features.device)
             enc = self.encoder._impl(_act(features), lens)
             logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
-            return None, logits, targets_eos
-        _, logits, targets_eos = self._taped(run)
+            return [logits], [self.decoder.__dict__.get("_grad_slots", {}).get("prj")], targets_eos
+        (logits,), targets_eos = _taped(self, run)
         return logits, targets_eos
 
 
@@ -787,8 +859,8 @@ class CTC_Transformer(Transformer):
             enc = self.encoder._impl(_act(features), lens)
             ctc_pred = self._ctc_logits(enc)
             logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
-            return ctc_pred, logits, targets_eos
-        ctc_pred, logits, targets_eos = self._taped(run)
+            return [ctc_pred, logits], _slots(self, "ctc", self.decoder, "prj"), targets_eos
+        (ctc_pred, logits), targets_eos = _taped(self, run)
         return len_features, ctc_pred.view(B, L, -1), (logits, targets_eos)
 
 
@@ -805,8 +877,8 @@ class Conv_CTC_Transformer(CTC_Transformer):
             enc = self.encoder._impl(conv, len_sequence)
             ctc_logits = self._ctc_logits(enc)
             logits, targets_eos = self.decoder._impl(targets, enc, len_sequence)
-            return ctc_logits, logits, (targets_eos, len_sequence, enc.B, enc.L)
-        ctc_logits, logits, (targets_eos, len_sequence, B, L) = self._taped(run)
+            return [ctc_logits, logits], _slots(self, "ctc", self.decoder, "prj"), (targets_eos, len_sequence, enc.B, enc.L)
+        (ctc_logits, logits), (targets_eos, len_sequence, B, L) = _taped(self, run)
         return ctc_logits.view(B, L, -1), len_sequence, logits, targets_eos
 
     @classmethod
@@ -847,18 +919,58 @@ class CIF_Model(_Cached):
         _xavier_all(self)
 
     def forward(self, features, len_features, targets, threshold=0.95, noise=None):
+        def run():
+            ctc3d, len_sequence, _num, num, logits = self._forward_impl(features, len_features, targets, threshold, noise)
+            slots = _slots(self, "ctc", self, "num", self.decoder, "prj")
+            return [ctc3d, _num, logits], slots, (len_sequence, num)
+        (ctc3d, _num, logits), (len_sequence, num) = _taped(self, run)
+        return ctc3d, len_sequence, _num, num, logits
+
+    def _forward_impl(self, features, len_features, targets, threshold, noise):
+        rec = _TAPE is not None
         conv, len_sequence = self.conv_encoder._impl(features, len_features)
         enc = self.encoder._impl(conv, len_sequence)
-        ctc_logits = ops.gemm_nt(enc.mma(), self._w("ctc", (self.ctc_fc.weight,)), None).view(enc.B, enc.L, -1)
-        alpha = self.assigner._impl(enc, len_sequence)
-        _num = alpha.sum(-1)
+        ctc2d = _vocab_proj(self, "ctc", self.ctc_fc.weight, enc)
+        asg_slot = {"g": None} if rec else None
+        alpha_raw = self.assigner._impl(enc, len_sequence, asg_slot)
+        _num = alpha_raw.sum(-1)
         num = (targets > 0).float().sum(-1)
         if noise is None:
-            noise = torch.rand(alpha.size(0), device=alpha.device)     # cif_model.py:47
-        alpha = alpha * ((num + noise - 0.5) / _num)[:, None]
-        l = self.cif(enc.view3(), alpha, threshold=threshold)
-        logits = self.decoder(l, targets)
-        return ctc_logits, len_sequence, _num, num, logits
+            noise = torch.rand(alpha_raw.size(0), device=alpha_raw.device)     # cif_model.py:47
+        num_noise = num + noise - 0.5
+        scale = num_noise / _num
+        alpha = alpha_raw * scale[:, None]
+        if not rec:
+            l = self.cif(enc.view3(), alpha, threshold=threshold)
+            logits = self.decoder(l, targets)
+            return ctc2d.view(enc.B, enc.L, -1), len_sequence, _num, num, logits
+        # ---- recording: CIF with its backward closure (d_l arrives through cif_slot, d(_num) through the "num" slot) -----------------
+        hidden = enc.view3()
+        cur, rem, fire_idx, n_fire, n_label, tok = ops.cif_scan(alpha.float(), threshold, want_tok=True)
+        stats = torch.stack([n_label.max(), n_fire.max()]).tolist()
+        if stats[1] > stats[0]:
+            raise RuntimeError("cif: a row fires %d times but max round(sum alpha) is %d (cif_model.py:100)" % (stats[1], stats[0]))
+        self.last_fire = (fire_idx, n_fire, n_label)
+        l = ops.cif_gather(hidden.float().contiguous(), cur, rem, fire_idx, n_fire, int(stats[0]))
+        cif_slot = {"g": None}
+        num_slot = {"g": None, "shape": tuple(_num.shape)}
+        self.__dict__.setdefault("_grad_slots", {})["num"] = num_slot
+
+        def bw_cif():
+            d_l = cif_slot["g"].reshape(l.shape)
+            d_hidden, d_alpha = ops.cif_bwd(hidden, cur, rem, tok, n_fire, d_l)
+            _acc(enc, d_hidden.view(enc.B * enc.L, -1))
+            # alpha = alpha_raw * (num_noise / sum(alpha_raw)): [B,L] glue ops (cif_model.py:44-48), plus d(_num) from the quantity loss
+            d_num = (d_alpha * alpha_raw).sum(-1) * (-num_noise / (_num * _num))
+            if num_slot["g"] is not None:
+                d_num = d_num + num_slot["g"]
+            asg_slot["g"] = d_alpha * scale[:, None] + d_num[:, None]
+            cif_slot["g"] = None
+            num_slot["g"] = None
+
+        _TAPE.push(bw_cif, ())
+        logits = self.decoder(l, targets, cif_slot)
+        return ctc2d.view(enc.B, enc.L, -1), len_sequence, _num, num, logits
 
     def cif(self, hidden, alphas, threshold, log=False, max_label_len=None):
         """cif_model.py:57-106."""

@@ -282,8 +282,8 @@ def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout):
     return grad
 
 
-def cif_scan(alpha, threshold):
-    """alpha f32 [B,L] -> cur, rem [B,L], fire_idx int32 [B,L], n_fire [B], n_label [B]"""
+def cif_scan(alpha, threshold, want_tok=False):
+    """alpha f32 [B,L] -> cur, rem [B,L], fire_idx int32 [B,L], n_fire [B], n_label [B] (+ tok int32 [B,L] when want_tok)"""
     _req_cuda(alpha)
     alpha = alpha.contiguous()
     B, L = alpha.shape
@@ -293,8 +293,11 @@ def cif_scan(alpha, threshold):
     fire_idx = torch.zeros((B, L), device=dev, dtype=torch.int32)
     n_fire = torch.empty(B, device=dev, dtype=torch.int32)
     n_label = torch.empty(B, device=dev, dtype=torch.int32)
-    check(lib().asr_cif_scan_fwd(_stream(), _p(alpha), B, L, float(threshold), _p(cur), _p(rem), _p(fire_idx), _p(n_fire), _p(n_label)),
-          "asr_cif_scan_fwd")
+    tok = torch.empty((B, L), device=dev, dtype=torch.int32) if want_tok else None
+    check(lib().asr_cif_scan_fwd(_stream(), _p(alpha), B, L, float(threshold), _p(cur), _p(rem), _p(fire_idx), _p(n_fire), _p(n_label),
+                                 _p(tok)), "asr_cif_scan_fwd")
+    if want_tok:
+        return cur, rem, fire_idx, n_fire, n_label, tok
     return cur, rem, fire_idx, n_fire, n_label
 
 
@@ -430,3 +433,19 @@ def conv_col2im_relu(dcol, y, Tout, Fout):
     dx = torch.empty_like(y)
     check(lib().asr_conv_col2im_relu(_stream(), _p(dcol), dcol.stride(0), _p(y), _p(dx), B, Tin, Fin, Tout, Fout), "asr_conv_col2im_relu")
     return dx
+
+
+def cif_bwd(hidden, cur, rem, tok, n_fire, d_out):
+    """-> (d_hidden [B,L,H], d_alpha [B,L]) for out = cif(hidden, alpha)"""
+    hidden = hidden.contiguous()
+    d_out = d_out.contiguous().float()
+    B, L, H = hidden.shape
+    Umax = d_out.shape[1]
+    d_hidden = torch.empty_like(hidden)
+    d_cur = torch.empty((B, L), device=hidden.device, dtype=torch.float32)
+    d_rem = torch.empty((B, L), device=hidden.device, dtype=torch.float32)
+    check(lib().asr_cif_gather_bwd(_stream(), _p(hidden), _p(cur), _p(rem), _p(tok), _p(n_fire), _p(d_out), B, L, H, Umax, _p(d_hidden),
+                                   _p(d_cur), _p(d_rem)), "asr_cif_gather_bwd")
+    d_alpha = torch.empty((B, L), device=hidden.device, dtype=torch.float32)
+    check(lib().asr_cif_scan_bwd(_stream(), _p(d_cur), _p(d_rem), _p(tok), B, L, _p(d_alpha)), "asr_cif_scan_bwd")
+    return d_hidden, d_alpha

@@ -41,16 +41,23 @@ def _param_order(model):
     return order
 
 
+def flat_offsets(order):
+    """Element offsets of the parameters in one flat buffer: each starts on a multiple of 8 elements (16 bytes of bf16), so odd-sized
+    parameters (e.g. a 1-element bias) cannot misalign the MFMA operands that follow; Q/K/V weight (bias) triples stay adjacent
+    because their sizes are multiples of 64.  Returns (offsets, total)."""
+    offs, n = [], 0
+    for p in order:
+        offs.append(n)
+        n = (n + p.numel() + 7) // 8 * 8
+    return offs, n
+
+
 class FlatParams:
     """Re-homes every parameter into one flat fp32 buffer, with a flat gradient buffer and a flat bf16 shadow."""
 
     def __init__(self, model, device):
         self.params = _param_order(model)
-        offs, n = [], 0
-        for p in self.params:
-            offs.append(n)
-            n += (p.numel() + 7) // 8 * 8 if False else p.numel()   # no padding: Q/K/V must stay adjacent
-        # every parameter here has a multiple-of-8 element count except scalars/biases of odd size; pad the tail only
+        offs, n = flat_offsets(self.params)
         self.numel = n
         total = (n + 63) // 64 * 64
         self.flat = torch.zeros(total, device=device, dtype=torch.float32)
@@ -130,8 +137,9 @@ class Trainer:
     (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
 
     def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=4,
-                 process_group=None):
+                 process_group=None, lambda_qua=0.001):
         self.model = model
+        self.lambda_qua = lambda_qua      # CIF models: loss = lambda_qua * qua + ctc + ce (solver.py:153, train.py:64)
         dev = next(model.parameters()).device
         self.fp = FlatParams(model, dev)
         self.fp.check_alignment()
@@ -148,22 +156,30 @@ class Trainer:
         """optimizer.py:24-29 (step_num already incremented)."""
         return self.k * self.init_lr * min(self.step_num ** (-0.5), self.step_num * (self.warmup ** (-1.5)))
 
-    def forward_loss(self, feats, lens, targets):
+    def forward_loss(self, feats, lens, targets, noise=None):
         """forward + joint loss with the tape recorded; returns (ctc, ce, state for backward)."""
         model = self.model
+        d_num = None
         with torch.no_grad(), modules.record() as tape:
-            out = model(feats, lens, targets)
-            if isinstance(model, modules.Conv_CTC_Transformer):
-                ctc_logits, ctc_len, logits, teos = out
+            if isinstance(model, modules.CIF_Model):
+                # CIF family (solver.py:146-153): CTC and CE both on `targets` (no <eos>), plus the quantity loss on sum(alpha)
+                ctc_logits, ctc_len, num_pred, num, logits = model(feats, lens, targets, noise=noise)
+                teos = targets
+                d_num = self.lambda_qua * 2.0 * (num_pred - num) / num.numel()
+                self.last_qua = ((num_pred - num) ** 2).mean()
             else:
-                ctc_len, ctc_logits, (logits, teos) = out
+                out = model(feats, lens, targets)
+                if isinstance(model, modules.Conv_CTC_Transformer):
+                    ctc_logits, ctc_len, logits, teos = out
+                else:
+                    ctc_len, ctc_logits, (logits, teos) = out
             ctc, nll, st = ops.ctc_loss_fwd(ctc_logits, ops.as_i32(ctc_len, ctc_logits.device), teos)
             V = logits.shape[-1]
             loss2, row_loss, lse, tg1 = ops.ce_loss_fwd(logits.reshape(-1, V), teos.reshape(-1), self.smoothing)
-        return ctc, loss2[0], (tape, st, logits, tg1, lse, loss2)
+        return ctc, loss2[0], (tape, st, logits, tg1, lse, loss2, d_num)
 
     def backward(self, state):
-        tape, st, logits, tg1, lse, loss2 = state
+        tape, st, logits, tg1, lse, loss2, d_num = state
         model = self.model
         one = torch.ones(1, device=logits.device)
         with torch.no_grad():
@@ -171,6 +187,8 @@ class Trainer:
             model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one)
             V = logits.shape[-1]
             model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one)
+            if d_num is not None:
+                model._grad_slots["num"]["g"] = d_num
             self.buckets.start()
             tape.backward(lambda fn: self.buckets.on_done(fn.params))
             self.buckets.finish()
@@ -181,10 +199,10 @@ class Trainer:
                       grad_scale=1.0 / self.world, p16=self.fp.flat16)
         modules.bump_param_epoch()     # derived (re-laid-out) weights are rebuilt from the new parameters on next use
 
-    def step(self, feats, lens, targets):
+    def step(self, feats, lens, targets, noise=None):
         """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync)."""
         self.fp.grad.zero_()
-        ctc, ce, state = self.forward_loss(feats, lens, targets)
+        ctc, ce, state = self.forward_loss(feats, lens, targets, noise=noise)
         self.backward(state)
         self.optimizer_step()
         return ctc, ce

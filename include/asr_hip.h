@@ -185,12 +185,19 @@ int asr_ce_loss_bwd(void* stream, const float* logits, int64_t ldl, const int64_
 /* ------------------------------------------------------------------------------------------------------------
  * CIF (cif_model.py:57-106).  asr_cif_scan_fwd runs the integrate-and-fire recurrence in the reference's exact fp32
  * operation order (one wavefront per utterance): cur/rem f32 [B,L] weights, fire_idx int32 [B,L] (frame index of
- * each fire, in order), n_fire int32 [B], n_label int32 [B] = round(sum alpha) (cif_model.py:95).
+ * each fire, in order), n_fire int32 [B], n_label int32 [B] = round(sum alpha) (cif_model.py:95), tok optional (see backward).
  * asr_cif_gather_fwd forms out[b,u,:] (f32 [B,Umax,H], zero-padded rows u >= n_fire[b]) as the same ordered
  * fp32 sum the reference accumulates.
  */
 int asr_cif_scan_fwd(void* stream, const float* alpha, int B, int L, float threshold, float* cur, float* rem,
-                     int32_t* fire_idx, int32_t* n_fire, int32_t* n_label);
+                     int32_t* fire_idx, int32_t* n_fire, int32_t* n_label, int32_t* tok);
+/* Backward of the two CIF kernels.  tok (int32 [B,L], optional output of asr_cif_scan_fwd): index of the token frame t accumulates
+ * into, bit 30 set when the frame fires.  gather_bwd: d_out f32 [B,Umax,H] -> d_hidden [B,L,H], d_cur / d_rem [B,L];
+ * scan_bwd: d_cur / d_rem -> d_alpha [B,L] (the autograd of cif_model.py:67-87 through the running `integrate`). */
+int asr_cif_gather_bwd(void* stream, const float* hidden, const float* cur, const float* rem, const int32_t* tok,
+                       const int32_t* n_fire, const float* d_out, int B, int L, int H, int Umax, float* d_hidden, float* d_cur,
+                       float* d_rem);
+int asr_cif_scan_bwd(void* stream, const float* d_cur, const float* d_rem, const int32_t* tok, int B, int L, float* d_alpha);
 int asr_cif_gather_fwd(void* stream, const float* hidden, const float* cur, const float* rem, const int32_t* fire_idx,
                        const int32_t* n_fire, int B, int L, int H, int Umax, float* out);
 

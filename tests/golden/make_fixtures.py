@@ -243,7 +243,11 @@ def g4_cif_model():
     alpha0 = model.assigner(enc_out, len_seq)
     alpha = alpha0 * ((num + noise - 0.5) / alpha0.sum(-1))[:, None]
     cif_out = model.cif(enc_out, alpha, 0.95)
-    np.savez_compressed(os.path.join(HERE, "g4_cif_model.npz"), names_shapes=names_shapes_to_json(ns), seed=104,
+    # the CIF solver's step (solver.py:146-157): loss = lambda_qua * qua + ctc + ce, lambda_qua = 0.001 (train.py:64)
+    model.zero_grad()
+    (0.001 * qua + ctc + ce).backward()
+    grads = {"grad:" + k: npy(p.grad).astype(np.float16 if p.grad.numel() > 20000 else np.float32) for k, p in model.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "g4_cif_model.npz"), names_shapes=names_shapes_to_json(ns), seed=104, **grads,
                         crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), noise=npy(noise),
                         ctc_logits=npy(ctc_logits), ctc_len=npy(l), num_pred=npy(_num), num=npy(num), logits=npy(logits),
                         alpha_raw=npy(alpha0), alpha=npy(alpha), cif_out=npy(cif_out), enc_out=npy(enc_out),

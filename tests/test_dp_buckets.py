@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import asr_amd
-from asr_amd.trainer import GradBuckets, _param_order
+from asr_amd.trainer import GradBuckets, _param_order, flat_offsets
 
 
 def _free_port():
@@ -27,10 +27,7 @@ def _worker(rank, world, port, out):
     torch.manual_seed(0)
     model = asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=0.0), asr_amd.Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.0))
     params = _param_order(model)
-    offs, n = [], 0
-    for p in params:
-        offs.append(n)
-        n += p.numel()
+    offs, n = flat_offsets(params)
     flat = torch.zeros((n + 63) // 64 * 64)
     for p, off in zip(params, offs):
         p.grad = flat[off:off + p.numel()].view(p.shape)

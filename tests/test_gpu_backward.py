@@ -149,3 +149,17 @@ def test_adam_step_matches_torch():
         ops.adam_step(p, gr.to(DEV), m, v, 1e-3, 0.9, 0.98, 1e-9, step, p16=p16)
     np.testing.assert_allclose(N(p), tp.detach().numpy(), atol=1e-6, rtol=1e-5)
     np.testing.assert_array_equal(N(p16), N(p.bfloat16()))
+
+
+@pytest.mark.parametrize("pfx", ["h", "r"])
+def test_cif_backward_matches_reference_autograd(golden_dir, pfx):
+    """d_hidden / d_alpha of cif() against the reference's autograd through its Python loop (tests/golden/g3_cif.npz)."""
+    import os
+    z = np.load(os.path.join(golden_dir, "g3_cif.npz"))
+    alpha = torch.from_numpy(z[f"{pfx}_alpha"]).to(DEV)
+    hidden = torch.from_numpy(z[f"{pfx}_hidden"]).to(DEV)
+    w = torch.from_numpy(z[f"{pfx}_w"]).to(DEV)          # loss = (out * w).sum()  ->  d_out = w
+    cur, rem, fire_idx, n_fire, n_label, tok = ops.cif_scan(alpha, 0.95, want_tok=True)
+    d_hidden, d_alpha = ops.cif_bwd(hidden, cur, rem, tok, n_fire, w)
+    np.testing.assert_allclose(N(d_hidden), z[f"{pfx}_ghidden"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(N(d_alpha), z[f"{pfx}_galpha"], atol=2e-5, rtol=1e-4)

@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 import asr_amd
-from asr_amd.trainer import _param_order
+from asr_amd.trainer import _param_order, flat_offsets
 from oracle import asr_oracle as O
 
 
@@ -22,11 +22,25 @@ def test_param_order_is_a_permutation_with_qkv_adjacent():
             assert pos[id(mod.w_ks.weight)] == i + 1 and pos[id(mod.w_vs.weight)] == i + 2
             j = pos[id(mod.w_qs.bias)]
             assert pos[id(mod.w_ks.bias)] == j + 1 and pos[id(mod.w_vs.bias)] == j + 2
-    off = 0
-    for p in order:
-        if p.dim() >= 2:
-            assert off % 8 == 0          # bf16 shadow rows start 16-byte aligned
-        off += p.numel()
+    offs, total = flat_offsets(order)
+    assert all(o % 8 == 0 for o in offs) and total >= sum(p.numel() for p in order)
+    # Q/K/V stay adjacent (no padding inside the triples) so their concatenation is a plain view
+    for mod in m.modules():
+        if isinstance(mod, asr_amd.MultiheadAttention):
+            i = pos[id(mod.w_qs.weight)]
+            assert offs[i + 1] == offs[i] + mod.w_qs.weight.numel() and offs[i + 2] == offs[i + 1] + mod.w_ks.weight.numel()
+
+
+def test_flat_offsets_survive_odd_sized_parameters():
+    import argparse
+    args = argparse.Namespace(d_input=80, LFR_m=1, d_model=64, n_conv_layers=2, n_layers_enc=1, n_head=2, d_inner=128, dropout=0.0,
+                              sos_id=2, eos_id=3, vocab_size=50, n_layers_dec=1, spec_aug_cfg=None, d_assigner_hidden=32, w_context=3,
+                              n_assigner_layers=2)
+    m = asr_amd.CIF_Model.create_model(args)      # has a 1-element parameter (assigner.linear.bias)
+    order = _param_order(m)
+    offs, _ = flat_offsets(order)
+    assert any(p.numel() == 1 for p in order)
+    assert all(o % 8 == 0 for o in offs)
 
 
 def test_noam_schedule_matches_oracle_and_reference_pins(golden_dir):
