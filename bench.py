@@ -62,12 +62,13 @@ CFG = dict(d_input=80, d_model=256, n_head=4, d_inner=2048, n_layers_enc=12, n_l
            sos_id=2, eos_id=3, B=32, T=1000, U=50)
 
 
-def build_model(asr_amd, dev):
+def build_model(asr_amd, dev, dropout, train):
     torch.manual_seed(0)
-    enc = asr_amd.Encoder(CFG["d_input"], CFG["n_layers_enc"], CFG["n_head"], CFG["d_model"], CFG["d_inner"], dropout=0.0)
+    enc = asr_amd.Encoder(CFG["d_input"], CFG["n_layers_enc"], CFG["n_head"], CFG["d_model"], CFG["d_inner"], dropout=dropout)
     dec = asr_amd.Decoder(CFG["sos_id"], CFG["eos_id"], CFG["vocab_size"], CFG["n_layers_dec"], CFG["n_head"], CFG["d_model"],
-                          CFG["d_inner"], dropout=0.0)
-    return asr_amd.CTC_Transformer(enc, dec).to(dev).eval()
+                          CFG["d_inner"], dropout=dropout)
+    model = asr_amd.CTC_Transformer(enc, dec).to(dev)
+    return model.train() if train else model.eval()
 
 
 def make_batch(dev, seed):
@@ -103,7 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--mode", default="train", choices=["train", "fwd"],
-                    help="train: forward+loss+backward+grad all-reduce+Adam (default); fwd: forward+loss only")
+                    help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only")
+    ap.add_argument("--dropout", type=float, default=0.1,
+                    help="dropout rate of the training step (0.1 = every shipped config of the reference, egs/*/conf); ignored by --mode fwd")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,7 +125,8 @@ def main():
     import asr_amd
     from asr_amd import ops
     asr_amd.set_precision(args.precision)
-    model = build_model(asr_amd, dev)
+    model = build_model(asr_amd, dev, args.dropout, train=(args.mode == "train"))
+    asr_amd.manual_seed(1234 + rank)       # dropout masks: reproducible, different on every rank
     x, lens, tg = make_batch(dev, seed=rank)
 
     trainer = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1) if args.mode == "train" else None
@@ -183,8 +187,8 @@ def main():
                              "WRITE_SIZE passes (profiles/r1/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 correction)")
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
-        what = ("training step: forward + joint CTC/CE loss + backward + grad all-reduce + Adam" if args.mode == "train"
-                else "forward + joint CTC/CE loss")
+        what = ("training step (train mode, dropout %g): forward + joint CTC/CE loss + backward + grad all-reduce + Adam" % args.dropout
+                if args.mode == "train" else "eval-mode forward + joint CTC/CE loss")
         result = {
             "metric": "fbank frames/sec (CTC_Transformer d256 h4 enc12/dec6, %s)" % what,
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,6 +210,7 @@ def main():
             result["cpu_baseline"] = cb
             # sanity: the GPU result on the same utterance agrees with the oracle (bf16 tolerance); not timed
             # (in train mode the weights have moved since `cb` copied them: cpu_baseline() reads the current weights)
+            model.eval()                   # the oracle run above is the eval-mode forward
             with torch.no_grad():
                 l1, cl1, (lg1, te1) = model(x[:1], lens[:1], tg[:1])
             import numpy as np

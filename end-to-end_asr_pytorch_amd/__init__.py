@@ -11,4 +11,5 @@ from .ctc_model import CTC_Model  # noqa: F401
 from .loss import cal_ce_loss, cal_ctc_ce_loss, cal_ctc_qua_ce_loss, cal_loss, ctc_loss  # noqa: F401
 from .modules import (Attention_Assigner, CIF_Model, Conv1d, Conv2dSubsample, Conv_CTC_Transformer, CTC_Transformer,  # noqa: F401
                       Decoder, Decoder_CIF, DecoderLayer, Encoder, EncoderLayer, MultiheadAttention, PositionalEncoding,
-                      PositionwiseFeedForward, Transformer, get_precision, precision, set_precision)
+                      PositionwiseFeedForward, Transformer, dropout_site_keys, dropout_thr16, get_precision, manual_seed, precision,
+                      set_precision)

@@ -17,24 +17,34 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
 _vp, _i, _i64, _f, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint
 
+
+class Dropout(ctypes.Structure):
+    """asr_dropout_t (include/asr_hip.h), passed by value.  thr16 == 0 disables dropout."""
+    _fields_ = [("thr16", ctypes.c_uint32), ("key0", ctypes.c_uint32), ("key1", ctypes.c_uint32)]
+
+
+NO_DROP = Dropout(0, 0, 0)
+_dr = Dropout
+
 # name -> argtypes (restype is int unless noted).  Kept in lock-step with include/asr_hip.h; tests/test_abi.py checks
 # every prototype in the header is exported by the .so and listed here.
 SIGNATURES = {
     "asr_gemm_nt": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u],
     "asr_gemm_nt_ex": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _i64, _vp, _i64],
     "asr_gemm_nn": [_vp, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp, _i64],
-    "asr_attention_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
-    "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i],
-    "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
-    "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asr_attention_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr],
+    "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _dr],
+    "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr],
+    "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dr, _dr],
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
-    "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _dr],
+    "asr_dropout_apply": [_vp, _vp, _vp, _i, _i, _i, _dr],
     "asr_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f],
     "asr_proj_heads": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f],
-    "asr_attention_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i],
-    "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f],
-    "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asr_attention_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _dr],
+    "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr, _dr],
+    "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _dr],
     "asr_conv_sub0_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asr_conv_sub1_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_debug_probe_tr": [_vp, _vp, _i, _i],

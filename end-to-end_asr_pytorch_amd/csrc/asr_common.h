@@ -50,6 +50,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- dropout (asr_hip.h: asr_dropout_t) ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_subkey(const asr_dropout_t& d, uint32_t n0) { return lowbias32(n0 * 0x9E3779B9u + d.key0); }
+// random word of element pair `pair` = n1 * ceil(N2/2) + (n2 >> 1): low half decides even n2, high half odd n2
+__device__ __forceinline__ uint32_t drop_word(const asr_dropout_t& d, uint32_t sub, uint32_t pair) { return lowbias32(pair ^ sub) ^ d.key1; }
+__device__ __forceinline__ bool drop_keep_lo(const asr_dropout_t& d, uint32_t w) { return (w & 0xFFFFu) >= d.thr16; }
+__device__ __forceinline__ bool drop_keep_hi(const asr_dropout_t& d, uint32_t w) { return (w >> 16) >= d.thr16; }
+__device__ __forceinline__ float drop_scale(const asr_dropout_t& d) { return 65536.f / (float)(65536u - d.thr16); }
+// 4 consecutive elements n2 = c .. c+3 (c even) of row n1: multiply by the keep mask * scale
+__device__ __forceinline__ f32x4 drop4(const asr_dropout_t& d, uint32_t sub, uint32_t n1, uint32_t n2h, uint32_t c, f32x4 v, float sc) {
+    const uint32_t pair = n1 * n2h + (c >> 1);
+    const uint32_t w0 = drop_word(d, sub, pair), w1 = drop_word(d, sub, pair + 1);
+    v[0] = drop_keep_lo(d, w0) ? v[0] * sc : 0.f;
+    v[1] = drop_keep_hi(d, w0) ? v[1] * sc : 0.f;
+    v[2] = drop_keep_lo(d, w1) ? v[2] * sc : 0.f;
+    v[3] = drop_keep_hi(d, w1) ? v[3] * sc : 0.f;
+    return v;
+}
+
 // online (max, sum-exp) pair combine
 __device__ __forceinline__ void lse_combine(float& m, float& s, float m2, float s2) {
     float mn = fmaxf(m, m2);

@@ -284,11 +284,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const bf16_t*
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-template <int NW, bool CAUSAL>
+template <int NW, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
                                                                       float* __restrict__ lse, int h, int Lq, int Lk,
-                                                                      const int32_t* __restrict__ k_len, int q_tiles) {
+                                                                      const int32_t* __restrict__ k_len, int q_tiles,
+                                                                      asr_dropout_t drop) {
     constexpr int QB = NW * 32, PIECES = 8 / NW;   // 1-KiB pieces (8 rows) per wave per operand tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -315,6 +316,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     const int wave_qlast = q0 + wave * 32 + 31;
     const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
     const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
+    // dropout of the probabilities (attention.py:83): index space [h*B, Lq, Lk] with leading index head*B + b (attention.py:43-49)
+    const uint32_t dsub = DROP ? drop_subkey(drop, (uint32_t)(hd * (gridDim.x / (q_tiles * h)) + b)) : 0u;
+    const uint32_t drow = DROP ? (uint32_t)qrow * (uint32_t)((Lk + 1) >> 1) : 0u;
 
     u32x4 qf[4];
 #pragma unroll
@@ -404,6 +408,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
             m = mn;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            if (DROP) {   // the row sum above is of the un-dropped probabilities; 1/keep is folded into the final normalisation
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t pair = drow + (uint32_t)((key0 + hf * 32 + 8 * g + 4 * hh) >> 1);
+                        const uint32_t w0 = drop_word(drop, dsub, pair), w1 = drop_word(drop, dsub, pair + 1);
+                        st[hf][4 * g] = drop_keep_lo(drop, w0) ? st[hf][4 * g] : 0.f;
+                        st[hf][4 * g + 1] = drop_keep_hi(drop, w0) ? st[hf][4 * g + 1] : 0.f;
+                        st[hf][4 * g + 2] = drop_keep_lo(drop, w1) ? st[hf][4 * g + 2] : 0.f;
+                        st[hf][4 * g + 3] = drop_keep_hi(drop, w1) ? st[hf][4 * g + 3] : 0.f;
+                    }
+            }
 
             // O^T += V^T . P^T : V^T fragments by transposing reads of the row-major V tile.
             // lane (group g16 = lane>>4, i = lane&15) addresses key row kb + (i>>2), d column dt*32 + 16*(g16&1) + 4*(i&3)
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     }
 
     if (qrow < Lq) {
-        const float inv = 1.f / l;
+        const float inv = (DROP ? drop_scale(drop) : 1.f) / l;
         bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -454,17 +471,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
 }
 
 template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B,
-                                  int h, int Lq, int Lk, const int32_t* k_len, int causal) {
+                                  int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop) {
     const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);
     dim3 grid(B * h * q_tiles), block(NW * 64);
     static const bool v1 = getenv("ASR_AMD_ATTN_V1") != nullptr;   // A/B switch: register-staged v1 kernel
-    if (!v1) {
-        if (causal)
-            hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
-        else
-            hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, false>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
-                               (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
+    if (!v1 || drop.thr16) {
+#define LAUNCH_V2(C, D)                                                                                                        \
+    hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,             \
+                       (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop)
+        if (causal) { if (drop.thr16) LAUNCH_V2(true, true); else LAUNCH_V2(true, false); }
+        else        { if (drop.thr16) LAUNCH_V2(false, true); else LAUNCH_V2(false, false); }
+#undef LAUNCH_V2
         ASR_LAUNCH_CHECK("attention_fwd_bf16_v2");
         return 0;
     }
@@ -481,8 +498,10 @@ template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, c
 }  // namespace
 
 extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
-                                 int B, int h, int Lq, int Lk, const int32_t* k_len, int causal) {
+                                 int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop) {
     ASR_REQUIRE(q && k && v && ctx, ASR_ERR_ARG, "attention: null pointer");
+    ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "attention: dropout thr16 must be < 65536");
+    ASR_REQUIRE(!(drop.thr16 && dtype != ASR_BF16), ASR_ERR_UNSUPPORTED, "attention: dropout runs on the bf16 (training) path only");
     ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention: B=%d h=%d Lq=%d Lk=%d", B, h, Lq, Lk);
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(ctx, 16), ASR_ERR_ALIGN,
                 "attention: q/k/v/ctx must be 16-byte aligned");
@@ -495,7 +514,7 @@ extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, con
         return 0;
     }
     ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
-    if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal);
-    if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal);
-    return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal);
+    if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop);
+    if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop);
+    return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop);
 }

@@ -122,13 +122,13 @@ __device__ __forceinline__ bf16x8 frag_tr2(const unsigned char* t, int cb, int h
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int NW, bool CAUSAL>
+template <int NW, bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dq_out, int64_t ldq,
                                                                  int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int q_tiles,
-                                                                 float scale) {
+                                                                 float scale, asr_dropout_t drop) {
     constexpr int QB = NW * 32, PIECES = 8 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V], row-major, LDS-DMA filled
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -156,6 +156,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
     const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
     const int64_t tok = ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;  // token-major row of this lane's query
+    const uint32_t dsub = DROP ? drop_subkey(drop, (uint32_t)(hd * (gridDim.x / (q_tiles * h)) + b)) : 0u;
+    const uint32_t drow = DROP ? (uint32_t)qrow * (uint32_t)((Lk + 1) >> 1) : 0u;
+    const float dsc = DROP ? drop_scale(drop) : 1.f;
 
     bf16x8 qf[4], dof[4];
     float dl = 0.f;
@@ -199,6 +202,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                 st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
                 dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
             }
+            if (DROP) {   // dP = dropout mask * (dO . V^T)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t pair = drow + (uint32_t)((key0 + hf * 32 + 8 * g + 4 * hh) >> 1);
+                    const uint32_t w0 = drop_word(drop, dsub, pair), w1 = drop_word(drop, dsub, pair + 1);
+                    dp[hf][4 * g] = drop_keep_lo(drop, w0) ? dp[hf][4 * g] * dsc : 0.f;
+                    dp[hf][4 * g + 1] = drop_keep_hi(drop, w0) ? dp[hf][4 * g + 1] * dsc : 0.f;
+                    dp[hf][4 * g + 2] = drop_keep_lo(drop, w1) ? dp[hf][4 * g + 2] * dsc : 0.f;
+                    dp[hf][4 * g + 3] = drop_keep_hi(drop, w1) ? dp[hf][4 * g + 3] * dsc : 0.f;
+                }
+            }
             if (interior) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -229,12 +243,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dv_out, int64_t ldkv,
-                                                              int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int k_tiles) {
+                                                              int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int k_tiles,
+                                                              asr_dropout_t drop) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 + 1024];   // [buf][Q|dO] row-major + [buf][lse|delta]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,6 +272,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const bf16_t* Qb = Q + (int64_t)bh * Lq * 64;
     const bf16_t* dOb = dO + (int64_t)b * Lq * (h * 64) + hd * 64;   // token-major rows, ld = h*64
     const int64_t ldo = (int64_t)h * 64;
+    const uint32_t dsub = DROP ? drop_subkey(drop, (uint32_t)(hd * (gridDim.x / (k_tiles * h)) + b)) : 0u;
+    const uint32_t lkh = (uint32_t)((Lk + 1) >> 1), dcol = (uint32_t)key >> 1;
+    const bool dodd = key & 1;
+    const float dsc = DROP ? drop_scale(drop) : 1.f;
 
     bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -297,6 +316,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         // interior tile: all 64 queries in range, all 32 keys of the wave valid and (causal) not in any query's future
         const bool interior = (q0 + 64 <= Lq) && (wave_kfirst + 31 < kl) && (!CAUSAL || wave_kfirst + 31 <= q0);
         f32x16 sq[2], dp[2];
+        auto out_products = [&](int hf) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(sq[hf], s2), sf = pack8(dp[hf], s2);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(dOs, 0, hf, s2, lane), pf, dv0, 0, 0, 0);   // dO^T from the dO tile
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(dOs, 1, hf, s2, lane), pf, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Qs, 0, hf, s2, lane), sf, dk0, 0, 0, 0);    // Q^T from the Q tile
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Qs, 1, hf, s2, lane), sf, dk1, 0, 0, 0);
+            }
+        };
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             sq[hf] = zero16();
@@ -312,27 +341,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 const int ql = hf * 32 + 8 * g + 4 * hh;   // 4 consecutive query rows live in regs 4g..4g+3
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql) * 1.4426950408889634f;   // base-2 for exp2(fma)
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ql);
+                float mk[4] = {1.f, 1.f, 1.f, 1.f};
+                if (DROP) {
+                    // the random word of (query, key pair) serves this lane (even key: low half) and its neighbour lane^1 (odd key:
+                    // high half): each hashes two of the four queries and the pair swaps them with a DPP quad permute
+                    const uint32_t qb = (uint32_t)(q0 + ql + (dodd ? 2 : 0));
+                    const uint32_t wa = drop_word(drop, dsub, qb * lkh + dcol), wb = drop_word(drop, dsub, (qb + 1) * lkh + dcol);
+                    const uint32_t pa = (uint32_t)__shfl_xor((int)wa, 1, 64), pb = (uint32_t)__shfl_xor((int)wb, 1, 64);
+                    const uint32_t w4[4] = {dodd ? pa : wa, dodd ? pb : wb, dodd ? wa : pa, dodd ? wb : pb};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mk[i] = (((w4[i] >> (dodd ? 16 : 0)) & 0xFFFFu) >= drop.thr16) ? dsc : 0.f;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int q = q0 + ql + i;
                     const bool bad = !interior && (!kok || q >= Lq || (CAUSAL && key > q));
                     const float e = __builtin_amdgcn_exp2f(fmaf(sq[hf][4 * g + i], 1.4426950408889634f, -l4[i]));
                     const float p = bad ? 0.f : e;
-                    sq[hf][4 * g + i] = p;                                   // P
-                    dp[hf][4 * g + i] = p * (dp[hf][4 * g + i] - d4[i]);     // dS
+                    sq[hf][4 * g + i] = DROP ? p * mk[i] : p;                                          // dropout(P), feeds dV
+                    dp[hf][4 * g + i] = p * ((DROP ? dp[hf][4 * g + i] * mk[i] : dp[hf][4 * g + i]) - d4[i]);     // dS
                 }
             }
+            if (DROP) out_products(hf);   // one 32-query half at a time: the hash temporaries need the registers of the other half
         }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = pack8(sq[hf], s2), sf = pack8(dp[hf], s2);
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(dOs, 0, hf, s2, lane), pf, dv0, 0, 0, 0);   // dO^T from the dO tile
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(dOs, 1, hf, s2, lane), pf, dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Qs, 0, hf, s2, lane), sf, dk0, 0, 0, 0);    // Q^T from the Q tile
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Qs, 1, hf, s2, lane), sf, dk1, 0, 0, 0);
-            }
+        if (!DROP) {
+            out_products(0);
+            out_products(1);
+        }
         __syncthreads();   // next tile's DMA landed; `cur` may be overwritten
     }
     if (key < Lk) {   // keys in [kl, Lk) get exact zeros
@@ -346,54 +381,56 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                     const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,
-                                    const int32_t* k_len, int causal, float scale) {
+                                    const int32_t* k_len, int causal, float scale, asr_dropout_t drop) {
     ASR_REQUIRE(q && k && v && o && d_o && lse && delta && dq, ASR_ERR_ARG, "attention_bwd_dq: null pointer");
+    ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "attention_bwd_dq: dropout thr16 must be < 65536");
     ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd_dq: bad sizes");
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(o, 16) && asr_aligned(d_o, 16) &&
                     asr_aligned(dq, 8) && ldq % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dq: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *O = (const bf16_t*)o, *dO = (const bf16_t*)d_o;
-#define LAUNCH_DQ(NW)                                                                                                            \
-    do {                                                                                                                         \
-        const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);                                                                      \
-        if (causal)                                                                                                              \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, true>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse,  \
-                               delta, (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale);                                       \
-        else                                                                                                                     \
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, false>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, \
-                               delta, (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale);                                       \
+#define LAUNCH_DQ2(NW, C, D)                                                                                              \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, C, D>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, delta, \
+                       (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale, drop)
+#define LAUNCH_DQ(NW)                                                                                  \
+    do {                                                                                               \
+        const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);                                            \
+        if (causal) { if (drop.thr16) LAUNCH_DQ2(NW, true, true); else LAUNCH_DQ2(NW, true, false); }  \
+        else { if (drop.thr16) LAUNCH_DQ2(NW, false, true); else LAUNCH_DQ2(NW, false, false); }       \
     } while (0)
     if (Lq <= 32) LAUNCH_DQ(1);
     else if (Lq <= 64) LAUNCH_DQ(2);
     else LAUNCH_DQ(4);
 #undef LAUNCH_DQ
+#undef LAUNCH_DQ2
     ASR_LAUNCH_CHECK("attention_bwd_dq");
     return 0;
 }
 
 extern "C" int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void* v, const void* d_o, const float* lse,
                                      const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
-                                     const int32_t* k_len, int causal) {
+                                     const int32_t* k_len, int causal, asr_dropout_t drop) {
     ASR_REQUIRE(q && k && v && d_o && lse && delta && dk && dv, ASR_ERR_ARG, "attention_bwd_dkv: null pointer");
+    ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "attention_bwd_dkv: dropout thr16 must be < 65536");
     ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd_dkv: bad sizes");
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(d_o, 16) && asr_aligned(dk, 8) &&
                     asr_aligned(dv, 8) && ldkv % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dkv: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)d_o;
     const int k_tiles = (Lk + 127) / 128;
-    if (causal)
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk,
-                           (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles);
-    else
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<false>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk,
-                           (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles);
+#define LAUNCH_DKV(C, D)                                                                                                         \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<C, D>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk, \
+                       (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles, drop)
+    if (causal) { if (drop.thr16) LAUNCH_DKV(true, true); else LAUNCH_DKV(true, false); }
+    else { if (drop.thr16) LAUNCH_DKV(false, true); else LAUNCH_DKV(false, false); }
+#undef LAUNCH_DKV
     ASR_LAUNCH_CHECK("attention_bwd_dkv");
     return 0;
 }
 
 extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                  const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
-                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale) {
-    if (int rc = asr_attention_bwd_dq(stream, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, causal, scale)) return rc;
-    return asr_attention_bwd_dkv(stream, q, k, v, d_o, lse, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, causal);
+                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop) {
+    if (int rc = asr_attention_bwd_dq(stream, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, causal, scale, drop)) return rc;
+    return asr_attention_bwd_dkv(stream, q, k, v, d_o, lse, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, causal, drop);
 }

@@ -299,8 +299,10 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
-                                                                float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D) {
+                                                                float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D,
+                                                                asr_dropout_t drop_x, asr_dropout_t drop_y) {
     __shared__ float red[3][4][256 * MAXJ];
+    const float scx = drop_scale(drop_x), scy = drop_scale(drop_y);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invD = 1.f / (float)D;
     f32x4 ag[MAXJ], ab[MAXJ], as[MAXJ], gam[MAXJ];
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
     f32x4 d[LNB_RPW][MAXJ], xh[LNB_RPW][MAXJ];
     float mu[LNB_RPW], rs[LNB_RPW];
     bool live[LNB_RPW];
+    uint32_t subx[LNB_RPW], tt[LNB_RPW];
     // phase 1: every load of the wave's rows in flight at once
 #pragma unroll
     for (int r = 0; r < LNB_RPW; ++r) {
@@ -326,11 +329,15 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         const bool keep = live[r] && (row_len ? (t < row_len[b]) : true);
         mu[r] = mean[rr];
         rs[r] = rstd[rr];
+        tt[r] = (uint32_t)t;
+        subx[r] = drop_x.thr16 ? drop_subkey(drop_x, (uint32_t)b) : 0u;
+        const uint32_t suby = drop_y.thr16 ? drop_subkey(drop_y, (uint32_t)b) : 0u;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
                 d[r][j] = keep ? *reinterpret_cast<const f32x4*>(dy + rr * D + c) : f32x4{0, 0, 0, 0};
+                if (drop_y.thr16) d[r][j] = drop4(drop_y, suby, (uint32_t)t, D >> 1, c, d[r][j], scy);
                 xh[r][j] = *reinterpret_cast<const f32x4*>(s + rr * D + c);
             } else {
                 d[r][j] = f32x4{0, 0, 0, 0};
@@ -373,9 +380,10 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         for (int j = 0; j < MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
-                const f32x4 o = (d[r][j] * gam[j] - m1 - xh[r][j] * m2) * rs[r];
+                f32x4 o = (d[r][j] * gam[j] - m1 - xh[r][j] * m2) * rs[r];
+                *reinterpret_cast<f32x4*>(ds + row * D + c) = o;                                  // gradient wrt the residual
+                if (drop_x.thr16) o = drop4(drop_x, subx[r], tt[r], D >> 1, c, o, scx);           // gradient wrt x (dropout's input)
                 as[j] += o;
-                *reinterpret_cast<f32x4*>(ds + row * D + c) = o;
                 if (ds16) {
                     bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
                     *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(ds16) + row * D + c) = ob;
@@ -400,14 +408,24 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy, int M, int D,
-                                                        int V, float* __restrict__ demb) {
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy, int M, int U,
+                                                        int D, int V, float* __restrict__ demb, asr_dropout_t drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     int64_t id = ids[row];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    for (int c = lane; c < D; c += 64) atomicAdd(demb + id * D + c, dy[row * D + c]);
+    const uint32_t b = (uint32_t)(row / U), u = (uint32_t)(row - (int64_t)b * U);
+    const uint32_t sub = drop.thr16 ? drop_subkey(drop, b) : 0u;
+    const float sc = drop_scale(drop);
+    for (int c = lane; c < D; c += 64) {
+        float g = dy[row * D + c];
+        if (drop.thr16) {
+            const uint32_t w = drop_word(drop, sub, u * (uint32_t)((D + 1) >> 1) + ((uint32_t)c >> 1));
+            g = ((c & 1) ? drop_keep_hi(drop, w) : drop_keep_lo(drop, w)) ? g * sc : 0.f;
+        }
+        atomicAdd(demb + id * D + c, g);
+    }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -511,25 +529,29 @@ extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda,
 
 extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
                                      const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
-                                     float* dbias, int B, int L, int D) {
+                                     float* dbias, int B, int L, int D, asr_dropout_t drop_x, asr_dropout_t drop_y) {
     ASR_REQUIRE(dy && s && mean && rstd && gamma && ds && dgamma && dbeta, ASR_ERR_ARG, "layernorm_bwd: null pointer");
+    ASR_REQUIRE(drop_x.thr16 < 65536u && drop_y.thr16 < 65536u, ASR_ERR_ARG, "layernorm_bwd: dropout thr16 must be < 65536");
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
     if (blocks > 256) blocks = 256;
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
-                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D);
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
     else
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
-                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D);
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
     ASR_LAUNCH_CHECK("add_layernorm_bwd");
     return 0;
 }
 
-extern "C" int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int M, int D, int V, float* demb) {
-    ASR_REQUIRE(ids && dy && demb && M > 0 && D > 0 && V > 0, ASR_ERR_ARG, "embed_bwd: bad args");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ids, dy, M, D, V, demb);
+extern "C" int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int B, int U, int D, int V, float* demb,
+                             asr_dropout_t drop) {
+    ASR_REQUIRE(ids && dy && demb && B > 0 && U > 0 && D > 0 && V > 0 && drop.thr16 < 65536u, ASR_ERR_ARG, "embed_bwd: bad args");
+    const int M = B * U;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ids, dy, M, U, D, V, demb,
+                       drop);
     ASR_LAUNCH_CHECK("embed_bwd");
     return 0;
 }

@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
                                                                 const float* __restrict__ pe, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ y32, bf16_t* __restrict__ y16,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                                float* s_out, int M, int L, int D, float eps) {
+                                                                float* s_out, int M, int L, int D, float eps,
+                                                                asr_dropout_t drop_x, asr_dropout_t drop_y) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -19,11 +20,14 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
     const float* xr = x + row * D;
     f32x4 v[LN_MAXJ];
     float s = 0.f;
+    const uint32_t subx = drop_x.thr16 ? drop_subkey(drop_x, b) : 0u, suby = drop_y.thr16 ? drop_subkey(drop_y, b) : 0u;
+    const float scx = drop_scale(drop_x), scy = drop_scale(drop_y);
 #pragma unroll
     for (int j = 0; j < LN_MAXJ; ++j) {
         const int c = lane * 4 + 256 * j;
         if (c < D) {
             v[j] = *reinterpret_cast<const f32x4*>(xr + c);
+            if (drop_x.thr16) v[j] = drop4(drop_x, subx, t, D >> 1, c, v[j], scx);
             if (res) v[j] += *reinterpret_cast<const f32x4*>(res + row * D + c);
             if (s_out) *reinterpret_cast<f32x4*>(s_out + row * D + c) = v[j];   // pre-norm sum for the backward (may alias x)
             s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
             const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
             f32x4 o = (v[j] - mean) * rstd * g + bt;
             if (pe) o += *reinterpret_cast<const f32x4*>(pe + (int64_t)t * D + c);
+            if (drop_y.thr16) o = drop4(drop_y, suby, t, D >> 1, c, o, scy);
             if (!keep) o = f32x4{0, 0, 0, 0};
             *reinterpret_cast<f32x4*>(y32 + row * D + c) = o;
             if (y16) {
@@ -66,20 +71,41 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
 
 __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, float* __restrict__ y32,
-                                                           bf16_t* __restrict__ y16, int M, int U, int D, int V) {
+                                                           bf16_t* __restrict__ y16, int M, int U, int D, int V,
+                                                           asr_dropout_t drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int u = (int)(row % U);
     int64_t id = ids[row];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // torch would raise; clamp keeps the kernel memory-safe
+    const uint32_t sub = drop.thr16 ? drop_subkey(drop, (uint32_t)(row / U)) : 0u;
+    const float sc = drop_scale(drop);
     for (int c = lane * 4; c < D; c += 256) {
         f32x4 o = *reinterpret_cast<const f32x4*>(emb + id * D + c) + *reinterpret_cast<const f32x4*>(pe + (int64_t)u * D + c);
+        if (drop.thr16) o = drop4(drop, sub, u, D >> 1, c, o, sc);
         *reinterpret_cast<f32x4*>(y32 + row * D + c) = o;
         if (y16) {
             bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
             *reinterpret_cast<bf16x4*>(y16 + row * D + c) = ob;
         }
+    }
+}
+
+// generic dropout over f32 [N0,N1,N2]: one thread per element pair (n2 even/odd halves of one random word)
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* x, float* y, int N1, int N2, int64_t pairs_per_n0,
+                                                            int64_t total_pairs, asr_dropout_t drop) {
+    const int n2h = (N2 + 1) >> 1;
+    const float sc = drop_scale(drop);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_pairs; i += stride) {
+        const int64_t n0 = i / pairs_per_n0;
+        const uint32_t pair = (uint32_t)(i - n0 * pairs_per_n0);
+        const uint32_t n1 = pair / n2h, ph = pair - n1 * n2h;
+        const uint32_t w = drop_word(drop, drop_subkey(drop, (uint32_t)n0), pair);
+        const int64_t e = (n0 * N1 + n1) * N2 + 2 * ph;
+        y[e] = drop_keep_lo(drop, w) ? x[e] * sc : 0.f;
+        if (2 * ph + 1 < (uint32_t)N2) y[e + 1] = drop_keep_hi(drop, w) ? x[e + 1] * sc : 0.f;
     }
 }
 
@@ -120,29 +146,45 @@ __global__ __launch_bounds__(256) void assigner_tail_kernel(const float* __restr
 
 extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
                                      const float* pe, const int32_t* row_len, float* y32, void* y16, float* mean, float* rstd,
-                                     float* s_out, int B, int L, int D, float eps) {
+                                     float* s_out, int B, int L, int D, float eps, asr_dropout_t drop_x, asr_dropout_t drop_y) {
     ASR_REQUIRE(x && gamma && beta && y32, ASR_ERR_ARG, "layernorm: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 256 * LN_MAXJ && D % 4 == 0, ASR_ERR_UNSUPPORTED,
                 "layernorm: D=%d must be a multiple of 4 and <= %d", D, 256 * LN_MAXJ);
+    ASR_REQUIRE(drop_x.thr16 < 65536u && drop_y.thr16 < 65536u, ASR_ERR_ARG, "layernorm: dropout thr16 must be < 65536");
     ASR_REQUIRE(asr_aligned(x, 16) && asr_aligned(y32, 16) && asr_aligned(gamma, 16) && asr_aligned(beta, 16) &&
                     (!residual || asr_aligned(residual, 16)) && (!pe || asr_aligned(pe, 16)) && (!y16 || asr_aligned(y16, 8)),
                 ASR_ERR_ALIGN, "layernorm: 16-byte alignment required");
     const int M = B * L;
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, residual,
-                       gamma, beta, pe, row_len, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, s_out, M, L, D, eps);
+                       gamma, beta, pe, row_len, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, s_out, M, L, D, eps, drop_x, drop_y);
     ASR_LAUNCH_CHECK("add_layernorm_fwd");
     return 0;
 }
 
 extern "C" int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16, int B,
-                                int U, int D, int V) {
+                                int U, int D, int V, asr_dropout_t drop) {
+    ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "embed: dropout thr16 must be < 65536");
     ASR_REQUIRE(ids && emb && pe && y32, ASR_ERR_ARG, "embed: null pointer");
     ASR_REQUIRE(B > 0 && U > 0 && D > 0 && D % 4 == 0 && V > 0, ASR_ERR_ARG, "embed: bad sizes");
     ASR_REQUIRE(asr_aligned(emb, 16) && asr_aligned(pe, 16) && asr_aligned(y32, 16), ASR_ERR_ALIGN, "embed: alignment");
     const int M = B * U;
     hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), ids, emb, pe, y32,
-                       reinterpret_cast<bf16_t*>(y16), M, U, D, V);
+                       reinterpret_cast<bf16_t*>(y16), M, U, D, V, drop);
     ASR_LAUNCH_CHECK("embed_pe_fwd");
+    return 0;
+}
+
+extern "C" int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, int N2, asr_dropout_t drop) {
+    ASR_REQUIRE(x && y && N0 > 0 && N1 > 0 && N2 > 0, ASR_ERR_ARG, "dropout_apply: bad args");
+    ASR_REQUIRE(drop.thr16 > 0 && drop.thr16 < 65536u, ASR_ERR_ARG, "dropout_apply: thr16 must be in (0, 65536)");
+    const int64_t ppn = (int64_t)N1 * ((N2 + 1) / 2);
+    ASR_REQUIRE(ppn < (int64_t)1 << 32, ASR_ERR_UNSUPPORTED, "dropout_apply: N1*N2/2 must be < 2^32");
+    const int64_t total = ppn * N0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, N1, N2,
+                       ppn, total, drop);
+    ASR_LAUNCH_CHECK("dropout_apply");
     return 0;
 }
 

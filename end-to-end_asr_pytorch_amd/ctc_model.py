@@ -3,7 +3,7 @@ import torch.nn as nn
 
 from . import ops
 from .modules import (Act, Encoder as _TEncoder, EncoderLayer as _TEncoderLayer, MultiheadAttention, PositionalEncoding,
-                      _Cached, _act, _xavier_all)
+                      _Cached, _act, _assign_names, _xavier_all)
 
 
 class MultiHeadAttention(MultiheadAttention):
@@ -70,6 +70,7 @@ class CTC_Model(nn.Module):
         _xavier_all(self)
 
     def forward(self, padded_input, input_lengths):
+        _assign_names(self)
         lens = ops.as_i32(input_lengths, padded_input.device)
         enc = self.encoder._impl(_act(padded_input), lens)
         return self.decoder._impl(enc, lens), input_lengths

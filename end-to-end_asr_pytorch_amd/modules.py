@@ -9,12 +9,15 @@ caller discards) is not produced (`None` is returned in its place).
 
 Precision: "bf16" (default; bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / losses) or "f32"
 (exact-fp32 MFMA, the parity mode).  Select with `set_precision()` or the `precision(...)` context.
-Dropout: the kernels implement p = 0 (eval / parity runs); constructing with dropout > 0 is accepted for
-signature compatibility and is a no-op in this round (DESIGN.md "out of scope").
+Dropout (training mode, rate > 0): fused into the kernels at the reference's seven sites (attention probabilities, fc / w_2
+outputs before the residual add, encoder input, decoder embedding, assigner) as a counter-based hash mask that the backward
+kernels regenerate - see `asr_dropout_t` in include/asr_hip.h.  Keys derive from (seed, qualified module name, call count):
+`manual_seed()` makes runs reproducible; the mask stream is not torch's (no implementation could match that bit for bit).
 """
 import contextlib
 import math
 import os
+import zlib
 
 import torch
 import torch.nn as nn
@@ -46,6 +49,71 @@ def precision(p):
 
 def _cdtype():
     return torch.bfloat16 if _PRECISION == "bf16" else torch.float32
+
+
+# ---- dropout keys -----------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+_DROP_STATE = {"seed": None, "calls": {}}
+
+
+def manual_seed(seed):
+    """Seed of the dropout masks (and reset of the per-site call counters): two runs with the same seed and the same sequence
+    of forward calls drop the same elements."""
+    _DROP_STATE["seed"] = int(seed) & _M64
+    _DROP_STATE["calls"] = {}
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def dropout_site_keys(seed, name, call):
+    """(key0, key1) of asr_dropout_t for dropout site `name` (the reference's qualified nn.Dropout module name, e.g.
+    "encoder.layer_stack.0.slf_attn.attention.dropout") on its `call`-th invocation (1-based)."""
+    h = _splitmix64(seed & _M64)
+    h = _splitmix64(h ^ zlib.crc32(name.encode()))
+    h = _splitmix64(h ^ (call & _M64))
+    return h & 0xFFFFFFFF, h >> 32
+
+
+def dropout_thr16(p):
+    return int(round(float(p) * 65536.0))
+
+
+def _assign_names(root):
+    """Qualified names for the dropout keys (done by the top-level model's forward; a module used stand-alone has the empty prefix)."""
+    if root.__dict__.get("_asr_named"):
+        return
+    for name, m in root.named_modules():
+        m.__dict__["_asr_name"] = name
+    root.__dict__["_asr_named"] = True
+
+
+def _drop(mod, suffix):
+    """asr_dropout_t of dropout site `<module name>.<suffix>` for this call, or None when inactive (eval mode / rate 0)."""
+    p = float(getattr(mod, "dropout_rate", 0.0) or 0.0)
+    if not mod.training or p <= 0.0:
+        return None
+    if _PRECISION != "bf16":
+        raise RuntimeError("dropout (training mode) runs on the bf16 path; the f32 parity mode needs .eval() or dropout = 0")
+    thr = dropout_thr16(p)
+    if thr <= 0:
+        return None
+    if thr >= 65536:
+        raise ValueError("dropout rate must be < 1")
+    if _DROP_STATE["seed"] is None:
+        manual_seed(torch.initial_seed())
+    prefix = mod.__dict__.get("_asr_name", "")
+    name = (prefix + "." + suffix) if prefix else suffix
+    calls = _DROP_STATE["calls"]
+    key = (id(mod), suffix)
+    calls[key] = calls.get(key, 0) + 1
+    k0, k1 = dropout_site_keys(_DROP_STATE["seed"], name, calls[key])
+    return ops.Dropout(thr, k0, k1)
 
 
 # ---- backward tape ---------------------------------------------------------------------------------------------
@@ -221,16 +289,18 @@ class MultiheadAttention(_Cached):
                                 self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
             k, v = kv[0], kv[1]
         rec = _TAPE is not None
-        ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec)
+        dp_attn, dp_fc = _drop(self, "attention.dropout"), _drop(self, "dropout")   # attention.py:83, :59
+        ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec, drop=dp_attn)
         o = ops.gemm_nt(ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,)), self._b("bfc", (self.fc.bias,)))
         y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
-                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec)
+                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec,
+                                                 drop_x=dp_fc)
         y = Act(y32, y16, B, Lq)
         if rec:
-            self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale)
+            self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc)
         return y
 
-    def _record_bw(self, xq, xkv, q, k, v, ctx, lse, s_sum, mean, rstd, y, k_len, causal, row_len, scale):
+    def _record_bw(self, xq, xkv, q, k, v, ctx, lse, s_sum, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc):
         h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
         hd = h * 64
         ln, fc = self.layer_norm, self.fc
@@ -239,19 +309,20 @@ class MultiheadAttention(_Cached):
 
         def bw():
             ds, ds16 = ops.add_layernorm_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
-                                             want_bf16=True, dbias=fc.bias.grad)
+                                             want_bf16=True, dbias=fc.bias.grad, drop_x=dp_fc)
             y.grad = None
             ops.gemm_tn(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
             d_ctx = ops.gemm_nn(ds16, self._w("fc", (fc.weight,)), out_dtype=torch.bfloat16)
             if xkv is xq:
                 dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
-                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:])
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:],
+                                  drop=dp_attn)
                 ops.gemm_tn(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
                 _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
             else:
                 dq = torch.empty((B * Lq, hd), device=ds.device, dtype=torch.bfloat16)
                 dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
-                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dkv[:, :hd], dkv[:, hd:])
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dkv[:, :hd], dkv[:, hd:], drop=dp_attn)
                 ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
                 _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
                 ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True, colsum=_gcat(qkvb[1:]))
@@ -288,15 +359,16 @@ class PositionwiseFeedForward(_Cached):
         rec = _TAPE is not None
         hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
         o = ops.gemm_nt(hid, self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)))
+        dp = _drop(self, "dropout")   # module.py:51
         y32, y16, mean, rstd = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
-                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec)
+                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec, drop_x=dp)
         y = Act(y32, y16, x.B, x.L)
         if rec:
             ln, w1, w2 = self.layer_norm, self.w_1, self.w_2
 
             def bw():
                 ds, ds16 = ops.add_layernorm_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
-                                                 want_bf16=True, dbias=w2.bias.grad)
+                                                 want_bf16=True, dbias=w2.bias.grad, drop_x=dp)
                 y.grad = None
                 ops.gemm_tn(ds16, hid, out=w2.weight.grad, accumulate=True)
                 d_hid = ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid)
@@ -346,9 +418,10 @@ class Encoder(_Cached):
         rec = _TAPE is not None
         x_in = x
         o = ops.gemm_nt(x.mma(), self._w("lin", (self.linear_in.weight,)), self._b("blin", (self.linear_in.bias,)))
+        dp = _drop(self, "dropout")   # encoder.py:48
         y32, y16, mean, rstd = ops.add_layernorm(o, None, self.layer_norm_in.weight, self.layer_norm_in.bias, B, L,
                                                  pe=self.positional_encoding.rows(L), want_bf16=(_PRECISION == "bf16"),
-                                                 eps=self.layer_norm_in.eps, save_stats=rec)
+                                                 eps=self.layer_norm_in.eps, save_stats=rec, drop_y=dp)
         x = Act(y32, y16, B, L)
         if rec:
             y0, ln, lin = x, self.layer_norm_in, self.linear_in
@@ -356,7 +429,7 @@ class Encoder(_Cached):
 
             def bw():
                 ds, ds16 = ops.add_layernorm_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
-                                                 want_bf16=True, dbias=lin.bias.grad)
+                                                 want_bf16=True, dbias=lin.bias.grad, drop_y=dp)
                 y0.grad = None
                 ops.gemm_tn(ds16, x_in.mma(), out=lin.weight.grad, accumulate=True)
                 if need_dx:
@@ -557,10 +630,15 @@ class Attention_Assigner(nn.Module):
         """-> alpha f32 [B,L].  When the tape is recording, `slot` ({"g": d_alpha}) is read by the pushed backward closure."""
         rec = _TAPE is not None and slot is not None
         w = self.linear.weight.detach().float().contiguous().view(-1)
+        dp = _drop(self, "dropout")   # attentionAssigner.py:35
         if not rec:
             hcv = self.conv._impl(x)
+            if dp is not None:
+                ops.dropout_apply(hcv, dp, x.B, x.L, hcv.shape[-1])
             return ops.assigner_tail(hcv, w, self.linear.bias.detach().float().contiguous(), lens, x.B, x.L)
         hcv, saved = self.conv._impl(x, save=True)
+        if dp is not None:   # hcv is the cropped copy; `saved` keeps the un-dropped activations as the conv stack's ReLU masks
+            ops.dropout_apply(hcv, dp, x.B, x.L, hcv.shape[-1])
         alpha = ops.assigner_tail(hcv, w, self.linear.bias.detach().float().contiguous(), lens, x.B, x.L)
         lin, conv = self.linear, self.conv
         params = [lin.weight, lin.bias]
@@ -575,6 +653,8 @@ class Attention_Assigner(nn.Module):
             lin.weight.grad.add_((dz[None, :] @ h2))
             lin.bias.grad.add_(dz.sum())
             d_hcv = dz[:, None] * w[None, :]
+            if dp is not None:
+                d_hcv = ops.dropout_apply(d_hcv.contiguous(), dp, x.B, x.L, d_hcv.shape[-1])
             _acc(x, conv._backward(saved, d_hcv.view(x.B, x.L, -1)))
             slot["g"] = None
 
@@ -669,14 +749,15 @@ class Decoder(_Cached):
         ys_in, ys_out = self.preprocess(targets)
         B, U = ys_in.shape
         dec_len = ((ys_in > 0).sum(1)).to(torch.int32)
+        dp = _drop(self, "dropout")   # decoder.py:83
         x32, x16 = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U),
-                                want_bf16=(_PRECISION == "bf16"))
+                                want_bf16=(_PRECISION == "bf16"), drop=dp)
         x = Act(x32, x16, B, U)
         if _TAPE is not None:
             x_emb, emb = x, self.tgt_word_emb
 
             def bw_emb():
-                ops.embed_bwd(ys_in, x_emb.grad, emb.weight.grad)
+                ops.embed_bwd(ys_in, x_emb.grad, emb.weight.grad, drop=dp)
                 x_emb.grad = None
 
             _TAPE.push(bw_emb, (emb.weight,))
@@ -717,7 +798,8 @@ class Decoder_CIF(_Cached):
         ys_in = self.preprocess(target)
         dec_len = (target > 0).sum(1).to(torch.int32)          # tail padding (every reference data path)
         cif32 = encoded_attentioned.contiguous().float().view(B * U, D)
-        e32, _ = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U))
+        dp = _drop(self, "dropout")   # decoder.py:385
+        e32, _ = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U), drop=dp)
         cat1 = torch.cat([cif32, e32], -1)
         w_in = self._w("inaff", (self.input_affine.weight,))
         a = Act(ops.gemm_nt(cat1, w_in, None), None, B, U)
@@ -729,7 +811,7 @@ class Decoder_CIF(_Cached):
                 d_cat = ops.gemm_nn(a0.grad, w_in)
                 a0.grad = None
                 cif_slot["g"] = d_cat[:, :D] if cif_slot["g"] is None else cif_slot["g"] + d_cat[:, :D]
-                ops.embed_bwd(ys_in, d_cat[:, D:].contiguous(), emb.weight.grad)
+                ops.embed_bwd(ys_in, d_cat[:, D:].contiguous(), emb.weight.grad, drop=dp)
 
             _TAPE.push(bw_in, (aff.weight, emb.weight))
         for layer in self.layer_stack:
@@ -832,6 +914,7 @@ class Transformer(_Cached):
         _xavier_all(self)
 
     def forward(self, features, len_features, padded_target):
+        _assign_names(self)
         def run():
             lens = ops.as_i32(len_features, features.device)
             enc = self.encoder._impl(_act(features), lens)
@@ -852,6 +935,7 @@ class CTC_Transformer(Transformer):
         return _vocab_proj(self, "ctc", self.ctc_fc.weight, enc)
 
     def forward(self, features, len_features, padded_target):
+        _assign_names(self)
         B, L = features.shape[0], features.shape[1]
 
         def run():
@@ -872,6 +956,7 @@ class Conv_CTC_Transformer(CTC_Transformer):
         self.conv_encoder = conv_encoder
 
     def forward(self, features, len_features, targets, spec_aug_cfg=False):
+        _assign_names(self)
         def run():
             conv, len_sequence = self.conv_encoder._impl(features, len_features)
             enc = self.encoder._impl(conv, len_sequence)
@@ -919,6 +1004,7 @@ class CIF_Model(_Cached):
         _xavier_all(self)
 
     def forward(self, features, len_features, targets, threshold=0.95, noise=None):
+        _assign_names(self)
         def run():
             ctc3d, len_sequence, _num, num, logits = self._forward_impl(features, len_features, targets, threshold, noise)
             slots = _slots(self, "ctc", self, "num", self.decoder, "prj")

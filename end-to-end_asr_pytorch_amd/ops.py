@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from ._lib import check, lib
+from ._lib import NO_DROP, Dropout, check, lib
 
 F32, BF16 = 0, 1
 GEMM_RELU = 1
@@ -116,7 +116,20 @@ def proj_heads(x2d, w, bias, n_proj, B, L, h, scale_first=1.0):
     return out
 
 
-def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False):
+def _d(drop):
+    return NO_DROP if drop is None else drop
+
+
+def dropout_apply(x, drop, N0, N1, N2, out=None):
+    """y = dropout(x) over f32 [N0,N1,N2] with the counter-based mask of `drop` (in place by default)."""
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == N0 * N1 * N2
+    y = x if out is None else out
+    check(lib().asr_dropout_apply(_stream(), _p(x), _p(y), N0, N1, N2, drop), "asr_dropout_apply")
+    return y
+
+
+def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False, drop=None):
     """q [B,h,Lq,64] (pre-scaled), k/v [B,h,Lk,64] -> ctx [B,Lq,h*64] (same dtype), lse [B,h,Lq] or None."""
     _req_cuda(q, k, v, k_len)
     B, h, Lq, dk = q.shape
@@ -126,11 +139,12 @@ def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False):
     lse = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32) if need_lse else None
     with _timed("attention_fwd[B%d h%d %dx%d]" % (B, h, Lq, Lk), 4.0 * B * h * 64 * Lq * Lk):
         check(lib().asr_attention_fwd(_stream(), _p(q), _p(k), _p(v), dtype_code(q), _p(ctx), _p(lse), B, h, Lq, Lk, _p(k_len),
-                                      1 if causal else 0), "asr_attention_fwd")
+                                      1 if causal else 0, _d(drop)), "asr_attention_fwd")
     return ctx, lse
 
 
-def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False):
+def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False,
+                  drop_x=None, drop_y=None):
     """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd).
     With save_stats the pre-norm sum x+residual overwrites x in place (it is what the backward needs)."""
     _req_cuda(x, residual, gamma, beta, pe, row_len)
@@ -143,19 +157,20 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
     nbytes = B * L * D * (4 + (4 if residual is not None else 0) + 4 + (2 if want_bf16 else 0))
     with _timed("add_layernorm[%dx%d]" % (B * L, D), float(nbytes)):
         check(lib().asr_add_layernorm_fwd(_stream(), _p(x), _p(residual), _p(gamma), _p(beta), _p(pe), _p(row_len), _p(y32), _p(y16),
-                                          _p(mean), _p(rstd), _p(x) if save_stats else None, B, L, D, float(eps)),
+                                          _p(mean), _p(rstd), _p(x) if save_stats else None, B, L, D, float(eps), _d(drop_x),
+                                          _d(drop_y)),
               "asr_add_layernorm_fwd")
     return y32, y16, mean, rstd
 
 
-def embed_pe(ids, emb, pe, want_bf16=False):
+def embed_pe(ids, emb, pe, want_bf16=False, drop=None):
     _req_cuda(ids, emb, pe)
     B, U = ids.shape
     V, D = emb.shape
     ids = ids.contiguous()
     y32 = torch.empty((B * U, D), device=emb.device, dtype=torch.float32)
     y16 = torch.empty((B * U, D), device=emb.device, dtype=torch.bfloat16) if want_bf16 else None
-    check(lib().asr_embed_pe_fwd(_stream(), _p(ids), _p(emb), _p(pe), _p(y32), _p(y16), B, U, D, V), "asr_embed_pe_fwd")
+    check(lib().asr_embed_pe_fwd(_stream(), _p(ids), _p(emb), _p(pe), _p(y32), _p(y16), B, U, D, V, _d(drop)), "asr_embed_pe_fwd")
     return y32, y16
 
 
@@ -371,7 +386,8 @@ def colsum(a2d, out=None, accumulate=False):
     return out
 
 
-def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, want_bf16=False, dbias=None):
+def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, want_bf16=False, dbias=None, drop_x=None,
+                      drop_y=None):
     """-> (ds f32 [M,D], ds16 or None); dgamma/dbeta (and dbias += colsum(ds) when given) accumulated in place."""
     _req_cuda(dy, s, mean, rstd, gamma, row_len, dgamma, dbeta)
     D = s.shape[-1]
@@ -381,11 +397,11 @@ def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, wa
     nbytes = B * L * D * (4 + 4 + 4 + (2 if want_bf16 else 0))
     with _timed("add_layernorm_bwd[%dx%d]" % (B * L, D), float(nbytes)):
         check(lib().asr_add_layernorm_bwd(_stream(), _p(dy), _p(s), _p(mean), _p(rstd), _p(gamma), _p(row_len), _p(ds), _p(ds16),
-                                          _p(dgamma), _p(dbeta), _p(dbias), B, L, D), "asr_add_layernorm_bwd")
+                                          _p(dgamma), _p(dbeta), _p(dbias), B, L, D, _d(drop_x), _d(drop_y)), "asr_add_layernorm_bwd")
     return ds, ds16
 
 
-def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out):
+def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out, drop=None):
     """q [B,h,Lq,64], k/v [B,h,Lk,64] bf16; ctx, d_ctx token-major bf16 [B,Lq,h*64]; dq_out / dk_out / dv_out are bf16 views with
     row stride (elements) dq_out.stride(0) / dk_out.stride(0) into token-major gradient buffers (last dim = h*64)."""
     _req_cuda(q, k, v, ctx, d_ctx, lse)
@@ -399,16 +415,18 @@ def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out
     base = float(B) * h * 64 * Lq * Lk
     with _timed("attention_bwd_dq[B%d h%d %dx%d]" % (B, h, Lq, Lk), 4.0 * base):
         check(lib().asr_attention_bwd_dq(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(delta), _p(dq_out),
-                                         dq_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, float(scale)),
+                                         dq_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, float(scale), _d(drop)),
               "asr_attention_bwd_dq")
     with _timed("attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, Lq, Lk), 6.0 * base):
         check(lib().asr_attention_bwd_dkv(_stream(), _p(q), _p(k), _p(v), _p(d_ctx), _p(lse), _p(delta), _p(dk_out), _p(dv_out),
-                                          dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0), "asr_attention_bwd_dkv")
+                                          dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, _d(drop)), "asr_attention_bwd_dkv")
 
 
-def embed_bwd(ids, dy, demb):
-    M, D = dy.shape
-    check(lib().asr_embed_bwd(_stream(), _p(ids.contiguous()), _p(dy), M, D, demb.shape[0], _p(demb)), "asr_embed_bwd")
+def embed_bwd(ids, dy, demb, drop=None):
+    B, U = ids.shape if ids.dim() == 2 else (ids.shape[0], 1)
+    D = dy.shape[-1]
+    assert dy.numel() == B * U * D and dy.is_contiguous()
+    check(lib().asr_embed_bwd(_stream(), _p(ids.contiguous()), _p(dy), B, U, D, demb.shape[0], _p(demb), _d(drop)), "asr_embed_bwd")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None):

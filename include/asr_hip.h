@@ -32,6 +32,25 @@ extern "C" {
 #define ASR_ERR_ALIGN (-2)     /* pointer or leading dimension not aligned as documented */
 #define ASR_ERR_UNSUPPORTED (-3)
 
+/* Dropout (nn.Dropout in training mode: attention.py:59,83, module.py:51, encoder.py:48, decoder.py:83,385,
+ * attentionAssigner.py:35).  No mask tensor exists: the keep decision is a counter-based hash of the element's index, regenerated
+ * by the backward kernels from the same descriptor.  For a tensor viewed as [N0, N1, N2] (attention probabilities
+ * [h*B (index head*B + b, attention.py:43-49), Lq, Lk]; activations [B, L, D]):
+ *     lowbias32(x): x ^= x>>16; x *= 0x7feb352d; x ^= x>>15; x *= 0x846ca68b; x ^= x>>16          (uint32 arithmetic)
+ *     sub  = lowbias32(n0 * 0x9E3779B9 + key0)
+ *     word = lowbias32((n1 * ceil(N2/2) + (n2 >> 1)) ^ sub) ^ key1
+ *     r16  = (n2 & 1) ? word >> 16 : word & 0xFFFF
+ *     element kept  <=>  r16 >= thr16;   kept elements are multiplied by 65536 / (65536 - thr16)
+ * thr16 = round(p * 65536) (p quantised to 2^-16); thr16 == 0 disables dropout.  oracle/asr_oracle.py restates this in numpy. */
+typedef struct asr_dropout {
+    uint32_t thr16;
+    uint32_t key0;
+    uint32_t key1;
+} asr_dropout_t;
+
+/* y = dropout(x) over f32 [N0,N1,N2] (y may alias x); also the backward of itself (apply to the gradient). */
+int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, int N2, asr_dropout_t drop);
+
 /* GEMM epilogue flags */
 #define ASR_GEMM_RELU 1u
 
@@ -78,7 +97,7 @@ int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t ldx, const 
  * lse (f32 [B,h,Lq], natural log of the softmax denominator incl. max) is written when non-NULL (for backward).
  */
 int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
-                      int B, int h, int Lq, int Lk, const int32_t* k_len, int causal);
+                      int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop);
 
 /* Backward of asr_attention_fwd (bf16 only).  q,k,v as in the forward; o = the forward's ctx and d_o = its gradient, both
  * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 [B,h,Lq] workspace.  Outputs are token-major bf16:
@@ -86,30 +105,34 @@ int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v,
  * [(b*Lk+j)*ldkv + head*64 + d] - i.e. directly the A operands of the projection GEMMs' backward. */
 int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
-                      int Lq, int Lk, const int32_t* k_len, int causal, float scale);
+                      int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop);
 /* The two kernels of asr_attention_bwd as separate calls (dq first: it also produces delta, which dkv consumes). */
 int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                          const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,
-                         const int32_t* k_len, int causal, float scale);
+                         const int32_t* k_len, int causal, float scale, asr_dropout_t drop);
 int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void* v, const void* d_o, const float* lse,
                           const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
-                          const int32_t* k_len, int causal);
+                          const int32_t* k_len, int causal, asr_dropout_t drop);
 
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.
  * mean/rstd (f32 [M]) and s_out (f32 [M,D], the pre-norm sum x+residual; may alias x) are optional saves for backward.
+ * drop_x: dropout applied to x before the residual add (attention.py:59-60, module.py:51-52: LN(dropout(fc(..)) + residual));
+ * drop_y: dropout applied to the output after the PE add (encoder.py:48-50: dropout(LN(linear(x)) + PE)).  Both over [B,L,D].
  */
 int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
                           const float* pe, const int32_t* row_len, float* y32, void* y16, float* mean, float* rstd,
-                          float* s_out, int B, int L, int D, float eps);
+                          float* s_out, int B, int L, int D, float eps, asr_dropout_t drop_x, asr_dropout_t drop_y);
 
 /* Backward of asr_add_layernorm_fwd: s = the pre-norm sum x+residual (f32 [M,D]), mean/rstd from the forward.
  * ds (f32, optional bf16 copy ds16) = gradient wrt s (= wrt x and wrt residual); rows t >= row_len[b] get zero and do
  * not contribute.  dgamma/dbeta (f32 [D]) are ACCUMULATED into (caller zeroes them); dbias (optional, f32 [D]) likewise
- * receives colsum(ds) = the bias gradient of the projection whose output was normalised. */
+ * receives colsum(ds) = the bias gradient of the projection whose output was normalised.
+ * drop_y (the forward's) masks dy first.  With drop_x, ds (f32) stays the gradient wrt the residual while ds16 and dbias carry
+ * the gradient wrt x = dropout-masked ds (the operand of the projection's backward GEMMs). */
 int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
                           const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
-                          float* dbias, int B, int L, int D);
+                          float* dbias, int B, int L, int D, asr_dropout_t drop_x, asr_dropout_t drop_y);
 
 /* Weight gradient  C[N,K] (+)= sum_m A[m,n] * B[m,k]  (nn.Linear: A = dY [M,N], B = X [M,K] -> dW).  A, B f32 or bf16
  * (converted to bf16 MFMA operands on load); C f32.  zero_first != 0 clears C first (the kernel accumulates with
@@ -119,16 +142,16 @@ int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const voi
                 int64_t ldc, int M, int N, int K, int zero_first, float* colsum);
 /* Bias gradient out[n] (+)= sum_m A[m,n]. */
 int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first);
-/* Embedding backward: demb[ids[r], :] += dy[r, :]  (f32 atomics; caller zeroes demb). */
-int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int M, int D, int V, float* demb);
+/* Embedding backward: demb[ids[r], :] += dropout_mask(dy[r, :])  (f32 atomics; caller zeroes demb).  M = B*U rows. */
+int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int B, int U, int D, int V, float* demb, asr_dropout_t drop);
 /* Fused Adam over a flat buffer (torch.optim.Adam semantics, no weight decay): g is multiplied by grad_scale first;
  * p16 (optional) receives the bf16 copy of the updated parameters (the MFMA operand shadow). */
 int asr_adam_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale);
 
-/* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = emb[ids[b,u],:] + pe[u,:]. */
+/* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = dropout(emb[ids[b,u],:] + pe[u,:]). */
 int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16,
-                     int B, int U, int D, int V);
+                     int B, int U, int D, int V, asr_dropout_t drop);
 
 /* Conv2dSubsample (conv_encoder.py:101-108).  Layer 0: feats f32 [B,T,D] with the implicit zero right-pad of
  * conv_encoder.py:104 -> relu(conv 1->32, 3x3, stride (2,1)) -> y [B,T1,F1,32] channel-last in `dtype`; only the

@@ -18,12 +18,96 @@ Graves-2006 alpha/beta recursion in log space and is pinned against torch 2.10 C
 Every function cites the reference file:line it follows (paths relative to /root/reference/).
 All parameters are addressed by the reference's own state_dict key names.
 """
+import contextlib
 import math
+import zlib
 
 import numpy as np
 
 F32 = np.float32
 NEG_INF = F32(-np.inf)
+
+
+# --------------------------------------------------------------------------------------
+# dropout  (nn.Dropout in train mode: attention.py:59,83  module.py:51  encoder.py:48  decoder.py:83,385
+#           attentionAssigner.py:35).  torch draws the Bernoulli mask from its global RNG stream, which no other
+# implementation can reproduce; the product path instead derives the keep decision from a counter-based hash of
+# the element index (include/asr_hip.h: asr_dropout_t).  This section restates that mask in numpy, so the
+# oracle - and the REFERENCE itself, with nn.Dropout.forward patched to draw from here in
+# tests/golden/make_fixtures.py (G6/G7) - can run "the reference's arithmetic under a given mask".
+# --------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def dropout_site_keys(seed, name, call):
+    """(key0, key1) for dropout site `name` (qualified nn.Dropout module name) on its call-th invocation (1-based)."""
+    h = _splitmix64(seed & _M64)
+    h = _splitmix64(h ^ zlib.crc32(name.encode()))
+    h = _splitmix64(h ^ (call & _M64))
+    return h & 0xFFFFFFFF, h >> 32
+
+
+def _lowbias32(x):
+    x = x.astype(np.uint32)
+    x = x ^ (x >> np.uint32(16))
+    x = x * np.uint32(0x7feb352d)
+    x = x ^ (x >> np.uint32(15))
+    x = x * np.uint32(0x846ca68b)
+    return x ^ (x >> np.uint32(16))
+
+
+def dropout_mask(shape3, thr16, key0, key1):
+    """Multiplicative mask (0 or 65536/(65536-thr16)) for a tensor viewed as [N0, N1, N2] - asr_hip.h's definition."""
+    N0, N1, N2 = (int(v) for v in shape3)
+    n2h = (N2 + 1) // 2
+    with np.errstate(over="ignore"):
+        sub = _lowbias32(np.arange(N0, dtype=np.uint32) * np.uint32(0x9E3779B9) + np.uint32(key0))
+        pair = np.arange(N1, dtype=np.uint32)[:, None] * np.uint32(n2h) + np.arange(n2h, dtype=np.uint32)[None, :]
+        word = _lowbias32(pair[None] ^ sub[:, None, None]) ^ np.uint32(key1)
+    r = np.stack([word & np.uint32(0xFFFF), word >> np.uint32(16)], -1).reshape(N0, N1, 2 * n2h)[:, :, :N2]
+    scale = F32(65536.0) / F32(65536 - thr16)
+    return (r >= np.uint32(thr16)).astype(F32) * scale
+
+
+class DropoutCtx:
+    """Mask source shared by the oracle functions below: keys from (seed, site name, per-site call count)."""
+
+    def __init__(self, seed, p):
+        self.seed, self.thr16, self.calls = int(seed), int(round(float(p) * 65536.0)), {}
+
+    def mask(self, name, shape3):
+        self.calls[name] = self.calls.get(name, 0) + 1
+        k0, k1 = dropout_site_keys(self.seed, name, self.calls[name])
+        return dropout_mask(shape3, self.thr16, k0, k1)
+
+
+_DROPOUT = None
+
+
+@contextlib.contextmanager
+def dropout(seed, p):
+    """with oracle.dropout(seed, p): ...  -> the forward functions below run in "train mode" under the hash masks."""
+    global _DROPOUT
+    old, _DROPOUT = _DROPOUT, (DropoutCtx(seed, p) if p > 0 else None)
+    try:
+        yield _DROPOUT
+    finally:
+        _DROPOUT = old
+
+
+def _drop(x, name):
+    """x [N0,N1,N2] -> dropout(x) at site `name` (identity outside a `dropout(...)` context)."""
+    if _DROPOUT is None:
+        return x
+    return (x * _DROPOUT.mask(name, x.shape)).astype(F32)
 
 
 # --------------------------------------------------------------------------------------
@@ -119,15 +203,18 @@ def multihead_attention(sd, pfx, q, k, v, mask, n_head, d_k=64, d_v=64):
     if mask is not None:
         attn = np.where(mask[:, None, :, :], NEG_INF, attn)
     attn = softmax_lastdim(attn.astype(F32))
+    if _DROPOUT is not None:   # attention.py:83 on the [h*B, Lq, Lk] tensor whose leading index is head*B + b (attention.py:43-49)
+        a = attn.transpose(1, 0, 2, 3).reshape(n_head * B, Lq, Lk)
+        attn = _drop(a, pfx + "attention.dropout").reshape(n_head, B, Lq, Lk).transpose(1, 0, 2, 3)
     out = (attn @ vh).transpose(0, 2, 1, 3).reshape(B, Lq, n_head * d_v)
-    out = linear(out, sd[pfx + "fc.weight"], sd[pfx + "fc.bias"])
+    out = _drop(linear(out, sd[pfx + "fc.weight"], sd[pfx + "fc.bias"]), pfx + "dropout")   # attention.py:59
     return layer_norm(out + residual, sd[pfx + "layer_norm.weight"], sd[pfx + "layer_norm.bias"])
 
 
 def positionwise_ffn(sd, pfx, x):
     """src/transformer/module.py:48-53 — LN(W2 relu(W1 x + b1) + b2 + x)."""
     h = np.maximum(linear(x, sd[pfx + "w_1.weight"], sd[pfx + "w_1.bias"]), 0)
-    o = linear(h, sd[pfx + "w_2.weight"], sd[pfx + "w_2.bias"])
+    o = _drop(linear(h, sd[pfx + "w_2.weight"], sd[pfx + "w_2.bias"]), pfx + "dropout")   # module.py:51
     return layer_norm(o + x, sd[pfx + "layer_norm.weight"], sd[pfx + "layer_norm.bias"])
 
 
@@ -146,7 +233,7 @@ def encoder_forward(sd, pfx, padded_input, input_lengths, n_layers, n_head):
     slf_mask = get_attn_pad_mask(input_lengths, L)
     x = layer_norm(linear(padded_input, sd[pfx + "linear_in.weight"], sd[pfx + "linear_in.bias"]),
                    sd[pfx + "layer_norm_in.weight"], sd[pfx + "layer_norm_in.bias"])
-    x = x + positional_encoding(L, x.shape[-1])[None]
+    x = _drop((x + positional_encoding(L, x.shape[-1])[None]).astype(F32), pfx + "dropout")   # encoder.py:48
     for i in range(n_layers):
         x = encoder_layer(sd, f"{pfx}layer_stack.{i}.", x, non_pad_mask, slf_mask, n_head)
     return x.astype(F32)
@@ -213,7 +300,7 @@ def conv1d_stack(sd, pfx, feats, n_layers, w_context, name="assigner"):
 
 def attention_assigner(sd, pfx, padded_input, input_lengths, n_layers, w_context):
     """src/transformer/attentionAssigner.py:25-40 — sigmoid(Linear(conv stack)) * length mask."""
-    x = conv1d_stack(sd, pfx + "conv.", padded_input, n_layers, w_context)
+    x = _drop(conv1d_stack(sd, pfx + "conv.", padded_input, n_layers, w_context), pfx + "dropout")   # attentionAssigner.py:35
     a = linear(x, sd[pfx + "linear.weight"], sd[pfx + "linear.bias"])[..., 0]
     a = (1.0 / (1.0 + np.exp(-a.astype(F32)))).astype(F32)
     return a * sequence_mask(input_lengths)
@@ -244,7 +331,7 @@ def decoder_forward(sd, pfx, targets, enc_out, enc_lengths, n_layers, n_head, so
     U = ys_in.shape[1]
     cross_mask = get_attn_pad_mask(enc_lengths, U)
     d = sd[pfx + "tgt_word_emb.weight"].shape[1]
-    x = sd[pfx + "tgt_word_emb.weight"][ys_in].astype(F32) + positional_encoding(U, d)[None]
+    x = _drop(sd[pfx + "tgt_word_emb.weight"][ys_in].astype(F32) + positional_encoding(U, d)[None], pfx + "dropout")   # decoder.py:83
     for i in range(n_layers):
         lp = f"{pfx}layer_stack.{i}."
         x = multihead_attention(sd, lp + "slf_attn.", x, x, x, slf_mask, n_head) * non_pad
@@ -262,7 +349,7 @@ def decoder_cif_forward(sd, pfx, cif_out, target, n_layers, n_head, sos_id):
     slf_mask = (get_attn_key_pad_mask(ys_in, ys_in).astype(np.uint8) + get_subsequent_mask(ys_in)) > 0
     U = ys_in.shape[1]
     d = sd[pfx + "tgt_word_emb.weight"].shape[1]
-    emb = sd[pfx + "tgt_word_emb.weight"][ys_in].astype(F32) + positional_encoding(U, d)[None]
+    emb = _drop(sd[pfx + "tgt_word_emb.weight"][ys_in].astype(F32) + positional_encoding(U, d)[None], pfx + "dropout")   # decoder.py:385
     x = linear(np.concatenate([cif_out, emb], -1), sd[pfx + "input_affine.weight"])
     for i in range(n_layers):
         x = encoder_layer(sd, f"{pfx}layer_stack.{i}.", x, non_pad, slf_mask, n_head)

@@ -8,6 +8,9 @@ Harness-side shims (they do not modify the reference):
   * transformer.decoder.pad_list -> utils.utils.pad_list(...)[0]   (decoder.py:54-56 vs utils.py:14)
   * torch.Tensor.cuda -> identity                                   (cif_model.py:47-100, decoder.py:361)
   * utils.utils.get_non_pad_mask injected for ctcModel/encoder.py:5
+  * G6/G7 only (train mode): nn.Dropout.forward draws its Bernoulli mask from the counter-based hash the product path uses
+    (oracle.dropout_mask; keys from the module's qualified name) instead of torch's RNG stream - the reference's arithmetic
+    under a reproducible mask.
 Usage:  python tests/golden/make_fixtures.py
 """
 import argparse
@@ -21,6 +24,9 @@ import torch.nn.functional as F
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from weights import crc_of, make_state_dict, names_shapes_to_json  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import asr_oracle as oracle  # noqa: E402  (dropout mask definition only)
 
 REF = "/root/reference/src"
 sys.path.insert(0, REF)
@@ -265,10 +271,86 @@ def g5_ctc_model():
     lens = torch.tensor([40, 31, 22, 17])
     logits, l = model(x, lens)
     loss = ctc_cal_loss(logits, l, tg)
+    model.zero_grad()
+    loss.backward()          # ctcModel/solver.py:30-36
+    grads = {"grad:" + k: npy(p.grad) for k, p in model.named_parameters()}
     np.savez_compressed(os.path.join(HERE, "g5_ctc_model.npz"), names_shapes=names_shapes_to_json(ns), seed=105,
                         crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), logits=npy(logits), len=npy(l),
-                        loss=npy(loss), **cfg_arrays())
+                        loss=npy(loss), **grads, **cfg_arrays())
     print("G5 loss", float(loss))
+
+
+class hash_dropout:
+    """Context: nn.Dropout modules of `model` multiply by oracle.dropout_mask(...) keyed by their qualified name."""
+
+    def __init__(self, model, seed):
+        self.names = {id(m): n for n, m in model.named_modules() if isinstance(m, torch.nn.Dropout)}
+        self.seed, self.calls, self.sites = seed, {}, []
+
+    def __enter__(self):
+        outer = self
+        self.orig = torch.nn.Dropout.forward
+
+        def fwd(mod, x):
+            if not mod.training or mod.p == 0:
+                return x
+            name = outer.names[id(mod)]
+            assert x.dim() == 3, (name, tuple(x.shape))
+            outer.calls[name] = outer.calls.get(name, 0) + 1
+            k0, k1 = oracle.dropout_site_keys(outer.seed, name, outer.calls[name])
+            outer.sites.append(name)
+            return x * torch.from_numpy(oracle.dropout_mask(tuple(x.shape), int(round(mod.p * 65536.0)), k0, k1))
+
+        torch.nn.Dropout.forward = fwd
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.Dropout.forward = self.orig
+
+
+def g6_ctc_transformer_train():
+    """CTC_Transformer S0 in TRAIN mode, dropout 0.1 at every site, under the hash masks (seed 606)."""
+    enc = Encoder(80, 2, 2, 64, 128, dropout=0.1)
+    dec = Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.1)
+    model = CTC_Transformer(enc, dec).train()
+    ns, sd = load_seeded(model, seed=106)
+    x, lens, tg = s0_batch(seed=6)
+    x = x[:, :40].contiguous()
+    lens = torch.tensor([40, 33, 25, 12])
+    with hash_dropout(model, 606) as hd:
+        l, ctc_logits, (logits, teos) = model(x, lens, tg)
+        ctc, ce = cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+        model.zero_grad()
+        (ctc + ce).backward()
+    grads = {"grad:" + k: npy(p.grad).astype(np.float16 if p.grad.numel() > 20000 else np.float32) for k, p in model.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "g6_ctc_transformer_train.npz"), names_shapes=names_shapes_to_json(ns), seed=106,
+                        drop_seed=606, drop_p=0.1, sites=np.array(hd.sites), crc=crc_of(sd), x=npy(x), lens=npy(lens),
+                        targets=npy(tg), ctc_logits=npy(ctc_logits), ctc_len=npy(l), logits=npy(logits), targets_eos=npy(teos),
+                        ctc_loss=npy(ctc), ce_loss_s01=npy(ce), **grads, **cfg_arrays())
+    print("G6 ctc", float(ctc), "ce", float(ce), "dropout sites", len(hd.sites))
+
+
+def g7_cif_model_train():
+    """CIF_Model S0 in TRAIN mode with dropout 0.1 (assigner + Decoder_CIF sites included), hash masks seed 707."""
+    args = argparse.Namespace(**dict(S0, dropout=0.1))
+    model = CIF_Model.create_model(args).train()
+    ns, sd = load_seeded(model, seed=107)
+    x, lens, tg = s0_batch(seed=7)
+    torch.manual_seed(4321)
+    noise = torch.rand(4)
+    torch.manual_seed(4321)
+    with hash_dropout(model, 707) as hd:
+        ctc_logits, l, _num, num, logits = model(x, lens, tg)
+        qua, ctc, ce = cal_ctc_qua_ce_loss(ctc_logits, l, _num, num, logits, tg, smoothing=0.1)
+        model.zero_grad()
+        (0.001 * qua + ctc + ce).backward()
+    grads = {"grad:" + k: npy(p.grad).astype(np.float16 if p.grad.numel() > 20000 else np.float32) for k, p in model.named_parameters()}
+    np.savez_compressed(os.path.join(HERE, "g7_cif_model_train.npz"), names_shapes=names_shapes_to_json(ns), seed=107,
+                        drop_seed=707, drop_p=0.1, sites=np.array(hd.sites), crc=crc_of(sd), x=npy(x), lens=npy(lens),
+                        targets=npy(tg), noise=npy(noise), ctc_logits=npy(ctc_logits), ctc_len=npy(l), num_pred=npy(_num),
+                        num=npy(num), logits=npy(logits), qua_loss=npy(qua), ctc_loss=npy(ctc), ce_loss_s01=npy(ce), **grads,
+                        **cfg_arrays())
+    print("G7 qua", float(qua), "ctc", float(ctc), "ce", float(ce), "dropout sites", len(hd.sites))
 
 
 if __name__ == "__main__":
@@ -279,3 +361,5 @@ if __name__ == "__main__":
     g3_cif()
     g4_cif_model()
     g5_ctc_model()
+    g6_ctc_transformer_train()
+    g7_cif_model_train()

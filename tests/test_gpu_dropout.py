@@ -1,0 +1,198 @@
+"""Training-mode dropout on the HIP path (asr_dropout_t): every fused site against a torch-fp32 reference of the same op under
+the SAME mask (oracle.dropout_mask restates the hash), then whole models in train mode against the reference's own train-mode
+outputs and gradients (fixtures G6 / G7: the reference run with nn.Dropout drawing these masks)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+from oracle import asr_oracle as O
+from weights import make_state_dict, names_shapes_from_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = lambda t: t.detach().float().cpu().numpy()
+THR = 6554   # p = 0.1
+
+
+def D(k0, k1, thr=THR):
+    return ops.Dropout(thr, k0, k1)
+
+
+def M(shape, k0, k1, thr=THR):
+    return torch.from_numpy(O.dropout_mask(shape, thr, k0, k1))
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7), (4, 100, 256), (2, 51, 51), (1, 1, 1), (5, 33, 2)])
+def test_dropout_apply_is_bit_exact(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    y = ops.dropout_apply(x.to(DEV).contiguous(), D(11, 22), *shape, out=torch.empty(shape, device=DEV))
+    np.testing.assert_array_equal(N(y), (x * M(shape, 11, 22)).numpy())
+    thr = 40000   # p ~ 0.61
+    y = ops.dropout_apply(x.to(DEV).contiguous(), D(5, 6, thr), *shape)
+    np.testing.assert_array_equal(N(y), (x * M(shape, 5, 6, thr)).numpy())
+
+
+@pytest.mark.parametrize("B,L,Dm", [(3, 37, 64), (2, 100, 256), (2, 9, 512)])
+def test_add_layernorm_dropout_fwd_bwd(B, L, Dm):
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B * L, Dm, generator=g, requires_grad=True)
+    res = torch.randn(B * L, Dm, generator=g, requires_grad=True)
+    gam = (torch.rand(Dm, generator=g) + 0.5).requires_grad_(True)
+    bet = torch.randn(Dm, generator=g).requires_grad_(True)
+    pe = torch.randn(L, Dm, generator=g)
+    lens = torch.tensor([L, max(1, L - 5), max(1, L // 2)][:B])
+    mx, my = M((B, L, Dm), 1, 2).view(B * L, Dm), M((B, L, Dm), 3, 4).view(B * L, Dm)
+    s = x * mx + res
+    y = torch.nn.functional.layer_norm(s, (Dm,), gam, bet, 1e-5)
+    y = (y + pe.repeat(B, 1)) * my
+    keep = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1, 1).float()
+    y = y * keep
+    dy = torch.randn(B * L, Dm, generator=g)
+    y.backward(dy)
+    xd = x.detach().to(DEV).clone()
+    y32, y16, mean, rstd = ops.add_layernorm(xd, res.detach().to(DEV), gam.detach().to(DEV), bet.detach().to(DEV), B, L,
+                                             pe=pe.to(DEV), row_len=lens.to(DEV).int(), want_bf16=True, save_stats=True,
+                                             drop_x=D(1, 2), drop_y=D(3, 4))
+    np.testing.assert_allclose(N(y32), y.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(N(xd), s.detach().numpy(), atol=1e-6)           # saved pre-norm sum = dropout(x) + residual
+    dg, db, dbias = (torch.zeros(Dm, device=DEV) for _ in range(3))
+    ds, ds16 = ops.add_layernorm_bwd(dy.to(DEV), xd, mean, rstd, gam.detach().to(DEV), lens.to(DEV).int(), B, L, dg, db,
+                                     want_bf16=True, dbias=dbias, drop_x=D(1, 2), drop_y=D(3, 4))
+    np.testing.assert_allclose(N(ds), res.grad.numpy(), atol=2e-4, rtol=1e-4)      # gradient wrt the residual: unmasked
+    np.testing.assert_allclose(N(ds16), x.grad.numpy(), atol=3e-2, rtol=2e-2)      # gradient wrt x: masked (bf16 GEMM operand)
+    np.testing.assert_array_equal(N(ds16) == 0, (x.grad.numpy() == 0) | (N(ds16) == 0))
+    np.testing.assert_allclose(N(dbias), x.grad.sum(0).numpy(), atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(N(dg), gam.grad.numpy(), atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(N(db), bet.grad.numpy(), atol=2e-3, rtol=1e-3)
+
+
+def test_embed_dropout_fwd_bwd():
+    g = torch.Generator().manual_seed(0)
+    B, U, Dm, V = 3, 9, 64, 50
+    ids = torch.randint(0, V, (B, U), generator=g)
+    emb = torch.randn(V, Dm, generator=g, requires_grad=True)
+    pe = torch.randn(U, Dm, generator=g)
+    m = M((B, U, Dm), 7, 8)
+    y = (emb[ids] + pe[None]) * m
+    dy = torch.randn(B, U, Dm, generator=g)
+    y.backward(dy)
+    y32, _ = ops.embed_pe(ids.to(DEV), emb.detach().to(DEV), pe.to(DEV), drop=D(7, 8))
+    np.testing.assert_allclose(N(y32).reshape(B, U, Dm), y.detach().numpy(), atol=1e-6)
+    demb = torch.zeros(V, Dm, device=DEV)
+    ops.embed_bwd(ids.to(DEV), dy.to(DEV).view(B * U, Dm).contiguous(), demb, drop=D(7, 8))
+    np.testing.assert_allclose(N(demb), emb.grad.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("B,h,Lq,Lk,causal,ragged", [(2, 2, 25, 25, False, True), (2, 4, 200, 200, False, True), (2, 2, 51, 51, True, True),
+                                                     (2, 2, 51, 250, False, True), (1, 2, 300, 300, True, False), (3, 1, 130, 77, False, False)])
+def test_attention_dropout_fwd_bwd(B, h, Lq, Lk, causal, ragged):
+    g = torch.Generator().manual_seed(Lq * 3 + Lk)
+    q = (torch.randn(B, h, Lq, 64, generator=g) * 0.4).bfloat16().float().requires_grad_(True)
+    k = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
+    v = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
+    k_len = None
+    if ragged:
+        k_len = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
+        k_len[0] = Lk
+    mask = torch.zeros(B, 1, Lq, Lk, dtype=torch.bool)
+    if k_len is not None:
+        mask |= (torch.arange(Lk)[None, :] >= k_len[:, None])[:, None, None, :]
+    if causal:
+        mask |= torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1)[None, None]
+    p = torch.softmax((q @ k.transpose(-1, -2)).masked_fill(mask, float("-inf")), -1)
+    # the reference's probability tensor is [h*B, Lq, Lk] with leading index head*B + b (attention.py:43-49)
+    dm = M((h * B, Lq, Lk), 31, 32).view(h, B, Lq, Lk).permute(1, 0, 2, 3)
+    ctx = ((p * dm) @ v).permute(0, 2, 1, 3).reshape(B, Lq, h * 64)
+    dctx = torch.randn(B, Lq, h * 64, generator=g).bfloat16().float()
+    ctx.backward(dctx)
+    qd, kd, vd = (t.detach().to(DEV).bfloat16() for t in (q, k, v))
+    kl = None if k_len is None else k_len.to(DEV).int()
+    ctx_d, lse = ops.attention_fwd(qd, kd, vd, kl, causal, need_lse=True, drop=D(31, 32))
+    np.testing.assert_allclose(N(ctx_d), ctx.detach().numpy(), atol=2e-2, rtol=2e-2)
+    ctx_nodrop, _ = ops.attention_fwd(qd, kd, vd, kl, causal)
+    assert (N(ctx_nodrop) - ctx.detach().numpy()).std() > 3 * (N(ctx_d) - ctx.detach().numpy()).std()   # the mask matters
+    dq = torch.zeros(B * Lq, h * 64, device=DEV, dtype=torch.bfloat16)
+    dkv = torch.zeros(B * Lk, 2 * h * 64, device=DEV, dtype=torch.bfloat16)
+    ops.attention_bwd(qd, kd, vd, ctx_d, dctx.to(DEV).bfloat16(), lse, kl, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:],
+                      drop=D(31, 32))
+    to_tok = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0] * t.shape[2], h * 64)
+    # as test_gpu_backward.test_attention_bwd, with the 1/keep = 1.11 scale on top of the bf16 rounding of dS and P
+    tol = dict(atol=5e-2 * max(1.0, (max(Lq, Lk) / 250.0) ** 0.5), rtol=3e-2)
+    np.testing.assert_allclose(N(dq), (to_tok(q.grad) * 0.125).numpy(), **tol)
+    np.testing.assert_allclose(N(dkv[:, :h * 64]), to_tok(k.grad).numpy(), **tol)
+    np.testing.assert_allclose(N(dkv[:, h * 64:]), to_tok(v.grad).numpy(), **tol)
+
+
+def test_dropout_is_rejected_on_the_f32_parity_path():
+    q = torch.randn(1, 1, 8, 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.attention_fwd(q, q, q, None, False, drop=D(1, 2))
+
+
+def _grad_check(model, z, rel=1.2e-1, abs_=5e-3, total=5e-2):
+    """bf16 training step vs the fp32 reference on the tiny S0 model: every kernel is checked tightly above; here a handful of ReLU
+    sign flips / near-uniform 8-position decoder attentions move small-norm gradients by several percent (measured: the same 3-10 %
+    on those tensors with any single dropout site enabled, and 4-12 % with none, test_gpu_trainer), so the per-tensor bound is
+    loose and the tight bound is on the whole gradient vector."""
+    bad, e2, n2 = [], 0.0, 0.0
+    for name, p in model.named_parameters():
+        ref = z["grad:" + name].astype(np.float32)
+        got = p.grad.float().cpu().numpy()
+        err, rn = np.linalg.norm(got - ref), np.linalg.norm(ref)
+        e2, n2 = e2 + float(err) ** 2, n2 + float(rn) ** 2
+        if err >= rel * rn and err >= abs_:
+            bad.append((name, float(err), float(rn)))
+    assert not bad, bad
+    assert (e2 / n2) ** 0.5 < total, (e2 / n2) ** 0.5
+
+
+def test_g6_ctc_transformer_train_mode_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g6_ctc_transformer_train.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    model = asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=0.1), asr_amd.Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.1))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    model = model.to(DEV).train()
+    asr_amd.set_precision("bf16")
+    asr_amd.manual_seed(int(z["drop_seed"]))
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    l, ctc_logits, (logits, teos) = model(x, lens, tg)
+    np.testing.assert_allclose(N(ctc_logits), z["ctc_logits"], atol=8e-2, rtol=2e-2)
+    np.testing.assert_allclose(N(logits), z["logits"], atol=8e-2, rtol=2e-2)
+    ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+    np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=5e-3)
+    np.testing.assert_allclose(float(ce), z["ce_loss_s01"], rtol=5e-3)
+    (ctc + ce).backward()
+    _grad_check(model, z)
+    # second call: new masks (call counter), eval mode: no dropout at all
+    l2, ctc2, _ = model(x, lens, tg)
+    assert (N(ctc2) - N(ctc_logits)).std() > 1e-2
+    model.eval()
+    a = N(model(x, lens, tg)[1])
+    b = N(model(x, lens, tg)[1])
+    np.testing.assert_array_equal(a, b)
+
+
+def test_g7_cif_model_train_mode_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g7_cif_model_train.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    cfg = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")}
+    cfg["dropout"] = 0.1
+    model = asr_amd.CIF_Model.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    model = model.to(DEV).train()
+    asr_amd.set_precision("bf16")
+    asr_amd.manual_seed(int(z["drop_seed"]))
+    x, lens, tg, noise = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets", "noise"))
+    tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1, lambda_qua=0.001)
+    ctc, ce, state = tr.forward_loss(x, lens, tg, noise=noise)
+    np.testing.assert_allclose(float(ctc), z["ctc_loss"], rtol=1e-2)
+    np.testing.assert_allclose(float(ce), z["ce_loss_s01"], rtol=1e-2)
+    tr.fp.grad.zero_()
+    tr.backward(state)
+    _grad_check(model, z)

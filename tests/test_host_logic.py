@@ -88,3 +88,10 @@ def test_conv_length_rule():
         got = torch.div(got + 1, 2, rounding_mode="floor")
     np.testing.assert_array_equal(got.numpy(), exp)
     assert conv.d_conv_out == 40
+
+
+def test_dropout_keys_match_the_oracle_restatement():
+    from oracle import asr_oracle as O
+    for seed, name, call in ((0, "encoder.dropout", 1), (606, "decoder.layer_stack.1.enc_attn.attention.dropout", 3), (2**63 + 5, "x", 10**6)):
+        assert asr_amd.dropout_site_keys(seed, name, call) == O.dropout_site_keys(seed, name, call)
+    assert asr_amd.dropout_thr16(0.1) == 6554 and asr_amd.dropout_thr16(0.0) == 0

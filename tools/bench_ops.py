@@ -65,10 +65,20 @@ def bench_attn():
         q = (torch.randn(B, h, Lq, 64, device=DEV) * 0.5).bfloat16()
         k = torch.randn(B, h, Lk, 64, device=DEV).bfloat16()
         v = torch.randn(B, h, Lk, 64, device=DEV).bfloat16()
-        t = timeit(lambda: ops.attention_fwd(q, k, v, None, causal))
         fl = 4.0 * B * h * 64 * Lq * Lk
-        print(json.dumps(dict(op="attention_fwd", shape=[B, h, Lq, Lk], causal=causal, us=round(t * 1e3, 2),
-                              TFLOPs=round(fl / t / 1e9, 1), frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+        for drop in (None, ops.Dropout(6554, 1, 2)):
+            t = timeit(lambda: ops.attention_fwd(q, k, v, None, causal, drop=drop))
+            print(json.dumps(dict(op="attention_fwd", shape=[B, h, Lq, Lk], causal=causal, dropout=0.1 if drop else 0.0, us=round(t * 1e3, 2),
+                                  TFLOPs=round(fl / t / 1e9, 1), frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+        if Lq == 1000:
+            ctx, lse = ops.attention_fwd(q, k, v, None, causal, need_lse=True)
+            dctx = torch.randn_like(ctx)
+            dq = torch.empty(B * Lq, h * 64, device=DEV, dtype=torch.bfloat16)
+            dkv = torch.empty(B * Lk, 2 * h * 64, device=DEV, dtype=torch.bfloat16)
+            for drop in (None, ops.Dropout(6554, 1, 2)):
+                t = timeit(lambda: ops.attention_bwd(q, k, v, ctx, dctx, lse, None, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:], drop=drop))
+                print(json.dumps(dict(op="attention_bwd(dq+dkv)", shape=[B, h, Lq, Lk], dropout=0.1 if drop else 0.0, us=round(t * 1e3, 2),
+                                      TFLOPs=round(2.5 * fl / t / 1e9, 1), frac_mfma_peak=round(2.5 * fl / t / 1e9 / 2500, 4))))
 
 
 def bench_gemm():
