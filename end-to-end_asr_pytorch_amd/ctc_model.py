@@ -3,7 +3,7 @@ import torch.nn as nn
 
 from . import ops
 from .modules import (Act, Encoder as _TEncoder, EncoderLayer as _TEncoderLayer, MultiheadAttention, PositionalEncoding,
-                      _Cached, _act, _assign_names, _xavier_all)
+                      _Cached, _act, _assign_names, _slots, _taped, _vocab_proj, _xavier_all)
 
 
 class MultiHeadAttention(MultiheadAttention):
@@ -51,7 +51,9 @@ class Decoder(_Cached):
         nn.init.xavier_normal_(self.tgt_word_prj.weight)
 
     def _impl(self, enc, lens, masking=True):
-        logits = ops.gemm_nt(enc.mma(), self._w("prj", (self.tgt_word_prj.weight,)), None).view(enc.B, enc.L, -1)
+        # on the tape the projection's closure receives d(logits) through self._grad_slots["prj"]; rows t >= len carry no gradient
+        # either way (the mask multiplies them by 0 and the CTC gradient is 0 there), so the mask needs no closure of its own
+        logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, enc).view(enc.B, enc.L, -1)
         if masking:
             ops.mask_rows_(logits, lens)
         return logits
@@ -71,6 +73,11 @@ class CTC_Model(nn.Module):
 
     def forward(self, padded_input, input_lengths):
         _assign_names(self)
-        lens = ops.as_i32(input_lengths, padded_input.device)
-        enc = self.encoder._impl(_act(padded_input), lens)
-        return self.decoder._impl(enc, lens), input_lengths
+
+        def run():
+            lens = ops.as_i32(input_lengths, padded_input.device)
+            enc = self.encoder._impl(_act(padded_input), lens)
+            logits = self.decoder._impl(enc, lens)
+            return [logits], _slots(self.decoder, "prj"), None
+        (logits,), _ = _taped(self, run)
+        return logits, input_lengths

@@ -17,6 +17,7 @@ import math
 import torch
 
 from . import modules, ops
+from .ctc_model import CTC_Model
 from .loss import cal_ce_loss  # noqa: F401  (API parity)
 
 
@@ -161,6 +162,11 @@ class Trainer:
         model = self.model
         d_num = None
         with torch.no_grad(), modules.record() as tape:
+            if isinstance(model, CTC_Model):
+                # pure-CTC family (ctcModel/solver.py:30): loss = cal_loss(logits, len_logits, targets) - CTC on the raw targets
+                logits, ctc_len = model(feats, lens)
+                ctc, nll, st = ops.ctc_loss_fwd(logits, ops.as_i32(ctc_len, logits.device), targets)
+                return ctc, torch.zeros((), device=logits.device), (tape, st, None, None, None, None, None)
             if isinstance(model, modules.CIF_Model):
                 # CIF family (solver.py:146-153): CTC and CE both on `targets` (no <eos>), plus the quantity loss on sum(alpha)
                 ctc_logits, ctc_len, num_pred, num, logits = model(feats, lens, targets, noise=noise)
@@ -181,8 +187,14 @@ class Trainer:
     def backward(self, state):
         tape, st, logits, tg1, lse, loss2, d_num = state
         model = self.model
-        one = torch.ones(1, device=logits.device)
+        one = torch.ones(1, device=self.fp.flat.device)
         with torch.no_grad():
+            if logits is None:     # CTC_Model: the CTC loss is the whole objective
+                model.decoder._grad_slots["prj"]["g"] = ops.ctc_loss_bwd(st, one)
+                self.buckets.start()
+                tape.backward(lambda fn: self.buckets.on_done(fn.params))
+                self.buckets.finish()
+                return
             # loss = ctc + ce (solver.py:88): both seeds are 1
             model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one)
             V = logits.shape[-1]

@@ -219,3 +219,43 @@ def test_cif_model_autograd_drop_in(golden_dir):
         if err >= 8e-2 * rn and err >= 5e-3:
             bad.append((name, err, rn))
     assert not bad, bad
+
+
+def test_ctc_model_gradients_match_reference(golden_dir):
+    """ctcModel family (ctcModel/solver.py:30-36): loss = cal_loss(logits, len, targets); both the trainer's step and plain
+    loss.backward() through the autograd bridge reproduce the reference's gradients (G5)."""
+    from asr_amd.ctc_model import CTC_Model, Decoder, Encoder
+    z = np.load(os.path.join(golden_dir, "g5_ctc_model.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    asr_amd.set_precision("bf16")
+
+    def fresh():
+        model = CTC_Model(Encoder(80, 2, 2, 64, 64, 64, 128, dropout=0.0, pe_maxlen=5000), Decoder(50, 64))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return model.to(DEV).train()
+
+    def check(model):
+        bad = []
+        for name, p in model.named_parameters():
+            ref = z["grad:" + name].astype(np.float32)
+            got = p.grad.float().cpu().numpy()
+            err, rn = np.linalg.norm(got - ref), np.linalg.norm(ref)
+            if err >= 6e-2 * rn and err >= 5e-3:
+                bad.append((name, float(err), float(rn)))
+        assert not bad, bad
+
+    model = fresh()
+    logits, l = model(x, lens)
+    loss = asr_amd.cal_loss(logits, l, tg)
+    np.testing.assert_allclose(float(loss), z["loss"], rtol=5e-3)
+    loss.backward()
+    check(model)
+    model = fresh()
+    tr = asr_amd.Trainer(model)
+    tr.fp.grad.zero_()
+    ctc, _, state = tr.forward_loss(x, lens, tg)
+    tr.backward(state)
+    np.testing.assert_allclose(float(ctc), z["loss"], rtol=5e-3)
+    check(model)
+    tr.optimizer_step()
