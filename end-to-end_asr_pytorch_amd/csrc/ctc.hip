@@ -26,14 +26,6 @@ __device__ __forceinline__ float lse2(float a, float b) {
     return m + logf(expf(a - m) + expf(b - m));
 }
 
-__global__ void ctc_prep_kernel(const int64_t* __restrict__ targets, int B, int Umax, int32_t* __restrict__ tgt_len) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int n = 0;
-    for (int u = 0; u < Umax; ++u) n += (targets[(int64_t)b * Umax + u] != 0);  // loss.py:40  targets.ne(0).sum(1)
-    tgt_len[b] = n;
-}
-
 // compact-table row stride = 128 * NP floats, NP = state pairs per lane of the recursion kernel (1, 2, 4 or 8): every lane of the
 // recursion wave owns an in-bounds 2*NP-float slice of each row, so its loads/stores need no predicate and a row is written
 // by one fully coalesced wave store (512 B for NP = 1).  Columns >= 2U+1 hold -inf.
@@ -49,11 +41,29 @@ constexpr int LSE_UNR = 6;  // float4 per thread held in registers: V <= 256*4*6
 
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ logits, int64_t ldl,
                                                              const int32_t* __restrict__ in_len, const int64_t* __restrict__ targets,
-                                                             const int32_t* __restrict__ tgt_len, int L, int V, int Umax, int blank,
-                                                             float* __restrict__ lse_out, float* __restrict__ lp_ext) {
-    const int row = blockIdx.x;
-    const int b = row / L, t = row - b * L;
-    if (t >= in_len[b]) return;
+                                                             int L, int V, int Umax, int blank,
+                                                             float* __restrict__ lse_out, float* __restrict__ lp_ext, int chunk, int W) {
+    // W == 0: one launch over all rows (blockIdx.x = b*L + t).  W > 0: launch `chunk` of the outside-in pipeline: blockIdx.x =
+    // b*2W + i covers, for utterance b, forward frame t = chunk*W + i (i < W, t <= mid) or backward frame
+    // t = Tb-1 - (chunk*W + i - W) (i >= W, t > mid) - the rows the two recursion wavefronts consume in their chunk `chunk`.
+    int b, t;
+    if (W == 0) {
+        b = blockIdx.x / L;
+        t = blockIdx.x - b * L;
+        if (t >= in_len[b]) return;
+    } else {
+        b = blockIdx.x / (2 * W);
+        const int i = blockIdx.x - b * 2 * W;
+        const int Tb = min(in_len[b], L), mid = Tb >> 1;
+        if (i < W) {
+            t = chunk * W + i;
+            if (t > mid || t >= Tb) return;
+        } else {
+            t = Tb - 1 - (chunk * W + i - W);
+            if (t <= mid) return;
+        }
+    }
+    const int row = b * L + t;
     const float* x = logits + (int64_t)row * ldl;
     const int tid = threadIdx.x;
     float m = -INFINITY, s = 0.f;
@@ -109,11 +119,13 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
     }
     __syncthreads();
     const float lse = lse_sh;
-    const int Sp = ctc_row_stride(Umax), Sb = 2 * tgt_len[b] + 1;
+    // all Umax label slots are gathered (padding slots read label 0); the recursion masks the states beyond 2*tgt_len+1
+    const int Sp = ctc_row_stride(Umax), Sb = 2 * Umax + 1;
     for (int sidx = tid; sidx < Sp; sidx += 256) {
         float v = -INFINITY;
         if (sidx < Sb) {
-            const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
+            int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
+            lab = min(max(lab, 0), V - 1);
             v = (x[lab] - lse) * LOG2E;
         }
         lp_ext[(int64_t)row * Sp + sidx] = v;
@@ -121,13 +133,18 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
 }
 
 constexpr float NEG_BIG = -1.0e30f;   // max(m, NEG_BIG) keeps exp2(x - m) = 0 and m + log2(0) = -inf when every input is -inf
+// base-2 log-sum-exp with the largest term's exp2(0) = 1 taken for granted (0 when every input is -inf): one quarter-rate
+// transcendental fewer per call on the recursion's dependent chain (v_max3 / v_med3 / v_min3 are full rate)
 __device__ __forceinline__ float l2se2(float a, float b) {
-    const float ms = fmaxf(fmaxf(a, b), NEG_BIG);
-    return ms + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - ms) + __builtin_amdgcn_exp2f(b - ms));
+    const float m = fmaxf(a, b), ms = fmaxf(m, NEG_BIG);
+    const float one = (m == -INFINITY) ? 0.f : 1.f;
+    return ms + __builtin_amdgcn_logf(one + __builtin_amdgcn_exp2f(fminf(a, b) - ms));
 }
 __device__ __forceinline__ float l2se3(float a, float b, float c) {
-    const float ms = fmaxf(fmaxf(fmaxf(a, b), c), NEG_BIG);
-    return ms + __builtin_amdgcn_logf((__builtin_amdgcn_exp2f(a - ms) + __builtin_amdgcn_exp2f(b - ms)) + __builtin_amdgcn_exp2f(c - ms));
+    const float m = __builtin_fmaxf(__builtin_fmaxf(a, b), c), ms = fmaxf(m, NEG_BIG);
+    const float md = __builtin_amdgcn_fmed3f(a, b, c), mn = __builtin_fminf(__builtin_fminf(a, b), c);
+    const float one = (m == -INFINITY) ? 0.f : 1.f;
+    return ms + __builtin_amdgcn_logf((one + __builtin_amdgcn_exp2f(md - ms)) + __builtin_amdgcn_exp2f(mn - ms));
 }
 // occupancy of a state = alpha * beta / y / p(l|x) (beta includes y_t like aten's); dead states (lp = -inf) give 0
 __device__ __forceinline__ float occupancy(float a2, float b2, float lp2, float nll2) {
@@ -146,7 +163,8 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {  // lane i <- lan
 // occupancies exp2(alpha + beta - lp + nll2).  Row t lives at al + row_of(t) * Sp where row_of(special_t) = special_row.
 template <int NP, bool DIRB, bool OCC>
 __device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* __restrict__ al, int t_first, int nsteps, float (&e)[NP],
-                                          float (&o)[NP], const float (&skip_add)[NP], float nll2, int special_t, int special_row) {
+                                          float (&o)[NP], const float (&skip_add)[NP], const float (&madd)[2 * NP], float nll2,
+                                          int special_t, int special_row) {
     constexpr int PF = NP <= 2 ? 8 : (NP == 4 ? 4 : 2);
     constexpr int Sp = 128 * NP;
     if (nsteps <= 0) return;
@@ -210,17 +228,17 @@ __device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* _
 #pragma unroll
         for (int i = 0; i < PF; ++i)
 #pragma unroll
-            for (int q = 0; q < 2 * NP; ++q) { cf[i][q] = pf[i][q]; ca[i][q] = OCC ? pa[i][q] : 0.f; }
+            for (int q = 0; q < 2 * NP; ++q) { cf[i][q] = pf[i][q] + madd[q]; ca[i][q] = OCC ? pa[i][q] : 0.f; }   // madd: -inf on states >= 2U+1
         fetch(k0 + PF);
 #pragma unroll
         for (int i = 0; i < PF; ++i) step(t_first + dir * (k0 + i), cf[i], ca[i]);
     }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        float ca[2 * NP];
+        float ca[2 * NP], cf[2 * NP];
 #pragma unroll
-        for (int q = 0; q < 2 * NP; ++q) ca[q] = OCC ? pa[i][q] : 0.f;
-        if (k0 + i < nsteps) step(t_first + dir * (k0 + i), pf[i], ca);
+        for (int q = 0; q < 2 * NP; ++q) { cf[q] = pf[i][q] + madd[q]; ca[q] = OCC ? pa[i][q] : 0.f; }
+        if (k0 + i < nsteps) step(t_first + dir * (k0 + i), cf, ca);
     }
 }
 
@@ -229,29 +247,45 @@ __device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* _
 // p(l|x) = sum_s alpha_mid(s) beta_mid(s) / y_mid(s)) and again for the gradient (PHASE 1: each wave continues over the other
 // half, turning the stored rows of the opposite direction into occupancies in place).  Workspace rows per utterance: L + 1
 // (rows 0..mid hold alpha, mid+1..T-1 hold beta, row L holds beta_mid).
+// PHASE 0 can be launched in `nchunk` pieces (chunk c advances each wavefront by W frames, resuming from the row the previous
+// launch stored; the last one also takes beta onto row mid and computes the loss), so that the log-sum-exp pass over the next
+// frames (ctc_lse_gather_kernel, same chunk geometry) runs on another stream while this latency-bound chain works on the
+// previous ones.  W >= mid + 1 with nchunk = 1 is the single-launch form.
 template <int NP, int PHASE>
 __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
-                                                       const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len, int L,
-                                                       int Umax, float* __restrict__ alpha, float* __restrict__ nll) {
+                                                       const int64_t* __restrict__ targets, int32_t* __restrict__ tgt_len, int L,
+                                                       int Umax, float* __restrict__ alpha, float* __restrict__ nll, int chunk, int W,
+                                                       int last) {
     constexpr int Sp = 128 * NP;
     __shared__ float xch[64][2 * NP];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int U = tgt_len[b];
+    const int j0 = lane * NP;
+    const int64_t* tg = targets + (int64_t)b * Umax;
+    int U;
+    if (PHASE == 0) {   // loss.py:40  targets.ne(0).sum(1)
+        int n = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) n += (j0 + p < Umax && tg[j0 + p] != 0) ? 1 : 0;
+        U = (int)wave_sum((float)n);
+        if (threadIdx.x == 0 && last) tgt_len[b] = U;
+    } else {
+        U = tgt_len[b];
+    }
     const int Tb = min(in_len[b], L);
     if (Tb <= 0) {
-        if (PHASE == 0 && threadIdx.x == 0) nll[b] = (U == 0) ? 0.f : INFINITY;
+        if (PHASE == 0 && threadIdx.x == 0 && last) nll[b] = (U == 0) ? 0.f : INFINITY;
         return;
     }
     const int mid = Tb >> 1;
-    const int j0 = lane * NP;
-    const int64_t* tg = targets + (int64_t)b * Umax;
-    float skip_f[NP], skip_b[NP];
+    float skip_f[NP], skip_b[NP], madd[2 * NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const int j = j0 + p;
         skip_f[p] = ((j >= 1 && j < U) && (tg[j] != tg[j - 1])) ? 0.f : -INFINITY;   // s-2 -> s, s = 2j+1
         skip_b[p] = ((j + 1 < U) && (tg[j] != tg[j + 1])) ? 0.f : -INFINITY;         // s -> s+2
+        madd[2 * p] = (j <= U) ? 0.f : -INFINITY;                                     // blank state 2j exists for j <= U
+        madd[2 * p + 1] = (j < U) ? 0.f : -INFINITY;                                  // label state 2j+1 for j < U
     }
     const float* lp = lp_ext + (int64_t)b * L * Sp + 2 * j0;
     float* al = alpha + (int64_t)b * (L + 1) * Sp + 2 * j0;
@@ -263,6 +297,11 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
             ov[q] = v[1];
         }
     };
+    auto load_lp = [&](int64_t row, float (&ev)[NP], float (&ov)[NP]) {   // table row with the states beyond 2U+1 masked
+        load_row(lp, row, ev, ov);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { ev[q] += madd[2 * q]; ov[q] += madd[2 * q + 1]; }
+    };
     auto store_row = [&](int64_t row, const float (&ev)[NP], const float (&ov)[NP]) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) *reinterpret_cast<f32x2*>(al + row * Sp + 2 * q) = f32x2{ev[q], ov[q]};
@@ -270,30 +309,64 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
     float e[NP], o[NP], le[NP], lo[NP];
 
     if (PHASE == 0) {
-        if (wave == 0) {        // alpha: t = 0 .. mid
-            load_row(lp, 0, le, lo);
+        const int k0 = chunk * W;                      // first step of this launch (step k: alpha frame k / beta frame Tb-1-k)
+        if (wave == 0) {        // alpha: frames 0 .. mid
+            bool have = false;
+            if (k0 == 0) {
+                load_lp(0, le, lo);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                e[p] = (j0 + p == 0) ? le[p] : -INFINITY;
-                o[p] = (j0 + p == 0) ? lo[p] : -INFINITY;
+                for (int p = 0; p < NP; ++p) {
+                    e[p] = (j0 + p == 0) ? le[p] : -INFINITY;
+                    o[p] = (j0 + p == 0) ? lo[p] : -INFINITY;
+                }
+                store_row(0, e, o);
+                ctc_chain<NP, false, false>(lp, al, 1, min(W - 1, mid), e, o, skip_f, madd, 0.f, -1, 0);
+                have = W - 1 >= mid;
+            } else if (k0 <= mid) {
+                load_row(al, k0 - 1, e, o);
+                ctc_chain<NP, false, false>(lp, al, k0, min(W, mid - k0 + 1), e, o, skip_f, madd, 0.f, -1, 0);
+                have = k0 + W - 1 >= mid;
             }
-            store_row(0, e, o);
-            ctc_chain<NP, false, false>(lp, al, 1, mid, e, o, skip_f, 0.f, -1, 0);
-        } else {                // beta: t = Tb-1 .. mid  (beta_mid goes to row L)
-            load_row(lp, Tb - 1, le, lo);
+            if (last && !have) load_row(al, mid, e, o);
+        } else {                // beta: frames Tb-1 .. mid+1 in chunks; the last launch takes it onto mid (stored at row L)
+            const int kmax = Tb - 2 - mid;             // last step whose frame is > mid (-1: none, Tb == 1)
+            bool have = false;
+            if (k0 == 0 && kmax >= 0) {
+                load_lp(Tb - 1, le, lo);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                e[p] = (j0 + p == U) ? le[p] : -INFINITY;
-                o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
+                for (int p = 0; p < NP; ++p) {
+                    e[p] = (j0 + p == U) ? le[p] : -INFINITY;
+                    o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
+                }
+                store_row(Tb - 1, e, o);
+                ctc_chain<NP, true, false>(lp, al, Tb - 2, min(W - 1, kmax), e, o, skip_b, madd, 0.f, -1, 0);
+                have = W - 1 >= kmax;
+            } else if (k0 > 0 && k0 <= kmax) {
+                load_row(al, Tb - k0, e, o);
+                ctc_chain<NP, true, false>(lp, al, Tb - 1 - k0, min(W, kmax - k0 + 1), e, o, skip_b, madd, 0.f, -1, 0);
+                have = k0 + W - 1 >= kmax;
             }
-            store_row((Tb - 1 == mid) ? L : Tb - 1, e, o);
-            ctc_chain<NP, true, false>(lp, al, Tb - 2, Tb - 1 - mid, e, o, skip_b, 0.f, mid, L);
+            if (last) {
+                if (kmax < 0) {                        // Tb == 1: beta starts on the meeting frame itself
+                    load_lp(mid, le, lo);
 #pragma unroll
-            for (int p = 0; p < NP; ++p) { xch[lane][2 * p] = e[p]; xch[lane][2 * p + 1] = o[p]; }
+                    for (int p = 0; p < NP; ++p) {
+                        e[p] = (j0 + p == U) ? le[p] : -INFINITY;
+                        o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
+                    }
+                    store_row(L, e, o);
+                } else {
+                    if (!have) load_row(al, mid + 1, e, o);
+                    ctc_chain<NP, true, false>(lp, al, mid, 1, e, o, skip_b, madd, 0.f, mid, L);
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { xch[lane][2 * p] = e[p]; xch[lane][2 * p + 1] = o[p]; }
+            }
         }
+        if (!last) return;
         __syncthreads();
         if (wave == 0) {        // log p(l|x) = lse_s( alpha_mid(s) + beta_mid(s) - lp_mid(s) )
-            load_row(lp, mid, le, lo);
+            load_lp(mid, le, lo);
             float v[2 * NP], m = -INFINITY;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -317,11 +390,11 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
         } else {
             load_row(al, L, e, o);                      // beta_mid
             load_row(al, mid, ae, ao);                  // alpha_mid, for the occupancy of row mid
-            load_row(lp, mid, le, lo);
+            load_lp(mid, le, lo);
         }
         __syncthreads();                                // wave 0 has read row mid before wave 1 overwrites it
         if (wave == 0) {
-            ctc_chain<NP, false, true>(lp, al, mid + 1, Tb - 1 - mid, e, o, skip_f, nll2, -1, 0);
+            ctc_chain<NP, false, true>(lp, al, mid + 1, Tb - 1 - mid, e, o, skip_f, madd, nll2, -1, 0);
         } else {
             float oe[NP], oo[NP];
 #pragma unroll
@@ -330,7 +403,7 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
                 oo[p] = occupancy(ao[p], o[p], lo[p], nll2);
             }
             store_row(mid, oe, oo);
-            ctc_chain<NP, true, true>(lp, al, mid - 1, mid, e, o, skip_b, nll2, -1, 0);
+            ctc_chain<NP, true, true>(lp, al, mid - 1, mid, e, o, skip_b, madd, nll2, -1, 0);
         }
     }
 }
@@ -406,16 +479,32 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 }
 
 template <int PHASE>
-int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, const int64_t* targets, const int32_t* tgt_len, int B,
-                     int L, int Umax, float* alpha, float* nll) {
+int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, const int64_t* targets, int32_t* tgt_len, int B, int L,
+                     int Umax, float* alpha, float* nll, int chunk, int W, int last) {
+#define LAUNCH_MITM(NP_)                                                                                                              \
+    hipLaunchKernelGGL((ctc_mitm_kernel<NP_, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll, \
+                       chunk, W, last)
     switch (ctc_np(Umax)) {
-        case 1: hipLaunchKernelGGL((ctc_mitm_kernel<1, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
-        case 2: hipLaunchKernelGGL((ctc_mitm_kernel<2, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
-        case 4: hipLaunchKernelGGL((ctc_mitm_kernel<4, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
-        default: hipLaunchKernelGGL((ctc_mitm_kernel<8, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll); break;
+        case 1: LAUNCH_MITM(1); break;
+        case 2: LAUNCH_MITM(2); break;
+        case 4: LAUNCH_MITM(4); break;
+        default: LAUNCH_MITM(8); break;
     }
+#undef LAUNCH_MITM
     return 0;
 }
+
+// two reusable events per host thread for the fork / join of the pipelined forward (no timing, so recording is cheap)
+struct PipeEvents {
+    hipEvent_t main_done = nullptr, aux_done = nullptr;
+    bool ok() {
+        if (!main_done) {
+            if (hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess) return false;
+            if (hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return false;
+        }
+        return true;
+    }
+};
 
 }  // namespace
 
@@ -423,16 +512,46 @@ extern "C" int asr_ctc_workspace_stride(int Umax) { return ctc_row_stride(Umax);
 
 extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                 int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
-                                int32_t* tgt_len) {
+                                int32_t* tgt_len, void* aux_stream, int n_chunks) {
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len, ASR_ERR_ARG, "ctc_fwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && blank >= 0 && blank < V && ldl >= V, ASR_ERR_ARG, "ctc_fwd: bad sizes");
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (U+1 must be <= 512)", Umax);
     ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd: workspaces must be 16-byte aligned");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(ctc_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, targets, B, Umax, tgt_len);
-    hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, tgt_len, L, V, Umax, blank,
-                       lse, lp_ext);
-    launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll);
+    hipStream_t s = static_cast<hipStream_t>(stream), s2 = static_cast<hipStream_t>(aux_stream);
+    if (!s2 || s2 == s || n_chunks <= 1 || L < 64) {   // single stream: one pass over the logits, then the two half-length chains
+        hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
+                           lp_ext, 0, 0);
+        launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, 0, L, 1);
+        ASR_LAUNCH_CHECK("ctc_loss_fwd");
+        return 0;
+    }
+    // pipelined: the frames are cut outside-in into n_chunks pieces (chunk c = the next W frames of BOTH wavefronts); the
+    // HBM-bound log-sum-exp pass of chunk c+1 (stream) overlaps the latency-bound recursion over chunk c (aux_stream)
+    static thread_local PipeEvents ev;
+    ASR_REQUIRE(ev.ok(), ASR_ERR_UNSUPPORTED, "ctc_fwd: cannot create events");
+    const int steps = L / 2 + 1;                           // alpha takes mid + 1 <= L/2 + 1 steps, beta at most as many
+    const int W = (steps + n_chunks - 1) / n_chunks;
+    const int nc = (steps + W - 1) / W;
+#define HIP_OK(call)                                                          \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) {                                              \
+            asr_set_error("ctc_loss_fwd: %s", hipGetErrorString(e__));        \
+            return (int)e__;                                                  \
+        }                                                                     \
+    } while (0)
+    HIP_OK(hipEventRecord(ev.main_done, s));               // fork: the aux stream starts behind whatever produced the logits
+    HIP_OK(hipStreamWaitEvent(s2, ev.main_done, 0));
+    for (int c = 0; c < nc; ++c) {
+        hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * 2 * W), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
+                           lp_ext, c, W);
+        HIP_OK(hipEventRecord(ev.main_done, s));
+        HIP_OK(hipStreamWaitEvent(s2, ev.main_done, 0));
+        launch_recursion<0>(s2, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, c, W, c == nc - 1);
+    }
+    HIP_OK(hipEventRecord(ev.aux_done, s2));               // join
+    HIP_OK(hipStreamWaitEvent(s, ev.aux_done, 0));
+#undef HIP_OK
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
 }
@@ -453,7 +572,7 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE((size_t)V * sizeof(float) <= 64 * 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: V=%d exceeds the LDS occupancy vector", V);
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_bwd: Umax too long");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_recursion<1>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, const_cast<float*>(nll));
+    launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
     int rb = (2048 + B - 1) / B;  // ~2048 workgroups in flight
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;

@@ -63,6 +63,7 @@ struct EpiDense {
     const bf16_t* relu_mask;  // optional bf16 [M,N] (ld_mask): C = relu_mask > 0 ? C : 0  (ReLU backward)
     int64_t ld_mask;
     bool vec_ok;              // host-checked: every pointer / leading dimension allows 4-wide vector access
+    bool wide_ok;             // ... and C rows allow 16-byte stores (the LDS-transposed full-cache-line epilogue)
 
     // fast path (kernel-uniform): the tile lies fully inside N and everything is vector-aligned -> no per-element logic
     struct Row { unsigned char* c; const float* add; const bf16_t* mask; };
@@ -71,7 +72,13 @@ struct EpiDense {
         return Row{reinterpret_cast<unsigned char*>(C) + (int64_t)m * ldc * (c_dtype == ASR_F32 ? 4 : 2),
                    addend ? addend + (int64_t)m * ld_add : nullptr, relu_mask ? relu_mask + (int64_t)m * ld_mask : nullptr};
     }
-    __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
+    // wide path (run_epilogue): math on the accumulator layout, stores from the LDS-transposed image
+    __device__ __forceinline__ bool wide(int n0_tile) const { return wide_ok && n0_tile + BN <= N; }
+    __device__ __forceinline__ int elem_size() const { return c_dtype == ASR_F32 ? 4 : 2; }
+    __device__ __forceinline__ unsigned char* row_ptr(int m, int nw) const {
+        return reinterpret_cast<unsigned char*>(C) + ((int64_t)m * ldc + nw) * (c_dtype == ASR_F32 ? 4 : 2);
+    }
+    __device__ __forceinline__ f32x4 apply(const Row& r, int n, f32x4 v) const {
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
         if (flags & ASR_GEMM_RELU) {
 #pragma unroll
@@ -83,6 +90,10 @@ struct EpiDense {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = ((float)mk[i] > 0.f) ? v[i] : 0.f;
         }
+        return v;
+    }
+    __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
+        v = apply(r, n, v);
         if (c_dtype == ASR_F32) {
             *reinterpret_cast<f32x4*>(r.c + (int64_t)n * 4) = v;
         } else {
@@ -169,6 +180,18 @@ template <typename CT> struct EpiHeads {
         const int b = m / L, t = m - b * L;
         return Row{out + ((int64_t)b * h * L + t) * 64};
     }
+    __device__ __forceinline__ bool wide(int n0_tile) const { return n0_tile + BN <= N; }
+    __device__ __forceinline__ int elem_size() const { return (int)sizeof(CT); }
+    __device__ __forceinline__ unsigned char* row_ptr(int m, int nw) const {   // nw: a multiple of 64 = one head's 64 columns
+        const int b = m / L, t = m - b * L;
+        const int slot = nw >> 6, which = slot / h, head = slot - which * h;
+        return reinterpret_cast<unsigned char*>(out + which * proj_stride + (((int64_t)b * h + head) * L + t) * 64);
+    }
+    __device__ __forceinline__ f32x4 apply(const Row&, int n, f32x4 v) const {
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if ((n >> 6) / h == 0) v *= scale_first;
+        return v;
+    }
     __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
         const int slot = n >> 6;                       // global head slot = which * h + head
@@ -204,8 +227,62 @@ template <typename CT> struct EpiHeads {
     }
 };
 
+// Epilogue.  The MFMA accumulator layout gives a lane 4 consecutive output columns of ONE row, so direct stores write 16 rows x
+// 32-byte (bf16) / 64-byte (f32) fragments per wave instruction - a quarter / half of each 128-byte line - and the output-bound
+// projections (K = 256: FFN1, QKV, ctc_fc, their data gradients) ran at 1.5-2 TB/s of stores.  With `scratch` (this wave's 8 KiB
+// of the LDS the K loop has finished with) the 64 x 64 sub-tile is transposed through LDS instead: epilogue math in the
+// accumulator layout, XOR-swizzled LDS image, then 16 bytes per lane with 8 (bf16) / 16 (f32) adjacent lanes covering a
+// row's whole 128 / 256 bytes.
 template <typename Epi>
-__device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int q4) {
+__device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int q4,
+                                             unsigned char* scratch = nullptr) {
+    if (scratch && epi.wide(n0)) {
+        const int lane = q4 * 16 + r16;
+        const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+        if (epi.elem_size() == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = i * 16 + r16, m = mw + rl;
+                const auto r = epi.row(min(m, epi.M - 1));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = epi.apply(r, nw + j * 16 + q4 * 4, acc[i][j]);
+                    const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                    const int c = 2 * j + (q4 >> 1);
+                    *reinterpret_cast<bf16x4*>(scratch + rl * 128 + ((c ^ (rl & 7)) << 4) + (q4 & 1) * 8) = o;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 8 + (lane >> 3), ch = lane & 7, m = mw + rl;
+                const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 128 + ((ch ^ (rl & 7)) << 4));
+                if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+            }
+        } else {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = 2 * half + ii;
+                    const int rl = ii * 16 + r16, m = mw + i * 16 + r16;
+                    const auto r = epi.row(min(m, epi.M - 1));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 v = epi.apply(r, nw + j * 16 + q4 * 4, acc[i][j]);
+                        const int c = 4 * j + q4;
+                        *reinterpret_cast<f32x4*>(scratch + rl * 256 + ((c ^ (rl & 7)) << 4)) = v;
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = it * 64 + lane, rl = idx >> 4, ch = idx & 15, m = mw + 32 * half + rl;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 256 + ((ch ^ (rl & 7)) << 4));
+                    if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+                }
+            }
+        }
+        return;
+    }
     if (epi.fast(n0)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -323,8 +400,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
                 for (int j = 0; j < 4; ++j) Mma<CT>::run(b[j], a[i], acc[i][j]);  // D[n_local][m_local]
         }
     }
-
-    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
+    __syncthreads();   // every wave is done with the operand tiles: their LDS becomes the epilogue's transpose scratch
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4, smem + wave * 8192);
 }
 
 // ---- LDS-DMA fast path (bf16 x bf16, K % 64 == 0): global_load_lds_dwordx4 writes each 1-KiB piece (8 rows x 128 B) of the
@@ -332,32 +409,45 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
 // flight while tile k is multiplied, and there is one barrier per K-tile.  The DMA destination is lane-linear, so the XOR
 // swizzle is applied to the per-lane SOURCE address (LDS slot p of row r is filled with chunk p ^ (r & 7)) and undone by the
 // same XOR on the fragment reads.  Rows past M / N are clamped to the last valid row (their outputs are never stored).
+// The kernel is PERSISTENT: a launch is at most 2 workgroups per CU, and each walks a sequence of output tiles with the K-tile
+// stream running straight across tile boundaries - the DMA of the next tile's first K-tile is issued before the current tile's
+// last multiply, so its latency and the epilogue's global stores overlap.  With K = 256 (4 K-tiles per output tile: every
+// projection of the d_model = 256 configs) the un-overlapped prologue + epilogue was most of a workgroup's life.
+// Tile order: hardware workgroup b sits on XCD b & 7 (round-robin dispatch); every XCD owns one contiguous range of tile ids
+// (n fastest), so the workgroups that share an A row-panel run on the same L2 at about the same time.
 template <typename Epi>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
-                                                             int64_t ldw, int M, int N, int K, int tiles_n, int nwg, Epi epi) {
+                                                             int64_t ldw, int M, int N, int K, int tiles_n, int ntiles, Epi epi) {
     constexpr int KT = 64, TILE = BM * ROWB;  // 16 KiB per operand tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];   // [buf][A|B]
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+    // this workgroup's tile sequence: ids first, first + step, ... < end  (all inside its XCD's range)
+    int first, end, step;
+    {
+        const int G = gridDim.x, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        end = lo + q + (xcd < r ? 1 : 0);
+        step = (G >> 3) + ((G & 7) > xcd ? 1 : 0);      // workgroups of this launch on this XCD
+        first = lo + li;
+    }
+    if (first >= end) return;
+    const int nk = K / KT;
 
-    // per-lane source rows for the 4 pieces this wave stages per operand: piece p = wave*4 + i covers tile rows 8p..8p+7
     const bf16_t* asrc[4];
     const bf16_t* wsrc[4];
+    auto set_tile = [&](int tile) {   // per-lane source rows of the 4 pieces this wave stages per operand (piece p: tile rows 8p..8p+7)
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * (wave * 4 + i) + (lane >> 3);
-        const int c = (lane & 7) ^ (row & 7);
-        asrc[i] = A + (int64_t)min(m0 + row, M - 1) * lda + c * 8;
-        wsrc[i] = W + (int64_t)min(n0 + row, N - 1) * ldw + c * 8;
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * (wave * 4 + i) + (lane >> 3);
+            const int c = (lane & 7) ^ (row & 7);
+            asrc[i] = A + (int64_t)min(tm * BM + row, M - 1) * lda + c * 8;
+            wsrc[i] = W + (int64_t)min(tn * BN + row, N - 1) * ldw + c * 8;
+        }
+    };
     auto stage = [&](int buf, int kt) {
         unsigned char* base = smem + buf * 2 * TILE;
 #pragma unroll
@@ -370,39 +460,49 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
         }
     };
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-    const int nk = K / KT;
+    set_tile(first);
     stage(0, 0);
-    __syncthreads();   // drains the DMA (vmcnt) and publishes tile 0
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const unsigned char* As = smem + cur * 2 * TILE;
-        const unsigned char* Bs = As + TILE;
+    int cur = 0;
+    __syncthreads();   // drains the DMA (vmcnt) and publishes the first K-tile
+    for (int tile = first; tile < end; tile += step) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int chunk = g * 4 + q4;
-            u32x4 a[4], b[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int arow = wm * 64 + i * 16 + r16;
-                a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
-                const int brow = wn * 64 + i * 16 + r16;
-                b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * ROWB + ((chunk ^ (brow & 7)) << 4));
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                stage(cur ^ 1, kt + 1);
+            } else if (tile + step < end) {       // stream on into the next output tile
+                set_tile(tile + step);
+                stage(cur ^ 1, 0);
             }
+            const unsigned char* As = smem + cur * 2 * TILE;
+            const unsigned char* Bs = As + TILE;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int g = 0; g < 2; ++g) {
+                const int chunk = g * 4 + q4;
+                u32x4 a[4], b[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
+                for (int i = 0; i < 4; ++i) {
+                    const int arow = wm * 64 + i * 16 + r16;
+                    a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                    const int brow = wn * 64 + i * 16 + r16;
+                    b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * ROWB + ((chunk ^ (brow & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
+            }
+            __syncthreads();   // next K-tile landed (the barrier's fence waits for the outstanding LDS-DMA) and `cur` is free to overwrite
+            cur ^= 1;
         }
-        __syncthreads();   // next tile landed (the barrier's fence waits for the outstanding LDS-DMA) and `cur` is free to overwrite
+        // the buffer just multiplied (cur ^ 1 after the toggle) is free until the next tile's second K-tile is staged into it
+        run_epilogue(epi, acc, tm * BM, tn * BN, wm, wn, r16, q4, smem + (cur ^ 1) * 2 * TILE + wave * 8192);
+        if (tile + step < end) __syncthreads();
     }
-    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
 }
 
 // ---- NN variant (data gradient): C[M,N] = A[M,Kr] . Bm[Kr,N], Bm row-major as the weight is stored ([out,in] with the
@@ -514,7 +614,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A
                 for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
         }
     }
-    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
+    __syncthreads();   // operand tiles are dead: their LDS is the epilogue's transpose scratch
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4, smem + wave * 8192);
 }
 
 // ---- NN variant, LDS-DMA + hardware-transpose form (bf16 A, K % 64 == 0, N % 128 == 0): the A tile is staged exactly like the
@@ -599,7 +700,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
         }
         __syncthreads();
     }
-    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4);
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4, smem + wave * 8192);   // the loop's last barrier freed both buffers
 }
 
 template <typename AT, typename CT, typename Epi>
@@ -619,6 +720,12 @@ bool dense_vec_ok(const EpiDense& e) {
            (!e.relu_mask || (e.ld_mask % 4 == 0 && asr_aligned(e.relu_mask, 8)));
 }
 
+bool dense_wide_ok(const EpiDense& e) {
+    static const bool off = getenv("ASR_AMD_NO_WIDE_EPI") != nullptr;   // A/B switch
+    if (off || !e.vec_ok) return false;
+    return e.c_dtype == ASR_F32 ? true : (e.ldc % 8 == 0 && asr_aligned(e.C, 16));
+}
+
 int check_operands(const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw, int K) {
     ASR_REQUIRE(A && W, ASR_ERR_ARG, "gemm: null operand");
     ASR_REQUIRE((a_dtype == ASR_F32 || a_dtype == ASR_BF16) && (w_dtype == ASR_F32 || w_dtype == ASR_BF16), ASR_ERR_ARG,
@@ -633,9 +740,11 @@ int check_operands(const void* A, int a_dtype, int64_t lda, const void* W, int w
 
 template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                                         const Epi& epi) {
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU (64 KiB of LDS each)
+    const int nwg = ntiles < max_wg ? ntiles : max_wg;
     hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
-                       reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, nwg, epi);
+                       reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, ntiles, epi);
     ASR_LAUNCH_CHECK("gemm_nt_glds");
     return 0;
 }
@@ -662,6 +771,7 @@ extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
     EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, nullptr, 0, nullptr, 0, false};
     epi.vec_ok = dense_vec_ok(epi);
+    epi.wide_ok = dense_wide_ok(epi);
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -673,6 +783,7 @@ extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t 
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
     EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask, false};
     epi.vec_ok = dense_vec_ok(epi);
+    epi.wide_ok = dense_wide_ok(epi);
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -705,6 +816,7 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
                 (long long)lda, K, N, (long long)ldb);
     EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask, false};
     epi.vec_ok = dense_vec_ok(epi);
+    epi.wide_ok = dense_wide_ok(epi);
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {

@@ -5,6 +5,7 @@ libasr_hip.so and returns torch tensors that own the outputs.  torch is plumbing
 no arithmetic on the product path is done by torch ops.  There is no CPU fallback: CPU tensors raise.
 """
 import ctypes
+import os
 
 import torch
 
@@ -223,7 +224,19 @@ class CtcState:
                  "tgt_len")
 
 
-def ctc_loss_fwd(logits, in_len, targets, blank=None):
+_AUX = {}
+CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "6"))   # pieces of the pipelined CTC forward (<= 1: single stream)
+
+
+def aux_stream(device):
+    """A high-priority side stream per device for latency-bound work that overlaps an HBM-bound pass (CTC recursion)."""
+    key = torch.device(device).index
+    if key not in _AUX:
+        _AUX[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _AUX[key]
+
+
+def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None):
     """logits f32 [B,L,V] (last dim contiguous, rows may be strided), in_len int32 [B], targets int64 [B,Umax].
     -> (loss scalar tensor [1], nll [B], state)"""
     _req_cuda(logits, in_len, targets)
@@ -242,9 +255,11 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None):
     st.alpha = torch.empty((B, L + 1, S), device=dev, dtype=torch.float32)   # +1 row: beta at the meeting point
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
+    nck = CTC_CHUNKS if n_chunks is None else n_chunks
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
         check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
-                                     _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len)), "asr_ctc_loss_fwd")
+                                     _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len),
+                                     ctypes.c_void_p(aux_stream(dev).cuda_stream) if nck > 1 else None, nck), "asr_ctc_loss_fwd")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
     return loss, st.nll, st

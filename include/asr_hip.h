@@ -181,11 +181,15 @@ int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y,
  * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L+1,S] with
  * S = asr_ctc_workspace_stride(Umax) (>= 2*Umax+1; one 512-byte wave store per row and 64 labels).
  * Outputs: nll f32 [B] (inf for infeasible rows, zero_infinity=False), tgt_len int32 [B].
+ * aux_stream / n_chunks (forward only): with a second stream and n_chunks > 1 the frames are cut outside-in into n_chunks pieces
+ * and the HBM-bound log-sum-exp pass of piece c+1 (on `stream`) overlaps the latency-bound alpha/beta recursion over piece c
+ * (on `aux_stream`); the call forks from and joins back into `stream` with two cached hipEvents (the only state the library
+ * keeps besides its code objects), so the caller sees ordinary stream semantics.  NULL / <= 1: everything on `stream`.
  */
 int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
-                     int32_t* tgt_len);
+                     int32_t* tgt_len, void* aux_stream, int n_chunks);
 /* mean_b(nll_b / max(tgt_len_b,1))  — reduction='mean' of F.ctc_loss.  loss: f32 [1]. */
 int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_len, int B, float* loss);
 /* Gradient wrt logits of gout * mean-reduced loss: g[b,t,v] = gout/(B*max(tgt_len_b,1)) * (softmax - occupancy),

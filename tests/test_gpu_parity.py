@@ -260,6 +260,29 @@ def test_ctc_vs_torch_cpu(B, L, U, V, repeat):
     assert float(ld.grad[-1, int(in_len[-1]):].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("scale,B,L,U,V", [(8.0, 3, 200, 20, 50), (25.0, 3, 120, 30, 12), (60.0, 2, 90, 40, 6), (200.0, 2, 64, 30, 5)])
+def test_ctc_peaky_logits(scale, B, L, U, V):
+    """The recursion runs in the linear domain with power-of-two rescaling and redoes an utterance in the log domain when the
+    two directions' overlap underflows: logits of growing dynamic range (per-frame probabilities down to e^-1000) must keep
+    matching aten's log-domain result (computed in float64)."""
+    g = torch.Generator().manual_seed(int(scale))
+    logits = torch.randn(B, L, V, generator=g) * scale
+    tg = torch.randint(1, V - 1, (B, U), generator=g)
+    in_len = torch.full((B,), L, dtype=torch.int64)
+    in_len[-1] = L - 7
+    lg = logits.double().requires_grad_(True)
+    tl = tg.ne(0).int().sum(1)
+    lp = torch.nn.functional.log_softmax(lg, -1).transpose(0, 1)
+    ref_nll = torch.nn.functional.ctc_loss(lp, tg, in_len, tl, blank=V - 1, reduction="none")
+    ref = torch.nn.functional.ctc_loss(lp, tg, in_len, tl, blank=V - 1)
+    ref.backward()
+    ld = logits.to(DEV).requires_grad_(True)
+    loss, nll = asr_amd.ctc_loss(ld, in_len.to(DEV), tg.to(DEV))
+    loss.backward()
+    np.testing.assert_allclose(N(nll), ref_nll.detach().numpy(), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(N(ld.grad), lg.grad.float().numpy(), atol=2e-5, rtol=2e-3)
+
+
 def test_ctc_strided_logits_rows():
     # logits living in a padded buffer (row stride > V) are consumed in place
     B, L, V, U = 2, 30, 50, 5
