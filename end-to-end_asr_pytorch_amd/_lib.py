@@ -63,7 +63,7 @@ SIGNATURES = {
     "asr_cif_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "asr_assigner_tail_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "asr_cast_f32_bf16": [_vp, _vp, _vp, _i64],
-    "asr_mask_rows": [_vp, _vp, _vp, _i, _i, _i],
+    "asr_mask_rows": [_vp, _vp, _vp, _i, _i, _i, _i64],
 }
 
 _lib = None

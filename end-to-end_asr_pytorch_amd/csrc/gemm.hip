@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "asr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -92,6 +93,16 @@ struct EpiDense {
         }
         return v;
     }
+    // the wide epilogue issues every global read of a pass as one batch (kernel-uniform branches around whole batches) and
+    // then only does arithmetic: with per-element `if (bias) load` the loads serialised, ~0.2 us each, 3 us per output tile
+    __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
+    __device__ __forceinline__ bool has_add() const { return addend != nullptr; }
+    __device__ __forceinline__ bool has_mask() const { return relu_mask != nullptr; }
+    __device__ __forceinline__ bool relu() const { return flags & ASR_GEMM_RELU; }
+    __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
+    __device__ __forceinline__ f32x4 get_add(int m, int n) const { return *reinterpret_cast<const f32x4*>(addend + (int64_t)m * ld_add + n); }
+    __device__ __forceinline__ bf16x4 get_mask(int m, int n) const { return *reinterpret_cast<const bf16x4*>(relu_mask + (int64_t)m * ld_mask + n); }
+    __device__ __forceinline__ f32x4 post(int, f32x4 v) const { return v; }
     __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
         v = apply(r, n, v);
         if (c_dtype == ASR_F32) {
@@ -166,6 +177,29 @@ struct EpiDense {
     }
 };
 
+// EpiDense with its options fixed at compile time (MODE bits: 1 bias, 2 ReLU, 4 addend, 8 relu_mask, 16 bf16 output): the wide
+// epilogue then is straight-line code.  With the options tested at run time every output fragment carried four scalar
+// branches, and the epilogue took 1.8 us of a 4.9 us output tile.
+template <unsigned MODE> struct EpiDenseS : EpiDense {
+    __device__ __forceinline__ bool has_bias() const { return MODE & 1u; }
+    __device__ __forceinline__ bool relu() const { return MODE & 2u; }
+    __device__ __forceinline__ bool has_add() const { return MODE & 4u; }
+    __device__ __forceinline__ bool has_mask() const { return MODE & 8u; }
+    __device__ __forceinline__ int elem_size() const { return (MODE & 16u) ? 2 : 4; }
+    __device__ __forceinline__ unsigned char* row_ptr(int m, int nw) const {
+        return reinterpret_cast<unsigned char*>(C) + ((int64_t)m * ldc + nw) * ((MODE & 16u) ? 2 : 4);
+    }
+};
+inline unsigned dense_mode(const EpiDense& e) {
+    return (e.bias ? 1u : 0u) | ((e.flags & ASR_GEMM_RELU) ? 2u : 0u) | (e.addend ? 4u : 0u) | (e.relu_mask ? 8u : 0u) |
+           (e.c_dtype == ASR_BF16 ? 16u : 0u);
+}
+template <unsigned MODE> inline EpiDenseS<MODE> dense_as(const EpiDense& e) {
+    EpiDenseS<MODE> r;
+    static_cast<EpiDense&>(r) = e;
+    return r;
+}
+
 template <typename CT> struct EpiHeads {
     CT* out;
     int64_t proj_stride;
@@ -187,11 +221,14 @@ template <typename CT> struct EpiHeads {
         const int slot = nw >> 6, which = slot / h, head = slot - which * h;
         return reinterpret_cast<unsigned char*>(out + which * proj_stride + (((int64_t)b * h + head) * L + t) * 64);
     }
-    __device__ __forceinline__ f32x4 apply(const Row&, int n, f32x4 v) const {
-        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
-        if ((n >> 6) / h == 0) v *= scale_first;
-        return v;
-    }
+    __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
+    __device__ __forceinline__ bool has_add() const { return false; }
+    __device__ __forceinline__ bool has_mask() const { return false; }
+    __device__ __forceinline__ bool relu() const { return false; }
+    __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
+    __device__ __forceinline__ f32x4 get_add(int, int) const { return f32x4{0, 0, 0, 0}; }
+    __device__ __forceinline__ bf16x4 get_mask(int, int) const { return bf16x4{}; }
+    __device__ __forceinline__ f32x4 post(int n, f32x4 v) const { return ((n >> 6) / h == 0) ? v * scale_first : v; }
     __device__ __forceinline__ void store_fast(const Row& r, int n, f32x4 v) const {
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
         const int slot = n >> 6;                       // global head slot = which * h + head
@@ -233,53 +270,87 @@ template <typename CT> struct EpiHeads {
 // of the LDS the K loop has finished with) the 64 x 64 sub-tile is transposed through LDS instead: epilogue math in the
 // accumulator layout, XOR-swizzled LDS image, then 16 bytes per lane with 8 (bf16) / 16 (f32) adjacent lanes covering a
 // row's whole 128 / 256 bytes.
-template <typename Epi>
+template <typename Epi, int SCRB = 4096>
 __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int q4,
                                              unsigned char* scratch = nullptr) {
     if (scratch && epi.wide(n0)) {
         const int lane = q4 * 16 + r16;
         const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-        if (epi.elem_size() == 2) {
+        const bool bf16_out = epi.elem_size() == 2;
+        const int ncol = nw + q4 * 4;                                   // + 16 j
+        f32x4 bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rl = i * 16 + r16, m = mw + rl;
-                const auto r = epi.row(min(m, epi.M - 1));
+        for (int j = 0; j < 4; ++j) bv[j] = f32x4{0, 0, 0, 0};
+        if (epi.has_bias()) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = epi.ld_bias(ncol + 16 * j);
+        }
+        auto pass_rows = [&](auto IBc, int pass) {
+            constexpr int IB = decltype(IBc)::value;                     // 16-row blocks of the sub-tile handled by this pass
+            f32x4 av[IB][4];
+            bf16x4 mk[IB][4];
+            if (epi.has_add()) {
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[ii][j] = epi.get_add(min(mw + (pass * IB + ii) * 16 + r16, epi.M - 1), ncol + 16 * j);
+            }
+            if (epi.has_mask()) {
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mk[ii][j] = epi.get_mask(min(mw + (pass * IB + ii) * 16 + r16, epi.M - 1), ncol + 16 * j);
+            }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int i = pass * IB + ii, rl = ii * 16 + r16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4 v = epi.apply(r, nw + j * 16 + q4 * 4, acc[i][j]);
-                    const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                    const int c = 2 * j + (q4 >> 1);
-                    *reinterpret_cast<bf16x4*>(scratch + rl * 128 + ((c ^ (rl & 7)) << 4) + (q4 & 1) * 8) = o;
-                }
-            }
+                    f32x4 v = acc[i][j] + bv[j];
+                    if (epi.relu()) {
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rl = it * 8 + (lane >> 3), ch = lane & 7, m = mw + rl;
-                const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 128 + ((ch ^ (rl & 7)) << 4));
-                if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
-            }
-        } else {
+                        for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
+                    }
+                    if (epi.has_add()) v += av[ii][j];
+                    if (epi.has_mask()) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii) {
-                    const int i = 2 * half + ii;
-                    const int rl = ii * 16 + r16, m = mw + i * 16 + r16;
-                    const auto r = epi.row(min(m, epi.M - 1));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 v = epi.apply(r, nw + j * 16 + q4 * 4, acc[i][j]);
+                        for (int x = 0; x < 4; ++x) v[x] = ((float)mk[ii][j][x] > 0.f) ? v[x] : 0.f;
+                    }
+                    v = epi.post(ncol + 16 * j, v);
+                    if (bf16_out) {
+                        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        const int c = 2 * j + (q4 >> 1);
+                        *reinterpret_cast<bf16x4*>(scratch + rl * 128 + ((c ^ (rl & 7)) << 4) + (q4 & 1) * 8) = o;
+                    } else {
                         const int c = 4 * j + q4;
                         *reinterpret_cast<f32x4*>(scratch + rl * 256 + ((c ^ (rl & 7)) << 4)) = v;
                     }
                 }
+            }
+            if (bf16_out) {
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int idx = it * 64 + lane, rl = idx >> 4, ch = idx & 15, m = mw + 32 * half + rl;
+                for (int it = 0; it < 2 * IB; ++it) {
+                    const int rl = it * 8 + (lane >> 3), ch = lane & 7, m = mw + pass * IB * 16 + rl;
+                    const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 128 + ((ch ^ (rl & 7)) << 4));
+                    if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4 * IB; ++it) {
+                    const int idx = it * 64 + lane, rl = idx >> 4, ch = idx & 15, m = mw + pass * IB * 16 + rl;
                     const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 256 + ((ch ^ (rl & 7)) << 4));
                     if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
                 }
             }
+        };
+        if (bf16_out) {
+            constexpr int IB = SCRB / 2048;          // 128 B per row
+#pragma unroll
+            for (int pass = 0; pass < 4 / IB; ++pass) pass_rows(std::integral_constant<int, IB>{}, pass);
+        } else {
+            constexpr int IB = SCRB / 4096;          // 256 B per row
+#pragma unroll
+            for (int pass = 0; pass < 4 / IB; ++pass) pass_rows(std::integral_constant<int, IB>{}, pass);
         }
         return;
     }
@@ -756,7 +827,20 @@ template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, 
     // K = 256 (-7 % on the [32000,2048,256] FFN1 shape, +10 % on the narrow-N ones, whole train step 1-2 % faster), so it is the
     // default whenever K % 64 == 0; ASR_AMD_GLDS_MINK raises the threshold for experiments)
     static const int glds_min_k = getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64;
-    if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= glds_min_k) return launch_glds(s, A, lda, W, ldw, M, N, K, epi);
+    if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= glds_min_k) {
+        if constexpr (std::is_same<Epi, EpiDense>::value) {
+            if (epi.wide_ok && !(epi.flags & ~ASR_GEMM_RELU)) {
+                switch (dense_mode(epi)) {   // the combinations the model's projections use; anything else takes the run-time form
+                    case 1u | 2u | 16u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 2u | 16u>(epi));   // FFN1
+                    case 1u | 16u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 16u>(epi));
+                    case 1u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u>(epi));                         // FFN2, fc, affine
+                    case 0u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<0u>(epi));                         // vocab projections
+                    default: break;
+                }
+            }
+        }
+        return launch_glds(s, A, lda, W, ldw, M, N, K, epi);
+    }
     if (w_dtype == ASR_F32) return launch_gemm<float, float>(s, A, lda, W, ldw, M, N, K, epi);
     if (a_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, A, lda, W, ldw, M, N, K, epi);
@@ -820,8 +904,16 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
-        hipLaunchKernelGGL((gemm_nn_tr_kernel<EpiDense>), dim3(nwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, K,
-                           tiles_n, nwg, epi);
+#define LAUNCH_NN_TR(E)                                                                                                          \
+    hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E)>), dim3(nwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, \
+                       K, tiles_n, nwg, E)
+        const unsigned mode = epi.wide_ok ? dense_mode(epi) : 0xffu;
+        if (mode == 4u) LAUNCH_NN_TR(dense_as<4u>(epi));                 // dX = dY . W + residual gradient (f32)
+        else if (mode == (8u | 16u)) LAUNCH_NN_TR(dense_as<8u | 16u>(epi));   // ReLU-masked hidden gradient (bf16)
+        else if (mode == 16u) LAUNCH_NN_TR(dense_as<16u>(epi));
+        else if (mode == 0u) LAUNCH_NN_TR(dense_as<0u>(epi));
+        else LAUNCH_NN_TR(epi);
+#undef LAUNCH_NN_TR
         ASR_LAUNCH_CHECK("gemm_nn_tr");
         return 0;
     }

@@ -120,11 +120,12 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) y[n4 * 4 + threadIdx.x] = (bf16_t)x[n4 * 4 + threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int32_t* __restrict__ len, int L, int V) {
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, const int32_t* __restrict__ len, int L, int V,
+                                                        int64_t ld) {
     const int row = blockIdx.x;  // b*L + t
     const int b = row / L, t = row - b * L;
     if (t < len[b]) return;
-    float* p = x + (int64_t)row * V;
+    float* p = x + (int64_t)row * ld;
     for (int c = threadIdx.x; c < V; c += blockDim.x) p[c] = 0.f;
 }
 
@@ -201,9 +202,9 @@ extern "C" int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t 
     return 0;
 }
 
-extern "C" int asr_mask_rows(void* stream, float* x, const int32_t* len, int B, int L, int V) {
-    ASR_REQUIRE(x && len && B > 0 && L > 0 && V > 0, ASR_ERR_ARG, "mask_rows: bad args");
-    hipLaunchKernelGGL(mask_rows_kernel, dim3(B * L), dim3(256), 0, static_cast<hipStream_t>(stream), x, len, L, V);
+extern "C" int asr_mask_rows(void* stream, float* x, const int32_t* len, int B, int L, int V, int64_t ld) {
+    ASR_REQUIRE(x && len && B > 0 && L > 0 && V > 0 && ld >= V, ASR_ERR_ARG, "mask_rows: bad args");
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(B * L), dim3(256), 0, static_cast<hipStream_t>(stream), x, len, L, V, ld);
     ASR_LAUNCH_CHECK("mask_rows");
     return 0;
 }

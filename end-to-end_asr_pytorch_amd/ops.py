@@ -205,8 +205,8 @@ def cast_bf16(x):
 
 def mask_rows_(x, lens):
     B, L, V = x.shape
-    assert x.is_contiguous()
-    check(lib().asr_mask_rows(_stream(), _p(x), _p(lens), B, L, V), "asr_mask_rows")
+    assert x.stride(2) == 1 and x.stride(0) == L * x.stride(1)
+    check(lib().asr_mask_rows(_stream(), _p(x), _p(lens), B, L, V, x.stride(1)), "asr_mask_rows")
     return x
 
 
@@ -225,7 +225,9 @@ class CtcState:
 
 
 _AUX = {}
-CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "6"))   # pieces of the pipelined CTC forward (<= 1: single stream)
+# pieces of the two-stream pipelined CTC forward; <= 1 = single stream, the default: on MI355X / ROCm 7.2 the cross-stream event
+# hand-offs cost 7-14 us each and the recursion runs 2.4x slower next to the log-sum-exp pass, so 4 chunks measured 188 us vs 171
+CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "1"))
 
 
 def aux_stream(device):

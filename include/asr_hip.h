@@ -239,8 +239,8 @@ int asr_debug_probe_tr(void* stream, void* out, int m0, int n0);
 
 /* Utility: dtype cast f32 -> bf16 (weights / activations entering the bf16 MFMA path). n elements. */
 int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t n);
-/* logits *= (t < len)  (ctcModel/decoder.py:33-36), in place, f32 [B,L,V] dense. */
-int asr_mask_rows(void* stream, float* x, const int32_t* len, int B, int L, int V);
+/* logits *= (t < len)  (ctcModel/decoder.py:33-36), in place, f32 [B,L,V] with row stride ld (elements) and batch stride L*ld. */
+int asr_mask_rows(void* stream, float* x, const int32_t* len, int B, int L, int V, int64_t ld);
 
 #ifdef __cplusplus
 }

@@ -48,7 +48,7 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     L = asr_amd.lib()
     rc = L.asr_gemm_nt(None, None, 0, 8, None, 0, 8, None, None, 0, 8, 4, 4, 8, 0)
     assert rc == -1 and b"gemm" in L.asr_last_error()
-    rc = L.asr_ctc_loss_fwd(None, None, 0, None, None, 1, 1, 4, 1, 3, None, None, None, None, None)
+    rc = L.asr_ctc_loss_fwd(None, None, 0, None, None, 1, 1, 4, 1, 3, None, None, None, None, None, None, 1)
     assert rc == -1
 
 
