@@ -203,7 +203,7 @@ def main():
                      "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
                      "fwd_bwd_GBps": (round(3 * 4.0 * CFG["B"] * CFG["T"] * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
                                       if ctc_b else None)} if ctc_k else None),
-            "kernels": kernels[:12],
+            "kernels": kernels[:12], "op_ms_total": round(sum(k["ms_per_step"] for k in kernels), 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, ref_ctc, ref_ce, ref_ctc_logits, ref_logits = cpu_baseline(model, x, lens, tg, n_utt=1)

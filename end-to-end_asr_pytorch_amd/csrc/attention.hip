@@ -11,6 +11,11 @@
 //     ds_read_b64 (V^T) fragment reads are bank-conflict free; V is transposed on the way in (4x4 register
 //     transpose + ds_write_b64); global loads for tile t+1 are issued before the MFMAs of tile t.
 //   * masks come from lengths (key j masked iff j >= k_len[b] or causal && j > i); no mask tensor is read.
+//   * scores are BASE-2 logits: q arrives pre-multiplied by log2(e)/sqrt(d_k) (folded into the Q projection's epilogue), so a
+//     probability is one v_exp_f32 of an accumulator register - the running maximum is subtracted by the MFMA itself (it is the
+//     accumulator's initial value) and is only moved, with the O / row-sum rescale that costs, when a tile's maximum outgrows it
+//     by 2^8: the kernel is VALU-bound (one quarter-rate exp per 256 MFMA flops at d_k = 64), every op removed from the
+//     per-probability path is throughput.
 // fp32 path: one wave per query row, plain VALU, exact fp32 - the parity/debug mode, not a performance path.
 #include <stdlib.h>
 
@@ -56,8 +61,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
         }
         const float mc = wave_max(s);
         const float mn = fmaxf(m, mc);
-        const float sc = (m == -INFINITY) ? 0.f : expf(m - mn);
-        const float p = valid ? expf(s - mn) : 0.f;
+        const float sc = (m == -INFINITY) ? 0.f : exp2f(m - mn);
+        const float p = valid ? exp2f(s - mn) : 0.f;
         l = l * sc + wave_sum(p);
         acc *= sc;
         const int cnt = min(64, kend - j0);
@@ -68,212 +73,12 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
         m = mn;
     }
     ctx[((int64_t)b * Lq + i) * (h * 64) + hd * 64 + lane] = acc / l;
-    if (lse && lane == 0) lse[(int64_t)bh * Lq + i] = m + logf(l);
+    if (lse && lane == 0) lse[(int64_t)bh * Lq + i] = m + log2f(l);   // base-2, like the scores
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // bf16 MFMA flash kernel
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int swz_chunk(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
-
-template <int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                   const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
-                                                                   float* __restrict__ lse, int h, int Lq, int Lk,
-                                                                   const int32_t* __restrict__ k_len, int q_tiles) {
-    constexpr int NTHR = NW * 64;
-    constexpr int QB = NW * 32;            // query rows per workgroup
-    constexpr int KCH = 512 / NTHR;        // 16-byte K chunks per thread per tile
-    constexpr int VBL = 256 / NTHR;        // 4x4 V blocks per thread per tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 8192];
-    unsigned char* Ks = smem;
-    unsigned char* Vt = smem + 8192;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    // XCD-aware map: workgroups are dealt round-robin over the 8 XCDs, so all query tiles of one (batch, head) are given
-    // the same blockIdx % 8 and adjacent slots -> they share that XCD's L2 copy of K/V (PMC: 279 -> ~65 MB fetched per launch).
-    int qt, bh;
-    {
-        const int BH = gridDim.x / q_tiles;
-        if ((BH & 7) == 0) {
-            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-            bh = (slot / q_tiles) * 8 + xcd;
-            qt = slot % q_tiles;
-        } else {
-            qt = blockIdx.x % q_tiles;
-            bh = blockIdx.x / q_tiles;
-        }
-    }
-    const int b = bh / h, hd = bh - b * h;
-    const int q0 = qt * QB;
-    const int kl = k_len ? min(k_len[b], Lk) : Lk;
-    const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
-    const int ntiles = (kmax + 63) >> 6;
-    const int qrow = q0 + wave * 32 + r;
-    const int wave_qlast = q0 + wave * 32 + 31;
-
-    const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
-    const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
-
-    u32x4 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = (qrow < Lq) ? *reinterpret_cast<const u32x4*>(Q + ((int64_t)bh * Lq + qrow) * 64 + 16 * s + 8 * hh)
-                            : u32x4{0, 0, 0, 0};
-
-    u32x4 kreg[KCH];
-    u32x2 vreg[VBL][4];
-    auto gload = [&](int t) {
-        const int key0 = t * 64;
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int id = tid + NTHR * i;
-            const int row = id >> 3, c = id & 7;
-            const int key = key0 + row;
-            kreg[i] = (key < kl) ? *reinterpret_cast<const u32x4*>(Kb + (int64_t)key * 64 + c * 8) : u32x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int i = 0; i < VBL; ++i) {
-            const int id = tid + NTHR * i;
-            const int dg = id & 15, kg = id >> 4;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int key = key0 + 4 * kg + kk;
-                vreg[i][kk] = (key < kl) ? *reinterpret_cast<const u32x2*>(Vb + (int64_t)key * 64 + 4 * dg) : u32x2{0, 0};
-            }
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int id = tid + NTHR * i;
-            const int row = id >> 3, c = id & 7;
-            *reinterpret_cast<u32x4*>(Ks + row * 128 + swz_chunk(row, c)) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VBL; ++i) {
-            const int id = tid + NTHR * i;
-            const int dg = id & 15, kg = id >> 4;
-            u32x2 ct[4];
-            transpose4x4_bf16(vreg[i], ct);
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                const int row = 4 * dg + dd;  // d index
-                const int off = row * 128 + swz_chunk(row, kg >> 1) + (((kg & 1) ^ ((row >> 4) & 1)) << 3);
-                *reinterpret_cast<u32x2*>(Vt + off) = ct[dd];
-            }
-        }
-    };
-
-    f32x16 o0, o1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m = -INFINITY, l = 0.f;
-
-    if (ntiles > 0) gload(0);
-    for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (t + 1 < ntiles) gload(t + 1);
-        const int key0 = t * 64;
-        if (CAUSAL && key0 > wave_qlast) continue;  // wave-uniform: whole tile in this wave's future
-
-        // ---- S^T = K . Q^T : two 32-key halves --------------------------------------------------------
-        f32x16 st[2];
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) st[hf][i] = 0.f;
-            const int row = hf * 32 + r;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + row * 128 + swz_chunk(row, 2 * s + hh));
-                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                                 __builtin_bit_cast(bf16x8, qf[s]), st[hf], 0, 0, 0);
-            }
-        }
-        // ---- mask + online softmax (query on the lane) ------------------------------------------------
-        // interior tiles (every key valid for every query of this wave) skip the mask arithmetic entirely (wave-uniform)
-        const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32);
-        float mloc = -INFINITY;
-        if (interior) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[hf][i]);
-        } else {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    const bool bad = key >= kl || (CAUSAL && key > qrow);
-                    st[hf][i] = bad ? -INFINITY : st[hf][i];
-                    mloc = fmaxf(mloc, st[hf][i]);
-                }
-        }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mn = fmaxf(m, mloc);
-        const float mbase = (mn == -INFINITY) ? 0.f : mn;
-        const float alpha = __expf(m - mbase);  // m = -inf -> 0
-        const float mb2 = mbase * 1.4426950408889634f;
-        float rs = 0.f;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -mb2));  // exp(s - m): one fma + v_exp_f32
-                st[hf][i] = p;
-                rs += p;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        m = mn;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-
-        // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[hf][8 * s2 + j];
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int row = dt * 32 + r;
-                    const int sub = (hh ^ ((row >> 4) & 1)) << 3;
-                    const u32x2 v0 = *reinterpret_cast<const u32x2*>(Vt + row * 128 + swz_chunk(row, hf * 4 + 2 * s2) + sub);
-                    const u32x2 v1 = *reinterpret_cast<const u32x2*>(Vt + row * 128 + swz_chunk(row, hf * 4 + 2 * s2 + 1) + sub);
-                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-                    if (dt == 0)
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
-                    else
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
-                }
-            }
-    }
-
-    if (qrow < Lq) {
-        const float inv = 1.f / l;
-        bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 8 * g + 4 * hh;
-            bf16x4 a = {(bf16_t)(o0[4 * g] * inv), (bf16_t)(o0[4 * g + 1] * inv), (bf16_t)(o0[4 * g + 2] * inv),
-                        (bf16_t)(o0[4 * g + 3] * inv)};
-            bf16x4 c = {(bf16_t)(o1[4 * g] * inv), (bf16_t)(o1[4 * g + 1] * inv), (bf16_t)(o1[4 * g + 2] * inv),
-                        (bf16_t)(o1[4 * g + 3] * inv)};
-            *reinterpret_cast<bf16x4*>(op + d) = a;
-            *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
-        }
-        if (lse && hh == 0) lse[(int64_t)bh * Lq + qrow] = m + logf(l);
-    }
-}
-
 // ---- v2: LDS-DMA staging + hardware-transposed V reads -----------------------------------------------------------------------
 // K and V tiles are copied ROW-MAJOR ([64 keys][64 d], 128-byte rows) straight into a double-buffered LDS image by
 // global_load_lds_dwordx4 (no staging VGPRs, no register transposes, one barrier per tile, the next tile's DMA in flight during
@@ -347,7 +152,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m = -INFINITY, l = 0.f;
+    // mref: the reference maximum the MFMA subtracts (accumulator init = -mref); the true running maximum never exceeds
+    // mref + MAXLAG.  first: nothing accumulated yet (mref is still the placeholder 0).
+    constexpr float MAXLAG = 8.f;
+    float mref = 0.f, l = 0.f;
+    bool first = true;
 
     if (ntiles > 0) stage(0, 0);
     __syncthreads();
@@ -362,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) st[hf][i] = 0.f;
+                for (int i = 0; i < 16; ++i) st[hf][i] = -mref;
                 const int row = hf * 32 + r;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -389,25 +198,35 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
                         mloc = fmaxf(mloc, st[hf][i]);
                     }
             }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float mn = fmaxf(m, mloc);
-            const float mbase = (mn == -INFINITY) ? 0.f : mn;
-            const float alpha = __expf(m - mbase);
-            const float mb2 = mbase * 1.4426950408889634f;
-            float rs = 0.f;
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));     // the other 16 keys of each half-tile live on lane ^ 32
+            // move the reference only when it has to: first tile, or this tile's maximum is more than 2^MAXLAG above it
+            const bool move = (first && mloc > -INFINITY) || mloc > MAXLAG;
+            if (__builtin_amdgcn_ballot_w64(move)) {          // wave-uniform branch; lanes that need no move use delta = 0
+                const float delta = move ? mloc : 0.f;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[hf][i] -= delta;
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                mref += delta;
+            }
+            first = first && !(mloc > -INFINITY);
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -mb2));
-                    st[hf][i] = p;
-                    rs += p;
+                for (int i = 0; i < 16; i += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(st[hf][i]), p1 = __builtin_amdgcn_exp2f(st[hf][i + 1]);
+                    st[hf][i] = p0;
+                    st[hf][i + 1] = p1;
+                    rs2 += f32x2{p0, p1};
                 }
+            float rs = rs2[0] + rs2[1];
             rs += __shfl_xor(rs, 32, 64);
-            l = l * alpha + rs;
-            m = mn;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            l += rs;
             if (DROP) {   // the row sum above is of the un-dropped probabilities; 1/keep is folded into the final normalisation
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
@@ -466,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
             *reinterpret_cast<bf16x4*>(op + d) = a;
             *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
         }
-        if (lse && hh == 0) lse[(int64_t)bh * Lq + qrow] = m + logf(l);
+        if (lse && hh == 0) lse[(int64_t)bh * Lq + qrow] = mref + __builtin_amdgcn_logf(l);   // base-2
     }
 }
 
@@ -474,8 +293,7 @@ template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, c
                                   int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop) {
     const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);
     dim3 grid(B * h * q_tiles), block(NW * 64);
-    static const bool v1 = getenv("ASR_AMD_ATTN_V1") != nullptr;   // A/B switch: register-staged v1 kernel
-    if (!v1 || drop.thr16) {
+    {
 #define LAUNCH_V2(C, D)                                                                                                        \
     hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,             \
                        (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop)
@@ -485,14 +303,6 @@ template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, c
         ASR_LAUNCH_CHECK("attention_fwd_bf16_v2");
         return 0;
     }
-    if (causal)
-        hipLaunchKernelGGL((attn_fwd_bf16_kernel<NW, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
-    else
-        hipLaunchKernelGGL((attn_fwd_bf16_kernel<NW, false>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles);
-    ASR_LAUNCH_CHECK("attention_fwd_bf16");
-    return 0;
 }
 
 }  // namespace

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
         for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[j];
     }
     dl += __shfl_xor(dl, 32, 64);
-    const float my_lse2 = (qok ? lse[(int64_t)bh * Lq + qrow] : 0.f) * 1.4426950408889634f;
+    const float my_lse2 = qok ? lse[(int64_t)bh * Lq + qrow] : 0.f;   // base-2, like the scores (q carries log2(e)/sqrt(d_k))
     if (qok && hh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
 
     f32x16 a0 = zero16(), a1 = zero16();
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
             if (interior) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -my_lse2));
+                    const float p = __builtin_amdgcn_exp2f(st[hf][i] - my_lse2);
                     st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
                 }
             } else {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                 for (int i = 0; i < 16; ++i) {
                     const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                     const bool bad = key >= kl || (CAUSAL && key > qrow) || !qok;
-                    const float p = bad ? 0.f : __builtin_amdgcn_exp2f(fmaf(st[hf][i], 1.4426950408889634f, -my_lse2));
+                    const float p = bad ? 0.f : __builtin_amdgcn_exp2f(st[hf][i] - my_lse2);
                     st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
                 }
             }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ql = hf * 32 + 8 * g + 4 * hh;   // 4 consecutive query rows live in regs 4g..4g+3
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql) * 1.4426950408889634f;   // base-2 for exp2(fma)
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);   // base-2
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ql);
                 float mk[4] = {1.f, 1.f, 1.f, 1.f};
                 if (DROP) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 for (int i = 0; i < 4; ++i) {
                     const int q = q0 + ql + i;
                     const bool bad = !interior && (!kok || q >= Lq || (CAUSAL && key > q));
-                    const float e = __builtin_amdgcn_exp2f(fmaf(sq[hf][4 * g + i], 1.4426950408889634f, -l4[i]));
+                    const float e = __builtin_amdgcn_exp2f(sq[hf][4 * g + i] - l4[i]);
                     const float p = bad ? 0.f : e;
                     sq[hf][4 * g + i] = DROP ? p * mk[i] : p;                                          // dropout(P), feeds dV
                     dp[hf][4 * g + i] = p * ((DROP ? dp[hf][4 * g + i] * mk[i] : dp[hf][4 * g + i]) - d4[i]);     // dS
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
     if (key < Lk) {   // keys in [kl, Lk) get exact zeros
         const int64_t off = ((int64_t)b * Lk + key) * ldkv + hd * 64;
-        store_T(dk_out + off, dk0, dk1, hh, 1.f);
+        store_T(dk_out + off, dk0, dk1, hh, 0.6931471805599453f);   // dS is per natural-log score; q carries log2(e): dK = dS^T.q * ln 2
         store_T(dv_out + off, dv0, dv1, hh, 1.f);
     }
 }

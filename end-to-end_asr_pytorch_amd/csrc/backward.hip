@@ -487,7 +487,8 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
     if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 &&
         ldb % 8 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 16)) {
         const int tiles_n = N / 128, tiles_k = K / 128, tiles = tiles_n * tiles_k;
-        int splits = (512 + tiles - 1) / tiles;
+        static const int target_wgs = getenv("ASR_AMD_TN_WGS") ? atoi(getenv("ASR_AMD_TN_WGS")) : 512;   // 2 resident per CU
+        int splits = (target_wgs + tiles - 1) / tiles;
         const int max_splits = (M + 511) / 512;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;

@@ -25,6 +25,7 @@ import torch.nn as nn
 from . import ops
 
 _PRECISION = os.environ.get("ASR_AMD_PRECISION", "bf16")
+_LOG2E = 1.4426950408889634
 
 
 def set_precision(p):
@@ -278,13 +279,14 @@ class MultiheadAttention(_Cached):
         """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act."""
         h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
         scale = 1.0 / math.sqrt(self.d_k)
+        qscale = scale * _LOG2E      # the attention kernels take base-2 logits (asr_hip.h): log2(e) rides on the Q projection
         if xkv is xq:
             W = self._w("qkv", (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight))
             bias = self._b("bqkv", (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias))
-            qkv = ops.proj_heads(xq.mma(), W, bias, 3, B, Lq, h, scale)
+            qkv = ops.proj_heads(xq.mma(), W, bias, 3, B, Lq, h, qscale)
             q, k, v = qkv[0], qkv[1], qkv[2]
         else:
-            q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, scale)[0]
+            q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
             kv = ops.proj_heads(xkv.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)),
                                 self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
             k, v = kv[0], kv[1]

@@ -84,24 +84,28 @@ int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda, const voi
 /* Head-major projection (attention.py:43-49: w_qs/w_ks/w_vs + view/permute/contiguous fused).
  * X[M = B*L, K] . W[n_proj*h*64, K]^T + bias -> out[p][B][h][L][64] for p < n_proj, out_dtype = w_dtype.
  * `proj_stride` = elements between consecutive projections' buffers.  If scale_first != 1, projection 0 (Q) is
- * multiplied by it (the 1/sqrt(d_k) of attention.py:77 folded in; exact for powers of two).
+ * multiplied by it: the 1/sqrt(d_k) of attention.py:77 and the log2(e) asr_attention_* expect are folded in here
+ * (one rounding to the output dtype either way).
  */
 int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t ldx, const void* W, int w_dtype, int64_t ldw,
                    const float* bias, void* out, int64_t proj_stride, int n_proj, int B, int L, int h, int K,
                    float scale_first);
 
 /* Fused scaled-dot-product attention (attention.py:76-84 bmm -> /sqrt(dk) -> masked_fill(-inf) -> softmax -> bmm,
- * plus the un-permute of attention.py:56-57).  q (pre-scaled) [B,h,Lq,64], k,v [B,h,Lk,64] in `dtype`;
- * ctx [B,Lq,h*64] in `dtype`.  Masks are expressed by lengths, not tensors: key j of batch b is masked iff
- * j >= k_len[b] (utils.py:157-165 / :146-154) or (causal && j > i) (utils.py:135-143).  k_len may be NULL.
- * lse (f32 [B,h,Lq], natural log of the softmax denominator incl. max) is written when non-NULL (for backward).
+ * plus the un-permute of attention.py:56-57).  q [B,h,Lq,64] PRE-MULTIPLIED by log2(e)/sqrt(d_k), k,v [B,h,Lk,64] in `dtype`;
+ * ctx [B,Lq,h*64] in `dtype`.  The scores q.k are therefore base-2 logits and the softmax is 2^s / sum 2^s - the same
+ * probabilities as attention.py's exp(q.k/sqrt(d_k)), one v_exp_f32 each with no multiply in front.  Masks are expressed by
+ * lengths, not tensors: key j of batch b is masked iff j >= k_len[b] (utils.py:157-165 / :146-154) or (causal && j > i)
+ * (utils.py:135-143).  k_len may be NULL.  lse (f32 [B,h,Lq], BASE-2 log of the softmax denominator incl. max) is written
+ * when non-NULL (for backward).
  */
 int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
                       int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop);
 
 /* Backward of asr_attention_fwd (bf16 only).  q,k,v as in the forward; o = the forward's ctx and d_o = its gradient, both
  * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 [B,h,Lq] workspace.  Outputs are token-major bf16:
- * dq[(b*Lq+i)*ldq + head*64 + d] (multiplied by `scale` = the 1/sqrt(d_k) the forward folded into q), dk / dv at
+ * dq[(b*Lq+i)*ldq + head*64 + d] (gradient wrt the UNSCALED query times `scale` = 1/sqrt(d_k), i.e. what the Q projection's
+ * backward consumes; the log2(e) in q cancels against the base-2 softmax), dk / dv at
  * [(b*Lk+j)*ldkv + head*64 + d] - i.e. directly the A operands of the projection GEMMs' backward. */
 int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,

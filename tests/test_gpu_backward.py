@@ -7,6 +7,7 @@ import asr_amd
 from asr_amd import ops
 
 pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
 DEV = "cuda:0"
 
 
@@ -103,7 +104,9 @@ def test_add_layernorm_bwd(D):
                                                      (2, 2, 51, 250, False, True), (1, 2, 300, 300, True, False), (1, 1, 1000, 1000, False, True)])
 def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
     g = torch.Generator().manual_seed(Lq * 3 + Lk)
-    q = (torch.randn(B, h, Lq, 64, generator=g) * 0.4).bfloat16().float().requires_grad_(True)
+    # device q carries log2(e) (asr_hip.h); the reference differentiates wrt exactly that tensor / log2(e)
+    qdev = (torch.randn(B, h, Lq, 64, generator=g) * 0.4 * LOG2E).bfloat16()
+    q = (qdev.float() / LOG2E).requires_grad_(True)
     k = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
     v = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
     k_len = None
@@ -120,7 +123,7 @@ def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
     ctx = (p @ v).permute(0, 2, 1, 3).reshape(B, Lq, h * 64)
     dctx = torch.randn(B, Lq, h * 64, generator=g).bfloat16().float()
     ctx.backward(dctx)
-    qd, kd, vd = (t.detach().to(DEV).bfloat16() for t in (q, k, v))
+    qd, kd, vd = qdev.to(DEV), k.detach().to(DEV).bfloat16(), v.detach().to(DEV).bfloat16()
     kl = None if k_len is None else k_len.to(DEV).int()
     ctx_d, lse = ops.attention_fwd(qd, kd, vd, kl, causal, need_lse=True)
     dq = torch.zeros(B * Lq, h * 64, device=DEV, dtype=torch.bfloat16)
@@ -128,7 +131,7 @@ def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
     ops.attention_bwd(qd, kd, vd, ctx_d, dctx.to(DEV).bfloat16(), lse, kl, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:])
     to_tok = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0] * t.shape[2], h * 64)
     # bf16 operands / outputs on sums over up to Lq (dK, dV) or Lk (dQ) terms: the absolute error grows ~ sqrt(L)
-    tol = dict(atol=3e-2 * max(1.0, (max(Lq, Lk) / 250.0) ** 0.5), rtol=3e-2)
+    tol = dict(atol=5e-2 * max(1.0, (max(Lq, Lk) / 250.0) ** 0.5), rtol=3e-2)
     np.testing.assert_allclose(N(dq), (to_tok(q.grad) * 0.125).numpy(), **tol)
     np.testing.assert_allclose(N(dkv[:, :h * 64]), to_tok(k.grad).numpy(), **tol)
     np.testing.assert_allclose(N(dkv[:, h * 64:]), to_tok(v.grad).numpy(), **tol)

@@ -14,6 +14,7 @@ from oracle import asr_oracle as O
 from weights import make_state_dict, names_shapes_from_json
 
 pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
 DEV = "cuda:0"
 N = lambda t: t.detach().float().cpu().numpy()
 THR = 6554   # p = 0.1
@@ -93,7 +94,9 @@ def test_embed_dropout_fwd_bwd():
                                                      (2, 2, 51, 250, False, True), (1, 2, 300, 300, True, False), (3, 1, 130, 77, False, False)])
 def test_attention_dropout_fwd_bwd(B, h, Lq, Lk, causal, ragged):
     g = torch.Generator().manual_seed(Lq * 3 + Lk)
-    q = (torch.randn(B, h, Lq, 64, generator=g) * 0.4).bfloat16().float().requires_grad_(True)
+    # device q carries log2(e) (asr_hip.h); the reference differentiates wrt exactly that tensor / log2(e)
+    qdev = (torch.randn(B, h, Lq, 64, generator=g) * 0.4 * LOG2E).bfloat16()
+    q = (qdev.float() / LOG2E).requires_grad_(True)
     k = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
     v = torch.randn(B, h, Lk, 64, generator=g).bfloat16().float().requires_grad_(True)
     k_len = None
@@ -111,7 +114,7 @@ def test_attention_dropout_fwd_bwd(B, h, Lq, Lk, causal, ragged):
     ctx = ((p * dm) @ v).permute(0, 2, 1, 3).reshape(B, Lq, h * 64)
     dctx = torch.randn(B, Lq, h * 64, generator=g).bfloat16().float()
     ctx.backward(dctx)
-    qd, kd, vd = (t.detach().to(DEV).bfloat16() for t in (q, k, v))
+    qd, kd, vd = qdev.to(DEV), k.detach().to(DEV).bfloat16(), v.detach().to(DEV).bfloat16()
     kl = None if k_len is None else k_len.to(DEV).int()
     ctx_d, lse = ops.attention_fwd(qd, kd, vd, kl, causal, need_lse=True, drop=D(31, 32))
     np.testing.assert_allclose(N(ctx_d), ctx.detach().numpy(), atol=2e-2, rtol=2e-2)
@@ -135,7 +138,7 @@ def test_dropout_is_rejected_on_the_f32_parity_path():
         ops.attention_fwd(q, q, q, None, False, drop=D(1, 2))
 
 
-def _grad_check(model, z, rel=1.2e-1, abs_=5e-3, total=5e-2):
+def _grad_check(model, z, rel=1.5e-1, abs_=5e-3, total=5e-2):
     """bf16 training step vs the fp32 reference on the tiny S0 model: every kernel is checked tightly above; here a handful of ReLU
     sign flips / near-uniform 8-position decoder attentions move small-norm gradients by several percent (measured: the same 3-10 %
     on those tensors with any single dropout site enabled, and 4-12 % with none, test_gpu_trainer), so the per-tensor bound is

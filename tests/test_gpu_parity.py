@@ -21,6 +21,7 @@ from oracle import asr_oracle as O
 from weights import make_state_dict, names_shapes_from_json
 
 pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
 DEV = "cuda:0"
 
 
@@ -128,10 +129,13 @@ def test_attention_fwd(prec, B, h, Lq, Lk, causal, ragged):
         k_len = torch.randint(max(1, Lk // 2), Lk + 1, (B,), generator=g)
         k_len[0] = Lk
     dt = torch.float32 if prec == "f32" else torch.bfloat16
-    qd, kd, vd = (t.to(DEV).to(dt) for t in (q, k, v))
+    # the kernels take q pre-multiplied by log2(e)/sqrt(d_k) (asr_hip.h): the device q is the rounded tensor, the reference
+    # uses exactly that tensor divided by log2(e), so both see the same scores
+    qd, kd, vd = ((q * LOG2E).to(DEV).to(dt), k.to(DEV).to(dt), v.to(DEV).to(dt))
     ctx, lse = ops.attention_fwd(qd, kd, vd, None if k_len is None else k_len.to(DEV).int(), causal, need_lse=True)
-    qr, kr, vr = (qd.float().cpu(), kd.float().cpu(), vd.float().cpu())
+    qr, kr, vr = (qd.float().cpu() / LOG2E, kd.float().cpu(), vd.float().cpu())
     rctx, rlse = ref_attention(qr, kr, vr, k_len, causal)
+    rlse = rlse * LOG2E     # the kernel's lse is base-2
     tol = 2e-5 if prec == "f32" else 2e-2
     np.testing.assert_allclose(N(ctx), rctx.numpy(), atol=tol, rtol=tol)
     np.testing.assert_allclose(N(lse), rlse.numpy(), atol=1e-4 if prec == "f32" else 2e-2, rtol=1e-4)
@@ -146,9 +150,9 @@ def test_attention_online_softmax_rescale_branch():
     v = torch.randn(B, h, L, 64, generator=g)
     k[0, 0, 200] = q[0, 0, 17] * 40.0
     for dt, tol in ((torch.float32, 5e-5), (torch.bfloat16, 3e-2)):
-        qd, kd, vd = (t.to(DEV).to(dt) for t in (q, k, v))
+        qd, kd, vd = ((q * LOG2E).to(DEV).to(dt), k.to(DEV).to(dt), v.to(DEV).to(dt))
         ctx, _ = ops.attention_fwd(qd, kd, vd, None, False)
-        rctx, _ = ref_attention(qd.float().cpu(), kd.float().cpu(), vd.float().cpu(), None, False)
+        rctx, _ = ref_attention(qd.float().cpu() / LOG2E, kd.float().cpu(), vd.float().cpu(), None, False)
         np.testing.assert_allclose(N(ctx), rctx.numpy(), atol=tol, rtol=tol)
 
 
