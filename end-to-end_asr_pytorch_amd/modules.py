@@ -745,6 +745,9 @@ class Decoder(_Cached):
 
     def preprocess(self, targets):
         """decoder.py:42-58 — strip pad(0), prepend <sos> / append <eos>, re-pad with 0."""
+        hint = self.__dict__.get("_pre_hint")      # the trainer pre-computes this before queueing the step (no mid-step host sync)
+        if hint is not None and hint[0] is targets:
+            return hint[1]
         comp, n = _compact_targets(targets)
         umax = int(n.max().item())
         ys = comp[:, :umax]
@@ -940,7 +943,10 @@ class CTC_Transformer(Transformer):
         super().__init__(encoder, decoder, spec_aug_cfg)
         self.ctc_fc = nn.Linear(encoder.d_output, decoder.d_output, bias=False)
 
-    def _ctc_logits(self, enc):
+    def _ctc_logits(self, enc, lens=None):
+        hook = self.__dict__.get("_ctc_hook")      # trainer: the whole CTC branch (projection, loss, both backwards) on a side stream
+        if hook is not None and _TAPE is not None:
+            return hook(enc, lens)
         return _vocab_proj(self, "ctc", self.ctc_fc.weight, enc)
 
     def forward(self, features, len_features, padded_target):
@@ -950,7 +956,7 @@ class CTC_Transformer(Transformer):
         def run():
             lens = ops.as_i32(len_features, features.device)
             enc = self.encoder._impl(_act(features), lens)
-            ctc_pred = self._ctc_logits(enc)
+            ctc_pred = self._ctc_logits(enc, lens)
             logits, targets_eos = self.decoder._impl(padded_target, enc, lens)
             return [ctc_pred, logits], _slots(self, "ctc", self.decoder, "prj"), targets_eos
         (ctc_pred, logits), targets_eos = _taped(self, run)
@@ -969,7 +975,7 @@ class Conv_CTC_Transformer(CTC_Transformer):
         def run():
             conv, len_sequence = self.conv_encoder._impl(features, len_features)
             enc = self.encoder._impl(conv, len_sequence)
-            ctc_logits = self._ctc_logits(enc)
+            ctc_logits = self._ctc_logits(enc, len_sequence)
             logits, targets_eos = self.decoder._impl(targets, enc, len_sequence)
             return [ctc_logits, logits], _slots(self, "ctc", self.decoder, "prj"), (targets_eos, len_sequence, enc.B, enc.L)
         (ctc_logits, logits), (targets_eos, len_sequence, B, L) = _taped(self, run)

@@ -230,11 +230,12 @@ _AUX = {}
 CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "1"))
 
 
-def aux_stream(device):
-    """A high-priority side stream per device for latency-bound work that overlaps an HBM-bound pass (CTC recursion)."""
-    key = torch.device(device).index
+def aux_stream(device, priority=0):
+    """A side stream per (device, priority): -1 for latency-bound work beside an HBM-bound pass (pipelined CTC forward), 0 for
+    bulk work that should fill the CUs a run of small kernels leaves idle (the trainer's CTC branch beside the decoder)."""
+    key = (torch.device(device).index, priority)
     if key not in _AUX:
-        _AUX[key] = torch.cuda.Stream(device=device, priority=-1)
+        _AUX[key] = torch.cuda.Stream(device=device, priority=priority)
     return _AUX[key]
 
 
@@ -261,7 +262,7 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None):
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
         check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
                                      _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len),
-                                     ctypes.c_void_p(aux_stream(dev).cuda_stream) if nck > 1 else None, nck), "asr_ctc_loss_fwd")
+                                     ctypes.c_void_p(aux_stream(dev, -1).cuda_stream) if nck > 1 else None, nck), "asr_ctc_loss_fwd")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
     return loss, st.nll, st

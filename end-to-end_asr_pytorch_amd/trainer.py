@@ -13,6 +13,7 @@ One process per GPU; utterances are sharded across ranks (each rank owns B_local
 per-rank mean losses.  (The reference has no multi-GPU code; DESIGN.md §6 states the exact-vs-DDP denominators.)
 """
 import math
+import os
 
 import torch
 
@@ -138,8 +139,10 @@ class Trainer:
     (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
 
     def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=4,
-                 process_group=None, lambda_qua=0.001):
+                 process_group=None, lambda_qua=0.001, overlap_ctc=None):
         self.model = model
+        # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); ASR_AMD_OVERLAP_CTC=0 serialises it
+        self.overlap_ctc = (os.environ.get("ASR_AMD_OVERLAP_CTC", "1") != "0") if overlap_ctc is None else bool(overlap_ctc)
         self.lambda_qua = lambda_qua      # CIF models: loss = lambda_qua * qua + ctc + ce (solver.py:153, train.py:64)
         dev = next(model.parameters()).device
         self.fp = FlatParams(model, dev)
@@ -157,8 +160,57 @@ class Trainer:
         """optimizer.py:24-29 (step_num already incremented)."""
         return self.k * self.init_lr * min(self.step_num ** (-0.5), self.step_num * (self.warmup ** (-1.5)))
 
+    def _ctc_side_branch(self, enc, lens, ctc_targets):
+        """The CTC branch of the joint models - ctc_fc projection, CTC loss forward AND backward, ctc_fc's own backward - depends
+        on nothing but the encoder output, while the decoder branch next to it is a long run of small kernels (M = B*(U+1) rows)
+        that leave most of the chip idle.  So it is queued on a side stream right after the encoder forward; its gradient wrt
+        the encoder output lands in a proxy activation that a `join` closure - placed on the main tape exactly where the
+        encoder's backward begins - adds in.  Called from the model's forward through `_ctc_hook`."""
+        model = self.model
+        main = torch.cuda.current_stream()
+        aux = ops.aux_stream(enc.f32.device)
+        aux.wait_stream(main)
+        proxy = modules.Act(enc.f32, enc.b16, enc.B, enc.L)
+        with torch.cuda.stream(aux):
+            with modules.record() as side_tape:
+                logits = modules._vocab_proj(model, "ctc", model.ctc_fc.weight, proxy)
+            ctc, nll, st = ops.ctc_loss_fwd(logits.view(enc.B, enc.L, -1), ops.as_i32(lens, logits.device), ctc_targets)
+            model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, torch.ones(1, device=logits.device))
+            side_tape.backward()
+        self._side = {"ctc": ctc, "st": st}
+        params = (model.ctc_fc.weight,)
+
+        def join():
+            main_now = torch.cuda.current_stream()
+            main_now.wait_stream(aux)
+            g = proxy.grad
+            g.record_stream(main_now)               # allocated on the side stream, last read here
+            modules._acc(enc, g)
+            proxy.grad = None
+
+        modules._TAPE.push(join, params)
+        ctc.record_stream(main)
+        return logits
+
     def forward_loss(self, feats, lens, targets, noise=None):
         """forward + joint loss with the tape recorded; returns (ctc, ce, state for backward)."""
+        model = self.model
+        d_num = None
+        self._side = None
+        side_ok = self.overlap_ctc and isinstance(model, modules.CTC_Transformer) and not isinstance(model, modules.CIF_Model)
+        if side_ok:
+            # the decoder's target bookkeeping has one host sync (max target length): do it now, before the step is queued
+            pre = model.decoder.preprocess(targets)
+            model.decoder.__dict__["_pre_hint"] = (targets, pre)
+            model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1])
+        try:
+            return self._forward_loss(feats, lens, targets, noise)
+        finally:
+            if side_ok:
+                model.__dict__.pop("_ctc_hook", None)
+                model.decoder.__dict__.pop("_pre_hint", None)
+
+    def _forward_loss(self, feats, lens, targets, noise):
         model = self.model
         d_num = None
         with torch.no_grad(), modules.record() as tape:
@@ -179,7 +231,10 @@ class Trainer:
                     ctc_logits, ctc_len, logits, teos = out
                 else:
                     ctc_len, ctc_logits, (logits, teos) = out
-            ctc, nll, st = ops.ctc_loss_fwd(ctc_logits, ops.as_i32(ctc_len, ctc_logits.device), teos)
+            if self._side is not None:     # already computed (and differentiated) on the side stream
+                ctc, st = self._side["ctc"], None
+            else:
+                ctc, nll, st = ops.ctc_loss_fwd(ctc_logits, ops.as_i32(ctc_len, ctc_logits.device), teos)
             V = logits.shape[-1]
             loss2, row_loss, lse, tg1 = ops.ce_loss_fwd(logits.reshape(-1, V), teos.reshape(-1), self.smoothing)
         return ctc, loss2[0], (tape, st, logits, tg1, lse, loss2, d_num)
@@ -196,7 +251,8 @@ class Trainer:
                 self.buckets.finish()
                 return
             # loss = ctc + ce (solver.py:88): both seeds are 1
-            model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one)
+            if st is not None:
+                model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one)
             V = logits.shape[-1]
             model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one)
             if d_num is not None:

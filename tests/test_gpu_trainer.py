@@ -265,3 +265,27 @@ def test_ctc_model_gradients_match_reference(golden_dir):
     np.testing.assert_allclose(float(ctc), z["loss"], rtol=5e-3)
     check(model)
     tr.optimizer_step()
+
+
+def test_ctc_side_stream_matches_serial_step(golden_dir):
+    """The trainer queues the CTC branch on a side stream beside the decoder (Trainer._ctc_side_branch): same losses, and the same
+    gradients up to fp32 summation order (the encoder-output gradient receives its CTC and decoder parts in a different order,
+    and the weight-gradient kernels accumulate with float atomics) as the serial order."""
+    z, sd, _ = build(golden_dir)
+    asr_amd.set_precision("bf16")
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    grads, losses = [], []
+    for overlap in (False, True):
+        model = asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=0.0), asr_amd.Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.0))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        model = model.to(DEV).eval()
+        tr = asr_amd.Trainer(model, overlap_ctc=overlap)
+        for _ in range(2):     # twice: the side stream's buffers get recycled
+            tr.fp.grad.zero_()
+            ctc, ce, st = tr.forward_loss(x, lens, tg)
+            tr.backward(st)
+        torch.cuda.synchronize()
+        grads.append(tr.fp.grad.clone())
+        losses.append((float(ctc), float(ce)))
+    assert losses[0] == losses[1]
+    np.testing.assert_allclose(grads[0].cpu().numpy(), grads[1].cpu().numpy(), rtol=2e-4, atol=2e-5)
