@@ -162,6 +162,9 @@ def main():
 
     # ---- live per-kernel timing over a second, identical run of the timed region (events add launch overhead, so the
     # headline value above is measured without them) ----
+    if trainer is not None:
+        trainer.overlap_ctc = False     # serial order for this pass: per-op durations are then uncontended (the CTC branch otherwise
+                                        # runs beside the decoder's kernels on a side stream and both would read slower than they are)
     ops.profile_start()
     for _ in range(args.steps):
         step()
@@ -183,7 +186,8 @@ def main():
         roofline = dict(kernel=dom["name"], bound=dom["bound"], achieved=dom["achieved"], peak=peak, unit=dom["unit"],
                         frac=round(dom["achieved"] / peak, 4), traffic=pmc_traffic(dom["name"]),
                         note="achieved = algorithmic FLOPs (or bytes) per launch / mean launch duration from HIP events "
-                             "on the launch stream; traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
+                             "on the launch stream, in a second pass of the same steps with the trainer's CTC side stream "
+                             "switched off (uncontended per-op durations; `value` is measured with it on); traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
                              "WRITE_SIZE passes (profiles/r1/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 correction)")
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]

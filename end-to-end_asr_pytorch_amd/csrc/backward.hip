@@ -158,12 +158,27 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, in
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
                                                             int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N, int K,
-                                                            int tiles_k, int m_per_split, float* __restrict__ colsum) {
+                                                            int tiles_k, int m_per_split, int splits, float* __restrict__ colsum) {
     constexpr int TILE = 64 * 256;   // 64 rows x 128 bf16
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];   // [buf][A|B]
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    // (tile, M-split) from the linear workgroup id.  Workgroups are dealt round-robin to the 8 XCDs; when the split count is a
+    // multiple of 8 every XCD gets whole M-ranges (all output tiles of splits/8 ranges), so each row of dY and X is fetched into
+    // one L2 only - with tile-major ids every XCD streamed a quarter of dY and half of X over ALL rows: 296 MB fetched for the
+    // 147 MB of the FFN weight gradient (rocprofv3 FETCH_SIZE).
+    const int tiles = gridDim.x / splits;
+    int tile, split;
+    if ((splits & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        split = xcd * (splits >> 3) + slot / tiles;
+        tile = slot - (slot / tiles) * tiles;
+    } else {
+        split = blockIdx.x / tiles;
+        tile = blockIdx.x - split * tiles;
+    }
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
-    const int m_begin = blockIdx.y * m_per_split, m_end = min(M, m_begin + m_per_split);   // multiples of 64 by construction
+    const int m_begin = split * m_per_split, m_end = min(M, m_begin + m_per_split);   // multiples of 64 by construction
+    if (m_begin >= m_end) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
@@ -492,10 +507,11 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
         const int max_splits = (M + 511) / 512;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
+        if (splits >= 8) splits = splits / 8 * 8;          // whole M-ranges per XCD (see the kernel's id mapping)
         const int m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
-        splits = (M + m_per_split - 1) / m_per_split;
-        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles, splits), dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, C, ldc, M,
-                           N, K, tiles_k, m_per_split, colsum);
+        if (splits < 8) splits = (M + m_per_split - 1) / m_per_split;   // (with >= 8 the count stays a multiple of 8; empty ranges exit)
+        hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(tiles * splits), dim3(256), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, C, ldc,
+                           M, N, K, tiles_k, m_per_split, splits, colsum);
         ASR_LAUNCH_CHECK("gemm_tn_tr");
         return 0;
     }
@@ -536,7 +552,8 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    if (blocks > 256) blocks = 256;
+    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 256;
+    if (blocks > max_blocks) blocks = max_blocks;
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);

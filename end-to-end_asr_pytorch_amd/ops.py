@@ -276,8 +276,9 @@ def ctc_loss_bwd(st, gout):
     """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,roundup(V,8)] buffer (rows 16-byte aligned so the
     gradient is directly a GEMM operand).  Consumes st.alpha."""
     Vp = _pad8(st.V)
-    gbuf = torch.zeros((st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32) if Vp != st.V else torch.empty(
-        (st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32)
+    gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32)
+    if Vp != st.V:
+        gbuf[:, :, st.V:].zero_()      # only the pad columns (the kernel writes every real one): not a 542 MB fill at S1
     grad = gbuf[:, :, :st.V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
     with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), 8.0 * st.B * st.L * st.V):
@@ -305,8 +306,9 @@ def ce_loss_fwd(logits2d, targets1d, smoothing):
 def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout):
     N, V = logits2d.shape
     Vp = _pad8(V)
-    gbuf = torch.zeros((N, Vp), device=logits2d.device, dtype=torch.float32) if Vp != V else torch.empty(
-        (N, Vp), device=logits2d.device, dtype=torch.float32)
+    gbuf = torch.empty((N, Vp), device=logits2d.device, dtype=torch.float32)
+    if Vp != V:
+        gbuf[:, V:].zero_()
     grad = gbuf[:, :V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
     n_word = loss2[1:2]

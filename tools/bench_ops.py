@@ -128,6 +128,13 @@ def bench_ln():
     dg, db_, dbias = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
     t = timeit(lambda: ops.add_layernorm_bwd(dy, x, mean, rstd, g_, None, B, L, dg, db_, want_bf16=True, dbias=dbias))
     print(json.dumps(dict(op="add_layernorm_bwd", shape=[B * L, D], us=round(t * 1e3, 2), GBps=round(nb / t / 1e6, 1))))
+    lens = torch.full((B,), L, dtype=torch.int32, device=DEV)
+    dx = ops.Dropout(6554, 1, 2)
+    xs = x.clone()
+    t = timeit(lambda: ops.add_layernorm(xs, r, g_, b_, B, L, row_len=lens, want_bf16=True, save_stats=True, drop_x=dx))
+    print(json.dumps(dict(op="add_layernorm(train: stats, mask, dropout)", us=round(t * 1e3, 2), GBps=round(B * L * D * 18 / t / 1e6, 1))))
+    t = timeit(lambda: ops.add_layernorm_bwd(dy, x, mean, rstd, g_, lens, B, L, dg, db_, want_bf16=True, dbias=dbias, drop_x=dx))
+    print(json.dumps(dict(op="add_layernorm_bwd(train: mask, dropout)", us=round(t * 1e3, 2), GBps=round(nb / t / 1e6, 1))))
 
 
 if __name__ == "__main__":
