@@ -133,7 +133,7 @@ def main():
 
     def step():
         if trainer is not None:
-            return trainer.step(x, lens, tg)
+            return trainer.step(x, lens, tg, max_target_len=CFG["U"])   # the loader knows its target lengths: no host sync in the step
         with torch.no_grad():
             l, ctc_logits, (logits, teos) = model(x, lens, tg)
             ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, 0.1)

@@ -743,13 +743,15 @@ class Decoder(_Cached):
         self.tgt_word_prj = nn.Linear(d_model, n_tgt_vocab, bias=False)
         nn.init.xavier_normal_(self.tgt_word_prj.weight)
 
-    def preprocess(self, targets):
-        """decoder.py:42-58 — strip pad(0), prepend <sos> / append <eos>, re-pad with 0."""
+    def preprocess(self, targets, umax=None):
+        """decoder.py:42-58 — strip pad(0), prepend <sos> / append <eos>, re-pad with 0.  `umax` = the longest target of the batch
+        when the caller knows it (the data loader does): without it one host sync reads it back from the device."""
         hint = self.__dict__.get("_pre_hint")      # the trainer pre-computes this before queueing the step (no mid-step host sync)
         if hint is not None and hint[0] is targets:
             return hint[1]
         comp, n = _compact_targets(targets)
-        umax = int(n.max().item())
+        if umax is None:
+            umax = int(n.max().item())
         ys = comp[:, :umax]
         B = targets.shape[0]
         ys_in = torch.cat([torch.full((B, 1), self.sos_id, dtype=targets.dtype, device=targets.device), ys], 1)

@@ -192,15 +192,16 @@ class Trainer:
         ctc.record_stream(main)
         return logits
 
-    def forward_loss(self, feats, lens, targets, noise=None):
-        """forward + joint loss with the tape recorded; returns (ctc, ce, state for backward)."""
+    def forward_loss(self, feats, lens, targets, noise=None, max_target_len=None):
+        """forward + joint loss with the tape recorded; returns (ctc, ce, state for backward).  max_target_len: the longest
+        target (non-pad tokens) of the batch if the caller knows it - the step then has no host synchronisation at all."""
         model = self.model
         d_num = None
         self._side = None
         side_ok = self.overlap_ctc and isinstance(model, modules.CTC_Transformer) and not isinstance(model, modules.CIF_Model)
         if side_ok:
             # the decoder's target bookkeeping has one host sync (max target length): do it now, before the step is queued
-            pre = model.decoder.preprocess(targets)
+            pre = model.decoder.preprocess(targets, umax=max_target_len)
             model.decoder.__dict__["_pre_hint"] = (targets, pre)
             model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1])
         try:
@@ -267,10 +268,10 @@ class Trainer:
                       grad_scale=1.0 / self.world, p16=self.fp.flat16)
         modules.bump_param_epoch()     # derived (re-laid-out) weights are rebuilt from the new parameters on next use
 
-    def step(self, feats, lens, targets, noise=None):
-        """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync)."""
+    def step(self, feats, lens, targets, noise=None, max_target_len=None):
+        """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync when max_target_len is given)."""
         self.fp.grad.zero_()
-        ctc, ce, state = self.forward_loss(feats, lens, targets, noise=noise)
+        ctc, ce, state = self.forward_loss(feats, lens, targets, noise=noise, max_target_len=max_target_len)
         self.backward(state)
         self.optimizer_step()
         return ctc, ce
