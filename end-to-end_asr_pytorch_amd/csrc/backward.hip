@@ -186,10 +186,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
     // staging: piece p (4 rows x 256 B) = rows 4p..4p+3; wave w stages pieces 4w..4w+3 of each operand
     const bf16_t* asrc[4];
     const bf16_t* bsrc[4];
+    int srow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 4 * (wave * 4 + i) + (lane >> 4);
         const int c = (lane & 15) ^ tr_sw(row);
+        srow[i] = row;
         asrc[i] = A + (int64_t)row * lda + n0 + c * 8;
         bsrc[i] = Bm + (int64_t)row * ldb + k0 + c * 8;
     }
@@ -198,9 +200,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (int64_t)m0 * lda),
+            // rows past M (only in the last, partial step when M is not a multiple of 64) are clamped to a valid row; their A
+            // fragments are zeroed before the MFMAs, so whatever they hold contributes nothing
+            const int64_t mr = min(m0, M - 1 - srow[i]);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + mr * lda),
                                              (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (int64_t)m0 * ldb),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + mr * ldb),
                                              (__attribute__((address_space(3))) void*)(base + TILE + p * 1024), 16, 0, 0);
         }
     };
@@ -229,9 +234,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
             const int row0 = g2 * 32 + 8 * q4 + (r16 >> 2);     // this lane's address row for the transposing read
             const int csub = 4 * (r16 & 3);
             u32x4 a[4], b[4];
+            const bool live = m0 + g2 * 32 + 8 * q4 + 8 <= m_end;     // this lane's 8 reduction rows exist (M is a multiple of 8)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 a[i] = tr_frag(At, row0, wm * 64 + i * 16 + csub);
+                if (!live) a[i] = u32x4{0, 0, 0, 0};
                 b[i] = tr_frag(Bt, row0, wn * 64 + i * 16 + csub);
             }
 #pragma unroll
@@ -499,12 +506,13 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
         }
     }
     static const bool no_tr = getenv("ASR_AMD_NO_TR") != nullptr;   // A/B switch
-    if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 64 == 0 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 &&
+    if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 8 == 0 && M >= 64 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 &&
         ldb % 8 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 16)) {
         const int tiles_n = N / 128, tiles_k = K / 128, tiles = tiles_n * tiles_k;
         static const int target_wgs = getenv("ASR_AMD_TN_WGS") ? atoi(getenv("ASR_AMD_TN_WGS")) : 512;   // 2 resident per CU
         int splits = (target_wgs + tiles - 1) / tiles;
-        const int max_splits = (M + 511) / 512;
+        static const int min_rows = getenv("ASR_AMD_TN_MINROWS") ? atoi(getenv("ASR_AMD_TN_MINROWS")) : 512;
+        const int max_splits = (M + min_rows - 1) / min_rows;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
         if (splits >= 8) splits = splits / 8 * 8;          // whole M-ranges per XCD (see the kernel's id mapping)

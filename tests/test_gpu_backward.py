@@ -16,7 +16,7 @@ def N(t):
 
 
 @pytest.mark.parametrize("M,N_,K", [(1000, 256, 2048), (777, 4236, 64), (300, 768, 256), (64, 128, 128), (1024, 256, 2048), (4096, 768, 256),
-                                    (3200, 2048, 256), (128, 128, 256)])
+                                    (3200, 2048, 256), (128, 128, 256), (1632, 256, 256), (1000, 2048, 256), (72, 128, 128)])
 @pytest.mark.parametrize("dts", [("bf16", "bf16"), ("f32", "bf16"), ("f32", "f32")])
 def test_gemm_tn(M, N_, K, dts):
     g = torch.Generator().manual_seed(M + K)

@@ -1,0 +1,124 @@
+"""Size-independent properties at the BASELINE.json shapes (B=32, T=1000, U=50, V=4234, d_model=256): the oracle cannot run
+these sizes in seconds, so the kernels are held to identities the arithmetic must satisfy at any size."""
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOG2E = 1.4426950408889634
+B, T, U, V, D = 32, 1000, 50, 4234, 256
+
+
+def test_ctc_full_size_properties():
+    g = torch.Generator().manual_seed(0)
+    logits = (torch.randn(B, T, V, generator=g) * 2).to(DEV)
+    tg = torch.randint(1, V - 1, (B, U), generator=g)
+    tg[3, 30:] = 0
+    tg[7, 1:] = 0
+    il = torch.randint(2 * U + 2, T + 1, (B,), generator=g)
+    il[0] = T
+    tg, il = tg.to(DEV), il.to(DEV)
+    loss, nll, st = ops.ctc_loss_fwd(logits, il, tg)
+    grad = ops.ctc_loss_bwd(st, torch.ones(1, device=DEV))
+    nll_h = nll.cpu().numpy()
+    assert np.all(np.isfinite(nll_h)) and np.all(nll_h > 0)
+    # (1) d loss / d logits[b,t,:] = scale * (softmax - occupancy): both sum to 1 over the vocabulary on every valid frame
+    # (in units of the gradient's own scale 1 / (B * target length).  alpha and beta are fp32 log-domain sums that reach
+    # |alpha| ~ 8 t with random logits, so each step rounds at ~1e-3 and a frame's occupancies total 1 only to ~1e-2 at
+    # T = 1000 - the same arithmetic, and the same error, as aten's fp32 ctc_loss; storing the table relative to a per-frame
+    # offset was tried and only halves it, because alpha keeps drifting by the number of live paths)
+    tl = (tg != 0).sum(1).clamp(min=1).float()
+    rs = (grad.sum(-1) * (B * tl)[:, None]).cpu().numpy()
+    assert np.abs(rs).max() < 3e-2, np.abs(rs).max()
+    # (2) frames past in_len carry exactly zero gradient; no gradient escapes into the row padding
+    t_idx = torch.arange(T, device=DEV)[None, :]
+    assert float(grad[(t_idx >= il[:, None])].abs().max()) == 0.0
+    # (3) utterances are independent: a permutation of the batch permutes the per-utterance losses bit for bit
+    perm = torch.randperm(B, generator=g).to(DEV)
+    _, nll_p, _ = ops.ctc_loss_fwd(logits[perm].contiguous(), il[perm].contiguous(), tg[perm].contiguous())
+    np.testing.assert_array_equal(nll_p.cpu().numpy(), nll_h[perm.cpu().numpy()])
+    # (4) adding a constant to every logit of a frame changes nothing (log-softmax invariance)
+    shift = torch.randn(B, T, 1, generator=g).to(DEV) * 3
+    _, nll_s, _ = ops.ctc_loss_fwd(logits + shift, il, tg)
+    np.testing.assert_allclose(nll_s.cpu().numpy(), nll_h, rtol=2e-5)
+    # (5) a single-label target: nll equals -log sum over alignments, checked against aten on that one utterance
+    lp = torch.log_softmax(logits[7:8, :int(il[7])].double().cpu(), -1).transpose(0, 1)
+    ref = torch.nn.functional.ctc_loss(lp, tg[7:8, :1].cpu(), il[7:8].cpu(), torch.tensor([1]), blank=V - 1, reduction="none")
+    np.testing.assert_allclose(nll_h[7], float(ref), rtol=1e-5)
+
+
+def test_cif_full_size_conservation():
+    """integrate-and-fire is a linear redistribution of alpha_t * h_t: whatever the firing pattern, the fired outputs plus the
+    unfired remainder add up to sum_t alpha_t h_t, and the number of fires is what the accumulated weight allows."""
+    g = torch.Generator().manual_seed(1)
+    H = 64
+    hidden = torch.randn(B, T, H, generator=g).to(DEV)
+    alpha = (torch.rand(B, T, generator=g) * 0.12).to(DEV)
+    alpha[5, 600:] = 0
+    thr = 0.95
+    cur, rem, fire_idx, n_fire, n_label = ops.cif_scan(alpha, thr)
+    out = ops.cif_gather(hidden.contiguous(), cur, rem, fire_idx, n_fire, int(n_fire.max()))
+    total = (alpha[:, :, None] * hidden).sum(1)
+    nf = n_fire.cpu().numpy()
+    fired = torch.stack([out[b, :nf[b]].sum(0) for b in range(B)])
+    # weight still in the accumulator after the last fire, spread over the frames since that fire
+    last = torch.tensor([int(fire_idx[b, nf[b] - 1]) if nf[b] else -1 for b in range(B)], device=DEV)
+    tail = torch.zeros(B, H, device=DEV)
+    for b in range(B):
+        lf = int(last[b])
+        w = alpha[b].clone()
+        if lf >= 0:
+            w[:lf] = 0
+            w[lf] = rem[b, lf]
+        tail[b] = (w[:, None] * hidden[b]).sum(0)
+    np.testing.assert_allclose((fired + tail).cpu().numpy(), total.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    s = alpha.sum(1).cpu().numpy()
+    assert np.all(nf <= np.floor(s / thr) + 1) and np.all(nf >= np.floor(s) - 1)
+
+
+def test_attention_full_size_rows_are_convex_combinations():
+    g = torch.Generator().manual_seed(2)
+    h = 4
+    q = (torch.randn(B, h, T, 64, generator=g) * 0.5 * LOG2E).to(DEV).bfloat16()
+    k = torch.randn(B, h, T, 64, generator=g).to(DEV).bfloat16()
+    klen = torch.randint(T // 2, T + 1, (B,), generator=g).to(DEV).int()
+    # V = const per (b, h, d): every output row must reproduce it exactly (probabilities sum to 1, masked keys weigh nothing)
+    c = torch.randn(B, h, 1, 64, generator=g).to(DEV).bfloat16()
+    ctx, lse = ops.attention_fwd(q, k, c.expand(B, h, T, 64).contiguous(), klen, False, need_lse=True)
+    want = c.permute(0, 2, 1, 3).reshape(B, 1, h * 64).float().expand(B, T, h * 64)
+    np.testing.assert_allclose(ctx.float().cpu().numpy(), want.cpu().numpy(), rtol=1.2e-2, atol=1e-3)
+    # keys at or beyond k_len must not matter: poison them
+    k2 = k.clone()
+    v = torch.randn(B, h, T, 64, generator=g).to(DEV).bfloat16()
+    v2 = v.clone()
+    for b in range(B):
+        k2[b, :, int(klen[b]):] = 77.0
+        v2[b, :, int(klen[b]):] = -55.0
+    a, _ = ops.attention_fwd(q, k, v, klen, False)
+    b_, _ = ops.attention_fwd(q, k2, v2, klen, False)
+    assert torch.equal(a, b_)
+
+
+def test_model_full_size_utterances_do_not_interact():
+    """S1 CTC_Transformer forward: each utterance's logits depend only on that utterance (its frames up to its length, its
+    targets) - not on its neighbours in the batch, and not on what sits in its padding."""
+    import bench
+    model = bench.build_model(asr_amd, torch.device(DEV), 0.0, False)
+    asr_amd.set_precision("bf16")
+    x, lens, tg = bench.make_batch(torch.device(DEV), 3)
+    lens = lens.clone()
+    lens[1], lens[2] = 700, 333
+    with torch.no_grad():
+        l0, ctc0, (dec0, _) = model(x, lens, tg)
+        x2 = x.clone()
+        x2[1, 700:] = 1e3            # garbage in the padding of utterance 1
+        x2[5] = torch.randn_like(x2[5]) * 3   # a different neighbour
+        _, ctc1, (dec1, _) = model(x2, lens, tg)
+    for b in (0, 1, 2, 9):
+        n = int(lens[b])
+        assert torch.equal(ctc0[b, :n], ctc1[b, :n]) and torch.equal(dec0[b], dec1[b])
+    assert not torch.equal(ctc0[5], ctc1[5])

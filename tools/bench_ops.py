@@ -98,7 +98,7 @@ def bench_gemm():
 
 
 def bench_bwdgemm():
-    for (M, N, K) in [(32000, 256, 2048), (32000, 2048, 256), (32000, 768, 256), (32000, 256, 256)]:
+    for (M, N, K) in [(32000, 256, 2048), (32000, 2048, 256), (32000, 768, 256), (32000, 256, 256), (1632, 256, 256), (1632, 2048, 256), (1632, 256, 2048)]:
         dy = torch.randn(M, N, device=DEV).bfloat16()
         x = torch.randn(M, K, device=DEV).bfloat16()
         out = torch.zeros(N, K, device=DEV)
