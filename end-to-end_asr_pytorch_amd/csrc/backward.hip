@@ -312,7 +312,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, in
 }
 
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LNB_RPW = 4;             // rows per wave handled TOGETHER: all loads issued up front, reductions interleaved
+#ifndef LNB_RPW_
+#define LNB_RPW_ 2
+#endif
+constexpr int LNB_RPW = LNB_RPW_;             // rows per wave handled TOGETHER: all loads issued up front, reductions interleaved
 constexpr int LNB_ROWS = 4 * LNB_RPW;  // rows per workgroup
 
 // MAXJ = float4 column groups per lane: 1 for D <= 256 (the model dimension of every shipped config), 4 up to D = 1024.
@@ -560,7 +563,7 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 256;
+    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 512;
     if (blocks > max_blocks) blocks = max_blocks;
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,

@@ -39,30 +39,12 @@ constexpr float LN2 = 0.6931471805599453f;
 // the extended labels' log-probs (stored base-2: (x - lse) * log2(e)) into the compact table row (stride Sp = 2U+2).
 constexpr int LSE_UNR = 6;  // float4 per thread held in registers: V <= 256*4*6 = 6144 takes the two-pass register path
 
-__global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ logits, int64_t ldl,
-                                                             const int32_t* __restrict__ in_len, const int64_t* __restrict__ targets,
-                                                             int L, int V, int Umax, int blank,
-                                                             float* __restrict__ lse_out, float* __restrict__ lp_ext, int chunk, int W) {
-    // W == 0: one launch over all rows (blockIdx.x = b*L + t).  W > 0: launch `chunk` of the outside-in pipeline: blockIdx.x =
-    // b*2W + i covers, for utterance b, forward frame t = chunk*W + i (i < W, t <= mid) or backward frame
-    // t = Tb-1 - (chunk*W + i - W) (i >= W, t > mid) - the rows the two recursion wavefronts consume in their chunk `chunk`.
-    int b, t;
-    if (W == 0) {
-        b = blockIdx.x / L;
-        t = blockIdx.x - b * L;
-        if (t >= in_len[b]) return;
-    } else {
-        b = blockIdx.x / (2 * W);
-        const int i = blockIdx.x - b * 2 * W;
-        const int Tb = min(in_len[b], L), mid = Tb >> 1;
-        if (i < W) {
-            t = chunk * W + i;
-            if (t > mid || t >= Tb) return;
-        } else {
-            t = Tb - 1 - (chunk * W + i - W);
-            if (t <= mid) return;
-        }
-    }
+constexpr int CTC_RPB = 4;   // table rows per workgroup in the flag-pipelined launch (one store drain + one counter add for all of them)
+
+// one table row (b, t): log-sum-exp over the vocabulary, then the gather of the extended labels' base-2 log-probs
+__device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets, int L, int V,
+                                            int Umax, int blank, float* __restrict__ lse_out, float* __restrict__ lp_ext, int b, int t,
+                                            bool publish) {
     const int row = b * L + t;
     const float* x = logits + (int64_t)row * ldl;
     const int tid = threadIdx.x;
@@ -121,17 +103,69 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
     const float lse = lse_sh;
     // all Umax label slots are gathered (padding slots read label 0); the recursion masks the states beyond 2*tgt_len+1
     const int Sp = ctc_row_stride(Umax), Sb = 2 * Umax + 1;
-    for (int sidx = tid; sidx < Sp; sidx += 256) {
+    auto gather = [&](int sidx) {
         float v = -INFINITY;
         if (sidx < Sb) {
             int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
             lab = min(max(lab, 0), V - 1);
             v = (x[lab] - lse) * LOG2E;
         }
-        lp_ext[(int64_t)row * Sp + sidx] = v;
+        return v;
+    };
+    if (publish) {   // published rows: one 8-byte write-through store per (blank, label) state pair
+        for (int pr = tid; pr < Sp / 2; pr += 256) {
+            const f32x2 v2 = {gather(2 * pr), gather(2 * pr + 1)};
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(lp_ext + (int64_t)row * Sp + 2 * pr),
+                               __builtin_bit_cast(unsigned long long, v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        for (int sidx = tid; sidx < Sp; sidx += 256) lp_ext[(int64_t)row * Sp + sidx] = gather(sidx);
     }
 }
 
+__global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                             const int32_t* __restrict__ in_len, const int64_t* __restrict__ targets,
+                                                             int L, int V, int Umax, int blank,
+                                                             float* __restrict__ lse_out, float* __restrict__ lp_ext, int chunk, int W,
+                                                             int* __restrict__ arrivals, int64_t arr_stride, int nchunks, int Bn) {
+    // arrivals == NULL: one launch over all rows, blockIdx.x = b*L + t.
+    // arrivals != NULL: the flag-pipelined form (asr_ctc_loss_fwd): ONE launch covers every chunk, chunk-major - chunk c holds, for
+    // every utterance, the forward frames [cW, (c+1)W) up to mid and the backward frames Tb-1-k, k in [cW, (c+1)W), above mid,
+    // i.e. what the two recursion wavefronts consume in their c-th piece.  A workgroup takes CTC_RPB consecutive rows of one
+    // (utterance, direction, chunk), stores them write-through (sc1), drains its stores, and one lane adds the row count to
+    // that arrival counter at agent scope (MI355X_MICROARCH.md § visibility).
+    if (!arrivals) {
+        const int b = blockIdx.x / L, t = blockIdx.x - b * L;
+        if (t >= in_len[b]) return;
+        ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, false);
+        return;
+    }
+    const int G = W / CTC_RPB;                       // row groups per (utterance, direction, chunk); W is a multiple of CTC_RPB
+    int bid = blockIdx.x;
+    chunk = bid / (Bn * 2 * G);
+    bid -= chunk * (Bn * 2 * G);
+    const int b = bid / (2 * G), gi = bid - b * 2 * G;
+    const int dirc = gi / G, g0 = (gi - dirc * G) * CTC_RPB;
+    const int Tb = min(in_len[b], L), mid = Tb >> 1;
+    int count = 0;
+    for (int r = 0; r < CTC_RPB; ++r) {
+        const int k = chunk * W + g0 + r;
+        const int t = dirc == 0 ? k : Tb - 1 - k;
+        const bool valid = dirc == 0 ? (t <= mid && t < Tb) : (t > mid);
+        if (!valid) break;                           // frames only run out at the end of a direction
+        ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, true);
+        ++count;
+    }
+    if (count == 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(arrivals + (int64_t)b * arr_stride + dirc * nchunks + chunk, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef CTC_PF1
+#define CTC_PF1 16    // table rows the NP = 1 recursion keeps in flight
+#endif
 constexpr float NEG_BIG = -1.0e30f;   // max(m, NEG_BIG) keeps exp2(x - m) = 0 and m + log2(0) = -inf when every input is -inf
 // base-2 log-sum-exp with the largest term's exp2(0) = 1 taken for granted (0 when every input is -inf): one quarter-rate
 // transcendental fewer per call on the recursion's dependent chain (v_max3 / v_med3 / v_min3 are full rate)
@@ -165,7 +199,7 @@ template <int NP, bool DIRB, bool OCC>
 __device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* __restrict__ al, int t_first, int nsteps, float (&e)[NP],
                                           float (&o)[NP], const float (&skip_add)[NP], const float (&madd)[2 * NP], float nll2,
                                           int special_t, int special_row) {
-    constexpr int PF = NP <= 2 ? 8 : (NP == 4 ? 4 : 2);
+    constexpr int PF = NP == 1 ? CTC_PF1 : (NP == 2 ? 8 : (NP == 4 ? 4 : 2));
     constexpr int Sp = 128 * NP;
     if (nsteps <= 0) return;
     auto row_of = [&](int t) { return t == special_t ? special_row : t; };
@@ -245,8 +279,8 @@ __device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* _
 // Meet-in-the-middle CTC recursion: one workgroup (2 wavefronts) per utterance.  Wave 0 runs alpha forward, wave 1 runs beta
 // backward, so the T-long dependent chain is cut in half for the loss (PHASE 0: they meet at mid = T/2 and
 // p(l|x) = sum_s alpha_mid(s) beta_mid(s) / y_mid(s)) and again for the gradient (PHASE 1: each wave continues over the other
-// half, turning the stored rows of the opposite direction into occupancies in place).  Workspace rows per utterance: L + 1
-// (rows 0..mid hold alpha, mid+1..T-1 hold beta, row L holds beta_mid).
+// half, turning the stored rows of the opposite direction into occupancies in place).  Workspace rows per utterance: L + 2
+// (rows 0..mid hold alpha, mid+1..T-1 hold beta, row L holds beta_mid, row L+1 the flag-pipelined forward's arrival counters).
 // PHASE 0 can be launched in `nchunk` pieces (chunk c advances each wavefront by W frames, resuming from the row the previous
 // launch stored; the last one also takes beta onto row mid and computes the loss), so that the log-sum-exp pass over the next
 // frames (ctc_lse_gather_kernel, same chunk geometry) runs on another stream while this latency-bound chain works on the
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
         madd[2 * p + 1] = (j < U) ? 0.f : -INFINITY;                                  // label state 2j+1 for j < U
     }
     const float* lp = lp_ext + (int64_t)b * L * Sp + 2 * j0;
-    float* al = alpha + (int64_t)b * (L + 1) * Sp + 2 * j0;
+    float* al = alpha + (int64_t)b * (L + 2) * Sp + 2 * j0;
     auto load_row = [&](const float* base, int64_t row, float (&ev)[NP], float (&ov)[NP]) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -408,6 +442,160 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
     }
 }
 
+// Flag-pipelined forward recursion: the same two half-length chains as ctc_mitm_kernel<NP, 0>, launched ONCE on a second stream
+// beside the (single, chunk-major) log-sum-exp launch.  Each wavefront waits, chunk by chunk, for the arrival counter of the W
+// table rows it is about to consume (relaxed agent-scope poll, bounded), issues one agent-scope acquire so that its CU's L1 holds
+// no stale line, and runs the chain over those rows - so the HBM-bound pass and the latency-bound recursion overlap inside one
+// pair of launches, with no event hand-offs (7-14 us each on this stack) between chunks.
+__device__ __forceinline__ bool ctc_wait_rows(const int* ctr, int need) {
+    if (need <= 0) return true;
+    bool ok = false;
+    for (int spin = 0; spin < (1 << 21); ++spin) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return ok;
+}
+
+template <int NP>
+__global__ __launch_bounds__(128) void ctc_mitm_flag_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
+                                                            const int64_t* __restrict__ targets, int32_t* __restrict__ tgt_len, int L,
+                                                            int Umax, float* __restrict__ alpha, float* __restrict__ nll, int W,
+                                                            int nchunks, const int* __restrict__ arrivals, int64_t arr_stride) {
+    constexpr int Sp = 128 * NP;
+    __shared__ float xch[64][2 * NP];
+    __shared__ int failed;
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = lane * NP;
+    const int64_t* tg = targets + (int64_t)b * Umax;
+    int n = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) n += (j0 + p < Umax && tg[j0 + p] != 0) ? 1 : 0;
+    const int U = (int)wave_sum((float)n);
+    if (threadIdx.x == 0) { tgt_len[b] = U; failed = 0; }
+    const int Tb = min(in_len[b], L);
+    if (Tb <= 0) {
+        if (threadIdx.x == 0) nll[b] = (U == 0) ? 0.f : INFINITY;
+        return;
+    }
+    __syncthreads();
+    const int mid = Tb >> 1;
+    float skip_f[NP], skip_b[NP], madd[2 * NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int j = j0 + p;
+        skip_f[p] = ((j >= 1 && j < U) && (tg[j] != tg[j - 1])) ? 0.f : -INFINITY;
+        skip_b[p] = ((j + 1 < U) && (tg[j] != tg[j + 1])) ? 0.f : -INFINITY;
+        madd[2 * p] = (j <= U) ? 0.f : -INFINITY;
+        madd[2 * p + 1] = (j < U) ? 0.f : -INFINITY;
+    }
+    const float* lp = lp_ext + (int64_t)b * L * Sp + 2 * j0;
+    float* al = alpha + (int64_t)b * (L + 2) * Sp + 2 * j0;
+    const int* arr_f = arrivals + (int64_t)b * arr_stride;      // forward-frame chunks
+    const int* arr_b = arr_f + nchunks;                        // backward-frame chunks
+    auto load_row = [&](const float* base, int64_t row, float (&ev)[NP], float (&ov)[NP]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const f32x2 v = *reinterpret_cast<const f32x2*>(base + row * Sp + 2 * q);
+            ev[q] = v[0];
+            ov[q] = v[1];
+        }
+    };
+    auto load_lp = [&](int64_t row, float (&ev)[NP], float (&ov)[NP]) {
+        load_row(lp, row, ev, ov);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { ev[q] += madd[2 * q]; ov[q] += madd[2 * q + 1]; }
+    };
+    auto store_row = [&](int64_t row, const float (&ev)[NP], const float (&ov)[NP]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<f32x2*>(al + row * Sp + 2 * q) = f32x2{ev[q], ov[q]};
+    };
+    float e[NP], o[NP], le[NP], lo[NP];
+    bool ok = true;
+    if (wave == 0) {            // alpha: frames 0 .. mid, chunk c = frames [cW, (c+1)W)
+        for (int c = 0; c * W <= mid && ok; ++c) {
+            const int k0 = c * W, rows = min(k0 + W, mid + 1) - k0;
+            ok = ctc_wait_rows(arr_f + c, rows);
+            if (!ok) break;
+            if (c == 0) {
+                load_lp(0, le, lo);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    e[p] = (j0 + p == 0) ? le[p] : -INFINITY;
+                    o[p] = (j0 + p == 0) ? lo[p] : -INFINITY;
+                }
+                store_row(0, e, o);
+                ctc_chain<NP, false, false>(lp, al, 1, rows - 1, e, o, skip_f, madd, 0.f, -1, 0);
+            } else {
+                ctc_chain<NP, false, false>(lp, al, k0, rows, e, o, skip_f, madd, 0.f, -1, 0);
+            }
+        }
+    } else {                    // beta: frames Tb-1 .. mid+1 in chunks (step k <-> frame Tb-1-k), then onto mid (row L)
+        const int kmax = Tb - 2 - mid;
+        for (int c = 0; c * W <= kmax && ok; ++c) {
+            const int k0 = c * W, rows = min(k0 + W, kmax + 1) - k0;
+            ok = ctc_wait_rows(arr_b + c, rows);
+            if (!ok) break;
+            if (c == 0) {
+                load_lp(Tb - 1, le, lo);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    e[p] = (j0 + p == U) ? le[p] : -INFINITY;
+                    o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
+                }
+                store_row(Tb - 1, e, o);
+                ctc_chain<NP, true, false>(lp, al, Tb - 2, rows - 1, e, o, skip_b, madd, 0.f, -1, 0);
+            } else {
+                ctc_chain<NP, true, false>(lp, al, Tb - 1 - k0, rows, e, o, skip_b, madd, 0.f, -1, 0);
+            }
+        }
+        if (ok) {               // the meeting frame's row belongs to forward chunk mid / W
+            const int cm = mid / W;
+            ok = ctc_wait_rows(arr_f + cm, min(cm * W + W, mid + 1) - cm * W);
+        }
+        if (ok) {
+            if (kmax < 0) {
+                load_lp(mid, le, lo);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    e[p] = (j0 + p == U) ? le[p] : -INFINITY;
+                    o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
+                }
+                store_row(L, e, o);
+            } else {
+                ctc_chain<NP, true, false>(lp, al, mid, 1, e, o, skip_b, madd, 0.f, mid, L);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { xch[lane][2 * p] = e[p]; xch[lane][2 * p + 1] = o[p]; }
+        }
+    }
+    if (!ok && lane == 0) failed = 1;
+    __syncthreads();
+    if (failed) {               // a producer never arrived (cannot happen unless the pass faulted): fail loudly, never hang
+        if (threadIdx.x == 0) nll[b] = __builtin_nanf("");
+        return;
+    }
+    if (wave == 0) {
+        load_lp(mid, le, lo);
+        float v[2 * NP], m = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            v[2 * p] = (le[p] == -INFINITY) ? -INFINITY : e[p] + xch[lane][2 * p] - le[p];
+            v[2 * p + 1] = (lo[p] == -INFINITY) ? -INFINITY : o[p] + xch[lane][2 * p + 1] - lo[p];
+            m = fmaxf(m, fmaxf(v[2 * p], v[2 * p + 1]));
+        }
+        m = wave_max(m);
+        const float ms = fmaxf(m, NEG_BIG);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2 * NP; ++q) sum += __builtin_amdgcn_exp2f(v[q] - ms);
+        sum = wave_sum(sum);
+        if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
+    }
+}
+
 __global__ void ctc_mean_kernel(const float* __restrict__ nll, const int32_t* __restrict__ tgt_len, int B, float* __restrict__ loss) {
     float s = 0.f;
     for (int b = threadIdx.x; b < B; b += 64) s += nll[b] / (float)max(tgt_len[b], 1);
@@ -445,7 +633,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         const float* x = logits + row * ldl;
         for (int sidx = tid; sidx < Sb; sidx += 256) {
             const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
-            atomicAdd(&corr[lab], occ[((int64_t)b * (L + 1) + t) * Sfull + sidx]);
+            atomicAdd(&corr[lab], occ[((int64_t)b * (L + 2) + t) * Sfull + sidx]);
         }
         __syncthreads();
         const float l = lse[row];
@@ -520,18 +708,22 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     hipStream_t s = static_cast<hipStream_t>(stream), s2 = static_cast<hipStream_t>(aux_stream);
     if (!s2 || s2 == s || n_chunks <= 1 || L < 64) {   // single stream: one pass over the logits, then the two half-length chains
         hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
-                           lp_ext, 0, 0);
+                           lp_ext, 0, 0, nullptr, 0, 0, B);
         launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, 0, L, 1);
         ASR_LAUNCH_CHECK("ctc_loss_fwd");
         return 0;
     }
-    // pipelined: the frames are cut outside-in into n_chunks pieces (chunk c = the next W frames of BOTH wavefronts); the
-    // HBM-bound log-sum-exp pass of chunk c+1 (stream) overlaps the latency-bound recursion over chunk c (aux_stream)
+    // flag-pipelined: ONE chunk-major log-sum-exp launch on `stream` publishes table rows chunk by chunk (write-through stores +
+    // arrival counters in row L+1 of the alpha workspace), ONE recursion launch on `aux_stream` consumes them as they arrive
     static thread_local PipeEvents ev;
     ASR_REQUIRE(ev.ok(), ASR_ERR_UNSUPPORTED, "ctc_fwd: cannot create events");
     const int steps = L / 2 + 1;                           // alpha takes mid + 1 <= L/2 + 1 steps, beta at most as many
-    const int W = (steps + n_chunks - 1) / n_chunks;
+    const int W = ((steps + n_chunks - 1) / n_chunks + CTC_RPB - 1) / CTC_RPB * CTC_RPB;
     const int nc = (steps + W - 1) / W;
+    const int Sp = ctc_row_stride(Umax);
+    ASR_REQUIRE(2 * nc <= Sp, ASR_ERR_UNSUPPORTED, "ctc_fwd: too many chunks (%d) for the counter row", nc);
+    int* arrivals = reinterpret_cast<int*>(alpha + (int64_t)(L + 1) * Sp);
+    const int64_t arr_stride = (int64_t)(L + 2) * Sp;
 #define HIP_OK(call)                                                          \
     do {                                                                      \
         hipError_t e__ = (call);                                              \
@@ -540,15 +732,21 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
             return (int)e__;                                                  \
         }                                                                     \
     } while (0)
-    HIP_OK(hipEventRecord(ev.main_done, s));               // fork: the aux stream starts behind whatever produced the logits
+    HIP_OK(hipMemset2DAsync(arrivals, (size_t)arr_stride * sizeof(float), 0, (size_t)2 * nc * sizeof(int), B, s));
+    HIP_OK(hipEventRecord(ev.main_done, s));               // fork: the recursion starts behind the logits' producer and the memset
     HIP_OK(hipStreamWaitEvent(s2, ev.main_done, 0));
-    for (int c = 0; c < nc; ++c) {
-        hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * 2 * W), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
-                           lp_ext, c, W);
-        HIP_OK(hipEventRecord(ev.main_done, s));
-        HIP_OK(hipStreamWaitEvent(s2, ev.main_done, 0));
-        launch_recursion<0>(s2, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, c, W, c == nc - 1);
+#define LAUNCH_FLAG(NP_)                                                                                                         \
+    hipLaunchKernelGGL((ctc_mitm_flag_kernel<NP_>), dim3(B), dim3(128), 0, s2, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, \
+                       nll, W, nc, arrivals, arr_stride)
+    switch (ctc_np(Umax)) {
+        case 1: LAUNCH_FLAG(1); break;
+        case 2: LAUNCH_FLAG(2); break;
+        case 4: LAUNCH_FLAG(4); break;
+        default: LAUNCH_FLAG(8); break;
     }
+#undef LAUNCH_FLAG
+    hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(nc * B * 2 * (W / CTC_RPB)), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax,
+                       blank, lse, lp_ext, 0, W, arrivals, arr_stride, nc, B);
     HIP_OK(hipEventRecord(ev.aux_done, s2));               // join
     HIP_OK(hipStreamWaitEvent(s, ev.aux_done, 0));
 #undef HIP_OK

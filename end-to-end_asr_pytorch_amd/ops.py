@@ -255,7 +255,7 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None):
     dev = logits.device
     st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
     st.lp_ext = torch.empty((B, L, S), device=dev, dtype=torch.float32)
-    st.alpha = torch.empty((B, L + 1, S), device=dev, dtype=torch.float32)   # +1 row: beta at the meeting point
+    st.alpha = torch.empty((B, L + 2, S), device=dev, dtype=torch.float32)   # +2 rows: beta at the meeting point, arrival counters
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
     nck = CTC_CHUNKS if n_chunks is None else n_chunks

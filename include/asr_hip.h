@@ -182,13 +182,14 @@ int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y,
  * CTC loss (loss.py:41-43 / ctcModel/loss.py:9-11: F.log_softmax(dim=-1) -> F.ctc_loss(blank=V-1)).
  * logits f32 [B,L,V] with row stride ldl (elements) and batch stride L*ldl; in_len int32 [B]; targets int64
  * [B,Umax] zero-padded; target length = number of non-zero ids per row (loss.py:40).
- * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L+1,S] with
+ * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L+2,S] with
  * S = asr_ctc_workspace_stride(Umax) (>= 2*Umax+1; one 512-byte wave store per row and 64 labels).
  * Outputs: nll f32 [B] (inf for infeasible rows, zero_infinity=False), tgt_len int32 [B].
- * aux_stream / n_chunks (forward only): with a second stream and n_chunks > 1 the frames are cut outside-in into n_chunks pieces
- * and the HBM-bound log-sum-exp pass of piece c+1 (on `stream`) overlaps the latency-bound alpha/beta recursion over piece c
- * (on `aux_stream`); the call forks from and joins back into `stream` with two cached hipEvents (the only state the library
- * keeps besides its code objects), so the caller sees ordinary stream semantics.  NULL / <= 1: everything on `stream`.
+ * aux_stream / n_chunks (forward only): with a second stream and n_chunks > 1 the frames are cut outside-in into n_chunks pieces;
+ * ONE chunk-major log-sum-exp launch on `stream` publishes the table rows (write-through stores + per-chunk arrival counters)
+ * and ONE recursion launch on `aux_stream` consumes each piece as it arrives, so the HBM-bound pass and the latency-bound
+ * alpha/beta recursion overlap.  The call forks from and joins back into `stream` with two cached hipEvents (the only state the
+ * library keeps besides its code objects), so the caller sees ordinary stream semantics.  NULL / <= 1: everything on `stream`.
  */
 int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,

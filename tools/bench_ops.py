@@ -40,7 +40,7 @@ def bench_ctc():
         ops.ctc_loss_bwd(st, gout)
     both = timeit(fb)
     nb = B * L * V * 4
-    for nck in (1, 2, 4, 6, 8, 12):
+    for nck in (1, 4, 8, 12, 16, 24, 32):
         t = timeit(lambda: ops.ctc_loss_fwd(logits, il, tg, n_chunks=nck))
         print(json.dumps(dict(op="ctc_loss_fwd", n_chunks=nck, ms=round(t, 4), GBps=round(nb / t / 1e6, 1), frac_hbm_peak=round(nb / t / 1e6 / 8000, 4))))
     print(json.dumps(dict(op="ctc_loss", shape=[B, L, U, V], fwd_ms=round(fwd, 4), fwd_bwd_ms=round(both, 4),
