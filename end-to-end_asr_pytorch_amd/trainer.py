@@ -138,7 +138,7 @@ class Trainer:
     """model: asr_amd.CTC_Transformer (or Transformer-family module that records a tape).  k, warmup: Noam schedule
     (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
 
-    def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=4,
+    def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=8,
                  process_group=None, lambda_qua=0.001, overlap_ctc=None):
         self.model = model
         # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); ASR_AMD_OVERLAP_CTC=0 serialises it
