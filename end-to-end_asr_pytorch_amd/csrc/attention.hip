@@ -7,9 +7,9 @@
 //     running rescale of O is a per-lane scalar.
 //   * P^T feeds the PV MFMA directly from those registers as the B operand (O^T = V^T.P^T); the k-order
 //     permutation this implies is absorbed by how the A operand (V^T) is read from LDS.
-//   * K tile [64 keys][64 d] and V^T tile [64 d][64 keys] live in LDS, XOR-swizzled so the ds_read_b128 (K) and
-//     ds_read_b64 (V^T) fragment reads are bank-conflict free; V is transposed on the way in (4x4 register
-//     transpose + ds_write_b64); global loads for tile t+1 are issued before the MFMAs of tile t.
+//   * K and V tiles [64 keys][64 d] are copied row-major into a double-buffered, XOR-swizzled LDS image by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers); K fragments are ds_read_b128 rows, V^T fragments come from the same
+//     kind of tile through ds_read_b64_tr_b16; the DMA of tile t+1 is in flight during the MFMAs of tile t.
 //   * masks come from lengths (key j masked iff j >= k_len[b] or causal && j > i); no mask tensor is read.
 //   * scores are BASE-2 logits: q arrives pre-multiplied by log2(e)/sqrt(d_k) (folded into the Q projection's epilogue), so a
 //     probability is one v_exp_f32 of an accumulator register - the running maximum is subtracted by the MFMA itself (it is the

@@ -19,53 +19,6 @@
 
 namespace {
 
-__device__ __forceinline__ int swz(int row, int chunk) { return (chunk ^ ((row >> 1) & 7)) << 4; }
-
-// stage a [64 rows][64 bf16] tile row-major (16-byte chunks, swizzled).  src row r at src + r*ld (elements).
-template <int NTHR>
-__device__ __forceinline__ void stage_rows(unsigned char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int tid) {
-#pragma unroll
-    for (int i = 0; i < 512 / NTHR; ++i) {
-        const int id = tid + NTHR * i;
-        const int row = id >> 3, c = id & 7;
-        const u32x4 v = (row0 + row < nrows) ? *reinterpret_cast<const u32x4*>(src + (int64_t)(row0 + row) * ld + c * 8) : u32x4{0, 0, 0, 0};
-        *reinterpret_cast<u32x4*>(dst + row * 128 + swz(row, c)) = v;
-    }
-}
-// stage the TRANSPOSE of a [64 rows][64 cols] tile: dst[col][row] (8-byte pieces of 4 rows, swizzled like the fwd V^T)
-template <int NTHR>
-__device__ __forceinline__ void stage_transposed(unsigned char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int tid) {
-#pragma unroll
-    for (int i = 0; i < 256 / NTHR; ++i) {
-        const int id = tid + NTHR * i;
-        const int cg = id & 15, rg = id >> 4;  // 4-col group, 4-row group
-        u32x2 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = row0 + 4 * rg + k;
-            v[k] = (r < nrows) ? *reinterpret_cast<const u32x2*>(src + (int64_t)r * ld + 4 * cg) : u32x2{0, 0};
-        }
-        u32x2 ct[4];
-        transpose4x4_bf16(v, ct);
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            const int row = 4 * cg + dd;
-            const int off = row * 128 + swz(row, rg >> 1) + (((rg & 1) ^ ((row >> 4) & 1)) << 3);
-            *reinterpret_cast<u32x2*>(dst + off) = ct[dd];
-        }
-    }
-}
-// A-operand fragment (32 rows x 16 k) of a row-major tile: lane (r, hh) reads chunk 2s+hh of row `row`
-__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* t, int row, int s, int hh) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(t + row * 128 + swz(row, 2 * s + hh)));
-}
-// A-operand fragment of a transposed tile for the "accumulator as B operand" k-order: k-block hf (32), step s2
-__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* t, int row, int hf, int s2, int hh) {
-    const int sub = (hh ^ ((row >> 4) & 1)) << 3;
-    const u32x2 v0 = *reinterpret_cast<const u32x2*>(t + row * 128 + swz(row, hf * 4 + 2 * s2) + sub);
-    const u32x2 v1 = *reinterpret_cast<const u32x2*>(t + row * 128 + swz(row, hf * 4 + 2 * s2 + 1) + sub);
-    return __builtin_bit_cast(bf16x8, u32x4{v0[0], v0[1], v1[0], v1[1]});
-}
 __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
     bf16x8 r;
 #pragma unroll
