@@ -30,8 +30,8 @@ _dr = Dropout
 # every prototype in the header is exported by the .so and listed here.
 SIGNATURES = {
     "asr_gemm_nt": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u],
-    "asr_gemm_nt_ex": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _i64, _vp, _i64],
-    "asr_gemm_nn": [_vp, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp, _i64],
+    "asr_gemm_nt_ex": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _i64, _vp, _i64, _vp, _i64],
+    "asr_gemm_nn": [_vp, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp, _i64, _i],
     "asr_attention_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr],
     "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _dr],
     "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr],

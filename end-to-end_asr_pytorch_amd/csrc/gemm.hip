@@ -65,6 +65,11 @@ struct EpiDense {
     int64_t ld_mask;
     bool vec_ok;              // host-checked: every pointer / leading dimension allows 4-wide vector access
     bool wide_ok;             // ... and C rows allow 16-byte stores (the LDS-transposed full-cache-line epilogue)
+    // ReLU sign bits (wide path only): bit (n & 7) of byte [m * ld_bits + n / 8] = output (m, n) > 0.  The FFN's first GEMM
+    // writes them next to its bf16 output; the hidden gradient's GEMM then masks from 1 bit instead of re-reading 16
+    unsigned char* bits_out;
+    const unsigned char* bits_in;
+    int64_t ld_bits;
 
     // fast path (kernel-uniform): the tile lies fully inside N and everything is vector-aligned -> no per-element logic
     struct Row { unsigned char* c; const float* add; const bf16_t* mask; };
@@ -98,6 +103,10 @@ struct EpiDense {
     __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
     __device__ __forceinline__ bool has_add() const { return addend != nullptr; }
     __device__ __forceinline__ bool has_mask() const { return relu_mask != nullptr; }
+    __device__ __forceinline__ bool has_bits_in() const { return bits_in != nullptr; }
+    __device__ __forceinline__ bool has_bits_out() const { return bits_out != nullptr; }
+    __device__ __forceinline__ unsigned get_byte(int m, int n) const { return bits_in[(int64_t)m * ld_bits + (n >> 3)]; }   // columns n..n+7, n % 8 == 0
+    __device__ __forceinline__ void put_bits(int m, int n, unsigned byte) const { bits_out[(int64_t)m * ld_bits + (n >> 3)] = (unsigned char)byte; }
     __device__ __forceinline__ bool relu() const { return flags & ASR_GEMM_RELU; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
     __device__ __forceinline__ f32x4 get_add(int m, int n) const { return *reinterpret_cast<const f32x4*>(addend + (int64_t)m * ld_add + n); }
@@ -185,6 +194,8 @@ template <unsigned MODE> struct EpiDenseS : EpiDense {
     __device__ __forceinline__ bool relu() const { return MODE & 2u; }
     __device__ __forceinline__ bool has_add() const { return MODE & 4u; }
     __device__ __forceinline__ bool has_mask() const { return MODE & 8u; }
+    __device__ __forceinline__ bool has_bits_out() const { return MODE & 32u; }
+    __device__ __forceinline__ bool has_bits_in() const { return MODE & 64u; }
     __device__ __forceinline__ int elem_size() const { return (MODE & 16u) ? 2 : 4; }
     __device__ __forceinline__ unsigned char* row_ptr(int m, int nw) const {
         return reinterpret_cast<unsigned char*>(C) + ((int64_t)m * ldc + nw) * ((MODE & 16u) ? 2 : 4);
@@ -192,7 +203,7 @@ template <unsigned MODE> struct EpiDenseS : EpiDense {
 };
 inline unsigned dense_mode(const EpiDense& e) {
     return (e.bias ? 1u : 0u) | ((e.flags & ASR_GEMM_RELU) ? 2u : 0u) | (e.addend ? 4u : 0u) | (e.relu_mask ? 8u : 0u) |
-           (e.c_dtype == ASR_BF16 ? 16u : 0u);
+           (e.c_dtype == ASR_BF16 ? 16u : 0u) | (e.bits_out ? 32u : 0u) | (e.bits_in ? 64u : 0u);
 }
 template <unsigned MODE> inline EpiDenseS<MODE> dense_as(const EpiDense& e) {
     EpiDenseS<MODE> r;
@@ -224,6 +235,10 @@ template <typename CT> struct EpiHeads {
     __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
     __device__ __forceinline__ bool has_add() const { return false; }
     __device__ __forceinline__ bool has_mask() const { return false; }
+    __device__ __forceinline__ bool has_bits_in() const { return false; }
+    __device__ __forceinline__ bool has_bits_out() const { return false; }
+    __device__ __forceinline__ unsigned get_byte(int, int) const { return 0u; }
+    __device__ __forceinline__ void put_bits(int, int, unsigned) const {}
     __device__ __forceinline__ bool relu() const { return false; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
     __device__ __forceinline__ f32x4 get_add(int, int) const { return f32x4{0, 0, 0, 0}; }
@@ -301,6 +316,14 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mk[ii][j] = epi.get_mask(min(mw + (pass * IB + ii) * 16 + r16, epi.M - 1), ncol + 16 * j);
             }
+            // sign-bit mask (bf16 outputs): one byte = the 8 consecutive columns a lane stores in the read-back below; the byte
+            // loads go out now, ahead of the LDS round trip
+            unsigned bt[2 * IB];
+            if (epi.has_bits_in()) {
+#pragma unroll
+                for (int it = 0; it < 2 * IB; ++it)
+                    bt[it] = epi.get_byte(min(mw + pass * IB * 16 + it * 8 + (lane >> 3), epi.M - 1), nw + (lane & 7) * 8);
+            }
 #pragma unroll
             for (int ii = 0; ii < IB; ++ii) {
                 const int i = pass * IB + ii, rl = ii * 16 + r16;
@@ -331,8 +354,26 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
 #pragma unroll
                 for (int it = 0; it < 2 * IB; ++it) {
                     const int rl = it * 8 + (lane >> 3), ch = lane & 7, m = mw + pass * IB * 16 + rl;
-                    const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 128 + ((ch ^ (rl & 7)) << 4));
-                    if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+                    u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 128 + ((ch ^ (rl & 7)) << 4));
+                    if (epi.has_bits_in()) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const unsigned lo = (bt[it] >> (2 * x)) & 1u, hi = (bt[it] >> (2 * x + 1)) & 1u;
+                            d[x] &= ((0u - lo) & 0xFFFFu) | ((0u - hi) & 0xFFFF0000u);
+                        }
+                    }
+                    if (m < epi.M) {
+                        *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+                        if (epi.has_bits_out()) {      // 8 consecutive bf16 outputs of this row -> one byte of sign bits (+0 and -0 are "off")
+                            unsigned byte = 0;
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) {
+                                byte |= ((d[x] & 0x7fffu) != 0u && !(d[x] & 0x8000u)) ? (1u << (2 * x)) : 0u;
+                                byte |= ((d[x] & 0x7fff0000u) != 0u && !(d[x] & 0x80000000u)) ? (2u << (2 * x)) : 0u;
+                            }
+                            epi.put_bits(m, nw + ch * 8, byte);
+                        }
+                    }
                 }
             } else {
 #pragma unroll
@@ -832,6 +873,7 @@ template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, 
             if (epi.wide_ok && !(epi.flags & ~ASR_GEMM_RELU)) {
                 switch (dense_mode(epi)) {   // the combinations the model's projections use; anything else takes the run-time form
                     case 1u | 2u | 16u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 2u | 16u>(epi));   // FFN1
+                    case 1u | 2u | 16u | 32u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 2u | 16u | 32u>(epi));   // FFN1 + sign bits
                     case 1u | 16u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 16u>(epi));
                     case 1u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u>(epi));                         // FFN2, fc, affine
                     case 0u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<0u>(epi));                         // vocab projections
@@ -861,13 +903,22 @@ extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda
 
 extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
                               const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags,
-                              const float* addend, int64_t ld_add, const void* relu_mask, int64_t ld_mask) {
+                              const float* addend, int64_t ld_add, const void* relu_mask, int64_t ld_mask, void* relu_bits_out,
+                              int64_t ld_bits) {
     ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm_ex: M=%d N=%d K=%d C=%p", M, N, K, C);
     ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm_ex: bad c_dtype");
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
     EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask, false};
     epi.vec_ok = dense_vec_ok(epi);
     epi.wide_ok = dense_wide_ok(epi);
+    if (relu_bits_out) {
+        // sign bits are produced by the LDS-transposed epilogue of the LDS-DMA kernel only: full 128-column tiles, bf16 x bf16
+        ASR_REQUIRE(epi.wide_ok && c_dtype == ASR_BF16 && N % 128 == 0 && ld_bits >= N / 8 && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 &&
+                        K % 64 == 0 && (flags & ASR_GEMM_RELU) && getenv("ASR_AMD_NO_GLDS") == nullptr,
+                    ASR_ERR_UNSUPPORTED, "gemm_ex: relu_bits_out needs bf16 operands/output, ReLU, N %% 128 == 0, K %% 64 == 0, aligned rows");
+        epi.bits_out = reinterpret_cast<unsigned char*>(relu_bits_out);
+        epi.ld_bits = ld_bits;
+    }
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -893,14 +944,22 @@ extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t 
 
 extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int64_t ldb, const float* bias, void* C,
                            int c_dtype, int64_t ldc, int M, int N, int K, const float* addend, int64_t ld_add, const void* relu_mask,
-                           int64_t ld_mask) {
+                           int64_t ld_mask, int mask_is_bits) {
     ASR_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, ASR_ERR_ARG, "gemm_nn: bad args");
     ASR_REQUIRE(lda % 8 == 0 && lda >= (K + 7) / 8 * 8 && N % 4 == 0 && ldb % 4 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 8),
                 ASR_ERR_ALIGN, "gemm_nn: lda=%lld must be a multiple of 8 covering K=%d rounded up (pad columns must be zero), N=%d ldb=%lld of 4",
                 (long long)lda, K, N, (long long)ldb);
-    EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, reinterpret_cast<const bf16_t*>(relu_mask), ld_mask, false};
+    EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, mask_is_bits ? nullptr : reinterpret_cast<const bf16_t*>(relu_mask),
+                 ld_mask, false};
     epi.vec_ok = dense_vec_ok(epi);
     epi.wide_ok = dense_wide_ok(epi);
+    if (mask_is_bits && relu_mask) {
+        ASR_REQUIRE(epi.wide_ok && a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) &&
+                        ld_mask >= N / 8 && getenv("ASR_AMD_NO_TR") == nullptr,
+                    ASR_ERR_UNSUPPORTED, "gemm_nn: a sign-bit mask needs the LDS-DMA kernel's shapes (bf16 A, K %% 64 == 0, N %% 128 == 0)");
+        epi.bits_in = reinterpret_cast<const unsigned char*>(relu_mask);
+        epi.ld_bits = ld_mask;
+    }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
@@ -910,6 +969,7 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
         const unsigned mode = epi.wide_ok ? dense_mode(epi) : 0xffu;
         if (mode == 4u) LAUNCH_NN_TR(dense_as<4u>(epi));                 // dX = dY . W + residual gradient (f32)
         else if (mode == (8u | 16u)) LAUNCH_NN_TR(dense_as<8u | 16u>(epi));   // ReLU-masked hidden gradient (bf16)
+        else if (mode == (64u | 16u)) LAUNCH_NN_TR(dense_as<64u | 16u>(epi));  // ... masked from the sign bits
         else if (mode == 16u) LAUNCH_NN_TR(dense_as<16u>(epi));
         else if (mode == 0u) LAUNCH_NN_TR(dense_as<0u>(epi));
         else LAUNCH_NN_TR(epi);

@@ -359,7 +359,16 @@ class PositionwiseFeedForward(_Cached):
     def _impl(self, x, row_len):
         hdt = _cdtype()
         rec = _TAPE is not None
-        hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
+        d_ff = self.w_1.weight.shape[0]
+        # training: the ReLU mask travels to the backward as 1 sign bit per hidden unit (written by this GEMM's epilogue) - the
+        # hidden gradient's GEMM then reads 8 MB instead of re-reading the 131 MB activation (S1 shape)
+        use_bits = rec and _PRECISION == "bf16" and d_ff % 128 == 0 and x.mma().dtype == torch.bfloat16 and x.f32.shape[1] % 64 == 0
+        bits = torch.empty((x.mma().shape[0], d_ff // 8), device=x.f32.device, dtype=torch.uint8) if use_bits else None
+        if use_bits:
+            hid = ops.gemm_nt_ex(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True,
+                                 relu_bits_out=bits)
+        else:
+            hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
         o = ops.gemm_nt(hid, self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)))
         dp = _drop(self, "dropout")   # module.py:51
         y32, y16, mean, rstd = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
@@ -373,7 +382,8 @@ class PositionwiseFeedForward(_Cached):
                                                  want_bf16=True, dbias=w2.bias.grad, drop_x=dp)
                 y.grad = None
                 ops.gemm_tn(ds16, hid, out=w2.weight.grad, accumulate=True)
-                d_hid = ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid)
+                d_hid = (ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_bits=bits) if bits is not None
+                         else ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid))
                 ops.gemm_tn(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
                 _acc(x, ops.gemm_nn(d_hid, self._w("w1", (w1.weight,)), addend=ds))
 

@@ -348,9 +348,10 @@ def cif_gather(hidden, cur, rem, fire_idx, n_fire, Umax):
 
 # ------------------------------------------------------------------------------------------------------------
 # backward-pass ops
-def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=None, relu_mask=None, out=None):
-    """C = A . W^T (+bias) (+addend) (masked by relu_mask > 0).  A [M,K] contiguous; W [N,K]."""
-    _req_cuda(a2d, w, bias, addend, relu_mask)
+def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=None, relu_mask=None, out=None, relu_bits_out=None):
+    """C = A . W^T (+bias) (+addend) (masked by relu_mask > 0).  A [M,K] contiguous; W [N,K].
+    relu_bits_out: uint8 [M, N/8] receiving the sign bits of the (ReLU'd, bf16) output - see asr_hip.h."""
+    _req_cuda(a2d, w, bias, addend, relu_mask, relu_bits_out)
     M, K = a2d.shape
     N = w.shape[0]
     assert a2d.is_contiguous() and w.is_contiguous() and w.shape[1] == K
@@ -358,14 +359,17 @@ def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=No
         out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
     with _timed("gemm_nt[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
         check(lib().asr_gemm_nt_ex(_stream(), _p(a2d), dtype_code(a2d), K, _p(w), dtype_code(w), K, _p(bias), _p(out), dtype_code(out),
-                                   N, M, N, K, GEMM_RELU if relu else 0, _p(addend), N, _p(relu_mask), N), "asr_gemm_nt_ex")
+                                   N, M, N, K, GEMM_RELU if relu else 0, _p(addend), N, _p(relu_mask), N, _p(relu_bits_out),
+                                   relu_bits_out.stride(0) if relu_bits_out is not None else 0), "asr_gemm_nt_ex")
     return out
 
 
-def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=None, K=None):
-    """dX[M,in] = A[M,out] . W[out,in]  (W bf16 as stored).  Optional f32 addend [M,in] and bf16 relu_mask [M,in].
+def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=None, K=None, relu_bits=None):
+    """dX[M,in] = A[M,out] . W[out,in]  (W bf16 as stored).  Optional f32 addend [M,in] and bf16 relu_mask [M,in] - or, instead
+    of the latter, relu_bits uint8 [M, in/8] (the sign-bit image gemm_nt_ex wrote).
     `K` (<= a2d.shape[1], rows of W used) and `lda` let A live in a wider / padded buffer."""
-    _req_cuda(a2d, w, addend, relu_mask)
+    _req_cuda(a2d, w, addend, relu_mask, relu_bits)
+    assert relu_mask is None or relu_bits is None
     M = a2d.shape[0]
     K = a2d.shape[1] if K is None else K
     lda = a2d.stride(0) if lda is None else lda
@@ -374,7 +378,8 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
     out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
     with _timed("gemm_nn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
         check(lib().asr_gemm_nn(_stream(), _p(a2d), dtype_code(a2d), lda, _p(w), N, None, _p(out), dtype_code(out), N, M, N, K,
-                                _p(addend), N, _p(relu_mask), N), "asr_gemm_nn")
+                                _p(addend), N, _p(relu_bits if relu_bits is not None else relu_mask),
+                                relu_bits.stride(0) if relu_bits is not None else N, 1 if relu_bits is not None else 0), "asr_gemm_nn")
     return out
 
 

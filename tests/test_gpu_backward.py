@@ -166,3 +166,25 @@ def test_cif_backward_matches_reference_autograd(golden_dir, pfx):
     d_hidden, d_alpha = ops.cif_bwd(hidden, cur, rem, tok, n_fire, w)
     np.testing.assert_allclose(N(d_hidden), z[f"{pfx}_ghidden"], atol=1e-5, rtol=1e-5)
     np.testing.assert_allclose(N(d_alpha), z[f"{pfx}_galpha"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N_,K", [(1000, 2048, 256), (130, 256, 64), (4096, 512, 512)])
+def test_relu_sign_bits_round_trip(M, N_, K):
+    """FFN backward without re-reading the hidden activation: the first GEMM's epilogue writes one sign bit per ReLU output and the
+    hidden gradient's GEMM masks from those bits - bit-identical to masking from the bf16 activation itself."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    w1 = (torch.randn(N_, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
+    b1 = torch.randn(N_, generator=g).to(DEV)
+    bits = torch.zeros(M, N_ // 8, device=DEV, dtype=torch.uint8)
+    hid = ops.gemm_nt_ex(x, w1, b1, out_dtype=torch.bfloat16, relu=True, relu_bits_out=bits)
+    hid_plain = ops.gemm_nt(x, w1, b1, out_dtype=torch.bfloat16, relu=True)
+    assert torch.equal(hid, hid_plain)
+    want = (hid.float() > 0).view(M, N_ // 8, 8).to(torch.uint8)
+    packed = (want << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, packed)
+    dy = torch.randn(M, 256, generator=g).to(DEV).bfloat16()
+    w2 = (torch.randn(256, N_, generator=g) / 16).to(DEV).bfloat16()
+    a = ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16, relu_mask=hid)
+    b = ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16, relu_bits=bits)
+    assert torch.equal(a, b)

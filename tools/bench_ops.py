@@ -106,6 +106,15 @@ def bench_bwdgemm():
         fl = 2.0 * M * N * K
         print(json.dumps(dict(op="gemm_tn", shape=[M, N, K], us=round(t * 1e3, 2), TFLOPs=round(fl / t / 1e9, 1),
                               frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
+    # FFN hidden gradient: ReLU mask from the bf16 activation vs from sign bits
+    M, N, K = 32000, 2048, 256
+    dy = torch.randn(M, K, device=DEV).bfloat16()
+    w = (torch.randn(K, N, device=DEV) / K ** 0.5).bfloat16()
+    hid = torch.relu(torch.randn(M, N, device=DEV)).bfloat16()
+    bits = torch.randint(0, 255, (M, N // 8), device=DEV, dtype=torch.uint8)
+    for name, kw in (("plain", {}), ("relu_mask", dict(relu_mask=hid)), ("relu_bits", dict(relu_bits=bits))):
+        t = timeit(lambda: ops.gemm_nn(dy, w, out_dtype=torch.bfloat16, **kw))
+        print(json.dumps(dict(op="gemm_nn[32000,2048,256] bf16 out, " + name, us=round(t * 1e3, 2))))
     for (M, N, K) in [(32000, 2048, 256), (32000, 256, 2048), (32000, 256, 768)]:
         dy = torch.randn(M, K, device=DEV).bfloat16()
         w = (torch.randn(K, N, device=DEV) / K ** 0.5).bfloat16()
