@@ -304,7 +304,18 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
             constexpr int IB = decltype(IBc)::value;                     // 16-row blocks of the sub-tile handled by this pass
             f32x4 av[IB][4];
             bf16x4 mk[IB][4];
-            if (epi.has_add()) {
+            // addend: with f32 output (and no ReLU after it) it is added in the read-back layout below - 16 adjacent lanes read a
+            // row's 256 bytes - instead of as 64-byte row fragments in the accumulator layout
+            const bool add_late = epi.has_add() && !bf16_out && !epi.relu() && !epi.has_mask();
+            f32x4 al[4 * IB];
+            if (add_late) {
+#pragma unroll
+                for (int it = 0; it < 4 * IB; ++it) {
+                    const int idx = it * 64 + lane;
+                    al[it] = epi.get_add(min(mw + pass * IB * 16 + (idx >> 4), epi.M - 1), nw + (idx & 15) * 4);
+                }
+            }
+            if (epi.has_add() && !add_late) {
 #pragma unroll
                 for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
@@ -334,7 +345,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
 #pragma unroll
                         for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
                     }
-                    if (epi.has_add()) v += av[ii][j];
+                    if (epi.has_add() && !add_late) v += av[ii][j];
                     if (epi.has_mask()) {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) v[x] = ((float)mk[ii][j][x] > 0.f) ? v[x] : 0.f;
@@ -379,7 +390,8 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
 #pragma unroll
                 for (int it = 0; it < 4 * IB; ++it) {
                     const int idx = it * 64 + lane, rl = idx >> 4, ch = idx & 15, m = mw + pass * IB * 16 + rl;
-                    const u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 256 + ((ch ^ (rl & 7)) << 4));
+                    u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 256 + ((ch ^ (rl & 7)) << 4));
+                    if (add_late) d = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, d) + al[it]);
                     if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
                 }
             }

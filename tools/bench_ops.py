@@ -115,6 +115,11 @@ def bench_bwdgemm():
     for name, kw in (("plain", {}), ("relu_mask", dict(relu_mask=hid)), ("relu_bits", dict(relu_bits=bits))):
         t = timeit(lambda: ops.gemm_nn(dy, w, out_dtype=torch.bfloat16, **kw))
         print(json.dumps(dict(op="gemm_nn[32000,2048,256] bf16 out, " + name, us=round(t * 1e3, 2))))
+    add = torch.randn(32000, 256, device=DEV)
+    for K in (2048, 768, 256):
+        dy2 = torch.randn(32000, K, device=DEV).bfloat16(); w2 = (torch.randn(K, 256, device=DEV) / K ** 0.5).bfloat16()
+        t = timeit(lambda: ops.gemm_nn(dy2, w2, addend=add))
+        print(json.dumps(dict(op="gemm_nn[32000,256,%d] f32 out + addend" % K, us=round(t * 1e3, 2))))
     for (M, N, K) in [(32000, 2048, 256), (32000, 256, 2048), (32000, 256, 768)]:
         dy = torch.randn(M, K, device=DEV).bfloat16()
         w = (torch.randn(K, N, device=DEV) / K ** 0.5).bfloat16()
