@@ -19,6 +19,9 @@ def short(name):
     k = m.group(1)
     if "EpiHeads" in name:
         k += "<EpiHeads>"
+    e = re.search(r"EpiDenseS<(\d+)u>", name)      # compile-time epilogue mode: tells FFN1 (19) from FFN2 (1) from the vocab GEMMs (0)
+    if e:
+        k += "<mode%s>" % e.group(1)
     return k
 
 
