@@ -275,8 +275,10 @@ class MultiheadAttention(_Cached):
         nn.init.xavier_normal_(self.fc.weight)
         self.dropout_rate = dropout
 
-    def _impl(self, xq, xkv, k_len, causal, row_len):
-        """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act."""
+    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None):
+        """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act.
+        kv_pre = (k, v, dkv) when the caller has already projected the keys / values (_CrossKV: one GEMM for all decoder layers);
+        dkv() -> (dk, dv) views the backward writes into, the K/V weight and input gradients are then the caller's business."""
         h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
         scale = 1.0 / math.sqrt(self.d_k)
         qscale = scale * _LOG2E      # the attention kernels take base-2 logits (asr_hip.h): log2(e) rides on the Q projection
@@ -287,9 +289,12 @@ class MultiheadAttention(_Cached):
             q, k, v = qkv[0], qkv[1], qkv[2]
         else:
             q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
-            kv = ops.proj_heads(xkv.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)),
-                                self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
-            k, v = kv[0], kv[1]
+            if kv_pre is not None:
+                k, v = kv_pre[0], kv_pre[1]
+            else:
+                kv = ops.proj_heads(xkv.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)),
+                                    self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
+                k, v = kv[0], kv[1]
         rec = _TAPE is not None
         dp_attn, dp_fc = _drop(self, "attention.dropout"), _drop(self, "dropout")   # attention.py:83, :59
         ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec, drop=dp_attn)
@@ -299,10 +304,12 @@ class MultiheadAttention(_Cached):
                                                  drop_x=dp_fc)
         y = Act(y32, y16, B, Lq)
         if rec:
-            self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc)
+            self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc,
+                            None if kv_pre is None else kv_pre[2])
         return y
 
-    def _record_bw(self, xq, xkv, q, k, v, ctx, lse, s_sum, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc):
+    def _record_bw(self, xq, xkv, q, k, v, ctx, lse, s_sum, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc,
+                   dkv_pre=None):
         h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
         hd = h * 64
         ln, fc = self.layer_norm, self.fc
@@ -323,14 +330,20 @@ class MultiheadAttention(_Cached):
                 _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
             else:
                 dq = torch.empty((B * Lq, hd), device=ds.device, dtype=torch.bfloat16)
-                dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
-                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dkv[:, :hd], dkv[:, hd:], drop=dp_attn)
+                if dkv_pre is not None:
+                    dk_out, dv_out = dkv_pre()
+                else:
+                    dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
+                    dk_out, dv_out = dkv[:, :hd], dkv[:, hd:]
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn)
                 ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
                 _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
-                ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True, colsum=_gcat(qkvb[1:]))
-                xkv.grad = ops.gemm_nn(dkv, self._w("kv", qkvw[1:]), addend=xkv.grad)
+                if dkv_pre is None:
+                    ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True, colsum=_gcat(qkvb[1:]))
+                    xkv.grad = ops.gemm_nn(dkv, self._w("kv", qkvw[1:]), addend=xkv.grad)
 
-        _TAPE.push(bw, qkvw + qkvb + (fc.weight, fc.bias, ln.weight, ln.bias))
+        mine = (qkvw[:1] + qkvb[:1]) if dkv_pre is not None else (qkvw + qkvb)
+        _TAPE.push(bw, mine + (fc.weight, fc.bias, ln.weight, ln.bias))
 
     def forward(self, q, k, v, mask=None, k_len=None, causal=False):
         """Reference signature + length-based masking: `k_len` (int [B]) / `causal`.  A bool `mask` [B,Lq,Lk] is
@@ -687,9 +700,9 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
-    def _impl(self, x, enc, dec_len, enc_len):
+    def _impl(self, x, enc, dec_len, enc_len, kv_pre=None):
         x = self.slf_attn._impl(x, x, dec_len, True, dec_len)
-        x = self.enc_attn._impl(x, enc, enc_len, False, dec_len)
+        x = self.enc_attn._impl(x, enc, enc_len, False, dec_len, kv_pre=kv_pre)
         return self.pos_ffn._impl(x, dec_len)
 
 
@@ -785,10 +798,46 @@ class Decoder(_Cached):
                 x_emb.grad = None
 
             _TAPE.push(bw_emb, (emb.weight,))
-        for layer in self.layer_stack:
-            x = layer._impl(x, enc, dec_len, enc_len)
+        cross = self._cross_kv(enc)
+        for i, layer in enumerate(self.layer_stack):
+            x = layer._impl(x, enc, dec_len, enc_len, kv_pre=cross(i))
         logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, x)
         return logits.view(B, U, self.n_tgt_vocab), ys_out
+
+    def cross_kv_params(self):
+        """([w_ks, w_vs weights of layer 0, 1, ...], [their biases]) - the trainer keeps each list adjacent in its flat buffers."""
+        att = [layer.enc_attn for layer in self.layer_stack]
+        return ([w for a in att for w in (a.w_ks.weight, a.w_vs.weight)], [b for a in att for b in (a.w_ks.bias, a.w_vs.bias)])
+
+    def _cross_kv(self, enc):
+        """The encoder-side keys / values of every decoder layer depend only on the encoder output: project them with ONE
+        [B*L, n_layers*2*h*64] GEMM instead of n_layers narrow ones, and in the backward collect every layer's dK / dV in one
+        [B*L, n_layers*2*h*64] buffer so the weight gradient and the gradient wrt the encoder output are one GEMM each (K = 3072
+        instead of six K = 512 passes that each re-read and re-write the [B*L, d_model] accumulator)."""
+        ws, bs = self.cross_kv_params()
+        n, h = len(self.layer_stack), self.n_head
+        hd = h * 64
+        W, bias = self._w("cross_kv", tuple(ws)), self._b("cross_kvb", tuple(bs))
+        kv = ops.proj_heads(enc.mma(), W, bias, 2 * n, enc.B, enc.L, h, 1.0)
+        if _TAPE is None:
+            return lambda i: (kv[2 * i], kv[2 * i + 1], None)
+        box = {}
+
+        def dkv_of(i):
+            def get():
+                if "dkv" not in box:
+                    box["dkv"] = torch.empty((enc.B * enc.L, 2 * n * hd), device=kv.device, dtype=torch.bfloat16)
+                d = box["dkv"]
+                return d[:, 2 * i * hd:(2 * i + 1) * hd], d[:, (2 * i + 1) * hd:(2 * i + 2) * hd]
+            return get
+
+        def bw():   # pushed before the layers -> runs after all of them have written their dK / dV columns
+            dkv = box.pop("dkv")
+            ops.gemm_tn(dkv, enc.mma(), out=_gcat(ws), accumulate=True, colsum=_gcat(bs))
+            enc.grad = ops.gemm_nn(dkv, W, addend=enc.grad)
+
+        _TAPE.push(bw, tuple(ws) + tuple(bs))
+        return lambda i: (kv[2 * i], kv[2 * i + 1], dkv_of(i))
 
     def forward(self, targets, encoder_padded_outputs, encoder_input_lengths):
         enc = _act(encoder_padded_outputs)

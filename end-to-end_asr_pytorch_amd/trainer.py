@@ -33,6 +33,10 @@ def _param_order(model):
             order.append(p)
 
     for m in model.modules():
+        if isinstance(m, modules.Decoder):       # cross-attention K/V weights (biases) of all layers adjacent: Decoder._cross_kv
+            ws, bs = m.cross_kv_params()
+            for p in ws + bs:
+                add(p)
         if isinstance(m, modules.MultiheadAttention):
             for p in (m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.w_qs.bias, m.w_ks.bias, m.w_vs.bias):
                 add(p)

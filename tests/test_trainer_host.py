@@ -16,19 +16,27 @@ def test_param_order_is_a_permutation_with_qkv_adjacent():
     order = _param_order(m)
     assert sorted(id(p) for p in order) == sorted(id(p) for p in m.parameters())
     pos = {id(p): i for i, p in enumerate(order)}
-    for mod in m.modules():
-        if isinstance(mod, asr_amd.MultiheadAttention):
-            i = pos[id(mod.w_qs.weight)]
-            assert pos[id(mod.w_ks.weight)] == i + 1 and pos[id(mod.w_vs.weight)] == i + 2
-            j = pos[id(mod.w_qs.bias)]
-            assert pos[id(mod.w_ks.bias)] == j + 1 and pos[id(mod.w_vs.bias)] == j + 2
+    cross = {id(layer.enc_attn) for mod in m.modules() if isinstance(mod, asr_amd.Decoder) for layer in mod.layer_stack}
+    selfs = [mod for mod in m.modules() if isinstance(mod, asr_amd.MultiheadAttention) and id(mod) not in cross]
+    assert selfs and cross
+    for mod in selfs:
+        i = pos[id(mod.w_qs.weight)]
+        assert pos[id(mod.w_ks.weight)] == i + 1 and pos[id(mod.w_vs.weight)] == i + 2
+        j = pos[id(mod.w_qs.bias)]
+        assert pos[id(mod.w_ks.bias)] == j + 1 and pos[id(mod.w_vs.bias)] == j + 2
     offs, total = flat_offsets(order)
     assert all(o % 8 == 0 for o in offs) and total >= sum(p.numel() for p in order)
     # Q/K/V stay adjacent (no padding inside the triples) so their concatenation is a plain view
+    for mod in selfs:
+        i = pos[id(mod.w_qs.weight)]
+        assert offs[i + 1] == offs[i] + mod.w_qs.weight.numel() and offs[i + 2] == offs[i + 1] + mod.w_ks.weight.numel()
+    # the decoder's cross-attention K/V weights (then biases) of ALL layers form one contiguous run (Decoder._cross_kv)
     for mod in m.modules():
-        if isinstance(mod, asr_amd.MultiheadAttention):
-            i = pos[id(mod.w_qs.weight)]
-            assert offs[i + 1] == offs[i] + mod.w_qs.weight.numel() and offs[i + 2] == offs[i + 1] + mod.w_ks.weight.numel()
+        if isinstance(mod, asr_amd.Decoder):
+            for group in mod.cross_kv_params():
+                i0 = pos[id(group[0])]
+                assert [pos[id(p)] for p in group] == list(range(i0, i0 + len(group)))
+                assert all(offs[i0 + k + 1] == offs[i0 + k] + group[k].numel() for k in range(len(group) - 1))
 
 
 def test_flat_offsets_survive_odd_sized_parameters():
