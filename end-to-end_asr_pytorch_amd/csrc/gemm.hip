@@ -100,13 +100,19 @@ struct EpiDense {
     }
     // the wide epilogue issues every global read of a pass as one batch (kernel-uniform branches around whole batches) and
     // then only does arithmetic: with per-element `if (bias) load` the loads serialised, ~0.2 us each, 3 us per output tile
+    // row cursor of the wide epilogue's read-back: the pointer of the first row once, then a kernel-uniform stride per step
+    // (recomputing m * ldc per store cost two 64-bit multiplies = eight quarter-rate VALU ops per 16-byte store)
+    struct Cur { unsigned char* p; };
+    __device__ __forceinline__ int64_t ld_bits_() const { return ld_bits; }
+    __device__ __forceinline__ void step(Cur& c, int rows) const { c.p += (int64_t)rows * ldc * (c_dtype == ASR_F32 ? 4 : 2); }
+    __device__ __forceinline__ const unsigned char* bits_in_ptr(int m, int n) const { return bits_in + (int64_t)m * ld_bits + (n >> 3); }
+    __device__ __forceinline__ unsigned char* bits_out_ptr(int m, int n) const { return bits_out + (int64_t)m * ld_bits + (n >> 3); }
     __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
     __device__ __forceinline__ bool has_add() const { return addend != nullptr; }
     __device__ __forceinline__ bool has_mask() const { return relu_mask != nullptr; }
     __device__ __forceinline__ bool has_bits_in() const { return bits_in != nullptr; }
     __device__ __forceinline__ bool has_bits_out() const { return bits_out != nullptr; }
-    __device__ __forceinline__ unsigned get_byte(int m, int n) const { return bits_in[(int64_t)m * ld_bits + (n >> 3)]; }   // columns n..n+7, n % 8 == 0
-    __device__ __forceinline__ void put_bits(int m, int n, unsigned byte) const { bits_out[(int64_t)m * ld_bits + (n >> 3)] = (unsigned char)byte; }
+    __device__ __forceinline__ Cur cur(int m, int nw) const { return Cur{row_ptr(m, nw)}; }
     __device__ __forceinline__ bool relu() const { return flags & ASR_GEMM_RELU; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
     __device__ __forceinline__ f32x4 get_add(int m, int n) const { return *reinterpret_cast<const f32x4*>(addend + (int64_t)m * ld_add + n); }
@@ -200,6 +206,8 @@ template <unsigned MODE> struct EpiDenseS : EpiDense {
     __device__ __forceinline__ unsigned char* row_ptr(int m, int nw) const {
         return reinterpret_cast<unsigned char*>(C) + ((int64_t)m * ldc + nw) * ((MODE & 16u) ? 2 : 4);
     }
+    __device__ __forceinline__ EpiDense::Cur cur(int m, int nw) const { return EpiDense::Cur{row_ptr(m, nw)}; }
+    __device__ __forceinline__ void step(EpiDense::Cur& c, int rows) const { c.p += (int64_t)rows * ldc * ((MODE & 16u) ? 2 : 4); }
 };
 inline unsigned dense_mode(const EpiDense& e) {
     return (e.bias ? 1u : 0u) | ((e.flags & ASR_GEMM_RELU) ? 2u : 0u) | (e.addend ? 4u : 0u) | (e.relu_mask ? 8u : 0u) |
@@ -237,8 +245,23 @@ template <typename CT> struct EpiHeads {
     __device__ __forceinline__ bool has_mask() const { return false; }
     __device__ __forceinline__ bool has_bits_in() const { return false; }
     __device__ __forceinline__ bool has_bits_out() const { return false; }
-    __device__ __forceinline__ unsigned get_byte(int, int) const { return 0u; }
-    __device__ __forceinline__ void put_bits(int, int, unsigned) const {}
+    // row cursor: (b, t) split by one division for the first row, then t += rows with a wrap into the next utterance's block
+    struct Cur { unsigned char* p; int t; };
+    __device__ __forceinline__ Cur cur(int m, int nw) const {
+        const int b = m / L;
+        return Cur{row_ptr(m, nw), m - b * L};
+    }
+    __device__ __forceinline__ void step(Cur& c, int rows) const {
+        c.p += (int64_t)rows * 64 * (int)sizeof(CT);
+        c.t += rows;
+        while (c.t >= L) {
+            c.t -= L;
+            c.p += (int64_t)(h - 1) * L * 64 * (int)sizeof(CT);
+        }
+    }
+    __device__ __forceinline__ int64_t ld_bits_() const { return 0; }
+    __device__ __forceinline__ const unsigned char* bits_in_ptr(int, int) const { return nullptr; }
+    __device__ __forceinline__ unsigned char* bits_out_ptr(int, int) const { return nullptr; }
     __device__ __forceinline__ bool relu() const { return false; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
     __device__ __forceinline__ f32x4 get_add(int, int) const { return f32x4{0, 0, 0, 0}; }
@@ -331,9 +354,13 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
             // loads go out now, ahead of the LDS round trip
             unsigned bt[2 * IB];
             if (epi.has_bits_in()) {
+                const int mf = mw + pass * IB * 16 + (lane >> 3);
+                const unsigned char* bp = epi.bits_in_ptr(mf, nw + (lane & 7) * 8);
 #pragma unroll
-                for (int it = 0; it < 2 * IB; ++it)
-                    bt[it] = epi.get_byte(min(mw + pass * IB * 16 + it * 8 + (lane >> 3), epi.M - 1), nw + (lane & 7) * 8);
+                for (int it = 0; it < 2 * IB; ++it) {
+                    bt[it] = (mf + it * 8 < epi.M) ? (unsigned)*bp : 0u;
+                    bp += 8 * epi.ld_bits_();
+                }
             }
 #pragma unroll
             for (int ii = 0; ii < IB; ++ii) {
@@ -362,9 +389,12 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                 }
             }
             if (bf16_out) {
+                const int ch = lane & 7, mf = mw + pass * IB * 16 + (lane >> 3);
+                auto rc = epi.cur(mf, nw);
+                unsigned char* bo = epi.has_bits_out() ? epi.bits_out_ptr(mf, nw + ch * 8) : nullptr;
 #pragma unroll
                 for (int it = 0; it < 2 * IB; ++it) {
-                    const int rl = it * 8 + (lane >> 3), ch = lane & 7, m = mw + pass * IB * 16 + rl;
+                    const int rl = it * 8 + (lane >> 3), m = mf + it * 8;
                     u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 128 + ((ch ^ (rl & 7)) << 4));
                     if (epi.has_bits_in()) {
 #pragma unroll
@@ -374,25 +404,32 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                         }
                     }
                     if (m < epi.M) {
-                        *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+                        *reinterpret_cast<u32x4*>(rc.p + ch * 16) = d;
                         if (epi.has_bits_out()) {      // 8 consecutive bf16 outputs of this row -> one byte of sign bits (+0 and -0 are "off")
-                            unsigned byte = 0;
+                            // branch-free: (magnitude + 0x7fff) carries into bit 15 / 31 of each half iff the magnitude is nonzero
+                            unsigned w = 0;
 #pragma unroll
                             for (int x = 0; x < 4; ++x) {
-                                byte |= ((d[x] & 0x7fffu) != 0u && !(d[x] & 0x8000u)) ? (1u << (2 * x)) : 0u;
-                                byte |= ((d[x] & 0x7fff0000u) != 0u && !(d[x] & 0x80000000u)) ? (2u << (2 * x)) : 0u;
+                                unsigned t = (d[x] & 0x7fff7fffu) + 0x7fff7fffu;
+                                if (!epi.relu()) t &= ~d[x];                   // without a ReLU in front negative outputs are "off" too
+                                w |= (t & 0x80008000u) >> (15 - 2 * x);        // half 0 -> bit 2x, half 1 -> bit 16 + 2x
                             }
-                            epi.put_bits(m, nw + ch * 8, byte);
+                            *bo = (unsigned char)((w & 0x55u) | ((w >> 15) & 0xAAu));
                         }
                     }
+                    epi.step(rc, 8);
+                    if (epi.has_bits_out()) bo += 8 * epi.ld_bits_();
                 }
             } else {
+                const int ch = lane & 15, mf = mw + pass * IB * 16 + (lane >> 4);
+                auto rc = epi.cur(mf, nw);
 #pragma unroll
                 for (int it = 0; it < 4 * IB; ++it) {
-                    const int idx = it * 64 + lane, rl = idx >> 4, ch = idx & 15, m = mw + pass * IB * 16 + rl;
+                    const int rl = it * 4 + (lane >> 4), m = mf + it * 4;
                     u32x4 d = *reinterpret_cast<const u32x4*>(scratch + rl * 256 + ((ch ^ (rl & 7)) << 4));
                     if (add_late) d = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, d) + al[it]);
-                    if (m < epi.M) *reinterpret_cast<u32x4*>(epi.row_ptr(m, nw) + ch * 16) = d;
+                    if (m < epi.M) *reinterpret_cast<u32x4*>(rc.p + ch * 16) = d;
+                    epi.step(rc, 4);
                 }
             }
         };

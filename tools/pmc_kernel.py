@@ -5,7 +5,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
-            acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"][:int(sys.argv[3]) if len(sys.argv) > 3 else 60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
     for c, v in sorted(cs.items()):
