@@ -32,9 +32,11 @@ SIGNATURES = {
     "asr_gemm_nt": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u],
     "asr_gemm_nt_ex": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _u, _vp, _i64, _vp, _i64, _vp, _i64],
     "asr_gemm_nn": [_vp, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp, _i64, _i],
-    "asr_attention_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr],
-    "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _dr],
-    "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr],
+    "asr_attention_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr, _vp],
+    "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _dr, _vp],
+    "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr, _vp],
+    "asr_attention_dropmask": [_vp, _dr, _i, _i, _i, _i, _vp],
+    "asr_attention_dropmask_words": [_i, _i, _i, _i],
     "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dr, _dr],
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
@@ -42,7 +44,7 @@ SIGNATURES = {
     "asr_dropout_apply": [_vp, _vp, _vp, _i, _i, _i, _dr],
     "asr_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f],
     "asr_proj_heads": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f],
-    "asr_attention_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _dr],
+    "asr_attention_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _dr, _vp],
     "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr, _dr],
     "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _dr],
     "asr_conv_sub0_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
@@ -124,6 +126,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        L.asr_attention_dropmask_words.restype = ctypes.c_int64
         L.asr_last_error.restype = ctypes.c_char_p
         L.asr_version.restype = ctypes.c_int
         _lib = L

@@ -61,6 +61,22 @@ __device__ __forceinline__ uint32_t drop_word(const asr_dropout_t& d, uint32_t s
 __device__ __forceinline__ bool drop_keep_lo(const asr_dropout_t& d, uint32_t w) { return (w & 0xFFFFu) >= d.thr16; }
 __device__ __forceinline__ bool drop_keep_hi(const asr_dropout_t& d, uint32_t w) { return (w >> 16) >= d.thr16; }
 __device__ __forceinline__ float drop_scale(const asr_dropout_t& d) { return 65536.f / (float)(65536u - d.thr16); }
+// ---- attention dropout mask as bit images (attention.hip: attn_dropmask_kernel) ----
+// One hash pass per layer call writes the keep bits twice, the attention kernels (forward, dQ, dK/dV) then read two 32-bit words
+// per lane and 64-key (64-query) tile instead of hashing 16 words each: the hash is 2 quarter-rate multiplies + 3 xor-shifts per
+// 2 elements, ~1.8x the cost of the exp2 of the same 2 elements, and was paid three times.
+//   Mk[bh][kw][q]  (kw = key / 32):  bit (key & 31)  = keep(q, key)     q-stationary kernels: lane = query, coalesced along q
+//   Mq[bh][qw][key] (qw = q / 32):   bit (q & 31)    = keep(q, key)     k-stationary kernel:  lane = key,   coalesced along key
+// with Lq / Lk rounded up to 128 (words of all-padding tiles are unspecified: every consumer masks those positions itself).
+// (Tried: images of 64-bit wave lane masks, scalar-loaded and applied with one v_cndmask per element via inverse ballot - 1 VALU
+// instead of 2 per element.  -6 us on the forward kernel alone, but +8 / +27 us on dQ / dK,dV: scalar loads share lgkmcnt with
+// the LDS reads those kernels keep in flight, and a wait on an out-of-order SMEM return drains them all.)
+__host__ __device__ __forceinline__ int drop_pad128(int n) { return (n + 127) & ~127; }
+__host__ __device__ __forceinline__ int64_t drop_mk_words(int BH, int Lq, int Lk) { return (int64_t)BH * (drop_pad128(Lk) / 32) * drop_pad128(Lq); }
+// all-ones / all-zeros from bit `pos` of w: the value is AND-ed onto the f32 bit pattern it keeps or drops
+__device__ __forceinline__ float drop_and(float v, uint32_t w, int pos) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe((int)w, (unsigned)pos, 1u));
+}
 // 4 consecutive elements n2 = c .. c+3 (c even) of row n1: multiply by the keep mask * scale
 __device__ __forceinline__ f32x4 drop4(const asr_dropout_t& d, uint32_t sub, uint32_t n1, uint32_t n2h, uint32_t c, f32x4 v, float sc) {
     const uint32_t pair = n1 * n2h + (c >> 1);

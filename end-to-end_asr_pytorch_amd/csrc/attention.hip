@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
                                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
                                                                       float* __restrict__ lse, int h, int Lq, int Lk,
                                                                       const int32_t* __restrict__ k_len, int q_tiles,
-                                                                      asr_dropout_t drop) {
+                                                                      asr_dropout_t drop, const uint32_t* __restrict__ drop_bits) {
     constexpr int QB = NW * 32, PIECES = 8 / NW;   // 1-KiB pieces (8 rows) per wave per operand tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,9 +121,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     const int wave_qlast = q0 + wave * 32 + 31;
     const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
     const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
-    // dropout of the probabilities (attention.py:83): index space [h*B, Lq, Lk] with leading index head*B + b (attention.py:43-49)
-    const uint32_t dsub = DROP ? drop_subkey(drop, (uint32_t)(hd * (gridDim.x / (q_tiles * h)) + b)) : 0u;
-    const uint32_t drow = DROP ? (uint32_t)qrow * (uint32_t)((Lk + 1) >> 1) : 0u;
+    // dropout of the probabilities (attention.py:83): keep bits from the Mk image (asr_common.h), this query's column of it
+    const int lqp = drop_pad128(Lq);
+    const uint32_t* mkp = DROP ? drop_bits + (int64_t)bh * (drop_pad128(Lk) / 32) * lqp + qrow : nullptr;
 
     u32x4 qf[4];
 #pragma unroll
@@ -162,6 +162,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
+        uint32_t wk[2] = {0u, 0u};
+        if (DROP) {   // before the DMA is queued: vmcnt retires in order, queued after it these two words would wait for the whole next tile
+            wk[0] = mkp[(int64_t)(2 * t) * lqp] >> (4 * hh);
+            wk[1] = mkp[(int64_t)(2 * t + 1) * lqp] >> (4 * hh);
+        }
         if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
         const unsigned char* Ks = smem + cur * 2 * 8192;
         const unsigned char* Vs = Ks + 8192;
@@ -231,14 +236,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t pair = drow + (uint32_t)((key0 + hf * 32 + 8 * g + 4 * hh) >> 1);
-                        const uint32_t w0 = drop_word(drop, dsub, pair), w1 = drop_word(drop, dsub, pair + 1);
-                        st[hf][4 * g] = drop_keep_lo(drop, w0) ? st[hf][4 * g] : 0.f;
-                        st[hf][4 * g + 1] = drop_keep_hi(drop, w0) ? st[hf][4 * g + 1] : 0.f;
-                        st[hf][4 * g + 2] = drop_keep_lo(drop, w1) ? st[hf][4 * g + 2] : 0.f;
-                        st[hf][4 * g + 3] = drop_keep_hi(drop, w1) ? st[hf][4 * g + 3] : 0.f;
-                    }
+                    for (int i = 0; i < 16; ++i) st[hf][i] = drop_and(st[hf][i], wk[hf], 8 * (i >> 2) + (i & 3));
             }
 
             // O^T += V^T . P^T : V^T fragments by transposing reads of the row-major V tile.
@@ -289,14 +287,54 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     }
 }
 
+// ---- dropout keep bits of one attention call, both images (asr_common.h) ----
+// A wave owns 32 queries x 64 keys with the forward kernel's element ownership (lane = query r, half hh; keys hf*32 + 8g + 4hh + x),
+// hashes its 16 words, and assembles: its nibbles -> with lane ^ 32 the two full 32-key words of query r (Mk); a 5-step 32 x 32 bit
+// transpose across each 32-lane half turns "word of query r" into "word of key c" (Mq).  Both stores are fully coalesced.
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(uint32_t* __restrict__ bits, int Bn, int h, int Lq, int Lk, asr_dropout_t drop) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.z, b = bh / h, hd = bh - b * h;
+    const int lqp = drop_pad128(Lq), lkp = drop_pad128(Lk);
+    const int qw = blockIdx.y * 4 + wave, qrow = qw * 32 + r, key0 = blockIdx.x * 64;
+    if (key0 >= Lk || qw * 32 >= Lq) return;                               // padding only: its bits are unspecified
+    const uint32_t dsub = drop_subkey(drop, (uint32_t)(hd * Bn + b));      // leading index head*B + b (attention.py:43-49)
+    const uint32_t drow = (uint32_t)qrow * (uint32_t)((Lk + 1) >> 1);
+    uint32_t mine[2] = {0u, 0u};
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t pair = drow + (uint32_t)((key0 + hf * 32 + 8 * g + 4 * hh) >> 1);
+            const uint32_t w0 = drop_word(drop, dsub, pair), w1 = drop_word(drop, dsub, pair + 1);
+            const uint32_t nib = (drop_keep_lo(drop, w0) ? 1u : 0u) | (drop_keep_hi(drop, w0) ? 2u : 0u) |
+                                 (drop_keep_lo(drop, w1) ? 4u : 0u) | (drop_keep_hi(drop, w1) ? 8u : 0u);
+            mine[hf] |= nib << (8 * g + 4 * hh);
+        }
+    const uint32_t full0 = mine[0] | (uint32_t)__shfl_xor((int)mine[0], 32, 64);
+    const uint32_t full1 = mine[1] | (uint32_t)__shfl_xor((int)mine[1], 32, 64);
+    uint32_t x = hh ? full1 : full0;       // lanes 0..31: keys key0..+31 of query r; lanes 32..63: keys key0+32..+63
+    const int64_t BH = gridDim.z;
+    bits[((int64_t)bh * (lkp / 32) + (key0 >> 5) + hh) * lqp + qrow] = x;
+    // 32 x 32 bit transpose over the 32 lanes of each half (rows = lanes, columns = bit positions)
+#pragma unroll
+    for (int j = 16; j >= 1; j >>= 1) {
+        const uint32_t m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
+        const uint32_t y = (uint32_t)__shfl_xor((int)x, j, 64);
+        if (r & j) x ^= ((y >> j) ^ x) & m;            // lower-left block <- partner's upper-right
+        else       x ^= (((x >> j) ^ y) & m) << j;     // upper-right block <- partner's lower-left
+    }
+    uint32_t* mq = bits + BH * (lkp / 32) * lqp;
+    mq[((int64_t)bh * (lqp / 32) + qw) * lkp + key0 + hh * 32 + r] = x;
+}
+
 template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B,
-                                  int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop) {
+                                  int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop, const uint32_t* drop_bits) {
     const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);
     dim3 grid(B * h * q_tiles), block(NW * 64);
     {
 #define LAUNCH_V2(C, D)                                                                                                        \
     hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,             \
-                       (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop)
+                       (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits)
         if (causal) { if (drop.thr16) LAUNCH_V2(true, true); else LAUNCH_V2(true, false); }
         else        { if (drop.thr16) LAUNCH_V2(false, true); else LAUNCH_V2(false, false); }
 #undef LAUNCH_V2
@@ -307,9 +345,22 @@ template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, c
 
 }  // namespace
 
+extern "C" int64_t asr_attention_dropmask_words(int B, int h, int Lq, int Lk) { return 2 * drop_mk_words(B * h, Lq, Lk); }
+
+extern "C" int asr_attention_dropmask(void* stream, asr_dropout_t drop, int B, int h, int Lq, int Lk, uint32_t* bits) {
+    ASR_REQUIRE(bits && B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_dropmask: bad args");
+    ASR_REQUIRE(drop.thr16 > 0 && drop.thr16 < 65536u, ASR_ERR_ARG, "attention_dropmask: thr16 must be in (0, 65536)");
+    hipLaunchKernelGGL(attn_dropmask_kernel, dim3(drop_pad128(Lk) / 64, drop_pad128(Lq) / 128, B * h), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), bits, B, h, Lq, Lk, drop);
+    ASR_LAUNCH_CHECK("attention_dropmask");
+    return 0;
+}
+
 extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
-                                 int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop) {
+                                 int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop,
+                                 const uint32_t* drop_bits) {
     ASR_REQUIRE(q && k && v && ctx, ASR_ERR_ARG, "attention: null pointer");
+    ASR_REQUIRE(!drop.thr16 || drop_bits, ASR_ERR_ARG, "attention: dropout needs the keep-bit images (asr_attention_dropmask)");
     ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "attention: dropout thr16 must be < 65536");
     ASR_REQUIRE(!(drop.thr16 && dtype != ASR_BF16), ASR_ERR_UNSUPPORTED, "attention: dropout runs on the bf16 (training) path only");
     ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention: B=%d h=%d Lq=%d Lk=%d", B, h, Lq, Lk);
@@ -324,7 +375,7 @@ extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, con
         return 0;
     }
     ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
-    if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop);
-    if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop);
-    return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop);
+    if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+    if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+    return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
 }

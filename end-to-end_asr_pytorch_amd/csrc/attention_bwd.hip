@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dq_out, int64_t ldq,
                                                                  int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int q_tiles,
-                                                                 float scale, asr_dropout_t drop) {
+                                                                 float scale, asr_dropout_t drop, const uint32_t* __restrict__ drop_bits) {
     constexpr int QB = NW * 32, PIECES = 8 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V], row-major, LDS-DMA filled
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
     const bf16_t* Vb = V + (int64_t)bh * Lk * 64;
     const int64_t tok = ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;  // token-major row of this lane's query
-    const uint32_t dsub = DROP ? drop_subkey(drop, (uint32_t)(hd * (gridDim.x / (q_tiles * h)) + b)) : 0u;
-    const uint32_t drow = DROP ? (uint32_t)qrow * (uint32_t)((Lk + 1) >> 1) : 0u;
+    const int lqp = drop_pad128(Lq);
+    const uint32_t* mkp = DROP ? drop_bits + (int64_t)bh * (drop_pad128(Lk) / 32) * lqp + qrow : nullptr;   // Mk image (asr_common.h)
     const float dsc = DROP ? drop_scale(drop) : 1.f;
 
     bf16x8 qf[4], dof[4];
@@ -138,6 +138,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * 64, cur = t & 1;
+        uint32_t wk[2] = {0u, 0u};
+        if (DROP) {   // ahead of the DMA: vmcnt retires in order, queued behind it these two words would wait for the whole next tile
+            wk[0] = mkp[(int64_t)(2 * t) * lqp] >> (4 * hh);
+            wk[1] = mkp[(int64_t)(2 * t + 1) * lqp] >> (4 * hh);
+        }
         if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
         const unsigned char* Ks = smem + cur * 16384;
         const unsigned char* Vs = Ks + 8192;
@@ -155,22 +160,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                 st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
                 dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
             }
-            if (DROP) {   // dP = dropout mask * (dO . V^T)
+            if (DROP) {   // dP = dropout mask * (dO . V^T); the 1/keep scale rides on the fma below
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint32_t pair = drow + (uint32_t)((key0 + hf * 32 + 8 * g + 4 * hh) >> 1);
-                    const uint32_t w0 = drop_word(drop, dsub, pair), w1 = drop_word(drop, dsub, pair + 1);
-                    dp[hf][4 * g] = drop_keep_lo(drop, w0) ? dp[hf][4 * g] * dsc : 0.f;
-                    dp[hf][4 * g + 1] = drop_keep_hi(drop, w0) ? dp[hf][4 * g + 1] * dsc : 0.f;
-                    dp[hf][4 * g + 2] = drop_keep_lo(drop, w1) ? dp[hf][4 * g + 2] * dsc : 0.f;
-                    dp[hf][4 * g + 3] = drop_keep_hi(drop, w1) ? dp[hf][4 * g + 3] * dsc : 0.f;
-                }
+                for (int i = 0; i < 16; ++i) dp[hf][i] = drop_and(dp[hf][i], wk[hf], 8 * (i >> 2) + (i & 3));
             }
             if (interior) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float p = __builtin_amdgcn_exp2f(st[hf][i] - my_lse2);
-                    st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
+                    st[hf][i] = p * (DROP ? __builtin_fmaf(dp[hf][i], dsc, -dl) : dp[hf][i] - dl);  // dS^T
                 }
             } else {
 #pragma unroll
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                     const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                     const bool bad = key >= kl || (CAUSAL && key > qrow) || !qok;
                     const float p = bad ? 0.f : __builtin_amdgcn_exp2f(st[hf][i] - my_lse2);
-                    st[hf][i] = p * (dp[hf][i] - dl);  // dS^T
+                    st[hf][i] = p * (DROP ? __builtin_fmaf(dp[hf][i], dsc, -dl) : dp[hf][i] - dl);  // dS^T
                 }
             }
         }
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               bf16_t* __restrict__ dk_out, bf16_t* __restrict__ dv_out, int64_t ldkv,
                                                               int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int k_tiles,
-                                                              asr_dropout_t drop) {
+                                                              asr_dropout_t drop, const uint32_t* __restrict__ drop_bits) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 + 1024];   // [buf][Q|dO] row-major + [buf][lse|delta]
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,9 +223,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const bf16_t* Qb = Q + (int64_t)bh * Lq * 64;
     const bf16_t* dOb = dO + (int64_t)b * Lq * (h * 64) + hd * 64;   // token-major rows, ld = h*64
     const int64_t ldo = (int64_t)h * 64;
-    const uint32_t dsub = DROP ? drop_subkey(drop, (uint32_t)(hd * (gridDim.x / (k_tiles * h)) + b)) : 0u;
-    const uint32_t lkh = (uint32_t)((Lk + 1) >> 1), dcol = (uint32_t)key >> 1;
-    const bool dodd = key & 1;
+    // Mq image (asr_common.h): after the Mk image; this key's column
+    const int lkp = drop_pad128(Lk), lqp = drop_pad128(Lq);
+    const uint32_t* mqp = DROP ? drop_bits + drop_mk_words(gridDim.x / k_tiles, Lq, Lk) + (int64_t)bh * (lqp / 32) * lkp + key : nullptr;
     const float dsc = DROP ? drop_scale(drop) : 1.f;
 
     bf16x8 kf[4], vf[4];
@@ -260,6 +258,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     __syncthreads();
     for (int t = qt_first; t < nqt; ++t) {
         const int q0 = t * 64, cur = (t - qt_first) & 1;
+        uint32_t wq[2] = {0u, 0u};
+        if (DROP) {   // ahead of the DMA (in-order vmcnt)
+            wq[0] = mqp[(int64_t)(2 * t) * lkp] >> (4 * hh);
+            wq[1] = mqp[(int64_t)(2 * t + 1) * lkp] >> (4 * hh);
+        }
         if (t + 1 < nqt) stage(cur ^ 1, t + 1);
         const unsigned char* Qs = smem + cur * 16384;
         const unsigned char* dOs = Qs + 8192;
@@ -294,33 +297,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 const int ql = hf * 32 + 8 * g + 4 * hh;   // 4 consecutive query rows live in regs 4g..4g+3
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);   // base-2
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + ql);
-                float mk[4] = {1.f, 1.f, 1.f, 1.f};
-                if (DROP) {
-                    // the random word of (query, key pair) serves this lane (even key: low half) and its neighbour lane^1 (odd key:
-                    // high half): each hashes two of the four queries and the pair swaps them with a DPP quad permute
-                    const uint32_t qb = (uint32_t)(q0 + ql + (dodd ? 2 : 0));
-                    const uint32_t wa = drop_word(drop, dsub, qb * lkh + dcol), wb = drop_word(drop, dsub, (qb + 1) * lkh + dcol);
-                    const uint32_t pa = (uint32_t)__shfl_xor((int)wa, 1, 64), pb = (uint32_t)__shfl_xor((int)wb, 1, 64);
-                    const uint32_t w4[4] = {dodd ? pa : wa, dodd ? pb : wb, dodd ? wa : pa, dodd ? wb : pb};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) mk[i] = (((w4[i] >> (dodd ? 16 : 0)) & 0xFFFFu) >= drop.thr16) ? dsc : 0.f;
-                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int q = q0 + ql + i;
                     const bool bad = !interior && (!kok || q >= Lq || (CAUSAL && key > q));
                     const float e = __builtin_amdgcn_exp2f(sq[hf][4 * g + i] - l4[i]);
                     const float p = bad ? 0.f : e;
-                    sq[hf][4 * g + i] = DROP ? p * mk[i] : p;                                          // dropout(P), feeds dV
-                    dp[hf][4 * g + i] = p * ((DROP ? dp[hf][4 * g + i] * mk[i] : dp[hf][4 * g + i]) - d4[i]);     // dS
+                    if (DROP) {
+                        sq[hf][4 * g + i] = drop_and(p * dsc, wq[hf], 8 * g + i);                                                // dropout(P), feeds dV
+                        dp[hf][4 * g + i] = p * __builtin_fmaf(drop_and(dp[hf][4 * g + i], wq[hf], 8 * g + i), dsc, -d4[i]);     // dS
+                    } else {
+                        sq[hf][4 * g + i] = p;
+                        dp[hf][4 * g + i] = p * (dp[hf][4 * g + i] - d4[i]);
+                    }
                 }
             }
-            if (DROP) out_products(hf);   // one 32-query half at a time: the hash temporaries need the registers of the other half
         }
-        if (!DROP) {
-            out_products(0);
-            out_products(1);
-        }
+        out_products(0);
+        out_products(1);
         __syncthreads();   // next tile's DMA landed; `cur` may be overwritten
     }
     if (key < Lk) {   // keys in [kl, Lk) get exact zeros
@@ -334,8 +328,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
 extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                     const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,
-                                    const int32_t* k_len, int causal, float scale, asr_dropout_t drop) {
+                                    const int32_t* k_len, int causal, float scale, asr_dropout_t drop, const uint32_t* drop_bits) {
     ASR_REQUIRE(q && k && v && o && d_o && lse && delta && dq, ASR_ERR_ARG, "attention_bwd_dq: null pointer");
+    ASR_REQUIRE(!drop.thr16 || drop_bits, ASR_ERR_ARG, "attention_bwd_dq: dropout needs the keep-bit images (asr_attention_dropmask)");
     ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "attention_bwd_dq: dropout thr16 must be < 65536");
     ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd_dq: bad sizes");
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(o, 16) && asr_aligned(d_o, 16) &&
@@ -344,7 +339,7 @@ extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, 
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *O = (const bf16_t*)o, *dO = (const bf16_t*)d_o;
 #define LAUNCH_DQ2(NW, C, D)                                                                                              \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, C, D>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, delta, \
-                       (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale, drop)
+                       (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale, drop, drop_bits)
 #define LAUNCH_DQ(NW)                                                                                  \
     do {                                                                                               \
         const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);                                            \
@@ -362,8 +357,9 @@ extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, 
 
 extern "C" int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void* v, const void* d_o, const float* lse,
                                      const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
-                                     const int32_t* k_len, int causal, asr_dropout_t drop) {
+                                     const int32_t* k_len, int causal, asr_dropout_t drop, const uint32_t* drop_bits) {
     ASR_REQUIRE(q && k && v && d_o && lse && delta && dk && dv, ASR_ERR_ARG, "attention_bwd_dkv: null pointer");
+    ASR_REQUIRE(!drop.thr16 || drop_bits, ASR_ERR_ARG, "attention_bwd_dkv: dropout needs the keep-bit images (asr_attention_dropmask)");
     ASR_REQUIRE(drop.thr16 < 65536u, ASR_ERR_ARG, "attention_bwd_dkv: dropout thr16 must be < 65536");
     ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_bwd_dkv: bad sizes");
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(d_o, 16) && asr_aligned(dk, 8) &&
@@ -373,7 +369,7 @@ extern "C" int asr_attention_bwd_dkv(void* stream, const void* q, const void* k,
     const int k_tiles = (Lk + 127) / 128;
 #define LAUNCH_DKV(C, D)                                                                                                         \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<C, D>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk, \
-                       (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles, drop)
+                       (bf16_t*)dv, ldkv, h, Lq, Lk, k_len, k_tiles, drop, drop_bits)
     if (causal) { if (drop.thr16) LAUNCH_DKV(true, true); else LAUNCH_DKV(true, false); }
     else { if (drop.thr16) LAUNCH_DKV(false, true); else LAUNCH_DKV(false, false); }
 #undef LAUNCH_DKV
@@ -383,7 +379,9 @@ extern "C" int asr_attention_bwd_dkv(void* stream, const void* q, const void* k,
 
 extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                  const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
-                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop) {
-    if (int rc = asr_attention_bwd_dq(stream, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, causal, scale, drop)) return rc;
-    return asr_attention_bwd_dkv(stream, q, k, v, d_o, lse, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, causal, drop);
+                                 int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop,
+                                 const uint32_t* drop_bits) {
+    if (int rc = asr_attention_bwd_dq(stream, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, causal, scale, drop, drop_bits))
+        return rc;
+    return asr_attention_bwd_dkv(stream, q, k, v, d_o, lse, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
 }

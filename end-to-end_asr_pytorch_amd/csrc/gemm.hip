@@ -308,9 +308,13 @@ template <typename CT> struct EpiHeads {
 // of the LDS the K loop has finished with) the 64 x 64 sub-tile is transposed through LDS instead: epilogue math in the
 // accumulator layout, XOR-swizzled LDS image, then 16 bytes per lane with 8 (bf16) / 16 (f32) adjacent lanes covering a
 // row's whole 128 / 256 bytes.
-template <typename Epi, int SCRB = 4096>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_loads` runs exactly once, right after the epilogue has ISSUED its first global reads (bias, sign bits, the first pass's
+// addend / mask): the persistent kernels queue the next output tile's LDS-DMA there.  vmcnt retires in order, so with the DMA
+// queued earlier (before the last K-tile's multiply) every one of those small reads had to wait for the whole prefetch first.
+template <typename Epi, int SCRB = 4096, typename Hook = NoHook>
 __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int q4,
-                                             unsigned char* scratch = nullptr) {
+                                             unsigned char* scratch = nullptr, Hook after_loads = Hook()) {
     if (scratch && epi.wide(n0)) {
         const int lane = q4 * 16 + r16;
         const int mw = m0 + wm * 64, nw = n0 + wn * 64;
@@ -322,6 +326,18 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
         if (epi.has_bias()) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = epi.ld_bias(ncol + 16 * j);
+        }
+        // sign-bit mask (bf16 outputs): one byte = the 8 consecutive columns a lane stores in the read-back below; all 8 byte
+        // loads of the sub-tile (rows lane / 8 + 8 it) go out now, ahead of everything else
+        unsigned bt_all[8];
+        if (epi.has_bits_in()) {
+            const int mf = mw + (lane >> 3);
+            const unsigned char* bp = epi.bits_in_ptr(mf, nw + (lane & 7) * 8);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                bt_all[it] = (mf + it * 8 < epi.M) ? (unsigned)*bp : 0u;
+                bp += 8 * epi.ld_bits_();
+            }
         }
         auto pass_rows = [&](auto IBc, int pass) {
             constexpr int IB = decltype(IBc)::value;                     // 16-row blocks of the sub-tile handled by this pass
@@ -350,18 +366,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mk[ii][j] = epi.get_mask(min(mw + (pass * IB + ii) * 16 + r16, epi.M - 1), ncol + 16 * j);
             }
-            // sign-bit mask (bf16 outputs): one byte = the 8 consecutive columns a lane stores in the read-back below; the byte
-            // loads go out now, ahead of the LDS round trip
-            unsigned bt[2 * IB];
-            if (epi.has_bits_in()) {
-                const int mf = mw + pass * IB * 16 + (lane >> 3);
-                const unsigned char* bp = epi.bits_in_ptr(mf, nw + (lane & 7) * 8);
-#pragma unroll
-                for (int it = 0; it < 2 * IB; ++it) {
-                    bt[it] = (mf + it * 8 < epi.M) ? (unsigned)*bp : 0u;
-                    bp += 8 * epi.ld_bits_();
-                }
-            }
+            if (pass == 0) after_loads();
 #pragma unroll
             for (int ii = 0; ii < IB; ++ii) {
                 const int i = pass * IB + ii, rl = ii * 16 + r16;
@@ -399,7 +404,8 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                     if (epi.has_bits_in()) {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
-                            const unsigned lo = (bt[it] >> (2 * x)) & 1u, hi = (bt[it] >> (2 * x + 1)) & 1u;
+                            const unsigned bt = bt_all[(pass * 2 * IB + it) & 7];
+                            const unsigned lo = (bt >> (2 * x)) & 1u, hi = (bt >> (2 * x + 1)) & 1u;
                             d[x] &= ((0u - lo) & 0xFFFFu) | ((0u - hi) & 0xFFFF0000u);
                         }
                     }
@@ -444,6 +450,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
         }
         return;
     }
+    after_loads();
     if (epi.fast(n0)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -633,12 +640,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) {
-                stage(cur ^ 1, kt + 1);
-            } else if (tile + step < end) {       // stream on into the next output tile
-                set_tile(tile + step);
-                stage(cur ^ 1, 0);
-            }
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
             const unsigned char* As = smem + cur * 2 * TILE;
             const unsigned char* Bs = As + TILE;
 #pragma unroll
@@ -660,9 +662,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
             __syncthreads();   // next K-tile landed (the barrier's fence waits for the outstanding LDS-DMA) and `cur` is free to overwrite
             cur ^= 1;
         }
-        // the buffer just multiplied (cur ^ 1 after the toggle) is free until the next tile's second K-tile is staged into it
-        run_epilogue(epi, acc, tm * BM, tn * BN, wm, wn, r16, q4, smem + (cur ^ 1) * 2 * TILE + wave * 8192);
-        if (tile + step < end) __syncthreads();
+        // the buffer just multiplied (cur ^ 1 after the toggle) is the epilogue's scratch; buffer `cur` (multiplied one K-tile
+        // earlier, every wave is past the barrier since) takes the next output tile's first K-tile, queued from inside the epilogue
+        const bool more = tile + step < end;
+        run_epilogue(epi, acc, tm * BM, tn * BN, wm, wn, r16, q4, smem + (cur ^ 1) * 2 * TILE + wave * 8192, [&]() {
+            if (more) {
+                set_tile(tile + step);
+                stage(cur, 0);
+            }
+        });
+        if (more) __syncthreads();   // drains the DMA and frees the scratch
     }
 }
 
@@ -796,29 +805,39 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, in
 
 template <typename Epi>
 __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
-                                                           int64_t ldb, int M, int N, int K, int tiles_n, int nwg, Epi epi) {
+                                                           int64_t ldb, int M, int N, int K, int tiles_n, int ntiles, Epi epi) {
     constexpr int KT = 64, TILE = BM * ROWB;   // 16 KiB: A tile [128 m][64 k]; B tile [64 k][128 n]
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, q4 = lane >> 4;
+    // persistent, like gemm_nt_glds_kernel: <= 2 workgroups per CU, each walking its XCD's contiguous tile range with the K-tile
+    // stream running across tile boundaries (one workgroup per tile left the first K-tile's latency and the epilogue exposed:
+    // the K = 256 hidden-gradient GEMM spent 59 % of its wave cycles waiting)
+    int first, end, step;
+    {
+        const int G = gridDim.x, xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        end = lo + q + (xcd < r ? 1 : 0);
+        step = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
+        first = lo + li;
+    }
+    if (first >= end) return;
+    const int nk = K / KT;
 
     const bf16_t* asrc[4];
     const bf16_t* bsrc[4];
+    auto set_tile = [&](int tile) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int arow = 8 * (wave * 4 + i) + (lane >> 3);                   // A piece: 8 rows x 128 B
-        asrc[i] = A + (int64_t)min(m0 + arow, M - 1) * lda + (((lane & 7) ^ (arow & 7)) * 8);
-        const int brow = 4 * (wave * 4 + i) + (lane >> 4);                   // B piece: 4 k-rows x 256 B
-        bsrc[i] = Bm + (int64_t)brow * ldb + n0 + (((lane & 15) ^ tr_sw(brow)) * 8);
-    }
+        for (int i = 0; i < 4; ++i) {
+            const int arow = 8 * (wave * 4 + i) + (lane >> 3);                   // A piece: 8 rows x 128 B
+            asrc[i] = A + (int64_t)min(tm * BM + arow, M - 1) * lda + (((lane & 7) ^ (arow & 7)) * 8);
+            const int brow = 4 * (wave * 4 + i) + (lane >> 4);                   // B piece: 4 k-rows x 256 B
+            bsrc[i] = Bm + (int64_t)brow * ldb + tn * BN + (((lane & 15) ^ tr_sw(brow)) * 8);
+        }
+    };
     auto stage = [&](int buf, int kt) {
         unsigned char* base = smem + buf * 2 * TILE;
 #pragma unroll
@@ -830,38 +849,51 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
                                              (__attribute__((address_space(3))) void*)(base + TILE + p * 1024), 16, 0, 0);
         }
     };
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    const int nk = K / KT;
+    set_tile(first);
     stage(0, 0);
+    int cur = 0;
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const unsigned char* As = smem + cur * 2 * TILE;
-        const unsigned char* Bt = As + TILE;
+    for (int tile = first; tile < end; tile += step) {
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int chunk = g * 4 + q4;
-            const int row0 = g * 32 + 8 * q4 + (r16 >> 2), csub = 4 * (r16 & 3);
-            u32x4 a[4], b[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int arow = wm * 64 + i * 16 + r16;
-                a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
-                b[i] = tr_frag(Bt, row0, wn * 64 + i * 16 + csub);
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            const unsigned char* As = smem + cur * 2 * TILE;
+            const unsigned char* Bt = As + TILE;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int chunk = g * 4 + q4;
+                const int row0 = g * 32 + 8 * q4 + (r16 >> 2), csub = 4 * (r16 & 3);
+                u32x4 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int arow = wm * 64 + i * 16 + r16;
+                    a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                    b[i] = tr_frag(Bt, row0, wn * 64 + i * 16 + csub);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
+            __syncthreads();
+            cur ^= 1;
         }
-        __syncthreads();
+        // the buffer just multiplied (cur ^ 1 after the toggle) is the epilogue's scratch; buffer `cur` (multiplied one K-tile
+        // earlier, every wave is past the barrier since) takes the next output tile's first K-tile, queued from inside the epilogue
+        const bool more = tile + step < end;
+        run_epilogue(epi, acc, tm * BM, tn * BN, wm, wn, r16, q4, smem + (cur ^ 1) * 2 * TILE + wave * 8192, [&]() {
+            if (more) {
+                set_tile(tile + step);
+                stage(cur, 0);
+            }
+        });
+        if (more) __syncthreads();   // drains the DMA and frees the scratch
     }
-    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4, smem + wave * 8192);   // the loop's last barrier freed both buffers
 }
 
 template <typename AT, typename CT, typename Epi>
@@ -1012,8 +1044,10 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
+        static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU, persistent
+        const int pwg = nwg < max_wg ? nwg : max_wg;
 #define LAUNCH_NN_TR(E)                                                                                                          \
-    hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E)>), dim3(nwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, \
+    hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E)>), dim3(pwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, \
                        K, tiles_n, nwg, E)
         const unsigned mode = epi.wide_ok ? dense_mode(epi) : 0xffu;
         if (mode == 4u) LAUNCH_NN_TR(dense_as<4u>(epi));                 // dX = dY . W + residual gradient (f32)

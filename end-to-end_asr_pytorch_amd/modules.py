@@ -26,6 +26,7 @@ from . import ops
 
 _PRECISION = os.environ.get("ASR_AMD_PRECISION", "bf16")
 _LOG2E = 1.4426950408889634
+_MASK_PREFETCH = os.environ.get("ASR_AMD_MASK_PREFETCH", "1") != "0"
 
 
 def set_precision(p):
@@ -275,7 +276,7 @@ class MultiheadAttention(_Cached):
         nn.init.xavier_normal_(self.fc.weight)
         self.dropout_rate = dropout
 
-    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None):
+    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None, attn_drop=None):
         """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act.
         kv_pre = (k, v, dkv) when the caller has already projected the keys / values (_CrossKV: one GEMM for all decoder layers);
         dkv() -> (dk, dv) views the backward writes into, the K/V weight and input gradients are then the caller's business."""
@@ -296,8 +297,14 @@ class MultiheadAttention(_Cached):
                                     self._b("bkv", (self.w_ks.bias, self.w_vs.bias)), 2, B, Lk, h, 1.0)
                 k, v = kv[0], kv[1]
         rec = _TAPE is not None
-        dp_attn, dp_fc = _drop(self, "attention.dropout"), _drop(self, "dropout")   # attention.py:83, :59
-        ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec, drop=dp_attn)
+        dp_fc = _drop(self, "dropout")   # attention.py:59
+        if attn_drop is not None:        # (asr_dropout_t, keep bits, event): hashed ahead of time on a side stream (Encoder._attn_masks)
+            dp_attn, dbits, ev = attn_drop
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            dp_attn = _drop(self, "attention.dropout")   # attention.py:83
+            dbits = ops.attention_dropmask(dp_attn, B, h, Lq, Lk, q.device)      # hashed once; forward, dQ and dK/dV kernels read bits
+        ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec, drop=dp_attn, drop_bits=dbits)
         o = ops.gemm_nt(ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,)), self._b("bfc", (self.fc.bias,)))
         y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
                                                  want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec,
@@ -305,11 +312,11 @@ class MultiheadAttention(_Cached):
         y = Act(y32, y16, B, Lq)
         if rec:
             self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc,
-                            None if kv_pre is None else kv_pre[2])
+                            None if kv_pre is None else kv_pre[2], dbits)
         return y
 
     def _record_bw(self, xq, xkv, q, k, v, ctx, lse, s_sum, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc,
-                   dkv_pre=None):
+                   dkv_pre=None, dbits=None):
         h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
         hd = h * 64
         ln, fc = self.layer_norm, self.fc
@@ -325,7 +332,7 @@ class MultiheadAttention(_Cached):
             if xkv is xq:
                 dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:],
-                                  drop=dp_attn)
+                                  drop=dp_attn, drop_bits=dbits)
                 ops.gemm_tn(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
                 _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
             else:
@@ -335,7 +342,7 @@ class MultiheadAttention(_Cached):
                 else:
                     dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
                     dk_out, dv_out = dkv[:, :hd], dkv[:, hd:]
-                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn)
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn, drop_bits=dbits)
                 ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
                 _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
                 if dkv_pre is None:
@@ -415,8 +422,8 @@ class EncoderLayer(nn.Module):
         self.slf_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
-    def _impl(self, x, lens, causal=False):
-        x = self.slf_attn._impl(x, x, lens, causal, lens)   # `*= non_pad_mask` fused into the LN kernel
+    def _impl(self, x, lens, causal=False, attn_drop=None):
+        x = self.slf_attn._impl(x, x, lens, causal, lens, attn_drop=attn_drop)   # `*= non_pad_mask` fused into the LN kernel
         return self.pos_ffn._impl(x, lens)
 
     def forward(self, enc_input, non_pad_mask=None, slf_attn_mask=None, lengths=None):
@@ -461,9 +468,32 @@ class Encoder(_Cached):
                     _acc(x_in, ops.gemm_nn(ds16, self._w("lin", (lin.weight,))))
 
             _TAPE.push(bw, (lin.weight, lin.bias, ln.weight, ln.bias))
-        for layer in self.layer_stack:
-            x = layer._impl(x, lens)
+        masks = self._attn_masks(B, L, y32.device)
+        for i, layer in enumerate(self.layer_stack):
+            x = layer._impl(x, lens, attn_drop=masks[i])
         return x
+
+    def _attn_masks(self, B, L, device):
+        """Attention-dropout keep bits of every layer, hashed on a side stream while the main stream runs the layers before it.
+        The masks depend on (seed, site, call count, shape) only - not on data - and the hash is pure integer VALU work (~60 us
+        per [32, 4, 1000, 1000] layer alone on the chip), which co-runs with the MFMA / HBM-bound kernels of the main stream."""
+        none = [None] * len(self.layer_stack)
+        if not (_MASK_PREFETCH and self.training and device.type == "cuda"):
+            return none
+        drops = [_drop(layer.slf_attn, "attention.dropout") for layer in self.layer_stack]
+        if all(d is None for d in drops):
+            return none
+        main, aux = torch.cuda.current_stream(), ops.aux_stream(device, slot=1)
+        out = []
+        with torch.cuda.stream(aux):
+            for layer, d in zip(self.layer_stack, drops):
+                bits = ops.attention_dropmask(d, B, layer.slf_attn.n_head, L, L, device)
+                if bits is not None:
+                    bits.record_stream(main)
+                ev = torch.cuda.Event()
+                ev.record(aux)
+                out.append((d, bits, ev))
+        return out
 
     def forward(self, padded_input, input_lengths):
         lens = ops.as_i32(input_lengths, padded_input.device)

@@ -130,17 +130,31 @@ def dropout_apply(x, drop, N0, N1, N2, out=None):
     return y
 
 
-def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False, drop=None):
-    """q [B,h,Lq,64] (pre-scaled), k/v [B,h,Lk,64] -> ctx [B,Lq,h*64] (same dtype), lse [B,h,Lq] or None."""
+def attention_dropmask(drop, B, h, Lq, Lk, device):
+    """Keep-bit images of one attention call's dropout (asr_hip.h: asr_attention_dropmask): hashed once, read by the forward and
+    both backward kernels.  -> uint32 tensor, or None when `drop` is off."""
+    if drop is None or drop.thr16 == 0:
+        return None
+    bits = torch.empty((int(lib().asr_attention_dropmask_words(B, h, Lq, Lk)),), device=device, dtype=torch.int32)
+    with _timed("attention_dropmask[B%d h%d %dx%d]" % (B, h, Lq, Lk), 0.0):
+        check(lib().asr_attention_dropmask(_stream(), drop, B, h, Lq, Lk, _p(bits)), "asr_attention_dropmask")
+    return bits
+
+
+def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False, drop=None, drop_bits=None):
+    """q [B,h,Lq,64] (pre-scaled), k/v [B,h,Lk,64] -> ctx [B,Lq,h*64] (same dtype), lse [B,h,Lq] or None.
+    drop_bits: attention_dropmask(...) of this call (made here when omitted; pass it to share it with attention_bwd)."""
     _req_cuda(q, k, v, k_len)
     B, h, Lq, dk = q.shape
     Lk = k.shape[2]
+    if drop_bits is None:
+        drop_bits = attention_dropmask(drop, B, h, Lq, Lk, q.device)
     assert dk == 64 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
     ctx = torch.empty((B, Lq, h * 64), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32) if need_lse else None
     with _timed("attention_fwd[B%d h%d %dx%d]" % (B, h, Lq, Lk), 4.0 * B * h * 64 * Lq * Lk):
         check(lib().asr_attention_fwd(_stream(), _p(q), _p(k), _p(v), dtype_code(q), _p(ctx), _p(lse), B, h, Lq, Lk, _p(k_len),
-                                      1 if causal else 0, _d(drop)), "asr_attention_fwd")
+                                      1 if causal else 0, _d(drop), _p(drop_bits)), "asr_attention_fwd")
     return ctx, lse
 
 
@@ -230,10 +244,11 @@ _AUX = {}
 CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "1"))
 
 
-def aux_stream(device, priority=0):
-    """A side stream per (device, priority): -1 for latency-bound work beside an HBM-bound pass (pipelined CTC forward), 0 for
-    bulk work that should fill the CUs a run of small kernels leaves idle (the trainer's CTC branch beside the decoder)."""
-    key = (torch.device(device).index, priority)
+def aux_stream(device, priority=0, slot=0):
+    """A side stream per (device, priority, slot): -1 for latency-bound work beside an HBM-bound pass (pipelined CTC forward), 0 for
+    bulk work that should fill the CUs a run of small kernels leaves idle (the trainer's CTC branch beside the decoder; slot 1:
+    the encoder's dropout-mask hashing beside its GEMMs)."""
+    key = (torch.device(device).index, priority, slot)
     if key not in _AUX:
         _AUX[key] = torch.cuda.Stream(device=device, priority=priority)
     return _AUX[key]
@@ -426,7 +441,7 @@ def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, wa
     return ds, ds16
 
 
-def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out, drop=None):
+def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out, drop=None, drop_bits=None):
     """q [B,h,Lq,64], k/v [B,h,Lk,64] bf16; ctx, d_ctx token-major bf16 [B,Lq,h*64]; dq_out / dk_out / dv_out are bf16 views with
     row stride (elements) dq_out.stride(0) / dk_out.stride(0) into token-major gradient buffers (last dim = h*64)."""
     _req_cuda(q, k, v, ctx, d_ctx, lse)
@@ -435,16 +450,19 @@ def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out
     assert q.dtype == torch.bfloat16 and ctx.is_contiguous() and d_ctx.is_contiguous() and d_ctx.dtype == torch.bfloat16
     assert dk_out.stride(0) == dv_out.stride(0) and dq_out.stride(1) == 1 and dk_out.stride(1) == 1
     delta = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32)
+    if drop_bits is None:
+        drop_bits = attention_dropmask(drop, B, h, Lq, Lk, q.device)
     # two kernels, timed separately (algorithmic FLOPs on the 5-product count 10*B*h*64*Lq*Lk: dq owns dQ + one of the two
     # shared recomputed products, dkv owns dV, dK + the other)
     base = float(B) * h * 64 * Lq * Lk
     with _timed("attention_bwd_dq[B%d h%d %dx%d]" % (B, h, Lq, Lk), 4.0 * base):
         check(lib().asr_attention_bwd_dq(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(delta), _p(dq_out),
-                                         dq_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, float(scale), _d(drop)),
-              "asr_attention_bwd_dq")
+                                         dq_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, float(scale), _d(drop),
+                                         _p(drop_bits)), "asr_attention_bwd_dq")
     with _timed("attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, Lq, Lk), 6.0 * base):
         check(lib().asr_attention_bwd_dkv(_stream(), _p(q), _p(k), _p(v), _p(d_ctx), _p(lse), _p(delta), _p(dk_out), _p(dv_out),
-                                          dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, _d(drop)), "asr_attention_bwd_dkv")
+                                          dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, _d(drop), _p(drop_bits)),
+              "asr_attention_bwd_dkv")
 
 
 def embed_bwd(ids, dy, demb, drop=None):

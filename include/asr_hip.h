@@ -102,9 +102,19 @@ int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t ldx, const 
  * lengths, not tensors: key j of batch b is masked iff j >= k_len[b] (utils.py:157-165 / :146-154) or (causal && j > i)
  * (utils.py:135-143).  k_len may be NULL.  lse (f32 [B,h,Lq], BASE-2 log of the softmax denominator incl. max) is written
  * when non-NULL (for backward).
+ * Dropout of the probabilities (attention.py:83; drop.thr16 != 0, bf16 only): the keep decisions are read from `drop_bits`, the
+ * bit images asr_attention_dropmask() wrote for this (drop, B, h, Lq, Lk); the caller keeps the buffer for the backward.
  */
 int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,
-                      int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop);
+                      int B, int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop, const uint32_t* drop_bits);
+
+/* Keep bits of one attention call's dropout, element (n0 = head*B + b, n1 = query, n2 = key) of asr_dropout_t's definition.
+ * One hash pass instead of one per attention kernel (forward, dQ, dK/dV).  `bits`: asr_attention_dropmask_words() uint32 words,
+ * holding the mask twice (Lq, Lk rounded up to 128 = Lqp, Lkp; BH = B*h; words of all-padding tiles unspecified):
+ *   words [0, BH*Lkp/32*Lqp):     Mk[bh][key/32][q]  bit (key & 31)    (query-stationary kernels read along q)
+ *   then  BH*Lqp/32*Lkp words:    Mq[bh][q/32][key]  bit (q & 31)      (the key-stationary dK/dV kernel reads along key) */
+int64_t asr_attention_dropmask_words(int B, int h, int Lq, int Lk);
+int asr_attention_dropmask(void* stream, asr_dropout_t drop, int B, int h, int Lq, int Lk, uint32_t* bits);
 
 /* Backward of asr_attention_fwd (bf16 only).  q,k,v as in the forward; o = the forward's ctx and d_o = its gradient, both
  * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 [B,h,Lq] workspace.  Outputs are token-major bf16:
@@ -113,14 +123,14 @@ int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v,
  * [(b*Lk+j)*ldkv + head*64 + d] - i.e. directly the A operands of the projection GEMMs' backward. */
 int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
-                      int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop);
+                      int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop, const uint32_t* drop_bits);
 /* The two kernels of asr_attention_bwd as separate calls (dq first: it also produces delta, which dkv consumes). */
 int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                          const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,
-                         const int32_t* k_len, int causal, float scale, asr_dropout_t drop);
+                         const int32_t* k_len, int causal, float scale, asr_dropout_t drop, const uint32_t* drop_bits);
 int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void* v, const void* d_o, const float* lse,
                           const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
-                          const int32_t* k_len, int causal, asr_dropout_t drop);
+                          const int32_t* k_len, int causal, asr_dropout_t drop, const uint32_t* drop_bits);
 
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.

@@ -13,7 +13,7 @@ def header_prototypes():
     src = open(os.path.join(ROOT, "include", "asr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(asr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(asr_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a.strip() for a in m.group(3).split(",")] if m.group(3).strip() != "void" else []
         protos[m.group(2)] = args
     return protos

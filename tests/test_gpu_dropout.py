@@ -132,6 +132,23 @@ def test_attention_dropout_fwd_bwd(B, h, Lq, Lk, causal, ragged):
     np.testing.assert_allclose(N(dkv[:, h * 64:]), to_tok(v.grad).numpy(), **tol)
 
 
+@pytest.mark.parametrize("B,h,Lq,Lk", [(2, 2, 25, 25), (1, 3, 130, 77), (2, 1, 51, 250), (1, 2, 300, 257)])
+def test_attention_dropmask_images_are_bit_exact(B, h, Lq, Lk):
+    """asr_attention_dropmask writes the oracle's keep decisions twice: Mk[bh][key/32][q] (bit key&31) and Mq[bh][q/32][key] (bit q&31)."""
+    bits = ops.attention_dropmask(D(31, 32), B, h, Lq, Lk, DEV)
+    lqp, lkp = (Lq + 127) // 128 * 128, (Lk + 127) // 128 * 128
+    w = bits.cpu().numpy().view(np.uint32)
+    assert w.size == 2 * B * h * (lkp // 32) * lqp
+    mk = w[:w.size // 2].reshape(B * h, lkp // 32, lqp)
+    mq = w[w.size // 2:].reshape(B * h, lqp // 32, lkp)
+    keep_k = ((mk[:, :, None, :] >> np.arange(32, dtype=np.uint32)[None, None, :, None]) & 1).reshape(B * h, lkp, lqp)     # [bh, key, q]
+    keep_q = ((mq[:, :, None, :] >> np.arange(32, dtype=np.uint32)[None, None, :, None]) & 1).reshape(B * h, lqp, lkp)     # [bh, q, key]
+    # oracle mask: [h*B, Lq, Lk] with leading index head*B + b; the device images are indexed bh = b*h + head
+    want = (M((h * B, Lq, Lk), 31, 32).numpy() > 0).reshape(h, B, Lq, Lk).transpose(1, 0, 2, 3).reshape(B * h, Lq, Lk)
+    np.testing.assert_array_equal(keep_q[:, :Lq, :Lk], want)
+    np.testing.assert_array_equal(keep_k[:, :Lk, :Lq].transpose(0, 2, 1), want)
+
+
 def test_dropout_is_rejected_on_the_f32_parity_path():
     q = torch.randn(1, 1, 8, 64, device=DEV)
     with pytest.raises(RuntimeError):

@@ -69,8 +69,12 @@ def bench_attn():
         k = torch.randn(B, h, Lk, 64, device=DEV).bfloat16()
         v = torch.randn(B, h, Lk, 64, device=DEV).bfloat16()
         fl = 4.0 * B * h * 64 * Lq * Lk
-        for drop in (None, ops.Dropout(6554, 1, 2)):
-            t = timeit(lambda: ops.attention_fwd(q, k, v, None, causal, drop=drop))
+        dd = ops.Dropout(6554, 1, 2)
+        t = timeit(lambda: ops.attention_dropmask(dd, B, h, Lq, Lk, DEV))
+        print(json.dumps(dict(op="attention_dropmask", shape=[B, h, Lq, Lk], us=round(t * 1e3, 2))))
+        bits = ops.attention_dropmask(dd, B, h, Lq, Lk, DEV)
+        for drop in (None, dd):
+            t = timeit(lambda: ops.attention_fwd(q, k, v, None, causal, drop=drop, drop_bits=bits if drop else None))
             print(json.dumps(dict(op="attention_fwd", shape=[B, h, Lq, Lk], causal=causal, dropout=0.1 if drop else 0.0, us=round(t * 1e3, 2),
                                   TFLOPs=round(fl / t / 1e9, 1), frac_mfma_peak=round(fl / t / 1e9 / 2500, 4))))
         if Lq == 1000:
@@ -78,8 +82,9 @@ def bench_attn():
             dctx = torch.randn_like(ctx)
             dq = torch.empty(B * Lq, h * 64, device=DEV, dtype=torch.bfloat16)
             dkv = torch.empty(B * Lk, 2 * h * 64, device=DEV, dtype=torch.bfloat16)
-            for drop in (None, ops.Dropout(6554, 1, 2)):
-                t = timeit(lambda: ops.attention_bwd(q, k, v, ctx, dctx, lse, None, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:], drop=drop))
+            for drop in (None, dd):
+                t = timeit(lambda: ops.attention_bwd(q, k, v, ctx, dctx, lse, None, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:], drop=drop,
+                                                     drop_bits=bits if drop else None))
                 print(json.dumps(dict(op="attention_bwd(dq+dkv)", shape=[B, h, Lq, Lk], dropout=0.1 if drop else 0.0, us=round(t * 1e3, 2),
                                       TFLOPs=round(2.5 * fl / t / 1e9, 1), frac_mfma_peak=round(2.5 * fl / t / 1e9 / 2500, 4))))
 

@@ -20,3 +20,24 @@ for _ in range(6):
     ops.gemm_tn(dy, hdn, out=gw2, accumulate=True)                                                 # dW2
     ops.gemm_tn(dh, x, out=gw1, accumulate=True, colsum=gb1)                                       # dW1
 torch.cuda.synchronize()
+
+if "--time" in sys.argv:
+    def t(fn, n=30):
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1000
+    fl = 2.0 * M * D * F
+    for name, fn in [("FFN1 nt relu bits bf16", lambda: ops.gemm_nt_ex(x, w1, b1, out_dtype=torch.bfloat16, relu=True, relu_bits_out=bits)),
+                     ("FFN1 nt relu bf16", lambda: ops.gemm_nt_ex(x, w1, b1, out_dtype=torch.bfloat16, relu=True)),
+                     ("FFN2 nt f32", lambda: ops.gemm_nt(hdn, w2, b2)),
+                     ("dH nn bits bf16", lambda: ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16, relu_bits=bits)),
+                     ("dH nn bf16 (no mask)", lambda: ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16)),
+                     ("dX nn f32", lambda: ops.gemm_nn(dh, w1)),
+                     ("dW2 tn", lambda: ops.gemm_tn(dy, hdn, out=gw2, accumulate=True)),
+                     ("dW1 tn colsum", lambda: ops.gemm_tn(dh, x, out=gw1, accumulate=True, colsum=gb1))]:
+        us = t(fn)
+        print("%-26s %7.1f us  %6.0f TFLOP/s" % (name, us, fl / us / 1e6))
