@@ -316,17 +316,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, in
 #define LNB_RPW_ 2
 #endif
 constexpr int LNB_RPW = LNB_RPW_;             // rows per wave handled TOGETHER: all loads issued up front, reductions interleaved
-constexpr int LNB_ROWS = 4 * LNB_RPW;  // rows per workgroup
+constexpr int LNB_WAVES = 8;                  // waves per workgroup: 256 workgroups x 8 waves fill the chip like 512 x 4 did, with half the
+                                              // contended column atomics at the end (512 workgroups: ~8 us of a 31 us launch)
+constexpr int LNB_ROWS = LNB_WAVES * LNB_RPW;  // rows per workgroup
 
 // MAXJ = float4 column groups per lane: 1 for D <= 256 (the model dimension of every shipped config), 4 up to D = 1024.
 template <int MAXJ>
-__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+__global__ __launch_bounds__(64 * LNB_WAVES) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D,
                                                                 asr_dropout_t drop_x, asr_dropout_t drop_y) {
-    __shared__ float red[3][4][256 * MAXJ];
+    __shared__ float red[3][LNB_WAVES][256 * MAXJ];
     const float scx = drop_scale(drop_x), scy = drop_scale(drop_y);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invD = 1.f / (float)D;
@@ -338,50 +340,73 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         gam[j] = (c < D) ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0, 0, 0, 0};
     }
     // persistent: a bounded number of workgroups stride over the rows keeping the per-column partials in registers, so the
-    // contended dgamma / dbeta / dbias atomics (every workgroup hits the same D addresses) happen once per workgroup, not per 16 rows
-    for (int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS + wave * LNB_RPW; row0 < M; row0 += (int64_t)gridDim.x * LNB_ROWS) {
-    f32x4 d[LNB_RPW][MAXJ], xh[LNB_RPW][MAXJ];
-    float mu[LNB_RPW], rs[LNB_RPW];
-    bool live[LNB_RPW];
-    uint32_t subx[LNB_RPW], tt[LNB_RPW];
-    // phase 1: every load of the wave's rows in flight at once
+    // contended dgamma / dbeta / dbias atomics (every workgroup hits the same D addresses) happen once per workgroup, not per 16 rows.
+    // The rows of iteration i+1 are loaded (into a second register set) BEFORE iteration i is reduced and stored: with the loads
+    // issued only after the previous stores a wave had nothing in flight for most of an iteration, and 8 waves per CU could not
+    // cover that (2.8 TB/s).
+    struct Rows {
+        f32x4 d[LNB_RPW][MAXJ], xh[LNB_RPW][MAXJ];
+        float mu[LNB_RPW], rs[LNB_RPW];
+        int len[LNB_RPW], b[LNB_RPW], t[LNB_RPW];
+        bool live[LNB_RPW];
+    };
+    auto load_rows = [&](Rows& R, int64_t row0) {
+#pragma unroll
+        for (int r = 0; r < LNB_RPW; ++r) {
+            const int64_t row = row0 + r;
+            R.live[r] = row < M;
+            const int64_t rr = R.live[r] ? row : (int64_t)M - 1;
+            R.b[r] = (int)(rr / L);
+            R.t[r] = (int)(rr - (int64_t)R.b[r] * L);
+            R.len[r] = row_len ? row_len[R.b[r]] : L;          // the loads below do not wait for it: masked rows are zeroed afterwards
+            R.mu[r] = mean[rr];
+            R.rs[r] = rstd[rr];
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c = lane * 4 + 256 * j;
+                if (c < D) {
+                    R.d[r][j] = *reinterpret_cast<const f32x4*>(dy + rr * D + c);
+                    R.xh[r][j] = *reinterpret_cast<const f32x4*>(s + rr * D + c);
+                } else {
+                    R.d[r][j] = f32x4{0, 0, 0, 0};
+                    R.xh[r][j] = f32x4{0, 0, 0, 0};
+                }
+            }
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * LNB_ROWS;
+    int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS + wave * LNB_RPW;
+    Rows cur;
+    if (row0 < M) load_rows(cur, row0);
+    for (; row0 < M; row0 += stride) {
+    Rows nxt;
+    const bool more = row0 + stride < M;
+    if (more) load_rows(nxt, row0 + stride);
+    uint32_t subx[LNB_RPW];
 #pragma unroll
     for (int r = 0; r < LNB_RPW; ++r) {
-        const int64_t row = row0 + r;
-        live[r] = row < M;
-        const int64_t rr = live[r] ? row : (int64_t)M - 1;
-        const int b = (int)(rr / L), t = (int)(rr - (int64_t)b * L);
-        const bool keep = live[r] && (row_len ? (t < row_len[b]) : true);
-        mu[r] = mean[rr];
-        rs[r] = rstd[rr];
-        tt[r] = (uint32_t)t;
-        subx[r] = drop_x.thr16 ? drop_subkey(drop_x, (uint32_t)b) : 0u;
-        const uint32_t suby = drop_y.thr16 ? drop_subkey(drop_y, (uint32_t)b) : 0u;
+        const bool keep = cur.live[r] && cur.t[r] < cur.len[r];
+        subx[r] = drop_x.thr16 ? drop_subkey(drop_x, (uint32_t)cur.b[r]) : 0u;
+        const uint32_t suby = drop_y.thr16 ? drop_subkey(drop_y, (uint32_t)cur.b[r]) : 0u;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
-            if (c < D) {
-                d[r][j] = keep ? *reinterpret_cast<const f32x4*>(dy + rr * D + c) : f32x4{0, 0, 0, 0};
-                if (drop_y.thr16) d[r][j] = drop4(drop_y, suby, (uint32_t)t, D >> 1, c, d[r][j], scy);
-                xh[r][j] = *reinterpret_cast<const f32x4*>(s + rr * D + c);
-            } else {
-                d[r][j] = f32x4{0, 0, 0, 0};
-                xh[r][j] = f32x4{0, 0, 0, 0};
-            }
+            if (!keep) cur.d[r][j] = f32x4{0, 0, 0, 0};
+            if (drop_y.thr16 && c < D) cur.d[r][j] = drop4(drop_y, suby, (uint32_t)cur.t[r], D >> 1, c, cur.d[r][j], scy);
         }
     }
-    // phase 2: per-row reductions (independent chains) and outputs
+    // per-row reductions (independent chains) and outputs
     float s1[LNB_RPW], s2[LNB_RPW];
 #pragma unroll
     for (int r = 0; r < LNB_RPW; ++r) {
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            xh[r][j] = (xh[r][j] - mu[r]) * rs[r];
-            ag[j] += d[r][j] * xh[r][j];
-            ab[j] += d[r][j];
-            const f32x4 g = d[r][j] * gam[j];
-            const f32x4 gx = g * xh[r][j];
+            cur.xh[r][j] = (cur.xh[r][j] - cur.mu[r]) * cur.rs[r];
+            ag[j] += cur.d[r][j] * cur.xh[r][j];
+            ab[j] += cur.d[r][j];
+            const f32x4 g = cur.d[r][j] * gam[j];
+            const f32x4 gx = g * cur.xh[r][j];
             a1 += (g[0] + g[1]) + (g[2] + g[3]);
             a2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
         }
@@ -398,16 +423,16 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
     }
 #pragma unroll
     for (int r = 0; r < LNB_RPW; ++r) {
-        if (!live[r]) continue;
+        if (!cur.live[r]) continue;
         const int64_t row = row0 + r;
         const float m1 = s1[r] * invD, m2 = s2[r] * invD;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < D) {
-                f32x4 o = (d[r][j] * gam[j] - m1 - xh[r][j] * m2) * rs[r];
+                f32x4 o = (cur.d[r][j] * gam[j] - m1 - cur.xh[r][j] * m2) * cur.rs[r];
                 *reinterpret_cast<f32x4*>(ds + row * D + c) = o;                                  // gradient wrt the residual
-                if (drop_x.thr16) o = drop4(drop_x, subx[r], tt[r], D >> 1, c, o, scx);           // gradient wrt x (dropout's input)
+                if (drop_x.thr16) o = drop4(drop_x, subx[r], (uint32_t)cur.t[r], D >> 1, c, o, scx);   // gradient wrt x (dropout's input)
                 as[j] += o;
                 if (ds16) {
                     bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
@@ -416,6 +441,7 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
             }
         }
     }
+    if (more) cur = nxt;
     }  // row loop
     // workgroup reduction of the dgamma / dbeta / dbias partials, then one atomic per column
 #pragma unroll
@@ -426,10 +452,13 @@ __global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const float* __r
         *reinterpret_cast<f32x4*>(&red[2][wave][c]) = as[j];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-        atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
-        if (dbias) atomicAdd(dbias + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+    for (int c = threadIdx.x; c < D; c += 64 * LNB_WAVES) {
+        float g = 0.f, bt = 0.f, bs = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNB_WAVES; ++w) { g += red[0][w][c]; bt += red[1][w][c]; bs += red[2][w][c]; }
+        atomicAdd(dgamma + c, g);
+        atomicAdd(dbeta + c, bt);
+        if (dbias) atomicAdd(dbias + c, bs);
     }
 }
 
@@ -563,13 +592,13 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 512;
+    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 256;
     if (blocks > max_blocks) blocks = max_blocks;
     if (D <= 256)
-        hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
     else
-        hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
     ASR_LAUNCH_CHECK("add_layernorm_bwd");
     return 0;
