@@ -70,6 +70,7 @@ struct EpiDense {
     unsigned char* bits_out;
     const unsigned char* bits_in;
     int64_t ld_bits;
+    bool atomic_out;          // split-K (persistent kernels, f32 C, wide path): partial tiles are float-atomically added into a zeroed C
 
     // fast path (kernel-uniform): the tile lies fully inside N and everything is vector-aligned -> no per-element logic
     struct Row { unsigned char* c; const float* add; const bf16_t* mask; };
@@ -114,6 +115,7 @@ struct EpiDense {
     __device__ __forceinline__ bool has_bits_out() const { return bits_out != nullptr; }
     __device__ __forceinline__ Cur cur(int m, int nw) const { return Cur{row_ptr(m, nw)}; }
     __device__ __forceinline__ bool relu() const { return flags & ASR_GEMM_RELU; }
+    __device__ __forceinline__ bool atomic() const { return atomic_out; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
     __device__ __forceinline__ f32x4 get_add(int m, int n) const { return *reinterpret_cast<const f32x4*>(addend + (int64_t)m * ld_add + n); }
     __device__ __forceinline__ bf16x4 get_mask(int m, int n) const { return *reinterpret_cast<const bf16x4*>(relu_mask + (int64_t)m * ld_mask + n); }
@@ -202,6 +204,7 @@ template <unsigned MODE> struct EpiDenseS : EpiDense {
     __device__ __forceinline__ bool has_mask() const { return MODE & 8u; }
     __device__ __forceinline__ bool has_bits_out() const { return MODE & 32u; }
     __device__ __forceinline__ bool has_bits_in() const { return MODE & 64u; }
+    __device__ __forceinline__ bool atomic() const { return MODE & 128u; }
     __device__ __forceinline__ int elem_size() const { return (MODE & 16u) ? 2 : 4; }
     __device__ __forceinline__ unsigned char* row_ptr(int m, int nw) const {
         return reinterpret_cast<unsigned char*>(C) + ((int64_t)m * ldc + nw) * ((MODE & 16u) ? 2 : 4);
@@ -211,7 +214,7 @@ template <unsigned MODE> struct EpiDenseS : EpiDense {
 };
 inline unsigned dense_mode(const EpiDense& e) {
     return (e.bias ? 1u : 0u) | ((e.flags & ASR_GEMM_RELU) ? 2u : 0u) | (e.addend ? 4u : 0u) | (e.relu_mask ? 8u : 0u) |
-           (e.c_dtype == ASR_BF16 ? 16u : 0u) | (e.bits_out ? 32u : 0u) | (e.bits_in ? 64u : 0u);
+           (e.c_dtype == ASR_BF16 ? 16u : 0u) | (e.bits_out ? 32u : 0u) | (e.bits_in ? 64u : 0u) | (e.atomic_out ? 128u : 0u);
 }
 template <unsigned MODE> inline EpiDenseS<MODE> dense_as(const EpiDense& e) {
     EpiDenseS<MODE> r;
@@ -263,6 +266,7 @@ template <typename CT> struct EpiHeads {
     __device__ __forceinline__ const unsigned char* bits_in_ptr(int, int) const { return nullptr; }
     __device__ __forceinline__ unsigned char* bits_out_ptr(int, int) const { return nullptr; }
     __device__ __forceinline__ bool relu() const { return false; }
+    __device__ __forceinline__ bool atomic() const { return false; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
     __device__ __forceinline__ f32x4 get_add(int, int) const { return f32x4{0, 0, 0, 0}; }
     __device__ __forceinline__ bf16x4 get_mask(int, int) const { return bf16x4{}; }
@@ -314,7 +318,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // queued earlier (before the last K-tile's multiply) every one of those small reads had to wait for the whole prefetch first.
 template <typename Epi, int SCRB = 4096, typename Hook = NoHook>
 __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int r16, int q4,
-                                             unsigned char* scratch = nullptr, Hook after_loads = Hook()) {
+                                             unsigned char* scratch = nullptr, Hook after_loads = Hook(), bool lead = true) {
+    // lead: split-K - only the first K-split of a tile adds the bias / addend (kernel-uniform)
     if (scratch && epi.wide(n0)) {
         const int lane = q4 * 16 + r16;
         const int mw = m0 + wm * 64, nw = n0 + wn * 64;
@@ -323,7 +328,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
         f32x4 bv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = f32x4{0, 0, 0, 0};
-        if (epi.has_bias()) {
+        if (epi.has_bias() && lead) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = epi.ld_bias(ncol + 16 * j);
         }
@@ -345,7 +350,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
             bf16x4 mk[IB][4];
             // addend: with f32 output (and no ReLU after it) it is added in the read-back layout below - 16 adjacent lanes read a
             // row's 256 bytes - instead of as 64-byte row fragments in the accumulator layout
-            const bool add_late = epi.has_add() && !bf16_out && !epi.relu() && !epi.has_mask();
+            const bool add_late = epi.has_add() && lead && !bf16_out && !epi.relu() && !epi.has_mask() && !epi.atomic();
             f32x4 al[4 * IB];
             if (add_late) {
 #pragma unroll
@@ -354,7 +359,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                     al[it] = epi.get_add(min(mw + pass * IB * 16 + (idx >> 4), epi.M - 1), nw + (idx & 15) * 4);
                 }
             }
-            if (epi.has_add() && !add_late) {
+            if (epi.has_add() && lead && !add_late) {
 #pragma unroll
                 for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
@@ -377,7 +382,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
 #pragma unroll
                         for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
                     }
-                    if (epi.has_add() && !add_late) v += av[ii][j];
+                    if (epi.has_add() && lead && !add_late) v += av[ii][j];
                     if (epi.has_mask()) {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) v[x] = ((float)mk[ii][j][x] > 0.f) ? v[x] : 0.f;
@@ -427,6 +432,19 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                     if (epi.has_bits_out()) bo += 8 * epi.ld_bits_();
                 }
             } else {
+                if (epi.atomic()) {
+                    // split-K: one row per wave instruction, lane = column - 64 lanes add 256 contiguous bytes (2 full cache lines).
+                    // (16-byte chunks per lane meant 4 instructions of 4 rows x 16 strided dwords: 8 quarter-filled lines each, and
+                    // the memory-side float atomics are paid per line)
+                    auto rc = epi.cur(mw + pass * IB * 16, nw);
+#pragma unroll
+                    for (int rl = 0; rl < 16 * IB; ++rl) {
+                        const float v = *reinterpret_cast<const float*>(scratch + rl * 256 + ((((lane >> 2) ^ (rl & 7))) << 4) + (lane & 3) * 4);
+                        if (mw + pass * IB * 16 + rl < epi.M) atomicAdd(reinterpret_cast<float*>(rc.p) + lane, v);
+                        epi.step(rc, 1);
+                    }
+                    return;
+                }
                 const int ch = lane & 15, mf = mw + pass * IB * 16 + (lane >> 4);
                 auto rc = epi.cur(mf, nw);
 #pragma unroll
@@ -585,7 +603,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
 // (n fastest), so the workgroups that share an A row-panel run on the same L2 at about the same time.
 template <typename Epi>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
-                                                             int64_t ldw, int M, int N, int K, int tiles_n, int ntiles, Epi epi) {
+                                                             int64_t ldw, int M, int N, int K, int tiles_n, int ntiles, int ksplit,
+                                                             Epi epi) {
+    // ksplit > 1 (host: few output tiles, long K, f32 C): `ntiles` counts (tile, K-split) pairs, split fastest; every pair is a
+    // "tile" of the walk below with its own K range, and the epilogue adds atomically (epi.atomic()) into a zeroed C
     constexpr int KT = 64, TILE = BM * ROWB;  // 16 KiB per operand tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];   // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -602,18 +623,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
         first = lo + li;
     }
     if (first >= end) return;
-    const int nk = K / KT;
+    const int nk_all = K / KT;
 
     const bf16_t* asrc[4];
     const bf16_t* wsrc[4];
-    auto set_tile = [&](int tile) {   // per-lane source rows of the 4 pieces this wave stages per operand (piece p: tile rows 8p..8p+7)
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    auto k_begin = [&](int vt) { return (int)((int64_t)(vt % ksplit) * nk_all / ksplit); };
+    auto k_count = [&](int vt) { return (int)((int64_t)(vt % ksplit + 1) * nk_all / ksplit) - k_begin(vt); };
+    auto set_tile = [&](int vt) {   // per-lane source rows of the 4 pieces this wave stages per operand (piece p: tile rows 8p..8p+7)
+        const int tile = vt / ksplit;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n, kb = k_begin(vt) * KT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * (wave * 4 + i) + (lane >> 3);
             const int c = (lane & 7) ^ (row & 7);
-            asrc[i] = A + (int64_t)min(tm * BM + row, M - 1) * lda + c * 8;
-            wsrc[i] = W + (int64_t)min(tn * BN + row, N - 1) * ldw + c * 8;
+            asrc[i] = A + (int64_t)min(tm * BM + row, M - 1) * lda + c * 8 + kb;
+            wsrc[i] = W + (int64_t)min(tn * BN + row, N - 1) * ldw + c * 8 + kb;
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -633,7 +657,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
     int cur = 0;
     __syncthreads();   // drains the DMA (vmcnt) and publishes the first K-tile
     for (int tile = first; tile < end; tile += step) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int otile = tile / ksplit;
+        const int tm = otile / tiles_n, tn = otile - tm * tiles_n, nk = k_count(tile);
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -670,7 +695,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __res
                 set_tile(tile + step);
                 stage(cur, 0);
             }
-        });
+        }, tile % ksplit == 0);
         if (more) __syncthreads();   // drains the DMA and frees the scratch
     }
 }
@@ -805,7 +830,8 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, in
 
 template <typename Epi>
 __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
-                                                           int64_t ldb, int M, int N, int K, int tiles_n, int ntiles, Epi epi) {
+                                                           int64_t ldb, int M, int N, int K, int tiles_n, int ntiles, int ksplit,
+                                                           Epi epi) {
     constexpr int KT = 64, TILE = BM * ROWB;   // 16 KiB: A tile [128 m][64 k]; B tile [64 k][128 n]
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -824,18 +850,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
         first = lo + li;
     }
     if (first >= end) return;
-    const int nk = K / KT;
+    const int nk_all = K / KT;
 
     const bf16_t* asrc[4];
     const bf16_t* bsrc[4];
-    auto set_tile = [&](int tile) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    auto k_begin = [&](int vt) { return (int)((int64_t)(vt % ksplit) * nk_all / ksplit); };      // split-K: see gemm_nt_glds_kernel
+    auto k_count = [&](int vt) { return (int)((int64_t)(vt % ksplit + 1) * nk_all / ksplit) - k_begin(vt); };
+    auto set_tile = [&](int vt) {
+        const int tile = vt / ksplit;
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n, kb = k_begin(vt) * KT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int arow = 8 * (wave * 4 + i) + (lane >> 3);                   // A piece: 8 rows x 128 B
-            asrc[i] = A + (int64_t)min(tm * BM + arow, M - 1) * lda + (((lane & 7) ^ (arow & 7)) * 8);
+            asrc[i] = A + (int64_t)min(tm * BM + arow, M - 1) * lda + (((lane & 7) ^ (arow & 7)) * 8) + kb;
             const int brow = 4 * (wave * 4 + i) + (lane >> 4);                   // B piece: 4 k-rows x 256 B
-            bsrc[i] = Bm + (int64_t)brow * ldb + tn * BN + (((lane & 15) ^ tr_sw(brow)) * 8);
+            bsrc[i] = Bm + (int64_t)(kb + brow) * ldb + tn * BN + (((lane & 15) ^ tr_sw(brow)) * 8);
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -854,7 +883,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
     int cur = 0;
     __syncthreads();
     for (int tile = first; tile < end; tile += step) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int otile = tile / ksplit;
+        const int tm = otile / tiles_n, tn = otile - tm * tiles_n, nk = k_count(tile);
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -891,7 +921,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
                 set_tile(tile + step);
                 stage(cur, 0);
             }
-        });
+        }, tile % ksplit == 0);
         if (more) __syncthreads();   // drains the DMA and frees the scratch
     }
 }
@@ -931,13 +961,38 @@ int check_operands(const void* A, int a_dtype, int64_t lda, const void* W, int w
     return 0;
 }
 
+// Split-K for the persistent kernels: the decoder's GEMMs have B*(U+1) = 1632 rows - 26 output tiles on a 256-CU chip, each a serial
+// walk over K (32 K-tiles at K = 2048: ~40 us for 1.7 GFLOP).  With few tiles, a long K and a plain f32 C (no ReLU / mask / bf16
+// rounding after the sum) the K range is cut so that ~all CUs get a (tile, split) pair; C is zeroed and the pairs add atomically.
+__global__ __launch_bounds__(256) void zero_f32x4_kernel(f32x4* __restrict__ p, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = f32x4{0, 0, 0, 0};
+}
+// hipMemsetAsync of the 1.6 MB decoder-sized C took ~25 us on this stack; a plain kernel takes ~3
+int zero_c(hipStream_t s, void* C, int64_t n) {   // n floats, n % 4 == 0, C 16-byte aligned (wide_ok)
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(zero_f32x4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<f32x4*>(C), n4);
+    ASR_LAUNCH_CHECK("gemm_zero_c");
+    return 0;
+}
+int pick_ksplit(const EpiDense& e, int ntiles, int K) {
+    static const bool off = getenv("ASR_AMD_SPLITK") && atoi(getenv("ASR_AMD_SPLITK")) == 0;
+    const int nk = K / 64;
+    if (off || !e.wide_ok || e.c_dtype != ASR_F32 || (e.flags & ASR_GEMM_RELU) || e.relu_mask || e.bits_in || e.bits_out ||
+        e.N % BN != 0 || e.ldc != e.N || ntiles > 64 || nk < 8 || (const void*)e.addend == (const void*)e.C)
+        return 1;
+    int sp = nk / 4;                       // >= 4 K-tiles per split
+    if (sp > 256 / ntiles) sp = 256 / ntiles;
+    return sp < 2 ? 1 : sp;
+}
+
 template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
-                                        const Epi& epi) {
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+                                        const Epi& epi, int ksplit = 1) {
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n * ksplit;
     static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU (64 KiB of LDS each)
     const int nwg = ntiles < max_wg ? ntiles : max_wg;
     hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
-                       reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, ntiles, epi);
+                       reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, ntiles, ksplit, epi);
     ASR_LAUNCH_CHECK("gemm_nt_glds");
     return 0;
 }
@@ -951,6 +1006,15 @@ template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, 
     static const int glds_min_k = getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64;
     if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= glds_min_k) {
         if constexpr (std::is_same<Epi, EpiDense>::value) {
+            const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+            if (const int sp = pick_ksplit(epi, tiles, K); sp > 1) {
+                if (int rc = zero_c(s, epi.C, (int64_t)M * N)) return rc;
+                EpiDense e2 = epi;
+                e2.atomic_out = true;
+                if (dense_mode(e2) == (1u | 128u)) return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 128u>(e2), sp);   // decoder FFN2
+                if (dense_mode(e2) == 128u) return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<128u>(e2), sp);
+                return launch_glds(s, A, lda, W, ldw, M, N, K, e2, sp);
+            }
             if (epi.wide_ok && !(epi.flags & ~ASR_GEMM_RELU)) {
                 switch (dense_mode(epi)) {   // the combinations the model's projections use; anything else takes the run-time form
                     case 1u | 2u | 16u: return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 2u | 16u>(epi));   // FFN1
@@ -1045,12 +1109,20 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
         static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU, persistent
-        const int pwg = nwg < max_wg ? nwg : max_wg;
+        const int sp = pick_ksplit(epi, nwg, K);
+        if (sp > 1) {
+            if (int rc = zero_c(s, C, (int64_t)M * N)) return rc;
+            epi.atomic_out = true;
+        }
+        const int vtiles = nwg * sp;
+        const int pwg = vtiles < max_wg ? vtiles : max_wg;
 #define LAUNCH_NN_TR(E)                                                                                                          \
     hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E)>), dim3(pwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, \
-                       K, tiles_n, nwg, E)
+                       K, tiles_n, vtiles, sp, E)
         const unsigned mode = epi.wide_ok ? dense_mode(epi) : 0xffu;
         if (mode == 4u) LAUNCH_NN_TR(dense_as<4u>(epi));                 // dX = dY . W + residual gradient (f32)
+        else if (mode == (4u | 128u)) LAUNCH_NN_TR(dense_as<4u | 128u>(epi));   // ... split-K (decoder rows)
+        else if (mode == 128u) LAUNCH_NN_TR(dense_as<128u>(epi));
         else if (mode == (8u | 16u)) LAUNCH_NN_TR(dense_as<8u | 16u>(epi));   // ReLU-masked hidden gradient (bf16)
         else if (mode == (64u | 16u)) LAUNCH_NN_TR(dense_as<64u | 16u>(epi));  // ... masked from the sign bits
         else if (mode == 16u) LAUNCH_NN_TR(dense_as<16u>(epi));

@@ -46,6 +46,27 @@ def test_gemm_nn(M, N_, K):
     np.testing.assert_allclose(N(out16), (ref - add).numpy(), atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("M,N_,K", [(1632, 256, 2048), (1632, 256, 768), (200, 128, 1024), (1632, 256, 3072), (640, 384, 512)])
+def test_split_k_gemms(M, N_, K):
+    """Few output tiles + long K + plain f32 C: the persistent NT / NN kernels cut K across workgroups and add partial tiles with
+    float atomics into a zeroed C (gemm.hip: pick_ksplit); bias / addend are applied by the first split only."""
+    g = torch.Generator().manual_seed(M + N_ + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w_nt = (torch.randn(N_, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N_, generator=g)
+    add = torch.randn(M, N_, generator=g)
+    ref_nt = a.float() @ w_nt.float().t() + bias
+    for _ in range(2):      # twice: the result must not depend on what an earlier launch left in a recycled C buffer
+        out = ops.gemm_nt(a.to(DEV), w_nt.to(DEV), bias.to(DEV))
+        np.testing.assert_allclose(N(out), ref_nt.numpy(), atol=3e-3, rtol=2e-3)
+    w_nn = (torch.randn(K, N_, generator=g) / K ** 0.5).bfloat16()
+    ref_nn = a.float() @ w_nn.float() + add
+    for _ in range(2):
+        out = ops.gemm_nn(a.to(DEV), w_nn.to(DEV), addend=add.to(DEV))
+        np.testing.assert_allclose(N(out), ref_nn.numpy(), atol=3e-3, rtol=2e-3)
+    np.testing.assert_allclose(N(ops.gemm_nn(a.to(DEV), w_nn.to(DEV))), (ref_nn - add).numpy(), atol=3e-3, rtol=2e-3)
+
+
 def test_colsum_and_embed_bwd():
     g = torch.Generator().manual_seed(0)
     a = torch.randn(1000, 300, generator=g)

@@ -120,5 +120,8 @@ def test_model_full_size_utterances_do_not_interact():
         _, ctc1, (dec1, _) = model(x2, lens, tg)
     for b in (0, 1, 2, 9):
         n = int(lens[b])
-        assert torch.equal(ctc0[b, :n], ctc1[b, :n]) and torch.equal(dec0[b], dec1[b])
-    assert not torch.equal(ctc0[5], ctc1[5])
+        assert torch.equal(ctc0[b, :n], ctc1[b, :n])
+        # the decoder's 1632-row GEMMs are split over K with float atomics (gemm.hip: pick_ksplit): the summation order, and with it
+        # the last bf16 bit of a few activations, varies from launch to launch - independence holds to that noise, not bit for bit
+        assert torch.allclose(dec0[b], dec1[b], rtol=2e-2, atol=2e-2)
+    assert not torch.equal(ctc0[5], ctc1[5]) and not torch.allclose(dec0[5], dec1[5], rtol=2e-2, atol=2e-2)

@@ -26,4 +26,4 @@ for ms, n, c in rows:
 print("total timed %.2f ms/step" % tot)
 for f, ms in sorted(fam.items(), key=lambda t: -t[1]): print("  %-22s %6.3f ms  %4.1f%%" % (f, ms, 100 * ms / tot))
 print()
-for ms, n, c in rows[:40]: print("%-44s %6.3f ms/step  %5.1f calls  %7.1f us/call" % (n, ms, c, ms / c * 1e3))
+for ms, n, c in rows[:70]: print("%-44s %6.3f ms/step  %5.1f calls  %7.1f us/call" % (n, ms, c, ms / c * 1e3))
