@@ -786,12 +786,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // split-K (gridDim.y > 1, host: pick_ksplit): this workgroup owns K-tiles [kt0, kt1) and adds its partial tile atomically
+    const int kt0 = (int)((int64_t)blockIdx.y * nk / gridDim.y), kt1 = (int)((int64_t)(blockIdx.y + 1) * nk / gridDim.y);
+    gload(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
         __syncthreads();
         lstore();
         __syncthreads();
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < kt1) gload(kt + 1);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int chunk = g * 4 + q4;
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_kernel(const AT* __restrict__ A
         }
     }
     __syncthreads();   // operand tiles are dead: their LDS is the epilogue's transpose scratch
-    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4, smem + wave * 8192);
+    run_epilogue(epi, acc, m0, n0, wm, wn, r16, q4, smem + wave * 8192, NoHook(), blockIdx.y == 0);
 }
 
 // ---- NN variant, LDS-DMA + hardware-transpose form (bf16 A, K % 64 == 0, N % 128 == 0): the A tile is staged exactly like the
@@ -1132,11 +1134,16 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
         ASR_LAUNCH_CHECK("gemm_nn_tr");
         return 0;
     }
+    const int sp = pick_ksplit(epi, nwg, K);     // e.g. the decoder's vocabulary data gradient [1632 x 256 x 4234]: 26 tiles x 67 K-tiles
+    if (sp > 1) {
+        if (int rc = zero_c(s, C, (int64_t)M * N)) return rc;
+        epi.atomic_out = true;
+    }
     if (a_dtype == ASR_F32)
-        hipLaunchKernelGGL((gemm_nn_kernel<float, EpiDense>), dim3(nwg), dim3(NT), 0, s, (const float*)A, lda, (const bf16_t*)Bm, ldb, M, N,
+        hipLaunchKernelGGL((gemm_nn_kernel<float, EpiDense>), dim3(nwg, sp), dim3(NT), 0, s, (const float*)A, lda, (const bf16_t*)Bm, ldb, M, N,
                            K, tiles_n, nwg, epi);
     else
-        hipLaunchKernelGGL((gemm_nn_kernel<bf16_t, EpiDense>), dim3(nwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N,
+        hipLaunchKernelGGL((gemm_nn_kernel<bf16_t, EpiDense>), dim3(nwg, sp), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N,
                            K, tiles_n, nwg, epi);
     ASR_LAUNCH_CHECK("gemm_nn");
     return 0;
