@@ -118,6 +118,31 @@ def _drop(mod, suffix):
     return ops.Dropout(thr, k0, k1)
 
 
+def _prefetch_attn_masks(sites, training, device):
+    """sites: [(MultiheadAttention, B, Lq, Lk)] in call order -> per site None or (asr_dropout_t, keep bits, event) for
+    MultiheadAttention._impl(attn_drop=).  The attention-dropout keep bits of every listed call are hashed on a side stream while
+    the main stream runs the layers before them: the masks depend on (seed, site, call count, shape) only - not on data - and the
+    hash is pure integer VALU work (~50-60 us per [32, 4, 1000, 1000] layer alone on the chip), which co-runs with the MFMA /
+    HBM-bound kernels of the main stream."""
+    none = [None] * len(sites)
+    if not (_MASK_PREFETCH and training and device.type == "cuda"):
+        return none
+    drops = [_drop(m, "attention.dropout") for m, _, _, _ in sites]
+    if all(d is None for d in drops):
+        return none
+    main, aux = torch.cuda.current_stream(), ops.aux_stream(device, slot=1)
+    out = []
+    with torch.cuda.stream(aux):
+        for (m, B, Lq, Lk), d in zip(sites, drops):
+            bits = ops.attention_dropmask(d, B, m.n_head, Lq, Lk, device)
+            if bits is not None:
+                bits.record_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(aux)
+            out.append((d, bits, ev))
+    return out
+
+
 # ---- backward tape ---------------------------------------------------------------------------------------------
 # The forward of every block pushes one closure that, run in reverse order, turns the gradient of the block's output Act
 # into parameter gradients (written straight into `p.grad`, which the trainer points into one flat buffer) and input
@@ -474,26 +499,7 @@ class Encoder(_Cached):
         return x
 
     def _attn_masks(self, B, L, device):
-        """Attention-dropout keep bits of every layer, hashed on a side stream while the main stream runs the layers before it.
-        The masks depend on (seed, site, call count, shape) only - not on data - and the hash is pure integer VALU work (~60 us
-        per [32, 4, 1000, 1000] layer alone on the chip), which co-runs with the MFMA / HBM-bound kernels of the main stream."""
-        none = [None] * len(self.layer_stack)
-        if not (_MASK_PREFETCH and self.training and device.type == "cuda"):
-            return none
-        drops = [_drop(layer.slf_attn, "attention.dropout") for layer in self.layer_stack]
-        if all(d is None for d in drops):
-            return none
-        main, aux = torch.cuda.current_stream(), ops.aux_stream(device, slot=1)
-        out = []
-        with torch.cuda.stream(aux):
-            for layer, d in zip(self.layer_stack, drops):
-                bits = ops.attention_dropmask(d, B, layer.slf_attn.n_head, L, L, device)
-                if bits is not None:
-                    bits.record_stream(main)
-                ev = torch.cuda.Event()
-                ev.record(aux)
-                out.append((d, bits, ev))
-        return out
+        return _prefetch_attn_masks([(layer.slf_attn, B, L, L) for layer in self.layer_stack], self.training, device)
 
     def forward(self, padded_input, input_lengths):
         lens = ops.as_i32(input_lengths, padded_input.device)
@@ -829,6 +835,7 @@ class Decoder(_Cached):
 
             _TAPE.push(bw_emb, (emb.weight,))
         cross = self._cross_kv(enc)
+        # (the decoder's 12 small attention masks are hashed inline: queueing them ahead like the encoder's measured neutral)
         for i, layer in enumerate(self.layer_stack):
             x = layer._impl(x, enc, dec_len, enc_len, kv_pre=cross(i))
         logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, x)
