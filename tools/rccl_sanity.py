@@ -1,0 +1,19 @@
+"""1-rank RCCL sanity on a GPU box: the trainer's bucketed async all-reduce over views of the flat gradient buffer (backend nccl)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+import torch, torch.distributed as dist
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+import asr_amd, bench
+from asr_amd import trainer as T
+dev = torch.device("cuda", 0)
+model = bench.build_model(asr_amd, dev, 0.1, True)
+x, lens, tg = bench.make_batch(dev, 0)
+tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+tr.buckets.world = 2          # force the all-reduce launches (sum over 1 rank = identity; Adam then averages by 1/2: only the plumbing is under test)
+l0 = [float(v) for v in tr.step(x, lens, tg, max_target_len=50)[:1]]
+for _ in range(3): out = tr.step(x, lens, tg, max_target_len=50)
+torch.cuda.synchronize()
+print("rccl sanity ok: launch order", tr.buckets.launch_order, "loss", l0, [float(v) for v in out[:1]])
+dist.destroy_process_group()
