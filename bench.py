@@ -206,7 +206,8 @@ def main():
             "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "fwd_GBps": ctc_k[0]["achieved"],
                      "fwd_frac_of_hbm_peak": round(ctc_k[0]["achieved"] / PEAK_HBM_GBS, 4),
                      "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
-                     "fwd_bwd_GBps": (round(3 * 4.0 * CFG["B"] * CFG["T"] * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
+                     # bytes: the logits read twice (f32) + the gradient written (bf16 image in the trainer)
+                     "fwd_bwd_GBps": (round((2 * 4.0 + (2.0 if trainer is not None else 4.0)) * CFG["B"] * CFG["T"] * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
                                       if ctc_b else None)} if ctc_k else None),
             "kernels": kernels[:12], "op_ms_total": round(sum(k["ms_per_step"] for k in kernels), 3),
         }

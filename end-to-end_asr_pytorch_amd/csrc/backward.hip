@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
     }
     if (do_colsum && q4 == 0) {   // rows are identical: lanes 0..15 (row group 0, register 0) hold the 16 column sums of fragment i
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(colsum + n0 + wm * 64 + i * 16 + r16, cs[i][0]);
+        for (int i = 0; i < 4; ++i)
+            if (n0 + wm * 64 + i * 16 + r16 < N) atomicAdd(colsum + n0 + wm * 64 + i * 16 + r16, cs[i][0]);
     }
     float* wlds = reinterpret_cast<float*>(smem) + wave * (32 * 64);
 #pragma unroll
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(const bf16_t* __rest
         const int k = k0 + wn * 64 + lane;
         for (int rr = 0; rr < 32; ++rr) {
             const int n = n0 + wm * 64 + pass * 32 + rr;
+            if (n >= N) break;      // ragged N (host: A's rows are readable up to the next multiple of 128): those output rows do not exist
             atomicAdd(C + (int64_t)n * ldc + k, wlds[rr * 64 + (lane ^ ((rr & 15) << 2))]);
         }
     }
@@ -538,9 +540,11 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
         }
     }
     static const bool no_tr = getenv("ASR_AMD_NO_TR") != nullptr;   // A/B switch
-    if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 8 == 0 && M >= 64 && N % 128 == 0 && K % 128 == 0 && lda % 8 == 0 &&
+    // N need not be a multiple of 128 when A's rows can be READ up to the next one (lda covers it: a padded gradient buffer)
+    const bool n_ok = N % 128 == 0 || lda >= (int64_t)(N + 127) / 128 * 128;
+    if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 8 == 0 && M >= 64 && n_ok && K % 128 == 0 && lda % 8 == 0 &&
         ldb % 8 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 16)) {
-        const int tiles_n = N / 128, tiles_k = K / 128, tiles = tiles_n * tiles_k;
+        const int tiles_n = (N + 127) / 128, tiles_k = K / 128, tiles = tiles_n * tiles_k;
         static const int target_wgs = getenv("ASR_AMD_TN_WGS") ? atoi(getenv("ASR_AMD_TN_WGS")) : 512;   // 2 resident per CU
         int splits = (target_wgs + tiles - 1) / tiles;
         static const int min_rows = getenv("ASR_AMD_TN_MINROWS") ? atoi(getenv("ASR_AMD_TN_MINROWS")) : 512;

@@ -754,6 +754,61 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     return 0;
 }
 
+// bf16 gradient (the trainer's path: the gradient is consumed by bf16 MFMA GEMMs only, which would round the f32 image on load to
+// exactly these values - half the write here, half the read in both of ctc_fc's backward GEMMs).  Rows are 16-byte aligned on
+// both sides (ldl % 4 == 0, ldg % 8 == 0, host-checked); columns V .. ldg-1 are written as zeros: ldg is chosen by the caller
+// so that the GEMM kernels can treat the rows as padded to their tile width.
+__global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
+                                                            const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
+                                                            int B, int L, int V, int Umax, int blank, const float* __restrict__ lse,
+                                                            const float* __restrict__ occ, const float* __restrict__ gout,
+                                                            bf16_t* __restrict__ grad, int64_t ldg) {
+    extern __shared__ float corr[];  // V floats (+ up to 3 pad entries read by the last vector group)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int Sfull = ctc_row_stride(Umax), Sb = 2 * tgt_len[b] + 1;
+    const int Tb = min(in_len[b], L);
+    const float scale = gout[0] / ((float)B * (float)max(tgt_len[b], 1));
+    const int ng = (int)(ldg >> 2);          // 4-column groups of a gradient row, pad included
+    for (int i = tid; i < V + 4; i += 256) corr[i] = 0.f;
+    __syncthreads();
+    for (int t = blockIdx.x; t < L; t += gridDim.x) {
+        const int64_t row = (int64_t)b * L + t;
+        bf16x4* g4 = reinterpret_cast<bf16x4*>(grad + row * ldg);
+        if (t >= Tb) {  // padded frame: zero gradient, no reads
+            for (int i = tid; i < ng; i += 256) g4[i] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            continue;
+        }
+        const float* x = logits + row * ldl;
+        for (int sidx = tid; sidx < Sb; sidx += 256) {
+            const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
+            atomicAdd(&corr[lab], occ[((int64_t)b * (L + 2) + t) * Sfull + sidx]);
+        }
+        __syncthreads();
+        const float l = lse[row];
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (int i = tid; i < ng; i += 256) {
+            const int c = i * 4;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (c + 4 <= V) {
+                const f32x4 v = x4[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = scale * (__expf(v[j] - l) - corr[c + j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < V) o[j] = scale * (__expf(x[c + j] - l) - corr[c + j]);
+            }
+            g4[i] = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+        }
+        __syncthreads();
+        for (int sidx = tid; sidx < Sb; sidx += 256) {
+            const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
+            corr[lab] = 0.f;
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_len, int B, float* loss) {
     ASR_REQUIRE(nll && tgt_len && loss && B > 0, ASR_ERR_ARG, "ctc_mean: bad args");
     hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), nll, tgt_len, B, loss);
@@ -763,19 +818,26 @@ extern "C" int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_l
 
 extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                 int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
-                                const float* nll, const int32_t* tgt_len, const float* gout, float* grad, int64_t ldg) {
+                                const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg) {
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len && gout && grad, ASR_ERR_ARG,
                 "ctc_bwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && ldl >= V && ldg >= V, ASR_ERR_ARG, "ctc_bwd: bad sizes");
-    ASR_REQUIRE((size_t)V * sizeof(float) <= 64 * 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: V=%d exceeds the LDS occupancy vector", V);
+    ASR_REQUIRE(grad_dtype == ASR_F32 || grad_dtype == ASR_BF16, ASR_ERR_ARG, "ctc_bwd: bad grad_dtype");
+    ASR_REQUIRE(grad_dtype == ASR_F32 || (ldg % 8 == 0 && ldl % 4 == 0 && asr_aligned(grad, 16) && asr_aligned(logits, 16)), ASR_ERR_ALIGN,
+                "ctc_bwd: a bf16 gradient needs 16-byte aligned rows (ldg %% 8 == 0, ldl %% 4 == 0)");
+    ASR_REQUIRE((size_t)(V + 4) * sizeof(float) <= 64 * 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: V=%d exceeds the LDS occupancy vector", V);
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_bwd: Umax too long");
     hipStream_t s = static_cast<hipStream_t>(stream);
     launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
     int rb = (2048 + B - 1) / B;  // ~2048 workgroups in flight
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3(rb, B), dim3(256), (size_t)V * sizeof(float), s, logits, ldl, in_len, targets, tgt_len, B, L,
-                       V, Umax, blank, lse, alpha, gout, grad, ldg);
+    if (grad_dtype == ASR_BF16)
+        hipLaunchKernelGGL(ctc_grad_bf16_kernel, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, logits, ldl, in_len, targets,
+                           tgt_len, B, L, V, Umax, blank, lse, alpha, gout, reinterpret_cast<bf16_t*>(grad), ldg);
+    else
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3(rb, B), dim3(256), (size_t)V * sizeof(float), s, logits, ldl, in_len, targets, tgt_len, B, L,
+                           V, Umax, blank, lse, alpha, gout, reinterpret_cast<float*>(grad), ldg);
     ASR_LAUNCH_CHECK("ctc_loss_bwd");
     return 0;
 }

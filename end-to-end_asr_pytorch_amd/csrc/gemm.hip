@@ -852,10 +852,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
         first = lo + li;
     }
     if (first >= end) return;
-    const int nk_all = K / KT;
+    // K need not be a multiple of 64: A's rows are readable and ZERO up to the next multiple (host contract: a padded gradient
+    // buffer), the weight rows past K - 1 are clamped to the last one (their products meet those zeros)
+    const int nk_all = (K + KT - 1) / KT;
 
     const bf16_t* asrc[4];
     const bf16_t* bsrc[4];
+    int brow_k[4];
     auto k_begin = [&](int vt) { return (int)((int64_t)(vt % ksplit) * nk_all / ksplit); };      // split-K: see gemm_nt_glds_kernel
     auto k_count = [&](int vt) { return (int)((int64_t)(vt % ksplit + 1) * nk_all / ksplit) - k_begin(vt); };
     auto set_tile = [&](int vt) {
@@ -866,7 +869,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
             const int arow = 8 * (wave * 4 + i) + (lane >> 3);                   // A piece: 8 rows x 128 B
             asrc[i] = A + (int64_t)min(tm * BM + arow, M - 1) * lda + (((lane & 7) ^ (arow & 7)) * 8) + kb;
             const int brow = 4 * (wave * 4 + i) + (lane >> 4);                   // B piece: 4 k-rows x 256 B
-            bsrc[i] = Bm + (int64_t)(kb + brow) * ldb + tn * BN + (((lane & 15) ^ tr_sw(brow)) * 8);
+            brow_k[i] = kb + brow;
+            bsrc[i] = Bm + tn * BN + (((lane & 15) ^ tr_sw(brow)) * 8);
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
             const int p = wave * 4 + i;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * KT),
                                              (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (int64_t)kt * KT * ldb),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (int64_t)min(brow_k[i] + kt * KT, K - 1) * ldb),
                                              (__attribute__((address_space(3))) void*)(base + TILE + p * 1024), 16, 0, 0);
         }
     };
@@ -1096,12 +1100,14 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     ASR_REQUIRE(lda % 8 == 0 && lda >= (K + 7) / 8 * 8 && N % 4 == 0 && ldb % 4 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 8),
                 ASR_ERR_ALIGN, "gemm_nn: lda=%lld must be a multiple of 8 covering K=%d rounded up (pad columns must be zero), N=%d ldb=%lld of 4",
                 (long long)lda, K, N, (long long)ldb);
+    // columns K .. lda-1 of A are zero by contract: with lda >= K rounded up to 64 the LDS-DMA kernel takes a K that is no multiple of 64
+    const bool k_ok = K % 64 == 0 || lda >= (int64_t)(K + 63) / 64 * 64;
     EpiDense epi{C, c_dtype, ldc, bias, 0u, M, N, addend, ld_add, mask_is_bits ? nullptr : reinterpret_cast<const bf16_t*>(relu_mask),
                  ld_mask, false};
     epi.vec_ok = dense_vec_ok(epi);
     epi.wide_ok = dense_wide_ok(epi);
     if (mask_is_bits && relu_mask) {
-        ASR_REQUIRE(epi.wide_ok && a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) &&
+        ASR_REQUIRE(epi.wide_ok && a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) &&
                         ld_mask >= N / 8 && getenv("ASR_AMD_NO_TR") == nullptr,
                     ASR_ERR_UNSUPPORTED, "gemm_nn: a sign-bit mask needs the LDS-DMA kernel's shapes (bf16 A, K %% 64 == 0, N %% 128 == 0)");
         epi.bits_in = reinterpret_cast<const unsigned char*>(relu_mask);
@@ -1109,7 +1115,7 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a_dtype == ASR_BF16 && K % 64 == 0 && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
+    if (a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
         static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU, persistent
         const int sp = pick_ksplit(epi, nwg, K);
         if (sp > 1) {

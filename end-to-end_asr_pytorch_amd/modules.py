@@ -762,7 +762,9 @@ def _vocab_proj(mod, key, weight, x):
             g = slot["g"]
             V = g.shape[-1]
             rows = g.numel() // V
-            ok = (g.dtype == torch.float32 and g.stride(-1) == 1 and g.stride(-2) % 8 == 0 and g.data_ptr() % 16 == 0 and
+            # f32, or the fused CTC backward's bf16 image (rows padded with zeros to a multiple of 128: both GEMMs below then run
+            # their LDS-DMA kernels on a vocabulary size that is a multiple of nothing)
+            ok = (g.dtype in (torch.float32, torch.bfloat16) and g.stride(-1) == 1 and g.stride(-2) % 8 == 0 and g.data_ptr() % 16 == 0 and
                   (g.dim() == 2 or g.stride(0) == g.shape[1] * g.stride(1)))
             if not ok:   # a gradient that did not come from the fused loss kernels: re-home it into a zero-padded, aligned buffer
                 buf = torch.zeros((rows, (V + 7) // 8 * 8), device=g.device, dtype=torch.float32)

@@ -287,19 +287,24 @@ def _pad8(v):
     return (v + 7) // 8 * 8
 
 
-def ctc_loss_bwd(st, gout):
-    """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,roundup(V,8)] buffer (rows 16-byte aligned so the
-    gradient is directly a GEMM operand).  Consumes st.alpha."""
-    Vp = _pad8(st.V)
-    gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32)
-    if Vp != st.V:
-        gbuf[:, :, st.V:].zero_()      # only the pad columns (the kernel writes every real one): not a 542 MB fill at S1
+def ctc_loss_bwd(st, gout, bf16=False):
+    """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,Vp] buffer (rows 16-byte aligned so the gradient is directly a
+    GEMM operand).  Consumes st.alpha.  bf16=True (a gradient that only feeds the projection's backward GEMMs, which run on bf16
+    MFMA anyway): half the bytes, Vp = roundup(V, 128) so that both GEMMs take their LDS-DMA kernels, pad written by the kernel."""
+    if bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0:
+        Vp = (st.V + 127) // 128 * 128
+        gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.bfloat16)
+    else:
+        Vp = _pad8(st.V)
+        gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.float32)
+        if Vp != st.V:
+            gbuf[:, :, st.V:].zero_()      # only the pad columns (the kernel writes every real one): not a 542 MB fill at S1
     grad = gbuf[:, :, :st.V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
-    with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), 8.0 * st.B * st.L * st.V):
+    with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), (4.0 + gbuf.element_size()) * st.B * st.L * st.V):
         check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax,
                                      st.blank, _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad),
-                                     Vp), "asr_ctc_loss_bwd")
+                                     dtype_code(gbuf), Vp), "asr_ctc_loss_bwd")
     return grad
 
 

@@ -67,6 +67,29 @@ def test_split_k_gemms(M, N_, K):
     np.testing.assert_allclose(N(ops.gemm_nn(a.to(DEV), w_nn.to(DEV))), (ref_nn - add).numpy(), atol=3e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("M,V", [(2048, 4234), (1000, 131), (1632, 4234)])
+def test_vocab_backward_gemms_on_a_padded_bf16_gradient(M, V):
+    """The projection's backward on the bf16 gradient image (rows zero-padded to a multiple of 128): the LDS-DMA NN kernel with a K
+    that is no multiple of 64 (weight rows past K-1 clamped) and the LDS-DMA TN kernel with an N that is no multiple of 128."""
+    g = torch.Generator().manual_seed(M + V)
+    D = 256
+    Vp = (V + 127) // 128 * 128
+    buf = torch.zeros(M, Vp)
+    buf[:, :V] = torch.randn(M, V, generator=g) * 0.1
+    gd = buf.bfloat16().to(DEV)
+    g2 = gd[:, :V]                                     # [M, V] view, row stride Vp
+    w = (torch.randn(V, D, generator=g) / V ** 0.5).bfloat16()
+    x = torch.randn(M, D, generator=g).bfloat16()
+    add = torch.randn(M, D, generator=g)
+    dx = ops.gemm_nn(g2, w.to(DEV), addend=add.to(DEV))
+    ref_dx = buf[:, :V].bfloat16().float() @ w.float() + add
+    np.testing.assert_allclose(N(dx), ref_dx.numpy(), atol=3e-3, rtol=2e-3)
+    dw = torch.zeros(V, D, device=DEV)
+    ops.gemm_tn(g2, x.to(DEV), out=dw, accumulate=True)
+    ref_dw = buf[:, :V].bfloat16().float().t() @ x.float()
+    np.testing.assert_allclose(N(dw), ref_dw.numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+
+
 def test_colsum_and_embed_bwd():
     g = torch.Generator().manual_seed(0)
     a = torch.randn(1000, 300, generator=g)

@@ -321,6 +321,27 @@ def test_ctc_strided_logits_rows():
     np.testing.assert_array_equal(N(n1), N(n2))
 
 
+@pytest.mark.parametrize("B,L,V,U", [(2, 30, 50, 5), (3, 77, 4234, 20), (2, 40, 131, 9)])
+def test_ctc_bf16_gradient_is_the_rounded_f32_gradient(B, L, V, U):
+    """asr_ctc_loss_bwd(grad_dtype = bf16): the trainer's gradient image - the f32 gradient rounded to bf16, rows padded with
+    written zeros to a multiple of 128 columns (the projection's backward GEMMs read the pad)."""
+    g = torch.Generator().manual_seed(V + L)
+    Vp8 = (V + 7) // 8 * 8
+    buf = torch.randn(B, L, Vp8, generator=g).to(DEV)
+    logits = buf[:, :, :V]
+    tg = torch.randint(1, V - 1, (B, U), generator=g).to(DEV)
+    il = torch.tensor([L] + [L - 7] * (B - 1)).to(DEV)
+    one = torch.ones(1, device=DEV)
+    _, _, s1 = ops.ctc_loss_fwd(logits, il, tg)
+    g32 = ops.ctc_loss_bwd(s1, one)
+    _, _, s2 = ops.ctc_loss_fwd(logits, il, tg)
+    g16 = ops.ctc_loss_bwd(s2, one, bf16=True)
+    assert g16.dtype == torch.bfloat16 and g16.stride(1) % 128 == 0
+    np.testing.assert_array_equal(N(g16), N(g32.bfloat16()))
+    whole = torch.as_strided(g16, (B, L, g16.stride(1)), (g16.stride(0), g16.stride(1), 1), g16.storage_offset())
+    assert float(whole[:, :, V:].float().abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # CE
 # ---------------------------------------------------------------------------------------------------------
