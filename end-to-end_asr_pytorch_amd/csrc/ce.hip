@@ -66,15 +66,20 @@ __global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ 
     }
 }
 
+// GT = float: columns 0 .. V-1 are written.  GT = bf16_t (the trainer's gradient image, see asr_ctc_loss_bwd): the whole row 0 .. ldg-1
+// is written, zeros past V, so ldg can be the backward GEMMs' padded row width.
+template <typename GT>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets,
                                                      int V, float eps, const float* __restrict__ lse, const float* __restrict__ n_word,
-                                                     const float* __restrict__ gout, float* __restrict__ grad, int64_t ldg) {
+                                                     const float* __restrict__ gout, GT* __restrict__ grad, int64_t ldg) {
     const int row = blockIdx.x, tid = threadIdx.x;
     const float* x = logits + (int64_t)row * ldl;
-    float* g = grad + (int64_t)row * ldg;
+    GT* g = grad + (int64_t)row * ldg;
     const int64_t tg = targets[row];
+    const int W = sizeof(GT) == 2 ? (int)ldg : V;
+    for (int c = V + tid; c < W; c += 256) g[c] = (GT)0.f;
     if (tg == 0) {
-        for (int c = tid; c < V; c += 256) g[c] = 0.f;
+        for (int c = tid; c < V; c += 256) g[c] = (GT)0.f;
         return;
     }
     const float gs = gout[0] / n_word[0];
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     const float wsum = w_on + (float)(V - 1) * w_off;
     for (int c = tid; c < V; c += 256) {
         const float p = __expf(x[c] - l);
-        g[c] = gs * (p * wsum - ((c == tg) ? w_on : w_off));
+        g[c] = (GT)(gs * (p * wsum - ((c == tg) ? w_on : w_off)));
     }
 }
 
@@ -107,10 +112,15 @@ extern "C" int asr_ce_mean(void* stream, const float* row_loss, const int64_t* t
 }
 
 extern "C" int asr_ce_loss_bwd(void* stream, const float* logits, int64_t ldl, const int64_t* targets, int N, int V, float smoothing,
-                               const float* lse, const float* n_word, const float* gout, float* grad, int64_t ldg) {
-    ASR_REQUIRE(logits && targets && lse && n_word && gout && grad && N > 0 && V > 0, ASR_ERR_ARG, "ce_bwd: bad args");
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ldl, targets, V, smoothing, lse,
-                       n_word, gout, grad, ldg);
+                               const float* lse, const float* n_word, const float* gout, void* grad, int grad_dtype, int64_t ldg) {
+    ASR_REQUIRE(logits && targets && lse && n_word && gout && grad && N > 0 && V > 0 && ldg >= V, ASR_ERR_ARG, "ce_bwd: bad args");
+    ASR_REQUIRE(grad_dtype == ASR_F32 || grad_dtype == ASR_BF16, ASR_ERR_ARG, "ce_bwd: bad grad_dtype");
+    if (grad_dtype == ASR_BF16)
+        hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ldl, targets, V, smoothing,
+                           lse, n_word, gout, reinterpret_cast<bf16_t*>(grad), ldg);
+    else
+        hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream), logits, ldl, targets, V, smoothing, lse,
+                           n_word, gout, reinterpret_cast<float*>(grad), ldg);
     ASR_LAUNCH_CHECK("ce_loss_bwd");
     return 0;
 }

@@ -323,17 +323,22 @@ def ce_loss_fwd(logits2d, targets1d, smoothing):
     return loss, row_loss, lse, targets1d
 
 
-def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout):
+def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout, bf16=False):
+    """bf16=True: the trainer's gradient image (see ctc_loss_bwd)."""
     N, V = logits2d.shape
-    Vp = _pad8(V)
-    gbuf = torch.empty((N, Vp), device=logits2d.device, dtype=torch.float32)
-    if Vp != V:
-        gbuf[:, V:].zero_()
+    if bf16:
+        Vp = (V + 127) // 128 * 128
+        gbuf = torch.empty((N, Vp), device=logits2d.device, dtype=torch.bfloat16)
+    else:
+        Vp = _pad8(V)
+        gbuf = torch.empty((N, Vp), device=logits2d.device, dtype=torch.float32)
+        if Vp != V:
+            gbuf[:, V:].zero_()
     grad = gbuf[:, :V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
     n_word = loss2[1:2]
     check(lib().asr_ce_loss_bwd(_stream(), _p(logits2d), logits2d.stride(0), _p(targets1d), N, V, float(smoothing), _p(lse),
-                                _p(n_word), _p(gout), _p(grad), Vp), "asr_ce_loss_bwd")
+                                _p(n_word), _p(gout), _p(grad), dtype_code(gbuf), Vp), "asr_ce_loss_bwd")
     return grad
 
 

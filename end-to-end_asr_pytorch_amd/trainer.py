@@ -259,7 +259,7 @@ class Trainer:
             if st is not None:
                 model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one, bf16=True)
             V = logits.shape[-1]
-            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one)
+            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one, bf16=True)
             if d_num is not None:
                 model._grad_slots["num"]["g"] = d_num
             self.buckets.start()

@@ -223,13 +223,14 @@ int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32
 
 /* Label-smoothed cross entropy (loss.py:5-31).  logits f32 [N,V] (row stride ldl), targets int64 [N] (0 = pad).
  * row_loss f32 [N] (0 on pad rows), lse f32 [N];  asr_ce_mean: loss[0] = sum(row_loss) / n_word, loss[1] = n_word
- * = count(target != 0) (f32 [2]);  asr_ce_loss_bwd: grad of gout * loss wrt logits, n_word = &loss[1].
+ * = count(target != 0) (f32 [2]);  asr_ce_loss_bwd: grad of gout * loss wrt logits, n_word = &loss[1]; grad f32 or bf16
+ * (`grad_dtype`) with row stride ldg - as bf16 the whole row is written, zeros in columns V .. ldg-1 (see asr_ctc_loss_bwd).
  */
 int asr_ce_loss_fwd(void* stream, const float* logits, int64_t ldl, const int64_t* targets, int N, int V,
                     float smoothing, float* row_loss, float* lse);
 int asr_ce_mean(void* stream, const float* row_loss, const int64_t* targets, int N, float* loss);
 int asr_ce_loss_bwd(void* stream, const float* logits, int64_t ldl, const int64_t* targets, int N, int V,
-                    float smoothing, const float* lse, const float* n_word, const float* gout, float* grad, int64_t ldg);
+                    float smoothing, const float* lse, const float* n_word, const float* gout, void* grad, int grad_dtype, int64_t ldg);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CIF (cif_model.py:57-106).  asr_cif_scan_fwd runs the integrate-and-fire recurrence in the reference's exact fp32

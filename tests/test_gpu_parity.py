@@ -370,6 +370,14 @@ def test_ce_loss(smoothing):
     np.testing.assert_allclose(float(loss), float(ref_l), rtol=1e-5)
     np.testing.assert_allclose(float(loss), float(rl), rtol=1e-5)
     np.testing.assert_allclose(N(ld.grad), lg.grad.numpy(), atol=1e-6)
+    # the trainer's bf16 gradient image: the same values rounded, rows zero-padded to a multiple of 128 columns
+    l2, row_loss, lse, tg1 = ops.ce_loss_fwd(logits.to(DEV), tg.to(DEV), smoothing)
+    one = torch.ones(1, device=DEV)
+    g32 = ops.ce_loss_bwd(logits.to(DEV), tg1, smoothing, lse, l2, one)
+    g16 = ops.ce_loss_bwd(logits.to(DEV), tg1, smoothing, lse, l2, one, bf16=True)
+    np.testing.assert_array_equal(N(g16), N(g32.bfloat16()))
+    whole = torch.as_strided(g16, (Nrows, g16.stride(0)), (g16.stride(0), 1), g16.storage_offset())
+    assert g16.stride(0) % 128 == 0 and float(whole[:, V:].float().abs().max()) == 0.0
 
 
 # ---------------------------------------------------------------------------------------------------------
