@@ -164,6 +164,7 @@ def main():
     # ---- live per-kernel timing over a second, identical run of the timed region (events add launch overhead, so the
     # headline value above is measured without them) ----
     if trainer is not None:
+        trainer.wgrad_stream = False    # (likewise the weight-gradient GEMMs, which the timed step runs on a second side stream)
         trainer.overlap_ctc = False     # serial order for this pass: per-op durations are then uncontended (the CTC branch otherwise
                                         # runs beside the decoder's kernels on a side stream and both would read slower than they are)
     ops.profile_start()

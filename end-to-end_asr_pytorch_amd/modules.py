@@ -118,6 +118,23 @@ def _drop(mod, suffix):
     return ops.Dropout(thr, k0, k1)
 
 
+_WGRAD = None      # set by Trainer.backward: {"stream": side stream, "keep": [operands kept alive until the streams join]}
+
+
+def _wg(a, b, **kw):
+    """Weight-gradient GEMM of an encoder / decoder layer.  Nothing later in the backward reads its result, so under the trainer
+    it is queued on a side stream behind an event of the main one (the operands exist by then) and overlaps the main chain."""
+    if _WGRAD is None:
+        return ops.gemm_tn(a, b, **kw)
+    main, side = torch.cuda.current_stream(), _WGRAD["stream"]
+    ev = torch.cuda.Event()
+    ev.record(main)
+    side.wait_event(ev)
+    _WGRAD["keep"].append((a, b))
+    with torch.cuda.stream(side):
+        return ops.gemm_tn(a, b, **kw)
+
+
 def _prefetch_attn_masks(sites, training, device):
     """sites: [(MultiheadAttention, B, Lq, Lk)] in call order -> per site None or (asr_dropout_t, keep bits, event) for
     MultiheadAttention._impl(attn_drop=).  The attention-dropout keep bits of every listed call are hashed on a side stream while
@@ -352,13 +369,13 @@ class MultiheadAttention(_Cached):
             ds, ds16 = ops.add_layernorm_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
                                              want_bf16=True, dbias=fc.bias.grad, drop_x=dp_fc)
             y.grad = None
-            ops.gemm_tn(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
+            _wg(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
             d_ctx = ops.gemm_nn(ds16, self._w("fc", (fc.weight,)), out_dtype=torch.bfloat16)
             if xkv is xq:
                 dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:],
                                   drop=dp_attn, drop_bits=dbits)
-                ops.gemm_tn(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
+                _wg(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
                 _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
             else:
                 dq = torch.empty((B * Lq, hd), device=ds.device, dtype=torch.bfloat16)
@@ -368,10 +385,10 @@ class MultiheadAttention(_Cached):
                     dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
                     dk_out, dv_out = dkv[:, :hd], dkv[:, hd:]
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn, drop_bits=dbits)
-                ops.gemm_tn(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
+                _wg(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
                 _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
                 if dkv_pre is None:
-                    ops.gemm_tn(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True, colsum=_gcat(qkvb[1:]))
+                    _wg(dkv, xkv.mma(), out=_gcat(qkvw[1:]), accumulate=True, colsum=_gcat(qkvb[1:]))
                     xkv.grad = ops.gemm_nn(dkv, self._w("kv", qkvw[1:]), addend=xkv.grad)
 
         mine = (qkvw[:1] + qkvb[:1]) if dkv_pre is not None else (qkvw + qkvb)
@@ -426,10 +443,10 @@ class PositionwiseFeedForward(_Cached):
                 ds, ds16 = ops.add_layernorm_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
                                                  want_bf16=True, dbias=w2.bias.grad, drop_x=dp)
                 y.grad = None
-                ops.gemm_tn(ds16, hid, out=w2.weight.grad, accumulate=True)
+                _wg(ds16, hid, out=w2.weight.grad, accumulate=True)
                 d_hid = (ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_bits=bits) if bits is not None
                          else ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid))
-                ops.gemm_tn(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
+                _wg(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
                 _acc(x, ops.gemm_nn(d_hid, self._w("w1", (w1.weight,)), addend=ds))
 
             _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
@@ -872,7 +889,7 @@ class Decoder(_Cached):
 
         def bw():   # pushed before the layers -> runs after all of them have written their dK / dV columns
             dkv = box.pop("dkv")
-            ops.gemm_tn(dkv, enc.mma(), out=_gcat(ws), accumulate=True, colsum=_gcat(bs))
+            _wg(dkv, enc.mma(), out=_gcat(ws), accumulate=True, colsum=_gcat(bs))
             enc.grad = ops.gemm_nn(dkv, W, addend=enc.grad)
 
         _TAPE.push(bw, tuple(ws) + tuple(bs))
