@@ -38,7 +38,7 @@ SIGNATURES = {
     "asr_attention_dropmask": [_vp, _dr, _i, _i, _i, _i, _vp],
     "asr_attention_dropmask_words": [_i, _i, _i, _i],
     "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dr, _dr],
-    "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp],
+    "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
     "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _dr],
     "asr_dropout_apply": [_vp, _vp, _vp, _i, _i, _i, _dr],

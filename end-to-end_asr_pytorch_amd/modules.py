@@ -132,7 +132,7 @@ def _wg(a, b, **kw):
     side.wait_event(ev)
     _WGRAD["keep"].append((a, b))
     with torch.cuda.stream(side):
-        return ops.gemm_tn(a, b, **kw)
+        return ops.gemm_tn(a, b, max_wgs=256, **kw)      # one workgroup per CU: the main chain's kernels keep the other slot
 
 
 def _prefetch_attn_masks(sites, training, device):

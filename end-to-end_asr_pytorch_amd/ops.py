@@ -408,7 +408,7 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
     return out
 
 
-def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None):
+def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     """dW[N,K] = A[M,N]^T . B[M,K]  (f32 result).  A/B f32 or bf16; rows may be strided (padded buffers).
     colsum (f32 [N]) += column sums of A (the bias gradient) in the same pass."""
     _req_cuda(a2d, b2d)
@@ -421,7 +421,7 @@ def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None):
     with _timed("gemm_tn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
         check(lib().asr_gemm_tn(_stream(), _p(a2d), dtype_code(a2d), a2d.stride(0), _p(b2d), dtype_code(b2d), b2d.stride(0), _p(out),
                                 out.stride(0), M, N, K,
-                                0 if accumulate else 1, _p(colsum)), "asr_gemm_tn")
+                                0 if accumulate else 1, _p(colsum), int(max_wgs)), "asr_gemm_tn")
     return out
 
 

@@ -155,9 +155,11 @@ int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const f
 /* Weight gradient  C[N,K] (+)= sum_m A[m,n] * B[m,k]  (nn.Linear: A = dY [M,N], B = X [M,K] -> dW).  A, B f32 or bf16
  * (converted to bf16 MFMA operands on load); C f32.  zero_first != 0 clears C first (the kernel accumulates with
  * float atomics across M-splits).  lda / ldb multiples of 4 and >= N / K rounded up to 4 (A and B may live in padded buffers).
- * colsum (optional, f32 [N]): += sum_m A[m,n], the bias gradient, accumulated in the same pass (caller zeroes it). */
+ * colsum (optional, f32 [N]): += sum_m A[m,n], the bias gradient, accumulated in the same pass (caller zeroes it).
+ * max_workgroups: 0 = the kernel's own choice (2 workgroups per CU: the launch has the chip to itself); a caller that queues the
+ * GEMM beside other kernels (a weight-gradient side stream) passes 256 = one per CU, half the M-splits and atomics. */
 int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int b_dtype, int64_t ldb, float* C,
-                int64_t ldc, int M, int N, int K, int zero_first, float* colsum);
+                int64_t ldc, int M, int N, int K, int zero_first, float* colsum, int max_workgroups);
 /* Bias gradient out[n] (+)= sum_m A[m,n]. */
 int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first);
 /* Embedding backward: demb[ids[r], :] += dropout_mask(dy[r, :])  (f32 atomics; caller zeroes demb).  M = B*U rows. */
