@@ -144,6 +144,12 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # initialisation, before the W warmup steps of the contract: the first steps of a process grow the caching allocator's pools,
+    # load code objects, create the side streams / event pool and (N > 1) the RCCL communicators; on a cold box one of them can
+    # cost tens of milliseconds, which W = 2..3 warmup steps do not always absorb
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
