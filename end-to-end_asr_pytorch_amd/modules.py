@@ -253,6 +253,18 @@ class _Cached(nn.Module):
         return self._derived(key, params, build)
 
     def _b(self, key, params):
+        """fp32 (concatenation of) bias vectors; under the trainer adjacent biases are one view of the flat master buffer (no
+        per-step torch.cat: the fused Adam kernel updates the master in place)."""
+        p0 = params[0]
+        flat = getattr(p0, "_asr_flat32", None)
+        if flat is not None:
+            off, n, ok = p0._asr_off, 0, True
+            for q in params:
+                ok = ok and getattr(q, "_asr_off", -1) == off + n and getattr(q, "_asr_flat32", None) is flat
+                n += q.numel()
+            if ok:
+                return flat[off:off + n]
+
         def build():
             b = params[0] if len(params) == 1 else torch.cat(list(params), 0)
             return b.detach().float().contiguous()

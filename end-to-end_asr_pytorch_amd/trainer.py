@@ -75,7 +75,7 @@ class FlatParams:
             self.flat[off:off + k].copy_(p.data.reshape(-1).to(device))
             p.data = self.flat[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
-            p._asr_off, p._asr_gflat, p._asr_flat16 = off, self.grad, self.flat16
+            p._asr_off, p._asr_gflat, p._asr_flat16, p._asr_flat32 = off, self.grad, self.flat16, self.flat
         self.sync_shadow()
 
     def sync_shadow(self):
