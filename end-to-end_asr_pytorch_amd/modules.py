@@ -838,6 +838,8 @@ class Decoder(_Cached):
         when the caller knows it (the data loader does): without it one host sync reads it back from the device."""
         hint = self.__dict__.get("_pre_hint")      # the trainer pre-computes this before queueing the step (no mid-step host sync)
         if hint is not None and hint[0] is targets:
+            if len(hint) > 2 and hint[2] is not None:          # computed on a side stream: order the consumer after it
+                torch.cuda.current_stream().wait_event(hint[2])
             return hint[1]
         comp, n = _compact_targets(targets)
         if umax is None:

@@ -173,7 +173,7 @@ class Trainer:
         """optimizer.py:24-29 (step_num already incremented)."""
         return self.k * self.init_lr * min(self.step_num ** (-0.5), self.step_num * (self.warmup ** (-1.5)))
 
-    def _ctc_side_branch(self, enc, lens, ctc_targets):
+    def _ctc_side_branch(self, enc, lens, ctc_targets, pre_event=None):
         """The CTC branch of the joint models - ctc_fc projection, CTC loss forward AND backward, ctc_fc's own backward - depends
         on nothing but the encoder output, while the decoder branch next to it is a long run of small kernels (M = B*(U+1) rows)
         that leave most of the chip idle.  So it is queued on a side stream right after the encoder forward; its gradient wrt
@@ -183,6 +183,9 @@ class Trainer:
         main = torch.cuda.current_stream()
         aux = ops.aux_stream(enc.f32.device)
         aux.wait_stream(main)
+        if pre_event is not None:
+            aux.wait_event(pre_event)
+            ctc_targets.record_stream(aux)
         proxy = modules.Act(enc.f32, enc.b16, enc.B, enc.L)
         with torch.cuda.stream(aux):
             with modules.record() as side_tape:
@@ -214,9 +217,22 @@ class Trainer:
         side_ok = self.overlap_ctc and isinstance(model, modules.CTC_Transformer) and not isinstance(model, modules.CIF_Model)
         if side_ok:
             # the decoder's target bookkeeping has one host sync (max target length): do it now, before the step is queued
-            pre = model.decoder.preprocess(targets, umax=max_target_len)
-            model.decoder.__dict__["_pre_hint"] = (targets, pre)
-            model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1])
+            ev = None
+            if max_target_len is not None and targets.is_cuda:
+                # ... and with the length known there is no sync at all: the ~15 small index kernels go to a side stream beside
+                # the encoder forward (first needed at the decoder / the CTC branch, which wait for the event)
+                main, aux = torch.cuda.current_stream(), ops.aux_stream(targets.device, slot=4)
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    pre = model.decoder.preprocess(targets, umax=max_target_len)
+                for t in pre:
+                    t.record_stream(main)
+                ev = torch.cuda.Event()
+                ev.record(aux)
+            else:
+                pre = model.decoder.preprocess(targets, umax=max_target_len)
+            model.decoder.__dict__["_pre_hint"] = (targets, pre, ev)
+            model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1], ev)
         try:
             return self._forward_loss(feats, lens, targets, noise)
         finally:
