@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("RESULT " + json.dumps(out))
 else:
     res = []
-    for env in ({}, {"ASR_AMD_OVERLAP_CTC": "0", "ASR_AMD_MASK_PREFETCH": "0", "ASR_AMD_SPLITK": "0"}):
+    for env in ({}, {"ASR_AMD_OVERLAP_CTC": "0", "ASR_AMD_MASK_PREFETCH": "0", "ASR_AMD_SPLITK": "0", "ASR_AMD_WGRAD_STREAM": "0"}):
         e = dict(os.environ); e.update(env)
         p = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
