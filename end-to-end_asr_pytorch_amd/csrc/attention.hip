@@ -89,16 +89,21 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-template <int NW, bool CAUSAL, bool DROP>
+// KS = 2 (few queries, many keys: the decoder's cross attention, Lq = 51 against Lk = 1000): the NW waves are NW/2 query groups x 2
+// key streams - stream kh takes the key tiles t = 2 it + kh - and the two streams' (reference, row sum, O) states are merged through
+// LDS at the end.  One workgroup per (batch, head) then walks 8 dependent iterations instead of 16: the walk is pure latency
+// (128 workgroups of 2 waves on a 256-CU chip), so halving it halves the kernel.
+template <int NW, bool CAUSAL, bool DROP, int KS = 1>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
                                                                       float* __restrict__ lse, int h, int Lq, int Lk,
                                                                       const int32_t* __restrict__ k_len, int q_tiles,
                                                                       asr_dropout_t drop, const uint32_t* __restrict__ drop_bits) {
-    constexpr int QB = NW * 32, PIECES = 8 / NW;   // 1-KiB pieces (8 rows) per wave per operand tile
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V]
+    constexpr int NWQ = NW / KS, QB = NWQ * 32, PIECES = 8 * KS / NW;   // 1-KiB pieces (8 rows) per wave per operand, per iteration
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 * KS];   // [buf][key stream][K|V]
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % NWQ, kh = wave_all / NWQ;          // query group, key stream
     const int r = lane & 31, hh = lane >> 5;
     int qt, bh;
     {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     const int q0 = qt * QB;
     const int kl = k_len ? min(k_len[b], Lk) : Lk;
     const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
-    const int ntiles = (kmax + 63) >> 6;
+    const int ntiles = (kmax + 63) >> 6, niter = (ntiles + KS - 1) / KS;
     const int qrow = q0 + wave * 32 + r;
     const int wave_qlast = q0 + wave * 32 + 31;
     const bf16_t* Kb = K + (int64_t)bh * Lk * 64;
@@ -133,12 +138,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
 
     // this lane's (row, source chunk) inside each piece it stages: piece p covers tile rows 8p..8p+7
     const int prow = lane >> 3;
-    auto stage = [&](int buf, int t) {
-        unsigned char* base = smem + buf * 2 * 8192;
-        const int key0 = t * 64;
+    auto stage = [&](int buf, int it) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int p = wave * PIECES + i;
+            const int pa = wave_all * PIECES + i;            // piece among the 8 * KS of this iteration
+            const int p = pa & 7, ks = pa >> 3;
+            unsigned char* base = smem + (buf * KS + ks) * 2 * 8192;
+            const int key0 = (it * KS + ks) * 64;
             const int row = 8 * p + prow;
             const int c = (lane & 7) ^ swz2(row);
             const int64_t goff = (int64_t)min(key0 + row, kl - 1) * 64 + c * 8;
@@ -160,18 +166,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
 
     if (ntiles > 0) stage(0, 0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
+    for (int it = 0; it < niter; ++it) {
+        const int cur = it & 1, t = it * KS + kh;
         uint32_t wk[2] = {0u, 0u};
         if (DROP) {   // before the DMA is queued: vmcnt retires in order, queued after it these two words would wait for the whole next tile
             wk[0] = mkp[(int64_t)(2 * t) * lqp] >> (4 * hh);
             wk[1] = mkp[(int64_t)(2 * t + 1) * lqp] >> (4 * hh);
         }
-        if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
-        const unsigned char* Ks = smem + cur * 2 * 8192;
+        if (it + 1 < niter) stage(cur ^ 1, it + 1);
+        const unsigned char* Ks = smem + (cur * KS + kh) * 2 * 8192;
         const unsigned char* Vs = Ks + 8192;
         const int key0 = t * 64;
-        if (!(CAUSAL && key0 > wave_qlast)) {   // wave-uniform: otherwise the whole tile lies in this wave's future
+        if (t < ntiles && !(CAUSAL && key0 > wave_qlast)) {   // wave-uniform: otherwise the whole tile lies in this wave's future (or past the end)
             f32x16 st[2];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
@@ -270,6 +276,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
         __syncthreads();   // next tile's DMA has landed (barrier fence drains vmcnt) and `cur` may be overwritten
     }
 
+    if (KS > 1) {   // merge the key streams: stream 1 parks its state in LDS (the operand tiles are dead), stream 0 folds it in
+        float* park = reinterpret_cast<float*>(smem) + (wave * 64 + lane) * 36;
+        if (kh == 1) {
+            park[0] = mref; park[1] = l; park[2] = first ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { park[3 + i] = o0[i]; park[19 + i] = o1[i]; }
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        if (park[2] == 0.f) {                 // the other stream saw at least one live key
+            const float mb = park[0], lb = park[1];
+            const float m = first ? mb : fmaxf(mref, mb);
+            const float sa = first ? 0.f : __builtin_amdgcn_exp2f(mref - m), sb = __builtin_amdgcn_exp2f(mb - m);
+            l = l * sa + lb * sb;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] = o0[i] * sa + park[3 + i] * sb; o1[i] = o1[i] * sa + park[19 + i] * sb; }
+            mref = m;
+        }
+    }
     if (qrow < Lq) {
         const float inv = (DROP ? drop_scale(drop) : 1.f) / l;
         bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
@@ -327,13 +352,14 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(uint32_t* __restrict
     mq[((int64_t)bh * (lqp / 32) + qw) * lkp + key0 + hh * 32 + r] = x;
 }
 
-template <int NW> int launch_bf16(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B,
+template <int NW, int KS = 1> int launch_bf16(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B,
                                   int h, int Lq, int Lk, const int32_t* k_len, int causal, asr_dropout_t drop, const uint32_t* drop_bits) {
-    const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);
+    constexpr int QB = NW / KS * 32;
+    const int q_tiles = (Lq + QB - 1) / QB;
     dim3 grid(B * h * q_tiles), block(NW * 64);
     {
 #define LAUNCH_V2(C, D)                                                                                                        \
-    hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,             \
+    hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D, KS>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,         \
                        (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits)
         if (causal) { if (drop.thr16) LAUNCH_V2(true, true); else LAUNCH_V2(true, false); }
         else        { if (drop.thr16) LAUNCH_V2(false, true); else LAUNCH_V2(false, false); }
@@ -376,6 +402,7 @@ extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, con
     }
     ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
     if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+    if (Lq <= 64 && Lk >= 256 && !causal) return launch_bf16<4, 2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);   // cross attention
     if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
     return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
 }

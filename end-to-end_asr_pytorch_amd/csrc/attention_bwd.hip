@@ -75,17 +75,20 @@ __device__ __forceinline__ bf16x8 frag_tr2(const unsigned char* t, int cb, int h
 }
 
 // ---------------------------------------------------------------------------------------------------------
-template <int NW, bool CAUSAL, bool DROP>
+// KS = 2: two key streams per workgroup, merged at the end (see attn_fwd_bf16_v2_kernel) - stream kh's NW/2 waves stage and consume
+// the key tiles t = 2 it + kh.
+template <int NW, bool CAUSAL, bool DROP, int KS = 1>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
                                                                  const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                                  float* __restrict__ delta, bf16_t* __restrict__ dq_out, int64_t ldq,
                                                                  int h, int Lq, int Lk, const int32_t* __restrict__ k_len, int q_tiles,
                                                                  float scale, asr_dropout_t drop, const uint32_t* __restrict__ drop_bits) {
-    constexpr int QB = NW * 32, PIECES = 8 / NW;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192];   // [buf][K|V], row-major, LDS-DMA filled
+    constexpr int NWQ = NW / KS, QB = NWQ * 32, PIECES = 8 / NWQ;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 8192 * KS];   // [buf][key stream][K|V], row-major, LDS-DMA filled
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % NWQ, kh = wave_all / NWQ;          // query group, key stream
     int qt, bh;   // XCD-aware map (see attention.hip): tiles of one (batch, head) share an XCD and are adjacent in time
     {
         const int BH = gridDim.x / q_tiles;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     const int q0 = qt * QB;
     const int kl = k_len ? min(k_len[b], Lk) : Lk;
     const int kmax = CAUSAL ? min(kl, q0 + QB) : kl;
-    const int ntiles = (kmax + 63) >> 6;
+    const int ntiles = (kmax + 63) >> 6, niter = (ntiles + KS - 1) / KS;
     const int qrow = q0 + wave * 32 + r;
     const int wave_qlast = q0 + wave * 32 + 31;
     const bool qok = qrow < Lq;
@@ -127,26 +130,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     }
     dl += __shfl_xor(dl, 32, 64);
     const float my_lse2 = qok ? lse[(int64_t)bh * Lq + qrow] : 0.f;   // base-2, like the scores (q carries log2(e)/sqrt(d_k))
-    if (qok && hh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
+    if (qok && hh == 0 && kh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
 
     f32x16 a0 = zero16(), a1 = zero16();
-    auto stage = [&](int buf, int t) {
-        dma_tile<PIECES>(smem + buf * 16384, Kb, 64, t * 64, kl, wave, lane);
-        dma_tile<PIECES>(smem + buf * 16384 + 8192, Vb, 64, t * 64, kl, wave, lane);
+    auto stage = [&](int buf, int it) {      // each key stream's waves stage their own tile
+        const int t = it * KS + kh;
+        dma_tile<PIECES>(smem + (buf * KS + kh) * 16384, Kb, 64, t * 64, kl, wave, lane);
+        dma_tile<PIECES>(smem + (buf * KS + kh) * 16384 + 8192, Vb, 64, t * 64, kl, wave, lane);
     };
     if (ntiles > 0) stage(0, 0);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int key0 = t * 64, cur = t & 1;
+    for (int it = 0; it < niter; ++it) {
+        const int t = it * KS + kh, key0 = t * 64, cur = it & 1;
         uint32_t wk[2] = {0u, 0u};
         if (DROP) {   // ahead of the DMA: vmcnt retires in order, queued behind it these two words would wait for the whole next tile
             wk[0] = mkp[(int64_t)(2 * t) * lqp] >> (4 * hh);
             wk[1] = mkp[(int64_t)(2 * t + 1) * lqp] >> (4 * hh);
         }
-        if (t + 1 < ntiles) stage(cur ^ 1, t + 1);
-        const unsigned char* Ks = smem + cur * 16384;
+        if (it + 1 < niter) stage(cur ^ 1, it + 1);
+        const unsigned char* Ks = smem + (cur * KS + kh) * 16384;
         const unsigned char* Vs = Ks + 8192;
-        if (CAUSAL && key0 > wave_qlast) { __syncthreads(); continue; }
+        if (t >= ntiles || (CAUSAL && key0 > wave_qlast)) { __syncthreads(); continue; }
         // interior tile: every key valid for every (in-range) query of this wave -> no mask arithmetic (wave-uniform)
         const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32) && (q0 + wave * 32 + 31 < Lq);
         f32x16 st[2], dp[2];
@@ -189,6 +193,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr2(Ks, 1, hf, s2, lane), pf, a1, 0, 0, 0);
             }
         __syncthreads();   // next tile's DMA landed; `cur` may be overwritten
+    }
+    if (KS > 1) {   // fold key stream 1's partial dQ into stream 0's
+        float* park = reinterpret_cast<float*>(smem) + (wave * 64 + lane) * 32;
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { park[i] = a0[i]; park[16 + i] = a1[i]; }
+        }
+        __syncthreads();
+        if (kh == 1) return;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a0[i] += park[i]; a1[i] += park[16 + i]; }
     }
     if (qok) store_T(dq_out + ((int64_t)b * Lq + qrow) * ldq + hd * 64, a0, a1, hh, scale);
 }
@@ -337,18 +352,19 @@ extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, 
                     asr_aligned(dq, 8) && ldq % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dq: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *O = (const bf16_t*)o, *dO = (const bf16_t*)d_o;
-#define LAUNCH_DQ2(NW, C, D)                                                                                              \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, C, D>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, delta, \
+#define LAUNCH_DQ2(NW, C, D, KS)                                                                                          \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, C, D, KS>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, delta, \
                        (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles, scale, drop, drop_bits)
-#define LAUNCH_DQ(NW)                                                                                  \
-    do {                                                                                               \
-        const int q_tiles = (Lq + NW * 32 - 1) / (NW * 32);                                            \
-        if (causal) { if (drop.thr16) LAUNCH_DQ2(NW, true, true); else LAUNCH_DQ2(NW, true, false); }  \
-        else { if (drop.thr16) LAUNCH_DQ2(NW, false, true); else LAUNCH_DQ2(NW, false, false); }       \
+#define LAUNCH_DQ(NW, KS)                                                                                    \
+    do {                                                                                                     \
+        const int q_tiles = (Lq + NW / KS * 32 - 1) / (NW / KS * 32);                                        \
+        if (causal) { if (drop.thr16) LAUNCH_DQ2(NW, true, true, KS); else LAUNCH_DQ2(NW, true, false, KS); }  \
+        else { if (drop.thr16) LAUNCH_DQ2(NW, false, true, KS); else LAUNCH_DQ2(NW, false, false, KS); }       \
     } while (0)
-    if (Lq <= 32) LAUNCH_DQ(1);
-    else if (Lq <= 64) LAUNCH_DQ(2);
-    else LAUNCH_DQ(4);
+    if (Lq <= 32) LAUNCH_DQ(1, 1);
+    else if (Lq <= 64 && Lk >= 256 && !causal) LAUNCH_DQ(4, 2);      // the decoder's cross attention: two key streams per workgroup
+    else if (Lq <= 64) LAUNCH_DQ(2, 1);
+    else LAUNCH_DQ(4, 1);
 #undef LAUNCH_DQ
 #undef LAUNCH_DQ2
     ASR_LAUNCH_CHECK("attention_bwd_dq");
