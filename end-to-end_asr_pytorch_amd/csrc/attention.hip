@@ -89,10 +89,10 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-// KS = 2 (few queries, many keys: the decoder's cross attention, Lq = 51 against Lk = 1000): the NW waves are NW/2 query groups x 2
-// key streams - stream kh takes the key tiles t = 2 it + kh - and the two streams' (reference, row sum, O) states are merged through
-// LDS at the end.  One workgroup per (batch, head) then walks 8 dependent iterations instead of 16: the walk is pure latency
-// (128 workgroups of 2 waves on a 256-CU chip), so halving it halves the kernel.
+// KS = 2 / 4 (few queries, many keys: the decoder's cross attention, Lq = 51 against Lk = 1000): the NW waves are NW/KS query groups x
+// KS key streams - stream kh takes the key tiles t = KS it + kh - and the streams' (reference, row sum, O) states are merged through
+// LDS at the end.  One workgroup per (batch, head) then walks 8 / 4 dependent iterations instead of 16: the walk is pure latency
+// (128 workgroups of 2 waves on a 256-CU chip), so cutting it cuts the kernel.
 template <int NW, bool CAUSAL, bool DROP, int KS = 1>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
@@ -277,22 +277,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     }
 
     if (KS > 1) {   // merge the key streams: stream 1 parks its state in LDS (the operand tiles are dead), stream 0 folds it in
-        float* park = reinterpret_cast<float*>(smem) + (wave * 64 + lane) * 36;
-        if (kh == 1) {
+        if (kh > 0) {
+            float* park = reinterpret_cast<float*>(smem) + (((kh - 1) * NWQ + wave) * 64 + lane) * 36;
             park[0] = mref; park[1] = l; park[2] = first ? 1.f : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { park[3 + i] = o0[i]; park[19 + i] = o1[i]; }
         }
         __syncthreads();
-        if (kh == 1) return;
-        if (park[2] == 0.f) {                 // the other stream saw at least one live key
-            const float mb = park[0], lb = park[1];
-            const float m = first ? mb : fmaxf(mref, mb);
-            const float sa = first ? 0.f : __builtin_amdgcn_exp2f(mref - m), sb = __builtin_amdgcn_exp2f(mb - m);
-            l = l * sa + lb * sb;
+        if (kh > 0) return;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] = o0[i] * sa + park[3 + i] * sb; o1[i] = o1[i] * sa + park[19 + i] * sb; }
-            mref = m;
+        for (int ks = 1; ks < KS; ++ks) {
+            const float* park = reinterpret_cast<const float*>(smem) + (((ks - 1) * NWQ + wave) * 64 + lane) * 36;
+            if (park[2] == 0.f) {                 // that stream saw at least one live key
+                const float mb = park[0], lb = park[1];
+                const float m = first ? mb : fmaxf(mref, mb);
+                const float sa = first ? 0.f : __builtin_amdgcn_exp2f(mref - m), sb = __builtin_amdgcn_exp2f(mb - m);
+                l = l * sa + lb * sb;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] = o0[i] * sa + park[3 + i] * sb; o1[i] = o1[i] * sa + park[19 + i] * sb; }
+                mref = m;
+                first = false;
+            }
         }
     }
     if (qrow < Lq) {
@@ -402,7 +407,9 @@ extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, con
     }
     ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
     if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
-    if (Lq <= 64 && Lk >= 256 && !causal) return launch_bf16<4, 2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);   // cross attention
+    static const int xks = getenv("ASR_AMD_XATTN_KS") ? atoi(getenv("ASR_AMD_XATTN_KS")) : 4;
+    if (xks >= 4 && Lq <= 64 && Lk >= 512 && !causal) return launch_bf16<8, 4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);   // cross attention
+    if (xks >= 2 && Lq <= 64 && Lk >= 256 && !causal) return launch_bf16<4, 2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
     if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
     return launch_bf16<4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
 }

@@ -75,8 +75,8 @@ __device__ __forceinline__ bf16x8 frag_tr2(const unsigned char* t, int cb, int h
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// KS = 2: two key streams per workgroup, merged at the end (see attn_fwd_bf16_v2_kernel) - stream kh's NW/2 waves stage and consume
-// the key tiles t = 2 it + kh.
+// KS = 2 / 4: several key streams per workgroup, merged at the end (see attn_fwd_bf16_v2_kernel) - stream kh's NW/KS waves stage and
+// consume the key tiles t = KS it + kh.
 template <int NW, bool CAUSAL, bool DROP, int KS = 1>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
@@ -195,15 +195,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
         __syncthreads();   // next tile's DMA landed; `cur` may be overwritten
     }
     if (KS > 1) {   // fold key stream 1's partial dQ into stream 0's
-        float* park = reinterpret_cast<float*>(smem) + (wave * 64 + lane) * 32;
-        if (kh == 1) {
+        if (kh > 0) {
+            float* park = reinterpret_cast<float*>(smem) + (((kh - 1) * NWQ + wave) * 64 + lane) * 32;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { park[i] = a0[i]; park[16 + i] = a1[i]; }
         }
         __syncthreads();
-        if (kh == 1) return;
+        if (kh > 0) return;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { a0[i] += park[i]; a1[i] += park[16 + i]; }
+        for (int ks = 1; ks < KS; ++ks) {
+            const float* park = reinterpret_cast<const float*>(smem) + (((ks - 1) * NWQ + wave) * 64 + lane) * 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { a0[i] += park[i]; a1[i] += park[16 + i]; }
+        }
     }
     if (qok) store_T(dq_out + ((int64_t)b * Lq + qrow) * ldq + hd * 64, a0, a1, hh, scale);
 }
@@ -361,8 +365,10 @@ extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, 
         if (causal) { if (drop.thr16) LAUNCH_DQ2(NW, true, true, KS); else LAUNCH_DQ2(NW, true, false, KS); }  \
         else { if (drop.thr16) LAUNCH_DQ2(NW, false, true, KS); else LAUNCH_DQ2(NW, false, false, KS); }       \
     } while (0)
+    static const int xks = getenv("ASR_AMD_XATTN_KS") ? atoi(getenv("ASR_AMD_XATTN_KS")) : 4;
     if (Lq <= 32) LAUNCH_DQ(1, 1);
-    else if (Lq <= 64 && Lk >= 256 && !causal) LAUNCH_DQ(4, 2);      // the decoder's cross attention: two key streams per workgroup
+    else if (xks >= 4 && Lq <= 64 && Lk >= 512 && !causal) LAUNCH_DQ(8, 4);      // the decoder's cross attention: several key streams per workgroup
+    else if (xks >= 2 && Lq <= 64 && Lk >= 256 && !causal) LAUNCH_DQ(4, 2);
     else if (Lq <= 64) LAUNCH_DQ(2, 1);
     else LAUNCH_DQ(4, 1);
 #undef LAUNCH_DQ
