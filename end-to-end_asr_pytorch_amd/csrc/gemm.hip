@@ -65,8 +65,8 @@ struct EpiDense {
     int64_t ld_mask;
     bool vec_ok;              // host-checked: every pointer / leading dimension allows 4-wide vector access
     bool wide_ok;             // ... and C rows allow 16-byte stores (the LDS-transposed full-cache-line epilogue)
-    // ReLU sign bits (wide path only): bit (n & 7) of byte [m * ld_bits + n / 8] = output (m, n) > 0.  The FFN's first GEMM
-    // writes them next to its bf16 output; the hidden gradient's GEMM then masks from 1 bit instead of re-reading 16
+    // ReLU sign bits (wide path only; layout: bits_slot below).  The FFN's first GEMM writes them next to its bf16 output; the hidden
+    // gradient's GEMM then masks from 1 bit instead of re-reading 16
     unsigned char* bits_out;
     const unsigned char* bits_in;
     int64_t ld_bits;
@@ -104,10 +104,12 @@ struct EpiDense {
     // row cursor of the wide epilogue's read-back: the pointer of the first row once, then a kernel-uniform stride per step
     // (recomputing m * ldc per store cost two 64-bit multiplies = eight quarter-rate VALU ops per 16-byte store)
     struct Cur { unsigned char* p; };
-    __device__ __forceinline__ int64_t ld_bits_() const { return ld_bits; }
     __device__ __forceinline__ void step(Cur& c, int rows) const { c.p += (int64_t)rows * ldc * (c_dtype == ASR_F32 ? 4 : 2); }
-    __device__ __forceinline__ const unsigned char* bits_in_ptr(int m, int n) const { return bits_in + (int64_t)m * ld_bits + (n >> 3); }
-    __device__ __forceinline__ unsigned char* bits_out_ptr(int m, int n) const { return bits_out + (int64_t)m * ld_bits + (n >> 3); }
+    // sign-bit image: per 64 x 64 wave sub-tile (mw / 64, nw / 64) 64 lanes x 8 bytes, lane = 8 (row & 7) + (col / 8 & 7), byte it =
+    // rows 8 it + (row & 7): exactly what a lane of the read-back phase produces / consumes, as ONE 8-byte access per sub-tile
+    __device__ __forceinline__ int64_t bits_slot(int mw, int nw, int lane) const { return (((int64_t)(mw >> 6) * (N >> 6) + (nw >> 6)) * 64 + lane) * 8; }
+    __device__ __forceinline__ const unsigned char* bits_in_ptr(int mw, int nw, int lane) const { return bits_in + bits_slot(mw, nw, lane); }
+    __device__ __forceinline__ unsigned char* bits_out_ptr(int mw, int nw, int lane) const { return bits_out + bits_slot(mw, nw, lane); }
     __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
     __device__ __forceinline__ bool has_add() const { return addend != nullptr; }
     __device__ __forceinline__ bool has_mask() const { return relu_mask != nullptr; }
@@ -262,9 +264,8 @@ template <typename CT> struct EpiHeads {
             c.p += (int64_t)(h - 1) * L * 64 * (int)sizeof(CT);
         }
     }
-    __device__ __forceinline__ int64_t ld_bits_() const { return 0; }
-    __device__ __forceinline__ const unsigned char* bits_in_ptr(int, int) const { return nullptr; }
-    __device__ __forceinline__ unsigned char* bits_out_ptr(int, int) const { return nullptr; }
+    __device__ __forceinline__ const unsigned char* bits_in_ptr(int, int, int) const { return nullptr; }
+    __device__ __forceinline__ unsigned char* bits_out_ptr(int, int, int) const { return nullptr; }
     __device__ __forceinline__ bool relu() const { return false; }
     __device__ __forceinline__ bool atomic() const { return false; }
     __device__ __forceinline__ f32x4 ld_bias(int n) const { return *reinterpret_cast<const f32x4*>(bias + n); }
@@ -334,16 +335,8 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
         }
         // sign-bit mask (bf16 outputs): one byte = the 8 consecutive columns a lane stores in the read-back below; all 8 byte
         // loads of the sub-tile (rows lane / 8 + 8 it) go out now, ahead of everything else
-        unsigned bt_all[8];
-        if (epi.has_bits_in()) {
-            const int mf = mw + (lane >> 3);
-            const unsigned char* bp = epi.bits_in_ptr(mf, nw + (lane & 7) * 8);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                bt_all[it] = (mf + it * 8 < epi.M) ? (unsigned)*bp : 0u;
-                bp += 8 * epi.ld_bits_();
-            }
-        }
+        u32x2 bt_in = {0u, 0u}, bt_out = {0u, 0u};
+        if (epi.has_bits_in()) bt_in = *reinterpret_cast<const u32x2*>(epi.bits_in_ptr(mw, nw, lane));
         auto pass_rows = [&](auto IBc, int pass) {
             constexpr int IB = decltype(IBc)::value;                     // 16-row blocks of the sub-tile handled by this pass
             f32x4 av[IB][4];
@@ -401,7 +394,6 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
             if (bf16_out) {
                 const int ch = lane & 7, mf = mw + pass * IB * 16 + (lane >> 3);
                 auto rc = epi.cur(mf, nw);
-                unsigned char* bo = epi.has_bits_out() ? epi.bits_out_ptr(mf, nw + ch * 8) : nullptr;
 #pragma unroll
                 for (int it = 0; it < 2 * IB; ++it) {
                     const int rl = it * 8 + (lane >> 3), m = mf + it * 8;
@@ -409,7 +401,8 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                     if (epi.has_bits_in()) {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
-                            const unsigned bt = bt_all[(pass * 2 * IB + it) & 7];
+                            const int bi = (pass * 2 * IB + it) & 7;
+                            const unsigned bt = bt_in[bi >> 2] >> ((bi & 3) * 8);
                             const unsigned lo = (bt >> (2 * x)) & 1u, hi = (bt >> (2 * x + 1)) & 1u;
                             d[x] &= ((0u - lo) & 0xFFFFu) | ((0u - hi) & 0xFFFF0000u);
                         }
@@ -425,11 +418,11 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
                                 if (!epi.relu()) t &= ~d[x];                   // without a ReLU in front negative outputs are "off" too
                                 w |= (t & 0x80008000u) >> (15 - 2 * x);        // half 0 -> bit 2x, half 1 -> bit 16 + 2x
                             }
-                            *bo = (unsigned char)((w & 0x55u) | ((w >> 15) & 0xAAu));
+                            const int bi = (pass * 2 * IB + it) & 7;
+                            bt_out[bi >> 2] |= ((w & 0x55u) | ((w >> 15) & 0xAAu)) << ((bi & 3) * 8);
                         }
                     }
                     epi.step(rc, 8);
-                    if (epi.has_bits_out()) bo += 8 * epi.ld_bits_();
                 }
             } else {
                 if (epi.atomic()) {
@@ -461,6 +454,7 @@ __device__ __forceinline__ void run_epilogue(const Epi& epi, const f32x4 (&acc)[
             constexpr int IB = SCRB / 2048;          // 128 B per row
 #pragma unroll
             for (int pass = 0; pass < 4 / IB; ++pass) pass_rows(std::integral_constant<int, IB>{}, pass);
+            if (epi.has_bits_out()) *reinterpret_cast<u32x2*>(epi.bits_out_ptr(mw, nw, lane)) = bt_out;   // rows past M: zero bytes, in the pad
         } else {
             constexpr int IB = SCRB / 4096;          // 256 B per row
 #pragma unroll
@@ -1064,7 +1058,7 @@ extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t 
     epi.wide_ok = dense_wide_ok(epi);
     if (relu_bits_out) {
         // sign bits are produced by the LDS-transposed epilogue of the LDS-DMA kernel only: full 128-column tiles, bf16 x bf16
-        ASR_REQUIRE(epi.wide_ok && c_dtype == ASR_BF16 && N % 128 == 0 && ld_bits >= N / 8 && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 &&
+        ASR_REQUIRE(epi.wide_ok && c_dtype == ASR_BF16 && N % 128 == 0 && ld_bits == N / 8 && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 &&
                         K % 64 == 0 && (flags & ASR_GEMM_RELU) && getenv("ASR_AMD_NO_GLDS") == nullptr,
                     ASR_ERR_UNSUPPORTED, "gemm_ex: relu_bits_out needs bf16 operands/output, ReLU, N %% 128 == 0, K %% 64 == 0, aligned rows");
         epi.bits_out = reinterpret_cast<unsigned char*>(relu_bits_out);
@@ -1108,7 +1102,7 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     epi.wide_ok = dense_wide_ok(epi);
     if (mask_is_bits && relu_mask) {
         ASR_REQUIRE(epi.wide_ok && a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) &&
-                        ld_mask >= N / 8 && getenv("ASR_AMD_NO_TR") == nullptr,
+                        ld_mask == N / 8 && getenv("ASR_AMD_NO_TR") == nullptr,
                     ASR_ERR_UNSUPPORTED, "gemm_nn: a sign-bit mask needs the LDS-DMA kernel's shapes (bf16 A, K %% 64 == 0, N %% 128 == 0)");
         epi.bits_in = reinterpret_cast<const unsigned char*>(relu_mask);
         epi.ld_bits = ld_mask;

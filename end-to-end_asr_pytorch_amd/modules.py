@@ -437,7 +437,7 @@ class PositionwiseFeedForward(_Cached):
         # training: the ReLU mask travels to the backward as 1 sign bit per hidden unit (written by this GEMM's epilogue) - the
         # hidden gradient's GEMM then reads 8 MB instead of re-reading the 131 MB activation (S1 shape)
         use_bits = rec and _PRECISION == "bf16" and d_ff % 128 == 0 and x.mma().dtype == torch.bfloat16 and x.f32.shape[1] % 64 == 0
-        bits = torch.empty((x.mma().shape[0], d_ff // 8), device=x.f32.device, dtype=torch.uint8) if use_bits else None
+        bits = ops.relu_bits_buffer(x.mma().shape[0], d_ff, x.f32.device) if use_bits else None
         if use_bits:
             hid = ops.gemm_nt_ex(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True,
                                  relu_bits_out=bits)

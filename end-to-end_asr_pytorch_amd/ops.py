@@ -373,12 +373,19 @@ def cif_gather(hidden, cur, rem, fire_idx, n_fire, Umax):
 
 # ------------------------------------------------------------------------------------------------------------
 # backward-pass ops
+def relu_bits_buffer(M, N, device):
+    """Workspace for gemm_nt_ex(relu_bits_out=) / gemm_nn(relu_bits=): roundup(M, 128) * N/8 bytes in the epilogues' own order
+    (asr_hip.h), shaped [roundup(M, 128), N/8]."""
+    return torch.empty(((M + 127) // 128 * 128, N // 8), device=device, dtype=torch.uint8)
+
+
 def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=None, relu_mask=None, out=None, relu_bits_out=None):
     """C = A . W^T (+bias) (+addend) (masked by relu_mask > 0).  A [M,K] contiguous; W [N,K].
-    relu_bits_out: uint8 [M, N/8] receiving the sign bits of the (ReLU'd, bf16) output - see asr_hip.h."""
+    relu_bits_out: relu_bits_buffer(M, N) receiving the sign bits of the (ReLU'd, bf16) output - see asr_hip.h."""
     _req_cuda(a2d, w, bias, addend, relu_mask, relu_bits_out)
     M, K = a2d.shape
     N = w.shape[0]
+    assert relu_bits_out is None or (relu_bits_out.is_contiguous() and relu_bits_out.numel() >= (M + 127) // 128 * 128 * (N // 8))
     assert a2d.is_contiguous() and w.is_contiguous() and w.shape[1] == K
     if out is None:
         out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
@@ -396,6 +403,7 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
     _req_cuda(a2d, w, addend, relu_mask, relu_bits)
     assert relu_mask is None or relu_bits is None
     M = a2d.shape[0]
+    assert relu_bits is None or (relu_bits.is_contiguous() and relu_bits.numel() >= (M + 127) // 128 * 128 * (w.shape[1] // 8))
     K = a2d.shape[1] if K is None else K
     lda = a2d.stride(0) if lda is None else lda
     N = w.shape[1]

@@ -70,8 +70,10 @@ int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda, const voi
 
 /* asr_gemm_nt with more epilogue terms: C += addend (f32 [M,N], ld_add) and, when relu_mask (bf16 [M,N], ld_mask: the forward's
  * post-ReLU activations) is given, C = relu_mask > 0 ? C : 0.  Either may be NULL.
- * relu_bits_out (optional; uint8 [M, ld_bits >= N/8], with ASR_GEMM_RELU, bf16 operands and output, N % 128 == 0): bit (n & 7) of
- * byte [m*ld_bits + n/8] = (C[m,n] > 0) - the ReLU mask of module.py:50 at 1 bit per element, for asr_gemm_nn(mask_is_bits). */
+ * relu_bits_out (optional; with ASR_GEMM_RELU, bf16 operands and output, N % 128 == 0; ld_bits = N/8): the ReLU mask of
+ * module.py:50 at 1 bit per element, for asr_gemm_nn(mask_is_bits).  A buffer of roundup(M, 128) * N/8 bytes in the epilogues'
+ * own order - per 64 x 64 block (m/64, n/64; blocks row-major) 64 slots of 8 bytes, slot 8 (m & 7) + (n/8 & 7), byte (m/8 & 7)
+ * of it, bit (n & 7) = (C[m,n] > 0) - so that a wave writes / reads one 8-byte word per lane and block. */
 int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,
                    const float* bias, void* C, int c_dtype, int64_t ldc, int M, int N, int K, unsigned flags,
                    const float* addend, int64_t ld_add, const void* relu_mask, int64_t ld_mask, void* relu_bits_out,
@@ -80,7 +82,7 @@ int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const 
 /* Data gradient  C[M,N] = A[M,K] . Bm[K,N] (+bias) (+addend) (masked by relu_mask > 0): for nn.Linear with weight W [out,in],
  * dX = dY . W is A = dY [M,out], Bm = W (bf16, as stored: no transposed copy), K = out, N = in.  A f32 or bf16 with lda % 8 == 0
  * covering K rounded up to 8 (columns K..lda of A must be zero).  mask_is_bits != 0: relu_mask is the uint8 sign-bit image written
- * by asr_gemm_nt_ex(relu_bits_out) and ld_mask its row stride in bytes (bf16 A, K % 64 == 0, N % 128 == 0 only). */
+ * by asr_gemm_nt_ex(relu_bits_out) and ld_mask = N/8 (bf16 A, N % 128 == 0 only). */
 int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int64_t ldb, const float* bias, void* C,
                 int c_dtype, int64_t ldc, int M, int N, int K, const float* addend, int64_t ld_add, const void* relu_mask,
                 int64_t ld_mask, int mask_is_bits);

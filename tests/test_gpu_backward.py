@@ -220,13 +220,17 @@ def test_relu_sign_bits_round_trip(M, N_, K):
     x = torch.randn(M, K, generator=g).to(DEV).bfloat16()
     w1 = (torch.randn(N_, K, generator=g) / K ** 0.5).to(DEV).bfloat16()
     b1 = torch.randn(N_, generator=g).to(DEV)
-    bits = torch.zeros(M, N_ // 8, device=DEV, dtype=torch.uint8)
+    bits = ops.relu_bits_buffer(M, N_, DEV).zero_()
     hid = ops.gemm_nt_ex(x, w1, b1, out_dtype=torch.bfloat16, relu=True, relu_bits_out=bits)
     hid_plain = ops.gemm_nt(x, w1, b1, out_dtype=torch.bfloat16, relu=True)
     assert torch.equal(hid, hid_plain)
+    # decode the image (asr_hip.h): [m/64][n/64][m & 7][n/8 & 7][m/8 & 7] bytes, bit n & 7
+    Mp = bits.shape[0]
+    img = bits.view(Mp // 64, N_ // 64, 8, 8, 8)                              # [bm, bn, m&7, n/8&7, m/8&7]
+    rows = img.permute(0, 4, 2, 1, 3).reshape(Mp, N_ // 8)                    # [bm, m/8&7, m&7 | bn, n/8&7] = row-major [m, n/8]
     want = (hid.float() > 0).view(M, N_ // 8, 8).to(torch.uint8)
     packed = (want << torch.arange(8, device=DEV, dtype=torch.uint8)).sum(-1).to(torch.uint8)
-    assert torch.equal(bits, packed)
+    assert torch.equal(rows[:M], packed) and int(rows[M:].sum()) == 0
     dy = torch.randn(M, 256, generator=g).to(DEV).bfloat16()
     w2 = (torch.randn(256, N_, generator=g) / 16).to(DEV).bfloat16()
     a = ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16, relu_mask=hid)
