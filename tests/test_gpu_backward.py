@@ -145,7 +145,8 @@ def test_add_layernorm_bwd(D):
 
 
 @pytest.mark.parametrize("B,h,Lq,Lk,causal,ragged", [(2, 2, 25, 25, False, True), (2, 4, 200, 200, False, True), (2, 2, 51, 51, True, True),
-                                                     (2, 2, 51, 250, False, True), (1, 2, 300, 300, True, False), (1, 1, 1000, 1000, False, True)])
+                                                     (2, 2, 51, 250, False, True), (1, 2, 300, 300, True, False), (1, 1, 1000, 1000, False, True),
+                                                     (2, 2, 51, 1000, False, True), (2, 2, 40, 300, False, True), (1, 2, 64, 700, False, False)])   # 2 / 4 key streams
 def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
     g = torch.Generator().manual_seed(Lq * 3 + Lk)
     # device q carries log2(e) (asr_hip.h); the reference differentiates wrt exactly that tensor / log2(e)
