@@ -321,9 +321,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
 // A wave owns 32 queries x 64 keys with the forward kernel's element ownership (lane = query r, half hh; keys hf*32 + 8g + 4hh + x),
 // hashes its 16 words, and assembles: its nibbles -> with lane ^ 32 the two full 32-key words of query r (Mk); a 5-step 32 x 32 bit
 // transpose across each 32-lane half turns "word of query r" into "word of key c" (Mq).  Both stores are fully coalesced.
-__global__ __launch_bounds__(256) void attn_dropmask_kernel(uint32_t* __restrict__ bits, int Bn, int h, int Lq, int Lk, asr_dropout_t drop) {
+struct MaskSites {            // up to 8 dropout sites of one shape hashed by one launch (the decoder's 6 self / 6 cross attention calls)
+    asr_dropout_t drop[8];
+    uint32_t* bits[8];
+};
+__global__ __launch_bounds__(256) void attn_dropmask_kernel(MaskSites sites, int BH, int Bn, int h, int Lq, int Lk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int bh = blockIdx.z, b = bh / h, hd = bh - b * h;
+    const int site = blockIdx.z / BH, bh = blockIdx.z - site * BH, b = bh / h, hd = bh - b * h;
+    const asr_dropout_t drop = sites.drop[site];
+    uint32_t* __restrict__ bits = sites.bits[site];
     const int lqp = drop_pad128(Lq), lkp = drop_pad128(Lk);
     const int qw = blockIdx.y * 4 + wave, qrow = qw * 32 + r, key0 = blockIdx.x * 64;
     if (key0 >= Lk || qw * 32 >= Lq) return;                               // padding only: its bits are unspecified
@@ -343,7 +349,6 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(uint32_t* __restrict
     const uint32_t full0 = mine[0] | (uint32_t)__shfl_xor((int)mine[0], 32, 64);
     const uint32_t full1 = mine[1] | (uint32_t)__shfl_xor((int)mine[1], 32, 64);
     uint32_t x = hh ? full1 : full0;       // lanes 0..31: keys key0..+31 of query r; lanes 32..63: keys key0+32..+63
-    const int64_t BH = gridDim.z;
     bits[((int64_t)bh * (lkp / 32) + (key0 >> 5) + hh) * lqp + qrow] = x;
     // 32 x 32 bit transpose over the 32 lanes of each half (rows = lanes, columns = bit positions)
 #pragma unroll
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(256) void attn_dropmask_kernel(uint32_t* __restrict
         if (r & j) x ^= ((y >> j) ^ x) & m;            // lower-left block <- partner's upper-right
         else       x ^= (((x >> j) ^ y) & m) << j;     // upper-right block <- partner's lower-left
     }
-    uint32_t* mq = bits + BH * (lkp / 32) * lqp;
+    uint32_t* mq = bits + (int64_t)BH * (lkp / 32) * lqp;
     mq[((int64_t)bh * (lqp / 32) + qw) * lkp + key0 + hh * 32 + r] = x;
 }
 
@@ -378,13 +383,25 @@ template <int NW, int KS = 1> int launch_bf16(hipStream_t s, const void* q, cons
 
 extern "C" int64_t asr_attention_dropmask_words(int B, int h, int Lq, int Lk) { return 2 * drop_mk_words(B * h, Lq, Lk); }
 
-extern "C" int asr_attention_dropmask(void* stream, asr_dropout_t drop, int B, int h, int Lq, int Lk, uint32_t* bits) {
-    ASR_REQUIRE(bits && B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_dropmask: bad args");
-    ASR_REQUIRE(drop.thr16 > 0 && drop.thr16 < 65536u, ASR_ERR_ARG, "attention_dropmask: thr16 must be in (0, 65536)");
-    hipLaunchKernelGGL(attn_dropmask_kernel, dim3(drop_pad128(Lk) / 64, drop_pad128(Lq) / 128, B * h), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), bits, B, h, Lq, Lk, drop);
+extern "C" int asr_attention_dropmask_multi(void* stream, int n, const asr_dropout_t* drops, uint32_t* const* bits, int B, int h, int Lq,
+                                            int Lk) {
+    ASR_REQUIRE(drops && bits && n > 0 && n <= 8 && B > 0 && h > 0 && Lq > 0 && Lk > 0, ASR_ERR_ARG, "attention_dropmask: bad args (1..8 sites)");
+    ASR_REQUIRE((int64_t)B * h * n <= 65535, ASR_ERR_UNSUPPORTED, "attention_dropmask: B*h*n exceeds the grid's z extent");
+    MaskSites sites;
+    for (int i = 0; i < 8; ++i) {
+        sites.drop[i] = drops[i < n ? i : 0];
+        sites.bits[i] = bits[i < n ? i : 0];
+    }
+    for (int i = 0; i < n; ++i)
+        ASR_REQUIRE(bits[i] && drops[i].thr16 > 0 && drops[i].thr16 < 65536u, ASR_ERR_ARG, "attention_dropmask: site %d: null buffer or thr16 outside (0, 65536)", i);
+    hipLaunchKernelGGL(attn_dropmask_kernel, dim3(drop_pad128(Lk) / 64, drop_pad128(Lq) / 128, B * h * n), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sites, B * h, B, h, Lq, Lk);
     ASR_LAUNCH_CHECK("attention_dropmask");
     return 0;
+}
+
+extern "C" int asr_attention_dropmask(void* stream, asr_dropout_t drop, int B, int h, int Lq, int Lk, uint32_t* bits) {
+    return asr_attention_dropmask_multi(stream, 1, &drop, &bits, B, h, Lq, Lk);
 }
 
 extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v, int dtype, void* ctx, float* lse,

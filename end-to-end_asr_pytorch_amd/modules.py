@@ -354,7 +354,8 @@ class MultiheadAttention(_Cached):
         dp_fc = _drop(self, "dropout")   # attention.py:59
         if attn_drop is not None:        # (asr_dropout_t, keep bits, event): hashed ahead of time on a side stream (Encoder._attn_masks)
             dp_attn, dbits, ev = attn_drop
-            torch.cuda.current_stream().wait_event(ev)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
         else:
             dp_attn = _drop(self, "attention.dropout")   # attention.py:83
             dbits = ops.attention_dropmask(dp_attn, B, h, Lq, Lk, q.device)      # hashed once; forward, dQ and dK/dV kernels read bits
@@ -765,9 +766,9 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
-    def _impl(self, x, enc, dec_len, enc_len, kv_pre=None):
-        x = self.slf_attn._impl(x, x, dec_len, True, dec_len)
-        x = self.enc_attn._impl(x, enc, enc_len, False, dec_len, kv_pre=kv_pre)
+    def _impl(self, x, enc, dec_len, enc_len, kv_pre=None, attn_drop=(None, None)):
+        x = self.slf_attn._impl(x, x, dec_len, True, dec_len, attn_drop=attn_drop[0])
+        x = self.enc_attn._impl(x, enc, enc_len, False, dec_len, kv_pre=kv_pre, attn_drop=attn_drop[1])
         return self.pos_ffn._impl(x, dec_len)
 
 
@@ -868,9 +869,21 @@ class Decoder(_Cached):
 
             _TAPE.push(bw_emb, (emb.weight,))
         cross = self._cross_kv(enc)
-        # (the decoder's 12 small attention masks are hashed inline: queueing them ahead like the encoder's measured neutral)
+        # the decoder's small attention masks: one launch for all self-attention calls, one for all cross-attention calls (queueing
+        # them ahead on a side stream like the encoder's measured neutral; 12 launches on this latency-bound chain are 12 x ~5 us)
+        n = len(self.layer_stack)
+        m_self = m_cross = [None] * n
+        if self.training and x32.is_cuda and n <= 8:
+            ds = [_drop(layer.slf_attn, "attention.dropout") for layer in self.layer_stack]
+            dc = [_drop(layer.enc_attn, "attention.dropout") for layer in self.layer_stack]
+            if all(d is not None for d in ds + dc):
+                m_self = [(d, b_, None) for d, b_ in zip(ds, ops.attention_dropmask_multi(ds, B, self.n_head, U, U, x32.device))]
+                m_cross = [(d, b_, None) for d, b_ in zip(dc, ops.attention_dropmask_multi(dc, B, self.n_head, U, enc.L, x32.device))]
+            elif any(d is not None for d in ds + dc):
+                m_self = [(d, ops.attention_dropmask(d, B, self.n_head, U, U, x32.device), None) for d in ds]
+                m_cross = [(d, ops.attention_dropmask(d, B, self.n_head, U, enc.L, x32.device), None) for d in dc]
         for i, layer in enumerate(self.layer_stack):
-            x = layer._impl(x, enc, dec_len, enc_len, kv_pre=cross(i))
+            x = layer._impl(x, enc, dec_len, enc_len, kv_pre=cross(i), attn_drop=(m_self[i], m_cross[i]))
         logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, x)
         return logits.view(B, U, self.n_tgt_vocab), ys_out
 

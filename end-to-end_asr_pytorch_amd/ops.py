@@ -141,6 +141,20 @@ def attention_dropmask(drop, B, h, Lq, Lk, device):
     return bits
 
 
+def attention_dropmask_multi(drops, B, h, Lq, Lk, device):
+    """attention_dropmask for up to 8 sites of one shape in one launch -> list of uint32 tensors (views of one allocation)."""
+    n = len(drops)
+    assert 0 < n <= 8 and all(d is not None and d.thr16 > 0 for d in drops)
+    words = int(lib().asr_attention_dropmask_words(B, h, Lq, Lk))
+    buf = torch.empty((n, words), device=device, dtype=torch.int32)
+    darr = (Dropout * n)(*drops)
+    parr = (ctypes.c_void_p * n)(*[buf[i].data_ptr() for i in range(n)])
+    with _timed("attention_dropmask[%dx B%d h%d %dx%d]" % (n, B, h, Lq, Lk), 0.0):
+        check(lib().asr_attention_dropmask_multi(_stream(), n, ctypes.cast(darr, ctypes.c_void_p), ctypes.cast(parr, ctypes.c_void_p),
+                                                 B, h, Lq, Lk), "asr_attention_dropmask_multi")
+    return [buf[i] for i in range(n)]
+
+
 def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False, drop=None, drop_bits=None):
     """q [B,h,Lq,64] (pre-scaled), k/v [B,h,Lk,64] -> ctx [B,Lq,h*64] (same dtype), lse [B,h,Lq] or None.
     drop_bits: attention_dropmask(...) of this call (made here when omitted; pass it to share it with attention_bwd)."""

@@ -117,6 +117,8 @@ int asr_attention_fwd(void* stream, const void* q, const void* k, const void* v,
  *   then  BH*Lqp/32*Lkp words:    Mq[bh][q/32][key]  bit (q & 31)      (the key-stationary dK/dV kernel reads along key) */
 int64_t asr_attention_dropmask_words(int B, int h, int Lq, int Lk);
 int asr_attention_dropmask(void* stream, asr_dropout_t drop, int B, int h, int Lq, int Lk, uint32_t* bits);
+/* ... of n <= 8 dropout sites of one shape in one launch (host arrays drops[n], bits[n]: one buffer per site). */
+int asr_attention_dropmask_multi(void* stream, int n, const asr_dropout_t* drops, uint32_t* const* bits, int B, int h, int Lq, int Lk);
 
 /* Backward of asr_attention_fwd (bf16 only).  q,k,v as in the forward; o = the forward's ctx and d_o = its gradient, both
  * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 [B,h,Lq] workspace.  Outputs are token-major bf16:
