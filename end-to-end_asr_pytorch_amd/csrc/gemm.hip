@@ -71,6 +71,7 @@ struct EpiDense {
     const unsigned char* bits_in;
     int64_t ld_bits;
     bool atomic_out;          // split-K (persistent kernels, f32 C, wide path): partial tiles are float-atomically added into a zeroed C
+    bool c_is_zero;           // host-side only: the caller hands over a C that is already all zeros (no zeroing launch before a split-K)
 
     // fast path (kernel-uniform): the tile lies fully inside N and everything is vector-aligned -> no per-element logic
     struct Row { unsigned char* c; const float* add; const bf16_t* mask; };
@@ -1008,7 +1009,8 @@ template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, 
         if constexpr (std::is_same<Epi, EpiDense>::value) {
             const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
             if (const int sp = pick_ksplit(epi, tiles, K); sp > 1) {
-                if (int rc = zero_c(s, epi.C, (int64_t)M * N)) return rc;
+                if (!epi.c_is_zero)
+                    if (int rc = zero_c(s, epi.C, (int64_t)M * N)) return rc;
                 EpiDense e2 = epi;
                 e2.atomic_out = true;
                 if (dense_mode(e2) == (1u | 128u)) return launch_glds(s, A, lda, W, ldw, M, N, K, dense_as<1u | 128u>(e2), sp);   // decoder FFN2
@@ -1040,9 +1042,10 @@ extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda
     ASR_REQUIRE(M > 0 && N > 0 && K > 0 && C, ASR_ERR_ARG, "gemm: M=%d N=%d K=%d C=%p", M, N, K, C);
     ASR_REQUIRE(c_dtype == ASR_F32 || c_dtype == ASR_BF16, ASR_ERR_ARG, "gemm: bad c_dtype");
     if (int rc = check_operands(A, a_dtype, lda, W, w_dtype, ldw, K)) return rc;
-    EpiDense epi{C, c_dtype, ldc, bias, flags, M, N, nullptr, 0, nullptr, 0, false};
+    EpiDense epi{C, c_dtype, ldc, bias, flags & ASR_GEMM_RELU, M, N, nullptr, 0, nullptr, 0, false};
     epi.vec_ok = dense_vec_ok(epi);
     epi.wide_ok = dense_wide_ok(epi);
+    epi.c_is_zero = (flags & ASR_GEMM_C_IS_ZERO) != 0;
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
 }
 
@@ -1100,6 +1103,8 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
                  ld_mask, false};
     epi.vec_ok = dense_vec_ok(epi);
     epi.wide_ok = dense_wide_ok(epi);
+    epi.c_is_zero = (mask_is_bits & 2) != 0;
+    mask_is_bits &= 1;
     if (mask_is_bits && relu_mask) {
         ASR_REQUIRE(epi.wide_ok && a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) &&
                         ld_mask == N / 8 && getenv("ASR_AMD_NO_TR") == nullptr,
@@ -1113,7 +1118,8 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
         static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU, persistent
         const int sp = pick_ksplit(epi, nwg, K);
         if (sp > 1) {
-            if (int rc = zero_c(s, C, (int64_t)M * N)) return rc;
+            if (!epi.c_is_zero)
+                if (int rc = zero_c(s, C, (int64_t)M * N)) return rc;
             epi.atomic_out = true;
         }
         const int vtiles = nwg * sp;
@@ -1136,7 +1142,8 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     }
     const int sp = pick_ksplit(epi, nwg, K);     // e.g. the decoder's vocabulary data gradient [1632 x 256 x 4234]: 26 tiles x 67 K-tiles
     if (sp > 1) {
-        if (int rc = zero_c(s, C, (int64_t)M * N)) return rc;
+        if (!epi.c_is_zero)
+            if (int rc = zero_c(s, C, (int64_t)M * N)) return rc;
         epi.atomic_out = true;
     }
     if (a_dtype == ASR_F32)

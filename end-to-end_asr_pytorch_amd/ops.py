@@ -86,17 +86,64 @@ def as_i32(t, device=None):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# ---- zero arena -------------------------------------------------------------------------------------------------
+# The decoder-sized GEMMs are split over K and accumulate with atomics into a zeroed C (gemm.hip: pick_ksplit); 19 of them per
+# training step would each launch a zeroing kernel on the latency-bound decoder chain (a dependent launch costs ~5 us whatever it
+# does).  The trainer zeroes ONE arena at the start of the step instead; GEMM outputs of split-K shape are cut from it and the
+# library is told (ASR_GEMM_C_IS_ZERO).  Every slice is handed out once per reset, so it is still zero when the GEMM runs.
+_ARENA = {"buf": None, "off": 0, "live": False, "dirty": 0}
+GEMM_C_IS_ZERO = 4
+
+
+def arena_reset(device, nbytes=64 << 20):
+    """Zero the arena (one fill launch) and make its slices available until the next reset.  Call once per step, on the stream
+    the GEMMs will run on."""
+    if os.environ.get("ASR_AMD_ZERO_ARENA", "1") == "0":
+        return
+    device = torch.device(device)
+    if _ARENA["buf"] is None or _ARENA["buf"].device != device or _ARENA["buf"].numel() * 4 < nbytes:
+        _ARENA["buf"] = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
+        _ARENA["dirty"] = 0
+    if _ARENA["dirty"]:
+        _ARENA["buf"][:_ARENA["dirty"]].zero_()      # only what was handed out since the last reset
+    _ARENA["off"], _ARENA["dirty"], _ARENA["live"] = 0, 0, True
+
+
+def arena_release():
+    _ARENA["live"] = False     # (slices already handed out stay valid: they are views of the arena tensor)
+
+
+def _arena_take(M, N, K, device):
+    """-> zeroed f32 [M, N] for a GEMM output that the library will split over K, or None."""
+    if not _ARENA["live"] or _ARENA["buf"].device != device:
+        return None
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles > 64 or K < 512 or N % 128 != 0:       # mirror of gemm.hip pick_ksplit (a mismatch only costs the zeroing launch)
+        return None
+    n = M * N
+    off = (_ARENA["off"] + 63) // 64 * 64
+    if off + n > _ARENA["buf"].numel():
+        return None
+    _ARENA["off"] = _ARENA["dirty"] = off + n
+    return _ARENA["buf"][off:off + n].view(M, N)
+
+
 def gemm_nt_raw(a, M, K, lda, w, bias=None, out_dtype=torch.float32, relu=False, out=None, ldc=None):
     """C[M,N] = act(A . W^T + bias) where A is addressed as rows of K elements with stride lda inside tensor `a`."""
     _req_cuda(a, w, bias)
     N = w.shape[0]
     assert w.dim() == 2 and w.shape[1] == K and w.is_contiguous()
+    flags = GEMM_RELU if relu else 0
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=out_dtype)
+        out = _arena_take(M, N, K, a.device) if (out_dtype == torch.float32 and not relu and a.dtype == torch.bfloat16) else None
+        if out is not None:
+            flags |= GEMM_C_IS_ZERO
+        else:
+            out = torch.empty((M, N), device=a.device, dtype=out_dtype)
         ldc = N
     with _timed("gemm_nt[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
         check(lib().asr_gemm_nt(_stream(), _p(a), dtype_code(a), lda, _p(w), dtype_code(w), K, _p(bias), _p(out), dtype_code(out),
-                                ldc if ldc is not None else N, M, N, K, GEMM_RELU if relu else 0), "asr_gemm_nt")
+                                ldc if ldc is not None else N, M, N, K, flags), "asr_gemm_nt")
     return out
 
 
@@ -422,11 +469,14 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
     lda = a2d.stride(0) if lda is None else lda
     N = w.shape[1]
     assert w.is_contiguous() and w.dtype == torch.bfloat16 and w.shape[0] >= K and a2d.stride(1) == 1
-    out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
+    out = _arena_take(M, N, K, a2d.device) if (out_dtype == torch.float32 and relu_mask is None and relu_bits is None) else None
+    zero_flag = 2 if out is not None else 0
+    if out is None:
+        out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
     with _timed("gemm_nn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
         check(lib().asr_gemm_nn(_stream(), _p(a2d), dtype_code(a2d), lda, _p(w), N, None, _p(out), dtype_code(out), N, M, N, K,
                                 _p(addend), N, _p(relu_bits if relu_bits is not None else relu_mask),
-                                relu_bits.stride(0) if relu_bits is not None else N, 1 if relu_bits is not None else 0), "asr_gemm_nn")
+                                relu_bits.stride(0) if relu_bits is not None else N, (1 if relu_bits is not None else 0) | zero_flag), "asr_gemm_nn")
     return out
 
 

@@ -321,7 +321,12 @@ class Trainer:
     def step(self, feats, lens, targets, noise=None, max_target_len=None):
         """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync when max_target_len is given)."""
         self.fp.grad.zero_()
-        ctc, ce, state = self.forward_loss(feats, lens, targets, noise=noise, max_target_len=max_target_len)
-        self.backward(state)
+        if feats.is_cuda:
+            ops.arena_reset(feats.device)      # pre-zeroed outputs for the step's split-K GEMMs (ops: zero arena)
+        try:
+            ctc, ce, state = self.forward_loss(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+            self.backward(state)
+        finally:
+            ops.arena_release()
         self.optimizer_step()
         return ctc, ce

@@ -53,6 +53,7 @@ int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, in
 
 /* GEMM epilogue flags */
 #define ASR_GEMM_RELU 1u
+#define ASR_GEMM_C_IS_ZERO 4u   /* the caller's C is already all zeros: a split-K launch (few output tiles, long K) skips its zeroing kernel */
 
 int asr_version(void);
 const char* asr_last_error(void);
@@ -82,7 +83,8 @@ int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const 
 /* Data gradient  C[M,N] = A[M,K] . Bm[K,N] (+bias) (+addend) (masked by relu_mask > 0): for nn.Linear with weight W [out,in],
  * dX = dY . W is A = dY [M,out], Bm = W (bf16, as stored: no transposed copy), K = out, N = in.  A f32 or bf16 with lda % 8 == 0
  * covering K rounded up to 8 (columns K..lda of A must be zero).  mask_is_bits != 0: relu_mask is the uint8 sign-bit image written
- * by asr_gemm_nt_ex(relu_bits_out) and ld_mask = N/8 (bf16 A, N % 128 == 0 only). */
+ * by asr_gemm_nt_ex(relu_bits_out) and ld_mask = N/8 (bf16 A, N % 128 == 0 only).  mask_is_bits & 2: C is already all zeros
+ * (see ASR_GEMM_C_IS_ZERO). */
 int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int64_t ldb, const float* bias, void* C,
                 int c_dtype, int64_t ldc, int M, int N, int K, const float* addend, int64_t ld_add, const void* relu_mask,
                 int64_t ld_mask, int mask_is_bits);
