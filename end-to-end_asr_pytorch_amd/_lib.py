@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libasr_hip.so")
 SOURCES = ["common.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
-           "backward.hip", "debug_probe.hip"]
+           "backward.hip", "fused_small.hip", "debug_probe.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
@@ -37,6 +37,7 @@ SIGNATURES = {
     "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr, _vp],
     "asr_attention_dropmask": [_vp, _dr, _i, _i, _i, _i, _vp],
     "asr_attention_dropmask_multi": [_vp, _i, _vp, _vp, _i, _i, _i, _i],
+    "asr_gemm_add_layernorm_small": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr],
     "asr_attention_dropmask_words": [_i, _i, _i, _i],
     "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dr, _dr],
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i],

@@ -360,10 +360,16 @@ class MultiheadAttention(_Cached):
             dp_attn = _drop(self, "attention.dropout")   # attention.py:83
             dbits = ops.attention_dropmask(dp_attn, B, h, Lq, Lk, q.device)      # hashed once; forward, dQ and dK/dV kernels read bits
         ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec, drop=dp_attn, drop_bits=dbits)
-        o = ops.gemm_nt(ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,)), self._b("bfc", (self.fc.bias,)))
-        y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
-                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec,
-                                                 drop_x=dp_fc)
+        ctx2, wfc = ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,))
+        if _PRECISION == "bf16" and ops.gemm_add_layernorm_small_ok(ctx2, wfc, xq.f32.shape[1], B, Lq):      # decoder-sized rows: one launch
+            o, y32, y16, mean, rstd = ops.gemm_add_layernorm_small(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
+                                                                   self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps,
+                                                                   save_stats=rec, drop_x=dp_fc)
+        else:
+            o = ops.gemm_nt(ctx2, wfc, self._b("bfc", (self.fc.bias,)))
+            y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
+                                                     want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec,
+                                                     drop_x=dp_fc)
         y = Act(y32, y16, B, Lq)
         if rec:
             self._record_bw(xq, xkv, q, k, v, ctx, lse, o, mean, rstd, y, k_len, causal, row_len, scale, dp_attn, dp_fc,
@@ -444,10 +450,16 @@ class PositionwiseFeedForward(_Cached):
                                  relu_bits_out=bits)
         else:
             hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
-        o = ops.gemm_nt(hid, self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)))
         dp = _drop(self, "dropout")   # module.py:51
-        y32, y16, mean, rstd = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
-                                                 want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec, drop_x=dp)
+        w2m = self._w("w2", (self.w_2.weight,))
+        if _PRECISION == "bf16" and ops.gemm_add_layernorm_small_ok(hid, w2m, x.f32.shape[1], x.B, x.L):       # decoder-sized rows: one launch
+            o, y32, y16, mean, rstd = ops.gemm_add_layernorm_small(hid, w2m, self._b("b2", (self.w_2.bias,)), x.f32, self.layer_norm.weight,
+                                                                   self.layer_norm.bias, x.B, x.L, row_len=row_len, eps=self.layer_norm.eps,
+                                                                   save_stats=rec, drop_x=dp)
+        else:
+            o = ops.gemm_nt(hid, w2m, self._b("b2", (self.w_2.bias,)))
+            y32, y16, mean, rstd = ops.add_layernorm(o, x.f32, self.layer_norm.weight, self.layer_norm.bias, x.B, x.L, row_len=row_len,
+                                                     want_bf16=(_PRECISION == "bf16"), eps=self.layer_norm.eps, save_stats=rec, drop_x=dp)
         y = Act(y32, y16, x.B, x.L)
         if rec:
             ln, w1, w2 = self.layer_norm, self.w_1, self.w_2

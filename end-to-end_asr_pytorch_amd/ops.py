@@ -219,6 +219,37 @@ def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False, drop=None, 
     return ctx, lse
 
 
+SMALL_FUSED_MAX_ROWS = int(os.environ.get("ASR_AMD_FUSED_SMALL_ROWS", "4096"))     # 0 switches the fused small-M block off
+
+
+def gemm_add_layernorm_small_ok(a2d, w, D, B, L):
+    """Shapes asr_gemm_add_layernorm_small takes (and is meant for)."""
+    # K <= 512: a workgroup walks K alone (one round trip to L2 per 256 of K, ~0.6 us each: at K = 2048 the split-K GEMM + LayerNorm
+    # pair is faster - 42 vs 52 us)
+    return (0 < B * L <= SMALL_FUSED_MAX_ROWS and D == 256 and w.shape[0] == 256 and a2d.dtype == torch.bfloat16 and
+            w.dtype == torch.bfloat16 and a2d.shape[1] % 32 == 0 and a2d.shape[1] <= 512 and a2d.is_contiguous() and w.is_contiguous())
+
+
+def gemm_add_layernorm_small(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=True, eps=1e-5, save_stats=False,
+                             drop_x=None):
+    """LayerNorm(dropout_x(A . W^T + bias) + residual) for decoder-sized rows in one launch (asr_hip.h).
+    -> (s_sum [M,256] pre-norm sum, y32, y16 or None, mean, rstd) - the tensors the unfused gemm_nt + add_layernorm pair leaves."""
+    _req_cuda(a2d, w, bias, residual, gamma, beta, row_len)
+    M, K = a2d.shape
+    assert M == B * L
+    dev = a2d.device
+    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32)
+    y32 = torch.empty((M, 256), device=dev, dtype=torch.float32)
+    y16 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16) if want_bf16 else None
+    mean = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
+    with _timed("gemm_add_layernorm_small[%dx256x%d]" % (M, K), 2.0 * M * 256 * K):
+        check(lib().asr_gemm_add_layernorm_small(_stream(), _p(a2d), K, _p(w), _p(bias), _p(residual), _p(gamma), _p(beta), _p(row_len),
+                                                 _p(s_sum), _p(y32), _p(y16), _p(mean), _p(rstd), B, L, K, float(eps), _d(drop_x)),
+              "asr_gemm_add_layernorm_small")
+    return s_sum, y32, y16, mean, rstd
+
+
 def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False,
                   drop_x=None, drop_y=None):
     """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd).

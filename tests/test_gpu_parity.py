@@ -343,6 +343,31 @@ def test_ctc_bf16_gradient_is_the_rounded_f32_gradient(B, L, V, U):
     assert float(whole[:, :, V:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,L,K,ragged,drop", [(32, 51, 256, True, True), (3, 17, 2048, True, False), (2, 8, 64, False, True), (5, 100, 512, True, True)])
+def test_gemm_add_layernorm_small_matches_the_unfused_pair(B, L, K, ragged, drop):
+    """asr_gemm_add_layernorm_small (decoder-sized rows: projection + dropout + residual + LayerNorm in one launch) against
+    asr_gemm_nt followed by asr_add_layernorm_fwd on the same inputs - every output tensor the backward consumes."""
+    g = torch.Generator().manual_seed(B * 100 + K)
+    M, D = B * L, 256
+    a = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(D, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    bias, res = torch.randn(D, generator=g).to(DEV), torch.randn(M, D, generator=g).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    lens = (torch.randint(max(1, L // 2), L + 1, (B,), generator=g) if ragged else torch.full((B,), L)).int().to(DEV)
+    dp = ops.Dropout(6554, 11, 12) if drop else None
+    o = ops.gemm_nt(a, w, bias)
+    y32, y16, mean, rstd = ops.add_layernorm(o, res, gamma, beta, B, L, row_len=lens, want_bf16=True, save_stats=True, drop_x=dp)
+    s2, y32b, y16b, mean2, rstd2 = ops.gemm_add_layernorm_small(a, w, bias, res, gamma, beta, B, L, row_len=lens, save_stats=True, drop_x=dp)
+    # same products, f32 accumulation in a different order (one K walk instead of tiles / split-K): fp32 noise only
+    np.testing.assert_allclose(N(s2), N(o), atol=2e-4 * max(1.0, (K / 256) ** 0.5), rtol=1e-4)     # `o` now holds the pre-norm sum
+    np.testing.assert_allclose(N(mean2), N(mean), atol=1e-4)
+    np.testing.assert_allclose(N(rstd2), N(rstd), rtol=1e-4)
+    np.testing.assert_allclose(N(y32b), N(y32), atol=1e-3, rtol=1e-3)
+    np.testing.assert_allclose(N(y16b), N(y16), atol=2e-2, rtol=2e-2)
+    t = torch.arange(L, device=DEV)[None, :] >= lens[:, None]
+    assert float(y32b.view(B, L, D)[t].abs().max() if t.any() else 0.0) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # CE
 # ---------------------------------------------------------------------------------------------------------
