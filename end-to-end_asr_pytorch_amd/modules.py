@@ -361,8 +361,8 @@ class MultiheadAttention(_Cached):
             dbits = ops.attention_dropmask(dp_attn, B, h, Lq, Lk, q.device)      # hashed once; forward, dQ and dK/dV kernels read bits
         ctx, lse = ops.attention_fwd(q, k, v, k_len, causal, need_lse=rec, drop=dp_attn, drop_bits=dbits)
         ctx2, wfc = ctx.view(B * Lq, h * 64), self._w("fc", (self.fc.weight,))
-        if _PRECISION == "bf16" and ops.gemm_add_layernorm_small_ok(ctx2, wfc, xq.f32.shape[1], B, Lq):      # decoder-sized rows: one launch
-            o, y32, y16, mean, rstd = ops.gemm_add_layernorm_small(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
+        if _PRECISION == "bf16" and ops.gemm_add_layernorm_ok(ctx2, wfc, xq.f32.shape[1], B, Lq):      # projection + LayerNorm in one launch
+            o, y32, y16, mean, rstd = ops.gemm_add_layernorm(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
                                                                    self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps,
                                                                    save_stats=rec, drop_x=dp_fc)
         else:
@@ -452,8 +452,8 @@ class PositionwiseFeedForward(_Cached):
             hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
         dp = _drop(self, "dropout")   # module.py:51
         w2m = self._w("w2", (self.w_2.weight,))
-        if _PRECISION == "bf16" and ops.gemm_add_layernorm_small_ok(hid, w2m, x.f32.shape[1], x.B, x.L):       # decoder-sized rows: one launch
-            o, y32, y16, mean, rstd = ops.gemm_add_layernorm_small(hid, w2m, self._b("b2", (self.w_2.bias,)), x.f32, self.layer_norm.weight,
+        if _PRECISION == "bf16" and ops.gemm_add_layernorm_ok(hid, w2m, x.f32.shape[1], x.B, x.L):       # projection + LayerNorm in one launch
+            o, y32, y16, mean, rstd = ops.gemm_add_layernorm(hid, w2m, self._b("b2", (self.w_2.bias,)), x.f32, self.layer_norm.weight,
                                                                    self.layer_norm.bias, x.B, x.L, row_len=row_len, eps=self.layer_norm.eps,
                                                                    save_stats=rec, drop_x=dp)
         else:
