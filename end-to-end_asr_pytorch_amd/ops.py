@@ -230,16 +230,16 @@ def gemm_add_layernorm_small_ok(a2d, w, D, B, L):
             w.dtype == torch.bfloat16 and a2d.shape[1] % 32 == 0 and a2d.shape[1] <= 512 and a2d.is_contiguous() and w.is_contiguous())
 
 
-# the 128 x 256-tile fused kernel for encoder-sized rows is parity-tested but NOT faster yet (one workgroup per CU: its three-output
-# epilogue has nothing to overlap with - 41.8 vs 45.3 us at K = 256, 98 vs 88 us at K = 2048), so the models use it only on request
-FUSED_LN = os.environ.get("ASR_AMD_FUSED_LN", "0") != "0"
+# the 128 x 256-tile fused kernel for encoder-sized rows pays (a little) for the attention output projection only: one workgroup per
+# CU, so its three-output epilogue has nothing to overlap with - 41.8 vs 45.3 us at K = 256, 98 vs 88 us at K = 2048
+FUSED_LN = int(os.environ.get("ASR_AMD_FUSED_LN", "2"))        # 0: off; 1: every shape it takes; 2: K <= 512 only (default)
 
 
 def gemm_add_layernorm_ok(a2d, w, D, B, L):
     """Shapes the fused projection + LayerNorm kernels take: the small-M one (above) or the 128 x 256-tile one for any M."""
     if gemm_add_layernorm_small_ok(a2d, w, D, B, L):
         return True
-    return (FUSED_LN and B * L > SMALL_FUSED_MAX_ROWS and D == 256 and w.shape[0] == 256 and a2d.dtype == torch.bfloat16 and
+    return (FUSED_LN and (FUSED_LN == 1 or a2d.shape[1] <= 512) and B * L > SMALL_FUSED_MAX_ROWS and D == 256 and w.shape[0] == 256 and a2d.dtype == torch.bfloat16 and
             w.dtype == torch.bfloat16 and a2d.shape[1] % 64 == 0 and a2d.is_contiguous() and w.is_contiguous())
 
 
