@@ -929,44 +929,47 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
 
 
 // ---- projection + bias + dropout + residual + LayerNorm in one kernel (N = 256 = d_model; attention.py:58-60, module.py:50-52) ----
-// A 128 x 256 tile gives a workgroup COMPLETE rows: 8 waves (2 row halves x 4 column quarters of 64), one workgroup per CU with
-// 96 KiB of LDS-DMA stages, persistent over the row tiles.  After the K loop the 64 x 64 accumulators become v = dropout(acc + bias)
-// + residual in place, the row sums meet in LDS across the four column waves (two passes: mean, then variance - like
+// A 64 x 256 tile gives a workgroup COMPLETE rows.  After the K loop the 64 x 64 accumulators become v = dropout(acc + bias) +
+// residual in place, the row sums meet in LDS across the four column waves (two passes: mean, then variance - like
 // add_layernorm_fwd_kernel), and the three outputs (pre-norm sum s, y32, y16) leave through run_epilogue's LDS-transposed
 // full-cache-line stores.  Against the GEMM + LayerNorm pair this never writes / re-reads the [M, 256] f32 GEMM output and is one
-// launch instead of two.
+// launch instead of two.  (Measured: 42 us against 15 + 30 us at K = 256, 102 against 58 + 30 us at K = 2048 - the epilogue is as
+// slow as the separate LayerNorm kernel, with 64-byte residual fragments and three store passes; a 128 x 256-tile, 8-wave version
+// with one workgroup per CU measured the same.  Parity-tested, not used by the models by default.)
 struct LnArgs {
     const float* bias; const float* res; const float* gamma; const float* beta; const int32_t* row_len;
     float* s_out; float* y32; bf16_t* y16; float* mean; float* rstd;
     int L; float eps; asr_dropout_t drop_x;
 };
-__global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
+// 64 x 256 tiles, 4 waves (one per 64-column quarter), K-tiles of 32 in 20 KiB stages, two workgroups per CU, persistent.
+__global__ __launch_bounds__(256, 2) void gemm_nt_ln64_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
                                                             int M, int K, int ntiles, LnArgs ln) {
-    constexpr int KT = 64, TA = 128 * ROWB, TW = 256 * ROWB, STAGE = TA + TW, D = 256;   // 16 + 32 KiB per stage
+    constexpr int KT = 32, RB = 64, TA = 64 * RB, TW = 256 * RB, STAGE = TA + TW, D = 256;   // 4 + 16 KiB per stage (rows of 32 bf16)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-    __shared__ float red[2][128][4];
+    __shared__ float red[2][64][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, r16 = lane & 15, q4 = lane >> 4;
+    const int wm = 0, wn = wave, r16 = lane & 15, q4 = lane >> 4;
     const int nk = K / KT;
-    // staging: 48 one-KiB pieces (8 rows x 128 B) per stage, 6 per wave: pieces 0..15 = A rows, 16..47 = W rows
-    const bf16_t* src[6];
-    int dst[6];
+    // staging: 20 one-KiB pieces (16 rows x 64 B) per stage, 5 per wave: pieces 0..3 = A rows, 4..19 = W rows; LDS slot (row, pc)
+    // holds the row's 16-byte chunk pc ^ ((row >> 1) & 3): 8 consecutive rows then fill 8 different 16-byte slots of a 256-byte bank row
+    const bf16_t* src[5];
+    int dst[5];
     auto set_tile = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int p = wave * 6 + i;
-            const bool isA = p < 16;
-            const int pr = isA ? p : p - 16;
-            const int row = 8 * pr + (lane >> 3);
-            const int c = (lane & 7) ^ (row & 7);
-            src[i] = isA ? A + (int64_t)min(tile * 128 + row, M - 1) * lda + c * 8 : W + (int64_t)row * K + c * 8;
+        for (int i = 0; i < 5; ++i) {
+            const int p = wave * 5 + i;
+            const bool isA = p < 4;
+            const int pr = isA ? p : p - 4;
+            const int row = 16 * pr + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 1) & 3);
+            src[i] = isA ? A + (int64_t)min(tile * 64 + row, M - 1) * lda + c * 8 : W + (int64_t)row * K + c * 8;
             dst[i] = (isA ? 0 : TA) + pr * 1024;
         }
     };
     auto stage = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 5; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * KT),
                                              (__attribute__((address_space(3))) void*)(smem + buf * STAGE + dst[i]), 16, 0, 0);
     };
@@ -977,7 +980,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(const bf16_t* __rest
     int cur = 0;
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * 128;
+        const int m0 = tile * 64;
         f32x4 acc[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -987,16 +990,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(const bf16_t* __rest
             if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
             const unsigned char* As = smem + cur * STAGE;
             const unsigned char* Bs = As + TA;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int chunk = g * 4 + q4;
+            {
                 u32x4 a[4], b[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int arow = wm * 64 + i * 16 + r16;
-                    a[i] = *reinterpret_cast<const u32x4*>(As + arow * ROWB + ((chunk ^ (arow & 7)) << 4));
+                    const int arow = i * 16 + r16;
+                    a[i] = *reinterpret_cast<const u32x4*>(As + arow * RB + ((q4 ^ ((arow >> 1) & 3)) << 4));
                     const int brow = wn * 64 + i * 16 + r16;
-                    b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * ROWB + ((chunk ^ (brow & 7)) << 4));
+                    b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * RB + ((q4 ^ ((brow >> 1) & 3)) << 4));
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -1087,6 +1088,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_ln_kernel(const bf16_t* __rest
         if (more) __syncthreads();   // drains the DMA; scratch and `red` are free again
     }
 }
+
 
 template <typename AT, typename CT, typename Epi>
 int launch_gemm(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const Epi& epi) {
@@ -1220,10 +1222,10 @@ extern "C" int asr_gemm_add_layernorm(void* stream, const void* A, int64_t lda, 
                     asr_aligned(beta, 16) && (!bias || asr_aligned(bias, 16)) && (!residual || asr_aligned(residual, 16)) &&
                     (!y16 || asr_aligned(y16, 16)), ASR_ERR_ALIGN, "gemm_add_layernorm: 16-byte alignment");
     const int M = B * L, ntiles = (M + 127) / 128;
-    static const int max_wg = getenv("ASR_AMD_GEMM_LN_WGS") ? atoi(getenv("ASR_AMD_GEMM_LN_WGS")) : 256;     // one per CU (100 KiB of LDS)
     LnArgs ln{bias, residual, gamma, beta, row_len, s_out, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, L, eps, drop_x};
-    hipLaunchKernelGGL(gemm_nt_ln_kernel, dim3(ntiles < max_wg ? ntiles : max_wg), dim3(512), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), M, K, ntiles, ln);
+    const int nt64 = (M + 63) / 64;
+    hipLaunchKernelGGL(gemm_nt_ln64_kernel, dim3(nt64 < 512 ? nt64 : 512), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), M, K, nt64, ln);
     ASR_LAUNCH_CHECK("gemm_add_layernorm");
     return 0;
 }

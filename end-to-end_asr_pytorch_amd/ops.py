@@ -230,9 +230,9 @@ def gemm_add_layernorm_small_ok(a2d, w, D, B, L):
             w.dtype == torch.bfloat16 and a2d.shape[1] % 32 == 0 and a2d.shape[1] <= 512 and a2d.is_contiguous() and w.is_contiguous())
 
 
-# the 128 x 256-tile fused kernel for encoder-sized rows pays (a little) for the attention output projection only: one workgroup per
-# CU, so its three-output epilogue has nothing to overlap with - 41.8 vs 45.3 us at K = 256, 98 vs 88 us at K = 2048
-FUSED_LN = int(os.environ.get("ASR_AMD_FUSED_LN", "2"))        # 0: off; 1: every shape it takes; 2: K <= 512 only (default)
+# the fused kernel for encoder-sized rows (gemm.hip: gemm_nt_ln64_kernel) is parity-tested but no faster than the GEMM + LayerNorm pair
+# yet (42 vs 45 us at K = 256, 102 vs 88 us at K = 2048), so the models use it only on request
+FUSED_LN = int(os.environ.get("ASR_AMD_FUSED_LN", "0"))        # 0: off (default); 1: every shape it takes; 2: K <= 512 only
 
 
 def gemm_add_layernorm_ok(a2d, w, D, B, L):
