@@ -3,116 +3,227 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md §8d "S1"): CTC_Transformer (no conv front-end), d_model=256 h=4
 (d_k=d_v=64) d_inner=2048 enc12/dec6, V=4234, per-GPU batch B=32 x T=1000 x 80-dim fbank (full-length
-utterances), U=50, bf16 MFMA operands / fp32 accumulate.  One "step" = one pass of the hot path over one
-synthetic batch: encoder + ctc_fc + decoder forward, joint CTC + label-smoothed-CE loss
-[+ backward + RCCL gradient all-reduce + Adam when --train is given].
+utterances), U=50, bf16 MFMA operands / fp32 accumulate.  `--model s2` runs SURVEY §8d "S2" instead
+(Conv_CTC_Transformer: 2 conv layers, encoder length 250).  One "step" = one pass of the hot path over one
+synthetic batch: forward, joint CTC + label-smoothed-CE loss, backward, gradient all-reduce (RCCL), Adam
+(`--mode fwd`: eval-mode forward + loss only).
 value = input fbank frames per second summed over all ranks (weak scaling: per-GPU batch fixed).
 
-rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, timed live with HIP events on the launch
-stream inside the timed region), "cpu_baseline" (the numpy oracle of the same forward+loss on a bounded sample of
-the same batch, timed on this node's host cores; N=1 only), "kernels" (per-kernel live timings), "ctc" (the fused
-CTC loss op alone).
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts N ranks itself (one process per GPU, before this
+process touches the GPU) and returns their exit code; under `python -m torch.distributed.run ... bench.py --gpus N` it is one
+rank and checks WORLD_SIZE == N.
+
+rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel family, timed live with HIP events on the launch
+stream), "cpu_baseline" (stock PyTorch CPU running the reference's op sequence - forward + loss + backward - on this node's
+host cores, oracle/torch_cpu_ref.py; N=1 only), "kernels" (per-op live timings), "ctc" (the fused CTC loss op alone).
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-PMC_FILE = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_train_s1.json")   # rocprofv3 --pmc passes, tools/pmc_summary.py
-
-
-def pmc_traffic(op_name):
-    """HBM bytes per launch of the kernel(s) behind a bench op, from the committed PMC summary (separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes of this same bench; FETCH doubled per MI355X_MICROARCH.md §HBM).  None when unknown."""
-    if not os.path.exists(PMC_FILE):
-        return None
-    pmc = json.load(open(PMC_FILE))
-    B, T, h = CFG["B"], CFG["T"], CFG["n_head"]
-    tiles = lambda m, n: ((m + 127) // 128) * ((n + 127) // 128) * 256
-    M = B * T
-    table = {
-        "attention_bwd_dq[B%d h%d %dx%d]" % (B, h, T, T): [["attn_bwd_dq_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)]],
-        "attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, T, T): [["attn_bwd_dkv_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)]],
-        "attention_fwd[B%d h%d %dx%d]" % (B, h, T, T): [["attn_fwd_bf16_v2_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)],
-                                                       ["attn_fwd_bf16_kernel|grid=%d" % (B * h * ((T + 127) // 128) * 256)]],
-        "ctc_loss_bwd[B%d L%d V%d U%d]" % (B, T, CFG["vocab_size"], CFG["U"] + 1): [["ctc_grad_kernel|grid=%d" % (64 * B * 256)]],
-        "gemm_nn[%dx%dx%d]" % (M, CFG["d_inner"], CFG["d_model"]): [["gemm_nn_tr_kernel<mode80>|grid=%d" % tiles(M, CFG["d_inner"])],
-                                                                    ["gemm_nn_tr_kernel<mode24>|grid=%d" % tiles(M, CFG["d_inner"])]],
-        # (the LDS-DMA NT kernel is persistent: 512 workgroups; the compile-time epilogue mode tells the FFN's first GEMM apart)
-        "gemm_nt[%dx%dx%d]" % (M, CFG["d_inner"], CFG["d_model"]): [["gemm_nt_glds_kernel<mode51>|grid=%d" % (512 * 256)],
-                                                                    ["gemm_nt_glds_kernel<mode19>|grid=%d" % (512 * 256)]],
-    }
-    for keys in table.get(op_name, []):
-        if all(k in pmc for k in keys):
-            return int(sum(pmc[k]["hbm_bytes"] for k in keys))
-    return None
-
-
-
-
 PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_HBM_GBS = 8000.0            # HBM3E spec peak, same table
 
 CFG = dict(d_input=80, d_model=256, n_head=4, d_inner=2048, n_layers_enc=12, n_layers_dec=6, vocab_size=4234,
-           sos_id=2, eos_id=3, B=32, T=1000, U=50)
+           sos_id=2, eos_id=3, B=32, T=1000, U=50, n_conv_layers=0)
 
 
-def build_model(asr_amd, dev, dropout, train):
-    torch.manual_seed(0)
-    enc = asr_amd.Encoder(CFG["d_input"], CFG["n_layers_enc"], CFG["n_head"], CFG["d_model"], CFG["d_inner"], dropout=dropout)
-    dec = asr_amd.Decoder(CFG["sos_id"], CFG["eos_id"], CFG["vocab_size"], CFG["n_layers_dec"], CFG["n_head"], CFG["d_model"],
-                          CFG["d_inner"], dropout=dropout)
-    model = asr_amd.CTC_Transformer(enc, dec).to(dev)
-    return model.train() if train else model.eval()
-
-
-def make_batch(dev, seed):
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(CFG["B"], CFG["T"], CFG["d_input"], generator=g)
-    lens = torch.full((CFG["B"],), CFG["T"], dtype=torch.int64)
-    tg = torch.randint(4, CFG["vocab_size"] - 1, (CFG["B"], CFG["U"]), generator=g)
-    return x.to(dev), lens.to(dev), tg.to(dev)
-
-
-def cpu_baseline(model, x, lens, tg, n_utt=1):
-    """numpy oracle (oracle/asr_oracle.py = CPU port of the reference's arithmetic) on the first n_utt utterances."""
-    import numpy as np
-    from oracle import asr_oracle as O
-    sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
-    cfg = dict(n_layers_enc=CFG["n_layers_enc"], n_layers_dec=CFG["n_layers_dec"], n_head=CFG["n_head"], sos_id=CFG["sos_id"],
-               eos_id=CFG["eos_id"])
-    xs, ls, ts = x[:n_utt].cpu().numpy(), lens[:n_utt].cpu().numpy(), tg[:n_utt].cpu().numpy()
-    t0 = time.time()
-    l, ctc_logits, (logits, teos), _ = O.ctc_transformer_forward(sd, xs, ls, ts, cfg)
-    ctc, ce = O.cal_ctc_ce_loss(ctc_logits, l, logits, teos, 0.1)
-    dt = time.time() - t0
-    return dict(value=float(n_utt * CFG["T"] / dt), unit="frames/s", cores=os.cpu_count(), kind="port",
-                sample="%d of the batch's %d utterances (T=%d), forward+loss, numpy fp32 oracle, %.1f s" % (
-                    n_utt, CFG["B"], CFG["T"], dt)), float(ctc), float(ce), ctc_logits, logits
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--model", default="s1", choices=["s1", "s2"],
+                    help="s1: CTC_Transformer on raw fbank (BASELINE configs[1]); s2: Conv_CTC_Transformer (configs[2], L = T/4)")
     ap.add_argument("--mode", default="train", choices=["train", "fwd"],
                     help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="dropout rate of the training step (0.1 = every shipped config of the reference, egs/*/conf); ignored by --mode fwd")
-    args = ap.parse_args()
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("ASR_AMD_GRAPH", "1")),
+                    help="1: replay the fixed-shape training step from a captured HIP graph when capture succeeds (default); 0: eager launches")
+    ap.add_argument("--ragged", action="store_true", help="per-utterance lengths U{T/2..T} (max forced to T) and targets U{U/2..U}")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children (this process has not touched the GPU) and
+    pass their exit code on."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
+def build_model(asr_amd, dev, dropout, train):
+    import torch
+    torch.manual_seed(0)
+    d_in = CFG["d_model"] if CFG["n_conv_layers"] else CFG["d_input"]
+    enc = asr_amd.Encoder(d_in, CFG["n_layers_enc"], CFG["n_head"], CFG["d_model"], CFG["d_inner"], dropout=dropout)
+    dec = asr_amd.Decoder(CFG["sos_id"], CFG["eos_id"], CFG["vocab_size"], CFG["n_layers_dec"], CFG["n_head"], CFG["d_model"],
+                          CFG["d_inner"], dropout=dropout)
+    if CFG["n_conv_layers"]:
+        conv = asr_amd.Conv2dSubsample(CFG["d_input"], CFG["d_model"], n_layers=CFG["n_conv_layers"])
+        model = asr_amd.Conv_CTC_Transformer(conv, enc, dec).to(dev)
+    else:
+        model = asr_amd.CTC_Transformer(enc, dec).to(dev)
+    return model.train() if train else model.eval()
+
+
+def make_batch(dev, seed, ragged=False):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    B, T, U = CFG["B"], CFG["T"], CFG["U"]
+    x = torch.randn(B, T, CFG["d_input"], generator=g)
+    tg = torch.randint(4, CFG["vocab_size"] - 1, (B, U), generator=g)
+    if ragged:
+        lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+        lens[0] = T
+        ul = torch.randint(U // 2, U + 1, (B,), generator=g)
+        ul[0] = U
+        tg = tg * (torch.arange(U)[None, :] < ul[:, None])
+    else:
+        lens = torch.full((B,), T, dtype=torch.int64)
+    return x.to(dev), lens.to(dev), tg.to(dev)
+
+
+def cpu_baseline(model, x, lens, tg, dropout, train):
+    """Stock PyTorch CPU, the reference's op sequence (oracle/torch_cpu_ref.py, pinned on the reference's own outputs in
+    tests/test_oracle_golden.py): forward + joint loss + backward on a bounded sample of this batch, all host cores; plus
+    F.ctc_loss forward + backward alone at the batch's (B, T, U, V).  Bounded to ~10-30 s: the sample shrinks when the host is
+    small (memory: the reference keeps [h*B, L, L] attention maps of every layer for autograd) or slow."""
+    import torch
+    from oracle import torch_cpu_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        avail = 32.0
+    L = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
+    per_utt = 1.0 + CFG["n_layers_enc"] * CFG["n_head"] * L * L * 4 * 3.2 / 2 ** 30     # ~GiB autograd keeps per utterance
+    n_utt = CFG["B"]
+    while n_utt > 2 and n_utt * per_utt > 0.45 * avail:
+        n_utt //= 2
+    model_name = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    sd = R.leaves({k: v for k, v in model.state_dict().items()}, requires_grad=True)
+    cfg = dict(n_layers_enc=CFG["n_layers_enc"], n_layers_dec=CFG["n_layers_dec"], n_head=CFG["n_head"], sos_id=CFG["sos_id"],
+               eos_id=CFG["eos_id"])
+    xs, ls, ts = x.cpu(), lens.cpu(), tg.cpu()
+
+    def one(n):
+        for t in sd.values():
+            t.grad = None
+        t0 = time.perf_counter()
+        R.joint_step(sd, xs[:n], ls[:n], ts[:n], cfg, conv_layers=CFG["n_conv_layers"], p=dropout if train else 0.0, train=train,
+                     backward=train)
+        return time.perf_counter() - t0
+
+    t_probe = one(2)                       # warm-up (thread pool, allocator) and a cost probe: 2 utterances
+    while n_utt > 2 and t_probe * n_utt / 2 > 12.0:
+        n_utt //= 2
+    if n_utt > 2:
+        one(n_utt)                         # warm-up at the timed size
+    iters = 3 if t_probe * n_utt / 2 < 6.0 else 1
+    dts = [one(n_utt) for _ in range(iters)]
+    dt = sum(dts) / len(dts)
+    ctc_iters = 20
+    ctc_ms = R.ctc_op(CFG["B"], L if CFG["n_conv_layers"] else CFG["T"], CFG["U"], CFG["vocab_size"], ctc_iters)
+    what = "forward + loss + backward (train mode, dropout %g)" % dropout if train else "eval-mode forward + loss"
+    return dict(value=round(n_utt * CFG["T"] / dt, 1), unit="frames/s", cores=cores, kind="port", impl="torch-cpu",
+                cpu_model=model_name, ms_per_step=round(dt * 1e3, 1), ctc_cpu_ms=round(ctc_ms, 2),
+                sample="%d of the batch's %d utterances (T=%d), %s, stock torch %s CPU ops in the reference's op order "
+                       "(oracle/torch_cpu_ref.py), %d threads, 1 warm-up + %d timed iteration(s) of %.2f s; ctc_cpu_ms = F.log_softmax + "
+                       "F.ctc_loss forward + backward at (B=%d, T=%d, U=%d, V=%d), mean of %d iterations" % (
+                           n_utt, CFG["B"], CFG["T"], what, torch.__version__, cores, iters, dt, CFG["B"],
+                           L if CFG["n_conv_layers"] else CFG["T"], CFG["U"], CFG["vocab_size"], ctc_iters))
+
+
+def oracle_parity(asr_amd, model, x, lens, tg, n_utt=2):
+    """max |GPU - numpy oracle| of both logit tensors on the first n_utt utterances (eval mode); asserted in tests/test_gpu_fullsize.py."""
+    import numpy as np
+    import torch
+    from oracle import asr_oracle as O
+    sd = {k: v.detach().float().cpu().numpy() for k, v in model.state_dict().items()}
+    cfg = dict(n_layers_enc=CFG["n_layers_enc"], n_layers_dec=CFG["n_layers_dec"], n_head=CFG["n_head"], sos_id=CFG["sos_id"],
+               eos_id=CFG["eos_id"], n_conv_layers=CFG["n_conv_layers"])
+    xs, ls, ts = x[:n_utt].cpu().numpy(), lens[:n_utt].cpu().numpy(), tg[:n_utt].cpu().numpy()
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        if CFG["n_conv_layers"]:
+            ref_ctc, _, ref_logits = O.conv_ctc_transformer_forward(sd, xs, ls, ts, cfg)[:3]
+            cl, _, lg, _ = model(x[:n_utt], lens[:n_utt], tg[:n_utt])
+        else:
+            _, ref_ctc, (ref_logits, _), _ = O.ctc_transformer_forward(sd, xs, ls, ts, cfg)
+            _, cl, (lg, _) = model(x[:n_utt], lens[:n_utt], tg[:n_utt])
+    model.train(was_training)
+    return {"ctc_logits": float(np.abs(cl.float().cpu().numpy() - ref_ctc).max()),
+            "logits": float(np.abs(lg.float().cpu().numpy() - ref_logits).max()), "utterances": n_utt}
+
+
+# ---- kernel families: which device kernel an op name runs on (for the dominant-KERNEL pick and the PMC lookup) -------------------
+def family(op_name):
+    return op_name.split("[", 1)[0]
+
+
+def pmc_traffic(fam_kernel, prof_dir):
+    """HBM bytes per launch of a device kernel from the committed PMC summary (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this same bench; FETCH doubled per MI355X_MICROARCH.md §HBM), launch-weighted over its grid sizes.  None when unknown."""
+    path = os.path.join(prof_dir, "pmc_traffic_train_s1.json")
+    if not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    tot, n = 0.0, 0
+    for k, v in pmc.items():
+        if k.split("|", 1)[0].split("<", 1)[0] == fam_kernel:
+            tot += v["hbm_bytes"] * v["launches"]
+            n += v["launches"]
+    return int(tot / n) if n else None
+
+
+FAMILY_KERNEL = {"gemm_tn": "gemm_tn_tr_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
+                 "attention_fwd": "attn_fwd_bf16_v2_kernel", "attention_bwd": "attn_bwd_fused_kernel",
+                 "attention_bwd_dq": "attn_bwd_dq_kernel", "attention_bwd_dkv": "attn_bwd_dkv_kernel",
+                 "add_layernorm": "add_layernorm_fwd_kernel", "add_layernorm_bwd": "add_layernorm_bwd_kernel",
+                 "ctc_loss_fwd": "ctc_fused_fwd_kernel", "ctc_loss_bwd": "ctc_grad_bf16_kernel", "proj_heads": "gemm_nt_glds_kernel"}
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(spawn_ranks(args))
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    if args.model == "s2":
+        CFG["n_conv_layers"] = 2
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -126,17 +237,25 @@ def main():
     import asr_amd
     from asr_amd import ops
     asr_amd.set_precision(args.precision)
-    model = build_model(asr_amd, dev, args.dropout, train=(args.mode == "train"))
+    train = args.mode == "train"
+    model = build_model(asr_amd, dev, args.dropout, train=train)
     asr_amd.manual_seed(1234 + rank)       # dropout masks: reproducible, different on every rank
-    x, lens, tg = make_batch(dev, seed=rank)
+    x, lens, tg = make_batch(dev, seed=rank, ragged=args.ragged)
 
-    trainer = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1) if args.mode == "train" else None
+    trainer = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1) if train else None
+    use_graph = bool(args.graph) and trainer is not None
 
     def step():
         if trainer is not None:
+            if use_graph:
+                return trainer.step_graphed(x, lens, tg, max_target_len=CFG["U"])
             return trainer.step(x, lens, tg, max_target_len=CFG["U"])   # the loader knows its target lengths: no host sync in the step
         with torch.no_grad():
-            l, ctc_logits, (logits, teos) = model(x, lens, tg)
+            out = model(x, lens, tg)
+            if CFG["n_conv_layers"]:
+                ctc_logits, l, logits, teos = out
+            else:
+                l, ctc_logits, (logits, teos) = out
             ctc, ce = asr_amd.cal_ctc_ce_loss(ctc_logits, l, logits, teos, 0.1)
         return ctc, ce
 
@@ -145,9 +264,8 @@ def main():
             torch.distributed.barrier()
 
     # initialisation, before the W warmup steps of the contract: the first steps of a process grow the caching allocator's pools,
-    # load code objects, create the side streams / event pool and (N > 1) the RCCL communicators; on a cold box one of them can
-    # cost tens of milliseconds, which W = 2..3 warmup steps do not always absorb
-    for _ in range(6):
+    # load code objects, create the side streams / event pool, capture the step's HIP graph and (N > 1) set up the RCCL communicators
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -166,13 +284,15 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    graphed = bool(trainer is not None and use_graph and trainer.graph_active())
+    losses = [float(v) for v in out]
 
     # ---- live per-kernel timing over a second, identical run of the timed region (events add launch overhead, so the
-    # headline value above is measured without them) ----
+    # headline value above is measured without them; eager launches, one stream: per-op durations are then uncontended) ----
     if trainer is not None:
-        trainer.wgrad_stream = False    # (likewise the weight-gradient GEMMs, which the timed step runs on a second side stream)
-        trainer.overlap_ctc = False     # serial order for this pass: per-op durations are then uncontended (the CTC branch otherwise
-                                        # runs beside the decoder's kernels on a side stream and both would read slower than they are)
+        use_graph = False
+        trainer.wgrad_stream = False
+        trainer.overlap_ctc = False
     ops.profile_start()
     for _ in range(args.steps):
         step()
@@ -180,56 +300,71 @@ def main():
 
     if rank == 0:
         frames = world * CFG["B"] * CFG["T"] * args.steps
-        kernels = []
+        kernels, fams = [], {}
+        hbm_ops = ("add_layernorm", "ctc_loss", "ce_loss", "cif_", "adam")
         for name, r in prof.items():
             per_ms = r["ms"] / r["calls"]
-            hbm = name.startswith(("add_layernorm", "ctc_loss"))
+            hbm = name.startswith(hbm_ops)
             ach = (r["work"] / r["calls"]) / (per_ms * 1e-3) / (1e9 if hbm else 1e12)
             kernels.append(dict(name=name, calls_per_step=r["calls"] / args.steps, ms_per_call=round(per_ms, 4),
                                 ms_per_step=round(r["ms"] / args.steps, 3), bound="hbm" if hbm else "mfma",
                                 achieved=round(ach, 2), unit="GB/s" if hbm else "TFLOP/s"))
+            f = fams.setdefault(family(name), dict(ms=0.0, work=0.0, calls=0, hbm=hbm))
+            f["ms"] += r["ms"]
+            f["work"] += r["work"]
+            f["calls"] += r["calls"]
         kernels.sort(key=lambda k: -k["ms_per_step"])
-        dom = kernels[0]
-        peak = PEAK_HBM_GBS if dom["bound"] == "hbm" else PEAK_MFMA_BF16_TFLOPS
-        roofline = dict(kernel=dom["name"], bound=dom["bound"], achieved=dom["achieved"], peak=peak, unit=dom["unit"],
-                        frac=round(dom["achieved"] / peak, 4), traffic=pmc_traffic(dom["name"]),
-                        note="achieved = algorithmic FLOPs (or bytes) per launch / mean launch duration from HIP events "
-                             "on the launch stream, in a second pass of the same steps with the trainer's CTC side stream "
-                             "switched off (uncontended per-op durations; `value` is measured with it on); traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
-                             "WRITE_SIZE passes (profiles/r1/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 correction)")
+        # dominant KERNEL = the family (all shapes of one device kernel) with the most time in the step
+        dom_name, dom = max(((n, f) for n, f in fams.items() if f["work"] > 0), key=lambda nf: nf[1]["ms"])
+        ach = dom["work"] / (dom["ms"] * 1e-3) / (1e9 if dom["hbm"] else 1e12)
+        peak = PEAK_HBM_GBS if dom["hbm"] else PEAK_MFMA_BF16_TFLOPS
+        prof_dir = os.path.join(ROOT, "profiles", "r2")
+        if not os.path.exists(os.path.join(prof_dir, "pmc_traffic_train_s1.json")):
+            prof_dir = os.path.join(ROOT, "profiles", "r1")
+        roofline = dict(kernel="%s (%s, all shapes)" % (dom_name, FAMILY_KERNEL.get(dom_name, dom_name)),
+                        bound="hbm" if dom["hbm"] else "mfma", achieved=round(ach, 2), peak=peak,
+                        unit="GB/s" if dom["hbm"] else "TFLOP/s", frac=round(ach / peak, 4),
+                        launches_per_step=dom["calls"] / args.steps, ms_per_step=round(dom["ms"] / args.steps, 3),
+                        avg_launch_us=round(dom["ms"] / dom["calls"] * 1e3, 2),
+                        traffic=pmc_traffic(FAMILY_KERNEL.get(dom_name, dom_name), prof_dir),
+                        note="dominant kernel = the op family (one device kernel, all shapes summed) with the most time per step; "
+                             "achieved = algorithmic FLOPs (or bytes) of all its launches / their summed duration from HIP events on the "
+                             "launch stream, in a second eager pass of the same steps without side streams (uncontended per-op "
+                             "durations; `value` is measured with them); traffic = mean HBM bytes per launch from separate rocprofv3 "
+                             "--pmc FETCH_SIZE / WRITE_SIZE passes (%s/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 "
+                             "correction)" % os.path.relpath(prof_dir, ROOT))
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
         what = ("training step (train mode, dropout %g): forward + joint CTC/CE loss + backward + grad all-reduce + Adam" % args.dropout
-                if args.mode == "train" else "eval-mode forward + joint CTC/CE loss")
+                if train else "eval-mode forward + joint CTC/CE loss")
+        mname = ("S2: Conv_CTC_Transformer (2 conv layers, L=%d)" % (CFG["T"] // 4)) if CFG["n_conv_layers"] else "S1: CTC_Transformer"
+        Lc = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
         result = {
-            "metric": "fbank frames/sec (CTC_Transformer d256 h4 enc12/dec6, %s)" % what,
+            "metric": "fbank frames/sec (%s d256 h4 enc12/dec6, %s)" % (mname.split(":")[1].strip().split(" ")[0], what),
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "S1: CTC_Transformer d_model=256 h=4 d_inner=2048 enc12/dec6 V=4234, per-GPU B=32 x T=1000 x 80 "
-                                   "fbank, U=50, " + what, "global_batch": world * CFG["B"],
-                       "seq_len": CFG["T"], "parallelism": "dp%d" % world},
+            "config": {"workload": "%s d_model=256 h=4 d_inner=2048 enc12/dec6 V=4234, per-GPU B=32 x T=1000 x 80 "
+                                   "fbank%s, U=50, %s" % (mname, " (ragged lengths)" if args.ragged else "", what),
+                       "global_batch": world * CFG["B"], "seq_len": CFG["T"], "parallelism": "dp%d" % world,
+                       "launch": "hip-graph replay" if graphed else "eager"},
+            "losses_last_step": losses,
             "roofline": roofline,
             "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "fwd_GBps": ctc_k[0]["achieved"],
                      "fwd_frac_of_hbm_peak": round(ctc_k[0]["achieved"] / PEAK_HBM_GBS, 4),
                      "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
                      # bytes: the logits read twice (f32) + the gradient written (bf16 image in the trainer)
-                     "fwd_bwd_GBps": (round((2 * 4.0 + (2.0 if trainer is not None else 4.0)) * CFG["B"] * CFG["T"] * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
+                     "fwd_bwd_GBps": (round((2 * 4.0 + (2.0 if trainer is not None else 4.0)) * CFG["B"] * Lc * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
                                       if ctc_b else None)} if ctc_k else None),
             "kernels": kernels[:12], "op_ms_total": round(sum(k["ms_per_step"] for k in kernels), 3),
+            "families": sorted(({"family": n, "ms_per_step": round(f["ms"] / args.steps, 3),
+                                 "achieved": round(f["work"] / (f["ms"] * 1e-3) / (1e9 if f["hbm"] else 1e12), 1) if f["work"] else None,
+                                 "unit": "GB/s" if f["hbm"] else "TFLOP/s"} for n, f in fams.items()), key=lambda d: -d["ms_per_step"])[:8],
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, ref_ctc, ref_ce, ref_ctc_logits, ref_logits = cpu_baseline(model, x, lens, tg, n_utt=16)   # ~15-20 s of host work
-            result["cpu_baseline"] = cb
-            # sanity: the GPU result on the same utterance agrees with the oracle (bf16 tolerance); not timed
-            # (in train mode the weights have moved since `cb` copied them: cpu_baseline() reads the current weights)
-            model.eval()                   # the oracle run above is the eval-mode forward
-            with torch.no_grad():
-                l1, cl1, (lg1, te1) = model(x[:16], lens[:16], tg[:16])
-            import numpy as np
-            result["parity_vs_oracle_max_abs"] = {
-                "ctc_logits": float(np.abs(cl1.float().cpu().numpy() - ref_ctc_logits).max()),
-                "logits": float(np.abs(lg1.float().cpu().numpy() - ref_logits).max())}
+            result["cpu_baseline"] = cpu_baseline(model, x, lens, tg, args.dropout, train)
+            # sanity: the GPU result on the same utterances agrees with the numpy oracle (bf16 tolerance); not timed
+            result["parity_vs_oracle_max_abs"] = oracle_parity(asr_amd, model, x, lens, tg, n_utt=2)
         print(json.dumps(result))
     if world > 1:
         if trainer is not None:   # data-parallel invariant: every rank holds bit-identical parameters after the same steps

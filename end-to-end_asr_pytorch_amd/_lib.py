@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libasr_hip.so")
 SOURCES = ["common.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
-           "backward.hip", "fused_small.hip", "debug_probe.hip"]
+           "backward.hip", "fused_small.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
@@ -20,10 +20,10 @@ _vp, _i, _i64, _f, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 
 class Dropout(ctypes.Structure):
     """asr_dropout_t (include/asr_hip.h), passed by value.  thr16 == 0 disables dropout."""
-    _fields_ = [("thr16", ctypes.c_uint32), ("key0", ctypes.c_uint32), ("key1", ctypes.c_uint32)]
+    _fields_ = [("thr16", ctypes.c_uint32), ("key0", ctypes.c_uint32), ("key1", ctypes.c_uint32), ("salt", ctypes.c_void_p)]
 
 
-NO_DROP = Dropout(0, 0, 0)
+NO_DROP = Dropout(0, 0, 0, None)
 _dr = Dropout
 
 # name -> argtypes (restype is int unless noted).  Kept in lock-step with include/asr_hip.h; tests/test_abi.py checks
@@ -46,13 +46,14 @@ SIGNATURES = {
     "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _dr],
     "asr_dropout_apply": [_vp, _vp, _vp, _i, _i, _i, _dr],
     "asr_adam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f],
+    "asr_step_tick": [_vp, _vp, _f, _f, _f, _f, _f],
+    "asr_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f],
     "asr_proj_heads": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _f],
     "asr_attention_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _dr, _vp],
     "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr, _dr],
     "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _dr],
     "asr_conv_sub0_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asr_conv_sub1_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
-    "asr_debug_probe_tr": [_vp, _vp, _i, _i],
     "asr_conv_im2col": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_conv_col2im_relu": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],

@@ -55,6 +55,15 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+// asr_dropout_t.salt (asr_hip.h): resolve the per-replay keys once at kernel entry (one scalar load)
+__device__ __forceinline__ asr_dropout_t drop_resolve(asr_dropout_t d) {
+    if (d.thr16 != 0 && d.salt != nullptr) {
+        const uint32_t s = *d.salt;
+        d.key0 ^= lowbias32(s ^ 0x5bd1e995u);
+        d.key1 ^= lowbias32(s + 0x27d4eb2fu);
+    }
+    return d;
+}
 __device__ __forceinline__ uint32_t drop_subkey(const asr_dropout_t& d, uint32_t n0) { return lowbias32(n0 * 0x9E3779B9u + d.key0); }
 // random word of element pair `pair` = n1 * ceil(N2/2) + (n2 >> 1): low half decides even n2, high half odd n2
 __device__ __forceinline__ uint32_t drop_word(const asr_dropout_t& d, uint32_t sub, uint32_t pair) { return lowbias32(pair ^ sub) ^ d.key1; }

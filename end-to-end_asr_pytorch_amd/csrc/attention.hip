@@ -328,7 +328,7 @@ struct MaskSites {            // up to 8 dropout sites of one shape hashed by on
 __global__ __launch_bounds__(256) void attn_dropmask_kernel(MaskSites sites, int BH, int Bn, int h, int Lq, int Lk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const int site = blockIdx.z / BH, bh = blockIdx.z - site * BH, b = bh / h, hd = bh - b * h;
-    const asr_dropout_t drop = sites.drop[site];
+    const asr_dropout_t drop = drop_resolve(sites.drop[site]);
     uint32_t* __restrict__ bits = sites.bits[site];
     const int lqp = drop_pad128(Lq), lkp = drop_pad128(Lk);
     const int qw = blockIdx.y * 4 + wave, qrow = qw * 32 + r, key0 = blockIdx.x * 64;

@@ -329,8 +329,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void add_layernorm_bwd_kernel(const
                                                                 const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D,
-                                                                asr_dropout_t drop_x, asr_dropout_t drop_y) {
+                                                                asr_dropout_t drop_x_in, asr_dropout_t drop_y_in) {
     __shared__ float red[3][LNB_WAVES][256 * MAXJ];
+    const asr_dropout_t drop_x = drop_resolve(drop_x_in), drop_y = drop_resolve(drop_y_in);
     const float scx = drop_scale(drop_x), scy = drop_scale(drop_y);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float invD = 1.f / (float)D;
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void add_layernorm_bwd_kernel(const
 }
 
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dy, int M, int U,
-                                                        int D, int V, float* __restrict__ demb, asr_dropout_t drop) {
+                                                        int D, int V, float* __restrict__ demb, asr_dropout_t drop_in) {
+    const asr_dropout_t drop = drop_resolve(drop_in);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -498,6 +500,36 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float pn = p[i] - (lr / bc1) * (mi / denom);
         p[i] = pn;
         if (p16) p16[i] = (bf16_t)pn;                          // bf16 MFMA shadow refreshed in the same pass
+    }
+}
+
+// ---- step state on the device (asr_hip.h: asr_step_tick) ----
+__global__ void step_tick_kernel(uint32_t* state, float k, float init_lr, float warmup, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t step = state[0] + 1u;
+    const double n = (double)step;
+    const double lr = (double)k * (double)init_lr * fmin(1.0 / sqrt(n), n * pow((double)warmup, -1.5));
+    state[0] = step;
+    reinterpret_cast<float*>(state)[1] = (float)lr;
+    reinterpret_cast<float*>(state)[2] = (float)(1.0 - pow((double)b1, n));
+    reinterpret_cast<float*>(state)[3] = (float)sqrt(1.0 - pow((double)b2, n));
+}
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, bf16_t* __restrict__ p16, int64_t n,
+                                                       const uint32_t* __restrict__ state, float b1, float b2, float eps, float gscale) {
+    const float lr = reinterpret_cast<const float*>(state)[1], bc1 = reinterpret_cast<const float*>(state)[2],
+                bc2_sqrt = reinterpret_cast<const float*>(state)[3];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        const float pn = p[i] - (lr / bc1) * (mi / denom);
+        p[i] = pn;
+        if (p16) p16[i] = (bf16_t)pn;
     }
 }
 
@@ -630,5 +662,23 @@ extern "C" int asr_adam_step(void* stream, float* p, const float* g, float* m, f
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
                        reinterpret_cast<bf16_t*>(p16), n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
     ASR_LAUNCH_CHECK("adam_step");
+    return 0;
+}
+
+extern "C" int asr_step_tick(void* stream, uint32_t* state, float k, float init_lr, float warmup, float beta1, float beta2) {
+    ASR_REQUIRE(state && warmup > 0.f, ASR_ERR_ARG, "step_tick: bad args");
+    hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state, k, init_lr, warmup, beta1, beta2);
+    ASR_LAUNCH_CHECK("step_tick");
+    return 0;
+}
+
+extern "C" int asr_adam_step_dev(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n,
+                                 const uint32_t* state, float beta1, float beta2, float eps, float grad_scale) {
+    ASR_REQUIRE(p && g && m && v && state && n > 0, ASR_ERR_ARG, "adam_dev: bad args");
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+                       reinterpret_cast<bf16_t*>(p16), n, state, beta1, beta2, eps, grad_scale);
+    ASR_LAUNCH_CHECK("adam_step_dev");
     return 0;
 }

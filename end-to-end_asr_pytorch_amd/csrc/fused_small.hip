@@ -18,8 +18,9 @@ __global__ __launch_bounds__(256) void gemm_ln_small_kernel(const bf16_t* __rest
                                                             const int32_t* __restrict__ row_len, float* __restrict__ s_out,
                                                             float* __restrict__ y32, bf16_t* __restrict__ y16,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out, int M, int L,
-                                                            int K, float eps, asr_dropout_t drop_x) {
+                                                            int K, float eps, asr_dropout_t drop_x_in) {
     constexpr int D = 256;
+    const asr_dropout_t drop_x = drop_resolve(drop_x_in);
     __shared__ float red[2][16][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q4 = lane >> 4;
     const int row0 = blockIdx.x * 16;

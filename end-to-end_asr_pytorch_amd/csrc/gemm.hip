@@ -944,6 +944,7 @@ struct LnArgs {
 // 64 x 256 tiles, 4 waves (one per 64-column quarter), K-tiles of 32 in 20 KiB stages, two workgroups per CU, persistent.
 __global__ __launch_bounds__(256, 2) void gemm_nt_ln64_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
                                                             int M, int K, int ntiles, LnArgs ln) {
+    ln.drop_x = drop_resolve(ln.drop_x);
     constexpr int KT = 32, RB = 64, TA = 64 * RB, TW = 256 * RB, STAGE = TA + TW, D = 256;   // 4 + 16 KiB per stage (rows of 32 bf16)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     __shared__ float red[2][64][4];

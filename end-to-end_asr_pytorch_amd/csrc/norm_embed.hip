@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
                                                                 float* __restrict__ y32, bf16_t* __restrict__ y16,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                 float* s_out, int M, int L, int D, float eps,
-                                                                asr_dropout_t drop_x, asr_dropout_t drop_y) {
+                                                                asr_dropout_t drop_x_in, asr_dropout_t drop_y_in) {
+    const asr_dropout_t drop_x = drop_resolve(drop_x_in), drop_y = drop_resolve(drop_y_in);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -72,7 +73,8 @@ __global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const float* x, 
 __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, float* __restrict__ y32,
                                                            bf16_t* __restrict__ y16, int M, int U, int D, int V,
-                                                           asr_dropout_t drop) {
+                                                           asr_dropout_t drop_in) {
+    const asr_dropout_t drop = drop_resolve(drop_in);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(256) void embed_pe_fwd_kernel(const int64_t* __rest
 
 // generic dropout over f32 [N0,N1,N2]: one thread per element pair (n2 even/odd halves of one random word)
 __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* x, float* y, int N1, int N2, int64_t pairs_per_n0,
-                                                            int64_t total_pairs, asr_dropout_t drop) {
+                                                            int64_t total_pairs, asr_dropout_t drop_in) {
+    const asr_dropout_t drop = drop_resolve(drop_in);
     const int n2h = (N2 + 1) >> 1;
     const float sc = drop_scale(drop);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -55,7 +55,7 @@ def _cdtype():
 
 # ---- dropout keys -----------------------------------------------------------------------------------------------
 _M64 = (1 << 64) - 1
-_DROP_STATE = {"seed": None, "calls": {}}
+_DROP_STATE = {"seed": None, "calls": {}, "salt": None}     # salt: device pointer of the step counter while a step is captured
 
 
 def manual_seed(seed):
@@ -115,7 +115,7 @@ def _drop(mod, suffix):
     key = (id(mod), suffix)
     calls[key] = calls.get(key, 0) + 1
     k0, k1 = dropout_site_keys(_DROP_STATE["seed"], name, calls[key])
-    return ops.Dropout(thr, k0, k1)
+    return ops.Dropout(thr, k0, k1, _DROP_STATE["salt"])
 
 
 _WGRAD = None      # set by Trainer.backward: {"stream": side stream, "keep": [operands kept alive until the streams join]}
@@ -148,6 +148,7 @@ def _prefetch_attn_masks(sites, training, device):
     if all(d is None for d in drops):
         return none
     main, aux = torch.cuda.current_stream(), ops.aux_stream(device, slot=1)
+    aux.wait_stream(main)      # fork from the main stream (ordering after the previous step's readers; required under graph capture)
     out = []
     with torch.cuda.stream(aux):
         for (m, B, Lq, Lk), d in zip(sites, drops):
@@ -176,12 +177,17 @@ def bump_param_epoch():
 class Tape:
     def __init__(self):
         self.fns = []
+        self.consumed = False
 
     def push(self, fn, params=()):
         fn.params = tuple(params)
         self.fns.append(fn)
 
     def backward(self, after_each=None):
+        if self.consumed:     # the closures free their saved activations as they run: like torch without retain_graph, one replay only
+            raise RuntimeError("asr_amd: this forward's backward tape has already been replayed (a second backward through the same "
+                               "forward is not supported: sum the losses and call backward once)")
+        self.consumed = True
         for fn in reversed(self.fns):
             fn()
             if after_each is not None:
@@ -417,7 +423,16 @@ class MultiheadAttention(_Cached):
         """Reference signature + length-based masking: `k_len` (int [B]) / `causal`.  A bool `mask` [B,Lq,Lk] is
         accepted when it is a key-padding mask (tail padding): it is reduced to k_len.  Returns (output, None)."""
         if mask is not None and k_len is None:
-            k_len = (~mask[:, -1, :].bool()).sum(-1)
+            mb = mask.bool()
+            k_len = (~mb[:, -1, :]).sum(-1)
+            Lq_, Lk_ = mb.shape[1], mb.shape[2]
+            tail = torch.arange(Lk_, device=mb.device)[None, None, :] >= k_len[:, None, None]
+            if bool((mb == tail).all()):
+                pass                                            # pure key-padding mask (tail padding)
+            elif Lq_ == Lk_ and bool((mb == (tail | torch.triu(torch.ones(Lq_, Lk_, dtype=torch.bool, device=mb.device), 1)[None])).all()):
+                causal = True                                   # key-padding | subsequent (decoder.py:74-78)
+            else:
+                raise NotImplementedError("attention mask is neither a tail key-padding mask nor key-padding | causal: pass k_len / causal")
         xq = _act(q)
         xkv = xq if (k is q and v is q) else _act(k)
         if k is not v:

@@ -278,7 +278,9 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
     y16 = torch.empty((B * L, D), device=x.device, dtype=torch.bfloat16) if want_bf16 else None
     mean = torch.empty(B * L, device=x.device, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(B * L, device=x.device, dtype=torch.float32) if save_stats else None
-    nbytes = B * L * D * (4 + (4 if residual is not None else 0) + 4 + (2 if want_bf16 else 0))
+    # algorithmic bytes: x and the residual read, y32 (+ the bf16 shadow) written, + the pre-norm sum written back over x when
+    # the backward needs it (save_stats)
+    nbytes = B * L * D * (4 + (4 if residual is not None else 0) + 4 + (2 if want_bf16 else 0) + (4 if save_stats else 0))
     with _timed("add_layernorm[%dx%d]" % (B * L, D), float(nbytes)):
         check(lib().asr_add_layernorm_fwd(_stream(), _p(x), _p(residual), _p(gamma), _p(beta), _p(pe), _p(row_len), _p(y32), _p(y16),
                                           _p(mean), _p(rstd), _p(x) if save_stats else None, B, L, D, float(eps), _d(drop_x),
@@ -607,6 +609,19 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None)
     assert p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32
     check(lib().asr_adam_step(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), float(lr), float(beta1), float(beta2),
                               float(eps), int(step), float(grad_scale)), "asr_adam_step")
+
+
+def step_tick(state, k, init_lr, warmup, beta1, beta2):
+    """state: int32 [8] device tensor (asr_hip.h: asr_step_tick) - step += 1, Noam lr and Adam bias corrections recomputed on device."""
+    _req_cuda(state)
+    check(lib().asr_step_tick(_stream(), _p(state), float(k), float(init_lr), float(warmup), float(beta1), float(beta2)), "asr_step_tick")
+
+
+def adam_step_dev(p, g, m, v, state, beta1, beta2, eps, grad_scale=1.0, p16=None):
+    """adam_step with (lr, bias corrections) read from the device step state (hipGraph replay)."""
+    _req_cuda(p, g, m, v, p16, state)
+    check(lib().asr_adam_step_dev(_stream(), _p(p), _p(g), _p(m), _p(v), _p(p16), p.numel(), _p(state), float(beta1), float(beta2),
+                                  float(eps), float(grad_scale)), "asr_adam_step_dev")
 
 
 def conv_im2col(x, C, Tout, Fout, ldc, out_dtype):

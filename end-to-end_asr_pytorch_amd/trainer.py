@@ -8,9 +8,12 @@ train.py:166-170) with every piece on the GPU path:
     buckets, launched as soon as a bucket's last gradient is final so it overlaps the rest of the backward ->
     Noam learning rate -> fused Adam over the flat buffer (which also refreshes the bf16 MFMA weight shadow).
 
-One process per GPU; utterances are sharded across ranks (each rank owns B_local of them); gradients are averaged
-(sum all-reduce, 1/world folded into the Adam kernel's grad_scale), i.e. DDP semantics: the mean over ranks of the
-per-rank mean losses.  (The reference has no multi-GPU code; DESIGN.md §6 states the exact-vs-DDP denominators.)
+One process per GPU; utterances are sharded across ranks (each rank owns B_local of them, the same number on every rank);
+gradients are summed by the all-reduce and 1/world is folded into the Adam kernel's grad_scale.  The result is the gradient of
+the GLOBAL-batch loss, not DDP's mean of per-rank means: CTC ('mean' = mean over utterances of nll / target length,
+loss.py:41-43) and the CIF quantity loss (mean over utterances) are already rank-separable with equal B_local, and the CE
+denominator n_word (loss.py:22-25) is all-reduced so that rank r seeds its CE backward with world * n_word_r / n_word_global
+(`exact_global_mean`; one 4-byte all-reduce per step).  tests/test_gpu_dp.py checks 2 ranks x B/2 against 1 rank x B.
 """
 import math
 import os
@@ -151,8 +154,10 @@ class Trainer:
     (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
 
     def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=8,
-                 process_group=None, lambda_qua=0.001, overlap_ctc=None):
+                 process_group=None, lambda_qua=0.001, overlap_ctc=None, exact_global_mean=True):
         self.model = model
+        self.group = process_group
+        self.exact_global_mean = exact_global_mean
         # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); ASR_AMD_OVERLAP_CTC=0 serialises it
         self.overlap_ctc = (os.environ.get("ASR_AMD_OVERLAP_CTC", "1") != "0") if overlap_ctc is None else bool(overlap_ctc)
         self.wgrad_stream = os.environ.get("ASR_AMD_WGRAD_STREAM", "1") != "0"     # weight-gradient GEMMs on a side stream (backward())
@@ -168,6 +173,41 @@ class Trainer:
         self.smoothing = label_smoothing
         self.buckets = GradBuckets(self.fp.grad, self.fp.params, self.fp.offsets, self.fp.numel, n_buckets, process_group)
         self.world = self.buckets.world
+        if self.world > 1:
+            # every rank starts from rank 0's parameters (what DDP's constructor does): ranks built with different seeds would
+            # otherwise all-reduce gradients onto different weights and diverge silently
+            src = torch.distributed.get_global_rank(process_group, 0) if process_group is not None else 0
+            torch.distributed.broadcast(self.fp.flat, src=src, group=process_group)
+            self.fp.sync_shadow()
+        self._graph, self._graph_key, self._graph_out, self._graph_failed, self._eager_steps = None, None, None, None, 0
+        self._state, self._state_step = None, -1
+        self._nw_handle = None
+        self._hook_shadow_sync()
+
+    def _hook_shadow_sync(self):
+        """model.load_state_dict() after construction rewrites the fp32 master in place: refresh the bf16 shadow the kernels read."""
+        fp = self.fp
+
+        def post(module, incompatible):
+            fp.sync_shadow()
+            modules.bump_param_epoch()
+        try:
+            self.model.register_load_state_dict_post_hook(post)
+        except AttributeError:      # very old torch: callers use Trainer.load_state_dict
+            pass
+
+    # ---- checkpoint state (the reference's package: transformer.py:86-97 keeps model.state_dict() + optimizer.state_dict()) ----
+    def state_dict(self):
+        return {"step_num": self.step_num, "m": self.m.detach().clone(), "v": self.v.detach().clone(), "k": self.k,
+                "warmup_steps": self.warmup, "init_lr": self.init_lr}
+
+    def load_state_dict(self, sd):
+        self.step_num = int(sd["step_num"])
+        self.m.copy_(sd["m"].to(self.m.device))
+        self.v.copy_(sd["v"].to(self.v.device))
+        self._state_step = -1
+        self.fp.sync_shadow()
+        modules.bump_param_epoch()
 
     def lr(self):
         """optimizer.py:24-29 (step_num already incremented)."""
@@ -267,6 +307,10 @@ class Trainer:
                 ctc, nll, st = ops.ctc_loss_fwd(ctc_logits, ops.as_i32(ctc_len, ctc_logits.device), teos)
             V = logits.shape[-1]
             loss2, row_loss, lse, tg1 = ops.ce_loss_fwd(logits.reshape(-1, V), teos.reshape(-1), self.smoothing)
+            self._nw_handle = None
+            if self.world > 1 and self.exact_global_mean:
+                nw = loss2[1:2].clone()
+                self._nw_handle = (torch.distributed.all_reduce(nw, group=self.group, async_op=True), nw)
         return ctc, loss2[0], (tape, st, logits, tg1, lse, loss2, d_num)
 
     def backward(self, state):
@@ -305,7 +349,13 @@ class Trainer:
             if st is not None:
                 model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one, bf16=True)
             V = logits.shape[-1]
-            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, one, bf16=True)
+            ce_seed = one
+            if self._nw_handle is not None:    # gradient of the global-batch CE mean: seed = world * n_word_local / n_word_global
+                h, nw = self._nw_handle
+                h.wait()
+                ce_seed = loss2[1:2] * (float(self.world) / nw)
+                self._nw_handle = None
+            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, ce_seed, bf16=True)
             if d_num is not None:
                 model._grad_slots["num"]["g"] = d_num
             self.buckets.start()
@@ -318,8 +368,7 @@ class Trainer:
                       grad_scale=1.0 / self.world, p16=self.fp.flat16)
         modules.bump_param_epoch()     # derived (re-laid-out) weights are rebuilt from the new parameters on next use
 
-    def step(self, feats, lens, targets, noise=None, max_target_len=None):
-        """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync when max_target_len is given)."""
+    def _fwd_bwd(self, feats, lens, targets, noise, max_target_len):
         self.fp.grad.zero_()
         if feats.is_cuda:
             ops.arena_reset(feats.device)      # pre-zeroed outputs for the step's split-K GEMMs (ops: zero arena)
@@ -328,5 +377,83 @@ class Trainer:
             self.backward(state)
         finally:
             ops.arena_release()
+        return ctc, ce
+
+    def step(self, feats, lens, targets, noise=None, max_target_len=None):
+        """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync when max_target_len is given)."""
+        ctc, ce = self._fwd_bwd(feats, lens, targets, noise, max_target_len)
         self.optimizer_step()
         return ctc, ce
+
+    # ---- the fixed-shape step as ONE hipGraph ----------------------------------------------------------------------------------
+    # A step is ~550 kernel launches on four streams; queued eagerly the host spends ~9 ms per step in ctypes / torch calls.  With
+    # fixed shapes (a bucketed loader, the synthetic bench) the whole step - zeroing, forward, losses, backward on its side
+    # streams, Adam - is captured once and replayed with one call.  What changes from step to step lives in device memory the
+    # graph reads: the step state of asr_step_tick (step number -> Noam lr, Adam bias corrections) and, through
+    # asr_dropout_t.salt, the dropout masks (a fresh mask per step from the same descriptors).
+    def graph_active(self):
+        return self._graph is not None
+
+    def _graph_ok(self, feats, max_target_len):
+        if self._graph_failed is not None or not feats.is_cuda or max_target_len is None:
+            return False
+        if self.world > 1 and os.environ.get("ASR_AMD_GRAPH_DP", "0") != "1":
+            return False          # collectives inside a captured step are opt-in (not measurable on the 1-GPU development box)
+        m = self.model
+        return isinstance(m, modules.CTC_Transformer) and not isinstance(m, modules.CIF_Model) and modules.get_precision() == "bf16"
+
+    def _sync_state(self, dev):
+        """device step state <- host step counter (first use, or after eager steps / a checkpoint load moved it)"""
+        if self._state is None:
+            self._state = torch.zeros(8, dtype=torch.int32, device=dev)
+        if self._state_step != self.step_num:
+            self._state.copy_(torch.tensor([self.step_num] + [0] * 7, dtype=torch.int32))
+            self._state_step = self.step_num
+
+    def step_graphed(self, feats, lens, targets, noise=None, max_target_len=None):
+        """`step` for a loader with fixed shapes: the first two calls run eagerly (allocator pools, code objects, side streams), the
+        third captures the step into a hipGraph, later calls with the same buffers replay it.  Falls back to `step` (and says why in
+        `self._graph_failed`) when the step cannot be captured."""
+        if not self._graph_ok(feats, max_target_len):
+            return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+        key = (feats.data_ptr(), tuple(feats.shape), lens.data_ptr(), targets.data_ptr(), tuple(targets.shape), max_target_len,
+               self.model.training, self.overlap_ctc, self.wgrad_stream)
+        if self._graph is None or self._graph_key != key:
+            if self._eager_steps < 2:
+                self._eager_steps += 1
+                return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+            self._capture(feats, lens, targets, noise, max_target_len, key)
+            if self._graph is None:
+                return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+        self._sync_state(feats.device)
+        self._graph.replay()
+        self.step_num += 1
+        self._state_step = self.step_num
+        modules.bump_param_epoch()
+        return self._graph_out
+
+    def _capture(self, feats, lens, targets, noise, max_target_len, key):
+        dev = feats.device
+        self._graph = None
+        self._sync_state(dev)
+        modules.bump_param_epoch()             # derived weights are rebuilt inside the capture (and so at every replay)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        modules._DROP_STATE["salt"] = self._state.data_ptr()
+        try:
+            with torch.cuda.graph(g):
+                ops.step_tick(self._state, self.k, self.init_lr, self.warmup, self.betas[0], self.betas[1])
+                ctc, ce = self._fwd_bwd(feats, lens, targets, noise, max_target_len)
+                ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self._state, self.betas[0], self.betas[1], self.eps,
+                                  grad_scale=1.0 / self.world, p16=self.fp.flat16)
+            self._graph, self._graph_key, self._graph_out = g, key, (ctc, ce)
+        except Exception as e:      # not capturable on this stack: keep training eagerly, remember why
+            self._graph_failed = "%s: %s" % (type(e).__name__, e)
+            import warnings
+            warnings.warn("asr_amd.Trainer: hipGraph capture of the step failed, running eagerly (%s)" % self._graph_failed)
+            try:
+                torch.cuda.synchronize(dev)
+            except Exception:
+                pass
+        finally:
+            modules._DROP_STATE["salt"] = None

@@ -1,38 +1,39 @@
-"""Mask helpers with the reference's names (src/utils/utils.py:125-165).
-
-The HIP path never materialises these tensors - kernels compare indices against lengths - but callers that build
-masks for their own purposes get the same values the reference produces.  Pure index arithmetic, any device."""
+"""Mask / padding helpers under the reference's names (src/utils/utils.py:5-14,125-165), for callers that build such tensors
+themselves.  The HIP path never materialises masks - kernels compare indices against lengths - so nothing on the product path
+imports this module; values match the reference's (tests/test_host_logic.py)."""
 import torch
 
 
 def sequence_mask(lengths, maxlen=None, dtype=torch.float):
-    if maxlen is None:
-        maxlen = int(lengths.max())
-    pos = torch.arange(1, maxlen + 1, device=lengths.device)[None, :]
-    return (pos <= lengths[:, None]).type(dtype)
+    """[B, maxlen] with 1 where position < length."""
+    n = int(lengths.max()) if maxlen is None else int(maxlen)
+    steps = torch.arange(n, device=lengths.device)
+    return (steps[None, :] < lengths[:, None]).to(dtype)
 
 
 def get_subsequent_mask(seq):
-    sz_b, len_s = seq.size()
-    m = torch.triu(torch.ones((len_s, len_s), device=seq.device, dtype=torch.uint8), diagonal=1)
-    return m.unsqueeze(0).expand(sz_b, -1, -1)
+    """[B, L, L] uint8, 1 strictly above the diagonal (a query may not see later keys)."""
+    B, L = seq.shape
+    idx = torch.arange(L, device=seq.device)
+    return (idx[None, :] > idx[:, None]).to(torch.uint8)[None].expand(B, L, L)
 
 
 def get_attn_key_pad_mask(seq_k, seq_q, pad_idx):
-    return seq_k.le(pad_idx).unsqueeze(1).expand(-1, seq_q.size(1), -1)
+    """[B, Lq, Lk] bool, True on padded keys (token id <= pad_idx)."""
+    return (seq_k <= pad_idx)[:, None, :].expand(seq_k.shape[0], seq_q.shape[1], seq_k.shape[1])
 
 
 def get_attn_pad_mask(input_lengths, expand_length):
-    pad_mask = sequence_mask(input_lengths) < 1.0
-    return pad_mask.unsqueeze(1).expand(-1, expand_length, -1)
+    """[B, expand_length, Lmax] bool, True on frames at or beyond each utterance's length."""
+    keep = sequence_mask(input_lengths, dtype=torch.bool)
+    return (~keep)[:, None, :].expand(keep.shape[0], expand_length, keep.shape[1])
 
 
 def pad_list(xs, pad_value, max_len=None):
-    """src/utils/utils.py:5-14 (returns (padded, lengths) like the reference's current version)."""
-    n_batch = len(xs)
-    lengths = torch.tensor([x.size(0) for x in xs]).long()
-    max_len = int(lengths.max()) if not max_len else max_len
-    pad = xs[0].new(n_batch, max_len, *xs[0].size()[1:]).fill_(pad_value)
-    for i in range(n_batch):
-        pad[i, :xs[i].size(0)] = xs[i]
-    return pad, lengths
+    """Stack variable-length tensors [len_i, ...] into [n, max_len, ...] filled with pad_value -> (padded, lengths)."""
+    lengths = torch.as_tensor([int(x.shape[0]) for x in xs], dtype=torch.long)
+    width = int(max_len) if max_len else int(lengths.max())
+    out = torch.full((len(xs), width) + tuple(xs[0].shape[1:]), pad_value, dtype=xs[0].dtype, device=xs[0].device)
+    for row, x in zip(out, xs):
+        row[:x.shape[0]] = x
+    return out, lengths

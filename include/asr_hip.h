@@ -41,11 +41,16 @@ extern "C" {
  *     word = lowbias32((n1 * ceil(N2/2) + (n2 >> 1)) ^ sub) ^ key1
  *     r16  = (n2 & 1) ? word >> 16 : word & 0xFFFF
  *     element kept  <=>  r16 >= thr16;   kept elements are multiplied by 65536 / (65536 - thr16)
- * thr16 = round(p * 65536) (p quantised to 2^-16); thr16 == 0 disables dropout.  oracle/asr_oracle.py restates this in numpy. */
+ * thr16 = round(p * 65536) (p quantised to 2^-16); thr16 == 0 disables dropout.  oracle/asr_oracle.py restates this in numpy.
+ * `salt` (optional DEVICE pointer to one uint32, read when the kernel runs): a launch captured into a hipGraph keeps its by-value
+ * arguments for every replay, so a captured training step points `salt` at the step counter of asr_step_tick and the kernels use
+ *     key0' = key0 ^ lowbias32(*salt ^ 0x5bd1e995),   key1' = key1 ^ lowbias32(*salt + 0x27d4eb2f)
+ * in place of (key0, key1): a fresh mask per replay, still a pure function of (descriptor, step).  NULL = keys as given. */
 typedef struct asr_dropout {
     uint32_t thr16;
     uint32_t key0;
     uint32_t key1;
+    const uint32_t* salt;
 } asr_dropout_t;
 
 /* y = dropout(x) over f32 [N0,N1,N2] (y may alias x); also the backward of itself (apply to the gradient). */
@@ -188,6 +193,14 @@ int asr_embed_bwd(void* stream, const int64_t* ids, const float* dy, int B, int 
  * p16 (optional) receives the bf16 copy of the updated parameters (the MFMA operand shadow). */
 int asr_adam_step(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale);
+/* Step state on the device, for a training step replayed from a hipGraph (scalars passed by value would be frozen at capture):
+ * state is 8 x 32-bit words {uint32 step, float lr, float 1-beta1^step, float sqrt(1-beta2^step), 4 spare}.  asr_step_tick adds 1 to
+ * `step` and recomputes the others - lr = k * init_lr * min(step^-0.5, step * warmup^-1.5), the Noam schedule of
+ * src/transformer/optimizer.py:24-29, evaluated in f64 - and asr_adam_step_dev is asr_adam_step reading (lr, bias corrections) from it.
+ * &state[0] is also what asr_dropout_t.salt points at. */
+int asr_step_tick(void* stream, uint32_t* state, float k, float init_lr, float warmup, float beta1, float beta2);
+int asr_adam_step_dev(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, const uint32_t* state,
+                      float beta1, float beta2, float eps, float grad_scale);
 
 /* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = dropout(emb[ids[b,u],:] + pe[u,:]). */
 int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16,
@@ -278,9 +291,6 @@ int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const fl
                           int B, int L, int Dh, float* alpha);
 /* Conv1d k=w stride 1 valid + ReLU over time with implicit zero right-pad (conv_encoder.py:33-43) is expressed by
  * the caller as w_context shifted GEMMs through asr_gemm_nt; no dedicated entry point. */
-
-/* Development probe (not on the product path): dumps what each lane receives from ds_read_b64_tr_b16 on a known LDS tile. */
-int asr_debug_probe_tr(void* stream, void* out, int m0, int n0);
 
 /* Utility: dtype cast f32 -> bf16 (weights / activations entering the bf16 MFMA path). n elements. */
 int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t n);

@@ -1,6 +1,11 @@
-"""The data-parallel training step with world_size 2 on the GPU box: two ranks share cuda:0 over gloo (the box has one GPU; the
-product backend is nccl = RCCL) and run bench.py's real step - bucketed async all-reduce overlapped with the HIP backward, fused
-Adam - after which bench.py itself asserts that both ranks hold bit-identical parameters."""
+"""The data-parallel training step on the GPU box.
+
+* world_size 2 sharing cuda:0 over gloo (the development box has one GPU; the product backend is nccl = RCCL): bench.py's real
+  step - bucketed async all-reduce overlapped with the HIP backward, fused Adam - after which bench.py itself asserts that both
+  ranks hold bit-identical parameters;
+* the §8(e) equivalence: 2 ranks x B/2 utterances == 1 rank x B utterances on the concatenated batch (tools/dp_equiv.py), with
+  target lengths that differ across ranks so that the CE denominator matters;
+* the same two checks over RCCL with one rank per GPU when the node has more than one (skipped on a 1-GPU box)."""
 import json
 import os
 import subprocess
@@ -12,12 +17,49 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_training_step_on_one_gpu():
-    env = dict(os.environ, ASR_AMD_DIST_BACKEND="gloo", ASR_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()      # (does not initialise the GPU)
+
+
+def _run(script_args, nproc, port, gloo_one_gpu):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if gloo_one_gpu:
+        env.update(ASR_AMD_DIST_BACKEND="gloo", ASR_AMD_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_two_rank_training_step_on_one_gpu():
+    out = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], 2, 29541, True)[-1]
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["value"] > 0
+
+
+def _check_equiv(lines, world):
+    assert len(lines) == world
+    for o in lines:
+        # the data-parallel gradient IS the single-process gradient of the concatenated batch (fp32 summation order / bf16
+        # rounding noise only) ...
+        assert o["exact"]["worst_rel_l2"] < 5e-3, o
+        # ... which DDP's mean of per-rank means is not when n_word differs across ranks (the test batch makes it differ by > 2x)
+        assert o["ddp"]["worst_rel_l2"] > 5e-2, o
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
+    _check_equiv(_run([os.path.join(ROOT, "tools", "dp_equiv.py")], 2, 29543, True), 2)
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
+def test_rccl_ranks_equal_one_rank():
+    n = min(_ngpu(), 8)
+    _check_equiv(_run([os.path.join(ROOT, "tools", "dp_equiv.py")], n, 29545, False), n)
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
+def test_rccl_training_step_all_gpus():
+    n = min(_ngpu(), 8)
+    out = _run([os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], n, 29547, False)[-1]
+    assert out["n_gpus"] == n and out["config"]["global_batch"] == 32 * n and out["value"] > 0
