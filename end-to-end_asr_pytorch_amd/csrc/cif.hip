@@ -2,9 +2,10 @@
 //
 // The firing decision `integrate > threshold` is a discrete function of an fp32 running sum that is decremented by
 // exactly 1.0 on fire; reproducing the reference's boundaries requires the reference's operation ORDER, so the
-// recurrence itself is not re-associated.  One wavefront per utterance walks the T frames: alpha is loaded 64
-// frames at a time (coalesced), each frame's value is broadcast with v_readlane and every lane runs the same scalar
-// recurrence (a few dependent VALU ops per frame); the lane that owns the frame records its weights.  The
+// recurrence itself is not re-associated.  One wavefront per utterance walks the T frames 64 at a time: the recurrence runs on
+// wave-uniform values (the utterance's weights sit in LDS and are read as broadcasts, 5 vector instructions per frame, ~20 cycles) and only leaves the
+// running sum before each frame in that frame's lane; fire flags, cur / rem weights, token indices and the fire list are then
+// computed lane-parallel per chunk.  The
 // H-wide weighted sums - the actual bandwidth - run in a second, fully parallel kernel: one workgroup per output
 // token, threads over channels, frames of the token's segment accumulated in the reference's order with separate
 // (non-fused) multiply and add so the fp32 results match the CPU loop bit-for-bit.
@@ -18,49 +19,94 @@
 
 namespace {
 
+// One frame of the recurrence on wave-uniform values (cif_model.py:71-77): 5 vector instructions, 3 of them on the dependent
+// chain (add -> compare -> select).  `al` is the frame's weight broadcast from LDS, `hist` collects in lane i the running sum
+// BEFORE frame i (one v_cndmask under a one-hot lane mask that a scalar shift moves along) - everything else a frame needs (its
+// own fire decision, cur, rem, token index) is recomputed from it lane-parallel after the chunk, with the same fp32 operations on
+// the same values, i.e. bit-identically.
+#define CIF_STEP(al)                                                                                                            \
+    {                                                                                                                           \
+        const float s_ = integrate + (al);                                                                                      \
+        asm volatile("v_cndmask_b32 %[h], %[h], %[v], %[m]\n\ts_lshl_b64 %[m], %[m], 1" : [h] "+v"(hist), [m] "+s"(onehot) : [v] "v"(integrate) : "scc"); \
+        integrate = (s_ > thr) ? (s_ - 1.0f) : s_;                                                                              \
+    }
+
+constexpr int CIF_LDS_FRAMES = 8192;      // frames of one utterance staged in LDS per pass (32 KiB)
+
 __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ alpha, int L, float thr, float* __restrict__ cur_out,
                                                       float* __restrict__ rem_out, int32_t* __restrict__ fire_idx,
                                                       int32_t* __restrict__ n_fire, int32_t* __restrict__ n_label,
                                                       int32_t* __restrict__ tok_out) {
+    __shared__ __attribute__((aligned(16))) float row[CIF_LDS_FRAMES];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const float* a = alpha + (int64_t)b * L;
+    const float* __restrict__ a = alpha + (int64_t)b * L;
     float integrate = 0.f;
     int n = 0;
-    float psum = 0.f;
-    for (int t0 = 0; t0 < L; t0 += 64) {
-        const int t = t0 + lane;
-        const float av = (t < L) ? a[t] : 0.f;
-        psum += av;
-        float my_cur = 0.f, my_rem = 0.f;
-        int my_tok = 0;
-        const int cnt = min(64, L - t0);
+    double psum = 0.0;
+    for (int base = 0; base < L; base += CIF_LDS_FRAMES) {
+        const int len = min(CIF_LDS_FRAMES, L - base);
+        // the utterance's weights into LDS: 16 independent loads per lane in flight (one round trip per 1024 frames)
+        for (int t0 = 0; t0 < len; t0 += 1024) {
+            float v[16];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            if (i < cnt) {  // wave-uniform
-                const float al = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, av), i));
-                const float dc = 1.0f - integrate;
-                integrate = integrate + al;
-                const bool fire = integrate > thr;
-                if (lane == i) my_tok = n | (fire ? (1 << 30) : 0);   // token being accumulated at this frame (+ fire flag)
-                if (fire) {
-                    integrate = integrate - 1.0f;
-                    if (lane == i) fire_idx[(int64_t)b * L + n] = t0 + i;
-                    ++n;
-                }
-                const float c = fire ? dc : al;
-                if (lane == i) { my_cur = c; my_rem = al - c; }
+            for (int j = 0; j < 16; ++j) {
+                const int t = t0 + j * 64 + lane;
+                const float x = a[base + min(t, len - 1)];      // (clamped: branch-free, all 16 loads in flight)
+                v[j] = (t < len) ? x : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int t = t0 + j * 64 + lane;
+                if (t < len) row[t] = v[j];
+                psum += (double)v[j];
             }
         }
-        if (t < L) {
-            cur_out[(int64_t)b * L + t] = my_cur;
-            rem_out[(int64_t)b * L + t] = my_rem;
-            if (tok_out) tok_out[(int64_t)b * L + t] = my_tok;
+        __syncthreads();
+        for (int t0 = 0; t0 < len; t0 += 64) {
+            const int t = t0 + lane;
+            const float av = (t < len) ? row[t] : 0.f;
+            float hist = 0.f;
+            const int cnt = min(64, len - t0);
+            if (cnt == 64) {
+                unsigned long long onehot = 1ull;
+                const f32x4* r4 = reinterpret_cast<const f32x4*>(row + t0);       // wave-uniform addresses: broadcast reads
+                f32x4 q[16];       // all 64 weights into registers first: the chain below then never waits on LDS
+#pragma unroll
+                for (int i = 0; i < 16; ++i) q[i] = r4[i];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { CIF_STEP(q[i][0]) CIF_STEP(q[i][1]) CIF_STEP(q[i][2]) CIF_STEP(q[i][3]) }
+            } else {
+                for (int i = 0; i < cnt; ++i) {      // ragged tail (< 64 frames): same steps
+                    const float al = row[t0 + i];
+                    const float s_ = integrate + al;
+                    hist = (lane == i) ? integrate : hist;
+                    integrate = (s_ > thr) ? (s_ - 1.0f) : s_;
+                }
+            }
+            // lane-parallel: this lane's frame from the sum that stood before it
+            const float sm = hist + av;
+            const bool fire = (t < len) && (sm > thr);
+            const unsigned long long fires = __ballot(fire);
+            const int before = __builtin_popcountll(fires & ((1ull << lane) - 1ull));
+            const float c = fire ? (1.0f - hist) : av;
+            if (t < len) {
+                const int64_t o = (int64_t)b * L + base + t;
+                cur_out[o] = c;
+                rem_out[o] = av - c;
+                if (tok_out) tok_out[o] = (n + before) | (fire ? (1 << 30) : 0);
+                if (fire) fire_idx[(int64_t)b * L + n + before] = base + t;
+            }
+            n += __builtin_popcountll(fires);
         }
+        __syncthreads();
     }
-    psum = wave_sum(psum);
+    // round(sum alpha) (cif_model.py:95): the sum is taken in f64, so the label count is the rounding of the exact sum whatever
+    // order a float reduction would have used (torch's CPU and GPU reductions differ from each other in the last bits too)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
     if (lane == 0) {
         n_fire[b] = n;
-        n_label[b] = (int32_t)rintf(psum);  // torch.round: half to even
+        n_label[b] = (int32_t)rint(psum);  // torch.round: half to even
     }
 }
 

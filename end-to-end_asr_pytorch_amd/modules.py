@@ -208,8 +208,16 @@ def record():
         _TAPE = old
 
 
+def _add_into(dst, src):
+    """dst += src through asr_add2d (f32 CUDA tensors with contiguous rows); anything else falls to torch (CPU-side tests)."""
+    if (dst.is_cuda and dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.is_contiguous() and src.dim() >= 1 and
+            src.stride(-1) == 1 and dst.shape == src.shape and (src.is_contiguous() or src.dim() == 2)):
+        return ops.add_(dst, src)
+    return dst.add_(src)
+
+
 def _acc(act, g):
-    act.grad = g if act.grad is None else act.grad.add_(g)
+    act.grad = g if act.grad is None else _add_into(act.grad, g)
 
 
 def _gcat(params):
@@ -633,7 +641,7 @@ class Conv2dSubsample(_Cached):
             act.grad = None
             d = d_out.shape[1]
             dwp = ops.gemm_tn(d_out, y_last)                                        # [d, F*32] in the permuted column order
-            aff.weight.grad.view(d, 32, F).add_(dwp.view(d, F, 32).permute(0, 2, 1))
+            ops.add_transposed_(aff.weight.grad, dwp, d, 32, F)                      # affine weight columns are c*F + f (conv_encoder.py:108)
             ops.colsum(d_out, out=aff.bias.grad, accumulate=True)
             dy = ops.gemm_nn(d_out, wp, out_dtype=torch.bfloat16, relu_mask=y_last)  # [M, F*32] = channel-last d(y_last), ReLU applied
             for i in range(n - 1, 0, -1):
@@ -642,7 +650,7 @@ class Conv2dSubsample(_Cached):
                 dy2 = dy.view(-1, 32)
                 col = ops.conv_im2col(ys[i - 1], 32, tout, fout, 288, torch.bfloat16)
                 dwm = ops.gemm_tn(dy2, col)                                         # [co, tap*32 + ci]
-                cv.weight.grad.add_(dwm.view(32, 9, 32).permute(0, 2, 1).reshape(32, 32, 3, 3))
+                ops.add_transposed_(cv.weight.grad, dwm, 32, 32, 9)                 # nn.Conv2d weight is [co, ci, 3, 3]
                 ops.colsum(dy2, out=cv.bias.grad, accumulate=True)
                 wm = self._derived("wm%d" % i, (cv.weight,),
                                    lambda cv=cv: ops.cast_bf16(cv.weight.detach().permute(0, 2, 3, 1).reshape(32, 288).contiguous()))
@@ -651,7 +659,7 @@ class Conv2dSubsample(_Cached):
             dy2 = dy.view(-1, 32)
             col0 = ops.conv_im2col(feats.view(B, T, D, 1), 1, tneed[0], fneed[0], 12, torch.float32)
             dw0 = ops.gemm_tn(dy2, col0)                                            # [32, 12]; taps in columns 0..8
-            convs[0].weight.grad.view(32, 9).add_(dw0[:, :9])
+            ops.add_transposed_(convs[0].weight.grad, dw0, 32, 9, 1, lds=dw0.stride(0))
             ops.colsum(dy2, out=convs[0].bias.grad, accumulate=True)
 
         params = [aff.weight, aff.bias]
@@ -718,16 +726,13 @@ class Conv1d(_Cached):
         for i in range(n - 1, -1, -1):
             m = getattr(self.conv, "{}/conv1d_{}".format(self.name, i))
             cin = bufs[i].shape[1]
-            d_pre = (d * (outs[i] > 0)).contiguous()                                  # ReLU backward on a [rows, d_hidden] tensor
+            d_pre = ops.relu_mask_mul(d, outs[i])                                     # ReLU backward from the saved output [rows + w, d_hidden]
             win = torch.as_strided(bufs[i], (rows, w * cin), (cin, 1))              # the overlapping row windows the forward GEMM read
-            dwg = ops.gemm_tn(d_pre[:rows], win)                                      # [O, w*cin]
-            m.weight.grad.add_(dwg.view(-1, w, cin).permute(0, 2, 1))
+            dwg = ops.gemm_tn(d_pre[:rows], win)                                      # [O, w*cin] in (tap, channel) column order
+            ops.add_transposed_(m.weight.grad, dwg, dwg.shape[0], cin, w)             # nn.Conv1d weight is [O, cin, w]
             ops.colsum(d_pre[:rows], out=m.bias.grad, accumulate=True)
             d_win = ops.gemm_nn(d_pre[:rows], self._wg(i))                            # [rows, w*cin] f32
-            d_in = torch.zeros((rows + w, cin), device=d.device, dtype=torch.float32)
-            for j in range(w):                                                        # overlap-add of the w window slots
-                d_in[j:j + rows].add_(d_win[:, j * cin:(j + 1) * cin])
-            d = d_in
+            d = ops.conv1d_overlap_add(d_win, rows, w, cin)                           # [rows + w, cin]
         return d[:rows].view(B, Lp, -1)[:, :L].reshape(B * L, -1).contiguous()
 
     def forward(self, feats, feat_lengths):
@@ -765,14 +770,10 @@ class Attention_Assigner(nn.Module):
             params += [cm.weight, cm.bias]
 
         def bw():
-            g = slot["g"]
-            dz = (g * alpha * (1.0 - alpha)).reshape(-1)        # sigmoid' (alpha is 0 on masked frames, so is dz); [B*L] glue ops
-            h2 = hcv.view(-1, hcv.shape[-1])
-            lin.weight.grad.add_((dz[None, :] @ h2))
-            lin.bias.grad.add_(dz.sum())
-            d_hcv = dz[:, None] * w[None, :]
+            # sigmoid' * Linear(d_h -> 1) backward in one kernel (alpha is 0 on masked frames, so is dz)
+            d_hcv = ops.assigner_tail_bwd(slot["g"], alpha, hcv, w, x.B, x.L, lin.weight.grad, lin.bias.grad)
             if dp is not None:
-                d_hcv = ops.dropout_apply(d_hcv.contiguous(), dp, x.B, x.L, d_hcv.shape[-1])
+                d_hcv = ops.dropout_apply(d_hcv, dp, x.B, x.L, d_hcv.shape[-1])
             _acc(x, conv._backward(saved, d_hcv.view(x.B, x.L, -1)))
             slot["g"] = None
 
@@ -993,7 +994,7 @@ class Decoder_CIF(_Cached):
                 ops.gemm_tn(a0.grad, cat1, out=aff.weight.grad, accumulate=True)
                 d_cat = ops.gemm_nn(a0.grad, w_in)
                 a0.grad = None
-                cif_slot["g"] = d_cat[:, :D] if cif_slot["g"] is None else cif_slot["g"] + d_cat[:, :D]
+                cif_slot["g"] = d_cat[:, :D].contiguous() if cif_slot["g"] is None else _add_into(cif_slot["g"], d_cat[:, :D])
                 ops.embed_bwd(ys_in, d_cat[:, D:].contiguous(), emb.weight.grad, drop=dp)
 
             _TAPE.push(bw_in, (aff.weight, emb.weight))
@@ -1006,7 +1007,7 @@ class Decoder_CIF(_Cached):
             def bw_split():   # runs after the vocab projection's closure has produced cat2.grad
                 g = cat2.grad
                 cat2.grad = None
-                cif_slot["g"] = g[:, :D] if cif_slot["g"] is None else cif_slot["g"] + g[:, :D]
+                cif_slot["g"] = g[:, :D].contiguous() if cif_slot["g"] is None else _add_into(cif_slot["g"], g[:, :D])
                 _acc(a_last, g[:, D:].contiguous())
 
             _TAPE.push(bw_split, ())
@@ -1205,13 +1206,9 @@ class CIF_Model(_Cached):
         ctc2d = _vocab_proj(self, "ctc", self.ctc_fc.weight, enc)
         asg_slot = {"g": None} if rec else None
         alpha_raw = self.assigner._impl(enc, len_sequence, asg_slot)
-        _num = alpha_raw.sum(-1)
-        num = (targets > 0).float().sum(-1)
         if noise is None:
             noise = torch.rand(alpha_raw.size(0), device=alpha_raw.device)     # cif_model.py:47
-        num_noise = num + noise - 0.5
-        scale = num_noise / _num
-        alpha = alpha_raw * scale[:, None]
+        alpha, _num, num, scale = ops.cif_rescale_fwd(alpha_raw, targets, noise)   # cif_model.py:44-48
         if not rec:
             l = self.cif(enc.view3(), alpha, threshold=threshold)
             logits = self.decoder(l, targets)
@@ -1232,11 +1229,8 @@ class CIF_Model(_Cached):
             d_l = cif_slot["g"].reshape(l.shape)
             d_hidden, d_alpha = ops.cif_bwd(hidden, cur, rem, tok, n_fire, d_l)
             _acc(enc, d_hidden.view(enc.B * enc.L, -1))
-            # alpha = alpha_raw * (num_noise / sum(alpha_raw)): [B,L] glue ops (cif_model.py:44-48), plus d(_num) from the quantity loss
-            d_num = (d_alpha * alpha_raw).sum(-1) * (-num_noise / (_num * _num))
-            if num_slot["g"] is not None:
-                d_num = d_num + num_slot["g"]
-            asg_slot["g"] = d_alpha * scale[:, None] + d_num[:, None]
+            # backward of alpha = alpha_raw * (num_noise / sum(alpha_raw)) (cif_model.py:44-48), plus d(_num) from the quantity loss
+            asg_slot["g"] = ops.cif_rescale_bwd(d_alpha, alpha_raw, scale, _num, num_slot["g"])
             cif_slot["g"] = None
             num_slot["g"] = None
 

@@ -611,6 +611,83 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None)
                               float(eps), int(step), float(grad_scale)), "asr_adam_step")
 
 
+def add_(dst, src):
+    """dst += src for f32 tensors viewed as [rows, cols] (last dim contiguous, rows uniformly strided) - on the HIP path."""
+    _req_cuda(dst, src)
+    assert dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.shape == src.shape
+    cols = dst.shape[-1] if dst.dim() else 1
+
+    def rows_of(t):       # -> (row stride, rows) of t seen as rows of `cols` contiguous elements
+        if t.is_contiguous():
+            return cols, t.numel() // cols
+        assert t.dim() == 2 and t.stride(1) == 1, "add_: rows must be contiguous"
+        return t.stride(0), t.shape[0]
+    (ldd, rows), (lds, rows_s) = rows_of(dst), rows_of(src)
+    assert rows == rows_s
+    check(lib().asr_add2d(_stream(), _p(dst), ldd, _p(src), lds, rows, cols), "asr_add2d")
+    return dst
+
+
+def add_transposed_(dst, src, O, A, Bn, lds=None):
+    """dst (contiguous, viewed [O, A, Bn]) += src[o, b, a] (src rows of `lds` >= A*Bn elements)."""
+    _req_cuda(dst, src)
+    assert dst.is_contiguous() and dst.dtype == torch.float32 and src.dtype == torch.float32 and dst.numel() == O * A * Bn
+    lds = A * Bn if lds is None else lds
+    check(lib().asr_add_transposed(_stream(), _p(dst), _p(src), O, A, Bn, lds), "asr_add_transposed")
+    return dst
+
+
+def relu_mask_mul(d, y, out=None):
+    """d * (y > 0) (f32 d, f32 / bf16 y, same numel, both contiguous)"""
+    _req_cuda(d, y)
+    assert d.is_contiguous() and y.is_contiguous() and d.numel() == y.numel() and d.dtype == torch.float32
+    out = torch.empty_like(d) if out is None else out
+    check(lib().asr_relu_mask_mul(_stream(), _p(d), _p(y), dtype_code(y), _p(out), d.numel()), "asr_relu_mask_mul")
+    return out
+
+
+def conv1d_overlap_add(d_win, rows, w, cin):
+    _req_cuda(d_win)
+    assert d_win.is_contiguous() and d_win.dtype == torch.float32 and d_win.shape == (rows, w * cin)
+    d_in = torch.empty((rows + w, cin), device=d_win.device, dtype=torch.float32)
+    check(lib().asr_conv1d_overlap_add(_stream(), _p(d_win), rows, w, cin, _p(d_in)), "asr_conv1d_overlap_add")
+    return d_in
+
+
+def assigner_tail_bwd(g, alpha, h, w, B, L, dw, db):
+    """-> d_h [B*L, Dh]; dw [Dh] / db [1] accumulated in place."""
+    _req_cuda(g, alpha, h, w, dw, db)
+    Dh = h.shape[-1]
+    g, alpha, h, w = g.contiguous().float(), alpha.contiguous(), h.contiguous(), w.contiguous()
+    assert dw.is_contiguous() and dw.numel() == Dh and db.numel() == 1 and h.numel() == B * L * Dh
+    d_h = torch.empty((B * L, Dh), device=h.device, dtype=torch.float32)
+    check(lib().asr_assigner_tail_bwd(_stream(), _p(g), _p(alpha), _p(h), _p(w), B, L, Dh, _p(d_h), _p(dw), _p(db)), "asr_assigner_tail_bwd")
+    return d_h
+
+
+def cif_rescale_fwd(alpha_raw, targets, noise):
+    """-> (alpha, num_pred, num, scale): cif_model.py:44-48"""
+    _req_cuda(alpha_raw, targets, noise)
+    B, L = alpha_raw.shape
+    alpha_raw, targets, noise = alpha_raw.contiguous(), targets.to(torch.int64).contiguous(), noise.float().contiguous()
+    alpha = torch.empty_like(alpha_raw)
+    num_pred, num, scale = (torch.empty(B, device=alpha_raw.device, dtype=torch.float32) for _ in range(3))
+    check(lib().asr_cif_rescale_fwd(_stream(), _p(alpha_raw), _p(targets), _p(noise), B, L, targets.shape[1], _p(alpha), _p(num_pred),
+                                    _p(num), _p(scale)), "asr_cif_rescale_fwd")
+    return alpha, num_pred, num, scale
+
+
+def cif_rescale_bwd(d_alpha, alpha_raw, scale, num_pred, d_num_in=None):
+    _req_cuda(d_alpha, alpha_raw, scale, num_pred, d_num_in)
+    B, L = alpha_raw.shape
+    d_alpha = d_alpha.contiguous()
+    dn = d_num_in.contiguous().float() if d_num_in is not None else None
+    d_raw = torch.empty_like(alpha_raw)
+    check(lib().asr_cif_rescale_bwd(_stream(), _p(d_alpha), _p(alpha_raw), _p(scale), _p(num_pred), _p(dn), B, L, _p(d_raw)),
+          "asr_cif_rescale_bwd")
+    return d_raw
+
+
 def step_tick(state, k, init_lr, warmup, beta1, beta2):
     """state: int32 [8] device tensor (asr_hip.h: asr_step_tick) - step += 1, Noam lr and Adam bias corrections recomputed on device."""
     _req_cuda(state)

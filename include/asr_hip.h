@@ -292,6 +292,31 @@ int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const fl
 /* Conv1d k=w stride 1 valid + ReLU over time with implicit zero right-pad (conv_encoder.py:33-43) is expressed by
  * the caller as w_context shifted GEMMs through asr_gemm_nt; no dedicated entry point. */
 
+/* ---- CIF family, training side (autograd of cif_model.py:44-48, attentionAssigner.py:37-40, conv_encoder.py:33-49) and the tape's
+ * gradient bookkeeping; all f32. */
+/* dst[r, 0..cols) += src[r, 0..cols) for r < rows (row strides ldd / lds in elements): gradient accumulation where two paths join. */
+int asr_add2d(void* stream, float* dst, int64_t ldd, const float* src, int64_t lds, int rows, int cols);
+/* dst[o][a][b] (contiguous [O, A, B]) += src[o * lds + b * A + a]: a weight gradient the GEMM produced in [O, B, A] order
+ * (conv kernels: nn.Conv1d / nn.Conv2d weights are [out, in, taps], the conv-as-GEMM weight matrix is [out, taps, in]). */
+int asr_add_transposed(void* stream, float* dst, const float* src, int O, int A, int B, int64_t lds);
+/* out = d * (y > 0): ReLU backward from the saved forward output y (f32 or bf16, `y_dtype`); out may alias d. */
+int asr_relu_mask_mul(void* stream, const float* d, const void* y, int y_dtype, float* out, int64_t n);
+/* Conv1d-as-GEMM input gradient: d_win f32 [rows, w * cin] is the gradient wrt the overlapping row windows the forward GEMM read
+ * (window r = input rows r .. r+w-1); d_in f32 [rows + w, cin] receives d_in[r] = sum_j d_win[r - j][j * cin ..]. */
+int asr_conv1d_overlap_add(void* stream, const float* d_win, int rows, int w, int cin, float* d_in);
+/* Backward of asr_assigner_tail_fwd: g = d(loss)/d(alpha) [B*L], alpha its output, h the [B*L, Dh] input, w [Dh]:
+ * d_h = dz * w with dz = g * alpha * (1 - alpha); dw [Dh] += dz^T h; db [1] += sum dz (caller-zeroed or accumulating). */
+int asr_assigner_tail_bwd(void* stream, const float* g, const float* alpha, const float* h, const float* w, int B, int L, int Dh,
+                          float* d_h, float* dw, float* db);
+/* Quantity scaling (cif_model.py:44-48): num_pred[b] = sum_t alpha_raw[b,t], num[b] = count(targets[b,:] > 0),
+ * scale[b] = (num + noise - 0.5) / num_pred, alpha = alpha_raw * scale.  noise f32 [B] (the reference draws torch.rand(B)).
+ * bwd: d_raw = d_alpha * scale + (d_num_in - sum_t(d_alpha * alpha_raw) * scale / num_pred); d_num_in (optional, [B]) is the
+ * quantity loss's gradient wrt num_pred. */
+int asr_cif_rescale_fwd(void* stream, const float* alpha_raw, const int64_t* targets, const float* noise, int B, int L, int U,
+                        float* alpha, float* num_pred, float* num, float* scale);
+int asr_cif_rescale_bwd(void* stream, const float* d_alpha, const float* alpha_raw, const float* scale, const float* num_pred,
+                        const float* d_num_in, int B, int L, float* d_raw);
+
 /* Utility: dtype cast f32 -> bf16 (weights / activations entering the bf16 MFMA path). n elements. */
 int asr_cast_f32_bf16(void* stream, const float* x, void* y, int64_t n);
 /* logits *= (t < len)  (ctcModel/decoder.py:33-36), in place, f32 [B,L,V] with row stride ld (elements) and batch stride L*ld. */

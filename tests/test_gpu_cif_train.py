@@ -1,0 +1,130 @@
+"""The CIF family's training-side kernels (csrc/cif_train.hip) against plain torch fp32 on the CPU: the autograd of
+attentionAssigner.py:37-40, conv_encoder.py:33-49 (conv1d as a GEMM over overlapping windows) and cif_model.py:44-48, plus the
+tape's accumulation helpers.  End to end they are covered by the G4 / G7 gradient fixtures (tests/test_gpu_backward.py)."""
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_add2d_and_add_transposed():
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.randn(37, 24, generator=g), torch.randn(37, 24, generator=g)
+    out = ops.add_(a.to(DEV).clone(), b.to(DEV))
+    np.testing.assert_array_equal(out.cpu().numpy(), (a + b).numpy())
+    wide = torch.randn(37, 40, generator=g)
+    out = ops.add_(a.to(DEV).clone(), wide.to(DEV)[:, 3:27])              # strided, unaligned source rows
+    np.testing.assert_array_equal(out.cpu().numpy(), (a + wide[:, 3:27]).numpy())
+    dst, src = torch.randn(5, 7, 3, generator=g), torch.randn(5, 3, 7, generator=g)
+    out = ops.add_transposed_(dst.to(DEV).clone(), src.to(DEV), 5, 7, 3)
+    np.testing.assert_array_equal(out.cpu().numpy(), (dst + src.permute(0, 2, 1)).numpy())
+    src12 = torch.randn(5, 12, generator=g)
+    d9 = torch.randn(5, 9, generator=g)
+    out = ops.add_transposed_(d9.to(DEV).clone(), src12.to(DEV), 5, 9, 1, lds=12)
+    np.testing.assert_array_equal(out.cpu().numpy(), (d9 + src12[:, :9]).numpy())
+
+
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+def test_relu_mask_mul(ydt):
+    g = torch.Generator().manual_seed(1)
+    d, y = torch.randn(1000, generator=g), torch.randn(1000, generator=g).to(ydt)
+    out = ops.relu_mask_mul(d.to(DEV), y.to(DEV))
+    np.testing.assert_array_equal(out.cpu().numpy(), (d * (y.float() > 0)).numpy())
+
+
+def test_conv1d_overlap_add_is_the_conv_input_gradient():
+    rows, w, cin = 50, 3, 8
+    g = torch.Generator().manual_seed(2)
+    d_win = torch.randn(rows, w * cin, generator=g)
+    got = ops.conv1d_overlap_add(d_win.to(DEV), rows, w, cin).cpu()
+    x = torch.zeros(rows + w, cin, requires_grad=True)
+    win = torch.as_strided(x, (rows, w * cin), (cin, 1))
+    (win * d_win).sum().backward()
+    np.testing.assert_allclose(got.numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_assigner_tail_backward():
+    B, L, Dh = 3, 41, 96
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(B, L, Dh, generator=g, requires_grad=True)
+    w = (torch.randn(Dh, generator=g) * 0.2).requires_grad_(True)
+    b = torch.tensor([0.1], requires_grad=True)
+    lens = torch.tensor([41, 30, 7])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).float()
+    alpha = torch.sigmoid(h @ w + b) * mask
+    gout = torch.randn(B, L, generator=g)
+    (alpha * gout).sum().backward()
+    a_dev = ops.assigner_tail(h.detach().to(DEV).view(B * L, Dh), w.detach().to(DEV), b.detach().to(DEV), lens.int().to(DEV), B, L)
+    np.testing.assert_allclose(a_dev.cpu().numpy(), alpha.detach().numpy(), rtol=1e-5, atol=1e-6)
+    dw, db = torch.zeros(Dh, device=DEV), torch.zeros(1, device=DEV)
+    d_h = ops.assigner_tail_bwd(gout.to(DEV), a_dev, h.detach().to(DEV), w.detach().to(DEV), B, L, dw, db)
+    np.testing.assert_allclose(d_h.cpu().numpy().reshape(B, L, Dh), h.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dw.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_cif_rescale_forward_and_backward():
+    B, L, U = 4, 133, 12
+    g = torch.Generator().manual_seed(4)
+    raw = torch.sigmoid(torch.randn(B, L, generator=g)).requires_grad_(True)
+    tg = torch.randint(1, 40, (B, U), generator=g)
+    tg[1, 5:] = 0
+    tg[3, 9:] = 0
+    noise = torch.rand(B, generator=g)
+    _num = raw.sum(-1)
+    num = (tg > 0).float().sum(-1)
+    alpha = raw * ((num + noise - 0.5) / _num)[:, None]                 # cif_model.py:44-48
+    d_alpha, d_num = torch.randn(B, L, generator=g), torch.randn(B, generator=g)
+    ((alpha * d_alpha).sum() + (_num * d_num).sum()).backward()
+    a, npred, n, scale = ops.cif_rescale_fwd(raw.detach().to(DEV), tg.to(DEV), noise.to(DEV))
+    np.testing.assert_allclose(a.cpu().numpy(), alpha.detach().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(npred.cpu().numpy(), _num.detach().numpy(), rtol=1e-6)
+    np.testing.assert_array_equal(n.cpu().numpy(), num.numpy())
+    d_raw = ops.cif_rescale_bwd(d_alpha.to(DEV), raw.detach().to(DEV), scale, npred, d_num.to(DEV))
+    np.testing.assert_allclose(d_raw.cpu().numpy(), raw.grad.numpy(), rtol=2e-4, atol=2e-5)
+    d_raw0 = ops.cif_rescale_bwd(d_alpha.to(DEV), raw.detach().to(DEV), scale, npred, None)
+    raw.grad = None
+    (raw * ((num + noise - 0.5) / raw.sum(-1))[:, None] * d_alpha).sum().backward()
+    np.testing.assert_allclose(d_raw0.cpu().numpy(), raw.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_conv1d_stack_backward_matches_torch_autograd():
+    """Conv1d._impl / _backward (conv1d as GEMM + the kernels above) vs nn.Conv1d autograd, f32 parity mode forward values aside:
+    gradients of a 2-layer k=3 stack in bf16 tolerance"""
+    B, L, C, Hd, w, n = 2, 37, 64, 64, 3, 2
+    torch.manual_seed(5)
+    mod = asr_amd.Conv1d(C, Hd, n, w, name="assigner").to(DEV)
+    x = torch.randn(B, L, C)
+    gy = torch.randn(B, L, Hd)
+    # torch reference (conv_encoder.py:33-49): right-pad time by n*w, n x (Conv1d valid + ReLU), crop to L
+    ref = [torch.nn.Conv1d(C if i == 0 else Hd, Hd, w) for i in range(n)]
+    for i, cm in enumerate(ref):
+        src = getattr(mod.conv, "assigner/conv1d_%d" % i)
+        cm.weight.data.copy_(src.weight.detach().cpu())
+        cm.bias.data.copy_(src.bias.detach().cpu())
+    xr = x.clone().requires_grad_(True)
+    y = torch.nn.functional.pad(xr.transpose(1, 2), (0, n * w))
+    for cm in ref:
+        y = torch.relu(cm(y))
+    y = y[:, :, :L].transpose(1, 2)
+    (y * gy).sum().backward()
+    for p in mod.parameters():
+        p.grad = torch.zeros_like(p)
+    with asr_amd.precision("bf16"), torch.no_grad():
+        act = asr_amd.modules._act(x.to(DEV))
+        out, saved = mod._impl(act, save=True)
+        d_x = mod._backward(saved, gy.to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy(), y.detach().numpy(), rtol=5e-2, atol=5e-2)
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12))
+    assert rel(d_x.cpu().numpy().reshape(B, L, C), xr.grad.numpy()) < 3e-2
+    for i, cm in enumerate(ref):
+        src = getattr(mod.conv, "assigner/conv1d_%d" % i)
+        assert rel(src.weight.grad.cpu().numpy(), cm.weight.grad.numpy()) < 3e-2, i
+        assert rel(src.bias.grad.cpu().numpy(), cm.bias.grad.numpy()) < 3e-2, i

@@ -1,0 +1,99 @@
+"""The training step replayed from a captured hipGraph (Trainer.step_graphed) against the same step queued eagerly: same losses,
+same parameter trajectory (to the float-atomic summation noise of the weight-gradient kernels), the device step state follows
+the Noam schedule of src/transformer/optimizer.py:24-29, and dropout draws a fresh mask on every replay."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from oracle import asr_oracle as O
+from weights import make_state_dict, names_shapes_from_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(golden_dir, dropout=0.0):
+    z = np.load(os.path.join(golden_dir, "g1_ctc_transformer.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    model = asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=dropout),
+                                    asr_amd.Decoder(2, 3, 50, 2, 2, 64, 128, dropout=dropout))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return z, model.to(DEV).train()
+
+
+def test_graph_replay_matches_eager_steps(golden_dir):
+    asr_amd.set_precision("bf16")
+    z, m_e = build(golden_dir)
+    _, m_g = build(golden_dir)
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    umax = int((tg != 0).sum(1).max())
+    te = asr_amd.Trainer(m_e, k=0.2, warmup_steps=5, label_smoothing=0.1)
+    tg_ = asr_amd.Trainer(m_g, k=0.2, warmup_steps=5, label_smoothing=0.1)
+    le, lg = [], []
+    for i in range(8):
+        c, e = te.step(x, lens, tg, max_target_len=umax)
+        le.append((float(c), float(e)))
+        c, e = tg_.step_graphed(x, lens, tg, max_target_len=umax)
+        lg.append((float(c), float(e)))
+    assert tg_.graph_active(), tg_._graph_failed
+    assert tg_.step_num == te.step_num == 8
+    np.testing.assert_allclose(np.array(lg), np.array(le), rtol=2e-3)
+    pe = te.fp.flat.float().cpu().numpy()
+    pg = tg_.fp.flat.float().cpu().numpy()
+    assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 2e-3
+    # device step state: {step, lr, 1 - b1^step, sqrt(1 - b2^step)}
+    st = tg_._state.cpu().numpy()
+    assert int(st[0]) == 8
+    f = st.view(np.float32)
+    np.testing.assert_allclose(f[1], O.noam_lr(8, 0.2, 64, 5), rtol=1e-6)
+    np.testing.assert_allclose(f[1], te.lr(), rtol=1e-6)
+    np.testing.assert_allclose(f[2], 1.0 - 0.9 ** 8, rtol=1e-6)
+    np.testing.assert_allclose(f[3], np.sqrt(1.0 - 0.98 ** 8), rtol=1e-6)
+    # eager steps after replays (and replays after them) stay on one trajectory: the host counter and the device state re-sync
+    te.step(x, lens, tg, max_target_len=umax)
+    tg_.step(x, lens, tg, max_target_len=umax)
+    c1, e1 = te.step(x, lens, tg, max_target_len=umax)
+    c2, e2 = tg_.step_graphed(x, lens, tg, max_target_len=umax)
+    assert tg_.step_num == te.step_num == 10 and int(tg_._state.cpu()[0]) == 10
+    np.testing.assert_allclose([float(c2), float(e2)], [float(c1), float(e1)], rtol=3e-3)
+
+
+def test_graph_replay_draws_new_dropout_masks(golden_dir):
+    asr_amd.set_precision("bf16")
+    z, model = build(golden_dir, dropout=0.3)
+    asr_amd.manual_seed(11)
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    umax = int((tg != 0).sum(1).max())
+    tr = asr_amd.Trainer(model, k=0.0, warmup_steps=5, label_smoothing=0.1)     # k = 0: lr 0, the weights never move
+    losses = []
+    for i in range(7):
+        c, e = tr.step_graphed(x, lens, tg, max_target_len=umax)
+        losses.append(float(c) + float(e))
+    assert tr.graph_active(), tr._graph_failed
+    replayed = losses[3:]          # calls 0, 1 eager, call 2 captures + replays
+    assert len(set(round(v, 5) for v in replayed)) == len(replayed), losses      # same weights, different masks -> different losses
+    assert np.std(replayed) < 0.2 * np.mean(replayed)
+
+
+def test_dropout_salt_resolves_like_the_header_says():
+    from asr_amd import ops
+    x = torch.randn(3, 5, 64, device=DEV)
+    salt = torch.tensor([12345], dtype=torch.int32, device=DEV)
+    thr, k0, k1 = 19661, 0x1234567, 0x89abcde
+    y = ops.dropout_apply(x.clone(), ops.Dropout(thr, k0, k1, salt.data_ptr()), 3, 5, 64).cpu().numpy()
+
+    def lowbias32(v):
+        v &= 0xFFFFFFFF
+        v ^= v >> 16
+        v = (v * 0x7feb352d) & 0xFFFFFFFF
+        v ^= v >> 15
+        v = (v * 0x846ca68b) & 0xFFFFFFFF
+        v ^= v >> 16
+        return v
+    r0 = k0 ^ lowbias32(12345 ^ 0x5bd1e995)
+    r1 = k1 ^ lowbias32((12345 + 0x27d4eb2f) & 0xFFFFFFFF)
+    exp = x.cpu().numpy() * O.dropout_mask((3, 5, 64), thr, r0, r1)      # (the mask carries the 1/keep scale)
+    np.testing.assert_allclose(y, exp, rtol=1e-6, atol=0)

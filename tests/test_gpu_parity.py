@@ -444,6 +444,50 @@ def test_cif_s3_shape_against_oracle():
     np.testing.assert_array_equal(N(out), ref_out)
 
 
+@pytest.mark.parametrize("L", [40, 64, 129, 8192, 9001])
+def test_cif_scan_chunking_and_long_rows(L):
+    """ragged tails (< 64 frames), exactly one chunk, and rows longer than one LDS pass (8192 frames) - cur / rem / token map /
+    fire list all bit-equal to the sequential oracle (cif_model.py:67-87)"""
+    B = 3
+    g = torch.Generator().manual_seed(L)
+    a = torch.sigmoid(torch.randn(B, L, generator=g)) * 0.4
+    a[1, L // 2:] = 0.0                                # an utterance that ends early (zero weights on padding)
+    a[2, 3] = 1.7                                      # alpha > 1: one fire per frame at most (cif_model.py:73-77)
+    hid = torch.randn(B, L, 8, generator=g)
+    ref_out, ref_idx, ref_nlabel = O.cif(hid.numpy(), a.numpy(), 0.95)
+    cur, rem, fire_idx, n_fire, n_label, tok = ops.cif_scan(a.to(DEV), 0.95, want_tok=True)
+    nf = N(n_fire).astype(int)
+    assert list(nf) == [len(i) for i in ref_idx]
+    for b in range(B):
+        np.testing.assert_array_equal(fire_idx[b, :nf[b]].cpu().numpy(), ref_idx[b])
+    np.testing.assert_array_equal(N(n_label).astype(np.int32), ref_nlabel)
+    tk = tok.cpu().numpy()
+    for b in range(B):                                 # token index per frame = fires strictly before it; bit 30 = fires here
+        fired = np.zeros(L, bool)
+        fired[ref_idx[b]] = True
+        np.testing.assert_array_equal(tk[b] & 0x3fffffff, np.concatenate([[0], np.cumsum(fired)[:-1]]))
+        np.testing.assert_array_equal((tk[b] >> 30) & 1, fired.astype(np.int64))
+    out = ops.cif_gather(hid.to(DEV), cur, rem, fire_idx, n_fire, int(max(ref_nlabel.max(), nf.max())))
+    np.testing.assert_array_equal(N(out)[:, :ref_out.shape[1]], ref_out[:, :out.shape[1]])
+
+
+def test_cif_label_count_rounds_half_to_even():
+    """n_label = round(sum alpha) (cif_model.py:95-96) on sums that are exact in every summation order (multiples of 2^-10):
+    k + 0.5 rounds to the even neighbour like torch.round"""
+    rows = []
+    for total in (20.5, 21.5, 3.5, 2.5, 7.0, 6.4990234375, 6.5009765625):
+        n = 64
+        a = np.full(n, np.float32(1.0 / 1024), np.float32)
+        a[0] = np.float32(total - (n - 1) / 1024.0)
+        a[0], a[1] = a[0] / 2, a[0] / 2 + a[1]          # keep every alpha < 1-ish without changing the sum
+        rows.append(a)
+    a = torch.from_numpy(np.stack(rows))
+    exp = torch.round(a.double().sum(-1)).int()
+    assert exp.tolist() == torch.round(a.sum(-1)).int().tolist() == [20, 22, 4, 2, 7, 6, 7]
+    n_label = ops.cif_scan(a.to(DEV), 0.95)[4]
+    assert n_label.cpu().tolist() == exp.tolist()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # whole models vs the reference's outputs (golden) and the oracle
 # ---------------------------------------------------------------------------------------------------------
