@@ -11,6 +11,8 @@
 // table rows are prefetched 8 steps ahead into registers, leaving ~a dozen dependent VALU ops per step on the chain.
 // Per-label occupancies are scattered into an LDS vector indexed by vocabulary id, so repeated labels need no global
 // atomics and the gradient row is produced by one coalesced stream.
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 namespace {
@@ -41,56 +43,58 @@ constexpr int LSE_UNR = 6;  // float4 per thread held in registers: V <= 256*4*6
 
 constexpr int CTC_RPB = 4;   // table rows per workgroup in the flag-pipelined launch (one store drain + one counter add for all of them)
 
-// one table row (b, t): log-sum-exp over the vocabulary, then the gather of the extended labels' base-2 log-probs
-__device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets, int L, int V,
-                                            int Umax, int blank, float* __restrict__ lse_out, float* __restrict__ lp_ext, int b, int t,
-                                            bool publish) {
-    const int row = b * L + t;
-    const float* x = logits + (int64_t)row * ldl;
+// A logits row held in registers (V <= 256 * 4 * LSE_UNR - 3): every load of the row is issued before anything waits on it.
+struct CtcRowRegs {
+    f32x4 v[LSE_UNR];
+    float xe;      // the thread's unaligned head / tail element
+};
+__device__ __forceinline__ bool ctc_row_fits_regs(int V) { return ((V + 3) >> 2) <= 256 * LSE_UNR; }
+__device__ __forceinline__ void ctc_row_load(const float* __restrict__ x, int V, CtcRowRegs& r) {
     const int tid = threadIdx.x;
-    float m = -INFINITY, s = 0.f;
     const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
     const int peel = min((4 - mis) & 3, V);
     const int nv4 = (V - peel) >> 2;
     const int tail0 = peel + nv4 * 4;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x + peel);
-    if (nv4 <= 256 * LSE_UNR) {
-        f32x4 v[LSE_UNR];
 #pragma unroll
-        for (int j = 0; j < LSE_UNR; ++j) {
-            const int i = tid + 256 * j;
-            v[j] = (i < nv4) ? x4[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        }
-        float xe = -INFINITY;  // peel / tail element of this thread
-        if (tid < peel) xe = x[tid];
-        else if (tid - peel < V - tail0 && tid >= peel) xe = x[tail0 + tid - peel];
-        m = xe;
-#pragma unroll
-        for (int j = 0; j < LSE_UNR; ++j) m = fmaxf(m, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
-        const float ms = (m == -INFINITY) ? 0.f : m;
-        s = __expf(xe - ms);
-#pragma unroll
-        for (int j = 0; j < LSE_UNR; ++j)
-            s += (__expf(v[j][0] - ms) + __expf(v[j][1] - ms)) + (__expf(v[j][2] - ms) + __expf(v[j][3] - ms));
-    } else {
-        if (tid < peel) { m = x[tid]; s = 1.f; }
-        for (int i = tid; i < nv4; i += 256) {
-            const f32x4 v = x4[i];
-            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            if (m4 > m) { s *= __expf(m - m4); m = m4; }
-            s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
-        }
-        if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
+    for (int j = 0; j < LSE_UNR; ++j) {
+        const int i = tid + 256 * j;
+        r.v[j] = (i < nv4) ? x4[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
+    r.xe = -INFINITY;
+    if (tid < peel) r.xe = x[tid];
+    else if (tid - peel < V - tail0 && tid >= peel) r.xe = x[tail0 + tid - peel];
+}
+__device__ __forceinline__ void ctc_row_reduce(const CtcRowRegs& r, float& m, float& s) {
+    m = r.xe;
+#pragma unroll
+    for (int j = 0; j < LSE_UNR; ++j) m = fmaxf(m, fmaxf(fmaxf(r.v[j][0], r.v[j][1]), fmaxf(r.v[j][2], r.v[j][3])));
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    s = __expf(r.xe - ms);
+#pragma unroll
+    for (int j = 0; j < LSE_UNR; ++j)
+        s += (__expf(r.v[j][0] - ms) + __expf(r.v[j][1] - ms)) + (__expf(r.v[j][2] - ms) + __expf(r.v[j][3] - ms));
+}
+
+// second half of a table row: block-combine the per-thread (max, sum-exp), then gather the extended labels' base-2 log-probs
+__device__ __forceinline__ void ctc_row_finish(const float* __restrict__ x, const int64_t* __restrict__ targets, int V, int Umax, int blank,
+                                               float* __restrict__ lse_out, float* __restrict__ lp_ext, int b, int row, float m, float s,
+                                               bool publish) {
+    const int tid = threadIdx.x;
     // wave then block combine
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
         lse_combine(m, s, m2, s2);
     }
+    // target length of this utterance (loss.py:40 targets.ne(0).sum(1)): rides on the same block reduction
+    int nlab = 0;
+    for (int i = tid; i < Umax; i += 256) nlab += targets[(int64_t)b * Umax + i] != 0 ? 1 : 0;
+    nlab = (int)wave_sum((float)nlab);
     __shared__ float sm[4], ss[4];
+    __shared__ int sn[4];
     __shared__ float lse_sh;
-    if ((tid & 63) == 0) { sm[tid >> 6] = m; ss[tid >> 6] = s; }
+    if ((tid & 63) == 0) { sm[tid >> 6] = m; ss[tid >> 6] = s; sn[tid >> 6] = nlab; }
     __syncthreads();
     if (tid == 0) {
         float M = sm[0], S = ss[0];
@@ -99,10 +103,12 @@ __device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, in
         lse_sh = l;
         lse_out[row] = l;
     }
+    const int Ub = sn[0] + sn[1] + sn[2] + sn[3];
     __syncthreads();
     const float lse = lse_sh;
-    // all Umax label slots are gathered (padding slots read label 0); the recursion masks the states beyond 2*tgt_len+1
-    const int Sp = ctc_row_stride(Umax), Sb = 2 * Umax + 1;
+    // the table row holds the states of THIS utterance's extended label sequence (2 * tgt_len + 1 of them); everything beyond is
+    // -inf, so the recursion needs no state mask of its own
+    const int Sp = ctc_row_stride(Umax), Sb = 2 * Ub + 1;
     auto gather = [&](int sidx) {
         float v = -INFINITY;
         if (sidx < Sb) {
@@ -123,44 +129,44 @@ __device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, in
     }
 }
 
+// one table row (b, t): log-sum-exp over the vocabulary, then the gather of the extended labels' base-2 log-probs
+__device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets, int L, int V,
+                                            int Umax, int blank, float* __restrict__ lse_out, float* __restrict__ lp_ext, int b, int t,
+                                            bool publish) {
+    const int row = b * L + t;
+    const float* x = logits + (int64_t)row * ldl;
+    const int tid = threadIdx.x;
+    float m = -INFINITY, s = 0.f;
+    if (ctc_row_fits_regs(V)) {
+        CtcRowRegs r;
+        ctc_row_load(x, V, r);
+        ctc_row_reduce(r, m, s);
+    } else {
+        const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
+        const int peel = min((4 - mis) & 3, V);
+        const int nv4 = (V - peel) >> 2;
+        const int tail0 = peel + nv4 * 4;
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x + peel);
+        if (tid < peel) { m = x[tid]; s = 1.f; }
+        for (int i = tid; i < nv4; i += 256) {
+            const f32x4 v = x4[i];
+            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            if (m4 > m) { s *= __expf(m - m4); m = m4; }
+            s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
+        }
+        if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
+    }
+    ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, s, publish);
+}
+
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ logits, int64_t ldl,
                                                              const int32_t* __restrict__ in_len, const int64_t* __restrict__ targets,
                                                              int L, int V, int Umax, int blank,
-                                                             float* __restrict__ lse_out, float* __restrict__ lp_ext, int chunk, int W,
-                                                             int* __restrict__ arrivals, int64_t arr_stride, int nchunks, int Bn) {
-    // arrivals == NULL: one launch over all rows, blockIdx.x = b*L + t.
-    // arrivals != NULL: the flag-pipelined form (asr_ctc_loss_fwd): ONE launch covers every chunk, chunk-major - chunk c holds, for
-    // every utterance, the forward frames [cW, (c+1)W) up to mid and the backward frames Tb-1-k, k in [cW, (c+1)W), above mid,
-    // i.e. what the two recursion wavefronts consume in their c-th piece.  A workgroup takes CTC_RPB consecutive rows of one
-    // (utterance, direction, chunk), stores them write-through (sc1), drains its stores, and one lane adds the row count to
-    // that arrival counter at agent scope (MI355X_MICROARCH.md § visibility).
-    if (!arrivals) {
-        const int b = blockIdx.x / L, t = blockIdx.x - b * L;
-        if (t >= in_len[b]) return;
-        ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, false);
-        return;
-    }
-    const int G = W / CTC_RPB;                       // row groups per (utterance, direction, chunk); W is a multiple of CTC_RPB
-    int bid = blockIdx.x;
-    chunk = bid / (Bn * 2 * G);
-    bid -= chunk * (Bn * 2 * G);
-    const int b = bid / (2 * G), gi = bid - b * 2 * G;
-    const int dirc = gi / G, g0 = (gi - dirc * G) * CTC_RPB;
-    const int Tb = min(in_len[b], L), mid = Tb >> 1;
-    int count = 0;
-    for (int r = 0; r < CTC_RPB; ++r) {
-        const int k = chunk * W + g0 + r;
-        const int t = dirc == 0 ? k : Tb - 1 - k;
-        const bool valid = dirc == 0 ? (t <= mid && t < Tb) : (t > mid);
-        if (!valid) break;                           // frames only run out at the end of a direction
-        ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, true);
-        ++count;
-    }
-    if (count == 0) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_fetch_add(arrivals + (int64_t)b * arr_stride + dirc * nchunks + chunk, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                             float* __restrict__ lse_out, float* __restrict__ lp_ext) {
+    // one workgroup per table row, blockIdx.x = b*L + t (the two-launch form; the fused form is ctc_fused_fwd_kernel)
+    const int b = blockIdx.x / L, t = blockIdx.x - b * L;
+    if (t >= in_len[b]) return;
+    ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, false);
 }
 
 #ifndef CTC_PF1
@@ -195,18 +201,30 @@ __device__ __forceinline__ float dpp_from_next_lane(float v) {  // lane i <- lan
 // o = state 2j+1 (label j); all values are base-2 logs.  DIRB = false: alpha (t increasing), true: beta (t decreasing).
 // OCC = false: the new state row is stored;  OCC = true: the OTHER direction's stored row is read and replaced in place by the
 // occupancies exp2(alpha + beta - lp + nll2).  Row t lives at al + row_of(t) * Sp where row_of(special_t) = special_row.
-template <int NP, bool DIRB, bool OCC>
-__device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* __restrict__ al, int t_first, int nsteps, float (&e)[NP],
-                                          float (&o)[NP], const float (&skip_add)[NP], const float (&madd)[2 * NP], float nll2,
-                                          int special_t, int special_row) {
-    constexpr int PF = NP == 1 ? CTC_PF1 : (NP == 2 ? 8 : (NP == 4 ? 4 : 2));
-    constexpr int Sp = 128 * NP;
+// Table rows are addressed through buffer descriptors (wave-uniform base in scalar registers, the lane's column offset in ONE
+// vector register, the row as a scalar offset): no per-row 64-bit address arithmetic on the vector pipe, one register pair per
+// row in flight.
+typedef __amdgpu_buffer_rsrc_t ctc_rsrc_t;
+__device__ __forceinline__ ctc_rsrc_t ctc_rsrc(const float* uniform_base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_base), 0, (int)bytes, 0x00020000);
+}
+
+// PFO > 0 overrides the prefetch depth: the fused forward (ctc_fused_fwd_kernel) runs its chains beside the streaming pass, where a
+// table row takes 2-3 us to arrive instead of ~0.6 - the ring must cover that at ~0.1 us per step.
+// lp_u / al_u: wave-uniform bases of the utterance's table / workspace; voff: the lane's byte offset into a row (8 * NP * lane).
+template <int NP, bool DIRB, bool OCC, int PFO = 0>
+__device__ __forceinline__ void ctc_chain(const float* __restrict__ lp_u, float* __restrict__ al_u, int voff, int L, int t_first,
+                                          int nsteps, float (&e)[NP], float (&o)[NP], const float (&skip_add)[NP],
+                                          const float (&madd)[2 * NP], float nll2, int special_t, int special_row) {
+    constexpr int PF = PFO > 0 ? PFO : (NP == 1 ? CTC_PF1 : (NP == 2 ? 8 : (NP == 4 ? 4 : 2)));
+    constexpr int Sp = 128 * NP, ROWB = Sp * 4;
     if (nsteps <= 0) return;
+    const ctc_rsrc_t rlp = ctc_rsrc(lp_u, (int64_t)L * ROWB), ral = ctc_rsrc(al_u, (int64_t)(L + 2) * ROWB);
     auto row_of = [&](int t) { return t == special_t ? special_row : t; };
-    auto load_row = [&](const float* base, int64_t row, float (&dst)[2 * NP]) {
+    auto load_row = [&](ctc_rsrc_t r, int row, float (&dst)[2 * NP]) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(base + row * Sp + 2 * q);
+            const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff + 8 * q, row * ROWB, 0));
             dst[2 * q] = v[0];
             dst[2 * q + 1] = v[1];
         }
@@ -232,46 +250,44 @@ __device__ __forceinline__ void ctc_chain(const float* __restrict__ lp, float* _
                 on[p] = l2se3(o[p], er, orr + skip_add[p]) + cf[2 * p + 1];
             }
         }
-        float* dst = al + (int64_t)row_of(t) * Sp;
+        const int soff = row_of(t) * ROWB;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             e[p] = en[p];
             o[p] = on[p];
-            if (!OCC)
-                *reinterpret_cast<f32x2*>(dst + 2 * p) = f32x2{e[p], o[p]};
-            else
-                *reinterpret_cast<f32x2*>(dst + 2 * p) =
-                    f32x2{occupancy(ca[2 * p], e[p], cf[2 * p], nll2), occupancy(ca[2 * p + 1], o[p], cf[2 * p + 1], nll2)};
+            const f32x2 w = !OCC ? f32x2{e[p], o[p]}
+                                 : f32x2{occupancy(ca[2 * p], e[p], cf[2 * p], nll2), occupancy(ca[2 * p + 1], o[p], cf[2 * p + 1], nll2)};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), ral, voff + 8 * p, soff, 0);
         }
     };
     const int dir = DIRB ? -1 : 1;
     float pf[PF][2 * NP], pa[PF][2 * NP];
-    auto fetch = [&](int k0) {   // steps k0..k0+PF-1, clamped to the chain (over-fetched rows are never consumed)
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {      // steps 0..PF-1, clamped to the chain (over-fetched rows are never consumed)
+        const int t = t_first + dir * min(i, nsteps - 1);
+        load_row(rlp, t, pf[i]);
+        if (OCC) load_row(ral, row_of(t), pa[i]);
+    }
+    int k0 = 0;
+    // register ring: slot i is consumed for step k0 + i and refilled at once with the row of step k0 + PF + i (loads return in
+    // order, so the wait before a slot's use leaves the PF - 1 younger loads in flight)
+    for (; k0 + PF <= nsteps; k0 += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int k = min(k0 + i, nsteps - 1);
-            const int t = t_first + dir * k;
-            load_row(lp, t, pf[i]);
-            if (OCC) load_row(al, row_of(t), pa[i]);
+            float cf[2 * NP], ca[2 * NP];
+#pragma unroll
+            for (int q = 0; q < 2 * NP; ++q) { cf[q] = pf[i][q]; ca[q] = OCC ? pa[i][q] : 0.f; }   // (columns >= 2U+1 of a table row are -inf)
+            const int tn = t_first + dir * min(k0 + PF + i, nsteps - 1);
+            load_row(rlp, tn, pf[i]);
+            if (OCC) load_row(ral, row_of(tn), pa[i]);
+            step(t_first + dir * (k0 + i), cf, ca);
         }
-    };
-    fetch(0);
-    int k0 = 0;
-    for (; k0 + PF <= nsteps; k0 += PF) {
-        float cf[PF][2 * NP], ca[PF][2 * NP];
-#pragma unroll
-        for (int i = 0; i < PF; ++i)
-#pragma unroll
-            for (int q = 0; q < 2 * NP; ++q) { cf[i][q] = pf[i][q] + madd[q]; ca[i][q] = OCC ? pa[i][q] : 0.f; }   // madd: -inf on states >= 2U+1
-        fetch(k0 + PF);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) step(t_first + dir * (k0 + i), cf[i], ca[i]);
     }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
         float ca[2 * NP], cf[2 * NP];
 #pragma unroll
-        for (int q = 0; q < 2 * NP; ++q) { cf[q] = pf[i][q] + madd[q]; ca[q] = OCC ? pa[i][q] : 0.f; }
+        for (int q = 0; q < 2 * NP; ++q) { cf[q] = pf[i][q]; ca[q] = OCC ? pa[i][q] : 0.f; }
         if (k0 + i < nsteps) step(t_first + dir * (k0 + i), cf, ca);
     }
 }
@@ -321,8 +337,11 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
         madd[2 * p] = (j <= U) ? 0.f : -INFINITY;                                     // blank state 2j exists for j <= U
         madd[2 * p + 1] = (j < U) ? 0.f : -INFINITY;                                  // label state 2j+1 for j < U
     }
-    const float* lp = lp_ext + (int64_t)b * L * Sp + 2 * j0;
-    float* al = alpha + (int64_t)b * (L + 2) * Sp + 2 * j0;
+    const float* lp_u = lp_ext + (int64_t)b * L * Sp;       // wave-uniform bases + the lane's byte offset: ctc_chain's addressing
+    float* al_u = alpha + (int64_t)b * (L + 2) * Sp;
+    const int voff = 8 * j0;
+    const float* lp = lp_u + 2 * j0;
+    float* al = al_u + 2 * j0;
     auto load_row = [&](const float* base, int64_t row, float (&ev)[NP], float (&ov)[NP]) {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -354,11 +373,11 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
                     o[p] = (j0 + p == 0) ? lo[p] : -INFINITY;
                 }
                 store_row(0, e, o);
-                ctc_chain<NP, false, false>(lp, al, 1, min(W - 1, mid), e, o, skip_f, madd, 0.f, -1, 0);
+                ctc_chain<NP, false, false>(lp_u, al_u, voff, L, 1, min(W - 1, mid), e, o, skip_f, madd, 0.f, -1, 0);
                 have = W - 1 >= mid;
             } else if (k0 <= mid) {
                 load_row(al, k0 - 1, e, o);
-                ctc_chain<NP, false, false>(lp, al, k0, min(W, mid - k0 + 1), e, o, skip_f, madd, 0.f, -1, 0);
+                ctc_chain<NP, false, false>(lp_u, al_u, voff, L, k0, min(W, mid - k0 + 1), e, o, skip_f, madd, 0.f, -1, 0);
                 have = k0 + W - 1 >= mid;
             }
             if (last && !have) load_row(al, mid, e, o);
@@ -373,11 +392,11 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
                     o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
                 }
                 store_row(Tb - 1, e, o);
-                ctc_chain<NP, true, false>(lp, al, Tb - 2, min(W - 1, kmax), e, o, skip_b, madd, 0.f, -1, 0);
+                ctc_chain<NP, true, false>(lp_u, al_u, voff, L, Tb - 2, min(W - 1, kmax), e, o, skip_b, madd, 0.f, -1, 0);
                 have = W - 1 >= kmax;
             } else if (k0 > 0 && k0 <= kmax) {
                 load_row(al, Tb - k0, e, o);
-                ctc_chain<NP, true, false>(lp, al, Tb - 1 - k0, min(W, kmax - k0 + 1), e, o, skip_b, madd, 0.f, -1, 0);
+                ctc_chain<NP, true, false>(lp_u, al_u, voff, L, Tb - 1 - k0, min(W, kmax - k0 + 1), e, o, skip_b, madd, 0.f, -1, 0);
                 have = k0 + W - 1 >= kmax;
             }
             if (last) {
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
                     store_row(L, e, o);
                 } else {
                     if (!have) load_row(al, mid + 1, e, o);
-                    ctc_chain<NP, true, false>(lp, al, mid, 1, e, o, skip_b, madd, 0.f, mid, L);
+                    ctc_chain<NP, true, false>(lp_u, al_u, voff, L, mid, 1, e, o, skip_b, madd, 0.f, mid, L);
                 }
 #pragma unroll
                 for (int p = 0; p < NP; ++p) { xch[lane][2 * p] = e[p]; xch[lane][2 * p + 1] = o[p]; }
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
         }
         __syncthreads();                                // wave 0 has read row mid before wave 1 overwrites it
         if (wave == 0) {
-            ctc_chain<NP, false, true>(lp, al, mid + 1, Tb - 1 - mid, e, o, skip_f, madd, nll2, -1, 0);
+            ctc_chain<NP, false, true>(lp_u, al_u, voff, L, mid + 1, Tb - 1 - mid, e, o, skip_f, madd, nll2, -1, 0);
         } else {
             float oe[NP], oo[NP];
 #pragma unroll
@@ -437,163 +456,258 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
                 oo[p] = occupancy(ao[p], o[p], lo[p], nll2);
             }
             store_row(mid, oe, oo);
-            ctc_chain<NP, true, true>(lp, al, mid - 1, mid, e, o, skip_b, madd, nll2, -1, 0);
+            ctc_chain<NP, true, true>(lp_u, al_u, voff, L, mid - 1, mid, e, o, skip_b, madd, nll2, -1, 0);
         }
     }
 }
 
-// Flag-pipelined forward recursion: the same two half-length chains as ctc_mitm_kernel<NP, 0>, launched ONCE on a second stream
-// beside the (single, chunk-major) log-sum-exp launch.  Each wavefront waits, chunk by chunk, for the arrival counter of the W
-// table rows it is about to consume (relaxed agent-scope poll, bounded), issues one agent-scope acquire so that its CU's L1 holds
-// no stale line, and runs the chain over those rows - so the HBM-bound pass and the latency-bound recursion overlap inside one
-// pair of launches, with no event hand-offs (7-14 us each on this stack) between chunks.
+// ---- fused forward: the streaming pass and the recursion in ONE launch ---------------------------------------------------------
+// The log-sum-exp / gather pass is HBM-bound (thousands of workgroups, and it wants every wave slot of the chip: at 4 workgroups
+// per CU it runs 132 us, at 8 per CU 120, as a kernel of its own 109), the recursion is a latency-bound chain on two wavefronts
+// per utterance (56 us on its own).  Run one after the other the chain adds its whole length to the op; as two launches on two
+// streams the hand-off events cost more than the overlap saved.  Here both are roles of one grid: the first B workgroups are
+// RECURSION workgroups (wave 0: alpha, wave 1: beta of utterance blockIdx.x), all others are PASS workgroups that walk the
+// table rows chunk-major - chunk c holds, for every utterance, the frames the two wavefronts consume in their c-th piece -
+// store them write-through, drain, and add the row count to the (utterance, direction, chunk) arrival counter at agent scope.
+// A recursion wavefront polls its chunk's counter (relaxed, s_sleep, bounded) and then runs the chain over the chunk.
+// Pass workgroups never wait, so the grid needs no co-residency guarantee: whatever the dispatch order, every counter is
+// eventually complete.
+//
+// One kernel = one register / LDS allocation for both roles, and the pass needs the occupancy: a register ring deep enough to
+// cover a loaded HBM round trip (2-3 us = 24+ table rows at 0.1 us per step) cost 118-247 registers, i.e. 1-4 workgroups per
+// CU, and the fused launch ran SLOWER than the two-launch form (163-380 us against 154).  So the chain's look-ahead lives in
+// LDS: table rows arrive by LDS-DMA (global_load_lds, two 512-byte rows per wave instruction, no registers) into a 20-row ring
+// per wavefront and are picked up by ds_read one pair ahead.  vmcnt bookkeeping is by hand (a pair's DMA is followed by exactly
+// 3 * CTC_RING_PAIRS - 3 vector-memory operations - one DMA and two row stores per pair - before it is waited for); dummy DMAs
+// past a chunk's end keep that count constant.  ~70 registers + 22.5 KiB LDS: 7 workgroups per CU.
+constexpr int CTC_RING_PAIRS = 10;                              // ring depth in row pairs (1 KiB each) per chain wavefront
+constexpr int CTC_RING_BYTES = (CTC_RING_PAIRS + 1) * 1024;     // + one dummy slot
+
 __device__ __forceinline__ bool ctc_wait_rows(const int* ctr, int need) {
     if (need <= 0) return true;
-    bool ok = false;
     for (int spin = 0; spin < (1 << 21); ++spin) {
-        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) { ok = true; break; }
-        __builtin_amdgcn_s_sleep(16);
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+        __builtin_amdgcn_s_sleep(4);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return ok;
+    return false;
 }
 
-template <int NP>
-__global__ __launch_bounds__(128) void ctc_mitm_flag_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
-                                                            const int64_t* __restrict__ targets, int32_t* __restrict__ tgt_len, int L,
-                                                            int Umax, float* __restrict__ alpha, float* __restrict__ nll, int W,
-                                                            int nchunks, const int* __restrict__ arrivals, int64_t arr_stride) {
-    constexpr int Sp = 128 * NP;
-    __shared__ float xch[64][2 * NP];
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void global_cvoid_t;
+
+// One step of the NP = 1 recursion (lane i owns states 2i, 2i+1; c = the frame's table row entries of this lane).
+template <bool DIRB>
+__device__ __forceinline__ void ctc_step1(float& e, float& o, const f32x2 c, float skip_add) {
+    float en, on;
+    if (!DIRB) {
+        const float left = dpp_from_prev_lane(o);
+        en = l2se2(e, left) + c[0];
+        on = l2se3(o, e, left + skip_add) + c[1];
+    } else {
+        const float re = dpp_from_next_lane(e), ro = dpp_from_next_lane(o);
+        en = l2se2(e, o) + c[0];
+        on = l2se3(o, re, ro + skip_add) + c[1];
+    }
+    e = en;
+    o = on;
+}
+
+// A run of an EVEN number of steps of one direction's chain: steps k = 0..nsteps-1 over frames first + dir * k, all of them
+// published (the caller has seen their arrival counters complete: a row that is read before its producer has written it would
+// stay in this XCD's L2 and be served again, stale, when it is read for real).  skip0: frame `first` is the chain's initial
+// state - its step is not taken (it only keeps the row pairs aligned to the chunk grid).  ring: this wavefront's LDS ring.
+template <bool DIRB>
+__device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ctc_rsrc_t ral, int lane, char* ring, int first, int nsteps,
+                                              bool skip0, float& e, float& o, float skip_add, int dbg = 0) {
+    constexpr int P = CTC_RING_PAIRS;
+    const int npairs = nsteps >> 1;
+    if (npairs <= 0) return;
+    const char* src_lane = reinterpret_cast<const char*>(lp_u) + lane * 16;
+    const unsigned rd = (unsigned)reinterpret_cast<uintptr_t>((lds_void_t*)ring) + lane * 8;   // LDS byte address of this lane's column
+    // pair q = steps 2q, 2q+1.  alpha: rows (first + 2q, + 1);  beta: rows (first - 2q - 1, first - 2q): the LOWER row sits in the
+    // first half of the slot either way (the DMA copies 1 KiB of the table as it lies in memory).  sc1: the rows were published
+    // write-through by other CUs, the loads bypass this CU's L1.  Pairs past the end re-read pair 0 into a dummy slot: that keeps
+    // the count of vector-memory operations between a pair's DMA and its wait constant.
+    auto dma = [&](int q, int slot) {
+        const bool real = q < npairs;
+        const int qq = real ? q : 0;
+        const int lo = DIRB ? first - 2 * qq - 1 : first + 2 * qq;
+        __builtin_amdgcn_global_load_lds((global_cvoid_t*)(src_lane + (int64_t)lo * 512), (lds_void_t*)(ring + (real ? slot : P) * 1024), 16, 0, 16);
+    };
+    auto step = [&](int t, const f32x2 c) {
+        ctc_step1<DIRB>(e, o, c, skip_add);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{e, o}), ral, lane * 8, t * 512, 0);
+    };
+#pragma unroll
+    for (int j = 0; j < P; ++j) dma(j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the pair read ahead: lower / upper table row.  Every asm statement takes them in-out ("+v"): one live range in one register
+    // pair from the ds_read to the wait - a fresh output per read would let the compiler place a register copy (a loop phi) between
+    // a read and its wait, copying the register before the data lands.
+    f32x2 nlo = {0.f, 0.f}, nhi = {0.f, 0.f};
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512" : "+v"(nlo), "+v"(nhi) : "v"(rd) : "memory");
+    const int dir = DIRB ? -1 : 1;
+    for (int q0 = 0; q0 < npairs; q0 += P) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int q = q0 + j;
+            if (q < npairs) {
+                // the pair read ahead one iteration ago: waited for and copied INSIDE one asm statement (a compiler-side copy of a
+                // register that an asynchronous ds_read is still to write could be scheduled ahead of a separate wait)
+                f32x2 clo, chi;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b64 %[a], %[l]\n\tv_mov_b64 %[b], %[h]"
+                             : [a] "=&v"(clo), [b] "=&v"(chi), [l] "+v"(nlo), [h] "+v"(nhi)::"memory");
+                const f32x2 c0 = DIRB ? chi : clo, c1 = DIRB ? clo : chi;      // step 2q, step 2q + 1
+                dma(q + P, j);                                                   // slot j has just been read: refill it
+                asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * P - 3) : "memory");  // pair q + 1 has landed
+                if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (dbg & 2) __builtin_amdgcn_s_sleep(64);
+                if (j + 1 < P)
+                    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
+                                 : "+v"(nlo), "+v"(nhi) : "v"(rd), "i"((j + 1) * 1024), "i"((j + 1) * 1024 + 512) : "memory");
+                else
+                    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:512" : "+v"(nlo), "+v"(nhi) : "v"(rd) : "memory");
+                if (!(skip0 && q == 0)) step(first + dir * 2 * q, c0);
+                else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{e, o}), ral, lane * 8, first * 512, 0);   // (the initial row; keeps the op count)
+                step(first + dir * (2 * q + 1), c1);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nlo), "+v"(nhi)::"memory");      // (the read-ahead of a pair nobody consumes)
+}
+
+__global__ __launch_bounds__(256, 7) void ctc_fused_fwd_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
+                                                               const int64_t* __restrict__ targets, int Bn, int L, int V, int Umax, int blank,
+                                                               float* __restrict__ lse_out, float* __restrict__ lp_ext,
+                                                               float* __restrict__ alpha, float* __restrict__ nll,
+                                                               int32_t* __restrict__ tgt_len, int W, int nchunks, int* __restrict__ arrivals,
+                                                               int64_t arr_stride, int dbg) {
+    constexpr int Sp = 128;
+    __shared__ __attribute__((aligned(16))) char ring[2][CTC_RING_BYTES];
+    if ((int)blockIdx.x >= Bn) {
+        // ---- PASS workgroup: CTC_RPB consecutive rows of one (chunk, utterance, direction) ----
+        const int G = W / CTC_RPB;
+        int bid = blockIdx.x - Bn;
+        const int chunk = bid / (Bn * 2 * G);
+        bid -= chunk * (Bn * 2 * G);
+        const int b = bid / (2 * G), gi = bid - b * 2 * G;
+        const int dirc = gi / G, g0 = (gi - dirc * G) * CTC_RPB;
+        const int Tb = min(in_len[b], L), mid = Tb >> 1;
+        int count = 0;
+        for (int r = 0; r < CTC_RPB; ++r) {
+            const int k = chunk * W + g0 + r;
+            const int t = dirc == 0 ? k : Tb - 1 - k;
+            const bool valid = dirc == 0 ? (t <= mid && t < Tb) : (t > mid);
+            if (!valid) break;                           // frames only run out at the end of a direction
+            ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, true);
+            ++count;
+        }
+        if (count == 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores have left
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add(arrivals + (int64_t)b * arr_stride + dirc * nchunks + chunk, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ---- RECURSION workgroup: one utterance; wave 0 runs alpha, wave 1 beta, waves 2 / 3 only keep the barriers company ----
+    __shared__ float xch[64][2];
     __shared__ int failed;
-    const int b = blockIdx.x, lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j0 = lane * NP;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
     const int64_t* tg = targets + (int64_t)b * Umax;
-    int n = 0;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) n += (j0 + p < Umax && tg[j0 + p] != 0) ? 1 : 0;
-    const int U = (int)wave_sum((float)n);
-    if (threadIdx.x == 0) { tgt_len[b] = U; failed = 0; }
-    const int Tb = min(in_len[b], L);
-    if (Tb <= 0) {
-        if (threadIdx.x == 0) nll[b] = (U == 0) ? 0.f : INFINITY;
-        return;
+    const int U = (int)wave_sum((float)((lane < Umax && tg[lane] != 0) ? 1 : 0));
+    const int Tb = min(in_len[b], L), mid = Tb >> 1;
+    if (threadIdx.x == 0) {
+        failed = 0;
+        tgt_len[b] = U;
+        if (Tb <= 0) nll[b] = (U == 0) ? 0.f : INFINITY;
     }
-    __syncthreads();
-    const int mid = Tb >> 1;
-    float skip_f[NP], skip_b[NP], madd[2 * NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int j = j0 + p;
-        skip_f[p] = ((j >= 1 && j < U) && (tg[j] != tg[j - 1])) ? 0.f : -INFINITY;
-        skip_b[p] = ((j + 1 < U) && (tg[j] != tg[j + 1])) ? 0.f : -INFINITY;
-        madd[2 * p] = (j <= U) ? 0.f : -INFINITY;
-        madd[2 * p + 1] = (j < U) ? 0.f : -INFINITY;
-    }
-    const float* lp = lp_ext + (int64_t)b * L * Sp + 2 * j0;
-    float* al = alpha + (int64_t)b * (L + 2) * Sp + 2 * j0;
-    const int* arr_f = arrivals + (int64_t)b * arr_stride;      // forward-frame chunks
-    const int* arr_b = arr_f + nchunks;                        // backward-frame chunks
-    auto load_row = [&](const float* base, int64_t row, float (&ev)[NP], float (&ov)[NP]) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const f32x2 v = *reinterpret_cast<const f32x2*>(base + row * Sp + 2 * q);
-            ev[q] = v[0];
-            ov[q] = v[1];
-        }
-    };
-    auto load_lp = [&](int64_t row, float (&ev)[NP], float (&ov)[NP]) {
-        load_row(lp, row, ev, ov);
-#pragma unroll
-        for (int q = 0; q < NP; ++q) { ev[q] += madd[2 * q]; ov[q] += madd[2 * q + 1]; }
-    };
-    auto store_row = [&](int64_t row, const float (&ev)[NP], const float (&ov)[NP]) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) *reinterpret_cast<f32x2*>(al + row * Sp + 2 * q) = f32x2{ev[q], ov[q]};
-    };
-    float e[NP], o[NP], le[NP], lo[NP];
+    const float* lp_u = lp_ext + (int64_t)b * L * Sp;
+    float* al_u = alpha + (int64_t)b * (L + 2) * Sp;
+    float e = -INFINITY, o = -INFINITY;
     bool ok = true;
-    if (wave == 0) {            // alpha: frames 0 .. mid, chunk c = frames [cW, (c+1)W)
-        for (int c = 0; c * W <= mid && ok; ++c) {
-            const int k0 = c * W, rows = min(k0 + W, mid + 1) - k0;
-            ok = ctc_wait_rows(arr_f + c, rows);
+    if (Tb > 0 && wv < 2) {
+        __builtin_amdgcn_s_setprio(3);                    // the chains outrank the pass workgroups sharing this CU's SIMDs
+        const ctc_rsrc_t ral = ctc_rsrc(al_u, (int64_t)(L + 2) * Sp * 4);
+        const int* arr = arrivals + (int64_t)b * arr_stride + wv * nchunks;      // this direction's chunk counters
+        const f32x2* lpl = reinterpret_cast<const f32x2*>(lp_u) + lane;           // this lane's (blank, label) column
+        auto row_sc1 = [&](int t) {      // a published row read around the L1 (8-byte agent-scope load)
+            const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(lpl + (int64_t)t * 64), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+            return __builtin_bit_cast(f32x2, v);
+        };
+        auto store_row = [&](int row) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{e, o}), ral, lane * 8, row * 512, 0);
+        };
+        // steps k = 0 .. klast of this direction: alpha frame k, beta frame Tb - 1 - k; step 0 is the initial state
+        const int klast = wv == 0 ? mid : Tb - 2 - mid;
+        const int f0 = wv == 0 ? 0 : Tb - 1, dir = wv == 0 ? 1 : -1;
+        const float skip = wv == 0 ? (((lane >= 1 && lane < U) && (tg[lane] != tg[lane - 1])) ? 0.f : -INFINITY)      // s-2 -> s, s = 2 lane + 1
+                                   : (((lane + 1 < U) && (tg[lane] != tg[lane + 1])) ? 0.f : -INFINITY);            // s -> s+2
+        auto rows_of = [&](int c) { return min(c * W + W, klast + 1) - c * W; };
+        auto init_state = [&](int t) {
+            const f32x2 r0 = row_sc1(t);
+            if (wv == 0) { e = (lane == 0) ? r0[0] : -INFINITY; o = (lane == 0) ? r0[1] : -INFINITY; }
+            else { e = (lane == U) ? r0[0] : -INFINITY; o = (lane == U - 1) ? r0[1] : -INFINITY; }
+        };
+        int c = 0;
+        while (c * W <= klast && ok) {
+            ok = ctc_wait_rows(arr + c, rows_of(c));
             if (!ok) break;
-            if (c == 0) {
-                load_lp(0, le, lo);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    e[p] = (j0 + p == 0) ? le[p] : -INFINITY;
-                    o[p] = (j0 + p == 0) ? lo[p] : -INFINITY;
+            // every later chunk that is complete already joins this run: one pipeline fill for all of them (a chain that lags the
+            // pass never stops at a chunk boundary; one that is ahead waits for data anyway)
+            int ce = c + 1;
+            while (ce * W <= klast && __hip_atomic_load(arr + ce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rows_of(ce)) ++ce;
+            const int ka = c * W, kb = min(ce * W, klast + 1);      // steps [ka, kb)
+            if (c == 0) init_state(f0);
+            const int n = kb - ka, neven = n & ~1;
+            f32x2 tail = {0.f, 0.f};
+            if (n & 1) tail = row_sc1(f0 + dir * (kb - 1));         // an odd run ends the direction: its last row comes by itself
+            if (wv == 0) ctc_lds_chain<false>(lp_u, ral, lane, ring[0], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
+            else ctc_lds_chain<true>(lp_u, ral, lane, ring[1], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
+            if (n & 1) {
+                if (!(c == 0 && n == 1)) {
+                    if (wv == 0) ctc_step1<false>(e, o, tail, skip);
+                    else ctc_step1<true>(e, o, tail, skip);
                 }
-                store_row(0, e, o);
-                ctc_chain<NP, false, false>(lp, al, 1, rows - 1, e, o, skip_f, madd, 0.f, -1, 0);
-            } else {
-                ctc_chain<NP, false, false>(lp, al, k0, rows, e, o, skip_f, madd, 0.f, -1, 0);
+                store_row(f0 + dir * (kb - 1));
             }
+            c = ce;
         }
-    } else {                    // beta: frames Tb-1 .. mid+1 in chunks (step k <-> frame Tb-1-k), then onto mid (row L)
-        const int kmax = Tb - 2 - mid;
-        for (int c = 0; c * W <= kmax && ok; ++c) {
-            const int k0 = c * W, rows = min(k0 + W, kmax + 1) - k0;
-            ok = ctc_wait_rows(arr_b + c, rows);
-            if (!ok) break;
-            if (c == 0) {
-                load_lp(Tb - 1, le, lo);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    e[p] = (j0 + p == U) ? le[p] : -INFINITY;
-                    o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
-                }
-                store_row(Tb - 1, e, o);
-                ctc_chain<NP, true, false>(lp, al, Tb - 2, rows - 1, e, o, skip_b, madd, 0.f, -1, 0);
-            } else {
-                ctc_chain<NP, true, false>(lp, al, Tb - 1 - k0, rows, e, o, skip_b, madd, 0.f, -1, 0);
+        if (wv == 1) {          // beta onto the meeting frame (stored as row L); its row belongs to forward chunk mid / W
+            if (ok) {
+                const int cm = mid / W;
+                ok = ctc_wait_rows(arrivals + (int64_t)b * arr_stride + cm, min(cm * W + W, mid + 1) - cm * W);
             }
-        }
-        if (ok) {               // the meeting frame's row belongs to forward chunk mid / W
-            const int cm = mid / W;
-            ok = ctc_wait_rows(arr_f + cm, min(cm * W + W, mid + 1) - cm * W);
-        }
-        if (ok) {
-            if (kmax < 0) {
-                load_lp(mid, le, lo);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    e[p] = (j0 + p == U) ? le[p] : -INFINITY;
-                    o[p] = (j0 + p == U - 1) ? lo[p] : -INFINITY;
-                }
-                store_row(L, e, o);
-            } else {
-                ctc_chain<NP, true, false>(lp, al, mid, 1, e, o, skip_b, madd, 0.f, mid, L);
+            if (ok) {
+                if (klast < 0) init_state(mid);        // Tb == 1: beta starts on the meeting frame itself
+                else ctc_step1<true>(e, o, row_sc1(mid), skip);
+                store_row(L);
             }
-#pragma unroll
-            for (int p = 0; p < NP; ++p) { xch[lane][2 * p] = e[p]; xch[lane][2 * p + 1] = o[p]; }
+            xch[lane][0] = e;
+            xch[lane][1] = o;
         }
+        __builtin_amdgcn_s_setprio(0);
     }
-    if (!ok && lane == 0) failed = 1;
+    __syncthreads();                                      // (failed initialised; beta's states visible)
+    if (!ok && lane == 0) failed = 1;                     // a producer never arrived (cannot happen unless the pass faulted)
     __syncthreads();
-    if (failed) {               // a producer never arrived (cannot happen unless the pass faulted): fail loudly, never hang
-        if (threadIdx.x == 0) nll[b] = __builtin_nanf("");
+    if (Tb <= 0 || wv != 0) return;
+    if (failed) {                                         // fail loudly, never hang
+        if (lane == 0) nll[b] = __builtin_nanf("");
         return;
     }
-    if (wave == 0) {
-        load_lp(mid, le, lo);
-        float v[2 * NP], m = -INFINITY;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            v[2 * p] = (le[p] == -INFINITY) ? -INFINITY : e[p] + xch[lane][2 * p] - le[p];
-            v[2 * p + 1] = (lo[p] == -INFINITY) ? -INFINITY : o[p] + xch[lane][2 * p + 1] - lo[p];
-            m = fmaxf(m, fmaxf(v[2 * p], v[2 * p + 1]));
-        }
-        m = wave_max(m);
-        const float ms = fmaxf(m, NEG_BIG);
-        float sum = 0.f;
-#pragma unroll
-        for (int q = 0; q < 2 * NP; ++q) sum += __builtin_amdgcn_exp2f(v[q] - ms);
-        sum = wave_sum(sum);
-        if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
-    }
+    // log p(l|x) = lse_s( alpha_mid(s) + beta_mid(s) - lp_mid(s) )   (table columns >= 2U+1 are -inf: dead states drop out)
+    const unsigned long long rv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(lp_u + (int64_t)mid * Sp + 2 * lane),
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const f32x2 r = __builtin_bit_cast(f32x2, rv);
+    const float v0 = (r[0] == -INFINITY) ? -INFINITY : e + xch[lane][0] - r[0];
+    const float v1 = (r[1] == -INFINITY) ? -INFINITY : o + xch[lane][1] - r[1];
+    const float m = wave_max(fmaxf(v0, v1));
+    const float ms = fmaxf(m, NEG_BIG);
+    const float sum = wave_sum(__builtin_amdgcn_exp2f(v0 - ms) + __builtin_amdgcn_exp2f(v1 - ms));
+    if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
 }
 
 __global__ void ctc_mean_kernel(const float* __restrict__ nll, const int32_t* __restrict__ tgt_len, int B, float* __restrict__ loss) {
@@ -682,18 +796,6 @@ int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, 
     return 0;
 }
 
-// two reusable events per host thread for the fork / join of the pipelined forward (no timing, so recording is cheap)
-struct PipeEvents {
-    hipEvent_t main_done = nullptr, aux_done = nullptr;
-    bool ok() {
-        if (!main_done) {
-            if (hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess) return false;
-            if (hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return false;
-        }
-        return true;
-    }
-};
-
 }  // namespace
 
 extern "C" int asr_ctc_workspace_stride(int Umax) { return ctc_row_stride(Umax); }
@@ -705,18 +807,18 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && blank >= 0 && blank < V && ldl >= V, ASR_ERR_ARG, "ctc_fwd: bad sizes");
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (U+1 must be <= 512)", Umax);
     ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd: workspaces must be 16-byte aligned");
-    hipStream_t s = static_cast<hipStream_t>(stream), s2 = static_cast<hipStream_t>(aux_stream);
-    if (!s2 || s2 == s || n_chunks <= 1 || L < 64) {   // single stream: one pass over the logits, then the two half-length chains
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    (void)aux_stream;                                  // (kept in the signature; the fused form needs no second stream)
+    if (n_chunks <= 1 || L < 64 || ctc_np(Umax) != 1) {   // two launches: one pass over the logits, then the two half-length chains
+                                                          // (the fused form is written for one state pair per lane: U + 1 <= 64)
         hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
-                           lp_ext, 0, 0, nullptr, 0, 0, B);
+                           lp_ext);
         launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, 0, L, 1);
         ASR_LAUNCH_CHECK("ctc_loss_fwd");
         return 0;
     }
-    // flag-pipelined: ONE chunk-major log-sum-exp launch on `stream` publishes table rows chunk by chunk (write-through stores +
-    // arrival counters in row L+1 of the alpha workspace), ONE recursion launch on `aux_stream` consumes them as they arrive
-    static thread_local PipeEvents ev;
-    ASR_REQUIRE(ev.ok(), ASR_ERR_UNSUPPORTED, "ctc_fwd: cannot create events");
+    // fused: ONE launch - pass workgroups publish table rows chunk by chunk (write-through stores + arrival counters in row L+1 of
+    // the alpha workspace), recursion workgroups of the same grid consume them as they arrive
     const int steps = L / 2 + 1;                           // alpha takes mid + 1 <= L/2 + 1 steps, beta at most as many
     const int W = ((steps + n_chunks - 1) / n_chunks + CTC_RPB - 1) / CTC_RPB * CTC_RPB;
     const int nc = (steps + W - 1) / W;
@@ -724,32 +826,17 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE(2 * nc <= Sp, ASR_ERR_UNSUPPORTED, "ctc_fwd: too many chunks (%d) for the counter row", nc);
     int* arrivals = reinterpret_cast<int*>(alpha + (int64_t)(L + 1) * Sp);
     const int64_t arr_stride = (int64_t)(L + 2) * Sp;
-#define HIP_OK(call)                                                          \
-    do {                                                                      \
-        hipError_t e__ = (call);                                              \
-        if (e__ != hipSuccess) {                                              \
-            asr_set_error("ctc_loss_fwd: %s", hipGetErrorString(e__));        \
-            return (int)e__;                                                  \
-        }                                                                     \
-    } while (0)
-    HIP_OK(hipMemset2DAsync(arrivals, (size_t)arr_stride * sizeof(float), 0, (size_t)2 * nc * sizeof(int), B, s));
-    HIP_OK(hipEventRecord(ev.main_done, s));               // fork: the recursion starts behind the logits' producer and the memset
-    HIP_OK(hipStreamWaitEvent(s2, ev.main_done, 0));
-#define LAUNCH_FLAG(NP_)                                                                                                         \
-    hipLaunchKernelGGL((ctc_mitm_flag_kernel<NP_>), dim3(B), dim3(128), 0, s2, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, \
-                       nll, W, nc, arrivals, arr_stride)
-    switch (ctc_np(Umax)) {
-        case 1: LAUNCH_FLAG(1); break;
-        case 2: LAUNCH_FLAG(2); break;
-        case 4: LAUNCH_FLAG(4); break;
-        default: LAUNCH_FLAG(8); break;
+    {
+        hipError_t e__ = hipMemset2DAsync(arrivals, (size_t)arr_stride * sizeof(float), 0, (size_t)2 * nc * sizeof(int), B, s);
+        if (e__ != hipSuccess) {
+            asr_set_error("ctc_loss_fwd: %s", hipGetErrorString(e__));
+            return (int)e__;
+        }
     }
-#undef LAUNCH_FLAG
-    hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(nc * B * 2 * (W / CTC_RPB)), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax,
-                       blank, lse, lp_ext, 0, W, arrivals, arr_stride, nc, B);
-    HIP_OK(hipEventRecord(ev.aux_done, s2));               // join
-    HIP_OK(hipStreamWaitEvent(s, ev.aux_done, 0));
-#undef HIP_OK
+    const int grid = B + nc * B * 2 * (W / CTC_RPB);
+    static const int dbg = [] { const char* e = getenv("ASR_AMD_CTC_DBG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(ctc_fused_fwd_kernel, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
+                       alpha, nll, tgt_len, W, nc, arrivals, arr_stride, dbg);
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
 }
