@@ -41,7 +41,6 @@ constexpr float LN2 = 0.6931471805599453f;
 // the extended labels' log-probs (stored base-2: (x - lse) * log2(e)) into the compact table row (stride Sp = 2U+2).
 constexpr int LSE_UNR = 6;  // float4 per thread held in registers: V <= 256*4*6 = 6144 takes the two-pass register path
 
-constexpr int CTC_RPB = 4;   // table rows per workgroup in the flag-pipelined launch (one store drain + one counter add for all of them)
 
 // A logits row held in registers (V <= 256 * 4 * LSE_UNR - 3): every load of the row is issued before anything waits on it.
 struct CtcRowRegs {
@@ -74,6 +73,26 @@ __device__ __forceinline__ void ctc_row_reduce(const CtcRowRegs& r, float& m, fl
 #pragma unroll
     for (int j = 0; j < LSE_UNR; ++j)
         s += (__expf(r.v[j][0] - ms) + __expf(r.v[j][1] - ms)) + (__expf(r.v[j][2] - ms) + __expf(r.v[j][3] - ms));
+}
+
+// a row too long for the register path: online (max, sum-exp) over a strided walk
+__device__ __forceinline__ void ctc_row_stream(const float* __restrict__ x, int V, float& m, float& s) {
+    const int tid = threadIdx.x;
+    m = -INFINITY;
+    s = 0.f;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
+    const int peel = min((4 - mis) & 3, V);
+    const int nv4 = (V - peel) >> 2;
+    const int tail0 = peel + nv4 * 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + peel);
+    if (tid < peel) { m = x[tid]; s = 1.f; }
+    for (int i = tid; i < nv4; i += 256) {
+        const f32x4 v = x4[i];
+        const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        if (m4 > m) { s *= __expf(m - m4); m = m4; }
+        s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
+    }
+    if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
 }
 
 // second half of a table row: block-combine the per-thread (max, sum-exp), then gather the extended labels' base-2 log-probs
@@ -142,19 +161,7 @@ __device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, in
         ctc_row_load(x, V, r);
         ctc_row_reduce(r, m, s);
     } else {
-        const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
-        const int peel = min((4 - mis) & 3, V);
-        const int nv4 = (V - peel) >> 2;
-        const int tail0 = peel + nv4 * 4;
-        const f32x4* x4 = reinterpret_cast<const f32x4*>(x + peel);
-        if (tid < peel) { m = x[tid]; s = 1.f; }
-        for (int i = tid; i < nv4; i += 256) {
-            const f32x4 v = x4[i];
-            const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            if (m4 > m) { s *= __expf(m - m4); m = m4; }
-            s += (__expf(v[0] - m) + __expf(v[1] - m)) + (__expf(v[2] - m) + __expf(v[3] - m));
-        }
-        if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
+        ctc_row_stream(x, V, m, s);
     }
     ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, s, publish);
 }
@@ -480,8 +487,8 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
 // per wavefront and are picked up by ds_read one pair ahead.  vmcnt bookkeeping is by hand (a pair's DMA is followed by exactly
 // 3 * CTC_RING_PAIRS - 3 vector-memory operations - one DMA and two row stores per pair - before it is waited for); dummy DMAs
 // past a chunk's end keep that count constant.  ~70 registers + 22.5 KiB LDS: 7 workgroups per CU.
-constexpr int CTC_RING_PAIRS = 10;                              // ring depth in row pairs (1 KiB each) per chain wavefront
-constexpr int CTC_RING_BYTES = (CTC_RING_PAIRS + 1) * 1024;     // + one dummy slot
+// ring depth in row pairs (1 KiB each, + one dummy slot) per chain wavefront: 10 pairs -> 22.5 KiB per workgroup, 7 per CU;
+// 8 pairs -> 18.5 KiB, 8 per CU
 
 __device__ __forceinline__ bool ctc_wait_rows(const int* ctr, int need) {
     if (need <= 0) return true;
@@ -516,10 +523,9 @@ __device__ __forceinline__ void ctc_step1(float& e, float& o, const f32x2 c, flo
 // published (the caller has seen their arrival counters complete: a row that is read before its producer has written it would
 // stay in this XCD's L2 and be served again, stale, when it is read for real).  skip0: frame `first` is the chain's initial
 // state - its step is not taken (it only keeps the row pairs aligned to the chunk grid).  ring: this wavefront's LDS ring.
-template <bool DIRB>
+template <bool DIRB, int P>
 __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ctc_rsrc_t ral, int lane, char* ring, int first, int nsteps,
                                               bool skip0, float& e, float& o, float skip_add, int dbg = 0) {
-    constexpr int P = CTC_RING_PAIRS;
     const int npairs = nsteps >> 1;
     if (npairs <= 0) return;
     const char* src_lane = reinterpret_cast<const char*>(lp_u) + lane * 16;
@@ -560,8 +566,6 @@ __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ct
                 const f32x2 c0 = DIRB ? chi : clo, c1 = DIRB ? clo : chi;      // step 2q, step 2q + 1
                 dma(q + P, j);                                                   // slot j has just been read: refill it
                 asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * P - 3) : "memory");  // pair q + 1 has landed
-                if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (dbg & 2) __builtin_amdgcn_s_sleep(64);
                 if (j + 1 < P)
                     asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
                                  : "+v"(nlo), "+v"(nhi) : "v"(rd), "i"((j + 1) * 1024), "i"((j + 1) * 1024 + 512) : "memory");
@@ -576,40 +580,70 @@ __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ct
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nlo), "+v"(nhi)::"memory");      // (the read-ahead of a pair nobody consumes)
 }
 
-__global__ __launch_bounds__(256, 7) void ctc_fused_fwd_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
+template <int P>
+__global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
                                                                const int64_t* __restrict__ targets, int Bn, int L, int V, int Umax, int blank,
                                                                float* __restrict__ lse_out, float* __restrict__ lp_ext,
                                                                float* __restrict__ alpha, float* __restrict__ nll,
                                                                int32_t* __restrict__ tgt_len, int W, int nchunks, int* __restrict__ arrivals,
                                                                int64_t arr_stride, int dbg) {
     constexpr int Sp = 128;
-    __shared__ __attribute__((aligned(16))) char ring[2][CTC_RING_BYTES];
+    __shared__ __attribute__((aligned(16))) char ring[2][(P + 1) * 1024];
+    const int RPB = dbg >> 8;                                // table rows per pass workgroup (W is a multiple of it)
     if ((int)blockIdx.x >= Bn) {
-        // ---- PASS workgroup: CTC_RPB consecutive rows of one (chunk, utterance, direction) ----
-        const int G = W / CTC_RPB;
-        int bid = blockIdx.x - Bn;
-        const int chunk = bid / (Bn * 2 * G);
-        bid -= chunk * (Bn * 2 * G);
-        const int b = bid / (2 * G), gi = bid - b * 2 * G;
-        const int dirc = gi / G, g0 = (gi - dirc * G) * CTC_RPB;
-        const int Tb = min(in_len[b], L), mid = Tb >> 1;
-        int count = 0;
-        for (int r = 0; r < CTC_RPB; ++r) {
-            const int k = chunk * W + g0 + r;
-            const int t = dirc == 0 ? k : Tb - 1 - k;
-            const bool valid = dirc == 0 ? (t <= mid && t < Tb) : (t > mid);
-            if (!valid) break;                           // frames only run out at the end of a direction
-            ctc_lse_row(logits, ldl, targets, L, V, Umax, blank, lse_out, lp_ext, b, t, true);
-            ++count;
+        // ---- PASS workgroup (persistent): walks row groups gid = pid, pid + npass, ... in chunk-major order; a group = RPB consecutive
+        // rows of one (chunk, utterance, direction).  Only wave 0 stores (64 state pairs + the row's lse), so the group's arrival is
+        // signalled by wave 0 alone, and not by draining its stores on the spot: vector-memory operations retire in order, so once
+        // the NEXT group's first row has landed in wave 0's registers every older store has left - the add costs no wait at all.
+        const int G = W / RPB, npass = gridDim.x - Bn, total = nchunks * Bn * 2 * G;
+        const bool w0 = threadIdx.x < 64;
+        int* pending = nullptr;
+        int pending_count = 0;
+        for (int gid = blockIdx.x - Bn; gid < total; gid += npass) {
+            int bid = gid;
+            const int chunk = bid / (Bn * 2 * G);
+            bid -= chunk * (Bn * 2 * G);
+            const int b = bid / (2 * G), gi = bid - b * 2 * G;
+            const int dirc = gi / G, g0 = (gi - dirc * G) * RPB;
+            const int Tb = min(in_len[b], L), mid = Tb >> 1;
+            int count = 0;
+            for (int r = 0; r < RPB; ++r) {              // frames only run out at the end of a direction
+                const int k = chunk * W + g0 + r;
+                const int t = dirc == 0 ? k : Tb - 1 - k;
+                count += (dirc == 0 ? (t <= mid && t < Tb) : (t > mid)) ? 1 : 0;
+            }
+            if (count == 0) continue;
+            const int kb = chunk * W + g0;
+            const int tstep = dirc == 0 ? 1 : -1, t0 = dirc == 0 ? kb : Tb - 1 - kb;
+            for (int r = 0; r < count; ++r) {
+                const int t = t0 + tstep * r, row = b * L + t;
+                const float* x = logits + (int64_t)row * ldl;
+                float m, sx;
+                if (ctc_row_fits_regs(V)) {
+                    CtcRowRegs rr;
+                    ctc_row_load(x, V, rr);
+                    ctc_row_reduce(rr, m, sx);
+                } else {
+                    ctc_row_stream(x, V, m, sx);
+                }
+                if (pending && w0) {                     // (this row's loads are back: the previous group's stores retired before them)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (threadIdx.x == 0) __hip_atomic_fetch_add(pending, pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                pending = nullptr;
+                ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, sx, true);
+            }
+            pending = arrivals + (int64_t)b * arr_stride + dirc * nchunks + chunk;
+            pending_count = count;
         }
-        if (count == 0) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through stores have left
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_fetch_add(arrivals + (int64_t)b * arr_stride + dirc * nchunks + chunk, count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pending && w0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(pending, pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     // ---- RECURSION workgroup: one utterance; wave 0 runs alpha, wave 1 beta, waves 2 / 3 only keep the barriers company ----
+    if (dbg & 4) return;       // (timing experiment: the pass alone)
     __shared__ float xch[64][2];
     __shared__ int failed;
     const int lane = threadIdx.x & 63;
@@ -664,8 +698,8 @@ __global__ __launch_bounds__(256, 7) void ctc_fused_fwd_kernel(const float* __re
             const int n = kb - ka, neven = n & ~1;
             f32x2 tail = {0.f, 0.f};
             if (n & 1) tail = row_sc1(f0 + dir * (kb - 1));         // an odd run ends the direction: its last row comes by itself
-            if (wv == 0) ctc_lds_chain<false>(lp_u, ral, lane, ring[0], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
-            else ctc_lds_chain<true>(lp_u, ral, lane, ring[1], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
+            if (wv == 0) ctc_lds_chain<false, P>(lp_u, ral, lane, ring[0], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
+            else ctc_lds_chain<true, P>(lp_u, ral, lane, ring[1], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
             if (n & 1) {
                 if (!(c == 0 && n == 1)) {
                     if (wv == 0) ctc_step1<false>(e, o, tail, skip);
@@ -819,8 +853,13 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     }
     // fused: ONE launch - pass workgroups publish table rows chunk by chunk (write-through stores + arrival counters in row L+1 of
     // the alpha workspace), recursion workgroups of the same grid consume them as they arrive
+    // knobs for A/B runs (defaults are the measured best): ASR_AMD_CTC_RPB rows per pass workgroup, ASR_AMD_CTC_RING ring pairs,
+    // ASR_AMD_CTC_DBG bit 2: pass only (no recursion: timing experiment, results invalid)
+    static const int rpb = [] { const char* e = getenv("ASR_AMD_CTC_RPB"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : (v == 2 ? 2 : 4); }();
+    static const int ringp = [] { const char* e = getenv("ASR_AMD_CTC_RING"); return e ? atoi(e) : 8; }();
+    static const int dbg = [] { const char* e = getenv("ASR_AMD_CTC_DBG"); return e ? atoi(e) : 0; }();
     const int steps = L / 2 + 1;                           // alpha takes mid + 1 <= L/2 + 1 steps, beta at most as many
-    const int W = ((steps + n_chunks - 1) / n_chunks + CTC_RPB - 1) / CTC_RPB * CTC_RPB;
+    const int W = ((steps + n_chunks - 1) / n_chunks + 7) / 8 * 8;      // (a multiple of every rows-per-workgroup choice, and even)
     const int nc = (steps + W - 1) / W;
     const int Sp = ctc_row_stride(Umax);
     ASR_REQUIRE(2 * nc <= Sp, ASR_ERR_UNSUPPORTED, "ctc_fwd: too many chunks (%d) for the counter row", nc);
@@ -833,10 +872,25 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
             return (int)e__;
         }
     }
-    const int grid = B + nc * B * 2 * (W / CTC_RPB);
-    static const int dbg = [] { const char* e = getenv("ASR_AMD_CTC_DBG"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(ctc_fused_fwd_kernel, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
-                       alpha, nll, tgt_len, W, nc, arrivals, arr_stride, dbg);
+    // B recursion workgroups + persistent pass workgroups filling every remaining slot of the chip (7 or 8 per CU by the kernel's
+    // LDS / register budget; more than fit would only queue)
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int groups = nc * B * 2 * (W / rpb);
+    int npass = n_cu * (ringp <= 8 ? 8 : 6) - B;      // (the 10-pair ring's 23 KiB round up past a seventh of the CU's LDS)
+    if (npass > groups) npass = groups;
+    if (npass < 1) npass = 1;
+    const int grid = B + npass;
+    const int kdbg = (dbg & 0xff) | (rpb << 8);
+    if (ringp <= 8)
+        hipLaunchKernelGGL(ctc_fused_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
+                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, kdbg);
+    else
+        hipLaunchKernelGGL(ctc_fused_fwd_kernel<10>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
+                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, kdbg);
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
 }

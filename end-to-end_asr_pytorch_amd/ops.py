@@ -350,9 +350,10 @@ class CtcState:
 
 
 _AUX = {}
-# pieces of the two-stream pipelined CTC forward; <= 1 = single stream, the default: on MI355X / ROCm 7.2 the cross-stream event
-# hand-offs cost 7-14 us each and the recursion runs 2.4x slower next to the log-sum-exp pass, so 4 chunks measured 188 us vs 171
-CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "1"))
+# chunks of the fused CTC forward (asr_hip.h: asr_ctc_loss_fwd n_chunks): the hand-off granularity between the streaming pass and the
+# recursion wavefronts of the same launch.  <= 1 = the two-launch form (pass, then recursion): 154-167 us at the north-star
+# shape against 133-139 fused with 32 chunks
+CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "32"))
 
 
 def aux_stream(device, priority=0, slot=0):
@@ -388,7 +389,7 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None):
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
         check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
                                      _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len),
-                                     ctypes.c_void_p(aux_stream(dev, -1).cuda_stream) if nck > 1 else None, nck), "asr_ctc_loss_fwd")
+                                     None, nck), "asr_ctc_loss_fwd")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
     return loss, st.nll, st

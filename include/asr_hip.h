@@ -234,11 +234,12 @@ int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y,
  * Workspaces (caller-owned, opaque layout): lse f32 [B,L]; lp_ext f32 [B,L,S]; alpha f32 [B,L+2,S] with
  * S = asr_ctc_workspace_stride(Umax) (>= 2*Umax+1; one 512-byte wave store per row and 64 labels).
  * Outputs: nll f32 [B] (inf for infeasible rows, zero_infinity=False), tgt_len int32 [B].
- * aux_stream / n_chunks (forward only): with a second stream and n_chunks > 1 the frames are cut outside-in into n_chunks pieces;
- * ONE chunk-major log-sum-exp launch on `stream` publishes the table rows (write-through stores + per-chunk arrival counters)
- * and ONE recursion launch on `aux_stream` consumes each piece as it arrives, so the HBM-bound pass and the latency-bound
- * alpha/beta recursion overlap.  The call forks from and joins back into `stream` with two cached hipEvents (the only state the
- * library keeps besides its code objects), so the caller sees ordinary stream semantics.  NULL / <= 1: everything on `stream`.
+ * n_chunks (forward only): > 1 (and U + 1 <= 64, L >= 64) selects the FUSED form - one launch in which persistent pass workgroups
+ * walk the logits chunk-major (frames cut outside-in into n_chunks pieces per direction), publish the table rows (write-through
+ * stores + per-chunk arrival counters kept in the alpha workspace) and the two recursion wavefronts of every utterance, resident
+ * in the same grid, consume each piece as it arrives through an LDS ring: the HBM-bound pass and the latency-bound alpha / beta
+ * recursion overlap.  <= 1: two launches (pass, then recursion).  Results are bit-identical.  aux_stream is unused (kept for ABI
+ * stability with round 1's two-stream form); pass NULL.
  */
 int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
