@@ -81,3 +81,11 @@ class CTC_Model(nn.Module):
             return [logits], _slots(self.decoder, "prj"), None
         (logits,), _ = _taped(self, run)
         return logits, input_lengths
+
+    def recognize(self, input, input_length, ctc_infer, args=None):
+        """ctc_model.py:34-48 - one utterance [T, D] through the encoder and the projection, then `ctc_infer(logits, len_logits)`
+        (e.g. asr_amd.GreedyDecoder)."""
+        import torch
+        with torch.no_grad():
+            logits, len_logits = self.forward(input.unsqueeze(0), input_length)
+        return ctc_infer(logits, len_logits)

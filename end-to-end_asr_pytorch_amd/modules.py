@@ -427,6 +427,16 @@ class MultiheadAttention(_Cached):
         mine = (qkvw[:1] + qkvb[:1]) if dkv_pre is not None else (qkvw + qkvb)
         _TAPE.push(bw, mine + (fc.weight, fc.bias, ln.weight, ln.bias))
 
+    def _impl_cached_self(self, x, k_cache, v_cache, t, k_len):
+        """Self-attention of ONE new position t (x: Act [B*1, d]) against the cache (decoding): its key / value are projected and
+        written into k_cache / v_cache [B, h, Tmax, 64] at position t, then the query attends to positions < k_len (= t + 1)."""
+        h, B = self.n_head, x.B
+        kv = ops.proj_heads(x.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)), self._b("bkv", (self.w_ks.bias, self.w_vs.bias)),
+                            2, B, 1, h, 1.0)
+        k_cache[:, :, t:t + 1].copy_(kv[0])
+        v_cache[:, :, t:t + 1].copy_(kv[1])
+        return self._impl(x, Act(None, None, B, k_cache.shape[2]), k_len, False, None, kv_pre=(k_cache, v_cache, None))
+
     def forward(self, q, k, v, mask=None, k_len=None, causal=False):
         """Reference signature + length-based masking: `k_len` (int [B]) / `causal`.  A bool `mask` [B,Lq,Lk] is
         accepted when it is a key-padding mask (tail padding): it is reduced to k_len.  Returns (output, None)."""
@@ -915,6 +925,62 @@ class Decoder(_Cached):
         logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, x)
         return logits.view(B, U, self.n_tgt_vocab), ys_out
 
+    @torch.no_grad()
+    def step(self, prefixs, encoded, len_encoded):
+        """decoder.py:98-120 - log-softmax scores [B, V] of the next token after `prefixs` int64 [B, i] (every prefix position
+        counts: the step's masks are causal-only).  The whole prefix is recomputed, like the reference; `batch_decode` does not."""
+        B, U = prefixs.shape
+        enc = _act(encoded)
+        enc_len = ops.as_i32(len_encoded, encoded.device)
+        dec_len = torch.full((B,), U, dtype=torch.int32, device=encoded.device)
+        x32, x16 = ops.embed_pe(prefixs.contiguous(), self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U),
+                                want_bf16=(_PRECISION == "bf16"))
+        x = Act(x32, x16, B, U)
+        cross = self._cross_kv(enc)
+        for i, layer in enumerate(self.layer_stack):
+            x = layer._impl(x, enc, dec_len, enc_len, kv_pre=cross(i))
+        last = Act(x.f32.view(B, U, -1)[:, -1].contiguous(), None if x.b16 is None else x.b16.view(B, U, -1)[:, -1].contiguous(), B, 1)
+        return ops.log_softmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, last))
+
+    @torch.no_grad()
+    def batch_decode(self, encoded, len_encoded, max_decode_len=100):
+        """decoder.py:138-164 - greedy decoding of a batch: -> (preds int64 [B, steps], len_decoded, torch.zeros(0)).
+        One new token per step through the layers, against per-layer self-attention K/V caches and the encoder-side K/V of all
+        layers projected once (see decode.py); the finished test is the reference's per-step host check."""
+        B = encoded.shape[0]
+        dev = encoded.device
+        enc = _act(encoded)
+        enc_len = ops.as_i32(len_encoded, dev)
+        cross = self._cross_kv(enc)
+        n, h, T = len(self.layer_stack), self.n_head, int(max_decode_len)
+        cdt = _cdtype()
+        kc = [torch.zeros((B, h, max(T, 1), 64), device=dev, dtype=cdt) for _ in range(n)]
+        vc = [torch.zeros((B, h, max(T, 1), 64), device=dev, dtype=cdt) for _ in range(n)]
+        emb = self.tgt_word_emb.weight.detach().float()
+        pe = self.positional_encoding.pe[0]
+        preds = torch.zeros((B, T + 1), dtype=torch.long, device=dev)
+        preds[:, 0] = self.sos_id
+        len_decoded = torch.ones_like(len_encoded)
+        finished = torch.zeros(B, dtype=torch.bool, device=dev)
+        steps = 0
+        for t in range(T):
+            x32, x16 = ops.embed_pe(preds[:, t:t + 1].contiguous(), emb, pe[t:t + 1].contiguous(), want_bf16=(_PRECISION == "bf16"))
+            x = Act(x32, x16, B, 1)
+            k_len = torch.full((B,), t + 1, dtype=torch.int32, device=dev)
+            for i, layer in enumerate(self.layer_stack):
+                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], t, k_len)
+                x = layer.enc_attn._impl(x, enc, enc_len, False, None, kv_pre=cross(i))
+                x = layer.pos_ffn._impl(x, None)
+            cur = ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x))      # argmax of log_softmax = argmax of the logits
+            preds[:, t + 1] = cur
+            finished = torch.logical_or(finished, cur.eq(self.eos_id))
+            len_decoded = len_decoded + (1 - finished.to(len_decoded.dtype))
+            steps = t + 1
+            if bool(finished.all()):
+                break
+        len_decoded = len_decoded - (1 - finished.to(len_decoded.dtype))      # for decoded length cut by encoded length (decoder.py:161)
+        return preds[:, 1:steps + 1], len_decoded, torch.zeros(0)
+
     def cross_kv_params(self):
         """([w_ks, w_vs weights of layer 0, 1, ...], [their biases]) - the trainer keeps each list adjacent in its flat buffers."""
         att = [layer.enc_attn for layer in self.layer_stack]
@@ -1152,6 +1218,14 @@ class Conv_CTC_Transformer(CTC_Transformer):
             return [ctc_logits, logits], _slots(self, "ctc", self.decoder, "prj"), (targets_eos, len_sequence, enc.B, enc.L)
         (ctc_logits, logits), (targets_eos, len_sequence, B, L) = _taped(self, run)
         return ctc_logits.view(B, L, -1), len_sequence, logits, targets_eos
+
+    @torch.no_grad()
+    def batch_recognize(self, features, len_features, beam_size):
+        """transformer.py:172-185 - greedy batch decoding.  As in the reference, the third argument is handed to
+        Decoder.batch_decode positionally, where it is `max_decode_len`."""
+        conv, len_sequences = self.conv_encoder._impl(features, len_features)
+        enc = self.encoder._impl(conv, len_sequences)
+        return self.decoder.batch_decode(enc.view3(), len_sequences, beam_size)
 
     @classmethod
     def create_model(cls, args):

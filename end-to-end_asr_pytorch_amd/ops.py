@@ -612,6 +612,37 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None)
                               float(eps), int(step), float(grad_scale)), "asr_adam_step")
 
 
+def argmax_rows(x2d):
+    """f32 [M, V] (row stride free) -> int64 [M], ties to the lowest index"""
+    _req_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype == torch.float32
+    M, V = x2d.shape
+    out = torch.empty(M, device=x2d.device, dtype=torch.int64)
+    check(lib().asr_argmax_rows(_stream(), _p(x2d), x2d.stride(0), M, V, _p(out)), "asr_argmax_rows")
+    return out
+
+
+def log_softmax_rows(x2d):
+    _req_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype == torch.float32
+    M, V = x2d.shape
+    y = torch.empty((M, V), device=x2d.device, dtype=torch.float32)
+    check(lib().asr_log_softmax_rows(_stream(), _p(x2d), x2d.stride(0), M, V, _p(y), V), "asr_log_softmax_rows")
+    return y
+
+
+def ctc_greedy_reduce(frames, lens, blank):
+    """frames int64 [B, L] (per-frame argmax), lens int [B] -> (tokens int64 [B, L] zero-padded, n_tokens int32 [B])"""
+    _req_cuda(frames, lens)
+    frames = frames.to(torch.int64).contiguous()
+    B, L = frames.shape
+    out = torch.empty((B, L), device=frames.device, dtype=torch.int64)
+    n = torch.empty(B, device=frames.device, dtype=torch.int32)
+    check(lib().asr_ctc_greedy_reduce(_stream(), _p(frames), _p(as_i32(lens, frames.device)), B, L, int(blank), _p(out), _p(n)),
+          "asr_ctc_greedy_reduce")
+    return out, n
+
+
 def add_(dst, src):
     """dst += src for f32 tensors viewed as [rows, cols] (last dim contiguous, rows uniformly strided) - on the HIP path."""
     _req_cuda(dst, src)

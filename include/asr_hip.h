@@ -293,6 +293,16 @@ int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const fl
 /* Conv1d k=w stride 1 valid + ReLU over time with implicit zero right-pad (conv_encoder.py:33-43) is expressed by
  * the caller as w_context shifted GEMMs through asr_gemm_nt; no dedicated entry point. */
 
+/* ---- greedy decoding ---------------------------------------------------------------------------------------
+ * asr_argmax_rows: out[m] = argmax_v x[m, v] (ties -> lowest index, like torch.argmax / torch.max on CPU): decoder.py:151
+ * (`torch.argmax(cur_score, -1)`), ctc_infer.py:77 (`torch.max(prob_tensor, 2)`).  x f32 [M, V] with row stride ld.
+ * asr_log_softmax_rows: y = x - logsumexp(x) per row (decoder.py:118 `F.log_softmax(logits, -1)`).
+ * asr_ctc_greedy_reduce: the collapse of ctc_infer.py:37-46 - of the first len[b] frame labels keep those that are not `blank` and
+ * differ from the previous frame's label; out int64 [B, L] zero-padded, out_len int32 [B]. */
+int asr_argmax_rows(void* stream, const float* x, int64_t ld, int M, int V, int64_t* out);
+int asr_log_softmax_rows(void* stream, const float* x, int64_t ldx, int M, int V, float* y, int64_t ldy);
+int asr_ctc_greedy_reduce(void* stream, const int64_t* frames, const int32_t* len, int B, int L, int blank, int64_t* out, int32_t* out_len);
+
 /* ---- CIF family, training side (autograd of cif_model.py:44-48, attentionAssigner.py:37-40, conv_encoder.py:33-49) and the tape's
  * gradient bookkeeping; all f32. */
 /* dst[r, 0..cols) += src[r, 0..cols) for r < rows (row strides ldd / lds in elements): gradient accumulation where two paths join. */

@@ -8,6 +8,7 @@ Harness-side shims (they do not modify the reference):
   * transformer.decoder.pad_list -> utils.utils.pad_list(...)[0]   (decoder.py:54-56 vs utils.py:14)
   * torch.Tensor.cuda -> identity                                   (cif_model.py:47-100, decoder.py:361)
   * utils.utils.get_non_pad_mask injected for ctcModel/encoder.py:5
+  * G9 only: transformer.decoder.get_subsequent_mask -> the same mask as bool (decoder.py:101 passes uint8 to masked_fill)
   * G6/G7 only (train mode): nn.Dropout.forward draws its Bernoulli mask from the counter-based hash the product path uses
     (oracle.dropout_mask; keys from the module's qualified name) instead of torch's RNG stream - the reference's arithmetic
     under a reproducible mask.
@@ -353,6 +354,106 @@ def g7_cif_model_train():
     print("G7 qua", float(qua), "ctc", float(ctc), "ce", float(ce), "dropout sites", len(hd.sites))
 
 
+S8 = dict(d_input=80, LFR_m=1, d_model=32, n_layers_enc=1, n_head=2, d_inner=64, dropout=0.0, sos_id=2, eos_id=3, vocab_size=20,
+          n_layers_dec=1)
+
+
+def g8_checkpoint():
+    """The reference's checkpoint package (transformer.py:86-97) after two optimizer steps of its own loop shape
+    (solver.py:83-93, optimizer.py:19-29, train.py:166-170), and the parameters after a third step from that state."""
+    enc = Encoder(S8["d_input"], S8["n_layers_enc"], S8["n_head"], S8["d_model"], S8["d_inner"], dropout=0.0)
+    dec = Decoder(S8["sos_id"], S8["eos_id"], S8["vocab_size"], S8["n_layers_dec"], S8["n_head"], S8["d_model"], S8["d_inner"], dropout=0.0)
+    model = CTC_Transformer(enc, dec).eval()
+    ns, sd = load_seeded(model, seed=108)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(3, 40, 80, generator=g)
+    lens = torch.tensor([40, 33, 21])
+    tg = torch.randint(4, 19, (3, 5), generator=g)
+    tg[1, 3:] = 0
+    opt = TransformerOptimizer(torch.optim.Adam(model.parameters(), betas=(0.9, 0.98), eps=1e-9), 0.2, S8["d_model"], 4000)
+
+    def one_step():
+        l, ctc_logits, (logits, teos) = model(x, lens, tg)
+        ctc, ce = cal_ctc_ce_loss(ctc_logits, l, logits, teos, smoothing=0.1)
+        opt.zero_grad()
+        (ctc + ce).backward()
+        opt.step()
+        return float(ctc + ce)
+
+    tr = [one_step(), one_step()]
+    package = CTC_Transformer.serialize(model, opt, 2, tr_loss=torch.tensor(tr + [0.0]), cv_loss=torch.tensor([0.5, 0.4, 0.0]))
+    out = dict(names_shapes=names_shapes_to_json(ns), seed=108, x=npy(x), lens=npy(lens), targets=npy(tg), epoch=package["epoch"],
+               tr_loss=npy(package["tr_loss"]), cv_loss=npy(package["cv_loss"]),
+               sd_keys="|".join(package["state_dict"].keys()))
+    for k, v in package["state_dict"].items():
+        if not k.endswith("positional_encoding.pe"):
+            out["sd:" + k] = npy(v).copy()
+    od = package["optim_dict"]
+    pg = od["param_groups"][0]
+    out.update(opt_lr=np.float64(pg["lr"]), opt_betas=np.asarray(pg["betas"], np.float64), opt_eps=np.float64(pg["eps"]),
+               opt_weight_decay=np.float64(pg["weight_decay"]), opt_params=np.asarray(pg["params"], np.int64))
+    for i, st in od["state"].items():
+        out["opt:%d:step" % i] = np.float64(float(st["step"]))
+        out["opt:%d:exp_avg" % i] = npy(st["exp_avg"]).copy()
+        out["opt:%d:exp_avg_sq" % i] = npy(st["exp_avg_sq"]).copy()
+    # the third step continues from the package state (the reference resumes Adam's state; its Noam counter restarts - solver.py:49-59
+    # loads only optimizer.state_dict() - so the step below uses step_num = 3 of the SAME run, which is what Adam's own counter says)
+    loss3 = one_step()
+    out["lr_step3"] = np.float64(opt.optimizer.param_groups[0]["lr"])
+    out["loss3"] = np.float64(loss3)
+    for k, p in model.named_parameters():
+        out["after3:" + k] = npy(p).copy()
+    np.savez_compressed(os.path.join(HERE, "g8_checkpoint.npz"), **out, **{f"cfg_{k}": np.asarray(v) for k, v in S8.items()})
+    print("G8 losses", tr, loss3, "params", sum(p.numel() for p in model.parameters()))
+
+
+def g9_decode():
+    """Greedy decoding: Decoder.batch_decode (decoder.py:138-164) as called by Conv_CTC_Transformer.batch_recognize
+    (transformer.py:172-185), Decoder.step scores (decoder.py:98-120), and ctcModel's GreedyDecoder (ctc_infer.py:28-46,69-80)."""
+    from ctcModel.ctc_infer import GreedyDecoder
+    # harness-side shim (G9 only): Decoder.step feeds get_subsequent_mask's uint8 tensor to masked_fill (decoder.py:101, attention.py:80),
+    # which torch >= 1.12 rejects - same values as bool
+    orig_mask = tdec.get_subsequent_mask
+    tdec.get_subsequent_mask = lambda seq: orig_mask(seq).bool()
+    args = argparse.Namespace(**S0)
+    model = Conv_CTC_Transformer.create_model(args).eval()
+    ns, sd = load_seeded(model, seed=109)
+    x, lens, tg = s0_batch(seed=9)
+    with torch.no_grad():
+        conv_out, len_seq = model.conv_encoder(x, lens)
+        enc_out = model.encoder(conv_out, len_seq)
+        preds, len_decoded, _ = model.decoder.batch_decode(enc_out, len_seq, max_decode_len=12)
+        preds2, len2, _ = model.batch_recognize(x, lens, 5)          # (the third argument lands in max_decode_len)
+        prefix = torch.cat([torch.full((4, 1), S0["sos_id"], dtype=torch.long), preds[:, :3]], 1)
+        scores = model.decoder.step(prefix, enc_out, len_seq)
+        ctc_logits = model.ctc_fc(enc_out)
+        gd = GreedyDecoder(space_idx=-1, blank_index=S0["vocab_size"] - 1)
+        ctc_tokens, ctc_lens = gd.decode(ctc_logits, len_seq)
+        # rows that finish at different steps: the same decoder with <eos> re-pointed at tokens it does emit early on
+        alt = {}
+        for eos in (14, 39):
+            model.decoder.eos_id = eos
+            p_, l_, _ = model.decoder.batch_decode(enc_out, len_seq, max_decode_len=12)
+            alt["preds_eos%d" % eos], alt["len_eos%d" % eos] = npy(p_), npy(l_)
+        model.decoder.eos_id = S0["eos_id"]
+        # GreedyDecoder on logits that do collapse (repeats, blanks, ragged lengths)
+        gg = torch.Generator().manual_seed(99)
+        syn = torch.randn(5, 40, 7, generator=gg)
+        syn[:, :, 6] += 0.8                                   # blank-heavy
+        syn = syn.repeat_interleave(2, dim=1)[:, :40]         # repeated frames
+        syn_len = torch.tensor([40, 31, 17, 5, 1])
+        syn_tok, syn_tok_len = GreedyDecoder(space_idx=-1, blank_index=6).decode(syn, syn_len)
+    tdec.get_subsequent_mask = orig_mask
+    np.savez_compressed(os.path.join(HERE, "g9_decode.npz"), names_shapes=names_shapes_to_json(ns), seed=109, crc=crc_of(sd), x=npy(x),
+                        lens=npy(lens), enc_out=npy(enc_out), enc_len=npy(len_seq), preds=npy(preds), len_decoded=npy(len_decoded),
+                        preds_rec5=npy(preds2), len_rec5=npy(len2), step_prefix=npy(prefix), step_scores=npy(scores),
+                        ctc_logits=npy(ctc_logits), ctc_tokens=np.asarray(ctc_tokens), ctc_lens=np.asarray(ctc_lens), syn_logits=npy(syn),
+                        syn_len=npy(syn_len), syn_tokens=np.asarray(syn_tok), syn_tokens_len=np.asarray(syn_tok_len), **alt, **cfg_arrays())
+    print("G9 preds", preds.tolist(), len_decoded.tolist(), "ctc", np.asarray(ctc_tokens).tolist(), ctc_lens)
+    print("   eos14", alt["preds_eos14"].tolist(), alt["len_eos14"].tolist(), "eos39", alt["preds_eos39"].shape, alt["len_eos39"].tolist())
+    print("   syn", np.asarray(syn_tok).shape, syn_tok_len)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g0_conv_ctc_transformer()
@@ -363,3 +464,5 @@ if __name__ == "__main__":
     g5_ctc_model()
     g6_ctc_transformer_train()
     g7_cif_model_train()
+    g8_checkpoint()
+    g9_decode()

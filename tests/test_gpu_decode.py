@@ -1,0 +1,89 @@
+"""Greedy decoding on the device against the reference's own outputs (tests/golden/g9_decode.npz):
+Decoder.batch_decode / step (src/transformer/decoder.py:98-164), Conv_CTC_Transformer.batch_recognize (transformer.py:172-185),
+ctcModel's GreedyDecoder (ctc_infer.py:28-46,69-80)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+from weights import crc_of, make_state_dict, names_shapes_from_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def load(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g9_decode.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    assert crc_of(sd) == int(z["crc"])
+    cfg = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")}
+    model = asr_amd.Conv_CTC_Transformer.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return z, cfg, model.to(DEV).eval()
+
+
+def test_batch_decode_is_token_exact_in_f32(golden_dir):
+    z, cfg, model = load(golden_dir)
+    enc, enc_len = torch.from_numpy(z["enc_out"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV)
+    with asr_amd.precision("f32"):
+        preds, n, extra = model.decoder.batch_decode(enc, enc_len, max_decode_len=12)
+        np.testing.assert_array_equal(preds.cpu().numpy(), z["preds"])
+        np.testing.assert_array_equal(n.cpu().numpy(), z["len_decoded"])
+        assert extra.numel() == 0
+        # rows that finish at different steps (the reference's `finished` / `len_decoded` bookkeeping, decoder.py:154-161)
+        for eos in (14, 39):
+            model.decoder.eos_id = eos
+            p, l, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=12)
+            np.testing.assert_array_equal(p.cpu().numpy(), z["preds_eos%d" % eos])
+            np.testing.assert_array_equal(l.cpu().numpy(), z["len_eos%d" % eos])
+        model.decoder.eos_id = cfg["eos_id"]
+        # end to end from the features; the third argument is max_decode_len (transformer.py:183)
+        p, l, _ = model.batch_recognize(torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["lens"]).to(DEV), 5)
+        np.testing.assert_array_equal(p.cpu().numpy(), z["preds_rec5"])
+        np.testing.assert_array_equal(l.cpu().numpy(), z["len_rec5"])
+
+
+def test_step_scores_and_cached_decode_agree_with_the_full_recompute(golden_dir):
+    z, cfg, model = load(golden_dir)
+    enc, enc_len = torch.from_numpy(z["enc_out"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV)
+    with asr_amd.precision("f32"):
+        scores = model.decoder.step(torch.from_numpy(z["step_prefix"]).to(DEV), enc, enc_len)
+    np.testing.assert_allclose(scores.cpu().numpy(), z["step_scores"], atol=2e-4, rtol=1e-4)
+    # bf16 product path: the same tokens here too (the fixture's argmax margins are far above bf16 noise) and scores within tolerance
+    with asr_amd.precision("bf16"):
+        s16 = model.decoder.step(torch.from_numpy(z["step_prefix"]).to(DEV), enc, enc_len)
+        p16, n16, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=12)
+    np.testing.assert_allclose(s16.cpu().numpy(), z["step_scores"], atol=8e-2, rtol=2e-2)
+    assert (p16.cpu().numpy() == z["preds"]).mean() >= 0.9
+
+
+def test_ctc_greedy_decoder(golden_dir):
+    z, cfg, model = load(golden_dir)
+    dec = asr_amd.GreedyDecoder(space_idx=-1, blank_index=6)
+    tok, n = dec.decode(torch.from_numpy(z["syn_logits"]).to(DEV), torch.from_numpy(z["syn_len"]).to(DEV))
+    assert n == z["syn_tokens_len"].tolist()
+    np.testing.assert_array_equal(tok, z["syn_tokens"])
+    assert tok.dtype == np.int32
+    # the model's own CTC head, blank = V - 1
+    dec = asr_amd.GreedyDecoder(space_idx=-1, blank_index=cfg["vocab_size"] - 1)
+    tok, n = dec(torch.from_numpy(z["ctc_logits"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV))
+    assert n == z["ctc_lens"].tolist()
+    np.testing.assert_array_equal(tok, z["ctc_tokens"])
+
+
+def test_argmax_and_log_softmax_rows():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 4234, generator=g)
+    x[3, 100] = x[3, 4000] = 9.0          # a tie: the lower index wins (torch.argmax on CPU)
+    x[5, :] = -1.5                        # all equal
+    buf = torch.zeros(37, 4240)
+    buf[:, :4234] = x
+    got = ops.argmax_rows(buf.to(DEV)[:, :4234])
+    np.testing.assert_array_equal(got.cpu().numpy(), torch.argmax(x, -1).numpy())
+    assert int(got[3]) == 100 and int(got[5]) == 0
+    ls = ops.log_softmax_rows(buf.to(DEV)[:, :4234])
+    np.testing.assert_allclose(ls.cpu().numpy(), torch.log_softmax(x, -1).numpy(), atol=2e-5, rtol=1e-5)
