@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libasr_hip.so")
 SOURCES = ["common.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
-           "backward.hip", "fused_small.hip", "cif_train.hip", "decode.hip"]
+           "backward.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
@@ -68,6 +68,8 @@ SIGNATURES = {
     "asr_cif_scan_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "asr_cif_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "asr_assigner_tail_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "asr_lfr_stack": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "asr_spec_aug": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "asr_argmax_rows": [_vp, _vp, _i64, _i, _i, _vp],
     "asr_log_softmax_rows": [_vp, _vp, _i64, _i, _i, _vp, _i64],
     "asr_ctc_greedy_reduce": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],

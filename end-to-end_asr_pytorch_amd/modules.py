@@ -1159,12 +1159,19 @@ class Transformer(_Cached):
     def __init__(self, encoder, decoder, spec_aug_cfg=None):
         super().__init__()
         self.encoder, self.decoder, self.spec_aug_cfg = encoder, decoder, spec_aug_cfg
-        if spec_aug_cfg:
-            raise NotImplementedError("spec_aug is a train-time augmentation outside the hot path (SURVEY.md §2 row 9)")
         _xavier_all(self)
+
+    def _augment(self, features, len_features):
+        """transformer.py:28-29 / :116-117 / :142-143, cif_model.py:31-32: SpecAugment whenever a config is set (in place on the batch,
+        like the reference), on the device (data.spec_aug)."""
+        if self.spec_aug_cfg:
+            from .data import spec_aug
+            features, len_features = spec_aug(features, len_features, self.spec_aug_cfg)
+        return features, len_features
 
     def forward(self, features, len_features, padded_target):
         _assign_names(self)
+        features, len_features = self._augment(features, len_features)
         def run():
             lens = ops.as_i32(len_features, features.device)
             enc = self.encoder._impl(_act(features), lens)
@@ -1189,6 +1196,7 @@ class CTC_Transformer(Transformer):
 
     def forward(self, features, len_features, padded_target):
         _assign_names(self)
+        features, len_features = self._augment(features, len_features)
         B, L = features.shape[0], features.shape[1]
 
         def run():
@@ -1210,6 +1218,7 @@ class Conv_CTC_Transformer(CTC_Transformer):
 
     def forward(self, features, len_features, targets, spec_aug_cfg=False):
         _assign_names(self)
+        features, len_features = self._augment(features, len_features)
         def run():
             conv, len_sequence = self.conv_encoder._impl(features, len_features)
             enc = self.encoder._impl(conv, len_sequence)
@@ -1259,13 +1268,14 @@ class CIF_Model(_Cached):
         super().__init__()
         self.conv_encoder, self.encoder, self.assigner, self.decoder = conv_encoder, encoder, assigner, decoder
         self.spec_aug_cfg = spec_aug_cfg
-        if spec_aug_cfg:
-            raise NotImplementedError("spec_aug is outside the hot path")
         self.ctc_fc = nn.Linear(encoder.d_output, decoder.d_output, bias=False)
         _xavier_all(self)
 
+    _augment = Transformer._augment
+
     def forward(self, features, len_features, targets, threshold=0.95, noise=None):
         _assign_names(self)
+        features, len_features = self._augment(features, len_features)
         def run():
             ctc3d, len_sequence, _num, num, logits = self._forward_impl(features, len_features, targets, threshold, noise)
             slots = _slots(self, "ctc", self, "num", self.decoder, "prj")

@@ -293,6 +293,20 @@ int asr_assigner_tail_fwd(void* stream, const float* x, const float* w, const fl
 /* Conv1d k=w stride 1 valid + ReLU over time with implicit zero right-pad (conv_encoder.py:33-43) is expressed by
  * the caller as w_context shifted GEMMs through asr_gemm_nt; no dedicated entry point. */
 
+/* ---- input step in front of the path ----------------------------------------------------------------------
+ * asr_lfr_stack: low-frame-rate stacking of a padded batch (utils/data.py:191-218 build_LFR_features): x f32 [B,T,D], len int32 [B]
+ * -> y f32 [B, ceil(T/n), m*D] with y[b,i,j*D:(j+1)*D] = x[b, min(i*n + j, len_b - 1)] for i < ceil(len_b / n) and zeros beyond;
+ * len_out[b] = ceil(len_b / n).
+ * asr_spec_aug: utils/utils.py:168-194 in place on x f32 [B,T,V].  rand01: the uniform [0,1) draws of the reference's loop in its
+ * order, f32 [(n_freq + n_time) * 2, B]: per mask rand(B) for the width, rand(B) for the start; width = (long)(max_width * r),
+ * start = (long)((extent - width) * r) with extent = V (frequency) or len_b (time).  A frequency band takes each frame's mean over
+ * frequency, a time span the utterance's mean over time (sum over the padded T rows / len_b), both of the UNmasked features; time
+ * masks are written last.  (The reference's frequency loop runs `time_mask_num` times - utils.py:177 - so its callers pass
+ * n_freq = time_mask_num.)  fmean f32 [B,T], tsum f32 [B,V]: workspaces. */
+int asr_lfr_stack(void* stream, const float* x, const int32_t* len, int B, int T, int D, int m, int n, float* y, int32_t* len_out);
+int asr_spec_aug(void* stream, float* x, const int32_t* len, int B, int T, int V, const float* rand01, int n_freq, int freq_width,
+                 int n_time, int time_width, float* fmean, float* tsum);
+
 /* ---- greedy decoding ---------------------------------------------------------------------------------------
  * asr_argmax_rows: out[m] = argmax_v x[m, v] (ties -> lowest index, like torch.argmax / torch.max on CPU): decoder.py:151
  * (`torch.argmax(cur_score, -1)`), ctc_infer.py:77 (`torch.max(prob_tensor, 2)`).  x f32 [M, V] with row stride ld.

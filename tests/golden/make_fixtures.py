@@ -8,6 +8,7 @@ Harness-side shims (they do not modify the reference):
   * transformer.decoder.pad_list -> utils.utils.pad_list(...)[0]   (decoder.py:54-56 vs utils.py:14)
   * torch.Tensor.cuda -> identity                                   (cif_model.py:47-100, decoder.py:361)
   * utils.utils.get_non_pad_mask injected for ctcModel/encoder.py:5
+  * G10 only: an empty `kaldi_io` module so that utils.data imports (its Kaldi ark reader is not exercised)
   * G9 only: transformer.decoder.get_subsequent_mask -> the same mask as bool (decoder.py:101 passes uint8 to masked_fill)
   * G6/G7 only (train mode): nn.Dropout.forward draws its Bernoulli mask from the counter-based hash the product path uses
     (oracle.dropout_mask; keys from the module's qualified name) instead of torch's RNG stream - the reference's arithmetic
@@ -454,6 +455,60 @@ def g9_decode():
     print("   syn", np.asarray(syn_tok).shape, syn_tok_len)
 
 
+def g10_input_pipeline():
+    """LFR stacking (utils/data.py:191-218), spec_aug (utils/utils.py:168-194) and AudioDataset's batching (utils/data.py:28-110).
+    utils.data imports kaldi_io at module level (absent here; only its ark reader uses it): an empty stand-in module satisfies the
+    import - none of the three functions touches it."""
+    import json
+    import tempfile
+    import types
+    sys.modules.setdefault("kaldi_io", types.ModuleType("kaldi_io"))
+    import utils.data as ud
+    out = {}
+    g = np.random.default_rng(10)
+    for T in (1, 7, 8, 9, 100):
+        x = g.standard_normal((T, 6)).astype(np.float32)
+        out["lfr_x_T%d" % T] = x
+        for m, n in ((4, 3), (1, 2), (3, 1), (1, 1), (7, 6)):
+            out["lfr_T%d_m%d_n%d" % (T, m, n)] = ud.build_LFR_features(x, m, n)
+    # spec_aug: zero-padded batch, fixed seed (the draws are torch.rand(size=[B]) calls in a fixed order: a test replays them)
+    gt = torch.Generator().manual_seed(10)
+    B, T, V = 4, 50, 16
+    lens = torch.tensor([50, 41, 33, 20])
+    feats = torch.randn(B, T, V, generator=gt) * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    out["sa_x"] = npy(feats).copy()
+    out["sa_lens"] = npy(lens)
+    for cfg in ("2-5-2-8", "1-16-3-12", "2-3-1-4"):
+        torch.manual_seed(1010)
+        y, _ = uu.spec_aug(feats.clone(), lens, cfg)
+        out["sa_y_" + cfg] = npy(y)
+    # batching: synthetic metadata + the reference's own test/data/data.json
+    utts = {}
+    for i in range(57):
+        ilen = int(g.integers(80, 1600))
+        olen = int(g.integers(3, 60))
+        utts["utt%03d" % i] = {"input": [{"shape": [ilen, 80]}], "output": [{"shape": [olen, 4233]}]}
+    utts["utt900"] = {"input": [{"shape": [300, 80]}], "output": [{"shape": [300, 4233]}]}      # dropped: T / U < 5
+    utts["utt901"] = dict(utts["utt003"])                                                         # a tie in length
+    ref_json = json.load(open("/root/reference/test/data/data.json", "rb"))["utts"]
+    plans = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, data in (("syn", utts), ("ref", ref_json)):
+            path = os.path.join(td, name + ".json")
+            json.dump({"utts": data}, open(path, "w"))
+            for tag, kw in (("count", dict(batch_size=8, max_length_in=800, max_length_out=30)),
+                            ("frames", dict(batch_size=8, max_length_in=800, max_length_out=30, batch_frames=2000)),
+                            ("first2", dict(batch_size=5, max_length_in=400, max_length_out=150, num_batches=2))):
+                ds = ud.AudioDataset(path, **kw)
+                plans["%s_%s" % (name, tag)] = [[k for k, _ in mb] for mb in ds.minibatch]
+    out["batch_utts_syn"] = json.dumps(utts)
+    out["batch_utts_ref"] = json.dumps({k: {"input": [{"shape": v["input"][0]["shape"]}], "output": [{"shape": v["output"][0]["shape"]}]}
+                                        for k, v in ref_json.items()})
+    out["batch_plans"] = json.dumps(plans)
+    np.savez_compressed(os.path.join(HERE, "g10_input.npz"), **out)
+    print("G10 lfr cases", sum(k.startswith("lfr_T") for k in out), "plans", {k: len(v) for k, v in plans.items()})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g0_conv_ctc_transformer()
@@ -466,3 +521,4 @@ if __name__ == "__main__":
     g7_cif_model_train()
     g8_checkpoint()
     g9_decode()
+    g10_input_pipeline()
