@@ -11,9 +11,10 @@
 namespace {
 
 __global__ __launch_bounds__(256) void lfr_stack_kernel(const float* __restrict__ x, const int32_t* __restrict__ len, int T, int D, int m,
-                                                        int n, int Tl, float* __restrict__ y, int32_t* __restrict__ len_out) {
+                                                        int n, int Tl, int64_t rows, float* __restrict__ y, int32_t* __restrict__ len_out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // output row (b, i)
+    if (row >= rows) return;
     const int b = (int)(row / Tl), i = (int)(row - (int64_t)b * Tl);
     const int Tb = min(len[b], T);
     const int Tlb = (Tb + n - 1) / n;                                      // ceil(T / n) (data.py:207)
@@ -85,7 +86,7 @@ extern "C" int asr_lfr_stack(void* stream, const float* x, const int32_t* len, i
     const int Tl = (T + n - 1) / n;
     const int64_t rows = (int64_t)B * Tl;
     hipLaunchKernelGGL(lfr_stack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, len, T, D, m, n,
-                       Tl, y, len_out);
+                       Tl, rows, y, len_out);
     ASR_LAUNCH_CHECK("lfr_stack");
     return 0;
 }
