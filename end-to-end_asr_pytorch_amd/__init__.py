@@ -4,7 +4,7 @@ Host code is Python on PyTorch-ROCm (device memory, streams, torch.distributed);
 hand-written gfx950 HIP kernels behind the C-ABI of include/asr_hip.h (csrc/libasr_hip.so, loaded with ctypes).
 Import as `asr_amd` (see asr_amd.py at the repo root - the directory name is not a Python identifier).
 """
-from . import _lib, checkpoint, data, decode, modules, ops, trainer, utils  # noqa: F401
+from . import _lib, checkpoint, data, decode, mask_lm, modules, ops, trainer, utils  # noqa: F401
 from .decode import GreedyDecoder, ctc_greedy_decode  # noqa: F401
 from .trainer import Trainer  # noqa: F401
 from ._lib import build_library, lib  # noqa: F401

@@ -62,6 +62,8 @@ SIGNATURES = {
     "asr_ctc_loss_bwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64],
     "asr_ce_loss_fwd": [_vp, _vp, _i64, _vp, _i, _i, _f, _vp, _vp],
     "asr_ce_mean": [_vp, _vp, _vp, _i, _vp],
+    "asr_ce_mean_masked": [_vp, _vp, _vp, _vp, _i, _vp],
+    "asr_token_mask": [_vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp],
     "asr_ce_loss_bwd": [_vp, _vp, _i64, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _i64],
     "asr_cif_scan_fwd": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "asr_cif_gather_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],

@@ -46,13 +46,15 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     }
 }
 
-__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ targets, int N,
-                                                      float* __restrict__ out) {
+// `counted` (optional, one byte per row): the denominator counts only rows with counted[i] != 0 while the numerator still sums
+// every non-pad row - mask_lm's cal_ce_mask_loss (src/mask_lm/loss.py:24-30)
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ targets,
+                                                      const unsigned char* __restrict__ counted, int N, float* __restrict__ out) {
     float s = 0.f, n = 0.f;
     for (int i = threadIdx.x; i < N; i += 256) {
         const bool np = targets[i] != 0;
         s += np ? row_loss[i] : 0.f;
-        n += np ? 1.f : 0.f;
+        n += (np && (!counted || counted[i])) ? 1.f : 0.f;
     }
     s = wave_sum(s);
     n = wave_sum(n);
@@ -106,8 +108,16 @@ extern "C" int asr_ce_loss_fwd(void* stream, const float* logits, int64_t ldl, c
 
 extern "C" int asr_ce_mean(void* stream, const float* row_loss, const int64_t* targets, int N, float* loss) {
     ASR_REQUIRE(row_loss && targets && loss && N > 0, ASR_ERR_ARG, "ce_mean: bad args");
-    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), row_loss, targets, N, loss);
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), row_loss, targets, nullptr, N, loss);
     ASR_LAUNCH_CHECK("ce_mean");
+    return 0;
+}
+
+extern "C" int asr_ce_mean_masked(void* stream, const float* row_loss, const int64_t* targets, const unsigned char* counted, int N,
+                                  float* loss) {
+    ASR_REQUIRE(row_loss && targets && counted && loss && N > 0, ASR_ERR_ARG, "ce_mean_masked: bad args");
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), row_loss, targets, counted, N, loss);
+    ASR_LAUNCH_CHECK("ce_mean_masked");
     return 0;
 }
 

@@ -78,7 +78,32 @@ __global__ __launch_bounds__(256) void spec_aug_apply_kernel(float* __restrict__
     }
 }
 
+// mask_lm token masking (src/mask_lm/Mask_LM.py:19-41): keep[b,t] = AND_{j=0..M} (r[b,(t+j) mod T] > p) - the reference ANDs the
+// draw mask with M circular left shifts of itself, so a draw <= p blanks the M positions before it as well; masked tokens become 0.
+__global__ __launch_bounds__(256) void token_mask_kernel(const int64_t* __restrict__ ids, const float* __restrict__ r, int B, int T, float p,
+                                                         int M, int64_t* __restrict__ out, unsigned char* __restrict__ masked) {
+    const int64_t total = (int64_t)B * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / T), t = (int)(i - (int64_t)b * T);
+        bool keep = true;
+        for (int j = 0; j <= M; ++j) keep = keep && (r[(int64_t)b * T + (t + j) % T] > p);
+        out[i] = keep ? ids[i] : 0;
+        masked[i] = keep ? 0 : 1;
+    }
+}
+
 }  // namespace
+
+extern "C" int asr_token_mask(void* stream, const int64_t* ids, const float* rand01, int B, int T, float p, int M, int64_t* out,
+                              unsigned char* masked) {
+    ASR_REQUIRE(ids && rand01 && out && masked && B > 0 && T > 0 && M >= 0, ASR_ERR_ARG, "token_mask: bad args");
+    int64_t blocks = ((int64_t)B * T + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(token_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ids, rand01, B, T, p, M, out,
+                       masked);
+    ASR_LAUNCH_CHECK("token_mask");
+    return 0;
+}
 
 extern "C" int asr_lfr_stack(void* stream, const float* x, const int32_t* len, int B, int T, int D, int m, int n, float* y,
                              int32_t* len_out) {

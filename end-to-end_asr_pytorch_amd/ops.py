@@ -435,6 +435,35 @@ def ce_loss_fwd(logits2d, targets1d, smoothing):
     return loss, row_loss, lse, targets1d
 
 
+def ce_mask_loss_fwd(logits2d, targets1d, counted1d, smoothing):
+    """mask_lm's cal_ce_mask_loss: like ce_loss_fwd, the denominator counting only rows with counted != 0 (bool / uint8 [N])."""
+    _req_cuda(logits2d, targets1d, counted1d)
+    N, V = logits2d.shape
+    assert logits2d.stride(1) == 1 and logits2d.dtype == torch.float32
+    targets1d = targets1d.to(torch.int64).contiguous()
+    counted = counted1d.to(torch.uint8).contiguous()
+    row_loss = torch.empty(N, device=logits2d.device, dtype=torch.float32)
+    lse = torch.empty(N, device=logits2d.device, dtype=torch.float32)
+    check(lib().asr_ce_loss_fwd(_stream(), _p(logits2d), logits2d.stride(0), _p(targets1d), N, V, float(smoothing), _p(row_loss),
+                                _p(lse)), "asr_ce_loss_fwd")
+    loss = torch.empty(2, device=logits2d.device, dtype=torch.float32)
+    check(lib().asr_ce_mean_masked(_stream(), _p(row_loss), _p(targets1d), _p(counted), N, _p(loss)), "asr_ce_mean_masked")
+    return loss, row_loss, lse, targets1d
+
+
+def token_mask(ids, rand01, p=0.05, M=10):
+    """Mask_LM.token_mask: -> (masked ids int64 [B,T], masked positions bool [B,T])"""
+    _req_cuda(ids, rand01)
+    ids = ids.to(torch.int64).contiguous()
+    B, T = ids.shape
+    rand01 = rand01.to(device=ids.device, dtype=torch.float32).contiguous()
+    assert rand01.shape == (B, T)
+    out = torch.empty_like(ids)
+    masked = torch.empty((B, T), device=ids.device, dtype=torch.uint8)
+    check(lib().asr_token_mask(_stream(), _p(ids), _p(rand01), B, T, float(p), int(M), _p(out), _p(masked)), "asr_token_mask")
+    return out, masked.bool()
+
+
 def ce_loss_bwd(logits2d, targets1d, smoothing, lse, loss2, gout, bf16=False):
     """bf16=True: the trainer's gradient image (see ctc_loss_bwd)."""
     N, V = logits2d.shape

@@ -267,6 +267,14 @@ int asr_ce_loss_fwd(void* stream, const float* logits, int64_t ldl, const int64_
 int asr_ce_mean(void* stream, const float* row_loss, const int64_t* targets, int N, float* loss);
 int asr_ce_loss_bwd(void* stream, const float* logits, int64_t ldl, const int64_t* targets, int N, int V,
                     float smoothing, const float* lse, const float* n_word, const float* gout, void* grad, int grad_dtype, int64_t ldg);
+/* mask_lm's cal_ce_mask_loss (src/mask_lm/loss.py:5-32): loss[0] = sum over non-pad rows of row_loss / n_word with
+ * loss[1] = n_word = count(target != 0 AND counted != 0) - the reference sums every non-pad row but counts only the masked ones.
+ * counted: one byte per row.  The backward is asr_ce_loss_bwd with n_word = &loss[1]. */
+int asr_ce_mean_masked(void* stream, const float* row_loss, const int64_t* targets, const unsigned char* counted, int N, float* loss);
+/* mask_lm token masking (src/mask_lm/Mask_LM.py:19-41): ids int64 [B,T], rand01 f32 [B,T] (the reference's torch.rand((B,T))):
+ * position t is kept iff rand01[b,(t+j) mod T] > p for every j in 0..M; out = kept ? ids : 0, masked (one byte) = !kept. */
+int asr_token_mask(void* stream, const int64_t* ids, const float* rand01, int B, int T, float p, int M, int64_t* out,
+                   unsigned char* masked);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CIF (cif_model.py:57-106).  asr_cif_scan_fwd runs the integrate-and-fire recurrence in the reference's exact fp32

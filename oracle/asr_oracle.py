@@ -575,6 +575,98 @@ def ctc_model_forward(sd, padded_input, input_lengths, cfg):
 
 
 # --------------------------------------------------------------------------------------
+# decoding helpers, input step, mask_lm  
+# --------------------------------------------------------------------------------------
+def ctc_greedy(frame_tokens, lengths, blank):
+    """src/ctcModel/ctc_infer.py:37-46 - keep a frame label that is not blank and differs from the previous frame's label."""
+    out = []
+    for row, n in zip(np.asarray(frame_tokens), np.asarray(lengths)):
+        keep, prev = [], None
+        for tok in row[:int(n)]:
+            if tok != blank and tok != prev:
+                keep.append(int(tok))
+            prev = tok
+        out.append(keep)
+    return out
+
+
+def lfr(inputs, m, n):
+    """src/utils/data.py:191-218 - stack m frames every n frames; the last frame repeats past the end."""
+    T = len(inputs)
+    rows = []
+    for i in range(int(np.ceil(T / n))):
+        rows.append(np.concatenate([inputs[min(i * n + j, T - 1)] for j in range(m)]))
+    return np.stack(rows)
+
+
+def spec_aug(x, lengths, config, rand):
+    """src/utils/utils.py:168-194 with the uniform draws handed in (rand [(loops * 2) * 2, B] in the reference's call order).
+    Both loops run time_mask_num times (utils.py:177, :186); means come from the unmasked features."""
+    _, fw, tn, tw = (int(v) for v in config.split("-"))
+    x = np.array(x, dtype=F32)
+    B, T, V = x.shape
+    fmean = x.mean(-1, dtype=F32)
+    tmean = (x.sum(1, dtype=F32) / np.asarray(lengths, dtype=F32)[:, None]).astype(F32)
+    r = np.asarray(rand, dtype=F32)
+    for k in range(tn):
+        fs = (F32(fw) * r[2 * k]).astype(np.int64)
+        f0 = ((V - fs).astype(F32) * r[2 * k + 1]).astype(np.int64)
+        for b in range(B):
+            x[b, :, f0[b]:f0[b] + fs[b]] = fmean[b][:, None]
+    for k in range(tn):
+        ts = (F32(tw) * r[2 * (tn + k)]).astype(np.int64)
+        t0 = ((np.asarray(lengths) - ts).astype(F32) * r[2 * (tn + k) + 1]).astype(np.int64)
+        for b in range(B):
+            x[b, t0[b]:t0[b] + ts[b], :] = tmean[b][None, :]
+    return x
+
+
+def token_mask(ids, rand, p=0.05, M=10):
+    """src/mask_lm/Mask_LM.py:19-41 - the keep mask ANDed with M circular left shifts of itself; masked ids become 0.
+    -> (masked ids, masked positions)"""
+    keep = np.asarray(rand, dtype=F32) > F32(p)
+    shifted = keep.copy()
+    for _ in range(M):
+        shifted = np.concatenate([shifted[:, 1:], shifted[:, :1]], 1)
+        keep = keep & shifted
+    return np.where(keep, ids, 0), ~keep
+
+
+def cal_ce_mask_loss(logits, targets, mask, smoothing=0.0):
+    """src/mask_lm/loss.py:5-32 - the smoothed CE of every non-pad row summed, divided by the count of masked non-pad rows."""
+    V = logits.shape[-1]
+    lg = logits.reshape(-1, V).astype(F32)
+    tg = np.asarray(targets).reshape(-1).astype(np.int64)
+    lp = log_softmax(lg)
+    eps = F32(smoothing)
+    one_hot = np.zeros_like(lg)
+    one_hot[np.arange(len(tg)), tg] = 1
+    one_hot = one_hot * (1 - eps) + (1 - one_hot) * eps / F32(V)
+    loss = -(one_hot * lp).sum(1, dtype=F32)
+    non_pad = tg != 0
+    n_word = int((non_pad & np.asarray(mask).reshape(-1)).sum())
+    return F32(loss[non_pad].sum(dtype=F32) / F32(n_word))
+
+
+def mask_lm_forward(sd, ids, lengths, n_layers, n_head, with_decoder=False):
+    """src/mask_lm/Mask_LM.py:43-63 after the masking: encoder (mask_lm/encoder.py:33-58: LN(Embedding) + PE, EncoderLayer stack),
+    fc, optionally the masked projection of mask_lm/decoder.py:19-38.  -> (logits_AE, logits or None)"""
+    pfx = "encoder."
+    non_pad_mask = sequence_mask(lengths)[:, :, None]
+    L = ids.shape[1]
+    slf_mask = get_attn_pad_mask(lengths, L)
+    x = layer_norm(sd[pfx + "token_emb.weight"][ids], sd[pfx + "layer_norm_in.weight"], sd[pfx + "layer_norm_in.bias"])
+    x = _drop((x + positional_encoding(L, x.shape[-1])[None]).astype(F32), pfx + "dropout")
+    for i in range(n_layers):
+        x = encoder_layer(sd, f"{pfx}layer_stack.{i}.", x, non_pad_mask, slf_mask, n_head)
+    logits_AE = linear(x, sd["fc.weight"])
+    logits = None
+    if with_decoder:
+        logits = linear(x, sd["decoder.tgt_word_prj.weight"]) * sequence_mask(lengths)[:, :, None]
+    return logits_AE, logits
+
+
+# --------------------------------------------------------------------------------------
 # harness semantics (SURVEY §8a row 19)
 # --------------------------------------------------------------------------------------
 def noam_lr(step, k, d_model, warmup):

@@ -509,6 +509,46 @@ def g10_input_pipeline():
     print("G10 lfr cases", sum(k.startswith("lfr_T") for k in out), "plans", {k: len(v) for k, v in plans.items()})
 
 
+def g11_mask_lm():
+    """mask_lm (src/mask_lm/Mask_LM.py:19-63, loss.py:5-45, the two solver steps solver.py:85-114 / :218-246): pre-training
+    forward with token masking + masked CE, fine-tuning forward + CTC, and the gradients of both."""
+    from mask_lm.Mask_LM import Mask_LM
+    from mask_lm.encoder import Encoder as MEncoder
+    from mask_lm.decoder import Decoder as MDecoder
+    from mask_lm.loss import cal_ce_mask_loss, cal_ctc_loss
+    n_src, n_tgt, d = 30, 12, 64
+    model = Mask_LM(MEncoder(n_src, 2, 2, d, 128, dropout=0.0), MDecoder(n_tgt, d)).eval()
+    ns, sd = load_seeded(model, seed=111)
+    g = torch.Generator().manual_seed(11)
+    B, T = 3, 60
+    lens = torch.tensor([60, 47, 31])
+    ids = torch.randint(1, n_src, (B, T), generator=g) * (torch.arange(T)[None, :] < lens[:, None])
+    torch.manual_seed(1111)                                   # token_mask draws torch.rand((B, T)) from the global generator
+    logits_AE, _, mask = model(ids, lens)
+    ce = cal_ce_mask_loss(logits_AE, ids, mask, smoothing=0.1)
+    model.zero_grad()
+    ce.backward()
+    grads_pre = {k: npy(p.grad).copy() for k, p in model.named_parameters() if p.grad is not None}
+    torch.manual_seed(1111)
+    masked_ids, _ = model.token_mask(ids)
+    ys = torch.randint(1, n_tgt - 1, (B, 5), generator=g)
+    ys[2, 3:] = 0
+    model.zero_grad()
+    _, logits, none = model(ids, lens, padded_target=ys, mask_input=False)
+    ctc = cal_ctc_loss(logits, lens, ys)
+    ctc.backward()
+    grads_ft = {k: npy(p.grad).copy() for k, p in model.named_parameters() if p.grad is not None}
+    out = dict(names_shapes=names_shapes_to_json(ns), seed=111, crc=crc_of(sd), ids=npy(ids), lens=npy(lens), masked_ids=npy(masked_ids),
+               masked_index=npy(mask), logits_AE=npy(logits_AE), ce_mask_loss=npy(ce), ys=npy(ys), logits=npy(logits), ctc_loss=npy(ctc),
+               n_src=n_src, n_tgt=n_tgt, d_model=d)
+    for k, v in grads_pre.items():
+        out["gpre:" + k] = v
+    for k, v in grads_ft.items():
+        out["gft:" + k] = v
+    np.savez_compressed(os.path.join(HERE, "g11_mask_lm.npz"), **out)
+    print("G11 ce", float(ce), "ctc", float(ctc), "masked", int(mask.sum()), "of", B * T, "none is", none)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g0_conv_ctc_transformer()
@@ -522,3 +562,4 @@ if __name__ == "__main__":
     g8_checkpoint()
     g9_decode()
     g10_input_pipeline()
+    g11_mask_lm()
