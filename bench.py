@@ -44,8 +44,10 @@ def parse_args():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--model", default="s1", choices=["s1", "s2"],
                     help="s1: CTC_Transformer on raw fbank (BASELINE configs[1]); s2: Conv_CTC_Transformer (configs[2], L = T/4)")
-    ap.add_argument("--mode", default="train", choices=["train", "fwd"],
-                    help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only")
+    ap.add_argument("--mode", default="train", choices=["train", "fwd", "decode"],
+                    help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only; "
+                         "decode: eval-mode encoder + greedy batch_decode (KV-cached, --decode-len steps) + CTC greedy decode")
+    ap.add_argument("--decode-len", type=int, default=50, help="max_decode_len of --mode decode (decoder.py:138)")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="dropout rate of the training step (0.1 = every shipped config of the reference, egs/*/conf); ignored by --mode fwd")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("ASR_AMD_GRAPH", "0")),
@@ -280,6 +282,18 @@ def main():
             if use_graph:
                 return trainer.step_graphed(x, lens, tg, max_target_len=CFG["U"])
             return trainer.step(x, lens, tg, max_target_len=CFG["U"])   # the loader knows its target lengths: no host sync in the step
+        if args.mode == "decode":
+            with torch.no_grad():
+                from asr_amd.modules import _act
+                if CFG["n_conv_layers"]:
+                    conv, l = model.conv_encoder._impl(x, lens)
+                    enc = model.encoder._impl(conv, l)
+                else:
+                    l = ops.as_i32(lens, dev)
+                    enc = model.encoder._impl(_act(x), l)
+                preds, n_dec, _ = model.decoder.batch_decode(enc.view3(), l, args.decode_len)
+                toks, n_ctc = asr_amd.ctc_greedy_decode(model._ctc_logits(enc).view(enc.B, enc.L, -1), l)
+            return n_dec.float().mean(), n_ctc.float().mean()
         with torch.no_grad():
             out = model(x, lens, tg)
             if CFG["n_conv_layers"]:
@@ -366,7 +380,8 @@ def main():
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
         what = ("training step (train mode, dropout %g): forward + joint CTC/CE loss + backward + grad all-reduce + Adam" % args.dropout
-                if train else "eval-mode forward + joint CTC/CE loss")
+                if train else ("eval-mode encoder + greedy batch_decode (%d steps, KV cache) + CTC greedy decode" % args.decode_len
+                               if args.mode == "decode" else "eval-mode forward + joint CTC/CE loss"))
         mname = ("S2: Conv_CTC_Transformer (2 conv layers, L=%d)" % (CFG["T"] // 4)) if CFG["n_conv_layers"] else "S1: CTC_Transformer"
         Lc = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
         result = {
@@ -391,7 +406,7 @@ def main():
                                  "achieved": round(f["work"] / (f["ms"] * 1e-3) / (1e9 if f["hbm"] else 1e12), 1) if f["work"] else None,
                                  "unit": "GB/s" if f["hbm"] else "TFLOP/s"} for n, f in fams.items()), key=lambda d: -d["ms_per_step"])[:8],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode != "decode":
             result["cpu_baseline"] = cpu_baseline(model, x, lens, tg, args.dropout, train)
             # sanity: the GPU result on the same utterances agrees with the numpy oracle (bf16 tolerance); not timed
             result["parity_vs_oracle_max_abs"] = oracle_parity(asr_amd, model, x, lens, tg, n_utt=2)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "asr_conv_col2im_relu": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],
     "asr_ctc_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "asr_ctc_counter_words": [_i, _i, _i],
     "asr_ctc_mean": [_vp, _vp, _vp, _i, _vp],
     "asr_ctc_loss_bwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64],
     "asr_ce_loss_fwd": [_vp, _vp, _i64, _vp, _i, _i, _f, _vp, _vp],
@@ -145,6 +146,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         L.asr_attention_dropmask_words.restype = ctypes.c_int64
+        L.asr_ctc_counter_words.restype = ctypes.c_int64
         L.asr_last_error.restype = ctypes.c_char_p
         L.asr_version.restype = ctypes.c_int
         _lib = L

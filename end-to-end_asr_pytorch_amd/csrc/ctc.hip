@@ -834,15 +834,28 @@ int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, 
 
 extern "C" int asr_ctc_workspace_stride(int Umax) { return ctc_row_stride(Umax); }
 
+// chunk geometry of the fused forward (shared by asr_ctc_loss_fwd and asr_ctc_counter_words)
+static inline void ctc_chunking(int L, int n_chunks, int& W, int& nc) {
+    const int steps = L / 2 + 1;                           // alpha takes mid + 1 <= L/2 + 1 steps, beta at most as many
+    W = ((steps + n_chunks - 1) / n_chunks + 7) / 8 * 8;   // (a multiple of every rows-per-workgroup choice, and even)
+    nc = (steps + W - 1) / W;
+}
+
+extern "C" int64_t asr_ctc_counter_words(int B, int L, int n_chunks) {
+    if (n_chunks <= 1 || L < 64 || B <= 0) return 0;
+    int W, nc;
+    ctc_chunking(L, n_chunks, W, nc);
+    return (int64_t)B * 2 * nc;
+}
+
 extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                 int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
-                                int32_t* tgt_len, void* aux_stream, int n_chunks) {
+                                int32_t* tgt_len, void* zero_counters, int n_chunks) {
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len, ASR_ERR_ARG, "ctc_fwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && blank >= 0 && blank < V && ldl >= V, ASR_ERR_ARG, "ctc_fwd: bad sizes");
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (U+1 must be <= 512)", Umax);
     ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd: workspaces must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    (void)aux_stream;                                  // (kept in the signature; the fused form needs no second stream)
     if (n_chunks <= 1 || L < 64 || ctc_np(Umax) != 1) {   // two launches: one pass over the logits, then the two half-length chains
                                                           // (the fused form is written for one state pair per lane: U + 1 <= 64)
         hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
@@ -858,14 +871,17 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     static const int rpb = [] { const char* e = getenv("ASR_AMD_CTC_RPB"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : (v == 2 ? 2 : 4); }();
     static const int ringp = [] { const char* e = getenv("ASR_AMD_CTC_RING"); return e ? atoi(e) : 8; }();
     static const int dbg = [] { const char* e = getenv("ASR_AMD_CTC_DBG"); return e ? atoi(e) : 0; }();
-    const int steps = L / 2 + 1;                           // alpha takes mid + 1 <= L/2 + 1 steps, beta at most as many
-    const int W = ((steps + n_chunks - 1) / n_chunks + 7) / 8 * 8;      // (a multiple of every rows-per-workgroup choice, and even)
-    const int nc = (steps + W - 1) / W;
+    int W, nc;
+    ctc_chunking(L, n_chunks, W, nc);
     const int Sp = ctc_row_stride(Umax);
     ASR_REQUIRE(2 * nc <= Sp, ASR_ERR_UNSUPPORTED, "ctc_fwd: too many chunks (%d) for the counter row", nc);
-    int* arrivals = reinterpret_cast<int*>(alpha + (int64_t)(L + 1) * Sp);
-    const int64_t arr_stride = (int64_t)(L + 2) * Sp;
-    {
+    // arrival counters: 2 * nc words per utterance - in a caller-zeroed buffer when one is handed in (the trainer's per-step zero
+    // arena: no memset node in front of the launch), else in row L + 1 of the alpha workspace, zeroed here
+    int* arrivals = reinterpret_cast<int*>(zero_counters);
+    int64_t arr_stride = 2 * nc;
+    if (!arrivals) {
+        arrivals = reinterpret_cast<int*>(alpha + (int64_t)(L + 1) * Sp);
+        arr_stride = (int64_t)(L + 2) * Sp;
         hipError_t e__ = hipMemset2DAsync(arrivals, (size_t)arr_stride * sizeof(float), 0, (size_t)2 * nc * sizeof(int), B, s);
         if (e__ != hipSuccess) {
             asr_set_error("ctc_loss_fwd: %s", hipGetErrorString(e__));

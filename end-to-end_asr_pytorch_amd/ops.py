@@ -386,10 +386,18 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None):
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
     nck = CTC_CHUNKS if n_chunks is None else n_chunks
+    # arrival counters of the fused form from the step's zero arena when one is live (no memset node in front of the launch)
+    counters = None
+    nwords = int(lib().asr_ctc_counter_words(B, L, nck)) if (_ARENA["live"] and _ARENA["buf"].device == dev and Umax + 1 <= 64) else 0
+    if nwords:
+        off = (_ARENA["off"] + 63) // 64 * 64
+        if off + nwords <= _ARENA["buf"].numel():
+            _ARENA["off"] = _ARENA["dirty"] = off + nwords
+            counters = _ARENA["buf"][off:off + nwords]
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
         check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
                                      _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len),
-                                     None, nck), "asr_ctc_loss_fwd")
+                                     _p(counters), nck), "asr_ctc_loss_fwd")
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
     return loss, st.nll, st

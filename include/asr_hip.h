@@ -238,13 +238,16 @@ int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y,
  * walk the logits chunk-major (frames cut outside-in into n_chunks pieces per direction), publish the table rows (write-through
  * stores + per-chunk arrival counters kept in the alpha workspace) and the two recursion wavefronts of every utterance, resident
  * in the same grid, consume each piece as it arrives through an LDS ring: the HBM-bound pass and the latency-bound alpha / beta
- * recursion overlap.  <= 1: two launches (pass, then recursion).  Results are bit-identical.  aux_stream is unused (kept for ABI
- * stability with round 1's two-stream form); pass NULL.
+ * recursion overlap.  <= 1: two launches (pass, then recursion).  Results are bit-identical.
+ * zero_counters: NULL, or an int32 buffer of asr_ctc_counter_words(B, L, n_chunks) words that the CALLER has zeroed (e.g. a slice
+ * of a per-step zero arena): the arrival counters then live there and the call queues no memset in front of its launch.
  */
 int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
-                     int32_t* tgt_len, void* aux_stream, int n_chunks);
+                     int32_t* tgt_len, void* zero_counters, int n_chunks);
+/* number of 32-bit words of the optional caller-zeroed counter buffer of the fused forward (0: the call would not take the fused form) */
+int64_t asr_ctc_counter_words(int B, int L, int n_chunks);
 /* mean_b(nll_b / max(tgt_len_b,1))  — reduction='mean' of F.ctc_loss.  loss: f32 [1]. */
 int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_len, int B, float* loss);
 /* Gradient wrt logits of gout * mean-reduced loss: g[b,t,v] = gout/(B*max(tgt_len_b,1)) * (softmax - occupancy),

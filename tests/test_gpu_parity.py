@@ -356,6 +356,25 @@ def test_ctc_fused_forward_repeated_calls_under_load():
     torch.cuda.synchronize()
 
 
+def test_ctc_fused_forward_counters_from_the_zero_arena():
+    """under the trainer the fused forward's arrival counters are a slice of the step's zero arena (no memset node): same bits"""
+    B, L, U, V = 6, 200, 11, 77
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(B, L, V, generator=g).to(DEV)
+    tg = torch.randint(1, V - 1, (B, U), generator=g).to(DEV)
+    il = torch.tensor([200, 180, 64, 33, 2, 1]).to(DEV)
+    l1, n1, _ = ops.ctc_loss_fwd(logits, il, tg, n_chunks=1)
+    for rep in range(3):
+        ops.arena_reset(DEV)
+        try:
+            used = ops._ARENA["off"]
+            l2, n2, _ = ops.ctc_loss_fwd(logits, il, tg, n_chunks=7)
+            assert ops._ARENA["off"] > used                      # a slice was taken
+        finally:
+            ops.arena_release()
+        np.testing.assert_array_equal(N(n1), N(n2))
+
+
 def test_ctc_strided_logits_rows():
     # logits living in a padded buffer (row stride > V) are consumed in place
     B, L, V, U = 2, 30, 50, 5
