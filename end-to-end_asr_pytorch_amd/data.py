@@ -105,3 +105,15 @@ def make_minibatches(utts, batch_size, max_length_in, max_length_out, num_batche
     cuts = _cut_by_frames(ordered, batch_frames) if batch_frames > 0 else _cut_by_count(ordered, batch_size, max_length_in, max_length_out)
     batches = list(cuts)
     return batches[:num_batches] if num_batches > 0 else batches
+
+
+def shard_by_length(lengths, world):
+    """Utterance indices per data-parallel rank with similar total frames: longest first, dealt in a snake
+    (0..N-1, N-1..0, ...) so that no rank collects all the long ones; every rank gets the same count when len(lengths) % world == 0
+    (the trainer's exact global-batch mean assumes equal counts).  -> list of `world` index lists."""
+    order = sorted(range(len(lengths)), key=lambda i: -int(lengths[i]))
+    shards = [[] for _ in range(world)]
+    for pos, idx in enumerate(order):
+        lap, slot = divmod(pos, world)
+        shards[slot if lap % 2 == 0 else world - 1 - slot].append(idx)
+    return shards

@@ -37,3 +37,14 @@ def test_minibatch_plans_match_reference(golden_dir):
     assert "utt900" not in flat
     if "utt003" in flat:
         assert flat.index("utt003") + 1 == flat.index("utt901")
+
+
+def test_shard_by_length_balances_frames():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(100, 1600, 256).tolist()
+    shards = data.shard_by_length(lens, 8)
+    assert sorted(i for s in shards for i in s) == list(range(256)) and all(len(s) == 32 for s in shards)
+    totals = [sum(lens[i] for i in s) for s in shards]
+    assert (max(totals) - min(totals)) / np.mean(totals) < 0.02          # contiguous slices of the sorted list would differ by > 2x
+    naive = [sum(sorted(lens, reverse=True)[r * 32:(r + 1) * 32]) for r in range(8)]
+    assert max(naive) / min(naive) > 2

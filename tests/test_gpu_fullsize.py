@@ -125,3 +125,26 @@ def test_model_full_size_utterances_do_not_interact():
         # the last bf16 bit of a few activations, varies from launch to launch - independence holds to that noise, not bit for bit
         assert torch.allclose(dec0[b], dec1[b], rtol=2e-2, atol=2e-2)
     assert not torch.equal(ctc0[5], ctc1[5]) and not torch.allclose(dec0[5], dec1[5], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("which", ["s1", "s2"])
+def test_full_size_logits_match_the_oracle_on_two_utterances(which):
+    """The benchmark models at their full dimensions (d256/h4/enc12/dec6, V=4234, T=1000; S2 = with the conv front end, L=250)
+    against the numpy oracle on 2 utterances of the benchmark batch - the check bench.py prints as `parity_vs_oracle_max_abs`,
+    asserted: bf16 MFMA operands vs the fp32 oracle, logits |error| <= 6e-2 (logit scale ~1; measured 1-2e-2)."""
+    import bench
+    old = dict(bench.CFG)
+    try:
+        bench.CFG["n_conv_layers"] = 2 if which == "s2" else 0
+        asr_amd.set_precision("bf16")
+        model = bench.build_model(asr_amd, torch.device(DEV), 0.1, train=False)
+        x, lens, tg = bench.make_batch(torch.device(DEV), seed=0, ragged=True)
+        # (max(lens) must equal the padded length - SURVEY §7, utils.py:126-127 - for the 2-utterance slice too)
+        lens[:2] = torch.tensor([bench.CFG["T"], bench.CFG["T"] - 137], device=DEV)
+        x[1, bench.CFG["T"] - 137:] = 0
+        par = bench.oracle_parity(asr_amd, model, x, lens, tg, n_utt=2)
+    finally:
+        bench.CFG.clear()
+        bench.CFG.update(old)
+    assert par["utterances"] == 2
+    assert par["ctc_logits"] <= 6e-2 and par["logits"] <= 6e-2, par
