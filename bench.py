@@ -50,10 +50,11 @@ def parse_args():
     ap.add_argument("--decode-len", type=int, default=50, help="max_decode_len of --mode decode (decoder.py:138)")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="dropout rate of the training step (0.1 = every shipped config of the reference, egs/*/conf); ignored by --mode fwd")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("ASR_AMD_GRAPH", "0")),
-                    help="1: replay the fixed-shape training step from a captured HIP graph; 0 (default): eager launches on the trainer's "
-                         "four streams - measured faster on ROCm 7.2 (13.7 vs 15.1 ms: the replay does not overlap the graph's branches "
-                         "the way the streams do)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("ASR_AMD_GRAPH", "-1")),
+                    help="launch mode of the fixed-shape training step.  -1 (default): Trainer.step_auto times a few eager steps against "
+                         "a few replays of the captured HIP graph during initialisation and keeps the faster (S1: eager, the four "
+                         "free-running streams overlap better than the graph's branches, 13.5 vs 15.1 ms; S2: graph, the 10-30 us "
+                         "kernels of L = 250 are launch-bound, 8.1 vs 12.4 ms); 1: always replay; 0: always eager")
     ap.add_argument("--ragged", action="store_true", help="per-utterance lengths U{T/2..T} (max forced to T) and targets U{U/2..U}")
     return ap.parse_args()
 
@@ -275,12 +276,15 @@ def main():
     x, lens, tg = make_batch(dev, seed=rank, ragged=args.ragged)
 
     trainer = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1) if train else None
-    use_graph = bool(args.graph) and trainer is not None
+    use_graph = args.graph == 1 and trainer is not None
+    auto_graph = args.graph < 0 and trainer is not None
 
     def step():
         if trainer is not None:
             if use_graph:
                 return trainer.step_graphed(x, lens, tg, max_target_len=CFG["U"])
+            if auto_graph:
+                return trainer.step_auto(x, lens, tg, max_target_len=CFG["U"])
             return trainer.step(x, lens, tg, max_target_len=CFG["U"])   # the loader knows its target lengths: no host sync in the step
         if args.mode == "decode":
             with torch.no_grad():
@@ -309,7 +313,7 @@ def main():
 
     # initialisation, before the W warmup steps of the contract: the first steps of a process grow the caching allocator's pools,
     # load code objects, create the side streams / event pool, capture the step's HIP graph and (N > 1) set up the RCCL communicators
-    for _ in range(3):
+    for _ in range(3):       # (with --graph -1 the first of these also runs step_auto's calibration: 2 + 4 eager steps, capture, 4 replays)
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -328,13 +332,14 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    graphed = bool(trainer is not None and use_graph and trainer.graph_active())
+    graphed = bool(trainer is not None and trainer.graph_active() and (use_graph or (auto_graph and trainer.launch_mode == "graph")))
+    launch_timing = trainer.launch_timing if trainer is not None else None
     losses = [float(v) for v in out]
 
     # ---- live per-kernel timing over a second, identical run of the timed region (events add launch overhead, so the
     # headline value above is measured without them; eager launches, one stream: per-op durations are then uncontended) ----
     if trainer is not None:
-        use_graph = False
+        use_graph = auto_graph = False
         trainer.wgrad_stream = False
         trainer.overlap_ctc = False
     ops.profile_start()
@@ -392,7 +397,8 @@ def main():
             "config": {"workload": "%s d_model=256 h=4 d_inner=2048 enc12/dec6 V=4234, per-GPU B=32 x T=1000 x 80 "
                                    "fbank%s, U=50, %s" % (mname, " (ragged lengths)" if args.ragged else "", what),
                        "global_batch": world * CFG["B"], "seq_len": CFG["T"], "parallelism": "dp%d" % world,
-                       "launch": "hip-graph replay" if graphed else "eager"},
+                       "launch": "hip-graph replay" if graphed else "eager",
+                       "launch_calibration_ms": launch_timing},
             "losses_last_step": losses,
             "roofline": roofline,
             "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "fwd_GBps": ctc_k[0]["achieved"],

@@ -181,6 +181,7 @@ class Trainer:
             self.fp.sync_shadow()
         self._graph, self._graph_key, self._graph_out, self._graph_failed, self._eager_steps = None, None, None, None, 0
         self._state, self._state_step = None, -1
+        self.launch_mode, self.launch_timing = None, None      # step_auto's choice ("eager" | "graph") and what it measured
         self._nw_handle = None
         self._hook_shadow_sync()
 
@@ -431,6 +432,48 @@ class Trainer:
         self._state_step = self.step_num
         modules.bump_param_epoch()
         return self._graph_out
+
+    def step_auto(self, feats, lens, targets, noise=None, max_target_len=None, trials=4):
+        """`step` that picks its own launch mode for a fixed-shape loader.  Which one wins depends on the workload: with long
+        utterances (S1, L = 1000) the step is GPU-bound and the eager launches on four free-running streams overlap better than
+        the replayed graph's branches (13.5 vs 15.1 ms); with the conv front end (S2, L = 250) the kernels are 10-30 us, the host
+        cannot queue them fast enough and the replay wins (8.1 vs 12.4 ms).  The first calls are the calibration - `trials` eager
+        steps, capture, `trials` replays, all of them real training steps - and every later call uses the faster mode
+        (`self.launch_mode`, timings in `self.launch_timing`)."""
+        if self.launch_mode is None:
+            if not self._graph_ok(feats, max_target_len):
+                self.launch_mode = "eager"
+            else:
+                return self._calibrate(feats, lens, targets, noise, max_target_len, trials)
+        if self.launch_mode == "graph":
+            return self.step_graphed(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+        return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+
+    def _calibrate(self, feats, lens, targets, noise, max_target_len, trials):
+        import time
+        dev = feats.device
+
+        def timed(fn):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(trials):
+                out = fn(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / trials * 1e3, out
+        for _ in range(2):                               # pools, code objects, side streams
+            self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+        t_eager, out = timed(self.step)
+        self._eager_steps = 2
+        out = self.step_graphed(feats, lens, targets, noise=noise, max_target_len=max_target_len)      # captures and replays once
+        if not self.graph_active():
+            self.launch_mode, self.launch_timing = "eager", {"eager_ms": round(t_eager, 3), "graph_ms": None}
+            return out
+        t_graph, out = timed(self.step_graphed)
+        self.launch_mode = "graph" if t_graph < t_eager else "eager"
+        self.launch_timing = {"eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3)}
+        if self.launch_mode == "eager":
+            self._graph = None                           # frees the graph's private pool
+        return out
 
     def _capture(self, feats, lens, targets, noise, max_target_len, key):
         dev = feats.device

@@ -99,3 +99,28 @@ def test_dropout_salt_resolves_like_the_header_says():
     r1 = k1 ^ lowbias32((12345 + 0x27d4eb2f) & 0xFFFFFFFF)
     exp = x.cpu().numpy() * O.dropout_mask((3, 5, 64), thr, r0, r1)      # (the mask carries the 1/keep scale)
     np.testing.assert_allclose(y, exp, rtol=1e-6, atol=0)
+
+
+def test_step_auto_calibrates_once_and_stays_on_the_eager_trajectory(golden_dir):
+    asr_amd.set_precision("bf16")
+    z, m_e = build(golden_dir)
+    _, m_a = build(golden_dir)
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    umax = int((tg != 0).sum(1).max())
+    te = asr_amd.Trainer(m_e, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    ta = asr_amd.Trainer(m_a, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    ta.step_auto(x, lens, tg, max_target_len=umax, trials=2)          # calibration: 2 + 2 eager, 1 capture + replay, 2 replays
+    assert ta.launch_mode in ("eager", "graph") and ta.step_num == 7
+    assert ta.launch_timing["eager_ms"] > 0 and ta.launch_timing["graph_ms"] > 0
+    assert ta.graph_active() == (ta.launch_mode == "graph")
+    for _ in range(7):
+        ce = te.step(x, lens, tg, max_target_len=umax)
+    for _ in range(3):
+        ce = te.step(x, lens, tg, max_target_len=umax)
+        ca = ta.step_auto(x, lens, tg, max_target_len=umax)
+    assert ta.step_num == te.step_num == 10
+    np.testing.assert_allclose([float(v) for v in ca], [float(v) for v in ce], rtol=5e-3)
+    # a step that cannot be captured (no max_target_len: a host read in the middle) settles on eager without calibrating
+    tb = asr_amd.Trainer(build(golden_dir)[1], k=0.2, warmup_steps=50, label_smoothing=0.1)
+    tb.step_auto(x, lens, tg)
+    assert tb.launch_mode == "eager" and tb.step_num == 1
