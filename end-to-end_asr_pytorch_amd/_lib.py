@@ -76,6 +76,9 @@ SIGNATURES = {
     "asr_argmax_rows": [_vp, _vp, _i64, _i, _i, _vp],
     "asr_log_softmax_rows": [_vp, _vp, _i64, _i, _i, _vp, _i64],
     "asr_ctc_greedy_reduce": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "asr_decode_embed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "asr_kv_cache_put": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asr_decode_advance": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_add2d": [_vp, _vp, _i64, _vp, _i64, _i, _i],
     "asr_add_transposed": [_vp, _vp, _vp, _i, _i, _i, _i64],
     "asr_relu_mask_mul": [_vp, _vp, _vp, _i, _vp, _i64],

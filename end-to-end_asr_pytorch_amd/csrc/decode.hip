@@ -67,6 +67,70 @@ __global__ __launch_bounds__(64) void ctc_greedy_reduce_kernel(const int64_t* __
     if (lane == 0) out_len[b] = kept;
 }
 
+
+// ---- greedy decoding with the step position in DEVICE memory: the per-token step (embed, 6 layers, projection, argmax, advance)
+// has no host-visible argument that changes from token to token, so it is captured once as a hipGraph and replayed.
+// state[0] = t (tokens decoded so far = position of the token being fed), state[1] = the step count at which every row had
+// produced <eos> (-1 until then; once set, advance changes nothing any more).
+
+// x[b] = emb[cur[b]] + pe[t]   (decoder.py:104-105 for the one new position)
+__global__ __launch_bounds__(256) void decode_embed_kernel(const int64_t* __restrict__ cur, const float* __restrict__ emb,
+                                                           const float* __restrict__ pe, const int32_t* __restrict__ state,
+                                                           float* __restrict__ y32, bf16_t* __restrict__ y16, int B, int D, int V, int max_pos) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const int t = min(max(state[0], 0), max_pos - 1);
+    int64_t id = cur[row];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(emb + id * D + c) + *reinterpret_cast<const f32x4*>(pe + (int64_t)t * D + c);
+        *reinterpret_cast<f32x4*>(y32 + (int64_t)row * D + c) = o;
+        if (y16) {
+            const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            *reinterpret_cast<bf16x4*>(y16 + (int64_t)row * D + c) = ob;
+        }
+    }
+}
+
+// the new position's key / value heads [B*h, 64] into slot t of the caches [B*h, Tmax, 64] (elements of `esz` bytes)
+__global__ __launch_bounds__(256) void kv_cache_put_kernel(const unsigned char* __restrict__ k_new, const unsigned char* __restrict__ v_new,
+                                                           unsigned char* __restrict__ k_cache, unsigned char* __restrict__ v_cache,
+                                                           const int32_t* __restrict__ state, int BH, int Tmax, int esz) {
+    const int t = state[0];
+    if (t < 0 || t >= Tmax) return;
+    const int rowb = 64 * esz, words = rowb / 4;                  // bytes / dwords per head row
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;    // one dword each
+    if (i >= (int64_t)BH * words) return;
+    const int bh = (int)(i / words), w = (int)(i - (int64_t)bh * words);
+    const int64_t dst = ((int64_t)bh * Tmax + t) * rowb + w * 4, src = (int64_t)bh * rowb + w * 4;
+    *reinterpret_cast<uint32_t*>(k_cache + dst) = *reinterpret_cast<const uint32_t*>(k_new + src);
+    *reinterpret_cast<uint32_t*>(v_cache + dst) = *reinterpret_cast<const uint32_t*>(v_new + src);
+}
+
+// decoder.py:151-158 for one step: append the argmax tokens, update `finished` and the decoded lengths, move to the next position
+__global__ __launch_bounds__(256) void decode_advance_kernel(const int64_t* __restrict__ cur, int64_t* __restrict__ preds, int32_t* __restrict__ state,
+                                                             int32_t* __restrict__ k_len, unsigned char* __restrict__ finished,
+                                                             int64_t* __restrict__ len_decoded, int eos, int B, int Tp1) {
+    const int t = state[0];
+    if (state[1] >= 0 || t + 1 >= Tp1) return;                    // (uniform: every thread reads the same words)
+    int all = 1;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int64_t c = cur[b];
+        preds[(int64_t)b * Tp1 + t + 1] = c;
+        const unsigned char f = finished[b] | (c == eos ? 1 : 0);
+        finished[b] = f;
+        len_decoded[b] += f ? 0 : 1;
+        k_len[b] = t + 2;
+        all &= f;
+    }
+    all = __syncthreads_and(all);
+    if (threadIdx.x == 0) {
+        state[0] = t + 1;
+        if (all) state[1] = t + 1;
+    }
+}
+
 }  // namespace
 
 extern "C" int asr_argmax_rows(void* stream, const float* x, int64_t ld, int M, int V, int64_t* out) {
@@ -88,5 +152,37 @@ extern "C" int asr_ctc_greedy_reduce(void* stream, const int64_t* frames, const 
     ASR_REQUIRE(frames && len && out && out_len && B > 0 && L > 0, ASR_ERR_ARG, "ctc_greedy_reduce: bad args");
     hipLaunchKernelGGL(ctc_greedy_reduce_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), frames, len, L, blank, out, out_len);
     ASR_LAUNCH_CHECK("ctc_greedy_reduce");
+    return 0;
+}
+
+extern "C" int asr_decode_embed(void* stream, const int64_t* cur, const float* emb, const float* pe, const int32_t* state, float* y32,
+                                void* y16, int B, int D, int V, int max_pos) {
+    ASR_REQUIRE(cur && emb && pe && state && y32 && B > 0 && D > 0 && D % 4 == 0 && V > 0 && max_pos > 0, ASR_ERR_ARG, "decode_embed: bad args");
+    ASR_REQUIRE(asr_aligned(emb, 16) && asr_aligned(pe, 16) && asr_aligned(y32, 16), ASR_ERR_ALIGN, "decode_embed: alignment");
+    hipLaunchKernelGGL(decode_embed_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), cur, emb, pe, state, y32,
+                       reinterpret_cast<bf16_t*>(y16), B, D, V, max_pos);
+    ASR_LAUNCH_CHECK("decode_embed");
+    return 0;
+}
+
+extern "C" int asr_kv_cache_put(void* stream, const void* k_new, const void* v_new, void* k_cache, void* v_cache, const int32_t* state,
+                                int BH, int Tmax, int dtype) {
+    ASR_REQUIRE(k_new && v_new && k_cache && v_cache && state && BH > 0 && Tmax > 0, ASR_ERR_ARG, "kv_cache_put: bad args");
+    ASR_REQUIRE(dtype == ASR_F32 || dtype == ASR_BF16, ASR_ERR_ARG, "kv_cache_put: dtype");
+    const int esz = dtype == ASR_F32 ? 4 : 2;
+    const int64_t n = (int64_t)BH * 16 * esz;
+    hipLaunchKernelGGL(kv_cache_put_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char*>(k_new), static_cast<const unsigned char*>(v_new), static_cast<unsigned char*>(k_cache),
+                       static_cast<unsigned char*>(v_cache), state, BH, Tmax, esz);
+    ASR_LAUNCH_CHECK("kv_cache_put");
+    return 0;
+}
+
+extern "C" int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t* state, int32_t* k_len, unsigned char* finished,
+                                  int64_t* len_decoded, int eos, int B, int Tp1) {
+    ASR_REQUIRE(cur && preds && state && k_len && finished && len_decoded && B > 0 && Tp1 > 1, ASR_ERR_ARG, "decode_advance: bad args");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cur, preds, state, k_len, finished,
+                       len_decoded, eos, B, Tp1);
+    ASR_LAUNCH_CHECK("decode_advance");
     return 0;
 }

@@ -433,8 +433,11 @@ class MultiheadAttention(_Cached):
         h, B = self.n_head, x.B
         kv = ops.proj_heads(x.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)), self._b("bkv", (self.w_ks.bias, self.w_vs.bias)),
                             2, B, 1, h, 1.0)
-        k_cache[:, :, t:t + 1].copy_(kv[0])
-        v_cache[:, :, t:t + 1].copy_(kv[1])
+        if torch.is_tensor(t):                      # position in device memory (Decoder.batch_decode's captured step)
+            ops.kv_cache_put(kv[0], kv[1], k_cache, v_cache, t)
+        else:
+            k_cache[:, :, t:t + 1].copy_(kv[0])
+            v_cache[:, :, t:t + 1].copy_(kv[1])
         return self._impl(x, Act(None, None, B, k_cache.shape[2]), k_len, False, None, kv_pre=(k_cache, v_cache, None))
 
     def forward(self, q, k, v, mask=None, k_len=None, causal=False):
@@ -946,40 +949,92 @@ class Decoder(_Cached):
     def batch_decode(self, encoded, len_encoded, max_decode_len=100):
         """decoder.py:138-164 - greedy decoding of a batch: -> (preds int64 [B, steps], len_decoded, torch.zeros(0)).
         One new token per step through the layers, against per-layer self-attention K/V caches and the encoder-side K/V of all
-        layers projected once (see decode.py); the finished test is the reference's per-step host check."""
-        B = encoded.shape[0]
+        layers projected once.  The step keeps everything that changes from token to token in DEVICE memory (position, cache
+        slot, key length, finished flags: asr_decode_embed / asr_kv_cache_put / asr_decode_advance), so its ~70 launches are
+        captured once as a hipGraph and replayed per token; the reference's per-step host check `finished.all()` becomes one
+        4-byte read every 8 tokens (the device stops advancing by itself once every row has produced <eos>)."""
+        B, L = encoded.shape[0], encoded.shape[1]
         dev = encoded.device
-        enc = _act(encoded)
-        enc_len = ops.as_i32(len_encoded, dev)
-        cross = self._cross_kv(enc)
-        n, h, T = len(self.layer_stack), self.n_head, int(max_decode_len)
-        cdt = _cdtype()
-        kc = [torch.zeros((B, h, max(T, 1), 64), device=dev, dtype=cdt) for _ in range(n)]
-        vc = [torch.zeros((B, h, max(T, 1), 64), device=dev, dtype=cdt) for _ in range(n)]
-        emb = self.tgt_word_emb.weight.detach().float()
-        pe = self.positional_encoding.pe[0]
-        preds = torch.zeros((B, T + 1), dtype=torch.long, device=dev)
-        preds[:, 0] = self.sos_id
-        len_decoded = torch.ones_like(len_encoded)
-        finished = torch.zeros(B, dtype=torch.bool, device=dev)
-        steps = 0
+        T = int(max_decode_len)
+        if T <= 0:
+            return torch.zeros((B, 0), dtype=torch.long, device=dev), torch.zeros_like(len_encoded), torch.zeros(0)
+        key = (B, L, T, str(dev), _PRECISION, _PARAM_EPOCH, self.sos_id, self.eos_id, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        dg = self.__dict__.get("_decode_graph")
+        if dg is None or dg["key"] != key:
+            dg = self._build_decode_graph(B, L, T, dev, key)
+            self.__dict__["_decode_graph"] = dg
+        dg["enc"].copy_(encoded.reshape(B * L, -1))
+        dg["enc_len"].copy_(ops.as_i32(len_encoded, dev))
+        dg["state"].copy_(dg["state0"])
+        dg["k_len"].fill_(1)
+        dg["finished"].zero_()
+        dg["len_decoded"].fill_(1)
+        dg["preds"].zero_()
+        dg["preds"][:, 0] = self.sos_id
+        dg["cur"].fill_(self.sos_id)
+        dg["prologue"]()
+        steps = T
         for t in range(T):
-            x32, x16 = ops.embed_pe(preds[:, t:t + 1].contiguous(), emb, pe[t:t + 1].contiguous(), want_bf16=(_PRECISION == "bf16"))
+            dg["step"]()
+            if (t & 7) == 7 or t == T - 1:
+                stop = int(dg["state"][1])
+                if stop >= 0:
+                    steps = stop
+                    break
+        fin = dg["finished"].to(len_encoded.dtype)
+        len_decoded = dg["len_decoded"].to(len_encoded.dtype) - (1 - fin)      # for decoded length cut by encoded length (decoder.py:161)
+        return dg["preds"][:, 1:steps + 1].clone(), len_decoded, torch.zeros(0)
+
+    def _build_decode_graph(self, B, L, T, dev, key):
+        n, h = len(self.layer_stack), self.n_head
+        cdt = _cdtype()
+        d = self.d_model
+        g = dict(key=key,
+                 enc=torch.zeros((B * L, d), device=dev, dtype=torch.float32), enc_len=torch.ones(B, dtype=torch.int32, device=dev),
+                 state=torch.zeros(2, dtype=torch.int32, device=dev), state0=torch.tensor([0, -1], dtype=torch.int32, device=dev),
+                 k_len=torch.ones(B, dtype=torch.int32, device=dev), finished=torch.zeros(B, dtype=torch.uint8, device=dev),
+                 len_decoded=torch.ones(B, dtype=torch.int64, device=dev), preds=torch.zeros((B, T + 1), dtype=torch.long, device=dev),
+                 cur=torch.zeros(B, dtype=torch.long, device=dev))
+        kc = [torch.zeros((B, h, T, 64), device=dev, dtype=cdt) for _ in range(n)]
+        vc = [torch.zeros((B, h, T, 64), device=dev, dtype=cdt) for _ in range(n)]
+        emb = self.tgt_word_emb.weight.detach().float()
+        pe = self.positional_encoding.pe[0].contiguous()
+        box = {}
+
+        def prologue():
+            enc = Act(g["enc"], None, B, L)
+            box["enc"], box["cross"] = enc, self._cross_kv(enc)
+
+        def step():
+            x32, x16 = ops.decode_embed(g["cur"], emb, pe, g["state"], want_bf16=(_PRECISION == "bf16"))
             x = Act(x32, x16, B, 1)
-            k_len = torch.full((B,), t + 1, dtype=torch.int32, device=dev)
             for i, layer in enumerate(self.layer_stack):
-                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], t, k_len)
-                x = layer.enc_attn._impl(x, enc, enc_len, False, None, kv_pre=cross(i))
+                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], g["state"], g["k_len"])
+                x = layer.enc_attn._impl(x, box["enc"], g["enc_len"], False, None, kv_pre=box["cross"](i))
                 x = layer.pos_ffn._impl(x, None)
-            cur = ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x))      # argmax of log_softmax = argmax of the logits
-            preds[:, t + 1] = cur
-            finished = torch.logical_or(finished, cur.eq(self.eos_id))
-            len_decoded = len_decoded + (1 - finished.to(len_decoded.dtype))
-            steps = t + 1
-            if bool(finished.all()):
-                break
-        len_decoded = len_decoded - (1 - finished.to(len_decoded.dtype))      # for decoded length cut by encoded length (decoder.py:161)
-        return preds[:, 1:steps + 1], len_decoded, torch.zeros(0)
+            ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), out=g["cur"])      # argmax of log_softmax = argmax of the logits
+            ops.decode_advance(g["cur"], g["preds"], g["state"], g["k_len"], g["finished"], g["len_decoded"], self.eos_id)
+
+        g["state"].copy_(g["state0"])
+        use_graph = os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0"
+        prologue()                      # eager warm-up of both parts: code objects, derived weights, allocator pools
+        step()
+        torch.cuda.synchronize(dev)
+        if use_graph:
+            try:
+                gp, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gp):
+                    prologue()
+                with torch.cuda.graph(gs, pool=gp.pool()):
+                    step()
+                g["prologue"], g["step"], g["graphs"] = gp.replay, gs.replay, (gp, gs)
+                return g
+            except Exception as e:          # not capturable on this stack: decode eagerly, remember why
+                import warnings
+                warnings.warn("asr_amd.Decoder: hipGraph capture of the decode step failed, decoding eagerly (%s: %s)" % (type(e).__name__, e))
+                torch.cuda.synchronize(dev)
+        g["prologue"], g["step"], g["graphs"] = prologue, step, None
+        return g
 
     def cross_kv_params(self):
         """([w_ks, w_vs weights of layer 0, 1, ...], [their biases]) - the trainer keeps each list adjacent in its flat buffers."""

@@ -649,14 +649,46 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, p16=None)
                               float(eps), int(step), float(grad_scale)), "asr_adam_step")
 
 
-def argmax_rows(x2d):
+def argmax_rows(x2d, out=None):
     """f32 [M, V] (row stride free) -> int64 [M], ties to the lowest index"""
     _req_cuda(x2d)
     assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype == torch.float32
     M, V = x2d.shape
-    out = torch.empty(M, device=x2d.device, dtype=torch.int64)
+    if out is None:
+        out = torch.empty(M, device=x2d.device, dtype=torch.int64)
+    assert out.dtype == torch.int64 and out.numel() == M and out.is_contiguous()
     check(lib().asr_argmax_rows(_stream(), _p(x2d), x2d.stride(0), M, V, _p(out)), "asr_argmax_rows")
     return out
+
+
+def decode_embed(cur, emb, pe, state, want_bf16=False):
+    """x[b] = emb[cur[b]] + pe[state[0]] -> (y32 [B, D], y16 or None): the decoder input of the one new position, position on the device"""
+    _req_cuda(cur, emb, pe, state)
+    B, (V, D) = cur.numel(), emb.shape
+    y32 = torch.empty((B, D), device=emb.device, dtype=torch.float32)
+    y16 = torch.empty((B, D), device=emb.device, dtype=torch.bfloat16) if want_bf16 else None
+    check(lib().asr_decode_embed(_stream(), _p(cur), _p(emb), _p(pe), _p(state), _p(y32), _p(y16), B, D, V, pe.shape[0]), "asr_decode_embed")
+    return y32, y16
+
+
+def kv_cache_put(k_new, v_new, k_cache, v_cache, state):
+    """k_cache[:, :, state[0]] = k_new[:, :, 0] (same for v); caches [B, h, Tmax, 64], new heads [B, h, 1, 64] of the same dtype"""
+    _req_cuda(k_new, v_new, k_cache, v_cache, state)
+    B, h, Tmax, dk = k_cache.shape
+    assert dk == 64 and k_new.is_contiguous() and v_new.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert k_new.dtype == k_cache.dtype == v_new.dtype == v_cache.dtype and k_new.numel() == B * h * 64
+    check(lib().asr_kv_cache_put(_stream(), _p(k_new), _p(v_new), _p(k_cache), _p(v_cache), _p(state), B * h, Tmax, dtype_code(k_cache)),
+          "asr_kv_cache_put")
+
+
+def decode_advance(cur, preds, state, k_len, finished, len_decoded, eos_id):
+    """decoder.py:151-158 on the device: append `cur` at preds[:, t + 1], update finished / len_decoded / k_len, t += 1"""
+    _req_cuda(cur, preds, state, k_len, finished, len_decoded)
+    B, Tp1 = preds.shape
+    assert preds.is_contiguous() and preds.dtype == torch.int64 and finished.dtype == torch.uint8 and len_decoded.dtype == torch.int64
+    assert k_len.dtype == torch.int32 and state.dtype == torch.int32
+    check(lib().asr_decode_advance(_stream(), _p(cur), _p(preds), _p(state), _p(k_len), _p(finished), _p(len_decoded), int(eos_id), B, Tp1),
+          "asr_decode_advance")
 
 
 def log_softmax_rows(x2d):

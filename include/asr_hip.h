@@ -327,6 +327,19 @@ int asr_spec_aug(void* stream, float* x, const int32_t* len, int B, int T, int V
 int asr_argmax_rows(void* stream, const float* x, int64_t ld, int M, int V, int64_t* out);
 int asr_log_softmax_rows(void* stream, const float* x, int64_t ldx, int M, int V, float* y, int64_t ldy);
 int asr_ctc_greedy_reduce(void* stream, const int64_t* frames, const int32_t* len, int B, int L, int blank, int64_t* out, int32_t* out_len);
+/* The per-token step of Decoder.batch_decode (decoder.py:138-164) with its position in device memory, so that the whole step is
+ * one capturable launch sequence (hipGraph replay per token).  state int32[2]: [0] = t, the position of the token being fed
+ * (0 = <sos>), [1] = the number of steps after which every row had produced <eos>, -1 until then.
+ * asr_decode_embed:   x[b] = emb[cur[b]] + pe[t]                       (decoder.py:104-105, the one new position)
+ * asr_kv_cache_put:   k_cache[b, h, t] = k_new[b, h], same for v       (caches [B*h, Tmax, 64], dtype ASR_F32 | ASR_BF16)
+ * asr_decode_advance: preds[b, t+1] = cur[b]; finished[b] |= cur[b] == eos; len_decoded[b] += !finished[b]; k_len[b] = t + 2;
+ *                     t += 1; state[1] = t once all rows are finished (and nothing changes after that)   (decoder.py:151-158) */
+int asr_decode_embed(void* stream, const int64_t* cur, const float* emb, const float* pe, const int32_t* state, float* y32, void* y16,
+                     int B, int D, int V, int max_pos);
+int asr_kv_cache_put(void* stream, const void* k_new, const void* v_new, void* k_cache, void* v_cache, const int32_t* state, int BH,
+                     int Tmax, int dtype);
+int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t* state, int32_t* k_len, unsigned char* finished,
+                       int64_t* len_decoded, int eos, int B, int Tp1);
 
 /* ---- CIF family, training side (autograd of cif_model.py:44-48, attentionAssigner.py:37-40, conv_encoder.py:33-49) and the tape's
  * gradient bookkeeping; all f32. */

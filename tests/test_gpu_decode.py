@@ -87,3 +87,34 @@ def test_argmax_and_log_softmax_rows():
     assert int(got[3]) == 100 and int(got[5]) == 0
     ls = ops.log_softmax_rows(buf.to(DEV)[:, :4234])
     np.testing.assert_allclose(ls.cpu().numpy(), torch.log_softmax(x, -1).numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_graph_replayed_decode_step_equals_the_eager_step(golden_dir, monkeypatch):
+    """Decoder.batch_decode replays its per-token step from a hipGraph (position, cache slot, key length and finished flags live in
+    device memory); with ASR_AMD_DECODE_GRAPH=0 the same step functions are queued eagerly.  Same tokens, lengths and stop step."""
+    z, cfg, model = load(golden_dir)
+    enc, enc_len = torch.from_numpy(z["enc_out"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ASR_AMD_DECODE_GRAPH", mode)
+        model.decoder.__dict__.pop("_decode_graph", None)
+        res = []
+        for eos in (cfg["eos_id"], 14, 39):
+            model.decoder.eos_id = eos
+            for T in (12, 3, 20):
+                p, l, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=T)
+                res.append((p.cpu().numpy(), l.cpu().numpy()))
+        assert (model.decoder.__dict__["_decode_graph"]["graphs"] is not None) == (mode == "1")
+        out[mode] = res
+    model.decoder.eos_id = cfg["eos_id"]
+    for (p1, l1), (p0, l0) in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(p1, p0)
+        np.testing.assert_array_equal(l1, l0)
+    # the cached graph is reused for a second batch of the same shape (new encoder outputs are copied into its input buffer)
+    monkeypatch.setenv("ASR_AMD_DECODE_GRAPH", "1")
+    p_a, _, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=20)
+    dg = model.decoder.__dict__["_decode_graph"]
+    assert dg["graphs"] is not None
+    p_b, _, _ = model.decoder.batch_decode(enc.flip(0).contiguous(), enc_len.flip(0).contiguous(), max_decode_len=20)
+    assert model.decoder.__dict__["_decode_graph"] is dg
+    np.testing.assert_array_equal(p_b.cpu().numpy(), p_a.cpu().numpy()[::-1])
