@@ -162,6 +162,27 @@ __global__ __launch_bounds__(256) void conv_im2col_kernel(const TI* __restrict__
     }
 }
 
+// bf16 -> bf16 with C % 8 == 0 and ldc % 8 == 0: one thread per 16-byte chunk (8 channels of one tap) - the element-wise kernel above
+// spent its time in 64-bit div / mod per 2-byte store (0.6 TB/s on the 184 MB patch matrix of the second conv layer)
+__global__ __launch_bounds__(256) void conv_im2col_vec8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int C, int Tin, int Fin,
+                                                               int Tout, int Fout, int ldc8, int64_t npos) {
+    const int cpt = C >> 3;                                        // chunks per tap
+    const int j8 = threadIdx.x % ldc8, prow = threadIdx.x / ldc8, rows_per_block = 256 / ldc8;
+    const int tap = j8 / cpt, c8 = (j8 - tap * cpt) * 8, kh = tap / 3, kw = tap - kh * 3;
+    const bool live = prow < rows_per_block && tap < 9;
+    for (int64_t pos = (int64_t)blockIdx.x * rows_per_block + prow; pos < npos && prow < rows_per_block; pos += (int64_t)gridDim.x * rows_per_block) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (live) {
+            const int f = (int)(pos % Fout);
+            const int64_t bt = pos / Fout;
+            const int t = (int)(bt % Tout), b = (int)(bt / Tout);
+            const int tt = 2 * t + kh, ff = f + kw;
+            if (tt < Tin && ff < Fin) v = *reinterpret_cast<const u32x4*>(x + (((int64_t)b * Tin + tt) * Fin + ff) * C + c8);
+        }
+        *reinterpret_cast<u32x4*>(col + pos * (int64_t)ldc8 * 8 + j8 * 8) = v;
+    }
+}
+
 // col2im (gather form) + ReLU mask: dx[b,ti,fi,c] = (y[b,ti,fi,c] > 0) * sum_{kh,kw} dcol[(b,(ti-kh)/2,fi-kw), tap*32 + c]
 // over taps with (ti-kh) even, 0 <= (ti-kh)/2 < Tout, 0 <= fi-kw < Fout.  One thread per (position, 4 channels).
 __global__ __launch_bounds__(256) void conv_col2im_kernel(const bf16_t* __restrict__ dcol, int ldc, const bf16_t* __restrict__ y,
@@ -207,7 +228,13 @@ extern "C" int asr_conv_im2col(void* stream, const void* x, int x_dtype, int C, 
         hipLaunchKernelGGL((conv_im2col_kernel<float, float>), g, b, 0, s, (const float*)x, (float*)col, C, Tin, Fin, Tout, Fout, ldc, total);
     else if (x_dtype == ASR_F32 && col_dtype == ASR_BF16)
         hipLaunchKernelGGL((conv_im2col_kernel<float, bf16_t>), g, b, 0, s, (const float*)x, (bf16_t*)col, C, Tin, Fin, Tout, Fout, ldc, total);
-    else if (x_dtype == ASR_BF16 && col_dtype == ASR_BF16)
+    else if (x_dtype == ASR_BF16 && col_dtype == ASR_BF16 && C % 8 == 0 && ldc % 8 == 0 && ldc / 8 <= 256 && asr_aligned(x, 16) && asr_aligned(col, 16)) {
+        const int ldc8 = ldc / 8, rpb = 256 / ldc8;
+        const int64_t npos = (int64_t)B * Tout * Fout;
+        int64_t nb = (npos + rpb - 1) / rpb;
+        if (nb > 16384) nb = 16384;
+        hipLaunchKernelGGL(conv_im2col_vec8_kernel, dim3((unsigned)nb), b, 0, s, (const bf16_t*)x, (bf16_t*)col, C, Tin, Fin, Tout, Fout, ldc8, npos);
+    } else if (x_dtype == ASR_BF16 && col_dtype == ASR_BF16)
         hipLaunchKernelGGL((conv_im2col_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)x, (bf16_t*)col, C, Tin, Fin, Tout, Fout, ldc, total);
     else
         ASR_REQUIRE(false, ASR_ERR_UNSUPPORTED, "im2col: dtype combination");
