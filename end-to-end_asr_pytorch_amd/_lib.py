@@ -76,6 +76,7 @@ SIGNATURES = {
     "asr_argmax_rows": [_vp, _vp, _i64, _i, _i, _vp],
     "asr_log_softmax_rows": [_vp, _vp, _i64, _i, _i, _vp, _i64],
     "asr_ctc_greedy_reduce": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "asr_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
     "asr_decode_embed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_kv_cache_put": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_decode_advance": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],

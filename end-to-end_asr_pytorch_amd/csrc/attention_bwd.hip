@@ -18,6 +18,7 @@
 #include "asr_common.h"
 
 namespace {
+constexpr float LN2F = 0.6931471805599453f;
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
     bf16x8 r;
@@ -343,6 +344,64 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 parity-mode backward (the partner of attn_fwd_f32_kernel): one wavefront per (batch, head, query), lane = head dimension for
+// the row vectors and = key for the scores; dK / dV are accumulated with float atomics into zeroed buffers.  Not a fast kernel: it
+// exists so that the backward tape can run end to end in fp32 and be compared with the reference's gradients at 1e-4 instead of
+// through bf16 rounding.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                           const float* __restrict__ O, const float* __restrict__ dO,
+                                                           const float* __restrict__ lse, float* __restrict__ dq, int64_t ldq,
+                                                           float* __restrict__ dk, float* __restrict__ dv, int64_t ldkv, int B, int h, int Lq,
+                                                           int Lk, const int32_t* __restrict__ k_len, int causal, float scale) {
+    __shared__ float qs[4][64], gs[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    if (gw >= (int64_t)B * h * Lq) return;
+    const int i = (int)(gw % Lq);
+    const int bh = (int)(gw / Lq);
+    const int b = bh / h, hd = bh - b * h;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int kend = causal ? min(kl, i + 1) : kl;
+    const float qd = Q[((int64_t)bh * Lq + i) * 64 + lane];                         // scaled query (scale * log2(e) folded in)
+    const float gd = dO[((int64_t)b * Lq + i) * (h * 64) + hd * 64 + lane];
+    const float od = O[((int64_t)b * Lq + i) * (h * 64) + hd * 64 + lane];
+    qs[wave][lane] = qd;
+    gs[wave][lane] = gd;
+    __builtin_amdgcn_wave_barrier();
+    const float delta = wave_sum(gd * od);
+    const float l2 = lse[(int64_t)bh * Lq + i];
+    float dq_acc = 0.f;
+    for (int j0 = 0; j0 < kend; j0 += 64) {
+        const int j = j0 + lane;
+        const bool valid = j < kend;
+        float p = 0.f, ds = 0.f;
+        if (valid) {
+            const float* kr = K + ((int64_t)bh * Lk + j) * 64;
+            const float* vr = V + ((int64_t)bh * Lk + j) * 64;
+            float s = 0.f, dp = 0.f;
+#pragma unroll 8
+            for (int dd = 0; dd < 64; ++dd) {
+                s = fmaf(qs[wave][dd], kr[dd], s);
+                dp = fmaf(gs[wave][dd], vr[dd], dp);
+            }
+            p = exp2f(s - l2);
+            ds = p * (dp - delta);
+        }
+        const int cnt = min(64, kend - j0);
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float pj = __shfl(p, jj, 64), dsj = __shfl(ds, jj, 64);
+            const int64_t krow = (int64_t)bh * Lk + j0 + jj, orow = ((int64_t)b * Lk + j0 + jj) * ldkv + hd * 64 + lane;
+            dq_acc = fmaf(dsj, K[krow * 64 + lane], dq_acc);
+            atomicAdd(dk + orow, dsj * qd * LN2F);                                  // q carries log2(e): d/dk of the natural-log score
+            atomicAdd(dv + orow, pj * gd);
+        }
+    }
+    dq[((int64_t)b * Lq + i) * ldq + hd * 64 + lane] = dq_acc * scale;              // gradient wrt the unscaled query, times scale
+}
+
 }  // namespace
 
 extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
@@ -406,4 +465,21 @@ extern "C" int asr_attention_bwd(void* stream, const void* q, const void* k, con
     if (int rc = asr_attention_bwd_dq(stream, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, causal, scale, drop, drop_bits))
         return rc;
     return asr_attention_bwd_dkv(stream, q, k, v, d_o, lse, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+}
+
+extern "C" int asr_attention_bwd_f32(void* stream, const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                                     const float* lse, float* dq, int64_t ldq, float* dk, float* dv, int64_t ldkv, int B, int h, int Lq,
+                                     int Lk, const int32_t* k_len, int causal, float scale) {
+    ASR_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv, ASR_ERR_ARG, "attention_bwd_f32: null pointer");
+    ASR_REQUIRE(B > 0 && h > 0 && Lq > 0 && Lk > 0 && ldq >= h * 64 && ldkv >= h * 64, ASR_ERR_ARG, "attention_bwd_f32: bad sizes");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // dk / dv are accumulated: zero the [B*Lk, h*64] windows (row stride ldkv) first
+    hipError_t e = hipMemset2DAsync(dk, (size_t)ldkv * 4, 0, (size_t)h * 64 * 4, (size_t)B * Lk, s);
+    if (e == hipSuccess) e = hipMemset2DAsync(dv, (size_t)ldkv * 4, 0, (size_t)h * 64 * 4, (size_t)B * Lk, s);
+    if (e != hipSuccess) { asr_set_error("attention_bwd_f32 memset: %s", hipGetErrorString(e)); return (int)e; }
+    const int64_t waves = (int64_t)B * h * Lq;
+    hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, q, k, v, o, d_o, lse, dq, ldq, dk, dv, ldkv,
+                       B, h, Lq, Lk, k_len, causal, scale);
+    ASR_LAUNCH_CHECK("attention_bwd_f32");
+    return 0;
 }

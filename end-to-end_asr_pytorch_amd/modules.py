@@ -33,6 +33,7 @@ def set_precision(p):
     global _PRECISION
     assert p in ("bf16", "f32")
     _PRECISION = p
+    ops.EXACT_F32 = p == "f32"
 
 
 def get_precision():
@@ -198,14 +199,18 @@ class Tape:
 @contextlib.contextmanager
 def record():
     global _TAPE
-    if _PRECISION != "bf16":
-        raise RuntimeError("the backward tape runs on the bf16 MFMA path")
-    old, t = _TAPE, Tape()
+    old, t = _TAPE, Tape()      # (bf16: the product path; f32: the parity mode - exact-f32 GEMMs, VALU attention, eval mode / dropout 0)
     _TAPE = t
     try:
         yield t
     finally:
         _TAPE = old
+
+
+def _ln_bwd(*a, **kw):
+    """ops.add_layernorm_bwd -> (ds f32, the backward GEMMs' operand): its bf16 image on the product path, ds itself in the fp32 parity mode"""
+    ds, ds16 = ops.add_layernorm_bwd(*a, want_bf16=(_PRECISION == "bf16"), **kw)
+    return ds, (ds16 if ds16 is not None else ds)
 
 
 def _add_into(dst, src):
@@ -399,23 +404,24 @@ class MultiheadAttention(_Cached):
         qkvb = (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)
 
         def bw():
-            ds, ds16 = ops.add_layernorm_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
-                                             want_bf16=True, dbias=fc.bias.grad, drop_x=dp_fc)
+            ds, ds16 = _ln_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
+                                  dbias=fc.bias.grad, drop_x=dp_fc)
             y.grad = None
             _wg(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
-            d_ctx = ops.gemm_nn(ds16, self._w("fc", (fc.weight,)), out_dtype=torch.bfloat16)
+            gdt = _cdtype()
+            d_ctx = ops.gemm_nn(ds16, self._w("fc", (fc.weight,)), out_dtype=gdt)
             if xkv is xq:
-                dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=torch.bfloat16)
+                dqkv = torch.empty((B * Lq, 3 * hd), device=ds.device, dtype=gdt)
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:],
                                   drop=dp_attn, drop_bits=dbits)
                 _wg(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
                 _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
             else:
-                dq = torch.empty((B * Lq, hd), device=ds.device, dtype=torch.bfloat16)
+                dq = torch.empty((B * Lq, hd), device=ds.device, dtype=gdt)
                 if dkv_pre is not None:
                     dk_out, dv_out = dkv_pre()
                 else:
-                    dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=torch.bfloat16)
+                    dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=gdt)
                     dk_out, dv_out = dkv[:, :hd], dkv[:, hd:]
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn, drop_bits=dbits)
                 _wg(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
@@ -501,12 +507,12 @@ class PositionwiseFeedForward(_Cached):
             ln, w1, w2 = self.layer_norm, self.w_1, self.w_2
 
             def bw():
-                ds, ds16 = ops.add_layernorm_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
-                                                 want_bf16=True, dbias=w2.bias.grad, drop_x=dp)
+                ds, ds16 = _ln_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
+                                      dbias=w2.bias.grad, drop_x=dp)
                 y.grad = None
                 _wg(ds16, hid, out=w2.weight.grad, accumulate=True)
-                d_hid = (ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_bits=bits) if bits is not None
-                         else ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=torch.bfloat16, relu_mask=hid))
+                d_hid = (ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=_cdtype(), relu_bits=bits) if bits is not None
+                         else ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=_cdtype(), relu_mask=hid))
                 _wg(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
                 _acc(x, ops.gemm_nn(d_hid, self._w("w1", (w1.weight,)), addend=ds))
 
@@ -563,8 +569,8 @@ class Encoder(_Cached):
             need_dx = x_in.needs_grad
 
             def bw():
-                ds, ds16 = ops.add_layernorm_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
-                                                 want_bf16=True, dbias=lin.bias.grad, drop_y=dp)
+                ds, ds16 = _ln_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
+                                      dbias=lin.bias.grad, drop_y=dp)
                 y0.grad = None
                 ops.gemm_tn(ds16, x_in.mma(), out=lin.weight.grad, accumulate=True)
                 if need_dx:
@@ -645,6 +651,8 @@ class Conv2dSubsample(_Cached):
         return act, lens.to(torch.int32)
 
     def _record_bw(self, feats, ys, tneed, fneed, act, wp, y_last):
+        if _PRECISION != "bf16":
+            raise NotImplementedError("Conv2dSubsample's backward (patch-matrix GEMMs) runs on the bf16 path only")
         n, F, aff = self.n_layers, self.d_conv_out, self.affine
         B, T, D = feats.shape
         convs = [getattr(self.conv, "subsample/conv{}".format(i)) for i in range(n)]
@@ -861,6 +869,25 @@ def _compact_targets(targets):
     return comp, n
 
 
+class _DecodeGraph(dict):
+    """The buffers, closures and hipGraphs of one Decoder.batch_decode shape.  Dropped in a fixed order, after the device is idle:
+    first the replay handles, then every tensor the graphs address (some live in the graphs' private pool), then the graphs."""
+    keep = None
+
+    def __del__(self):
+        try:
+            if self.get("graphs") is not None:
+                torch.cuda.synchronize()
+            self.pop("prologue", None)
+            self.pop("step", None)
+            graphs = self.pop("graphs", None)
+            self.keep = None
+            self.clear()
+            del graphs
+        except Exception:
+            pass
+
+
 class Decoder(_Cached):
     """src/transformer/decoder.py:13-96 (forward path; decode loops are out of scope)."""
 
@@ -989,12 +1016,15 @@ class Decoder(_Cached):
         n, h = len(self.layer_stack), self.n_head
         cdt = _cdtype()
         d = self.d_model
-        g = dict(key=key,
-                 enc=torch.zeros((B * L, d), device=dev, dtype=torch.float32), enc_len=torch.ones(B, dtype=torch.int32, device=dev),
-                 state=torch.zeros(2, dtype=torch.int32, device=dev), state0=torch.tensor([0, -1], dtype=torch.int32, device=dev),
-                 k_len=torch.ones(B, dtype=torch.int32, device=dev), finished=torch.zeros(B, dtype=torch.uint8, device=dev),
-                 len_decoded=torch.ones(B, dtype=torch.int64, device=dev), preds=torch.zeros((B, T + 1), dtype=torch.long, device=dev),
-                 cur=torch.zeros(B, dtype=torch.long, device=dev))
+        enc_buf = torch.zeros((B * L, d), device=dev, dtype=torch.float32)
+        enc_len = torch.ones(B, dtype=torch.int32, device=dev)
+        state = torch.zeros(2, dtype=torch.int32, device=dev)
+        state0 = torch.tensor([0, -1], dtype=torch.int32, device=dev)
+        k_len = torch.ones(B, dtype=torch.int32, device=dev)
+        finished = torch.zeros(B, dtype=torch.uint8, device=dev)
+        len_decoded = torch.ones(B, dtype=torch.int64, device=dev)
+        preds = torch.zeros((B, T + 1), dtype=torch.long, device=dev)
+        cur = torch.zeros(B, dtype=torch.long, device=dev)
         kc = [torch.zeros((B, h, T, 64), device=dev, dtype=cdt) for _ in range(n)]
         vc = [torch.zeros((B, h, T, 64), device=dev, dtype=cdt) for _ in range(n)]
         emb = self.tgt_word_emb.weight.detach().float()
@@ -1002,20 +1032,25 @@ class Decoder(_Cached):
         box = {}
 
         def prologue():
-            enc = Act(g["enc"], None, B, L)
+            enc = Act(enc_buf, None, B, L)
             box["enc"], box["cross"] = enc, self._cross_kv(enc)
 
         def step():
-            x32, x16 = ops.decode_embed(g["cur"], emb, pe, g["state"], want_bf16=(_PRECISION == "bf16"))
+            x32, x16 = ops.decode_embed(cur, emb, pe, state, want_bf16=(_PRECISION == "bf16"))
             x = Act(x32, x16, B, 1)
             for i, layer in enumerate(self.layer_stack):
-                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], g["state"], g["k_len"])
-                x = layer.enc_attn._impl(x, box["enc"], g["enc_len"], False, None, kv_pre=box["cross"](i))
+                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], state, k_len)
+                x = layer.enc_attn._impl(x, box["enc"], enc_len, False, None, kv_pre=box["cross"](i))
                 x = layer.pos_ffn._impl(x, None)
-            ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), out=g["cur"])      # argmax of log_softmax = argmax of the logits
-            ops.decode_advance(g["cur"], g["preds"], g["state"], g["k_len"], g["finished"], g["len_decoded"], self.eos_id)
+            ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), out=cur)      # argmax of log_softmax = argmax of the logits
+            ops.decode_advance(cur, preds, state, k_len, finished, len_decoded, self.eos_id)
 
-        g["state"].copy_(g["state0"])
+        g = _DecodeGraph(key=key, enc=enc_buf, enc_len=enc_len, state=state, state0=state0, k_len=k_len, finished=finished,
+                         len_decoded=len_decoded, preds=preds, cur=cur)
+        # everything the captured kernels address must outlive the capture: the graphs hold raw pointers, not references (the K/V
+        # caches live in the ordinary allocator pool - dropped with these closures they would be handed to the next torch.empty)
+        g.keep = (kc, vc, emb, pe, box, prologue, step)
+        state.copy_(state0)
         use_graph = os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0"
         prologue()                      # eager warm-up of both parts: code objects, derived weights, allocator pools
         step()
@@ -1058,7 +1093,7 @@ class Decoder(_Cached):
         def dkv_of(i):
             def get():
                 if "dkv" not in box:
-                    box["dkv"] = torch.empty((enc.B * enc.L, 2 * n * hd), device=kv.device, dtype=torch.bfloat16)
+                    box["dkv"] = torch.empty((enc.B * enc.L, 2 * n * hd), device=kv.device, dtype=_cdtype())
                 d = box["dkv"]
                 return d[:, 2 * i * hd:(2 * i + 1) * hd], d[:, (2 * i + 1) * hd:(2 * i + 2) * hd]
             return get

@@ -556,6 +556,17 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
     K = a2d.shape[1] if K is None else K
     lda = a2d.stride(0) if lda is None else lda
     N = w.shape[1]
+    if w.dtype == torch.float32:        # fp32 parity mode: dY . W as the exact-f32 NT GEMM on a transposed copy of W (test plumbing)
+        assert relu_bits is None and lda == a2d.stride(0)
+        Kp = (K + 3) // 4 * 4                                   # the GEMM wants K % 4 == 0: zero columns add nothing
+        a = torch.zeros((M, Kp), device=a2d.device, dtype=torch.float32)
+        a[:, :K].copy_(a2d[:, :K])
+        wt = torch.zeros((N, Kp), device=a2d.device, dtype=torch.float32)
+        wt[:, :K].copy_(w[:K].t())
+        out = gemm_nt_ex(a, wt, None, torch.float32, addend=addend)
+        if relu_mask is not None:
+            out = relu_mask_mul(out, relu_mask.contiguous(), out=out)
+        return out if out_dtype == torch.float32 else out.to(out_dtype)
     assert w.is_contiguous() and w.dtype == torch.bfloat16 and w.shape[0] >= K and a2d.stride(1) == 1
     out = _arena_take(M, N, K, a2d.device) if (out_dtype == torch.float32 and relu_mask is None and relu_bits is None) else None
     zero_flag = 2 if out is not None else 0
@@ -568,6 +579,30 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
     return out
 
 
+EXACT_F32 = False      # set by modules.set_precision("f32"): weight gradients on the exact-f32 MFMA GEMM instead of bf16 operands
+
+
+def _gemm_tn_f32(a2d, b2d, out, accumulate, colsum_out):
+    """fp32 parity mode: dW = A^T . B as the exact-f32 NT GEMM over transposed, zero-padded copies (test plumbing, not a fast path)"""
+    M, N = a2d.shape
+    K = b2d.shape[1]
+    Mp = (M + 3) // 4 * 4
+    at = torch.zeros((N, Mp), device=a2d.device, dtype=torch.float32)
+    at[:, :M].copy_(a2d.t())
+    bt = torch.zeros((K, Mp), device=a2d.device, dtype=torch.float32)
+    bt[:, :M].copy_(b2d.t())
+    res = gemm_nt_ex(at, bt, None, torch.float32)
+    if out is None:
+        out = res
+    elif accumulate:
+        add_(out, res)
+    else:
+        out.copy_(res)
+    if colsum_out is not None:
+        colsum(a2d, out=colsum_out, accumulate=True)
+    return out
+
+
 def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     """dW[N,K] = A[M,N]^T . B[M,K]  (f32 result).  A/B f32 or bf16; rows may be strided (padded buffers).
     colsum (f32 [N]) += column sums of A (the bias gradient) in the same pass."""
@@ -575,6 +610,8 @@ def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     M, N = a2d.shape
     K = b2d.shape[1]
     assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and b2d.shape[0] == M
+    if EXACT_F32:
+        return _gemm_tn_f32(a2d, b2d, out, accumulate, colsum)
     if out is None:
         out = torch.empty((N, K), device=a2d.device, dtype=torch.float32)
         accumulate = False
@@ -617,6 +654,13 @@ def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out
     _req_cuda(q, k, v, ctx, d_ctx, lse)
     B, h, Lq, _ = q.shape
     Lk = k.shape[2]
+    if q.dtype == torch.float32:        # fp32 parity mode: one slow VALU kernel, f32 gradients (no dropout in this mode)
+        assert drop is None and ctx.is_contiguous() and d_ctx.is_contiguous() and d_ctx.dtype == torch.float32
+        assert dq_out.dtype == dk_out.dtype == dv_out.dtype == torch.float32 and dk_out.stride(0) == dv_out.stride(0)
+        check(lib().asr_attention_bwd_f32(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(dq_out), dq_out.stride(0),
+                                          _p(dk_out), _p(dv_out), dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0,
+                                          float(scale)), "asr_attention_bwd_f32")
+        return
     assert q.dtype == torch.bfloat16 and ctx.is_contiguous() and d_ctx.is_contiguous() and d_ctx.dtype == torch.bfloat16
     assert dk_out.stride(0) == dv_out.stride(0) and dq_out.stride(1) == 1 and dk_out.stride(1) == 1
     delta = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32)

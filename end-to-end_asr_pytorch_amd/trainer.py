@@ -232,7 +232,7 @@ class Trainer:
             with modules.record() as side_tape:
                 logits = modules._vocab_proj(model, "ctc", model.ctc_fc.weight, proxy)
             ctc, nll, st = ops.ctc_loss_fwd(logits.view(enc.B, enc.L, -1), ops.as_i32(lens, logits.device), ctc_targets)
-            model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, torch.ones(1, device=logits.device), bf16=True)
+            model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, torch.ones(1, device=logits.device), bf16=(modules.get_precision() == "bf16"))
             side_tape.backward()
         self._side = {"ctc": ctc, "st": st}
         params = (model.ctc_fc.weight,)
@@ -341,14 +341,14 @@ class Trainer:
         one = torch.ones(1, device=self.fp.flat.device)
         with torch.no_grad():
             if logits is None:     # CTC_Model: the CTC loss is the whole objective
-                model.decoder._grad_slots["prj"]["g"] = ops.ctc_loss_bwd(st, one, bf16=True)
+                model.decoder._grad_slots["prj"]["g"] = ops.ctc_loss_bwd(st, one, bf16=(modules.get_precision() == "bf16"))
                 self.buckets.start()
                 tape.backward(lambda fn: self.buckets.on_done(fn.params))
                 self.buckets.finish()
                 return
             # loss = ctc + ce (solver.py:88): both seeds are 1
             if st is not None:
-                model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one, bf16=True)
+                model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, one, bf16=(modules.get_precision() == "bf16"))
             V = logits.shape[-1]
             ce_seed = one
             if self._nw_handle is not None:    # gradient of the global-batch CE mean: seed = world * n_word_local / n_word_global
@@ -356,7 +356,7 @@ class Trainer:
                 h.wait()
                 ce_seed = loss2[1:2] * (float(self.world) / nw)
                 self._nw_handle = None
-            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, ce_seed, bf16=True)
+            model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, ce_seed, bf16=(modules.get_precision() == "bf16"))
             if d_num is not None:
                 model._grad_slots["num"]["g"] = d_num
             self.buckets.start()

@@ -143,6 +143,14 @@ int asr_attention_bwd_dkv(void* stream, const void* q, const void* k, const void
                           const float* delta, void* dk, void* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
                           const int32_t* k_len, int causal, asr_dropout_t drop, const uint32_t* drop_bits);
 
+/* The fp32 parity-mode backward (partner of asr_attention_fwd with f32 operands): q (scaled as for the forward), k, v f32
+ * [B,h,L,64]; o, d_o f32 token-major [B,Lq,h*64]; dq / dk / dv f32 token-major with row strides ldq / ldkv, same meaning as
+ * asr_attention_bwd's outputs.  No dropout (the f32 mode runs in eval mode / with dropout 0).  A slow VALU kernel with float
+ * atomics: it lets the whole backward tape run in fp32 so that gradients compare with the reference's at 1e-4. */
+int asr_attention_bwd_f32(void* stream, const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                          const float* lse, float* dq, int64_t ldq, float* dk, float* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
+                          const int32_t* k_len, int causal, float scale);
+
 /* asr_gemm_add_layernorm: the same fused block as asr_gemm_add_layernorm_small below for any M (encoder-sized rows: a persistent
  * kernel of 128 x 256 tiles, K % 64 == 0, outputs through full-cache-line stores).
  * Decoder-sized rows (M = B*L of a few thousand): the projection and the residual + LayerNorm after it in ONE launch,
