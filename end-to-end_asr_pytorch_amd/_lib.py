@@ -56,6 +56,7 @@ SIGNATURES = {
     "asr_conv_sub1_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_conv_im2col": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_conv_col2im_relu": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
+    "asr_conv_col2im_relu_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],
     "asr_ctc_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "asr_ctc_counter_words": [_i, _i, _i],

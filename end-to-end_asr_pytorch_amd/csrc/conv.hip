@@ -185,8 +185,10 @@ __global__ __launch_bounds__(256) void conv_im2col_vec8_kernel(const bf16_t* __r
 
 // col2im (gather form) + ReLU mask: dx[b,ti,fi,c] = (y[b,ti,fi,c] > 0) * sum_{kh,kw} dcol[(b,(ti-kh)/2,fi-kw), tap*32 + c]
 // over taps with (ti-kh) even, 0 <= (ti-kh)/2 < Tout, 0 <= fi-kw < Fout.  One thread per (position, 4 channels).
-__global__ __launch_bounds__(256) void conv_col2im_kernel(const bf16_t* __restrict__ dcol, int ldc, const bf16_t* __restrict__ y,
-                                                          bf16_t* __restrict__ dx, int Tin, int Fin, int Tout, int Fout, int64_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void conv_col2im_kernel(const T* __restrict__ dcol, int ldc, const T* __restrict__ y,
+                                                          T* __restrict__ dx, int Tin, int Fin, int Tout, int Fout, int64_t total) {
+    typedef T vec4 __attribute__((ext_vector_type(4)));
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c4 = (int)(i & 7) * 4;
@@ -203,15 +205,15 @@ __global__ __launch_bounds__(256) void conv_col2im_kernel(const bf16_t* __restri
         for (int kw = 0; kw < 3; ++kw) {
             const int f = fi - kw;
             if (f < 0 || f >= Fout) continue;
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>(dcol + (((int64_t)b * Tout + t) * Fout + f) * ldc + (kh * 3 + kw) * 32 + c4);
+            const vec4 v = *reinterpret_cast<const vec4*>(dcol + (((int64_t)b * Tout + t) * Fout + f) * ldc + (kh * 3 + kw) * 32 + c4);
             acc += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
         }
     }
-    const bf16x4 yv = *reinterpret_cast<const bf16x4*>(y + pos * 32 + c4);
-    bf16x4 o;
+    const vec4 yv = *reinterpret_cast<const vec4*>(y + pos * 32 + c4);
+    vec4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (bf16_t)(((float)yv[e] > 0.f) ? acc[e] : 0.f);
-    *reinterpret_cast<bf16x4*>(dx + pos * 32 + c4) = o;
+    for (int e = 0; e < 4; ++e) o[e] = (T)(((float)yv[e] > 0.f) ? acc[e] : 0.f);
+    *reinterpret_cast<vec4*>(dx + pos * 32 + c4) = o;
 }
 
 }  // namespace
@@ -246,9 +248,19 @@ extern "C" int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, con
                                     int Fout) {
     ASR_REQUIRE(dcol && y && dx && B > 0 && ldc >= 288 && ldc % 4 == 0, ASR_ERR_ARG, "col2im: bad args");
     const int64_t total = (int64_t)B * Tin * Fin * 8;
-    hipLaunchKernelGGL(conv_col2im_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(conv_col2im_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        (const bf16_t*)dcol, ldc, (const bf16_t*)y, (bf16_t*)dx, Tin, Fin, Tout, Fout, total);
     ASR_LAUNCH_CHECK("conv_col2im");
+    return 0;
+}
+
+extern "C" int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const float* y, float* dx, int B, int Tin, int Fin, int Tout,
+                                        int Fout) {
+    ASR_REQUIRE(dcol && y && dx && B > 0 && ldc >= 288 && ldc % 4 == 0, ASR_ERR_ARG, "col2im_f32: bad args");
+    const int64_t total = (int64_t)B * Tin * Fin * 8;
+    hipLaunchKernelGGL(conv_col2im_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dcol,
+                       ldc, y, dx, Tin, Fin, Tout, Fout, total);
+    ASR_LAUNCH_CHECK("conv_col2im_f32");
     return 0;
 }
 

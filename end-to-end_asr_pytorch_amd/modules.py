@@ -651,8 +651,6 @@ class Conv2dSubsample(_Cached):
         return act, lens.to(torch.int32)
 
     def _record_bw(self, feats, ys, tneed, fneed, act, wp, y_last):
-        if _PRECISION != "bf16":
-            raise NotImplementedError("Conv2dSubsample's backward (patch-matrix GEMMs) runs on the bf16 path only")
         n, F, aff = self.n_layers, self.d_conv_out, self.affine
         B, T, D = feats.shape
         convs = [getattr(self.conv, "subsample/conv{}".format(i)) for i in range(n)]
@@ -664,18 +662,20 @@ class Conv2dSubsample(_Cached):
             dwp = ops.gemm_tn(d_out, y_last)                                        # [d, F*32] in the permuted column order
             ops.add_transposed_(aff.weight.grad, dwp, d, 32, F)                      # affine weight columns are c*F + f (conv_encoder.py:108)
             ops.colsum(d_out, out=aff.bias.grad, accumulate=True)
-            dy = ops.gemm_nn(d_out, wp, out_dtype=torch.bfloat16, relu_mask=y_last)  # [M, F*32] = channel-last d(y_last), ReLU applied
+            cdt = _cdtype()
+            dy = ops.gemm_nn(d_out, wp, out_dtype=cdt, relu_mask=y_last)  # [M, F*32] = channel-last d(y_last), ReLU applied
             for i in range(n - 1, 0, -1):
                 cv = convs[i]
                 tout, fout = tneed[i], fneed[i]
                 dy2 = dy.view(-1, 32)
-                col = ops.conv_im2col(ys[i - 1], 32, tout, fout, 288, torch.bfloat16)
+                col = ops.conv_im2col(ys[i - 1], 32, tout, fout, 288, cdt)
                 dwm = ops.gemm_tn(dy2, col)                                         # [co, tap*32 + ci]
                 ops.add_transposed_(cv.weight.grad, dwm, 32, 32, 9)                 # nn.Conv2d weight is [co, ci, 3, 3]
                 ops.colsum(dy2, out=cv.bias.grad, accumulate=True)
                 wm = self._derived("wm%d" % i, (cv.weight,),
-                                   lambda cv=cv: ops.cast_bf16(cv.weight.detach().permute(0, 2, 3, 1).reshape(32, 288).contiguous()))
-                dcol = ops.gemm_nn(dy2, wm, out_dtype=torch.bfloat16)
+                                   lambda cv=cv: (ops.cast_bf16 if _PRECISION == "bf16" else (lambda t: t.float()))(
+                                       cv.weight.detach().permute(0, 2, 3, 1).reshape(32, 288).contiguous()))
+                dcol = ops.gemm_nn(dy2, wm, out_dtype=cdt)
                 dy = ops.conv_col2im_relu(dcol, ys[i - 1], tout, fout)              # [B,Tin,Fin,32], masked by relu'(y_{i-1})
             dy2 = dy.view(-1, 32)
             col0 = ops.conv_im2col(feats.view(B, T, D, 1), 1, tneed[0], fneed[0], 12, torch.float32)

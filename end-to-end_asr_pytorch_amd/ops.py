@@ -859,6 +859,11 @@ def conv_col2im_relu(dcol, y, Tout, Fout):
     """dcol bf16 [B*Tout*Fout, 288(+pad)], y bf16 [B,Tin,Fin,32] (forward output, ReLU mask) -> dx bf16 [B,Tin,Fin,32]."""
     B, Tin, Fin, _ = y.shape
     dx = torch.empty_like(y)
+    assert dcol.dtype == y.dtype and y.is_contiguous()
+    if y.dtype == torch.float32:       # fp32 parity mode
+        check(lib().asr_conv_col2im_relu_f32(_stream(), _p(dcol), dcol.stride(0), _p(y), _p(dx), B, Tin, Fin, Tout, Fout),
+              "asr_conv_col2im_relu_f32")
+        return dx
     check(lib().asr_conv_col2im_relu(_stream(), _p(dcol), dcol.stride(0), _p(y), _p(dx), B, Tin, Fin, Tout, Fout), "asr_conv_col2im_relu")
     return dx
 

@@ -234,6 +234,9 @@ int asr_conv_im2col(void* stream, const void* x, int x_dtype, int C, void* col, 
                     int Tout, int Fout);
 int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y, void* dx, int B, int Tin, int Fin, int Tout,
                          int Fout);
+/* ... in the fp32 parity mode (dcol, y, dx f32). */
+int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const float* y, float* dx, int B, int Tin, int Fin, int Tout,
+                             int Fout);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CTC loss (loss.py:41-43 / ctcModel/loss.py:9-11: F.log_softmax(dim=-1) -> F.ctc_loss(blank=V-1)).
