@@ -78,6 +78,8 @@ SIGNATURES = {
     "asr_log_softmax_rows": [_vp, _vp, _i64, _i, _i, _vp, _i64],
     "asr_ctc_greedy_reduce": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "asr_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
+    "asr_topk_rows": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
+    "asr_beam_prune": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "asr_decode_embed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_kv_cache_put": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_decode_advance": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],

@@ -131,6 +131,74 @@ __global__ __launch_bounds__(256) void decode_advance_kernel(const int64_t* __re
     }
 }
 
+
+// ---- beam search (decoder.py:166-234) ---------------------------------------------------------------------------------------------
+// torch.topk(x, k, sorted=True) over the rows of x [M, V]: k passes of "largest (value, lowest index) strictly after the previous
+// pick in (value desc, index asc) order" - one wavefront per row; V is the vocabulary (or beam * beam), k the beam size.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, int64_t ld, int M, int V, int k, float* __restrict__ vals,
+                                                        int64_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * ld;
+    float lastv = INFINITY;
+    int lasti = -1;
+    for (int j = 0; j < k; ++j) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < V; c += 64) {
+            const float v = xr[c];
+            const bool after = (v < lastv) || (v == lastv && c > lasti);          // not picked yet
+            if (after && (bi == 0x7fffffff || v > best)) { best = v; bi = c; }     // first maximum of this lane's columns
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > best || (v2 == best && i2 < bi))) { best = v2; bi = i2; }
+        }
+        if (lane == 0) {
+            vals[row * k + j] = bi == 0x7fffffff ? -INFINITY : best;
+            idx[row * k + j] = bi == 0x7fffffff ? 0 : bi;
+        }
+        lastv = best;
+        lasti = bi;
+    }
+}
+
+// One pruning step (decoder.py:196-209) per utterance: candidates c = parent * beam + j with score scores[parent] + next_scores[parent][j]
+// (an f32 add, like the reference's broadcast add), the best `beam` of the beam * beam in sorted order -> their scores, parent ROWS
+// (k_indices // beam_size, global row ids) and tokens.  One wavefront per utterance, lane = candidate (beam * beam <= 64).
+__global__ __launch_bounds__(64) void beam_prune_kernel(const float* __restrict__ scores, const float* __restrict__ next_scores,
+                                                        const int64_t* __restrict__ next_preds, int beam, float* __restrict__ new_scores,
+                                                        int64_t* __restrict__ parent, int64_t* __restrict__ new_tok) {
+    const int b = blockIdx.x, lane = threadIdx.x, nc = beam * beam;
+    const int row = b * beam + lane / beam;
+    const float v = lane < nc ? scores[row] + next_scores[(int64_t)b * nc + lane] : -INFINITY;
+    const int64_t tok = lane < nc ? next_preds[(int64_t)b * nc + lane] : 0;
+    float lastv = INFINITY;
+    int lasti = -1;
+    for (int j = 0; j < beam; ++j) {
+        const bool after = lane < nc && ((v < lastv) || (v == lastv && lane > lasti));
+        float best = after ? v : -INFINITY;
+        int bi = after ? lane : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > best || (v2 == best && i2 < bi))) { best = v2; bi = i2; }
+        }
+        if (bi == 0x7fffffff) bi = 0;                               // (fewer than `beam` candidates cannot happen: nc >= beam)
+        if (lane == bi) {
+            new_scores[b * beam + j] = v;
+            parent[b * beam + j] = row;
+            new_tok[b * beam + j] = tok;
+        }
+        lastv = best;
+        lasti = bi;
+    }
+}
+
 }  // namespace
 
 extern "C" int asr_argmax_rows(void* stream, const float* x, int64_t ld, int M, int V, int64_t* out) {
@@ -184,5 +252,22 @@ extern "C" int asr_decode_advance(void* stream, const int64_t* cur, int64_t* pre
     hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), cur, preds, state, k_len, finished,
                        len_decoded, eos, B, Tp1);
     ASR_LAUNCH_CHECK("decode_advance");
+    return 0;
+}
+
+extern "C" int asr_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx) {
+    ASR_REQUIRE(x && vals && idx && M > 0 && V > 0 && k > 0 && k <= V, ASR_ERR_ARG, "topk_rows: bad args (M=%d V=%d k=%d)", M, V, k);
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, M, V, k, vals, idx);
+    ASR_LAUNCH_CHECK("topk_rows");
+    return 0;
+}
+
+extern "C" int asr_beam_prune(void* stream, const float* scores, const float* next_scores, const int64_t* next_preds, int B, int beam,
+                              float* new_scores, int64_t* parent, int64_t* new_tok) {
+    ASR_REQUIRE(scores && next_scores && next_preds && new_scores && parent && new_tok && B > 0, ASR_ERR_ARG, "beam_prune: bad args");
+    ASR_REQUIRE(beam >= 1 && beam * beam <= 64, ASR_ERR_UNSUPPORTED, "beam_prune: beam_size %d (beam * beam must fit one wavefront)", beam);
+    hipLaunchKernelGGL(beam_prune_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), scores, next_scores, next_preds, beam,
+                       new_scores, parent, new_tok);
+    ASR_LAUNCH_CHECK("beam_prune");
     return 0;
 }

@@ -1012,6 +1012,36 @@ class Decoder(_Cached):
         len_decoded = dg["len_decoded"].to(len_encoded.dtype) - (1 - fin)      # for decoded length cut by encoded length (decoder.py:161)
         return dg["preds"][:, 1:steps + 1].clone(), len_decoded, torch.zeros(0)
 
+    @torch.no_grad()
+    def batch_beam_decode(self, encoded, len_encoded, beam_size=1, max_decode_len=100):
+        """decoder.py:166-234 - beam search over a batch -> (preds int64 [B, beam, steps], len_decoded [B, beam], scores f32 [B, beam]),
+        beams sorted by score.  Like the reference every step recomputes the whole prefix (`step`), the initial scores are
+        [0, -1e10, ...] per utterance, and `finished` / `len_decoded` stay with the beam SLOT when the beams are re-gathered.
+        top-k over the vocabulary and the beam * beam pruning are HIP kernels (asr_topk_rows, asr_beam_prune); what torch does
+        here is integer bookkeeping on [B * beam] / [B * beam, steps] tensors."""
+        B, beam = len_encoded.size(0), int(beam_size)
+        dev = encoded.device
+        enc = encoded[:, None].repeat(1, beam, 1, 1).view(B * beam, -1, encoded.size(-1))
+        lens = len_encoded[:, None].repeat(1, beam).view(-1)
+        preds = torch.full((B * beam, 1), self.sos_id, dtype=torch.long, device=dev)
+        len_decoded = torch.ones_like(lens)
+        scores = torch.tensor([0.0] + [-1e10] * (beam - 1), dtype=torch.float32, device=dev).repeat(B)
+        finished = torch.zeros(B * beam, dtype=torch.bool, device=dev)
+        for _ in range(int(max_decode_len)):
+            z = ops.log_softmax_rows(self.step(preds, enc, lens))            # (decoder.py:191 applies log_softmax to step's log-probs again)
+            next_scores, next_preds = ops.topk_rows(z, beam)
+            scores, parent, nxt = ops.beam_prune(scores, next_scores, next_preds, beam)
+            preds = torch.cat([preds[parent], nxt[:, None]], 1)
+            finished = torch.logical_or(finished, nxt.eq(self.eos_id))
+            len_decoded = len_decoded + (1 - finished.to(len_decoded.dtype))
+            if bool(finished.all()):
+                break
+        len_decoded = len_decoded - (1 - finished.to(len_decoded.dtype))
+        preds = preds[:, 1:]
+        scores_sorted, order = ops.topk_rows(scores.view(B, beam), beam)
+        order = (torch.arange(B, device=dev)[:, None] * beam + order).view(-1)
+        return preds[order].view(B, beam, -1), len_decoded[order].view(B, beam), scores_sorted
+
     def _build_decode_graph(self, B, L, T, dev, key):
         n, h = len(self.layer_stack), self.n_head
         cdt = _cdtype()

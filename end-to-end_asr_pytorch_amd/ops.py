@@ -705,6 +705,32 @@ def argmax_rows(x2d, out=None):
     return out
 
 
+def topk_rows(x2d, k):
+    """torch.topk(x, k, sorted=True) over the last dim of f32 [M, V] -> (values f32 [M, k], indices int64 [M, k]); ties in index order"""
+    _req_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype == torch.float32
+    M, V = x2d.shape
+    vals = torch.empty((M, k), device=x2d.device, dtype=torch.float32)
+    idx = torch.empty((M, k), device=x2d.device, dtype=torch.int64)
+    check(lib().asr_topk_rows(_stream(), _p(x2d), x2d.stride(0), M, V, int(k), _p(vals), _p(idx)), "asr_topk_rows")
+    return vals, idx
+
+
+def beam_prune(scores, next_scores, next_preds, beam):
+    """decoder.py:196-209: scores f32 [B*beam], next_scores f32 / next_preds int64 [B*beam, beam] -> (new scores [B*beam],
+    parent rows int64 [B*beam], new tokens int64 [B*beam])"""
+    _req_cuda(scores, next_scores, next_preds)
+    n = scores.numel()
+    B = n // beam
+    assert scores.is_contiguous() and next_scores.is_contiguous() and next_preds.is_contiguous() and next_scores.shape == (n, beam)
+    ns = torch.empty(n, device=scores.device, dtype=torch.float32)
+    parent = torch.empty(n, device=scores.device, dtype=torch.int64)
+    tok = torch.empty(n, device=scores.device, dtype=torch.int64)
+    check(lib().asr_beam_prune(_stream(), _p(scores), _p(next_scores), _p(next_preds), B, int(beam), _p(ns), _p(parent), _p(tok)),
+          "asr_beam_prune")
+    return ns, parent, tok
+
+
 def decode_embed(cur, emb, pe, state, want_bf16=False):
     """x[b] = emb[cur[b]] + pe[state[0]] -> (y32 [B, D], y16 or None): the decoder input of the one new position, position on the device"""
     _req_cuda(cur, emb, pe, state)

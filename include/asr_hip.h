@@ -338,6 +338,13 @@ int asr_spec_aug(void* stream, float* x, const int32_t* len, int B, int T, int V
 int asr_argmax_rows(void* stream, const float* x, int64_t ld, int M, int V, int64_t* out);
 int asr_log_softmax_rows(void* stream, const float* x, int64_t ldx, int M, int V, float* y, int64_t ldy);
 int asr_ctc_greedy_reduce(void* stream, const int64_t* frames, const int32_t* len, int B, int L, int blank, int64_t* out, int32_t* out_len);
+/* Beam search (decoder.py:166-234).  asr_topk_rows: torch.topk(x, k, sorted=True) over the rows of x f32 [M, V] (row stride ld):
+ * vals f32 [M, k], idx int64 [M, k], equal values in index order.  asr_beam_prune: the pruning of decoder.py:196-209 - per
+ * utterance the best `beam` of the beam * beam candidates scores[parent] + next_scores[parent][j] -> their scores, parent rows
+ * (k_indices // beam_size as global row ids into [B * beam]) and tokens next_preds[parent][j]; beam * beam <= 64. */
+int asr_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx);
+int asr_beam_prune(void* stream, const float* scores, const float* next_scores, const int64_t* next_preds, int B, int beam,
+                   float* new_scores, int64_t* parent, int64_t* new_tok);
 /* The per-token step of Decoder.batch_decode (decoder.py:138-164) with its position in device memory, so that the whole step is
  * one capturable launch sequence (hipGraph replay per token).  state int32[2]: [0] = t, the position of the token being fed
  * (0 = <sos>), [1] = the number of steps after which every row had produced <eos>, -1 until then.

@@ -590,6 +590,60 @@ def ctc_greedy(frame_tokens, lengths, blank):
     return out
 
 
+def decoder_step(sd, pfx, prefixs, enc_out, enc_lengths, n_layers, n_head):
+    """src/transformer/decoder.py:98-120 - log-softmax scores of the next token; every prefix position counts (no pad mask)."""
+    prefixs = np.asarray(prefixs).astype(np.int64)
+    U = prefixs.shape[1]
+    slf_mask = get_subsequent_mask(prefixs) > 0
+    cross_mask = get_attn_pad_mask(enc_lengths, U)
+    d = sd[pfx + "tgt_word_emb.weight"].shape[1]
+    x = sd[pfx + "tgt_word_emb.weight"][prefixs].astype(F32) + positional_encoding(U, d)[None]
+    for i in range(n_layers):
+        lp = f"{pfx}layer_stack.{i}."
+        x = multihead_attention(sd, lp + "slf_attn.", x, x, x, slf_mask, n_head)
+        x = multihead_attention(sd, lp + "enc_attn.", x, enc_out, enc_out, cross_mask, n_head)
+        x = positionwise_ffn(sd, lp + "pos_ffn.", x)
+    return log_softmax(linear(x[:, -1], sd[pfx + "tgt_word_prj.weight"]))
+
+
+def _topk(x, k):
+    """torch.topk(sorted=True) over the last dim; ties to the lower index -> (values, indices)"""
+    idx = np.argsort(-x, axis=-1, kind="stable")[..., :k]
+    return np.take_along_axis(x, idx, -1), idx
+
+
+def batch_beam_decode(sd, pfx, enc_out, enc_lengths, n_layers, n_head, sos_id, eos_id, beam_size, max_decode_len):
+    """src/transformer/decoder.py:166-234.  Restated with its quirks: the initial scores are [0, -1e10, ...] (`inf = 1e10`, :10),
+    every step recomputes the whole prefix, `finished` and `len_decoded` belong to the beam SLOT (they are not re-gathered with the
+    beams at :204-209), finished beams keep being extended.  -> (preds [B, beam, steps], len_decoded [B, beam], scores [B, beam])"""
+    B = len(enc_lengths)
+    enc = np.repeat(np.asarray(enc_out)[:, None], beam_size, 1).reshape(B * beam_size, *np.asarray(enc_out).shape[1:])
+    lens = np.repeat(np.asarray(enc_lengths)[:, None], beam_size, 1).reshape(-1)
+    preds = np.full((B * beam_size, 1), sos_id, np.int64)
+    len_decoded = np.ones(B * beam_size, np.int64)
+    scores = np.tile(np.array([0.0] + [-1e10] * (beam_size - 1), F32), B)
+    finished = np.zeros(B * beam_size, bool)
+    base = np.repeat(np.arange(B), beam_size)
+    for _ in range(max_decode_len):
+        z = log_softmax(decoder_step(sd, pfx, preds, enc, lens, n_layers, n_head))
+        next_scores, next_preds = _topk(z, beam_size)
+        cand = (scores[:, None] + next_scores).astype(F32).reshape(B, beam_size * beam_size)
+        _, k_idx = _topk(cand, beam_size)
+        k_idx = base * beam_size * beam_size + k_idx.reshape(-1)
+        scores = cand.reshape(-1)[k_idx]
+        nxt = next_preds.reshape(-1)[k_idx]
+        preds = np.concatenate([preds[k_idx // beam_size], nxt[:, None]], 1)
+        finished = finished | (nxt == eos_id)
+        len_decoded = len_decoded + 1 - finished.astype(np.int64)
+        if finished.all():
+            break
+    len_decoded = len_decoded - (1 - finished.astype(np.int64))
+    preds = preds[:, 1:]
+    s_sorted, order = _topk(scores.reshape(B, beam_size), beam_size)
+    order = base * beam_size + order.reshape(-1)
+    return preds[order].reshape(B, beam_size, -1), len_decoded[order].reshape(B, beam_size), s_sorted
+
+
 def lfr(inputs, m, n):
     """src/utils/data.py:191-218 - stack m frames every n frames; the last frame repeats past the end."""
     T = len(inputs)

@@ -549,6 +549,33 @@ def g11_mask_lm():
     print("G11 ce", float(ce), "ctc", float(ctc), "masked", int(mask.sum()), "of", B * T, "none is", none)
 
 
+def g12_beam_decode():
+    """Decoder.batch_beam_decode (decoder.py:166-234): beam search over a batch with the full prefix recomputed per step
+    (Decoder.step), scores initialised to [0, -1e10, ...] per utterance (`inf = 1e10`, decoder.py:10), pruning by top-k over
+    beam * beam candidates, `finished` / `len_decoded` kept per beam SLOT (they are not re-gathered with the beams), final sort."""
+    orig_mask = tdec.get_subsequent_mask
+    tdec.get_subsequent_mask = lambda seq: orig_mask(seq).bool()     # same harness shim as G9
+    args = argparse.Namespace(**S0)
+    model = Conv_CTC_Transformer.create_model(args).eval()
+    ns, sd = load_seeded(model, seed=109)
+    x, lens, tg = s0_batch(seed=9)
+    out = {}
+    with torch.no_grad():
+        conv_out, len_seq = model.conv_encoder(x, lens)
+        enc_out = model.encoder(conv_out, len_seq)
+        for beam, T, eos in ((3, 8, S0["eos_id"]), (3, 8, 14), (2, 6, 39), (1, 5, S0["eos_id"]), (4, 7, 47)):
+            model.decoder.eos_id = eos
+            p, l, sc = model.decoder.batch_beam_decode(enc_out, len_seq, beam_size=beam, max_decode_len=T)
+            tag = "b%d_T%d_eos%d" % (beam, T, eos)
+            out["preds_" + tag], out["len_" + tag], out["scores_" + tag] = npy(p), npy(l), npy(sc)
+            print("G12", tag, npy(p)[0].tolist(), npy(l)[0].tolist(), npy(sc)[0].tolist())
+        model.decoder.eos_id = S0["eos_id"]
+    tdec.get_subsequent_mask = orig_mask
+    np.savez_compressed(os.path.join(HERE, "g12_beam_decode.npz"), names_shapes=names_shapes_to_json(ns), seed=109, crc=crc_of(sd),
+                        enc_out=npy(enc_out), enc_len=npy(len_seq), cases="3,8,%d|3,8,14|2,6,39|1,5,%d|4,7,47" % (S0["eos_id"], S0["eos_id"]),
+                        **out, **cfg_arrays())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g0_conv_ctc_transformer()
@@ -563,3 +590,4 @@ if __name__ == "__main__":
     g9_decode()
     g10_input_pipeline()
     g11_mask_lm()
+    g12_beam_decode()

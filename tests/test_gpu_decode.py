@@ -120,3 +120,31 @@ def test_graph_replayed_decode_step_equals_the_eager_step(golden_dir, monkeypatc
     assert model.decoder.__dict__["_decode_graph"] is dg
     np.testing.assert_array_equal(p_a.cpu().numpy(), a0)        # (the first result is not the replay's scratch)
     np.testing.assert_array_equal(p_b.cpu().numpy(), a0[::-1])
+
+
+def test_batch_beam_decode_matches_the_reference(golden_dir):
+    """decoder.py:166-234 against the reference's own beams (G12: five beam-size / eos settings, beams that finish at different
+    steps, the slot-bound `finished` / `len_decoded` quirk): tokens and lengths exact, scores to fp32 tolerance."""
+    z = np.load(os.path.join(golden_dir, "g12_beam_decode.npz"))
+    _, cfg, model = load(golden_dir)                       # same seeded weights as G9
+    enc, enc_len = torch.from_numpy(z["enc_out"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV)
+    with asr_amd.precision("f32"):
+        for case in str(z["cases"]).split("|"):
+            beam, T, eos = (int(v) for v in case.split(","))
+            tag = "b%d_T%d_eos%d" % (beam, T, eos)
+            model.decoder.eos_id = eos
+            p, l, sc = model.decoder.batch_beam_decode(enc, enc_len, beam_size=beam, max_decode_len=T)
+            np.testing.assert_array_equal(p.cpu().numpy(), z["preds_" + tag])
+            np.testing.assert_array_equal(l.cpu().numpy(), z["len_" + tag])
+            np.testing.assert_allclose(sc.cpu().numpy(), z["scores_" + tag], rtol=1e-5, atol=2e-4)
+    model.decoder.eos_id = cfg["eos_id"]
+    # top-k kernel against torch.topk on rows without ties, and its tie order (index order)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 4234, generator=g).to(DEV)
+    v, i = asr_amd.ops.topk_rows(x, 5)
+    tv, ti = torch.topk(x, 5, sorted=True)
+    np.testing.assert_array_equal(i.cpu().numpy(), ti.cpu().numpy())
+    np.testing.assert_array_equal(v.cpu().numpy(), tv.cpu().numpy())
+    t = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, -1.0]], device=DEV)
+    v, i = asr_amd.ops.topk_rows(t, 4)
+    assert i.cpu().tolist() == [[1, 2, 4, 3]] and v.cpu().tolist() == [[3.0, 3.0, 3.0, 2.0]]
