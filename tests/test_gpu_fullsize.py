@@ -1,5 +1,7 @@
 """Size-independent properties at the BASELINE.json shapes (B=32, T=1000, U=50, V=4234, d_model=256): the oracle cannot run
 these sizes in seconds, so the kernels are held to identities the arithmetic must satisfy at any size."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,3 +150,65 @@ def test_full_size_logits_match_the_oracle_on_two_utterances(which):
         bench.CFG.update(old)
     assert par["utterances"] == 2
     assert par["ctc_logits"] <= 6e-2 and par["logits"] <= 6e-2, par
+
+
+@pytest.mark.parametrize("which", ["s1", "s2"])
+def test_full_size_gradients_match_stock_torch_on_two_utterances(which):
+    """The whole training step's gradients at the benchmark models' FULL dimensions (d256/h4/enc12/dec6, V=4234, T=1000; S2 with the
+    conv front end) on 2 ragged utterances, against stock PyTorch CPU autograd (float64) of the reference's op sequence
+    (oracle/torch_cpu_ref.py, itself pinned on the reference's outputs and gradients): the fp32 parity mode to 1e-2 relative L2 per
+    parameter and 3e-3 over the whole gradient vector (the fp32 noise floor at 18 layers), the bf16 product path to its rounding floor.  Full-size shapes reach tile edges the S0 fixtures cannot (L = 1000 =
+    7 x 128 + 104 rows, V = 4234 = 33 x 128 + 10 columns, 863 valid frames in the second utterance)."""
+    import bench
+    from oracle import torch_cpu_ref as R
+    old = dict(bench.CFG)
+    try:
+        bench.CFG["n_conv_layers"] = 2 if which == "s2" else 0
+        dev = torch.device(DEV)
+        model = bench.build_model(asr_amd, dev, 0.0, train=True)
+        x, lens, tg = bench.make_batch(dev, seed=0, ragged=True)
+        x, lens, tg = x[:2].contiguous(), lens[:2].clone(), tg[:2].contiguous()
+        T = bench.CFG["T"]
+        lens[:] = torch.tensor([T, T - 137], device=DEV)
+        x[1, T - 137:] = 0
+        cfg = dict(n_head=bench.CFG["n_head"], n_layers_enc=bench.CFG["n_layers_enc"], n_layers_dec=bench.CFG["n_layers_dec"],
+                   sos_id=bench.CFG["sos_id"], eos_id=bench.CFG["eos_id"])
+        # float64 on the CPU: at this depth two fp32 evaluations differ by 1-2e-3 in the whole gradient vector (tools/f32_noise_floor.py:
+        # torch CPU fp32 is 1.8e-3 from the f64 result, this repo's f32 mode 1.2e-3), so the arbiter has to be more exact than both
+        sd = {k: v.detach().cpu().double().requires_grad_(not k.endswith(".pe")) for k, v in model.state_dict().items()}
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+        ctc_ref, ce_ref, _, _ = R.joint_step(sd, x.cpu().double(), lens.cpu(), tg.cpu(), cfg, conv_layers=bench.CFG["n_conv_layers"], p=0.0,
+                                             train=False, smoothing=0.1, backward=True)
+        ctc_ref, ce_ref = float(ctc_ref.detach()), float(ce_ref.detach())
+        ref = {k: v.grad.double().numpy() for k, v in sd.items() if v.requires_grad and v.grad is not None}
+        assert len(ref) > 200
+        out = {}
+        for prec in ("f32", "bf16"):
+            with asr_amd.precision(prec):
+                tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+                tr.fp.grad.zero_()
+                ctc, ce, state = tr.forward_loss(x, lens, tg)
+                tr.backward(state)
+                torch.cuda.synchronize()
+                errs = []
+                for name, p in model.named_parameters():
+                    g, r = p.grad.detach().double().cpu().numpy(), ref[name]
+                    errs.append((float(np.linalg.norm(g - r)), float(np.linalg.norm(r)), name))
+                out[prec] = (float(ctc), float(ce), errs)
+    finally:
+        bench.CFG.clear()
+        bench.CFG.update(old)
+    for prec, ltol, gtol, atol in (("f32", 1e-5, 1e-2, 1e-5), ("bf16", 1e-2, 1.2e-1, 2e-3)):
+        ctc, ce, errs = out[prec]
+        np.testing.assert_allclose(ctc, float(ctc_ref), rtol=ltol)
+        np.testing.assert_allclose(ce, float(ce_ref), rtol=ltol)
+        # (bf16: with random weights attention over 1000 keys is nearly flat, the w_qs / w_ks gradients have norms of 0.02-0.07 beside
+        # 10-16 for the other matrices and carry the rounding of everything upstream: they are held to an absolute bound instead)
+        big = max(r for e, r, n in errs)
+        bad = [(e, r, n) for e, r, n in errs if e > gtol * r and e > (atol if prec == "f32" else 2.5e-3 * big)]
+        assert not bad, (prec, bad[:8])
+    # the whole gradient vector: f32 to 3e-3, bf16 to 6 % (measured: S1 < 4 %, S2 with its bf16 conv stack 5.0 %)
+    for prec, tol in (("f32", 3e-3), ("bf16", 6e-2)):
+        errs = out[prec][2]
+        tot_e, tot_r = np.sqrt(sum(e * e for e, r, n in errs)), np.sqrt(sum(r * r for e, r, n in errs))
+        assert tot_e <= tol * tot_r, (prec, tot_e, tot_r)
