@@ -237,7 +237,17 @@ class Trainer:
         self._side = {"ctc": ctc, "st": st}
         params = (model.ctc_fc.weight,)
 
+        seg = self.__dict__.get("_seg_events")      # tools/step_segments.py: GPU time of the decoder segment (encoder forward's end ->
+        if seg is not None:                          # ... the point where the encoder's backward begins)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(main)
+            seg.append(("enc_fwd_end", e))
+
         def join():
+            if seg is not None:
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record(torch.cuda.current_stream())
+                seg.append(("enc_bwd_begin", e2))
             main_now = torch.cuda.current_stream()
             main_now.wait_stream(aux)
             g = proxy.grad
