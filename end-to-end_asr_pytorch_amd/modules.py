@@ -1420,11 +1420,16 @@ class CIF_Model(_Cached):
         # ---- recording: CIF with its backward closure (d_l arrives through cif_slot, d(_num) through the "num" slot) -----------------
         hidden = enc.view3()
         cur, rem, fire_idx, n_fire, n_label, tok = ops.cif_scan(alpha.float(), threshold, want_tok=True)
-        stats = torch.stack([n_label.max(), n_fire.max()]).tolist()
-        if stats[1] > stats[0]:
-            raise RuntimeError("cif: a row fires %d times but max round(sum alpha) is %d (cif_model.py:100)" % (stats[1], stats[0]))
+        umax = self.__dict__.get("_umax_hint")
+        if umax is None:       # the reference's own host sync (`.max()` used as a tensor size, cif_model.py:98)
+            stats = torch.stack([n_label.max(), n_fire.max()]).tolist()
+            if stats[1] > stats[0]:
+                raise RuntimeError("cif: a row fires %d times but max round(sum alpha) is %d (cif_model.py:100)" % (stats[1], stats[0]))
+            umax = int(stats[0])
+        # (trainer, longest target known: alpha was rescaled to sum to num +- 0.5 per row (cif_model.py:44-48), so round(sum alpha) = num
+        # and a row fires at most num times - max_label_len IS the longest target, no read-back)
         self.last_fire = (fire_idx, n_fire, n_label)
-        l = ops.cif_gather(hidden.float().contiguous(), cur, rem, fire_idx, n_fire, int(stats[0]))
+        l = ops.cif_gather(hidden.float().contiguous(), cur, rem, fire_idx, n_fire, int(umax))
         cif_slot = {"g": None}
         num_slot = {"g": None, "shape": tuple(_num.shape)}
         self.__dict__.setdefault("_grad_slots", {})["num"] = num_slot

@@ -284,9 +284,14 @@ class Trainer:
                 pre = model.decoder.preprocess(targets, umax=max_target_len)
             model.decoder.__dict__["_pre_hint"] = (targets, pre, ev)
             model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1], ev)
+        cif_hint = isinstance(model, modules.CIF_Model) and max_target_len is not None
+        if cif_hint:
+            model.__dict__["_umax_hint"] = int(max_target_len)
         try:
             return self._forward_loss(feats, lens, targets, noise)
         finally:
+            if cif_hint:
+                model.__dict__.pop("_umax_hint", None)
             if side_ok:
                 model.__dict__.pop("_ctc_hook", None)
                 model.decoder.__dict__.pop("_pre_hint", None)
@@ -411,7 +416,7 @@ class Trainer:
         if self.world > 1 and os.environ.get("ASR_AMD_GRAPH_DP", "0") != "1":
             return False          # collectives inside a captured step are opt-in (not measurable on the 1-GPU development box)
         m = self.model
-        return isinstance(m, modules.CTC_Transformer) and not isinstance(m, modules.CIF_Model) and modules.get_precision() == "bf16"
+        return isinstance(m, (modules.CTC_Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"
 
     def _sync_state(self, dev):
         """device step state <- host step counter (first use, or after eager steps / a checkpoint load moved it)"""

@@ -124,3 +124,30 @@ def test_step_auto_calibrates_once_and_stays_on_the_eager_trajectory(golden_dir)
     tb = asr_amd.Trainer(build(golden_dir)[1], k=0.2, warmup_steps=50, label_smoothing=0.1)
     tb.step_auto(x, lens, tg)
     assert tb.launch_mode == "eager" and tb.step_num == 1
+
+
+def test_cif_model_step_replays_from_a_graph(golden_dir):
+    """CIF family: with the longest target given the step has no host read-back (max_label_len = the longest target, cif_model.py:44-48
+    make round(sum alpha) = num) and is capturable; replayed steps follow the eager trajectory (same recorded noise)."""
+    import argparse
+    z = np.load(os.path.join(golden_dir, "g4_cif_model.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    cfg = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")}
+    asr_amd.set_precision("bf16")
+
+    def fresh():
+        m = asr_amd.CIF_Model.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return m.to(DEV).eval()
+    x, lens, tg, noise = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets", "noise"))
+    umax = int((tg != 0).sum(1).max())
+    te = asr_amd.Trainer(fresh(), k=0.2, warmup_steps=50, label_smoothing=0.1, lambda_qua=0.001)
+    tg_ = asr_amd.Trainer(fresh(), k=0.2, warmup_steps=50, label_smoothing=0.1, lambda_qua=0.001)
+    le, lg = [], []
+    for i in range(6):
+        le.append([float(v) for v in te.step(x, lens, tg, noise=noise)])                       # (reads max_label_len back, like the reference)
+        lg.append([float(v) for v in tg_.step_graphed(x, lens, tg, noise=noise, max_target_len=umax)])
+    assert tg_.graph_active(), tg_._graph_failed
+    np.testing.assert_allclose(np.array(lg), np.array(le), rtol=5e-3)
+    pe, pg = te.fp.flat.float().cpu().numpy(), tg_.fp.flat.float().cpu().numpy()
+    assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 2e-3

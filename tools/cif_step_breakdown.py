@@ -24,6 +24,13 @@ a.record()
 for _ in range(10): out = tr.step(x, lens, tg)
 b.record(); torch.cuda.synchronize()
 print("CIF_Model S2 train step: %.3f ms  (%.2f M frames/s)  losses %s" % (a.elapsed_time(b) / 10, B * T / (a.elapsed_time(b) / 10) / 1e3, [float(v) for v in out[:3]]))
+out = tr.step_auto(x, lens, tg, max_target_len=U)          # no host read-back in the step; eager vs hipGraph replay, calibrated
+torch.cuda.synchronize()
+a.record()
+for _ in range(10): out = tr.step_auto(x, lens, tg, max_target_len=U)
+b.record(); torch.cuda.synchronize()
+print("  with max_target_len, step_auto -> %s %s: %.3f ms  (%.2f M frames/s)  losses %s" % (tr.launch_mode, tr.launch_timing, a.elapsed_time(b) / 10, B * T / (a.elapsed_time(b) / 10) / 1e3, [float(v) for v in out[:3]]))
+tr._graph = None
 ops.profile_start()
 for _ in range(5): tr.step(x, lens, tg)
 prof = ops.profile_stop()
