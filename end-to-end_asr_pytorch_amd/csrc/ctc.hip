@@ -95,61 +95,36 @@ __device__ __forceinline__ void ctc_row_stream(const float* __restrict__ x, int 
     if (tid < V - tail0) lse_combine(m, s, x[tail0 + tid], 1.f);
 }
 
-// wave64 reductions on DPP (gfx9 row operations + the two row broadcasts): 6 one-cycle-issue VALU ops and a v_readlane, against 6
-// ds_bpermute round trips through the LDS pipe for a __shfl_xor butterfly.  The result is wave-uniform.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_f(float ident, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_max_dpp(float v) {
-    constexpr float I = -INFINITY;
-    v = fmaxf(v, dpp_f<0xB1, 0xf>(I, v));      // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_f<0x4E, 0xf>(I, v));      // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_f<0x141, 0xf>(I, v));     // row_half_mirror
-    v = fmaxf(v, dpp_f<0x140, 0xf>(I, v));     // row_mirror: every lane of a 16-lane row holds the row's result
-    v = fmaxf(v, dpp_f<0x142, 0xa>(I, v));     // row_bcast:15 into rows 1 and 3
-    v = fmaxf(v, dpp_f<0x143, 0xc>(I, v));     // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's result
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += dpp_f<0xB1, 0xf>(0.f, v);
-    v += dpp_f<0x4E, 0xf>(0.f, v);
-    v += dpp_f<0x141, 0xf>(0.f, v);
-    v += dpp_f<0x140, 0xf>(0.f, v);
-    v += dpp_f<0x142, 0xa>(0.f, v);
-    v += dpp_f<0x143, 0xc>(0.f, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// second half of a table row: block-combine the per-thread (max, sum-exp), then gather the extended labels' base-2 log-probs.
-// Per wave: the maximum first (DPP), every lane's sum rescaled to it (one exp), the sum (DPP); the four waves' (max, sum) pairs
-// meet in LDS behind ONE barrier (two alternating slots: a wave may run a whole row ahead of the slowest one, not two) and every
-// thread forms the row's log-sum-exp from them itself.  Ub = the utterance's target length (loss.py:40 targets.ne(0).sum(1)).
-__device__ __forceinline__ int ctc_target_len(const int64_t* __restrict__ targets, int b, int Umax) {
-    int nlab = 0;                          // (wave-uniform: every wave counts for itself - the row is 8 * Umax bytes of L1 / L2 hits)
-    for (int i0 = 0; i0 < Umax; i0 += 64) {
-        const int i = i0 + (threadIdx.x & 63);
-        nlab += __builtin_popcountll(__ballot(i < Umax && targets[(int64_t)b * Umax + i] != 0));
-    }
-    return nlab;
-}
+// second half of a table row: block-combine the per-thread (max, sum-exp), then gather the extended labels' base-2 log-probs
 __device__ __forceinline__ void ctc_row_finish(const float* __restrict__ x, const int64_t* __restrict__ targets, int V, int Umax, int blank,
                                                float* __restrict__ lse_out, float* __restrict__ lp_ext, int b, int row, float m, float s,
-                                               bool publish, int Ub, int parity) {
+                                               bool publish) {
     const int tid = threadIdx.x;
-    const float mw = wave_max_dpp(m);
-    const float sw = wave_sum_dpp((m == -INFINITY) ? 0.f : s * __expf(m - mw));
-    __shared__ float smx[2][4], ssx[2][4];
-    if ((tid & 63) == 0) { smx[parity][tid >> 6] = mw; ssx[parity][tid >> 6] = sw; }
-    __syncthreads();
-    const float m0 = smx[parity][0], m1 = smx[parity][1], m2 = smx[parity][2], m3 = smx[parity][3];
-    const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-    float lse = -INFINITY;
-    if (M != -INFINITY) {
-        const float S = (ssx[parity][0] * __expf(m0 - M) + ssx[parity][1] * __expf(m1 - M)) + (ssx[parity][2] * __expf(m2 - M) + ssx[parity][3] * __expf(m3 - M));
-        lse = M + logf(S);
+    // wave then block combine
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        lse_combine(m, s, m2, s2);
     }
-    if (tid == 0) lse_out[row] = lse;
+    // target length of this utterance (loss.py:40 targets.ne(0).sum(1)): rides on the same block reduction
+    int nlab = 0;
+    for (int i = tid; i < Umax; i += 256) nlab += targets[(int64_t)b * Umax + i] != 0 ? 1 : 0;
+    nlab = (int)wave_sum((float)nlab);
+    __shared__ float sm[4], ss[4];
+    __shared__ int sn[4];
+    __shared__ float lse_sh;
+    if ((tid & 63) == 0) { sm[tid >> 6] = m; ss[tid >> 6] = s; sn[tid >> 6] = nlab; }
+    __syncthreads();
+    if (tid == 0) {
+        float M = sm[0], S = ss[0];
+        for (int w = 1; w < 4; ++w) lse_combine(M, S, sm[w], ss[w]);
+        const float l = M + logf(S);
+        lse_sh = l;
+        lse_out[row] = l;
+    }
+    const int Ub = sn[0] + sn[1] + sn[2] + sn[3];
+    __syncthreads();
+    const float lse = lse_sh;
     // the table row holds the states of THIS utterance's extended label sequence (2 * tgt_len + 1 of them); everything beyond is
     // -inf, so the recursion needs no state mask of its own
     const int Sp = ctc_row_stride(Umax), Sb = 2 * Ub + 1;
@@ -188,7 +163,7 @@ __device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, in
     } else {
         ctc_row_stream(x, V, m, s);
     }
-    ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, s, publish, ctc_target_len(targets, b, Umax), 0);
+    ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, s, publish);
 }
 
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ logits, int64_t ldl,
@@ -623,7 +598,7 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
         const int G = W / RPB, npass = gridDim.x - Bn, total = nchunks * Bn * 2 * G;
         const bool w0 = threadIdx.x < 64;
         int* pending = nullptr;
-        int pending_count = 0, rows_done = 0;
+        int pending_count = 0;
         for (int gid = blockIdx.x - Bn; gid < total; gid += npass) {
             int bid = gid;
             const int chunk = bid / (Bn * 2 * G);
@@ -640,7 +615,6 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
             if (count == 0) continue;
             const int kb = chunk * W + g0;
             const int tstep = dirc == 0 ? 1 : -1, t0 = dirc == 0 ? kb : Tb - 1 - kb;
-            const int Ub = ctc_target_len(targets, b, Umax);
             for (int r = 0; r < count; ++r) {
                 const int t = t0 + tstep * r, row = b * L + t;
                 const float* x = logits + (int64_t)row * ldl;
@@ -657,7 +631,7 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
                     if (threadIdx.x == 0) __hip_atomic_fetch_add(pending, pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 pending = nullptr;
-                ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, sx, true, Ub, (rows_done++) & 1);
+                ctc_row_finish(x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, sx, true);
             }
             pending = arrivals + (int64_t)b * arr_stride + dirc * nchunks + chunk;
             pending_count = count;
