@@ -52,6 +52,11 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
     _check_equiv(_run([os.path.join(ROOT, "tools", "dp_equiv.py")], 2, 29543, True), 2)
 
 
+def test_eight_ranks_equal_one_rank_on_the_concatenated_batch():
+    """The world size of BASELINE.json configs[4] (8 shards of the utterance batch, 8 gradient buckets each), still over gloo on one GPU."""
+    _check_equiv(_run([os.path.join(ROOT, "tools", "dp_equiv.py")], 8, 29549, True), 8)
+
+
 @pytest.mark.skipif(_ngpu() < 2, reason="needs >= 2 GPUs (RCCL over xGMI)")
 def test_rccl_ranks_equal_one_rank():
     n = min(_ngpu(), 8)
