@@ -42,8 +42,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--model", default="s1", choices=["s1", "s2"],
-                    help="s1: CTC_Transformer on raw fbank (BASELINE configs[1]); s2: Conv_CTC_Transformer (configs[2], L = T/4)")
+    ap.add_argument("--model", default="s1", choices=["s1", "s2", "cif"],
+                    help="s1: CTC_Transformer on raw fbank (BASELINE configs[1]); s2: Conv_CTC_Transformer (configs[2], L = T/4); cif: CIF_Model "
+                         "(configs[3] in-model: conv front end, 3-layer assigner, integrate-and-fire, Decoder_CIF; --mode train only)")
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "decode"],
                     help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only; "
                          "decode: eval-mode encoder + greedy batch_decode (KV-cached, --decode-len steps) + CTC greedy decode")
@@ -76,6 +77,13 @@ def spawn_ranks(args):
 def build_model(asr_amd, dev, dropout, train):
     import torch
     torch.manual_seed(0)
+    if CFG.get("cif"):
+        a = argparse.Namespace(d_input=CFG["d_input"], LFR_m=1, d_model=CFG["d_model"], n_conv_layers=CFG["n_conv_layers"],
+                               n_layers_enc=CFG["n_layers_enc"], n_head=CFG["n_head"], d_inner=CFG["d_inner"], dropout=dropout,
+                               sos_id=CFG["sos_id"], eos_id=CFG["eos_id"], vocab_size=CFG["vocab_size"], n_layers_dec=CFG["n_layers_dec"],
+                               spec_aug_cfg=None, d_assigner_hidden=CFG["d_model"], w_context=3, n_assigner_layers=3)
+        model = asr_amd.CIF_Model.create_model(a).to(dev)
+        return model.train() if train else model.eval()
     d_in = CFG["d_model"] if CFG["n_conv_layers"] else CFG["d_input"]
     enc = asr_amd.Encoder(d_in, CFG["n_layers_enc"], CFG["n_head"], CFG["d_model"], CFG["d_inner"], dropout=dropout)
     dec = asr_amd.Decoder(CFG["sos_id"], CFG["eos_id"], CFG["vocab_size"], CFG["n_layers_dec"], CFG["n_head"], CFG["d_model"],
@@ -255,8 +263,12 @@ def main():
     world = int(world_env or "1")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
-    if args.model == "s2":
+    if args.model in ("s2", "cif"):
         CFG["n_conv_layers"] = 2
+    if args.model == "cif":
+        CFG["cif"] = True
+        if args.mode != "train":
+            raise SystemExit("bench.py: --model cif runs --mode train only")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -275,7 +287,8 @@ def main():
     asr_amd.manual_seed(1234 + rank)       # dropout masks: reproducible, different on every rank
     x, lens, tg = make_batch(dev, seed=rank, ragged=args.ragged)
 
-    trainer = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1) if train else None
+    trainer = (asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1, **({"lambda_qua": 0.001} if CFG.get("cif") else {}))
+               if train else None)
     use_graph = args.graph == 1 and trainer is not None
     auto_graph = args.graph < 0 and trainer is not None
 
@@ -388,6 +401,8 @@ def main():
                 if train else ("eval-mode encoder + greedy batch_decode (%d steps, KV cache) + CTC greedy decode" % args.decode_len
                                if args.mode == "decode" else "eval-mode forward + joint CTC/CE loss"))
         mname = ("S2: Conv_CTC_Transformer (2 conv layers, L=%d)" % (CFG["T"] // 4)) if CFG["n_conv_layers"] else "S1: CTC_Transformer"
+        if CFG.get("cif"):
+            mname = "S3-in-model: CIF_Model (2 conv layers, L=%d, 3-layer assigner, threshold 0.95, loss = 0.001 qua + ctc + ce)" % (CFG["T"] // 4)
         Lc = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
         result = {
             "metric": "fbank frames/sec (%s d256 h4 enc12/dec6, %s)" % (mname.split(":")[1].strip().split(" ")[0], what),
@@ -412,7 +427,7 @@ def main():
                                  "achieved": round(f["work"] / (f["ms"] * 1e-3) / (1e9 if f["hbm"] else 1e12), 1) if f["work"] else None,
                                  "unit": "GB/s" if f["hbm"] else "TFLOP/s"} for n, f in fams.items()), key=lambda d: -d["ms_per_step"])[:8],
         }
-        if world == 1 and not args.no_cpu_baseline and args.mode != "decode":
+        if world == 1 and not args.no_cpu_baseline and args.mode != "decode" and not CFG.get("cif"):
             result["cpu_baseline"] = cpu_baseline(model, x, lens, tg, args.dropout, train)
             # sanity: the GPU result on the same utterances agrees with the numpy oracle (bf16 tolerance); not timed
             result["parity_vs_oracle_max_abs"] = oracle_parity(asr_amd, model, x, lens, tg, n_utt=2)

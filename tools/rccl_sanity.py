@@ -17,3 +17,12 @@ for _ in range(3): out = tr.step(x, lens, tg, max_target_len=50)
 torch.cuda.synchronize()
 print("rccl sanity ok: launch order", tr.buckets.launch_order, "loss", l0, [float(v) for v in out[:1]])
 dist.destroy_process_group()
+if "--graph" in sys.argv:      # are RCCL collectives capturable in a hipGraph on this stack?  (1 rank, all-reduce forced, whole step captured)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    model = bench.build_model(asr_amd, dev, 0.1, True)
+    tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+    tr.buckets.world = 2
+    for _ in range(6): out = tr.step_graphed(x, lens, tg, max_target_len=50)
+    torch.cuda.synchronize()
+    print("rccl in graph:", "captured" if tr.graph_active() else ("NOT captured: %s" % tr._graph_failed), "loss", [float(v) for v in out[:1]])
+    dist.destroy_process_group()
