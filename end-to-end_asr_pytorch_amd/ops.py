@@ -92,6 +92,7 @@ def as_i32(t, device=None):
 # does).  The trainer zeroes ONE arena at the start of the step instead; GEMM outputs of split-K shape are cut from it and the
 # library is told (ASR_GEMM_C_IS_ZERO).  Every slice is handed out once per reset, so it is still zero when the GEMM runs.
 _ARENA = {"buf": None, "off": 0, "live": False, "dirty": 0}
+SPLITK_TILES = int(os.environ.get("ASR_AMD_SPLITK_TILES", "64"))     # gemm.hip pick_ksplit: output tiles up to which K is split
 GEMM_C_IS_ZERO = 4
 
 
@@ -118,7 +119,7 @@ def _arena_take(M, N, K, device):
     if not _ARENA["live"] or _ARENA["buf"].device != device:
         return None
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles > 64 or K < 512 or N % 128 != 0:       # mirror of gemm.hip pick_ksplit (a mismatch only costs the zeroing launch)
+    if tiles > SPLITK_TILES or K < 512 or N % 128 != 0:       # mirror of gemm.hip pick_ksplit (a mismatch only costs the zeroing launch)
         return None
     n = M * N
     off = (_ARENA["off"] + 63) // 64 * 64
