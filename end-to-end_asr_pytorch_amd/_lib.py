@@ -57,6 +57,10 @@ SIGNATURES = {
     "asr_conv_im2col": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_conv_col2im_relu": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_conv_col2im_relu_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i],
+    "asr_conv_sub1_bwd_x": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asr_conv_sub1_bwd_w": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
+    "asr_conv_sub1_bwd_w_workspace_floats": [],
+    "asr_conv_sub0_bwd_w": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],
     "asr_ctc_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "asr_ctc_counter_words": [_i, _i, _i],
@@ -154,6 +158,7 @@ def lib():
             fn.restype = ctypes.c_int
         L.asr_attention_dropmask_words.restype = ctypes.c_int64
         L.asr_ctc_counter_words.restype = ctypes.c_int64
+        L.asr_conv_sub1_bwd_w_workspace_floats.restype = ctypes.c_int64
         L.asr_last_error.restype = ctypes.c_char_p
         L.asr_version.restype = ctypes.c_int
         _lib = L

@@ -313,6 +313,32 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, in
     if (c < N) atomicAdd(out + c, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
+// narrow contiguous matrices (N <= 128 columns, lda == N: the conv layers' [positions, 32 channels] gradients): the kernel above
+// would keep 8 of 64 lanes busy.  The matrix is walked as a flat array of 4-element chunks; a thread's chunks all belong to the
+// same column group because its stride is a multiple of the chunks per row.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const T* __restrict__ A, int64_t nchunks, int cpr, float* __restrict__ out) {
+    __shared__ f32x4 red[256];
+    f32x4 s = {0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += stride) {
+        if constexpr (sizeof(T) == 4) {
+            s += *reinterpret_cast<const f32x4*>(A + c * 4);
+        } else {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(A + c * 4);
+            s += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < cpr) {                      // thread g < cpr owns column group g: threads g, g + cpr, ... hold its partials
+        f32x4 t = {0, 0, 0, 0};
+        for (int i = threadIdx.x; i < 256; i += cpr) t += red[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(out + threadIdx.x * 4 + e, t[e]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 #ifndef LNB_RPW_
 #define LNB_RPW_ 2
@@ -613,6 +639,19 @@ extern "C" int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda,
     const int col_blocks = (N + 255) / 256;
     int row_blocks = (1024 + col_blocks - 1) / col_blocks;          // ~1024 workgroups
     if (row_blocks > (M + 31) / 32) row_blocks = (M + 31) / 32;
+    if (lda == N && N % 4 == 0 && N <= 128 && 256 % (N / 4) == 0 && asr_aligned(A, 16)) {
+        const int cpr = N / 4;
+        const int64_t nchunks = (int64_t)M * cpr;
+        int64_t nb = (nchunks + 256 * 8 - 1) / (256 * 8);
+        if (nb > 1024) nb = 1024;
+        if (nb < 1) nb = 1;
+        if (a_dtype == ASR_F32)
+            hipLaunchKernelGGL(colsum_narrow_kernel<float>, dim3((unsigned)nb), dim3(256), 0, s, (const float*)A, nchunks, cpr, out);
+        else
+            hipLaunchKernelGGL(colsum_narrow_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)A, nchunks, cpr, out);
+        ASR_LAUNCH_CHECK("colsum_narrow");
+        return 0;
+    }
     const int rows_per_block = (M + row_blocks - 1) / row_blocks;
     dim3 grid(col_blocks, (M + rows_per_block - 1) / rows_per_block);
     if (a_dtype == ASR_F32)

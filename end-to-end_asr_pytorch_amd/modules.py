@@ -167,6 +167,7 @@ def _prefetch_attn_masks(sites, training, device):
 # into parameter gradients (written straight into `p.grad`, which the trainer points into one flat buffer) and input
 # gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
 _TAPE = None
+_DIRECT_CONV_BWD = os.environ.get("ASR_AMD_DIRECT_CONV_BWD", "1") != "0"    # A/B: 0 = the patch-matrix backward of the conv layers
 _PARAM_EPOCH = 0   # bumped by the trainer after each fused Adam step (raw-pointer updates do not bump tensor versions)
 
 
@@ -659,15 +660,25 @@ class Conv2dSubsample(_Cached):
             d_out = act.grad
             act.grad = None
             d = d_out.shape[1]
-            dwp = ops.gemm_tn(d_out, y_last)                                        # [d, F*32] in the permuted column order
+            cdt = _cdtype()
+            # [d, F*32] in the permuted column order (bf16 x bf16 operands take the LDS-DMA weight-gradient kernel; with the f32 gradient
+            # as it arrives the generic kernel converts on load and is 3x slower at [8000, 256] x [8000, 1280])
+            dwp = ops.gemm_tn(ops.cast_bf16(d_out) if (cdt == torch.bfloat16 and y_last.dtype == torch.bfloat16) else d_out, y_last)
             ops.add_transposed_(aff.weight.grad, dwp, d, 32, F)                      # affine weight columns are c*F + f (conv_encoder.py:108)
             ops.colsum(d_out, out=aff.bias.grad, accumulate=True)
-            cdt = _cdtype()
             dy = ops.gemm_nn(d_out, wp, out_dtype=cdt, relu_mask=y_last)  # [M, F*32] = channel-last d(y_last), ReLU applied
             for i in range(n - 1, 0, -1):
                 cv = convs[i]
                 tout, fout = tneed[i], fneed[i]
                 dy2 = dy.view(-1, 32)
+                xin = ys[i - 1]
+                if (_DIRECT_CONV_BWD and cdt == torch.bfloat16 and fout <= 48 and xin.shape[2] <= 50 and xin.shape[2] >= fout + 2 and
+                        xin.shape[1] >= 2 * tout + 1):
+                    # direct kernels: dy and x read once each (the patch-matrix route below moves 184 MB four times at S2)
+                    dwm = ops.conv_sub1_bwd_w(dy2, xin, tout, fout, db=cv.bias.grad)
+                    ops.add_transposed_(cv.weight.grad, dwm, 32, 32, 9)
+                    dy = ops.conv_sub1_bwd_x(dy2, cv.weight.detach().float().contiguous(), xin, tout, fout)
+                    continue
                 col = ops.conv_im2col(ys[i - 1], 32, tout, fout, 288, cdt)
                 dwm = ops.gemm_tn(dy2, col)                                         # [co, tap*32 + ci]
                 ops.add_transposed_(cv.weight.grad, dwm, 32, 32, 9)                 # nn.Conv2d weight is [co, ci, 3, 3]
@@ -678,6 +689,10 @@ class Conv2dSubsample(_Cached):
                 dcol = ops.gemm_nn(dy2, wm, out_dtype=cdt)
                 dy = ops.conv_col2im_relu(dcol, ys[i - 1], tout, fout)              # [B,Tin,Fin,32], masked by relu'(y_{i-1})
             dy2 = dy.view(-1, 32)
+            if (_DIRECT_CONV_BWD and cdt == torch.bfloat16 and dy2.dtype == torch.bfloat16 and fneed[0] <= 48 and feats.dtype == torch.float32 and
+                    feats.is_contiguous()):
+                ops.conv_sub0_bwd_w(dy2, feats, convs[0].weight.grad, convs[0].bias.grad, tneed[0], fneed[0])
+                return
             col0 = ops.conv_im2col(feats.view(B, T, D, 1), 1, tneed[0], fneed[0], 12, torch.float32)
             dw0 = ops.gemm_tn(dy2, col0)                                            # [32, 12]; taps in columns 0..8
             ops.add_transposed_(convs[0].weight.grad, dw0, 32, 9, 1, lds=dw0.stride(0))

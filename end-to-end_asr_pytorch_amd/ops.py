@@ -895,6 +895,39 @@ def conv_col2im_relu(dcol, y, Tout, Fout):
     return dx
 
 
+def conv_sub1_bwd_x(dy, w, xin, Tout, Fout):
+    """dy bf16 [B*Tout*Fout, 32] (any shape with that layout), w f32 [32,32,3,3], xin bf16 [B,Tin,Fin,32] -> dx bf16 like xin (ReLU-masked)"""
+    _req_cuda(dy, w, xin)
+    B, Tin, Fin, _ = xin.shape
+    assert dy.dtype == torch.bfloat16 and xin.dtype == torch.bfloat16 and dy.is_contiguous() and xin.is_contiguous()
+    assert dy.numel() == B * Tout * Fout * 32 and w.dtype == torch.float32 and w.is_contiguous() and tuple(w.shape) == (32, 32, 3, 3)
+    dx = torch.empty_like(xin)
+    check(lib().asr_conv_sub1_bwd_x(_stream(), _p(dy), _p(w), _p(xin), _p(dx), B, Tin, Fin, Tout, Fout), "asr_conv_sub1_bwd_x")
+    return dx
+
+
+def conv_sub1_bwd_w(dy, x, Tout, Fout, db=None):
+    """-> dw f32 [32, 288] (column tap*32 + ci) of dy bf16 [B,Tout,Fout,32] against the layer input x bf16 [B,Tin,Fin,32]; db (f32 [32]) += sum dy"""
+    _req_cuda(dy, x, db)
+    B, Tin, Fin, _ = x.shape
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
+    assert dy.numel() == B * Tout * Fout * 32
+    dw = torch.zeros((32, 288), device=x.device, dtype=torch.float32)
+    ws = torch.empty(int(lib().asr_conv_sub1_bwd_w_workspace_floats()), device=x.device, dtype=torch.float32)
+    check(lib().asr_conv_sub1_bwd_w(_stream(), _p(dy), _p(x), _p(dw), _p(db), _p(ws), B, Tin, Fin, Tout, Fout), "asr_conv_sub1_bwd_w")
+    return dw
+
+
+def conv_sub0_bwd_w(dy, feats, dw, db, T1, F1):
+    """dw f32 [32,1,3,3] += and db f32 [32] += of the first conv layer from dy bf16 [B,T1,F1,32] and the features f32 [B,T,D]"""
+    _req_cuda(dy, feats, dw, db)
+    B, T, D = feats.shape
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.numel() == B * T1 * F1 * 32
+    assert feats.dtype == torch.float32 and feats.is_contiguous() and dw.is_contiguous() and dw.numel() == 288 and dw.dtype == torch.float32
+    ws = torch.empty(int(lib().asr_conv_sub1_bwd_w_workspace_floats()), device=feats.device, dtype=torch.float32)
+    check(lib().asr_conv_sub0_bwd_w(_stream(), _p(dy), _p(feats), _p(dw), _p(db), _p(ws), B, T, D, T1, F1), "asr_conv_sub0_bwd_w")
+
+
 def cif_bwd(hidden, cur, rem, tok, n_fire, d_out):
     """-> (d_hidden [B,L,H], d_alpha [B,L]) for out = cif(hidden, alpha)"""
     hidden = hidden.contiguous()

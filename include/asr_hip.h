@@ -234,6 +234,20 @@ int asr_conv_im2col(void* stream, const void* x, int x_dtype, int C, void* col, 
                     int Tout, int Fout);
 int asr_conv_col2im_relu(void* stream, const void* dcol, int ldc, const void* y, void* dx, int B, int Tin, int Fin, int Tout,
                          int Fout);
+/* Direct backward of a 32 -> 32 channel conv layer (conv_encoder.py:104, bf16), without the patch matrix:
+ * asr_conv_sub1_bwd_x: dx[b,ti,fi,ci] = (xin > 0) * sum_{kh,kw,co} dy[b,(ti-kh)/2,fi-kw,co] * w[co][ci][kh][kw]  (dy bf16 [B,Tout,Fout,32],
+ *   w f32 [32,32,3,3] as stored, xin = the layer's input activation bf16 [B,Tin,Fin,32] = the ReLU mask, dx like xin).
+ * asr_conv_sub1_bwd_w: dw f32 [32, 288] (+=, column tap*32 + ci: the conv-as-GEMM weight matrix, see asr_add_transposed) and
+ *   db f32 [32] (+=, optional) from dy and the layer's input x; Fout <= 48, Fin <= 50 (the staged tile).  workspace: f32
+ *   [asr_conv_sub1_bwd_w_workspace_floats()] - the workgroups' partial sums, added up by a second small launch. */
+int asr_conv_sub1_bwd_x(void* stream, const void* dy, const float* w, const void* xin, void* dx, int B, int Tin, int Fin, int Tout, int Fout);
+int64_t asr_conv_sub1_bwd_w_workspace_floats(void);
+/* ... and of the first layer (1 -> 32 channels, conv_encoder.py:103): dw f32 [32, 9] (+=, the nn.Conv2d weight [32,1,3,3] as stored),
+ * db f32 [32] (+=) from dy bf16 [B,T1,F1,32] and the features f32 [B,T,D]; same workspace; F1 <= 48. */
+int asr_conv_sub0_bwd_w(void* stream, const void* dy, const float* feats, float* dw, float* db, float* workspace, int B, int T, int D, int T1,
+                        int F1);
+int asr_conv_sub1_bwd_w(void* stream, const void* dy, const void* x, float* dw, float* db, float* workspace, int B, int Tin, int Fin,
+                        int Tout, int Fout);
 /* ... in the fp32 parity mode (dcol, y, dx f32). */
 int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const float* y, float* dx, int B, int Tin, int Fin, int Tout,
                              int Fout);

@@ -198,7 +198,7 @@ def test_full_size_gradients_match_stock_torch_on_two_utterances(which):
     finally:
         bench.CFG.clear()
         bench.CFG.update(old)
-    for prec, ltol, gtol, atol in (("f32", 1e-5, 1e-2, 1e-5), ("bf16", 1e-2, 1.2e-1, 2e-3)):
+    for prec, ltol, gtol, atol in (("f32", 1e-5, 1e-2, 1e-5), ("bf16", 1e-2, 1.5e-1, 2e-3)):
         ctc, ce, errs = out[prec]
         np.testing.assert_allclose(ctc, float(ctc_ref), rtol=ltol)
         np.testing.assert_allclose(ce, float(ce_ref), rtol=ltol)
@@ -207,8 +207,11 @@ def test_full_size_gradients_match_stock_torch_on_two_utterances(which):
         big = max(r for e, r, n in errs)
         bad = [(e, r, n) for e, r, n in errs if e > gtol * r and e > (atol if prec == "f32" else 2.5e-3 * big)]
         assert not bad, (prec, bad[:8])
-    # the whole gradient vector: f32 to 3e-3, bf16 to 6 % (measured: S1 < 4 %, S2 with its bf16 conv stack 5.0 %)
-    for prec, tol in (("f32", 3e-3), ("bf16", 6e-2)):
+    # the whole gradient vector: f32 to 3e-3 (measured 1.2e-3 / 1.7e-4), bf16 to 3 % at S1 (measured 1.5-1.6 %) and 8 % at S2, whose bf16
+    # conv stack sits under everything (measured 5.1-5.6 %, moving with the float-atomic summation order of the weight gradients)
+    for prec, tol in (("f32", 3e-3), ("bf16", 3e-2 if which == "s1" else 8e-2)):
         errs = out[prec][2]
         tot_e, tot_r = np.sqrt(sum(e * e for e, r, n in errs)), np.sqrt(sum(r * r for e, r, n in errs))
+        print("full-size gradients %s %s: whole vector %.2e, worst parameter %.2e (of those with |g| > 1e-2 max|g|)" % (
+            which, prec, tot_e / tot_r, max(e / r for e, r, n in errs if r > 1e-2 * max(rr for _, rr, _ in errs))))
         assert tot_e <= tol * tot_r, (prec, tot_e, tot_r)
