@@ -237,3 +237,45 @@ def test_relu_sign_bits_round_trip(M, N_, K):
     a = ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16, relu_mask=hid)
     b = ops.gemm_nn(dy, w2, out_dtype=torch.bfloat16, relu_bits=bits)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 21, 42, 10, 40), (3, 9, 42, 4, 40), (1, 501, 42, 250, 40), (2, 13, 20, 6, 18)])
+def test_direct_conv_layer_backward_kernels(shape):
+    """asr_conv_sub1_bwd_x / asr_conv_sub1_bwd_w (32 -> 32 channels, 3x3, stride (2, 1)) and asr_conv_sub0_bwd_w (1 -> 32) against torch
+    autograd of F.conv2d on the same bf16-rounded operands: chunk tails (Tout not a multiple of 4 / 8), the last input row
+    (Tin = 2 Tout + 1), narrow feature maps and the S2 shape's row length."""
+    import torch.nn.functional as F
+    from asr_amd import ops
+    B, Tin, Fin, Tout, Fout = shape
+    g = torch.Generator().manual_seed(Tin)
+    x = torch.randn(B, Tin, Fin, 32, generator=g).bfloat16()            # the layer's input activation (ReLU output of the previous layer)
+    x = torch.where(torch.rand(B, Tin, Fin, 32, generator=g) < 0.3, torch.zeros_like(x), x.abs())
+    w = (torch.randn(32, 32, 3, 3, generator=g) * 0.1)
+    dy = torch.randn(B, Tout, Fout, 32, generator=g).bfloat16()
+    # reference: y = conv(x) on the [Tout, Fout] window the kernels see; gradient wrt x masked by relu'(x) like the layer below
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)            # [B, C, T, F]
+    wr = w.bfloat16().float().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=(2, 1))[:, :, :Tout, :Fout]
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    dx_ref = (xr.grad.permute(0, 2, 3, 1) * (x.float() > 0)).numpy()
+    dw_ref = wr.grad.numpy()                                            # [co, ci, kh, kw]
+    db_ref = dy.float().sum((0, 1, 2)).numpy()
+    dxg = ops.conv_sub1_bwd_x(dy.to(DEV), w.to(DEV), x.to(DEV), Tout, Fout)
+    np.testing.assert_allclose(dxg.float().cpu().numpy(), dx_ref, atol=3e-2 * np.abs(dx_ref).max(), rtol=2e-2)
+    db = torch.zeros(32, device=DEV)
+    dwm = ops.conv_sub1_bwd_w(dy.to(DEV), x.to(DEV), Tout, Fout, db=db).cpu().numpy()          # [co, tap*32 + ci]
+    got = dwm.reshape(32, 9, 32).transpose(0, 2, 1).reshape(32, 32, 3, 3)
+    np.testing.assert_allclose(got, dw_ref, atol=2e-3 * np.abs(dw_ref).max(), rtol=2e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref, atol=1e-3 * np.abs(db_ref).max() + 1e-3, rtol=1e-3)
+    # the first layer: features [B, T, D] f32 (one channel), dy0 on [T1, F1]
+    T, D, T1, F1 = Tin, Fin + 3, Tout, Fout
+    feats = torch.randn(B, T, D, generator=g)
+    fr = feats.bfloat16().float()[:, None].requires_grad_(False)
+    w0 = torch.zeros(32, 1, 3, 3, requires_grad=True)
+    y0 = F.conv2d(F.pad(fr, (0, 2, 0, 2)), w0, stride=(2, 1))[:, :, :T1, :F1]
+    y0.backward(dy.float().permute(0, 3, 1, 2))
+    dw0 = torch.zeros(32, 1, 3, 3, device=DEV)
+    db0 = torch.zeros(32, device=DEV)
+    ops.conv_sub0_bwd_w(dy.to(DEV), feats.to(DEV), dw0, db0, T1, F1)
+    np.testing.assert_allclose(dw0.cpu().numpy(), w0.grad.numpy(), atol=3e-3 * np.abs(w0.grad.numpy()).max(), rtol=3e-3)
+    np.testing.assert_allclose(db0.cpu().numpy(), db_ref, atol=1e-3 * np.abs(db_ref).max() + 1e-3, rtol=1e-3)
