@@ -84,7 +84,11 @@ __host__ __device__ __forceinline__ int drop_pad128(int n) { return (n + 127) & 
 __host__ __device__ __forceinline__ int64_t drop_mk_words(int BH, int Lq, int Lk) { return (int64_t)BH * (drop_pad128(Lk) / 32) * drop_pad128(Lq); }
 // all-ones / all-zeros from bit `pos` of w: the value is AND-ed onto the f32 bit pattern it keeps or drops
 __device__ __forceinline__ float drop_and(float v, uint32_t w, int pos) {
-    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & __builtin_amdgcn_sbfe((int)w, (unsigned)pos, 1u));
+    // (through asm: written with __builtin_amdgcn_sbfe the compiler rewrites bfe + and as and + cmp + cndmask - three VALU
+    // instructions per probability in kernels that are VALU-bound)
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"(pos));
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
 }
 // 4 consecutive elements n2 = c .. c+3 (c even) of row n1: multiply by the keep mask * scale
 __device__ __forceinline__ f32x4 drop4(const asr_dropout_t& d, uint32_t sub, uint32_t n1, uint32_t n2h, uint32_t c, f32x4 v, float sc) {
