@@ -891,7 +891,7 @@ class _DecodeGraph(dict):
 
     def __del__(self):
         try:
-            if self.get("graphs") is not None:
+            if self.get("graphs") is not None and not torch.cuda.is_current_stream_capturing():   # (never synchronise inside someone's capture)
                 torch.cuda.synchronize()
             self.pop("prologue", None)
             self.pop("step", None)
