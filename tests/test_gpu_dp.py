@@ -30,7 +30,17 @@ def _run(script_args, nproc, port, gloo_one_gpu):
            "--master-port", str(port)] + script_args
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
-    return [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    out, dec = [], json.JSONDecoder()
+    for line in r.stdout.splitlines():          # ranks share the pipe: two records can land on one line
+        i = line.find("{")
+        while i >= 0:
+            try:
+                obj, end = dec.raw_decode(line, i)
+            except json.JSONDecodeError:
+                break
+            out.append(obj)
+            i = line.find("{", end)
+    return out
 
 
 def test_two_rank_training_step_on_one_gpu():
