@@ -404,6 +404,23 @@ def main():
         if CFG.get("cif"):
             mname = "S3-in-model: CIF_Model (2 conv layers, L=%d, 3-layer assigner, threshold 0.95, loss = 0.001 qua + ctc + ce)" % (CFG["T"] // 4)
         Lc = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
+        ctc_iso = None
+        if ctc_k and args.mode != "decode":
+            # the CTC forward as SURVEY 8(d) row 2 prices it: the stand-alone op on fp32 logits of the workload's shape, back-to-back
+            g = torch.Generator().manual_seed(0)
+            lg_ = torch.randn(CFG["B"], Lc, CFG["vocab_size"], generator=g).to(dev)
+            tg_ = torch.randint(1, CFG["vocab_size"] - 1, (CFG["B"], CFG["U"]), generator=g).to(dev)
+            il_ = torch.full((CFG["B"],), Lc, dtype=torch.int32, device=dev)
+            for _ in range(5):
+                ops.ctc_loss_fwd(lg_, il_, tg_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                ops.ctc_loss_fwd(lg_, il_, tg_)
+            e1.record()
+            torch.cuda.synchronize()
+            ctc_iso = e0.elapsed_time(e1) / 30
+            del lg_
         result = {
             "metric": "fbank frames/sec (%s d256 h4 enc12/dec6, %s)" % (mname.split(":")[1].strip().split(" ")[0], what),
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -421,7 +438,14 @@ def main():
                      "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
                      # bytes: the logits read twice (f32) + the gradient written (bf16 image in the trainer)
                      "fwd_bwd_GBps": (round((2 * 4.0 + (2.0 if trainer is not None else 4.0)) * CFG["B"] * Lc * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
-                                      if ctc_b else None)} if ctc_k else None),
+                                      if ctc_b else None),
+                     "fwd_ms_standalone": (round(ctc_iso, 4) if ctc_iso else None),
+                     "fwd_frac_of_hbm_peak_standalone": (round(4.0 * CFG["B"] * Lc * CFG["vocab_size"] / (ctc_iso * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                                                         if ctc_iso else None),
+                     "note": "ms_per_step_fwd / fwd_frac_of_hbm_peak: inside the step, right behind the ctc_fc GEMM that wrote the logits - "
+                             "a bare streaming read of those 542 MB takes 0.138-0.145 ms in that situation (tools/micro/hbm_read.hip, "
+                             "DESIGN.md 4); *_standalone: the op alone on resident fp32 logits of the same shape, 30 launches back-to-back"}
+                    if ctc_k else None),
             "kernels": kernels[:12], "op_ms_total": round(sum(k["ms_per_step"] for k in kernels), 3),
             "families": sorted(({"family": n, "ms_per_step": round(f["ms"] / args.steps, 3),
                                  "achieved": round(f["work"] / (f["ms"] * 1e-3) / (1e9 if f["hbm"] else 1e12), 1) if f["work"] else None,
