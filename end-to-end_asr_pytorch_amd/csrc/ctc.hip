@@ -842,7 +842,7 @@ static inline void ctc_chunking(int L, int n_chunks, int& W, int& nc) {
 }
 
 extern "C" int64_t asr_ctc_counter_words(int B, int L, int n_chunks) {
-    if (n_chunks <= 1 || L < 64 || B <= 0) return 0;
+    if (n_chunks <= 1 || L < 64 || B <= 0 || B > 512) return 0;
     int W, nc;
     ctc_chunking(L, n_chunks, W, nc);
     return (int64_t)B * 2 * nc;
@@ -856,7 +856,10 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (U+1 must be <= 512)", Umax);
     ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd: workspaces must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n_chunks <= 1 || L < 64 || ctc_np(Umax) != 1) {   // two launches: one pass over the logits, then the two half-length chains
+    // The fused form's recursion workgroups (one per utterance, the grid's first blocks) WAIT for the pass workgroups behind them: they
+    // must never be able to fill the chip on their own.  Up to 512 utterances (2 of the 8 slots per CU on 256 CUs) they cannot; larger
+    // batches take the two-launch form.
+    if (n_chunks <= 1 || L < 64 || ctc_np(Umax) != 1 || B > 512) {   // two launches: one pass over the logits, then the two half-length chains
                                                           // (the fused form is written for one state pair per lane: U + 1 <= 64)
         hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
                            lp_ext);

@@ -677,3 +677,18 @@ def test_aishell_width_model_matches_oracle(prec):
             ctc, ce = tr.step(T(x.numpy()), T(lens.numpy()), T(tg.numpy()))
             first = first or (float(ctc) + float(ce))
         assert np.isfinite(float(ctc) + float(ce)) and float(ctc) + float(ce) < first
+
+
+def test_ctc_large_batch_takes_the_two_launch_form():
+    """More utterances than the fused forward may hold resident (its recursion workgroups wait for the pass workgroups scheduled
+    behind them): B = 600 runs the two-launch form and agrees with F.ctc_loss."""
+    g = torch.Generator().manual_seed(3)
+    B, L, V, U = 600, 96, 30, 7
+    logits = torch.randn(B, L, V, generator=g)
+    tg = torch.randint(1, V - 1, (B, U), generator=g)
+    il = torch.randint(L // 2, L + 1, (B,), generator=g)
+    il[0] = L
+    loss, nll = asr_amd.ctc_loss(T(logits), T(il), T(tg))
+    lp = torch.nn.functional.log_softmax(logits, -1).transpose(0, 1)
+    ref = torch.nn.functional.ctc_loss(lp, tg, il, torch.full((B,), U), blank=V - 1, reduction="none")
+    np.testing.assert_allclose(N(nll), ref.numpy(), rtol=1e-5, atol=1e-4)
