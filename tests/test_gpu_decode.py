@@ -148,3 +148,24 @@ def test_batch_beam_decode_matches_the_reference(golden_dir):
     t = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0, -1.0]], device=DEV)
     v, i = asr_amd.ops.topk_rows(t, 4)
     assert i.cpu().tolist() == [[1, 2, 4, 3]] and v.cpu().tolist() == [[3.0, 3.0, 3.0, 2.0]]
+
+
+def test_batch_decode_smallest_shapes(golden_dir, monkeypatch):
+    """One decode step, one utterance, zero steps - replayed and eager forms agree; the first token equals the full-length run's."""
+    z, cfg, model = load(golden_dir)
+    enc, enc_len = torch.from_numpy(z["enc_out"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV)
+    ref, _, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=12)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ASR_AMD_DECODE_GRAPH", mode)
+        model.decoder.__dict__.pop("_decode_graph", None)
+        p1, l1, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=1)
+        pb, lb, _ = model.decoder.batch_decode(enc[:1].contiguous(), enc_len[:1].contiguous(), max_decode_len=4)
+        p0, l0, _ = model.decoder.batch_decode(enc, enc_len, max_decode_len=0)
+        assert tuple(p1.shape) == (enc.shape[0], 1) and tuple(pb.shape) == (1, 4) and tuple(p0.shape) == (enc.shape[0], 0)
+        np.testing.assert_array_equal(p1.cpu().numpy(), ref[:, :1].cpu().numpy())
+        np.testing.assert_array_equal(pb.cpu().numpy(), ref[:1, :4].cpu().numpy())
+        assert int(l0.abs().sum()) == 0
+        res[mode] = (p1.cpu().numpy(), l1.cpu().numpy(), pb.cpu().numpy(), lb.cpu().numpy())
+    for a, b in zip(res["1"], res["0"]):
+        np.testing.assert_array_equal(a, b)
