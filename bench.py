@@ -49,6 +49,7 @@ def parse_args():
                     help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only; "
                          "decode: eval-mode encoder + greedy batch_decode (KV-cached, --decode-len steps) + CTC greedy decode")
     ap.add_argument("--decode-len", type=int, default=50, help="max_decode_len of --mode decode (decoder.py:138)")
+    ap.add_argument("--beam", type=int, default=5, help="beam size of --model cif --mode decode (Decoder_CIF.recognize_beam, decoder.py:425)")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="dropout rate of the training step (0.1 = every shipped config of the reference, egs/*/conf); ignored by --mode fwd")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("ASR_AMD_GRAPH", "-1")),
@@ -267,8 +268,8 @@ def main():
         CFG["n_conv_layers"] = 2
     if args.model == "cif":
         CFG["cif"] = True
-        if args.mode != "train":
-            raise SystemExit("bench.py: --model cif runs --mode train only")
+        if args.mode == "fwd":
+            raise SystemExit("bench.py: --model cif runs --mode train or --mode decode")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -292,6 +293,8 @@ def main():
     use_graph = args.graph == 1 and trainer is not None
     auto_graph = args.graph < 0 and trainer is not None
 
+    lens_host = [int(v) for v in lens.tolist()]
+
     def step():
         if trainer is not None:
             if use_graph:
@@ -299,6 +302,16 @@ def main():
             if auto_graph:
                 return trainer.step_auto(x, lens, tg, max_target_len=CFG["U"])
             return trainer.step(x, lens, tg, max_target_len=CFG["U"])   # the loader knows its target lengths: no host sync in the step
+        if args.mode == "decode" and CFG.get("cif"):
+            # the reference's CIF inference (cif_model.py:108-131) for the whole padded batch: one batched beam search; `target_num` = U
+            # tokens per utterance (the random-init assigner would otherwise fire on about every second frame)
+            if os.environ.get("ASR_AMD_CIF_PER_UTT") == "1":      # the reference's call shape: one utterance at a time
+                dargs = argparse.Namespace(beam_size=args.beam, nbest=1)
+                res = [model.recognize(x[u, :lens_host[u]], lens[u:u + 1], None, dargs, target_num=CFG["U"]) for u in range(x.shape[0])]
+            else:
+                res = model.batch_recognize(x, lens, args.beam, 1, target_num=CFG["U"])
+            t_ = torch.tensor(sum(ls[0] - 1 for ys, ls in res) / float(x.shape[0]))
+            return t_, t_
         if args.mode == "decode":
             with torch.no_grad():
                 from asr_amd.modules import _act
@@ -398,7 +411,9 @@ def main():
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
         what = ("training step (train mode, dropout %g): forward + joint CTC/CE loss + backward + grad all-reduce + Adam" % args.dropout
-                if train else ("eval-mode encoder + greedy batch_decode (%d steps, KV cache) + CTC greedy decode" % args.decode_len
+                if train else (("CIF_Model.batch_recognize: conv + encoder + assigner + CIF (target_num %d) + one batched Decoder_CIF beam search "
+                                "(beam %d, K/V caches, step replayed as a hipGraph)" % (CFG["U"], args.beam)) if (args.mode == "decode" and CFG.get("cif")) else
+                               "eval-mode encoder + greedy batch_decode (%d steps, KV cache) + CTC greedy decode" % args.decode_len
                                if args.mode == "decode" else "eval-mode forward + joint CTC/CE loss"))
         mname = ("S2: Conv_CTC_Transformer (2 conv layers, L=%d)" % (CFG["T"] // 4)) if CFG["n_conv_layers"] else "S1: CTC_Transformer"
         if CFG.get("cif"):

@@ -83,10 +83,15 @@ SIGNATURES = {
     "asr_ctc_greedy_reduce": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "asr_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
     "asr_topk_rows": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
+    "asr_lsm_topk_rows": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
     "asr_beam_prune": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "asr_decode_embed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_kv_cache_put": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_decode_advance": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asr_beam_cat_frames": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "asr_beam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asr_beam_reorder_cache": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "asr_beam_advance": [_vp, _vp, _vp, _i],
     "asr_add2d": [_vp, _vp, _i64, _vp, _i64, _i, _i],
     "asr_add_transposed": [_vp, _vp, _vp, _i, _i, _i, _i64],
     "asr_relu_mask_mul": [_vp, _vp, _vp, _i, _vp, _i64],

@@ -166,6 +166,58 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
     }
 }
 
+// top-k of log_softmax(x) per row in one pass over the row (decoder.py:418-440: F.log_softmax then torch.topk): the row lives in
+// registers (NPL values per lane, one wavefront per row), the logsumexp is reduced in log_softmax_rows_kernel's order (same values),
+// then k rounds of topk_rows_kernel's selection on the registers
+template <int NPL>
+__global__ __launch_bounds__(256) void lsm_topk_rows_kernel(const float* __restrict__ x, int64_t ld, int M, int V, int k,
+                                                            float* __restrict__ vals, int64_t* __restrict__ idx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + row * ld;
+    float y[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) y[i] = lane + 64 * i < V ? xr[lane + 64 * i] : -INFINITY;
+    float m = -INFINITY, s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i)
+        if (lane + 64 * i < V) lse_combine(m, s, y[i], 1.f);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        lse_combine(m, s, m2, s2);
+    }
+    const float l = m + logf(s);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) y[i] -= l;
+    float lastv = INFINITY;
+    int lasti = -1;
+    for (int j = 0; j < k; ++j) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int c = lane + 64 * i;
+            const float v = y[i];
+            const bool after = c < V && ((v < lastv) || (v == lastv && c > lasti));
+            if (after && (bi == 0x7fffffff || v > best)) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > best || (v2 == best && i2 < bi))) { best = v2; bi = i2; }
+        }
+        if (lane == 0) {
+            vals[row * k + j] = bi == 0x7fffffff ? -INFINITY : best;
+            idx[row * k + j] = bi == 0x7fffffff ? 0 : bi;
+        }
+        lastv = best;
+        lasti = bi;
+    }
+}
+
 // One pruning step (decoder.py:196-209) per utterance: candidates c = parent * beam + j with score scores[parent] + next_scores[parent][j]
 // (an f32 add, like the reference's broadcast add), the best `beam` of the beam * beam in sorted order -> their scores, parent ROWS
 // (k_indices // beam_size, global row ids) and tokens.  One wavefront per utterance, lane = candidate (beam * beam <= 64).
@@ -197,6 +249,129 @@ __global__ __launch_bounds__(64) void beam_prune_kernel(const float* __restrict_
         lastv = best;
         lasti = bi;
     }
+}
+
+// ---- batched beam search over integrated frames (Decoder_CIF.recognize_beam, decoder.py:425-475, for B utterances at once) ----------
+// Rows r = b * beam + j are the hypotheses; the step position t lives in state[0]; utterance b is live while t < n_steps[b].
+
+// out[r] = [frames[b, t, :D] | other] (f32), other = other32[r, :D2] or, with `cur`, emb[cur[r]] + pe[t] (D2 = D): the decoder's input
+// rows (decoder.py:407-408) and the rows of the output projection (decoder.py:416)
+__global__ __launch_bounds__(256) void beam_cat_frames_kernel(const float* __restrict__ frames, const int32_t* __restrict__ state,
+                                                              const float* __restrict__ other32, const int64_t* __restrict__ cur,
+                                                              const float* __restrict__ emb, const float* __restrict__ pe,
+                                                              float* __restrict__ out, int N, int beam, int Tmax, int D, int D2, int V,
+                                                              int max_pos) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int t = min(max(state[0], 0), Tmax - 1);
+    const float* fr = frames + ((int64_t)(row / beam) * Tmax + t) * D;
+    float* o = out + (int64_t)row * (D + D2);
+    for (int c = lane * 4; c < D; c += 256) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(fr + c);
+    if (cur) {
+        int64_t id = cur[row];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        const int tp = min(t, max_pos - 1);
+        for (int c = lane * 4; c < D2; c += 256)
+            *reinterpret_cast<f32x4*>(o + D + c) =
+                *reinterpret_cast<const f32x4*>(emb + id * D2 + c) + *reinterpret_cast<const f32x4*>(pe + (int64_t)tp * D2 + c);
+    } else {
+        for (int c = lane * 4; c < D2; c += 256)
+            *reinterpret_cast<f32x4*>(o + D + c) = *reinterpret_cast<const f32x4*>(other32 + (int64_t)row * D2 + c);
+    }
+}
+
+// One search step for utterance b = blockIdx.x (decoder.py:445-462): candidates c = j * beam + k (hypothesis-major, rank-minor) with
+// score scores[row j] + next_scores[row j][k]; the best `beam` by score, ties in candidate order (Python's stable sort), become the new
+// hypotheses IN PLACE: scores, token rows preds[., 0..t] gathered from the parents plus the new token at column t + 1, `cur`, and the
+// parent row ids (for the K/V caches).  A finished utterance (t >= n_steps[b]) keeps everything and reports identity parents.
+constexpr int BEAM_MAX_W = 512;
+__global__ __launch_bounds__(64) void beam_step_kernel(float* __restrict__ scores, const float* __restrict__ next_scores,
+                                                       const int64_t* __restrict__ next_preds, int64_t* __restrict__ preds,
+                                                       const int32_t* __restrict__ state, const int32_t* __restrict__ n_steps,
+                                                       int64_t* __restrict__ parent, int64_t* __restrict__ cur, int beam, int W) {
+    __shared__ int sel_row[8];
+    __shared__ int64_t sel_tok[8];
+    __shared__ float sel_score[8];
+    __shared__ int64_t rows[8 * BEAM_MAX_W];
+    const int b = blockIdx.x, lane = threadIdx.x, nc = beam * beam;
+    const int t = state[0];
+    if (t >= n_steps[b] || t + 1 >= W) {
+        if (lane < beam) parent[b * beam + lane] = b * beam + lane;
+        return;
+    }
+    const int row = b * beam + lane / beam;
+    const float v = lane < nc ? scores[row] + next_scores[(int64_t)b * nc + lane] : -INFINITY;
+    const int64_t tok = lane < nc ? next_preds[(int64_t)b * nc + lane] : 0;
+    float lastv = INFINITY;
+    int lasti = -1;
+    for (int j = 0; j < beam; ++j) {
+        const bool after = lane < nc && ((v < lastv) || (v == lastv && lane > lasti));
+        float best = after ? v : -INFINITY;
+        int bi = after ? lane : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > best || (v2 == best && i2 < bi))) { best = v2; bi = i2; }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        if (lane == bi) { sel_row[j] = row; sel_tok[j] = tok; sel_score[j] = v; }
+        lastv = best;
+        lasti = bi;
+    }
+    __syncthreads();
+    for (int j = 0; j < beam; ++j)
+        for (int c = lane; c <= t; c += 64) rows[j * BEAM_MAX_W + c] = preds[(int64_t)sel_row[j] * W + c];
+    __syncthreads();
+    for (int j = 0; j < beam; ++j) {
+        int64_t* pr = preds + (int64_t)(b * beam + j) * W;
+        for (int c = lane; c <= t; c += 64) pr[c] = rows[j * BEAM_MAX_W + c];
+    }
+    if (lane < beam) {
+        const int r = b * beam + lane;
+        preds[(int64_t)r * W + t + 1] = sel_tok[lane];
+        scores[r] = sel_score[lane];
+        cur[r] = sel_tok[lane];
+        parent[r] = sel_row[lane];
+    }
+}
+
+// K/V caches [n_kv, N, h, Tmax, 64] re-gathered by parent row, in place: a thread owns one 16-byte piece of one cache position for all
+// `beam` rows of its utterance (reads every source, then writes), positions <= t only
+__global__ __launch_bounds__(256) void beam_reorder_cache_kernel(uint4* __restrict__ cache, const int64_t* __restrict__ parent,
+                                                                 const int32_t* __restrict__ state, int n_kv, int B, int beam, int h,
+                                                                 int Tmax, int segs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int seg = (int)(i % segs);
+    const int pos = (int)((i / segs) % Tmax);
+    const int hd = (int)((i / ((int64_t)segs * Tmax)) % h);
+    const int b = (int)((i / ((int64_t)segs * Tmax * h)) % B);
+    const int kv = (int)(i / ((int64_t)segs * Tmax * h * B));
+    if (kv >= n_kv || pos > state[0]) return;
+    bool same = true;
+    int src[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        src[r] = r < beam ? (int)(parent[b * beam + r] - (int64_t)b * beam) : 0;
+        same = same && (r >= beam || src[r] == r);
+    }
+    if (same) return;
+    const int64_t row_stride = (int64_t)h * Tmax * segs;
+    uint4* base = cache + (((int64_t)kv * B * beam + (int64_t)b * beam) * h + hd) * Tmax * segs + (int64_t)pos * segs + seg;
+    uint4 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (r < beam) v[r] = base[(int64_t)min(max(src[r], 0), beam - 1) * row_stride];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (r < beam) base[(int64_t)r * row_stride] = v[r];
+}
+
+// t += 1, every row's key length += 1
+__global__ __launch_bounds__(256) void beam_advance_kernel(int32_t* __restrict__ state, int32_t* __restrict__ k_len, int N) {
+    for (int r = threadIdx.x; r < N; r += 256) k_len[r] += 1;
+    if (threadIdx.x == 0) state[0] += 1;
 }
 
 }  // namespace
@@ -269,5 +444,62 @@ extern "C" int asr_beam_prune(void* stream, const float* scores, const float* ne
     hipLaunchKernelGGL(beam_prune_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), scores, next_scores, next_preds, beam,
                        new_scores, parent, new_tok);
     ASR_LAUNCH_CHECK("beam_prune");
+    return 0;
+}
+
+extern "C" int asr_beam_cat_frames(void* stream, const float* frames, const int32_t* state, const float* other32, const int64_t* cur,
+                                   const float* emb, const float* pe, float* out, int N, int beam, int Tmax, int D, int D2, int V, int max_pos) {
+    ASR_REQUIRE(frames && state && out && N > 0 && beam > 0 && N % beam == 0 && Tmax > 0 && D > 0 && D2 > 0 && D % 4 == 0 && D2 % 4 == 0,
+                ASR_ERR_ARG, "beam_cat_frames: bad args");
+    ASR_REQUIRE((cur && emb && pe && V > 0 && max_pos > 0) || (!cur && other32), ASR_ERR_ARG, "beam_cat_frames: needs `other32` or cur + emb + pe");
+    ASR_REQUIRE(asr_aligned(frames, 16) && asr_aligned(out, 16) && asr_aligned(other32, 16) && asr_aligned(emb, 16) && asr_aligned(pe, 16),
+                ASR_ERR_ALIGN, "beam_cat_frames: alignment");
+    hipLaunchKernelGGL(beam_cat_frames_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), frames, state, other32, cur,
+                       emb, pe, out, N, beam, Tmax, D, D2, V, max_pos);
+    ASR_LAUNCH_CHECK("beam_cat_frames");
+    return 0;
+}
+
+extern "C" int asr_beam_step(void* stream, float* scores, const float* next_scores, const int64_t* next_preds, int64_t* preds,
+                             const int32_t* state, const int32_t* n_steps, int64_t* parent, int64_t* cur, int B, int beam, int W) {
+    ASR_REQUIRE(scores && next_scores && next_preds && preds && state && n_steps && parent && cur && B > 0 && W > 1, ASR_ERR_ARG,
+                "beam_step: bad args");
+    ASR_REQUIRE(beam >= 1 && beam * beam <= 64, ASR_ERR_UNSUPPORTED, "beam_step: beam_size %d (beam * beam must fit one wavefront)", beam);
+    ASR_REQUIRE(W <= BEAM_MAX_W, ASR_ERR_UNSUPPORTED, "beam_step: %d token columns (at most %d)", W, BEAM_MAX_W);
+    hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), scores, next_scores, next_preds, preds, state,
+                       n_steps, parent, cur, beam, W);
+    ASR_LAUNCH_CHECK("beam_step");
+    return 0;
+}
+
+extern "C" int asr_beam_reorder_cache(void* stream, void* cache, const int64_t* parent, const int32_t* state, int n_kv, int B, int beam, int h,
+                                      int Tmax, int dtype) {
+    ASR_REQUIRE(cache && parent && state && n_kv > 0 && B > 0 && h > 0 && Tmax > 0, ASR_ERR_ARG, "beam_reorder_cache: bad args");
+    ASR_REQUIRE(beam >= 1 && beam <= 8, ASR_ERR_UNSUPPORTED, "beam_reorder_cache: beam_size %d (at most 8)", beam);
+    ASR_REQUIRE(dtype == ASR_F32 || dtype == ASR_BF16, ASR_ERR_ARG, "beam_reorder_cache: dtype");
+    ASR_REQUIRE(asr_aligned(cache, 16), ASR_ERR_ALIGN, "beam_reorder_cache: alignment");
+    const int segs = dtype == ASR_F32 ? 16 : 8;
+    const int64_t n = (int64_t)n_kv * B * h * Tmax * segs;
+    hipLaunchKernelGGL(beam_reorder_cache_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint4*>(cache), parent, state, n_kv, B, beam, h, Tmax, segs);
+    ASR_LAUNCH_CHECK("beam_reorder_cache");
+    return 0;
+}
+
+extern "C" int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, int N) {
+    ASR_REQUIRE(state && k_len && N > 0, ASR_ERR_ARG, "beam_advance: bad args");
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), state, k_len, N);
+    ASR_LAUNCH_CHECK("beam_advance");
+    return 0;
+}
+
+extern "C" int asr_lsm_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx) {
+    ASR_REQUIRE(x && vals && idx && M > 0 && V > 0 && k > 0 && k <= V && ld >= V, ASR_ERR_ARG, "lsm_topk_rows: bad args (M=%d V=%d k=%d)", M, V, k);
+    ASR_REQUIRE(V <= 64 * 72, ASR_ERR_UNSUPPORTED, "lsm_topk_rows: V = %d (at most 4608; use asr_log_softmax_rows + asr_topk_rows)", V);
+    if (V <= 64 * 16)
+        hipLaunchKernelGGL(lsm_topk_rows_kernel<16>, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, M, V, k, vals, idx);
+    else
+        hipLaunchKernelGGL(lsm_topk_rows_kernel<72>, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, M, V, k, vals, idx);
+    ASR_LAUNCH_CHECK("lsm_topk_rows");
     return 0;
 }

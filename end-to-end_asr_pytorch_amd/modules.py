@@ -1215,6 +1215,156 @@ class Decoder_CIF(_Cached):
         logits = _vocab_proj(self, "prj", self.tgt_word_prj.weight, cat2)
         return logits.view(B, U, self.n_tgt_vocab)
 
+    # ---- inference (decoder.py:401-552) -----------------------------------------------------------------------------------------
+    def _prefix_layers(self, ys, frames32):
+        """input_affine([frames | emb(ys) + pe]) through the layers under the causal mask -> Act [N * U, d] (no pad mask: every
+        prefix position counts, decoder.py:403-404)"""
+        N, U = ys.shape
+        e32, _ = ops.embed_pe(ys.contiguous(), self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U))
+        a = Act(ops.gemm_nt(torch.cat([frames32, e32], -1), self._w("inaff", (self.input_affine.weight,)), None), None, N, U)
+        return a
+
+    def _last_scores(self, frame_last32, x_last32):
+        N = x_last32.shape[0]
+        cat2 = Act(torch.cat([frame_last32, x_last32], -1).contiguous(), None, N, 1)
+        return ops.log_softmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, cat2))
+
+    @torch.no_grad()
+    def step_forward(self, ys, encoded_attentioned, t):
+        """decoder.py:401-423 - log-softmax scores [N, V] of the token after the prefix `ys` int64 [N, t + 1]; the whole prefix is
+        recomputed, like the reference (`recognize_beam` below does not)."""
+        N, U = ys.shape
+        D = encoded_attentioned.shape[-1]
+        frames = encoded_attentioned[:, :t + 1].contiguous().float()
+        a = self._prefix_layers(ys, frames.view(N * U, D))
+        dec_len = torch.full((N,), U, dtype=torch.int32, device=ys.device)
+        for layer in self.layer_stack:
+            a = layer._impl(a, dec_len, causal=True)
+        return self._last_scores(frames[:, -1], a.f32.view(N, U, -1)[:, -1])
+
+    @torch.no_grad()
+    def step_forward_cache(self, ys, enc_attentioned, dec_cache, t):
+        """decoder.py:477-496 - the reference's cached step, same contract: `dec_cache` [N, t, n_layers, d] holds every layer's
+        outputs at the earlier positions -> (scores [N, V], new cache [N, t + 1, n_layers, d]).  Each layer is evaluated on its whole
+        input under the causal mask and the last row kept (= EncoderLayer.forward_cache, encoder.py:81-87: the last query against all
+        positions); `recognize_beam` keeps per-layer K / V instead and never re-reads earlier positions."""
+        N, U = ys.shape
+        D = enc_attentioned.shape[-1]
+        frames = enc_attentioned[:, :t + 1].contiguous().float()
+        x = self._prefix_layers(ys, frames.view(N * U, D))
+        dec_len = torch.full((N,), U, dtype=torch.int32, device=ys.device)
+        new_cache = []
+        for i, layer in enumerate(self.layer_stack):
+            last = layer._impl(x, dec_len, causal=True).f32.view(N, U, -1)[:, -1:]
+            full = torch.cat([dec_cache[:, :, i].to(last.dtype), last], 1).contiguous()
+            new_cache.append(full.unsqueeze(2))
+            x = Act(full.view(N * U, -1), None, N, U)
+        return self._last_scores(frames[:, -1], x.f32.view(N, U, -1)[:, -1]), torch.cat(new_cache, 2)
+
+    @torch.no_grad()
+    def recognize_beam(self, encoded_attentioned, char_list, args):
+        """decoder.py:425-475 - beam search over ONE utterance's integrated frames [1, U, d]: exactly U steps (no <eos> handling),
+        each live hypothesis extended by its `beam` best tokens, candidates (hypothesis-major, rank-minor) cut to the `beam` best by
+        accumulated score with ties in candidate order (Python's stable sort).  -> ([token lists incl. <sos>], [their lengths]), the
+        `nbest` best.  Runs `batch_recognize_beam` on a batch of one."""
+        U = int(encoded_attentioned.shape[1])
+        n = torch.full((1,), U, dtype=torch.int32, device=encoded_attentioned.device)
+        return self.batch_recognize_beam(encoded_attentioned[:1], n, args.beam_size, args.nbest, n_host=[U])[0]
+
+    @torch.no_grad()
+    def batch_recognize_beam(self, frames, n_frames, beam_size, nbest=1, n_host=None):
+        """`recognize_beam` for B utterances at once: frames f32 [B, Umax, d], utterance b decodes exactly n_frames[b] steps ->
+        [(token lists incl. <sos>, lengths)] per utterance, each what the reference's per-utterance search returns.
+        MI355X form: the B * beam hypotheses are the rows of one batch; per step ONE new position goes through the layers against
+        per-layer K / V caches, the pruning (asr_topk_rows, asr_beam_step) gathers token rows and scores in place and the caches are
+        re-gathered by parent row (asr_beam_reorder_cache); the position lives in device memory, so the ~60 launches of a step are
+        captured once per (B, beam, length bucket) as a hipGraph and replayed.  The first step runs `beam` copies of <sos> per
+        utterance with scores [0, -1e10, ...], so only the first copy's extensions survive (needs beam <= vocabulary size)."""
+        beam, nbest = int(beam_size), int(nbest)
+        B, Umax, D = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        dev = frames.device
+        if beam > self.n_tgt_vocab:
+            raise ValueError("recognize_beam: beam_size %d exceeds the vocabulary (%d)" % (beam, self.n_tgt_vocab))
+        if n_host is None:
+            n_host = [int(v) for v in n_frames.tolist()]
+        steps = max(n_host) if n_host else 0
+        if steps > Umax:
+            raise ValueError("recognize_beam: %d steps asked of %d integrated frames" % (steps, Umax))
+        if steps > 0:
+            Tmax = max(32, (steps + 31) // 32 * 32)
+            key = (B, beam, Tmax, D, str(dev), _PRECISION, _PARAM_EPOCH, self.sos_id, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+            g = self.__dict__.get("_beam_graph")
+            if g is None or g["key"] != key:
+                self.__dict__["_beam_graph"] = None
+                g = self._build_beam_graph(B, beam, Tmax, D, dev, key)
+                self.__dict__["_beam_graph"] = g
+            g["frames"][:, :steps].copy_(frames[:, :steps])
+            g["n_steps"].copy_(ops.as_i32(n_frames, dev))
+            g["state"].zero_()
+            g["k_len"].fill_(1)
+            g["preds"].fill_(self.sos_id)
+            g["cur"].fill_(self.sos_id)
+            g["scores"].copy_(g["scores0"])
+            for _ in range(steps):
+                g["step"]()
+            preds = g["preds"].view(B, beam, -1).cpu()
+        out = []
+        for b, n in enumerate(n_host):
+            if n == 0:
+                out.append(([[self.sos_id]], [1]))
+                continue
+            ys = preds[b, :min(beam, nbest), :n + 1].tolist()
+            out.append((ys, [len(y) for y in ys]))
+        return out
+
+    def _build_beam_graph(self, B, beam, Tmax, D, dev, key):
+        n, h, cdt, N = len(self.layer_stack), self.n_head, _cdtype(), B * beam
+        frames = torch.zeros((B, Tmax, D), device=dev, dtype=torch.float32)
+        n_steps = torch.zeros(B, dtype=torch.int32, device=dev)
+        state = torch.zeros(2, dtype=torch.int32, device=dev)
+        k_len = torch.ones(N, dtype=torch.int32, device=dev)
+        cache = torch.zeros((2 * n, N, h, Tmax, 64), device=dev, dtype=cdt)        # [K of layer 0, V of layer 0, K of layer 1, ...]
+        preds = torch.full((N, Tmax + 1), self.sos_id, dtype=torch.long, device=dev)
+        scores0 = torch.tensor([0.0] + [-1e10] * (beam - 1), dtype=torch.float32, device=dev).repeat(B)
+        scores = scores0.clone()
+        cur = torch.full((N,), self.sos_id, dtype=torch.long, device=dev)
+        parent = torch.zeros(N, dtype=torch.long, device=dev)
+        emb = self.tgt_word_emb.weight.detach().float()
+        pe = self.positional_encoding.pe[0].contiguous()
+
+        def step():
+            cat1 = ops.beam_cat_frames(frames, state, beam, cur=cur, emb=emb, pe=pe)            # decoder.py:407-408
+            x = Act(ops.gemm_nt(cat1, self._w("inaff", (self.input_affine.weight,)), None), None, N, 1)
+            for j, layer in enumerate(self.layer_stack):
+                x = layer.slf_attn._impl_cached_self(x, cache[2 * j], cache[2 * j + 1], state, k_len)
+                x = layer.pos_ffn._impl(x, None)
+            cat2 = Act(ops.beam_cat_frames(frames, state, beam, other=x.f32.contiguous()), None, N, 1)     # decoder.py:416
+            best, ids = ops.lsm_topk_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, cat2), beam)
+            ops.beam_step(scores, best, ids, preds, state, n_steps, parent, cur, beam)
+            ops.beam_reorder_cache(cache, parent, state, beam)
+            ops.beam_advance(state, k_len)
+
+        g = _DecodeGraph(key=key, frames=frames, n_steps=n_steps, state=state, k_len=k_len, preds=preds, scores=scores, scores0=scores0, cur=cur)
+        g.keep = (cache, parent, emb, pe, step)     # the captured kernels address these by raw pointer
+        n_steps.fill_(1)
+        step()                          # eager warm-up: code objects, derived weights, allocator pools
+        torch.cuda.synchronize(dev)
+        if os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0":
+            try:
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs):
+                    step()
+                g["step"], g["graphs"] = gs.replay, (gs,)
+                return g
+            except Exception as e:          # not capturable on this stack: search eagerly, remember why
+                import warnings
+                warnings.warn("asr_amd.Decoder_CIF: hipGraph capture of the beam step failed, searching eagerly (%s: %s)" % (type(e).__name__, e))
+                torch.cuda.synchronize(dev)
+        g["step"], g["graphs"] = step, None
+        return g
+
+    recognize_beam_cache = recognize_beam      # decoder.py:498-552: the cached search IS the implementation above
+
 
 # ------------------------------------------------------------------------------------------------------------
 class _TapeFn(torch.autograd.Function):
@@ -1466,6 +1616,31 @@ class CIF_Model(_Cached):
         """cif_model.py:57-106."""
         out, self.last_fire = cif_forward(hidden, alphas, threshold, max_label_len)
         return out
+
+    @torch.no_grad()
+    def recognize(self, input, input_length, char_list, args, threshold=0.95, target_num=None):
+        """cif_model.py:108-131 - beam search for ONE utterance `input` [T, D] -> ([token lists incl. <sos>], [lengths])."""
+        lens = torch.as_tensor(input_length, device=input.device).view(1)
+        return self.batch_recognize(input.unsqueeze(0), lens, args.beam_size, args.nbest, threshold, target_num)[0]
+
+    @torch.no_grad()
+    def batch_recognize(self, features, len_features, beam_size, nbest=1, threshold=0.95, target_num=None):
+        """`recognize` for a padded batch: conv front end, encoder, assigner, optional rescale of each row's weights to `target_num`
+        (a number or one per utterance, cif_model.py:120-123), integrate-and-fire, then ONE batched beam search
+        (Decoder_CIF.batch_recognize_beam).  Utterance b decodes round(sum alpha_b) steps - the length of the reference's zero-padded
+        frame tensor for that utterance (cif_model.py:98-101).  -> [(token lists incl. <sos>, lengths)] per utterance, equal to
+        `recognize` on each utterance alone when the batch is zero-padded (the loader's pad_list; the 'same' conv front end reads
+        up to two frames past an utterance's end, conv_encoder.py:103-105)."""
+        _assign_names(self)
+        conv, len_sequence = self.conv_encoder._impl(features, len_features)
+        enc = self.encoder._impl(conv, len_sequence)
+        alpha = self.assigner._impl(enc, len_sequence, None)
+        if target_num is not None and (torch.is_tensor(target_num) or target_num):
+            num = torch.as_tensor(target_num, device=alpha.device, dtype=alpha.dtype).expand(alpha.shape[0])
+            alpha = alpha * (num / alpha.sum(-1))[:, None]           # [B, L] rows
+        l = self.cif(enc.view3(), alpha, threshold=threshold)
+        n_label = self.last_fire[2]
+        return self.decoder.batch_recognize_beam(l, n_label, beam_size, nbest)
 
     @classmethod
     def create_model(cls, args):

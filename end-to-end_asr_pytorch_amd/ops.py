@@ -717,6 +717,19 @@ def topk_rows(x2d, k):
     return vals, idx
 
 
+def lsm_topk_rows(x2d, k):
+    """topk_rows(log_softmax_rows(x), k) in one kernel (rows up to 4608 columns; longer rows chain the two)"""
+    _req_cuda(x2d)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype == torch.float32
+    M, V = x2d.shape
+    if V > 4608:
+        return topk_rows(log_softmax_rows(x2d), k)
+    vals = torch.empty((M, k), device=x2d.device, dtype=torch.float32)
+    idx = torch.empty((M, k), device=x2d.device, dtype=torch.int64)
+    check(lib().asr_lsm_topk_rows(_stream(), _p(x2d), x2d.stride(0), M, V, int(k), _p(vals), _p(idx)), "asr_lsm_topk_rows")
+    return vals, idx
+
+
 def beam_prune(scores, next_scores, next_preds, beam):
     """decoder.py:196-209: scores f32 [B*beam], next_scores f32 / next_preds int64 [B*beam, beam] -> (new scores [B*beam],
     parent rows int64 [B*beam], new tokens int64 [B*beam])"""
@@ -760,6 +773,53 @@ def decode_advance(cur, preds, state, k_len, finished, len_decoded, eos_id):
     assert k_len.dtype == torch.int32 and state.dtype == torch.int32
     check(lib().asr_decode_advance(_stream(), _p(cur), _p(preds), _p(state), _p(k_len), _p(finished), _p(len_decoded), int(eos_id), B, Tp1),
           "asr_decode_advance")
+
+
+def beam_cat_frames(frames, state, beam, other=None, cur=None, emb=None, pe=None):
+    """rows [frames[b, t] | other[r]] or [frames[b, t] | emb[cur[r]] + pe[t]] (t = state[0], b = r // beam) -> f32 [N, D + D2]"""
+    B, Tmax, D = frames.shape
+    N = B * beam
+    _req_cuda(frames, state)
+    assert frames.is_contiguous() and frames.dtype == torch.float32
+    if cur is not None:
+        _req_cuda(cur, emb, pe)
+        V, D2 = emb.shape
+        out = torch.empty((N, D + D2), device=frames.device, dtype=torch.float32)
+        check(lib().asr_beam_cat_frames(_stream(), _p(frames), _p(state), None, _p(cur), _p(emb), _p(pe), _p(out), N, beam, Tmax, D, D2, V,
+                                        pe.shape[0]), "asr_beam_cat_frames")
+    else:
+        _req_cuda(other)
+        assert other.is_contiguous() and other.dtype == torch.float32 and other.shape[0] == N
+        D2 = other.shape[1]
+        out = torch.empty((N, D + D2), device=frames.device, dtype=torch.float32)
+        check(lib().asr_beam_cat_frames(_stream(), _p(frames), _p(state), _p(other), None, None, None, _p(out), N, beam, Tmax, D, D2, 0, 0),
+              "asr_beam_cat_frames")
+    return out
+
+
+def beam_step(scores, next_scores, next_preds, preds, state, n_steps, parent, cur, beam):
+    """one pruning step of every live utterance, in place (scores [N], preds int64 [N, W], cur, parent int64 [N])"""
+    _req_cuda(scores, next_scores, next_preds, preds, state, n_steps, parent, cur)
+    N, W = preds.shape
+    assert preds.is_contiguous() and preds.dtype == torch.int64 and next_preds.dtype == torch.int64 and next_scores.shape == (N, beam)
+    assert n_steps.dtype == torch.int32 and state.dtype == torch.int32 and n_steps.numel() * beam == N and scores.dtype == torch.float32
+    check(lib().asr_beam_step(_stream(), _p(scores), _p(next_scores), _p(next_preds), _p(preds), _p(state), _p(n_steps), _p(parent), _p(cur),
+                              N // beam, int(beam), W), "asr_beam_step")
+
+
+def beam_reorder_cache(cache, parent, state, beam):
+    """cache [n_kv, N, h, Tmax, 64] re-gathered along N by `parent`, in place, positions <= state[0]"""
+    _req_cuda(cache, parent, state)
+    n_kv, N, h, Tmax, dk = cache.shape
+    assert dk == 64 and cache.is_contiguous() and parent.dtype == torch.int64
+    check(lib().asr_beam_reorder_cache(_stream(), _p(cache), _p(parent), _p(state), n_kv, N // beam, int(beam), h, Tmax, dtype_code(cache)),
+          "asr_beam_reorder_cache")
+
+
+def beam_advance(state, k_len):
+    _req_cuda(state, k_len)
+    assert state.dtype == torch.int32 and k_len.dtype == torch.int32
+    check(lib().asr_beam_advance(_stream(), _p(state), _p(k_len), k_len.numel()), "asr_beam_advance")
 
 
 def log_softmax_rows(x2d):

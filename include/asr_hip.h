@@ -359,6 +359,9 @@ int asr_ctc_greedy_reduce(void* stream, const int64_t* frames, const int32_t* le
 int asr_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx);
 int asr_beam_prune(void* stream, const float* scores, const float* next_scores, const int64_t* next_preds, int B, int beam,
                    float* new_scores, int64_t* parent, int64_t* new_tok);
+/* asr_lsm_topk_rows: asr_topk_rows of log_softmax(x) without materialising it (decoder.py:418-440, F.log_softmax then torch.topk):
+ * same values and order as the two calls; V <= 4608 (ASR_ERR_UNSUPPORTED beyond - chain the two). */
+int asr_lsm_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx);
 /* The per-token step of Decoder.batch_decode (decoder.py:138-164) with its position in device memory, so that the whole step is
  * one capturable launch sequence (hipGraph replay per token).  state int32[2]: [0] = t, the position of the token being fed
  * (0 = <sos>), [1] = the number of steps after which every row had produced <eos>, -1 until then.
@@ -372,6 +375,24 @@ int asr_kv_cache_put(void* stream, const void* k_new, const void* v_new, void* k
                      int Tmax, int dtype);
 int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t* state, int32_t* k_len, unsigned char* finished,
                        int64_t* len_decoded, int eos, int B, int Tp1);
+/* Beam search over integrated frames for B utterances at once (Decoder_CIF.recognize_beam, decoder.py:425-475, which decodes ONE
+ * utterance with a Python loop over hypotheses; Decoder_CIF.step_forward_cache, decoder.py:477-496).  Hypothesis rows r = b * beam + j;
+ * the step position t is state[0]; utterance b is live while t < n_steps[b] (its number of integrated frames).
+ * asr_beam_cat_frames:    out[r] = [frames[b, t, :D] | other] f32 [N, D + D2]; other = other32[r, :D2] or, when `cur` is given,
+ *                         emb[cur[r]] + pe[t] (D2 = row length of emb): decoder.py:407-408 (input_affine's rows) and :416 (tgt_word_prj's)
+ * asr_beam_step:          decoder.py:445-462 for every live utterance, in place: the best `beam` of the beam * beam candidates
+ *                         scores[row j] + next_scores[row j][k] (ties in candidate order = Python's stable sort) -> scores, token rows
+ *                         preds[r, 0..t] gathered from the parents + the new token at column t + 1 (preds int64 [N, W], W <= 512),
+ *                         cur[r], parent[r] (global row ids); a finished utterance is left as it is and reports identity parents
+ * asr_beam_reorder_cache: caches [n_kv, N, h, Tmax, 64] (ASR_F32 | ASR_BF16) re-gathered by parent row in place, positions <= t
+ * asr_beam_advance:       t += 1; k_len[r] += 1 */
+int asr_beam_cat_frames(void* stream, const float* frames, const int32_t* state, const float* other32, const int64_t* cur, const float* emb,
+                        const float* pe, float* out, int N, int beam, int Tmax, int D, int D2, int V, int max_pos);
+int asr_beam_step(void* stream, float* scores, const float* next_scores, const int64_t* next_preds, int64_t* preds, const int32_t* state,
+                  const int32_t* n_steps, int64_t* parent, int64_t* cur, int B, int beam, int W);
+int asr_beam_reorder_cache(void* stream, void* cache, const int64_t* parent, const int32_t* state, int n_kv, int B, int beam, int h, int Tmax,
+                           int dtype);
+int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, int N);
 
 /* ---- CIF family, training side (autograd of cif_model.py:44-48, attentionAssigner.py:37-40, conv_encoder.py:33-49) and the tape's
  * gradient bookkeeping; all f32. */

@@ -644,6 +644,76 @@ def batch_beam_decode(sd, pfx, enc_out, enc_lengths, n_layers, n_head, sos_id, e
     return preds[order].reshape(B, beam_size, -1), len_decoded[order].reshape(B, beam_size), s_sorted
 
 
+def decoder_cif_step_forward(sd, pfx, ys, cif_out, t, n_layers, n_head):
+    """src/transformer/decoder.py:401-423 (Decoder_CIF.step_forward): log-softmax scores [N, V] of the token after the prefix
+    `ys` int64 [N, t + 1], the decoder fed the first t + 1 integrated frames; causal mask only, no pad mask."""
+    ys = np.asarray(ys).astype(np.int64)
+    U = ys.shape[1]
+    slf_mask = get_subsequent_mask(ys) > 0
+    ones = np.ones((ys.shape[0], U, 1), F32)
+    d = sd[pfx + "tgt_word_emb.weight"].shape[1]
+    emb = sd[pfx + "tgt_word_emb.weight"][ys].astype(F32) + positional_encoding(U, d)[None]
+    frames = np.asarray(cif_out, F32)[:, :t + 1]
+    x = linear(np.concatenate([frames, emb], -1), sd[pfx + "input_affine.weight"])
+    for i in range(n_layers):
+        x = encoder_layer(sd, f"{pfx}layer_stack.{i}.", x, ones, slf_mask, n_head)
+    x = np.concatenate([frames, x], -1)
+    return log_softmax(linear(x[:, -1], sd[pfx + "tgt_word_prj.weight"]))
+
+
+def decoder_cif_step_forward_cache(sd, pfx, ys, cif_out, dec_cache, t, n_layers, n_head):
+    """src/transformer/decoder.py:477-496 with EncoderLayer.forward_cache (encoder.py:81-87): only the last position goes through
+    each layer (its query against the layer's whole input, no mask), the earlier positions' layer outputs come from `dec_cache`
+    [N, t, n_layers, d] -> (scores [N, V], new cache [N, t + 1, n_layers, d])"""
+    ys = np.asarray(ys).astype(np.int64)
+    U = ys.shape[1]
+    d = sd[pfx + "tgt_word_emb.weight"].shape[1]
+    emb = sd[pfx + "tgt_word_emb.weight"][ys].astype(F32) + positional_encoding(U, d)[None]
+    frames = np.asarray(cif_out, F32)[:, :t + 1]
+    x = linear(np.concatenate([frames, emb], -1), sd[pfx + "input_affine.weight"])
+    new_cache = []
+    for i in range(n_layers):
+        lp = f"{pfx}layer_stack.{i}."
+        last = multihead_attention(sd, lp + "slf_attn.", x[:, -1:], x, x, None, n_head)
+        last = positionwise_ffn(sd, lp + "pos_ffn.", last)
+        x = np.concatenate([np.asarray(dec_cache, F32)[:, :, i], last], 1)
+        new_cache.append(x[:, :, None])
+    new_cache = np.concatenate(new_cache, 2)
+    x = np.concatenate([frames, x], -1)
+    return log_softmax(linear(x[:, -1], sd[pfx + "tgt_word_prj.weight"])), new_cache
+
+
+def decoder_cif_recognize_beam(sd, pfx, cif_out, n_layers, n_head, sos_id, beam_size, nbest):
+    """src/transformer/decoder.py:425-475 (Decoder_CIF.recognize_beam), one utterance: exactly `maxlen` = number of integrated
+    frames steps (no <eos> handling), every live hypothesis extended by its `beam` best tokens, the candidates (hypothesis-major,
+    rank-minor) stable-sorted by accumulated score and cut to `beam`.  -> (token lists incl. <sos>, their lengths, scores)"""
+    cif_out = np.asarray(cif_out, F32)
+    hyps = [(F32(0.0), [sos_id])]
+    for i in range(cif_out.shape[1]):
+        kept = []
+        for score, yseq in hyps:
+            z = decoder_cif_step_forward(sd, pfx, np.array([yseq]), cif_out, i, n_layers, n_head)
+            best, ids = _topk(z, beam_size)
+            for j in range(beam_size):
+                kept.append((F32(score + best[0, j]), yseq + [int(ids[0, j])]))
+        order = sorted(range(len(kept)), key=lambda c: -kept[c][0])      # stable, like Python's sorted(reverse=True) on the scores
+        hyps = [kept[c] for c in order[:beam_size]]
+    order = sorted(range(len(hyps)), key=lambda c: -hyps[c][0])[:min(len(hyps), nbest)]
+    return [hyps[c][1] for c in order], [len(hyps[c][1]) for c in order], [hyps[c][0] for c in order]
+
+
+def cif_model_recognize(sd, feats, cfg, beam_size, nbest, threshold=0.95, target_num=None):
+    """src/transformer/cif_model.py:108-131 (CIF_Model.recognize), one utterance feats [T, D]"""
+    feats = np.asarray(feats, F32)[None]
+    conv_out, lens = conv2d_subsample(sd, "conv_encoder.", feats, np.array([feats.shape[1]]), cfg["n_conv_layers"])
+    enc = encoder_forward(sd, "encoder.", conv_out, lens, cfg["n_layers_enc"], cfg["n_head"])
+    alpha = attention_assigner(sd, "assigner.", enc, lens, cfg["n_assigner_layers"], cfg["w_context"])
+    if target_num:
+        alpha = alpha * (F32(target_num) / alpha.sum(-1, dtype=F32))[:, None]
+    l, _, _ = cif(enc, alpha, threshold)
+    return decoder_cif_recognize_beam(sd, "decoder.", l, cfg["n_layers_dec"], cfg["n_head"], cfg["sos_id"], beam_size, nbest), l, alpha
+
+
 def lfr(inputs, m, n):
     """src/utils/data.py:191-218 - stack m frames every n frames; the last frame repeats past the end."""
     T = len(inputs)

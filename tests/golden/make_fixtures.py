@@ -576,6 +576,56 @@ def g12_beam_decode():
                         **out, **cfg_arrays())
 
 
+def g13_cif_recognize():
+    """CIF_Model.recognize (cif_model.py:108-131) -> Decoder_CIF.recognize_beam (decoder.py:425-475), one utterance at a time:
+    the G4 model in eval mode, three utterances, several beam / nbest / target_num settings; also one step_forward /
+    step_forward_cache call (decoder.py:401-423, 477-496) and recognize_beam_cache (:498-552) on the same integrated frames."""
+    orig_mask = tdec.get_subsequent_mask
+    tdec.get_subsequent_mask = lambda seq: orig_mask(seq).bool()     # same harness shim as G9
+    args = argparse.Namespace(**S0)
+    model = CIF_Model.create_model(args).eval()
+    ns, sd = load_seeded(model, seed=104)
+    x, lens, tg = s0_batch(seed=4)
+    chars = ["c%d" % i for i in range(S0["vocab_size"])]
+    out, cases = {}, []
+    import contextlib
+    import io
+    with torch.no_grad():
+        for u, beam, nbest, tnum in ((0, 3, 2, None), (1, 1, 1, None), (2, 4, 4, 6), (3, 2, 1, 5), (0, 5, 3, 9)):
+            T = int(lens[u])
+            dec_args = argparse.Namespace(beam_size=beam, nbest=nbest)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ys, ls = model.recognize(x[u, :T], lens[u:u + 1], chars, dec_args, target_num=tnum)
+                # the integrated frames recognize() decoded, recomputed the same way (cif_model.py:117-126)
+                conv_out, len_seq = model.conv_encoder(x[u, :T].unsqueeze(0), lens[u:u + 1])
+                enc_out = model.encoder(conv_out, len_seq)
+                alpha = model.assigner(enc_out, len_seq)
+                if tnum:
+                    alpha = alpha * (tnum / alpha.sum(-1))[:, None].repeat(1, alpha.size(1))
+                l = model.cif(enc_out, alpha, threshold=0.95)
+                ys_c, ls_c = model.decoder.recognize_beam_cache(l, chars, dec_args)
+            tag = "u%d_b%d_n%d_t%d" % (u, beam, nbest, tnum or 0)
+            cases.append("%d,%d,%d,%d" % (u, beam, nbest, tnum or 0))
+            width = max(ls)
+            out["yseq_" + tag] = np.array([y + [-1] * (width - len(y)) for y in ys], np.int64)
+            out["len_" + tag] = np.array(ls, np.int64)
+            out["yseq_cache_" + tag] = np.array([y + [-1] * (max(ls_c) - len(y)) for y in ys_c], np.int64)
+            out["cif_" + tag], out["alpha_" + tag] = npy(l), npy(alpha)
+            print("G13", tag, "frames", tuple(l.shape), ys[0], "cache-equal", ys == ys_c)
+        # one step of each stepping form on the last case's frames: prefix of 3 tokens for 2 hypotheses
+        l2 = l.repeat(2, 1, 1)
+        prefix = torch.tensor([[S0["sos_id"], 7, 11], [S0["sos_id"], 5, 5]])
+        sc = model.decoder.step_forward(prefix, l2, 2)
+        cache = torch.zeros([2, 0, S0["n_layers_dec"], S0["d_model"]])
+        for t in range(3):
+            sc_c, cache = model.decoder.step_forward_cache(prefix[:, :t + 1], l2, cache, t)
+        out["step_prefix"], out["step_scores"], out["step_scores_cache"], out["step_cache"] = npy(prefix), npy(sc), npy(sc_c), npy(cache)
+        print("G13 step_forward vs cache max diff", float((sc - sc_c).abs().max()))
+    tdec.get_subsequent_mask = orig_mask
+    np.savez_compressed(os.path.join(HERE, "g13_cif_recognize.npz"), names_shapes=names_shapes_to_json(ns), seed=104, crc=crc_of(sd),
+                        x=npy(x), lens=npy(lens), cases="|".join(cases), **out, **cfg_arrays())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g0_conv_ctc_transformer()
@@ -591,3 +641,4 @@ if __name__ == "__main__":
     g10_input_pipeline()
     g11_mask_lm()
     g12_beam_decode()
+    g13_cif_recognize()

@@ -169,3 +169,20 @@ def test_batch_decode_smallest_shapes(golden_dir, monkeypatch):
         res[mode] = (p1.cpu().numpy(), l1.cpu().numpy(), pb.cpu().numpy(), lb.cpu().numpy())
     for a, b in zip(res["1"], res["0"]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("V", [50, 1024, 1025, 4234, 4608, 5000])
+def test_lsm_topk_rows_equals_the_two_kernels(V):
+    g = torch.Generator().manual_seed(V)
+    x = (3.0 * torch.randn(37, V, generator=g)).to(DEV)
+    x[3, 7] = x[3, 11] = x[3].max() + 1.0                     # a tie for the first place: index order
+    v, i = ops.lsm_topk_rows(x, 5)
+    v2, i2 = ops.topk_rows(ops.log_softmax_rows(x), 5)
+    np.testing.assert_array_equal(i.cpu().numpy(), i2.cpu().numpy())
+    np.testing.assert_array_equal(v.cpu().numpy(), v2.cpu().numpy())
+    assert i[3, :2].tolist() == [7, 11]
+    # a strided view (rows padded like the vocabulary projection's buffer)
+    buf = torch.zeros((9, (V + 7) // 8 * 8 + 8), device=DEV)
+    buf[:, :V] = x[:9]
+    v3, i3 = ops.lsm_topk_rows(buf[:, :V], 3)
+    np.testing.assert_array_equal(i3.cpu().numpy(), i2[:9, :3].cpu().numpy())
