@@ -1,7 +1,8 @@
 """The input step in front of the path: low-frame-rate stacking, SpecAugment, frame-budget batching.
 
-Reference: src/utils/data.py:28-110 (AudioDataset batching), :191-218 (build_LFR_features), src/utils/utils.py:168-194 (spec_aug).
-Feature files themselves (Kaldi ark via kaldi_io) stay out of scope: the functions here start from arrays / shape metadata.
+Reference: src/utils/data.py:28-110 (AudioDataset batching), :113-160 (LFRCollate / _collate_fn), :163-188 (load_inputs_and_targets),
+:191-218 (build_LFR_features), src/utils/utils.py:168-194 (spec_aug).  Feature matrices are read from Kaldi ark files by `kaldi_ark`
+(the reference goes through the third-party kaldi_io package).
 """
 import ctypes
 
@@ -117,3 +118,39 @@ def shard_by_length(lengths, world):
         lap, slot = divmod(pos, world)
         shards[slot if lap % 2 == 0 else world - 1 - slot].append(idx)
     return shards
+
+
+def load_inputs_and_targets(batch, token2idx, label_type="token", LFR_m=1, LFR_n=1, read_mat=None):
+    """utils/data.py:163-188: one minibatch (list of (key, sample) from `make_minibatches`) -> (xs, ys): feature matrices read from
+    sample['input'][0]['feat'] ("file.ark:offset"), LFR-stacked on the host when LFR_m / LFR_n != 1, utterances without labels
+    dropped, the rest sorted long to short (stable), labels mapped through token2idx to int64 arrays."""
+    from . import kaldi_ark
+    read_mat = read_mat or kaldi_ark.read_mat
+    xs = [read_mat(b[1]["input"][0]["feat"]) for b in batch]
+    ys = [b[1]["output"][0][label_type].split() for b in batch]
+    if LFR_m != 1 or LFR_n != 1:
+        xs = [build_LFR_features(x, LFR_m, LFR_n) for x in xs]
+    order = sorted((i for i in range(len(xs)) if len(ys[i]) > 0), key=lambda i: -len(xs[i]))
+    if len(order) != len(xs):
+        print("warning: Target sequences include empty token")
+    return [xs[i] for i in order], [np.fromiter((token2idx[t] for t in ys[i]), dtype=np.int64) for i in order]
+
+
+class LFRCollate(object):
+    """utils/data.py:113-160 (LFRCollate + _collate_fn): the DataLoader's collate_fn.  `batch` is a list holding ONE minibatch
+    (AudioDataset.__getitem__) -> (xs_pad f32 [N, Tmax, D] zero-padded, ilens int64 [N], ys_pad int64 [N, Umax] zero-padded)."""
+
+    def __init__(self, token2idx, label_type, LFR_m=1, LFR_n=1, read_mat=None):
+        self.token2idx, self.label_type, self.LFR_m, self.LFR_n, self.read_mat = token2idx, label_type, LFR_m, LFR_n, read_mat
+
+    def __call__(self, batch):
+        assert len(batch) == 1
+        xs, ys = load_inputs_and_targets(batch[0], self.token2idx, self.label_type, self.LFR_m, self.LFR_n, self.read_mat)
+        ilens = torch.from_numpy(np.array([x.shape[0] for x in xs], dtype=np.int64))
+        xs_pad = torch.zeros((len(xs), max(x.shape[0] for x in xs), xs[0].shape[1]), dtype=torch.float32)
+        for i, x in enumerate(xs):
+            xs_pad[i, :x.shape[0]] = torch.from_numpy(np.asarray(x, dtype=np.float32))
+        ys_pad = torch.zeros((len(ys), max(len(y) for y in ys)), dtype=torch.long)
+        for i, y in enumerate(ys):
+            ys_pad[i, :len(y)] = torch.from_numpy(y)
+        return xs_pad, ilens, ys_pad

@@ -626,6 +626,61 @@ def g13_cif_recognize():
                         x=npy(x), lens=npy(lens), cases="|".join(cases), **out, **cfg_arrays())
 
 
+def g14_collate():
+    """The reference's AudioDataset + AudioDataLoader / LFRCollate / load_inputs_and_targets (utils/data.py:28-188) over a small
+    corpus: features in a Kaldi ark written by THIS repo's writer (the reference reads arks through the third-party kaldi_io, absent
+    here: the harness points kaldi_io.read_mat at the repo's reader - this fixture pins the batching / sorting / label mapping /
+    padding / LFR logic, not the ark format), two configurations (plain, LFR 4/3), an utterance with an empty label string."""
+    import json
+    import tempfile
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "end-to-end_asr_pytorch_amd"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kaldi_ark", os.path.join(os.path.dirname(os.path.dirname(HERE)),
+                                                                              "end-to-end_asr_pytorch_amd", "kaldi_ark.py"))
+    kaldi_ark = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kaldi_ark)
+    kio = sys.modules.setdefault("kaldi_io", types.ModuleType("kaldi_io"))
+    kio.read_mat = kaldi_ark.read_mat
+    import utils.data as ud
+    ud.kaldi_io = kio
+    g = np.random.default_rng(14)
+    vocab = ["<unk>", "<blk>", "<sos>", "<eos>"] + ["t%d" % i for i in range(20)]
+    token2idx = {t: i for i, t in enumerate(vocab)}
+    out, utts, feats = {}, {}, {}
+    for i in range(11):
+        T = int(g.integers(30, 90))
+        U = int(g.integers(2, 6))
+        feats["utt%02d" % i] = g.standard_normal((T, 5)).astype(np.float32)
+        toks = " ".join(vocab[int(j)] for j in g.integers(4, len(vocab), U))
+        utts["utt%02d" % i] = {"input": [{"shape": [T, 5]}], "output": [{"shape": [U, len(vocab)], "token": toks}]}
+    utts["utt03"]["output"][0]["token"] = ""           # dropped by load_inputs_and_targets with a warning (data.py:177-181)
+    with tempfile.TemporaryDirectory() as td:
+        ark = os.path.join(td, "feats.ark")
+        with open(ark, "wb") as f:
+            for k, m in feats.items():
+                utts[k]["input"][0]["feat"] = "%s:%d" % (ark, kaldi_ark.write_mat(f, m, key=k))
+        path = os.path.join(td, "data.json")
+        json.dump({"utts": utts}, open(path, "w"))
+        ds = ud.AudioDataset(path, batch_size=4, max_length_in=60, max_length_out=4)
+        for tag, (m, n) in (("plain", (1, 1)), ("lfr43", (4, 3))):
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                batches = list(ud.AudioDataLoader(ds, batch_size=1, token2idx=token2idx, LFR_m=m, LFR_n=n, label_type="token"))
+            out["n_%s" % tag] = len(batches)
+            for i, (xs, il, ys) in enumerate(batches):
+                # utils.utils.pad_list returns (padded, lengths) and _collate_fn passes the pair on (data.py:156-158): keep the padded part
+                xs, ys = (xs[0] if isinstance(xs, tuple) else xs), (ys[0] if isinstance(ys, tuple) else ys)
+                out["%s_x%d" % (tag, i)], out["%s_l%d" % (tag, i)], out["%s_y%d" % (tag, i)] = npy(xs), npy(il), npy(ys)
+            print("G14", tag, [tuple(out["%s_x%d" % (tag, i)].shape) for i in range(len(batches))])
+    for k, m in feats.items():
+        out["feat_" + k] = m
+    meta = {k: {"input": [{"shape": v["input"][0]["shape"]}], "output": [{"shape": v["output"][0]["shape"], "token": v["output"][0]["token"]}]}
+            for k, v in utts.items()}
+    np.savez_compressed(os.path.join(HERE, "g14_collate.npz"), utts=json.dumps(meta), vocab=json.dumps(vocab), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     g0_conv_ctc_transformer()
@@ -642,3 +697,4 @@ if __name__ == "__main__":
     g11_mask_lm()
     g12_beam_decode()
     g13_cif_recognize()
+    g14_collate()
