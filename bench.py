@@ -49,7 +49,8 @@ def parse_args():
                     help="train: forward+loss+backward+grad all-reduce+Adam in train mode (default); fwd: eval-mode forward+loss only; "
                          "decode: eval-mode encoder + greedy batch_decode (KV-cached, --decode-len steps) + CTC greedy decode")
     ap.add_argument("--decode-len", type=int, default=50, help="max_decode_len of --mode decode (decoder.py:138)")
-    ap.add_argument("--beam", type=int, default=5, help="beam size of --model cif --mode decode (Decoder_CIF.recognize_beam, decoder.py:425)")
+    ap.add_argument("--beam", type=int, default=0, help="--mode decode: beam size; 0 = greedy batch_decode for s1 / s2 (Decoder.batch_beam_decode, "
+                         "decoder.py:166, when > 0) and beam 5 for --model cif (Decoder_CIF.recognize_beam, decoder.py:425)")
     ap.add_argument("--dropout", type=float, default=0.1,
                     help="dropout rate of the training step (0.1 = every shipped config of the reference, egs/*/conf); ignored by --mode fwd")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("ASR_AMD_GRAPH", "-1")),
@@ -268,6 +269,7 @@ def main():
         CFG["n_conv_layers"] = 2
     if args.model == "cif":
         CFG["cif"] = True
+        args.beam = args.beam or 5
         if args.mode == "fwd":
             raise SystemExit("bench.py: --model cif runs --mode train or --mode decode")
     if world > 1:
@@ -321,7 +323,10 @@ def main():
                 else:
                     l = ops.as_i32(lens, dev)
                     enc = model.encoder._impl(_act(x), l)
-                preds, n_dec, _ = model.decoder.batch_decode(enc.view3(), l, args.decode_len)
+                if args.beam > 0:
+                    preds, n_dec, _ = model.decoder.batch_beam_decode(enc.view3(), l, args.beam, args.decode_len)
+                else:
+                    preds, n_dec, _ = model.decoder.batch_decode(enc.view3(), l, args.decode_len)
                 toks, n_ctc = asr_amd.ctc_greedy_decode(model._ctc_logits(enc).view(enc.B, enc.L, -1), l)
             return n_dec.float().mean(), n_ctc.float().mean()
         with torch.no_grad():
@@ -413,7 +418,9 @@ def main():
         what = ("training step (train mode, dropout %g): forward + joint CTC/CE loss + backward + grad all-reduce + Adam" % args.dropout
                 if train else (("CIF_Model.batch_recognize: conv + encoder + assigner + CIF (target_num %d) + one batched Decoder_CIF beam search "
                                 "(beam %d, K/V caches, step replayed as a hipGraph)" % (CFG["U"], args.beam)) if (args.mode == "decode" and CFG.get("cif")) else
-                               "eval-mode encoder + greedy batch_decode (%d steps, KV cache) + CTC greedy decode" % args.decode_len
+                               ("eval-mode encoder + batch_beam_decode (beam %d, %d steps, K/V caches, replayed step) + CTC greedy decode" % (args.beam, args.decode_len)
+                                if args.beam > 0 else
+                                "eval-mode encoder + greedy batch_decode (%d steps, KV cache) + CTC greedy decode" % args.decode_len)
                                if args.mode == "decode" else "eval-mode forward + joint CTC/CE loss"))
         mname = ("S2: Conv_CTC_Transformer (2 conv layers, L=%d)" % (CFG["T"] // 4)) if CFG["n_conv_layers"] else "S1: CTC_Transformer"
         if CFG.get("cif"):

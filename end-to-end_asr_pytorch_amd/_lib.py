@@ -91,7 +91,7 @@ SIGNATURES = {
     "asr_beam_cat_frames": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_beam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_beam_reorder_cache": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
-    "asr_beam_advance": [_vp, _vp, _vp, _i],
+    "asr_beam_advance": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "asr_add2d": [_vp, _vp, _i64, _vp, _i64, _i, _i],
     "asr_add_transposed": [_vp, _vp, _vp, _i, _i, _i, _i64],
     "asr_relu_mask_mul": [_vp, _vp, _vp, _i, _vp, _i64],

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void beam_step_kernel(float* __restrict__ score
     __shared__ int64_t rows[8 * BEAM_MAX_W];
     const int b = blockIdx.x, lane = threadIdx.x, nc = beam * beam;
     const int t = state[0];
-    if (t >= n_steps[b] || t + 1 >= W) {
+    if (t >= n_steps[b] || t + 1 >= W || state[1] >= 0) {      // (state[1]: the step count at which the search stopped, -1 while it runs)
         if (lane < beam) parent[b * beam + lane] = b * beam + lane;
         return;
     }
@@ -368,10 +368,30 @@ __global__ __launch_bounds__(256) void beam_reorder_cache_kernel(uint4* __restri
         if (r < beam) base[(int64_t)r * row_stride] = v[r];
 }
 
-// t += 1, every row's key length += 1
-__global__ __launch_bounds__(256) void beam_advance_kernel(int32_t* __restrict__ state, int32_t* __restrict__ k_len, int N) {
-    for (int r = threadIdx.x; r < N; r += 256) k_len[r] += 1;
-    if (threadIdx.x == 0) state[0] += 1;
+// End of a search step: t += 1, every row's key length += 1; with `finished` given also decoder.py:211-216 - finished[r] |= cur[r] == eos,
+// len_decoded[r] += !finished[r] (both stay with the beam SLOT, like the reference's), and once every row is finished state[1] = the
+// number of steps taken: from then on asr_beam_step and this kernel change nothing (the host reads the flag every few steps)
+__global__ __launch_bounds__(256) void beam_advance_kernel(int32_t* __restrict__ state, int32_t* __restrict__ k_len, int N,
+                                                           const int64_t* __restrict__ cur, int eos, unsigned char* __restrict__ finished,
+                                                           int64_t* __restrict__ len_decoded) {
+    if (state[1] >= 0) return;
+    const int t = state[0];
+    int all = 1;
+    for (int r = threadIdx.x; r < N; r += 256) {
+        k_len[r] += 1;
+        if (finished) {
+            const unsigned char f = finished[r] | (unsigned char)(cur[r] == eos);
+            finished[r] = f;
+            len_decoded[r] += f ? 0 : 1;
+            all &= f;
+        }
+    }
+    if (finished) all = __syncthreads_and(all);
+    __syncthreads();                                   // every thread has read state[] before it changes
+    if (threadIdx.x == 0) {
+        state[0] = t + 1;
+        if (finished && all) state[1] = t + 1;
+    }
 }
 
 }  // namespace
@@ -486,9 +506,12 @@ extern "C" int asr_beam_reorder_cache(void* stream, void* cache, const int64_t* 
     return 0;
 }
 
-extern "C" int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, int N) {
+extern "C" int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, int N, const int64_t* cur, int eos, unsigned char* finished,
+                                int64_t* len_decoded) {
     ASR_REQUIRE(state && k_len && N > 0, ASR_ERR_ARG, "beam_advance: bad args");
-    hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), state, k_len, N);
+    ASR_REQUIRE(!finished || (cur && len_decoded), ASR_ERR_ARG, "beam_advance: `finished` needs cur and len_decoded");
+    hipLaunchKernelGGL(beam_advance_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), state, k_len, N, cur, eos, finished,
+                       len_decoded);
     ASR_LAUNCH_CHECK("beam_advance");
     return 0;
 }

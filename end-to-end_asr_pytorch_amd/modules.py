@@ -1030,32 +1030,110 @@ class Decoder(_Cached):
     @torch.no_grad()
     def batch_beam_decode(self, encoded, len_encoded, beam_size=1, max_decode_len=100):
         """decoder.py:166-234 - beam search over a batch -> (preds int64 [B, beam, steps], len_decoded [B, beam], scores f32 [B, beam]),
-        beams sorted by score.  Like the reference every step recomputes the whole prefix (`step`), the initial scores are
-        [0, -1e10, ...] per utterance, and `finished` / `len_decoded` stay with the beam SLOT when the beams are re-gathered.
-        top-k over the vocabulary and the beam * beam pruning are HIP kernels (asr_topk_rows, asr_beam_prune); what torch does
-        here is integer bookkeeping on [B * beam] / [B * beam, steps] tensors."""
-        B, beam = len_encoded.size(0), int(beam_size)
+        beams sorted by score.  The reference's arithmetic and quirks - initial scores [0, -1e10, ...] per utterance, log_softmax
+        applied to `step`'s log-probabilities again (:191), `finished` / `len_decoded` staying with the beam SLOT when the beams are
+        re-gathered - on the decode path's machinery instead of a per-step recompute of the whole prefix: the B * beam hypotheses are
+        rows that feed ONE new position per step through the layers against per-layer self-attention K / V caches (re-gathered by
+        parent row after the pruning); the beams of an utterance are `beam` query positions of ONE cross-attention over that
+        utterance's encoder K / V (projected once for all layers, not replicated per beam); position, stop flag and <eos> bookkeeping
+        live in device memory (asr_beam_step / asr_beam_reorder_cache / asr_beam_advance), so the step is captured once per shape and
+        replayed; the reference's per-step `finished.all()` becomes a 4-byte read every 8 steps."""
+        B, L = encoded.shape[0], encoded.shape[1]
+        beam, T = int(beam_size), int(max_decode_len)
         dev = encoded.device
-        enc = encoded[:, None].repeat(1, beam, 1, 1).view(B * beam, -1, encoded.size(-1))
-        lens = len_encoded[:, None].repeat(1, beam).view(-1)
-        preds = torch.full((B * beam, 1), self.sos_id, dtype=torch.long, device=dev)
-        len_decoded = torch.ones_like(lens)
-        scores = torch.tensor([0.0] + [-1e10] * (beam - 1), dtype=torch.float32, device=dev).repeat(B)
-        finished = torch.zeros(B * beam, dtype=torch.bool, device=dev)
-        for _ in range(int(max_decode_len)):
-            z = ops.log_softmax_rows(self.step(preds, enc, lens))            # (decoder.py:191 applies log_softmax to step's log-probs again)
-            next_scores, next_preds = ops.topk_rows(z, beam)
-            scores, parent, nxt = ops.beam_prune(scores, next_scores, next_preds, beam)
-            preds = torch.cat([preds[parent], nxt[:, None]], 1)
-            finished = torch.logical_or(finished, nxt.eq(self.eos_id))
-            len_decoded = len_decoded + (1 - finished.to(len_decoded.dtype))
-            if bool(finished.all()):
-                break
-        len_decoded = len_decoded - (1 - finished.to(len_decoded.dtype))
-        preds = preds[:, 1:]
-        scores_sorted, order = ops.topk_rows(scores.view(B, beam), beam)
+        if T <= 0:
+            z = torch.zeros((B, beam), dtype=len_encoded.dtype, device=dev)
+            return (torch.zeros((B, beam, 0), dtype=torch.long, device=dev), z,
+                    torch.tensor([0.0] + [-1e10] * (beam - 1), dtype=torch.float32, device=dev).repeat(B).view(B, beam))
+        key = (B, L, T, beam, str(dev), _PRECISION, _PARAM_EPOCH, self.sos_id, self.eos_id, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        g = self.__dict__.get("_beam_graph")
+        if g is None or g["key"] != key:
+            self.__dict__["_beam_graph"] = None
+            g = self._build_beam_graph(B, L, T, beam, dev, key)
+            self.__dict__["_beam_graph"] = g
+        g["enc"].copy_(encoded.reshape(B * L, -1))
+        g["enc_len"].copy_(ops.as_i32(len_encoded, dev))
+        g["state"].copy_(g["state0"])
+        g["k_len"].fill_(1)
+        g["finished"].zero_()
+        g["len_decoded"].fill_(1)
+        g["preds"].fill_(self.sos_id)
+        g["cur"].fill_(self.sos_id)
+        g["scores"].copy_(g["scores0"])
+        g["prologue"]()
+        steps = T
+        for t in range(T):
+            g["step"]()
+            if (t & 7) == 7 or t == T - 1:
+                stop = int(g["state"][1])
+                if stop >= 0:
+                    steps = stop
+                    break
+        fin = g["finished"].to(len_encoded.dtype)
+        len_decoded = g["len_decoded"].to(len_encoded.dtype) - (1 - fin)
+        scores_sorted, order = ops.topk_rows(g["scores"].view(B, beam), beam)
         order = (torch.arange(B, device=dev)[:, None] * beam + order).view(-1)
-        return preds[order].view(B, beam, -1), len_decoded[order].view(B, beam), scores_sorted
+        return g["preds"][:, 1:steps + 1][order].view(B, beam, -1), len_decoded[order].view(B, beam), scores_sorted
+
+    def _build_beam_graph(self, B, L, T, beam, dev, key):
+        n, h, cdt, d, N = len(self.layer_stack), self.n_head, _cdtype(), self.d_model, B * beam
+        enc_buf = torch.zeros((B * L, d), device=dev, dtype=torch.float32)
+        enc_len = torch.ones(B, dtype=torch.int32, device=dev)
+        state0 = torch.tensor([0, -1], dtype=torch.int32, device=dev)
+        state = state0.clone()
+        k_len = torch.ones(N, dtype=torch.int32, device=dev)
+        finished = torch.zeros(N, dtype=torch.uint8, device=dev)
+        len_decoded = torch.ones(N, dtype=torch.int64, device=dev)
+        preds = torch.full((N, T + 1), self.sos_id, dtype=torch.long, device=dev)
+        scores0 = torch.tensor([0.0] + [-1e10] * (beam - 1), dtype=torch.float32, device=dev).repeat(B)
+        scores = scores0.clone()
+        cur = torch.full((N,), self.sos_id, dtype=torch.long, device=dev)
+        parent = torch.zeros(N, dtype=torch.long, device=dev)
+        n_steps = torch.full((B,), T + 1, dtype=torch.int32, device=dev)          # every utterance takes every step (the <eos> stop is global)
+        cache = torch.zeros((2 * n, N, h, T, 64), device=dev, dtype=cdt)
+        emb = self.tgt_word_emb.weight.detach().float()
+        pe = self.positional_encoding.pe[0].contiguous()
+        box = {}
+
+        def prologue():
+            enc = Act(enc_buf, None, B, L)
+            box["enc"], box["cross"] = enc, self._cross_kv(enc)
+
+        def step():
+            x32, x16 = ops.decode_embed(cur, emb, pe, state, want_bf16=(_PRECISION == "bf16"))
+            x = Act(x32, x16, N, 1)
+            for i, layer in enumerate(self.layer_stack):
+                x = layer.slf_attn._impl_cached_self(x, cache[2 * i], cache[2 * i + 1], state, k_len)
+                xq = Act(x.f32, x.b16, B, beam)               # the beams of an utterance: `beam` queries of one cross-attention
+                xq = layer.enc_attn._impl(xq, box["enc"], enc_len, False, None, kv_pre=box["cross"](i))
+                x = layer.pos_ffn._impl(Act(xq.f32, xq.b16, N, 1), None)
+            z = ops.log_softmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x))      # Decoder.step's log-probabilities ...
+            best, ids = ops.lsm_topk_rows(z, beam)                                                # ... log_softmax again (decoder.py:191), top-k
+            ops.beam_step(scores, best, ids, preds, state, n_steps, parent, cur, beam)
+            ops.beam_reorder_cache(cache, parent, state, beam)
+            ops.beam_advance(state, k_len, cur, self.eos_id, finished, len_decoded)
+
+        g = _DecodeGraph(key=key, enc=enc_buf, enc_len=enc_len, state=state, state0=state0, k_len=k_len, finished=finished,
+                         len_decoded=len_decoded, preds=preds, scores=scores, scores0=scores0, cur=cur)
+        g.keep = (cache, parent, n_steps, emb, pe, box, prologue, step)     # the captured kernels address these by raw pointer
+        prologue()                      # eager warm-up of both parts: code objects, derived weights, allocator pools
+        step()
+        torch.cuda.synchronize(dev)
+        if os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0":
+            try:
+                gp, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gp):
+                    prologue()
+                with torch.cuda.graph(gs, pool=gp.pool()):
+                    step()
+                g["prologue"], g["step"], g["graphs"] = gp.replay, gs.replay, (gp, gs)
+                return g
+            except Exception as e:          # not capturable on this stack: search eagerly, remember why
+                import warnings
+                warnings.warn("asr_amd.Decoder: hipGraph capture of the beam step failed, searching eagerly (%s: %s)" % (type(e).__name__, e))
+                torch.cuda.synchronize(dev)
+        g["prologue"], g["step"], g["graphs"] = prologue, step, None
+        return g
 
     def _build_decode_graph(self, B, L, T, dev, key):
         n, h = len(self.layer_stack), self.n_head
@@ -1300,7 +1378,7 @@ class Decoder_CIF(_Cached):
                 self.__dict__["_beam_graph"] = g
             g["frames"][:, :steps].copy_(frames[:, :steps])
             g["n_steps"].copy_(ops.as_i32(n_frames, dev))
-            g["state"].zero_()
+            g["state"].copy_(g["state0"])
             g["k_len"].fill_(1)
             g["preds"].fill_(self.sos_id)
             g["cur"].fill_(self.sos_id)
@@ -1321,7 +1399,8 @@ class Decoder_CIF(_Cached):
         n, h, cdt, N = len(self.layer_stack), self.n_head, _cdtype(), B * beam
         frames = torch.zeros((B, Tmax, D), device=dev, dtype=torch.float32)
         n_steps = torch.zeros(B, dtype=torch.int32, device=dev)
-        state = torch.zeros(2, dtype=torch.int32, device=dev)
+        state0 = torch.tensor([0, -1], dtype=torch.int32, device=dev)
+        state = state0.clone()
         k_len = torch.ones(N, dtype=torch.int32, device=dev)
         cache = torch.zeros((2 * n, N, h, Tmax, 64), device=dev, dtype=cdt)        # [K of layer 0, V of layer 0, K of layer 1, ...]
         preds = torch.full((N, Tmax + 1), self.sos_id, dtype=torch.long, device=dev)
@@ -1344,7 +1423,8 @@ class Decoder_CIF(_Cached):
             ops.beam_reorder_cache(cache, parent, state, beam)
             ops.beam_advance(state, k_len)
 
-        g = _DecodeGraph(key=key, frames=frames, n_steps=n_steps, state=state, k_len=k_len, preds=preds, scores=scores, scores0=scores0, cur=cur)
+        g = _DecodeGraph(key=key, frames=frames, n_steps=n_steps, state=state, state0=state0, k_len=k_len, preds=preds, scores=scores,
+                         scores0=scores0, cur=cur)
         g.keep = (cache, parent, emb, pe, step)     # the captured kernels address these by raw pointer
         n_steps.fill_(1)
         step()                          # eager warm-up: code objects, derived weights, allocator pools

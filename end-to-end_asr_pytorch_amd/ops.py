@@ -816,10 +816,15 @@ def beam_reorder_cache(cache, parent, state, beam):
           "asr_beam_reorder_cache")
 
 
-def beam_advance(state, k_len):
+def beam_advance(state, k_len, cur=None, eos_id=0, finished=None, len_decoded=None):
+    """end of a search step (state[1] must be -1 while the search runs); with `finished` also the <eos> bookkeeping of decoder.py:211-216"""
     _req_cuda(state, k_len)
     assert state.dtype == torch.int32 and k_len.dtype == torch.int32
-    check(lib().asr_beam_advance(_stream(), _p(state), _p(k_len), k_len.numel()), "asr_beam_advance")
+    if finished is not None:
+        _req_cuda(cur, finished, len_decoded)
+        assert finished.dtype == torch.uint8 and len_decoded.dtype == torch.int64 and cur.dtype == torch.int64
+    check(lib().asr_beam_advance(_stream(), _p(state), _p(k_len), k_len.numel(), _p(cur), int(eos_id), _p(finished), _p(len_decoded)),
+          "asr_beam_advance")
 
 
 def log_softmax_rows(x2d):

@@ -385,14 +385,17 @@ int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t
  *                         preds[r, 0..t] gathered from the parents + the new token at column t + 1 (preds int64 [N, W], W <= 512),
  *                         cur[r], parent[r] (global row ids); a finished utterance is left as it is and reports identity parents
  * asr_beam_reorder_cache: caches [n_kv, N, h, Tmax, 64] (ASR_F32 | ASR_BF16) re-gathered by parent row in place, positions <= t
- * asr_beam_advance:       t += 1; k_len[r] += 1 */
+ * asr_beam_advance:       t += 1; k_len[r] += 1; with `finished` (Decoder.batch_beam_decode, decoder.py:211-216) also finished[r] |=
+ *                         cur[r] == eos, len_decoded[r] += !finished[r], and state[1] = steps taken once every row is finished - from
+ *                         then on asr_beam_step and asr_beam_advance change nothing (state[1] must be -1 while the search runs) */
 int asr_beam_cat_frames(void* stream, const float* frames, const int32_t* state, const float* other32, const int64_t* cur, const float* emb,
                         const float* pe, float* out, int N, int beam, int Tmax, int D, int D2, int V, int max_pos);
 int asr_beam_step(void* stream, float* scores, const float* next_scores, const int64_t* next_preds, int64_t* preds, const int32_t* state,
                   const int32_t* n_steps, int64_t* parent, int64_t* cur, int B, int beam, int W);
 int asr_beam_reorder_cache(void* stream, void* cache, const int64_t* parent, const int32_t* state, int n_kv, int B, int beam, int h, int Tmax,
                            int dtype);
-int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, int N);
+int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, int N, const int64_t* cur, int eos, unsigned char* finished,
+                     int64_t* len_decoded);
 
 /* ---- CIF family, training side (autograd of cif_model.py:44-48, attentionAssigner.py:37-40, conv_encoder.py:33-49) and the tape's
  * gradient bookkeeping; all f32. */
