@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
 SOURCES = ["common.hip", "gemm.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
-           "backward.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "input.hip"]
+           "backward.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
@@ -88,6 +88,9 @@ SIGNATURES = {
     "asr_decode_embed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_kv_cache_put": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_decode_advance": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
+    "asr_decode_block_workspace_bytes": [_i],
+    "asr_decode_ffn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f],
+    "asr_decode_self_attn": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f],
     "asr_beam_cat_frames": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_beam_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_beam_reorder_cache": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
@@ -164,6 +167,7 @@ def lib():
         L.asr_attention_dropmask_words.restype = ctypes.c_int64
         L.asr_ctc_counter_words.restype = ctypes.c_int64
         L.asr_conv_sub1_bwd_w_workspace_floats.restype = ctypes.c_int64
+        L.asr_decode_block_workspace_bytes.restype = ctypes.c_int64
         L.asr_last_error.restype = ctypes.c_char_p
         L.asr_version.restype = ctypes.c_int
         _lib = L

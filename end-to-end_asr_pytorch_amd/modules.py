@@ -168,6 +168,20 @@ def _prefetch_attn_masks(sites, training, device):
 # gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
 _TAPE = None
 _DIRECT_CONV_BWD = os.environ.get("ASR_AMD_DIRECT_CONV_BWD", "1") != "0"    # A/B: 0 = the patch-matrix backward of the conv layers
+_DECODE_FUSED = os.environ.get("ASR_AMD_DECODE_FUSED", "1") != "0"     # one-launch sub-layers in the per-token decode steps (decode_blocks.hip)
+_IN_DECODE_STEP = False    # set while a per-token decode step is being queued / captured (rows = hypotheses, one position each)
+
+
+@contextlib.contextmanager
+def _decode_step():
+    global _IN_DECODE_STEP
+    prev, _IN_DECODE_STEP = _IN_DECODE_STEP, True
+    try:
+        yield
+    finally:
+        _IN_DECODE_STEP = prev
+
+
 _PARAM_EPOCH = 0   # bumped by the trainer after each fused Adam step (raw-pointer updates do not bump tensor versions)
 
 
@@ -436,8 +450,16 @@ class MultiheadAttention(_Cached):
 
     def _impl_cached_self(self, x, k_cache, v_cache, t, k_len):
         """Self-attention of ONE new position t (x: Act [B*1, d]) against the cache (decoding): its key / value are projected and
-        written into k_cache / v_cache [B, h, Tmax, 64] at position t, then the query attends to positions < k_len (= t + 1)."""
+        written into k_cache / v_cache [B, h, Tmax, 64] at position t, then the query attends to positions < k_len (= t + 1).
+        bf16, d_model = 256, position on the device: the whole sub-layer is ONE launch (asr_decode_self_attn)."""
         h, B = self.n_head, x.B
+        if (_DECODE_FUSED and _PRECISION == "bf16" and torch.is_tensor(t) and x.L == 1 and k_cache.dtype == torch.bfloat16 and
+                self.w_qs.weight.shape[0] == h * 64 and ops.decode_blocks_ok(x, heads=h)):
+            y32, y16 = ops.decode_self_attn(x.b16 if x.b16 is not None else ops.cast_bf16(x.f32), x.f32, self._w("qkv", (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight)),
+                                            self._b("bqkv", (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)), self._w("fc", (self.fc.weight,)),
+                                            self._b("bfc", (self.fc.bias,)), self.layer_norm.weight, self.layer_norm.bias, k_cache, v_cache, t,
+                                            self.layer_norm.eps)
+            return Act(y32, y16, B, 1)
         kv = ops.proj_heads(x.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)), self._b("bkv", (self.w_ks.bias, self.w_vs.bias)),
                             2, B, 1, h, 1.0)
         if torch.is_tensor(t):                      # position in device memory (Decoder.batch_decode's captured step)
@@ -484,6 +506,13 @@ class PositionwiseFeedForward(_Cached):
         hdt = _cdtype()
         rec = _TAPE is not None
         d_ff = self.w_1.weight.shape[0]
+        if (_DECODE_FUSED and not rec and _PRECISION == "bf16" and row_len is None and not self.training and _IN_DECODE_STEP and
+                ops.decode_blocks_ok(x, d_ff=d_ff)):
+            # the per-token decode step: the whole sub-layer in ONE launch (asr_decode_ffn)
+            y32, y16 = ops.decode_ffn(x.b16 if x.b16 is not None else ops.cast_bf16(x.f32), x.f32, self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)),
+                                      self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)), self.layer_norm.weight,
+                                      self.layer_norm.bias, self.layer_norm.eps)
+            return Act(y32, y16, x.B, x.L)
         # training: the ReLU mask travels to the backward as 1 sign bit per hidden unit (written by this GEMM's epilogue) - the
         # hidden gradient's GEMM then reads 8 MB instead of re-reading the 131 MB activation (S1 shape)
         use_bits = rec and _PRECISION == "bf16" and d_ff % 128 == 0 and x.mma().dtype == torch.bfloat16 and x.f32.shape[1] % 64 == 0
@@ -1100,6 +1129,10 @@ class Decoder(_Cached):
             box["enc"], box["cross"] = enc, self._cross_kv(enc)
 
         def step():
+            with _decode_step():
+                _step_body()
+
+        def _step_body():
             x32, x16 = ops.decode_embed(cur, emb, pe, state, want_bf16=(_PRECISION == "bf16"))
             x = Act(x32, x16, N, 1)
             for i, layer in enumerate(self.layer_stack):
@@ -1159,6 +1192,10 @@ class Decoder(_Cached):
             box["enc"], box["cross"] = enc, self._cross_kv(enc)
 
         def step():
+            with _decode_step():
+                _step_body()
+
+        def _step_body():
             x32, x16 = ops.decode_embed(cur, emb, pe, state, want_bf16=(_PRECISION == "bf16"))
             x = Act(x32, x16, B, 1)
             for i, layer in enumerate(self.layer_stack):
@@ -1412,6 +1449,10 @@ class Decoder_CIF(_Cached):
         pe = self.positional_encoding.pe[0].contiguous()
 
         def step():
+            with _decode_step():
+                _step_body()
+
+        def _step_body():
             cat1 = ops.beam_cat_frames(frames, state, beam, cur=cur, emb=emb, pe=pe)            # decoder.py:407-408
             x = Act(ops.gemm_nt(cat1, self._w("inaff", (self.input_affine.weight,)), None), None, N, 1)
             for j, layer in enumerate(self.layer_stack):

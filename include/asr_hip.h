@@ -375,6 +375,21 @@ int asr_kv_cache_put(void* stream, const void* k_new, const void* v_new, void* k
                      int Tmax, int dtype);
 int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t* state, int32_t* k_len, unsigned char* finished,
                        int64_t* len_decoded, int eos, int B, int Tp1);
+/* Whole sub-layers of the per-token decode step in one launch each (decode_blocks.hip): the step's M = B or B * beam rows form
+ * row blocks whose workgroups split a sub-layer by hidden units / heads, add partial output rows with float atomics into a
+ * zeroed accumulator and let the last arrival apply bias + residual + LayerNorm (and re-zero accumulator and counter).
+ * d_model = 256, bf16 operands.  `workspace`: asr_decode_block_workspace_bytes(M) bytes, zeroed ONCE by the caller, reusable by
+ * every call on the same stream.
+ * asr_decode_ffn:       y = LayerNorm(relu(x W1^T + b1) W2^T + b2 + x)            PositionwiseFeedForward, module.py:48-53
+ * asr_decode_self_attn: MultiheadAttention.forward (attention.py:33-62) for ONE new position per row against that row's K / V cache
+ *                       [M, h, Tmax, 64] bf16: q / k / v projections (Wqkv rows [q | k | v] x (h * 64)), k and v written into slot
+ *                       t = state[0], softmax(q . K[0..t] / 8) V, output projection + bias + residual + LayerNorm */
+int64_t asr_decode_block_workspace_bytes(int M);
+int asr_decode_ffn(void* stream, const void* x16, const float* x32, const void* W1, const float* b1, const void* W2, const float* b2,
+                   const float* gamma, const float* beta, void* workspace, float* y32, void* y16, int M, int d_model, int d_ff, float eps);
+int asr_decode_self_attn(void* stream, const void* x16, const float* x32, const void* Wqkv, const float* bqkv, const void* Wo, const float* bo,
+                         const float* gamma, const float* beta, void* k_cache, void* v_cache, const int32_t* state, void* workspace, float* y32,
+                         void* y16, int M, int d_model, int h, int Tmax, float eps);
 /* Beam search over integrated frames for B utterances at once (Decoder_CIF.recognize_beam, decoder.py:425-475, which decodes ONE
  * utterance with a Python loop over hypotheses; Decoder_CIF.step_forward_cache, decoder.py:477-496).  Hypothesis rows r = b * beam + j;
  * the step position t is state[0]; utterance b is live while t < n_steps[b] (its number of integrated frames).

@@ -1,0 +1,71 @@
+"""The fused sub-layers of the per-token decode step (decode_blocks.hip) against stock torch in f32 on the same bf16-rounded operands:
+PositionwiseFeedForward (src/transformer/module.py:48-53) and MultiheadAttention for one new position against a K / V cache
+(src/transformer/attention.py:33-62)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from asr_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("M", [1, 16, 33, 160])
+def test_decode_ffn(M):
+    g = torch.Generator().manual_seed(M)
+    x = rnd(g, M, 256)
+    w1, b1 = rnd(g, 2048, 256, scale=256 ** -0.5), rnd(g, 2048, scale=0.1)
+    w2, b2 = rnd(g, 256, 2048, scale=2048 ** -0.5), rnd(g, 256, scale=0.1)
+    gamma, beta = 1.0 + rnd(g, 256, scale=0.1), rnd(g, 256, scale=0.1)
+    xb, w1b, w2b = x.bfloat16(), w1.bfloat16(), w2.bfloat16()
+    hid = torch.relu(xb.float() @ w1b.float().t() + b1).bfloat16().float()                       # the kernel keeps the hidden row in bf16
+    ref = F.layer_norm(hid @ w2b.float().t() + b2 + x, (256,), gamma, beta, 1e-5)
+    args = [t.to(DEV).contiguous() for t in (xb, x, w1b, b1, w2b, b2, gamma, beta)]
+    for _ in range(3):                                                                            # the workspace comes back zeroed
+        y32, y16 = ops.decode_ffn(*args, 1e-5)
+        np.testing.assert_allclose(y32.cpu().numpy(), ref.numpy(), rtol=0, atol=6e-3)
+        np.testing.assert_allclose(y16.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
+    assert int(ops.decode_block_workspace(M, torch.device(DEV)).view(torch.int32).abs().sum()) == 0       # comes back zeroed
+
+
+@pytest.mark.parametrize("M,h,Tmax,t", [(1, 4, 64, 0), (16, 4, 64, 5), (33, 4, 64, 63), (40, 4, 128, 64), (160, 4, 100, 99), (7, 2, 32, 17)])
+def test_decode_self_attn(M, h, Tmax, t):
+    g = torch.Generator().manual_seed(1000 * M + t)
+    D = 256
+    x = rnd(g, M, D)
+    wq, wk, wv = (rnd(g, h * 64, D, scale=D ** -0.5) for _ in range(3))
+    bq, bk, bv = (rnd(g, h * 64, scale=0.1) for _ in range(3))
+    wo, bo = rnd(g, D, h * 64, scale=(h * 64) ** -0.5), rnd(g, D, scale=0.1)
+    gamma, beta = 1.0 + rnd(g, D, scale=0.1), rnd(g, D, scale=0.1)
+    kc, vc = rnd(g, M, h, Tmax, 64).bfloat16(), rnd(g, M, h, Tmax, 64).bfloat16()
+    xb = x.bfloat16()
+    wqkv = torch.cat([wq, wk, wv], 0).bfloat16()
+    bqkv = torch.cat([bq, bk, bv], 0)
+    wob = wo.bfloat16()
+    # reference
+    proj = xb.float() @ wqkv.float().t() + bqkv
+    q, k, v = (proj[:, i * h * 64:(i + 1) * h * 64].view(M, h, 64) for i in range(3))
+    k_new, v_new = k.bfloat16(), v.bfloat16()
+    K = torch.cat([kc[:, :, :t].float(), k_new.float()[:, :, None]], 2)                            # [M, h, t + 1, 64]
+    V = torch.cat([vc[:, :, :t].float(), v_new.float()[:, :, None]], 2)
+    att = torch.softmax((q[:, :, None] @ K.transpose(2, 3)) / 8.0, -1)                             # [M, h, 1, t + 1]
+    o = (att @ V).reshape(M, h * 64).bfloat16().float()                                            # the kernel feeds the output projection in bf16
+    ref = F.layer_norm(o @ wob.float().t() + bo + x, (D,), gamma, beta, 1e-5)
+    state = torch.tensor([t, -1], dtype=torch.int32, device=DEV)
+    kcd, vcd = kc.to(DEV).contiguous(), vc.to(DEV).contiguous()
+    args = [a.to(DEV).contiguous() for a in (xb, x, wqkv, bqkv, wob, bo, gamma, beta)]
+    y32, y16 = ops.decode_self_attn(*args, kcd, vcd, state, 1e-5)
+    np.testing.assert_allclose(y32.cpu().numpy(), ref.numpy(), rtol=0, atol=1.5e-2)
+    np.testing.assert_allclose(kcd[:, :, t].float().cpu().numpy(), k_new.float().numpy(), rtol=8e-3, atol=1e-5)      # one bf16 ulp
+    np.testing.assert_allclose(vcd[:, :, t].float().cpu().numpy(), v_new.float().numpy(), rtol=8e-3, atol=1e-5)
+    other = [p for p in range(Tmax) if p != t]
+    np.testing.assert_array_equal(kcd[:, :, other].float().cpu().numpy(), kc[:, :, other].float().numpy())      # nothing else is touched
+    y32b, _ = ops.decode_self_attn(*args, kcd, vcd, state, 1e-5)                                   # same slot again: same result
+    np.testing.assert_allclose(y32b.cpu().numpy(), y32.cpu().numpy(), rtol=0, atol=2e-6)          # (the heads' partial rows meet in float atomics)
+    assert int(ops.decode_block_workspace(M, torch.device(DEV)).view(torch.int32).abs().sum()) == 0
