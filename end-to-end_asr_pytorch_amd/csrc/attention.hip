@@ -423,8 +423,14 @@ extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, con
         return 0;
     }
     ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
-    if (Lq <= 32) return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
     static const int xks = getenv("ASR_AMD_XATTN_KS") ? atoi(getenv("ASR_AMD_XATTN_KS")) : 4;
+    if (Lq <= 32) {
+        // a handful of queries against a long key sequence (the decode step's cross attention: Lq = 1 or the beam, Lk = the encoder
+        // length): one query group, four key streams - a quarter of the dependent walk
+        if (xks >= 4 && Lk >= 512 && !causal) return launch_bf16<4, 4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+        if (xks >= 2 && Lk >= 192 && !causal) return launch_bf16<2, 2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+        return launch_bf16<1>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
+    }
     if (xks >= 4 && Lq <= 64 && Lk >= 512 && !causal) return launch_bf16<8, 4>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);   // cross attention
     if (xks >= 2 && Lq <= 64 && Lk >= 256 && !causal) return launch_bf16<4, 2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);
     if (Lq <= 64) return launch_bf16<2>(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, causal, drop, drop_bits);

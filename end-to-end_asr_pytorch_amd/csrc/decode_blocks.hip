@@ -19,32 +19,17 @@ constexpr int DM = 256;
 
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// bias + residual + LayerNorm of a row block's accumulated rows by its last workgroup: lane (r16, q4) of wave w owns row r16,
-// columns 64 w + 16 j + 4 q4 .. + 3 (gemm_ln_small_kernel's epilogue); re-zeroes the accumulator rows and the counter
-__device__ __forceinline__ void finish_rows(float* __restrict__ accbuf, int* __restrict__ counter, const float* __restrict__ bias,
-                                            const float* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                            float* __restrict__ y32, bf16_t* __restrict__ y16, int row0, int rows, int M, float eps,
-                                            float (&red)[2][16][4]) {
+// mean and 1 / std of row r16 over its 256 columns (a lane holds v[j]: columns 64 wave + 16 j + 4 q4 .. + 3); two workgroup barriers
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[4], float eps, float (&red)[2][16][4], float& mean, float& rstd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q4 = lane >> 4;
-    const int row = row0 + r16;
-    const bool live = r16 < rows && row < M;
-    const int rr = live ? row : min(row0, M - 1);
-    f32x4 v[4];
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = wave * 64 + 16 * j + 4 * q4;
-        const float* ap = accbuf + (int64_t)rr * DM + c;
-        v[j] = f32x4{ld_agent(ap), ld_agent(ap + 1), ld_agent(ap + 2), ld_agent(ap + 3)};
-        if (bias) v[j] += *reinterpret_cast<const f32x4*>(bias + c);
-        v[j] += *reinterpret_cast<const f32x4*>(res + (int64_t)rr * DM + c);
-        sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-    }
+    for (int j = 0; j < 4; ++j) sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     if (q4 == 0) red[0][r16][wave] = sum;
     __syncthreads();
-    const float mean = ((red[0][r16][0] + red[0][r16][1]) + (red[0][r16][2] + red[0][r16][3])) * (1.f / DM);
+    mean = ((red[0][r16][0] + red[0][r16][1]) + (red[0][r16][2] + red[0][r16][3])) * (1.f / DM);
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -56,7 +41,30 @@ __device__ __forceinline__ void finish_rows(float* __restrict__ accbuf, int* __r
     if (q4 == 0) red[1][r16][wave] = q;
     __syncthreads();
     const float var = ((red[1][r16][0] + red[1][r16][1]) + (red[1][r16][2] + red[1][r16][3])) * (1.f / DM);
-    const float rstd = 1.0f / sqrtf(var + eps);
+    rstd = 1.0f / sqrtf(var + eps);
+}
+
+// bias + residual + LayerNorm of a row block's accumulated rows by its last workgroup: lane (r16, q4) of wave w owns row r16,
+// columns 64 w + 16 j + 4 q4 .. + 3 (gemm_ln_small_kernel's epilogue); re-zeroes the accumulator rows and the counter
+__device__ __forceinline__ void finish_rows(float* __restrict__ accbuf, int* __restrict__ counter, const float* __restrict__ bias,
+                                            const float* __restrict__ res, const f32x4* resv, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float* __restrict__ y32, bf16_t* __restrict__ y16, int row0,
+                                            int rows, int M, float eps, float (&red)[2][16][4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q4 = lane >> 4;
+    const int row = row0 + r16;
+    const bool live = r16 < rows && row < M;
+    const int rr = live ? row : min(row0, M - 1);
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = wave * 64 + 16 * j + 4 * q4;
+        const float* ap = accbuf + (int64_t)rr * DM + c;
+        v[j] = f32x4{ld_agent(ap), ld_agent(ap + 1), ld_agent(ap + 2), ld_agent(ap + 3)};
+        if (bias) v[j] += *reinterpret_cast<const f32x4*>(bias + c);
+        v[j] += resv ? resv[j] : *reinterpret_cast<const f32x4*>(res + (int64_t)rr * DM + c);
+    }
+    float mean, rstd;
+    row_stats(v, eps, red, mean, rstd);
     if (live) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -94,14 +102,21 @@ __device__ __forceinline__ bool add_partial(float* __restrict__ accbuf, int* __r
     return last;
 }
 
-// y = LayerNorm(relu(x W1^T + b1) W2^T + b2 + x): grid (d_ff / 128, row blocks); a workgroup owns 128 hidden units of 16 rows
+// y = LayerNorm(relu(x W1^T + b1) W2^T + b2 + x): grid (d_ff / 128, row blocks); a workgroup owns 128 hidden units of 16 rows.
+// PRE: x itself is the end of the attention sub-layer in front, x = LayerNorm0(ctx Wo^T + bo + res) (attention.py:58-60), computed
+// by EVERY workgroup of the row block for its 16 rows (16 x 256 x 256: cheaper than the launch it replaces) - ctx is the attention
+// output [M, 256] bf16, res the attention sub-layer's input.
+template <bool PRE>
 __global__ __launch_bounds__(256) void decode_ffn_kernel(const bf16_t* __restrict__ x16, const float* __restrict__ x32,
+                                                         const bf16_t* __restrict__ Wo, const float* __restrict__ bo,
+                                                         const float* __restrict__ gamma0, const float* __restrict__ beta0, float eps0,
                                                          const bf16_t* __restrict__ W1, const float* __restrict__ b1,
                                                          const bf16_t* __restrict__ W2, const float* __restrict__ b2,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ accbuf, int* __restrict__ counters, float* __restrict__ y32,
                                                          bf16_t* __restrict__ y16, int M, int d_ff, float eps) {
     __shared__ __attribute__((aligned(16))) bf16_t H[16][128 + 8];
+    __shared__ __attribute__((aligned(16))) bf16_t X[PRE ? 16 : 1][DM + 8];
     __shared__ float red[2][16][4];
     __shared__ int last_flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q4 = lane >> 4;
@@ -109,7 +124,37 @@ __global__ __launch_bounds__(256) void decode_ffn_kernel(const bf16_t* __restric
     const int arow = min(row0 + r16, M - 1);
     u32x4 ar[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) ar[s] = *reinterpret_cast<const u32x4*>(x16 + (int64_t)arow * DM + s * 32 + q4 * 8);
+    for (int s = 0; s < 8; ++s) ar[s] = *reinterpret_cast<const u32x4*>(x16 + (int64_t)arow * DM + s * 32 + q4 * 8);     // (PRE: ctx rows)
+    f32x4 xres[4];
+    if constexpr (PRE) {
+        f32x4 a0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a0[j] = f32x4{0, 0, 0, 0};
+            u32x4 wr[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wr[s] = *reinterpret_cast<const u32x4*>(Wo + (int64_t)(wave * 64 + 16 * j + r16) * DM + s * 32 + q4 * 8);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) Mma<bf16_t>::run(wr[s], ar[s], a0[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wave * 64 + 16 * j + 4 * q4;
+            a0[j] += *reinterpret_cast<const f32x4*>(x32 + (int64_t)arow * DM + c);
+            if (bo) a0[j] += *reinterpret_cast<const f32x4*>(bo + c);
+        }
+        float mean, rstd;
+        row_stats(a0, eps0, red, mean, rstd);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wave * 64 + 16 * j + 4 * q4;
+            xres[j] = (a0[j] - mean) * rstd * *reinterpret_cast<const f32x4*>(gamma0 + c) + *reinterpret_cast<const f32x4*>(beta0 + c);
+            *reinterpret_cast<bf16x4*>(&X[r16][c]) = bf16x4{(bf16_t)xres[j][0], (bf16_t)xres[j][1], (bf16_t)xres[j][2], (bf16_t)xres[j][3]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) ar[s] = *reinterpret_cast<const u32x4*>(&X[r16][s * 32 + q4 * 8]);
+    }
     // hidden slice: wave w computes hidden units 128 hs + 32 w + 16 j + (4 q4 + reg), j = 0, 1
     f32x4 a1[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
     u32x4 w1r[2][8];
@@ -147,7 +192,7 @@ __global__ __launch_bounds__(256) void decode_ffn_kernel(const bf16_t* __restric
         for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(w2r[j][s], hfrag, a2[j]);
     }
     if (!add_partial(accbuf, counters + blockIdx.y, a2, row0, 16, M, (int)gridDim.x, last_flag)) return;
-    finish_rows(accbuf, counters + blockIdx.y, b2, x32, gamma, beta, y32, y16, row0, 16, M, eps, red);
+    finish_rows(accbuf, counters + blockIdx.y, b2, x32, PRE ? xres : nullptr, gamma, beta, y32, y16, row0, 16, M, eps, red);
 }
 
 // Self-attention of the ONE new position of every row against that row's K / V cache, with the projections around it:
@@ -290,7 +335,7 @@ __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16_t* __r
         }
     }
     if (!add_partial(accbuf, counters + blockIdx.y, a2, row0, ROWS, M, (int)gridDim.x, last_flag)) return;
-    finish_rows(accbuf, counters + blockIdx.y, bo, x32, gamma, beta, y32, y16, row0, ROWS, M, eps, red);
+    finish_rows(accbuf, counters + blockIdx.y, bo, x32, nullptr, gamma, beta, y32, y16, row0, ROWS, M, eps, red);
 }
 
 }  // namespace
@@ -302,18 +347,26 @@ extern "C" int64_t asr_decode_block_workspace_bytes(int M) {     // accumulator 
 
 extern "C" int asr_decode_ffn(void* stream, const void* x16, const float* x32, const void* W1, const float* b1, const void* W2, const float* b2,
                               const float* gamma, const float* beta, void* workspace, float* y32, void* y16, int M, int d_model, int d_ff,
-                              float eps) {
+                              float eps, const void* pre_Wo, const float* pre_bo, const float* pre_gamma, const float* pre_beta, float pre_eps) {
     ASR_REQUIRE(x16 && x32 && W1 && b1 && W2 && gamma && beta && workspace && y32 && M > 0, ASR_ERR_ARG, "decode_ffn: null pointer / bad sizes");
     ASR_REQUIRE(d_model == DM && d_ff > 0 && d_ff % 128 == 0, ASR_ERR_UNSUPPORTED, "decode_ffn: d_model %d / d_ff %d (256 and a multiple of 128)",
                 d_model, d_ff);
+    ASR_REQUIRE(!pre_Wo || (pre_gamma && pre_beta), ASR_ERR_ARG, "decode_ffn: the attention-output prologue needs its LayerNorm weights");
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(x32, 16) && asr_aligned(W1, 16) && asr_aligned(W2, 16) && asr_aligned(b1, 16) &&
                     (!b2 || asr_aligned(b2, 16)) && asr_aligned(gamma, 16) && asr_aligned(beta, 16) && asr_aligned(workspace, 16) &&
-                    asr_aligned(y32, 16) && (!y16 || asr_aligned(y16, 8)), ASR_ERR_ALIGN, "decode_ffn: 16-byte alignment");
+                    asr_aligned(y32, 16) && (!y16 || asr_aligned(y16, 8)) && asr_aligned(pre_Wo, 16) && asr_aligned(pre_bo, 16) &&
+                    asr_aligned(pre_gamma, 16) && asr_aligned(pre_beta, 16), ASR_ERR_ALIGN, "decode_ffn: 16-byte alignment");
     const int rb = (M + 15) / 16;
     float* accbuf = static_cast<float*>(workspace);
     int* counters = reinterpret_cast<int*>(accbuf + (int64_t)rb * 16 * DM);
-    hipLaunchKernelGGL(decode_ffn_kernel, dim3(d_ff / 128, rb), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t*)x16, x32,
-                       (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, gamma, beta, accbuf, counters, y32, (bf16_t*)y16, M, d_ff, eps);
+    if (pre_Wo)
+        hipLaunchKernelGGL(decode_ffn_kernel<true>, dim3(d_ff / 128, rb), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t*)x16, x32,
+                           (const bf16_t*)pre_Wo, pre_bo, pre_gamma, pre_beta, pre_eps, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, gamma, beta,
+                           accbuf, counters, y32, (bf16_t*)y16, M, d_ff, eps);
+    else
+        hipLaunchKernelGGL(decode_ffn_kernel<false>, dim3(d_ff / 128, rb), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t*)x16, x32,
+                           nullptr, nullptr, nullptr, nullptr, 0.f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, gamma, beta, accbuf, counters,
+                           y32, (bf16_t*)y16, M, d_ff, eps);
     ASR_LAUNCH_CHECK("decode_ffn");
     return 0;
 }

@@ -448,6 +448,15 @@ class MultiheadAttention(_Cached):
         mine = (qkvw[:1] + qkvb[:1]) if dkv_pre is not None else (qkvw + qkvb)
         _TAPE.push(bw, mine + (fc.weight, fc.bias, ln.weight, ln.bias))
 
+    def _impl_ctx(self, xq, xkv, k_len, kv_pre):
+        """decode step only (eval, no tape): the attention output [B * Lq, h * 64] BEFORE the output projection - the caller runs
+        projection + residual + LayerNorm inside the next launch (PositionwiseFeedForward._impl_after_attention)"""
+        h, B, Lq = self.n_head, xq.B, xq.L
+        qscale = _LOG2E / math.sqrt(self.d_k)
+        q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
+        ctx, _ = ops.attention_fwd(q, kv_pre[0], kv_pre[1], k_len, False, need_lse=False, drop=None, drop_bits=None)
+        return ctx.view(B * Lq, h * 64)
+
     def _impl_cached_self(self, x, k_cache, v_cache, t, k_len):
         """Self-attention of ONE new position t (x: Act [B*1, d]) against the cache (decoding): its key / value are projected and
         written into k_cache / v_cache [B, h, Tmax, 64] at position t, then the query attends to positions < k_len (= t + 1).
@@ -548,6 +557,15 @@ class PositionwiseFeedForward(_Cached):
 
             _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
         return y
+
+    def _impl_after_attention(self, ctx16, attn, x_in):
+        """decode step only: LayerNorm_attn(ctx . Wfc^T + bfc + x_in) and this feed-forward sub-layer in ONE launch (asr_decode_ffn
+        with its prologue); ctx16 bf16 [M, 256] is `attn`'s attention output, x_in the Act that entered the attention sub-layer"""
+        pre = (attn._w("fc", (attn.fc.weight,)), attn._b("bfc", (attn.fc.bias,)), attn.layer_norm.weight, attn.layer_norm.bias, attn.layer_norm.eps)
+        y32, y16 = ops.decode_ffn(ctx16, x_in.f32, self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)),
+                                  self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)), self.layer_norm.weight,
+                                  self.layer_norm.bias, self.layer_norm.eps, pre=pre)
+        return Act(y32, y16, x_in.B, x_in.L)
 
     def forward(self, x):
         return self._impl(_act(x), None).view3()
@@ -859,6 +877,19 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
+    def _decode_cross_ffn(self, x, enc, enc_len, kv_pre, n_rows):
+        """the cross-attention and feed-forward sub-layers of one decode step (x: Act [B, Lq] rows, Lq = 1 or the beam) -> Act
+        [n_rows, 1]: query projection, attention, then output projection + LayerNorm + feed-forward in one launch when the step's
+        rows fit the fused kernel (bf16, d_model 256, <= 64 rows), else the two sub-layers as usual"""
+        ffn, att = self.pos_ffn, self.enc_attn
+        if (_DECODE_FUSED and _PRECISION == "bf16" and _IN_DECODE_STEP and not ffn.training and att.fc.weight.shape[1] == 256 and
+                ops.decode_blocks_ok(x, d_ff=ffn.w_1.weight.shape[0])):
+            ctx = att._impl_ctx(x, enc, enc_len, kv_pre)
+            y = ffn._impl_after_attention(ctx, att, x)
+            return Act(y.f32, y.b16, n_rows, 1)
+        xq = att._impl(x, enc, enc_len, False, None, kv_pre=kv_pre)
+        return ffn._impl(Act(xq.f32, xq.b16, n_rows, 1), None)
+
     def _impl(self, x, enc, dec_len, enc_len, kv_pre=None, attn_drop=(None, None)):
         x = self.slf_attn._impl(x, x, dec_len, True, dec_len, attn_drop=attn_drop[0])
         x = self.enc_attn._impl(x, enc, enc_len, False, dec_len, kv_pre=kv_pre, attn_drop=attn_drop[1])
@@ -1138,8 +1169,7 @@ class Decoder(_Cached):
             for i, layer in enumerate(self.layer_stack):
                 x = layer.slf_attn._impl_cached_self(x, cache[2 * i], cache[2 * i + 1], state, k_len)
                 xq = Act(x.f32, x.b16, B, beam)               # the beams of an utterance: `beam` queries of one cross-attention
-                xq = layer.enc_attn._impl(xq, box["enc"], enc_len, False, None, kv_pre=box["cross"](i))
-                x = layer.pos_ffn._impl(Act(xq.f32, xq.b16, N, 1), None)
+                x = layer._decode_cross_ffn(xq, box["enc"], enc_len, box["cross"](i), N)
             z = ops.log_softmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x))      # Decoder.step's log-probabilities ...
             best, ids = ops.lsm_topk_rows(z, beam)                                                # ... log_softmax again (decoder.py:191), top-k
             ops.beam_step(scores, best, ids, preds, state, n_steps, parent, cur, beam)
@@ -1200,8 +1230,7 @@ class Decoder(_Cached):
             x = Act(x32, x16, B, 1)
             for i, layer in enumerate(self.layer_stack):
                 x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], state, k_len)
-                x = layer.enc_attn._impl(x, box["enc"], enc_len, False, None, kv_pre=box["cross"](i))
-                x = layer.pos_ffn._impl(x, None)
+                x = layer._decode_cross_ffn(x, box["enc"], enc_len, box["cross"](i), B)
             ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), out=cur)      # argmax of log_softmax = argmax of the logits
             ops.decode_advance(cur, preds, state, k_len, finished, len_decoded, self.eos_id)
 

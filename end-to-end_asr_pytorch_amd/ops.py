@@ -793,15 +793,22 @@ def decode_blocks_ok(x, d_ff=None, heads=None):
             (d_ff is None or d_ff % 128 == 0) and (heads is None or 1 <= heads <= 16))
 
 
-def decode_ffn(x16, x32, w1, b1, w2, b2, gamma, beta, eps):
+def decode_ffn(x16, x32, w1, b1, w2, b2, gamma, beta, eps, pre=None):
+    """the feed-forward sub-layer of the decode step in one launch; pre = (Wo bf16 [256, 256], bo, gamma0, beta0, eps0): x16 is then the
+    attention output and x32 the attention sub-layer's input - its output projection + residual + LayerNorm run in the same launch"""
     _req_cuda(x16, x32, w1, b1, w2, gamma, beta)
     M, D = x32.shape
     assert x16.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and x16.is_contiguous() and x32.is_contiguous()
+    assert tuple(x16.shape) == (M, D)
     y32 = torch.empty((M, D), device=x32.device, dtype=torch.float32)
     y16 = torch.empty((M, D), device=x32.device, dtype=torch.bfloat16)
     ws = decode_block_workspace(M, x32.device)
+    wo, bo, g0, bt0, eps0 = pre if pre is not None else (None, None, None, None, 0.0)
+    if pre is not None:
+        _req_cuda(wo, g0, bt0)
+        assert wo.dtype == torch.bfloat16 and tuple(wo.shape) == (D, D)
     check(lib().asr_decode_ffn(_stream(), _p(x16), _p(x32), _p(w1), _p(b1), _p(w2), _p(b2), _p(gamma), _p(beta), _p(ws), _p(y32), _p(y16), M, D,
-                               w1.shape[0], float(eps)), "asr_decode_ffn")
+                               w1.shape[0], float(eps), _p(wo), _p(bo), _p(g0), _p(bt0), float(eps0)), "asr_decode_ffn")
     return y32, y16
 
 

@@ -380,13 +380,16 @@ int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t
  * zeroed accumulator and let the last arrival apply bias + residual + LayerNorm (and re-zero accumulator and counter).
  * d_model = 256, bf16 operands.  `workspace`: asr_decode_block_workspace_bytes(M) bytes, zeroed ONCE by the caller, reusable by
  * every call on the same stream.
- * asr_decode_ffn:       y = LayerNorm(relu(x W1^T + b1) W2^T + b2 + x)            PositionwiseFeedForward, module.py:48-53
+ * asr_decode_ffn:       y = LayerNorm(relu(x W1^T + b1) W2^T + b2 + x)            PositionwiseFeedForward, module.py:48-53;
+ *                       with pre_Wo: x = LayerNorm0(ctx pre_Wo^T + pre_bo + res) first (the end of the attention sub-layer in front,
+ *                       attention.py:58-60), x16 then holds the attention output ctx [M, 256] and x32 that sub-layer's input res
  * asr_decode_self_attn: MultiheadAttention.forward (attention.py:33-62) for ONE new position per row against that row's K / V cache
  *                       [M, h, Tmax, 64] bf16: q / k / v projections (Wqkv rows [q | k | v] x (h * 64)), k and v written into slot
  *                       t = state[0], softmax(q . K[0..t] / 8) V, output projection + bias + residual + LayerNorm */
 int64_t asr_decode_block_workspace_bytes(int M);
 int asr_decode_ffn(void* stream, const void* x16, const float* x32, const void* W1, const float* b1, const void* W2, const float* b2,
-                   const float* gamma, const float* beta, void* workspace, float* y32, void* y16, int M, int d_model, int d_ff, float eps);
+                   const float* gamma, const float* beta, void* workspace, float* y32, void* y16, int M, int d_model, int d_ff, float eps,
+                   const void* pre_Wo, const float* pre_bo, const float* pre_gamma, const float* pre_beta, float pre_eps);
 int asr_decode_self_attn(void* stream, const void* x16, const float* x32, const void* Wqkv, const float* bqkv, const void* Wo, const float* bo,
                          const float* gamma, const float* beta, void* k_cache, void* v_cache, const int32_t* state, void* workspace, float* y32,
                          void* y16, int M, int d_model, int h, int Tmax, float eps);

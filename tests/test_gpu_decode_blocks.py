@@ -69,3 +69,24 @@ def test_decode_self_attn(M, h, Tmax, t):
     y32b, _ = ops.decode_self_attn(*args, kcd, vcd, state, 1e-5)                                   # same slot again: same result
     np.testing.assert_allclose(y32b.cpu().numpy(), y32.cpu().numpy(), rtol=0, atol=2e-6)          # (the heads' partial rows meet in float atomics)
     assert int(ops.decode_block_workspace(M, torch.device(DEV)).view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M", [1, 32, 50])
+def test_decode_ffn_with_the_attention_output_prologue(M):
+    """x = LayerNorm0(ctx Wo^T + bo + res) (attention.py:58-60) computed inside the feed-forward launch"""
+    g = torch.Generator().manual_seed(77 + M)
+    ctx, res = rnd(g, M, 256), rnd(g, M, 256)
+    wo, bo = rnd(g, 256, 256, scale=256 ** -0.5), rnd(g, 256, scale=0.1)
+    g0, bt0 = 1.0 + rnd(g, 256, scale=0.1), rnd(g, 256, scale=0.1)
+    w1, b1 = rnd(g, 2048, 256, scale=256 ** -0.5), rnd(g, 2048, scale=0.1)
+    w2, b2 = rnd(g, 256, 2048, scale=2048 ** -0.5), rnd(g, 256, scale=0.1)
+    gamma, beta = 1.0 + rnd(g, 256, scale=0.1), rnd(g, 256, scale=0.1)
+    cb, wob, w1b, w2b = ctx.bfloat16(), wo.bfloat16(), w1.bfloat16(), w2.bfloat16()
+    x = F.layer_norm(cb.float() @ wob.float().t() + bo + res, (256,), g0, bt0, 1e-5)
+    hid = torch.relu(x.bfloat16().float() @ w1b.float().t() + b1).bfloat16().float()
+    ref = F.layer_norm(hid @ w2b.float().t() + b2 + x, (256,), gamma, beta, 1e-5)
+    d = lambda t: t.to(DEV).contiguous()
+    for _ in range(2):
+        y32, y16 = ops.decode_ffn(d(cb), d(res), d(w1b), d(b1), d(w2b), d(b2), d(gamma), d(beta), 1e-5, pre=(d(wob), d(bo), d(g0), d(bt0), 1e-5))
+        np.testing.assert_allclose(y32.cpu().numpy(), ref.numpy(), rtol=0, atol=1.2e-2)
+    assert int(ops.decode_block_workspace(M, torch.device(DEV)).view(torch.int32).abs().sum()) == 0

@@ -119,7 +119,8 @@ def ref_attention(q, k, v, k_len, causal):
 @pytest.mark.parametrize("B,h,Lq,Lk,causal,ragged", [
     (2, 2, 25, 25, False, True), (3, 4, 200, 200, False, True), (2, 2, 8, 8, True, True), (2, 2, 51, 51, True, True),
     (2, 4, 51, 250, False, True), (1, 1, 130, 130, True, False), (2, 2, 300, 300, False, False), (1, 2, 1000, 1000, False, True),
-    (2, 2, 51, 1000, False, True), (2, 2, 40, 300, False, True), (1, 2, 64, 700, False, False), (1, 1, 33, 520, False, True)])   # 2 / 4 key streams
+    (2, 2, 51, 1000, False, True), (2, 2, 40, 300, False, True), (1, 2, 64, 700, False, False), (1, 1, 33, 520, False, True),   # 2 / 4 key streams
+    (3, 4, 1, 1000, False, True), (2, 2, 5, 700, False, True), (2, 1, 32, 513, False, False), (2, 2, 1, 250, False, True), (1, 2, 7, 200, False, True)])   # decode: few queries
 def test_attention_fwd(prec, B, h, Lq, Lk, causal, ragged):
     g = torch.Generator().manual_seed(B * 1000 + Lq)
     q = torch.randn(B, h, Lq, 64, generator=g) * 0.5
