@@ -451,7 +451,8 @@ def main():
             "config": {"workload": "%s d_model=256 h=4 d_inner=2048 enc12/dec6 V=4234, per-GPU B=32 x T=1000 x 80 "
                                    "fbank%s, U=50, %s" % (mname, " (ragged lengths)" if args.ragged else "", what),
                        "global_batch": world * CFG["B"], "seq_len": CFG["T"], "parallelism": "dp%d" % world,
-                       "launch": "hip-graph replay" if graphed else "eager",
+                       "launch": (("per-token step replayed as a hip-graph, encoder eager" if os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0" else "eager")
+                                  if args.mode == "decode" else ("hip-graph replay" if graphed else "eager")),
                        "launch_calibration_ms": launch_timing},
             "losses_last_step": losses,
             "roofline": roofline,
