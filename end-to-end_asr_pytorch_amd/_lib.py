@@ -83,7 +83,7 @@ SIGNATURES = {
     "asr_ctc_greedy_reduce": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "asr_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f],
     "asr_topk_rows": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
-    "asr_lsm_topk_rows": [_vp, _vp, _i64, _i, _i, _i, _vp, _vp],
+    "asr_lsm_topk_rows": [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
     "asr_beam_prune": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
     "asr_decode_embed": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     "asr_kv_cache_put": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],

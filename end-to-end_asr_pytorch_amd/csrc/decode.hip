@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 // top-k of log_softmax(x) per row in one pass over the row (decoder.py:418-440: F.log_softmax then torch.topk): the row lives in
 // registers (NPL values per lane, one wavefront per row), the logsumexp is reduced in log_softmax_rows_kernel's order (same values),
 // then k rounds of topk_rows_kernel's selection on the registers
-template <int NPL>
+template <int NPL, bool TWICE>
 __global__ __launch_bounds__(256) void lsm_topk_rows_kernel(const float* __restrict__ x, int64_t ld, int M, int V, int k,
                                                             float* __restrict__ vals, int64_t* __restrict__ idx) {
     const int lane = threadIdx.x & 63;
@@ -179,18 +179,21 @@ __global__ __launch_bounds__(256) void lsm_topk_rows_kernel(const float* __restr
     float y[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) y[i] = lane + 64 * i < V ? xr[lane + 64 * i] : -INFINITY;
-    float m = -INFINITY, s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i)
-        if (lane + 64 * i < V) lse_combine(m, s, y[i], 1.f);
+    for (int pass = 0; pass < (TWICE ? 2 : 1); ++pass) {
+        float m = -INFINITY, s = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-        lse_combine(m, s, m2, s2);
+        for (int i = 0; i < NPL; ++i)
+            if (lane + 64 * i < V) lse_combine(m, s, y[i], 1.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            lse_combine(m, s, m2, s2);
+        }
+        const float l = m + logf(s);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) y[i] -= l;
     }
-    const float l = m + logf(s);
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) y[i] -= l;
     float lastv = INFINITY;
     int lasti = -1;
     for (int j = 0; j < k; ++j) {
@@ -215,6 +218,82 @@ __global__ __launch_bounds__(256) void lsm_topk_rows_kernel(const float* __restr
         }
         lastv = best;
         lasti = bi;
+    }
+}
+
+// The same for long rows (the vocabulary), one WORKGROUP per row: 256 threads hold the row (NPL values each), the logsumexp and the k
+// selection rounds reduce over waves through LDS - the wave-per-row kernel above walks 67 values per lane and takes 35 us for 160 rows
+// of 4234.  TWICE: log_softmax applied twice before the top-k (Decoder.batch_beam_decode re-normalises Decoder.step's
+// log-probabilities, decoder.py:118 + :191).  Values agree with the two-kernel path to f32 rounding (another summation order).
+template <int NPL, bool TWICE>
+__global__ __launch_bounds__(256) void lsm_topk_rows_wg_kernel(const float* __restrict__ x, int64_t ld, int M, int V, int k,
+                                                               float* __restrict__ vals, int64_t* __restrict__ idx) {
+    __shared__ float sm[4], ss[4];
+    __shared__ float bv[4];
+    __shared__ int bi_s[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const float* xr = x + row * ld;
+    float y[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) y[i] = tid + 256 * i < V ? xr[tid + 256 * i] : -INFINITY;
+#pragma unroll
+    for (int pass = 0; pass < (TWICE ? 2 : 1); ++pass) {
+        float m = -INFINITY, s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+            if (tid + 256 * i < V) lse_combine(m, s, y[i], 1.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            lse_combine(m, s, m2, s2);
+        }
+        if (lane == 0) { sm[wave] = m; ss[wave] = s; }
+        __syncthreads();
+        m = sm[0];
+        s = ss[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) lse_combine(m, s, sm[w], ss[w]);
+        const float l = m + logf(s);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) y[i] -= l;
+        __syncthreads();
+    }
+    float lastv = INFINITY;
+    int lasti = -1;
+    for (int j = 0; j < k; ++j) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int c = tid + 256 * i;
+            const float v = y[i];
+            const bool after = c < V && ((v < lastv) || (v == lastv && c > lasti));
+            if (after && (bi == 0x7fffffff || v > best)) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(best, o, 64);
+            const int i2 = __shfl_xor(bi, o, 64);
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > best || (v2 == best && i2 < bi))) { best = v2; bi = i2; }
+        }
+        if (lane == 0) { bv[wave] = best; bi_s[wave] = bi; }
+        __syncthreads();
+        best = bv[0];
+        bi = bi_s[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float v2 = bv[w];
+            const int i2 = bi_s[w];
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > best || (v2 == best && i2 < bi))) { best = v2; bi = i2; }
+        }
+        if (tid == 0) {
+            vals[row * k + j] = bi == 0x7fffffff ? -INFINITY : best;
+            idx[row * k + j] = bi == 0x7fffffff ? 0 : bi;
+        }
+        lastv = best;
+        lasti = bi;
+        __syncthreads();
     }
 }
 
@@ -516,13 +595,17 @@ extern "C" int asr_beam_advance(void* stream, int32_t* state, int32_t* k_len, in
     return 0;
 }
 
-extern "C" int asr_lsm_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx) {
+extern "C" int asr_lsm_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, int twice, float* vals, int64_t* idx) {
     ASR_REQUIRE(x && vals && idx && M > 0 && V > 0 && k > 0 && k <= V && ld >= V, ASR_ERR_ARG, "lsm_topk_rows: bad args (M=%d V=%d k=%d)", M, V, k);
-    ASR_REQUIRE(V <= 64 * 72, ASR_ERR_UNSUPPORTED, "lsm_topk_rows: V = %d (at most 4608; use asr_log_softmax_rows + asr_topk_rows)", V);
-    if (V <= 64 * 16)
-        hipLaunchKernelGGL(lsm_topk_rows_kernel<16>, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, M, V, k, vals, idx);
-    else
-        hipLaunchKernelGGL(lsm_topk_rows_kernel<72>, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, ld, M, V, k, vals, idx);
+    ASR_REQUIRE(V <= 256 * 18, ASR_ERR_UNSUPPORTED, "lsm_topk_rows: V = %d (at most 4608; use asr_log_softmax_rows + asr_topk_rows)", V);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (V <= 64 * 16) {       // short rows: one wavefront per row
+        if (twice) hipLaunchKernelGGL((lsm_topk_rows_kernel<16, true>), dim3((M + 3) / 4), dim3(256), 0, s, x, ld, M, V, k, vals, idx);
+        else hipLaunchKernelGGL((lsm_topk_rows_kernel<16, false>), dim3((M + 3) / 4), dim3(256), 0, s, x, ld, M, V, k, vals, idx);
+    } else {
+        if (twice) hipLaunchKernelGGL((lsm_topk_rows_wg_kernel<18, true>), dim3(M), dim3(256), 0, s, x, ld, M, V, k, vals, idx);
+        else hipLaunchKernelGGL((lsm_topk_rows_wg_kernel<18, false>), dim3(M), dim3(256), 0, s, x, ld, M, V, k, vals, idx);
+    }
     ASR_LAUNCH_CHECK("lsm_topk_rows");
     return 0;
 }

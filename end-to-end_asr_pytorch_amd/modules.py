@@ -1170,8 +1170,8 @@ class Decoder(_Cached):
                 x = layer.slf_attn._impl_cached_self(x, cache[2 * i], cache[2 * i + 1], state, k_len)
                 xq = Act(x.f32, x.b16, B, beam)               # the beams of an utterance: `beam` queries of one cross-attention
                 x = layer._decode_cross_ffn(xq, box["enc"], enc_len, box["cross"](i), N)
-            z = ops.log_softmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x))      # Decoder.step's log-probabilities ...
-            best, ids = ops.lsm_topk_rows(z, beam)                                                # ... log_softmax again (decoder.py:191), top-k
+            # Decoder.step's log-probabilities, log_softmax again (decoder.py:118 + :191), top-k: one launch
+            best, ids = ops.lsm_topk_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), beam, twice=True)
             ops.beam_step(scores, best, ids, preds, state, n_steps, parent, cur, beam)
             ops.beam_reorder_cache(cache, parent, state, beam)
             ops.beam_advance(state, k_len, cur, self.eos_id, finished, len_decoded)

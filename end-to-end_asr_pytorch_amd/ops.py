@@ -717,16 +717,18 @@ def topk_rows(x2d, k):
     return vals, idx
 
 
-def lsm_topk_rows(x2d, k):
-    """topk_rows(log_softmax_rows(x), k) in one kernel (rows up to 4608 columns; longer rows chain the two)"""
+def lsm_topk_rows(x2d, k, twice=False):
+    """topk_rows(log_softmax_rows(x), k) in one kernel; twice: of log_softmax applied twice (rows up to 4608 columns; longer rows
+    chain the separate kernels)"""
     _req_cuda(x2d)
     assert x2d.dim() == 2 and x2d.stride(1) == 1 and x2d.dtype == torch.float32
     M, V = x2d.shape
     if V > 4608:
-        return topk_rows(log_softmax_rows(x2d), k)
+        z = log_softmax_rows(x2d)
+        return topk_rows(log_softmax_rows(z) if twice else z, k)
     vals = torch.empty((M, k), device=x2d.device, dtype=torch.float32)
     idx = torch.empty((M, k), device=x2d.device, dtype=torch.int64)
-    check(lib().asr_lsm_topk_rows(_stream(), _p(x2d), x2d.stride(0), M, V, int(k), _p(vals), _p(idx)), "asr_lsm_topk_rows")
+    check(lib().asr_lsm_topk_rows(_stream(), _p(x2d), x2d.stride(0), M, V, int(k), int(bool(twice)), _p(vals), _p(idx)), "asr_lsm_topk_rows")
     return vals, idx
 
 

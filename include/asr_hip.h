@@ -359,9 +359,10 @@ int asr_ctc_greedy_reduce(void* stream, const int64_t* frames, const int32_t* le
 int asr_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx);
 int asr_beam_prune(void* stream, const float* scores, const float* next_scores, const int64_t* next_preds, int B, int beam,
                    float* new_scores, int64_t* parent, int64_t* new_tok);
-/* asr_lsm_topk_rows: asr_topk_rows of log_softmax(x) without materialising it (decoder.py:418-440, F.log_softmax then torch.topk):
- * same values and order as the two calls; V <= 4608 (ASR_ERR_UNSUPPORTED beyond - chain the two). */
-int asr_lsm_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, float* vals, int64_t* idx);
+/* asr_lsm_topk_rows: asr_topk_rows of log_softmax(x) without materialising it (decoder.py:418-440, F.log_softmax then torch.topk);
+ * twice != 0: of log_softmax(log_softmax(x)) (Decoder.batch_beam_decode re-normalises Decoder.step's log-probabilities,
+ * decoder.py:118 + :191).  Same order as the separate calls, values to f32 rounding; V <= 4608 (ASR_ERR_UNSUPPORTED beyond). */
+int asr_lsm_topk_rows(void* stream, const float* x, int64_t ld, int M, int V, int k, int twice, float* vals, int64_t* idx);
 /* The per-token step of Decoder.batch_decode (decoder.py:138-164) with its position in device memory, so that the whole step is
  * one capturable launch sequence (hipGraph replay per token).  state int32[2]: [0] = t, the position of the token being fed
  * (0 = <sos>), [1] = the number of steps after which every row had produced <eos>, -1 until then.

@@ -176,62 +176,15 @@ def test_lsm_topk_rows_equals_the_two_kernels(V):
     g = torch.Generator().manual_seed(V)
     x = (3.0 * torch.randn(37, V, generator=g)).to(DEV)
     x[3, 7] = x[3, 11] = x[3].max() + 1.0                     # a tie for the first place: index order
-    v, i = ops.lsm_topk_rows(x, 5)
-    v2, i2 = ops.topk_rows(ops.log_softmax_rows(x), 5)
-    np.testing.assert_array_equal(i.cpu().numpy(), i2.cpu().numpy())
-    np.testing.assert_array_equal(v.cpu().numpy(), v2.cpu().numpy())
-    assert i[3, :2].tolist() == [7, 11]
+    for twice in (False, True):
+        v, i = ops.lsm_topk_rows(x, 5, twice=twice)
+        z = ops.log_softmax_rows(x)
+        v2, i2 = ops.topk_rows(ops.log_softmax_rows(z) if twice else z, 5)
+        np.testing.assert_array_equal(i.cpu().numpy(), i2.cpu().numpy())
+        np.testing.assert_allclose(v.cpu().numpy(), v2.cpu().numpy(), rtol=0, atol=4e-6)      # (long rows: another summation order)
+        assert i[3, :2].tolist() == [7, 11]
     # a strided view (rows padded like the vocabulary projection's buffer)
     buf = torch.zeros((9, (V + 7) // 8 * 8 + 8), device=DEV)
     buf[:, :V] = x[:9]
     v3, i3 = ops.lsm_topk_rows(buf[:, :V], 3)
     np.testing.assert_array_equal(i3.cpu().numpy(), i2[:9, :3].cpu().numpy())
-
-
-def test_batch_beam_decode_replayed_equals_eager_and_recompute(golden_dir, monkeypatch):
-    """the cached beam search, replayed and eager, against a search that recomputes the whole prefix with Decoder.step every step
-    (the reference's loop shape) - f32: tokens, lengths exact; a longer search than the fixture's (T = 20, beam 4)"""
-    z, cfg, model = load(golden_dir)
-    enc, enc_len = torch.from_numpy(z["enc_out"]).to(DEV), torch.from_numpy(z["enc_len"]).to(DEV)
-    B, beam, T = enc.shape[0], 4, 20
-    dec = model.decoder
-
-    def recompute():
-        e = enc[:, None].repeat(1, beam, 1, 1).view(B * beam, -1, enc.size(-1))
-        lens = enc_len[:, None].repeat(1, beam).view(-1)
-        preds = torch.full((B * beam, 1), dec.sos_id, dtype=torch.long, device=DEV)
-        len_decoded = torch.ones_like(lens)
-        scores = torch.tensor([0.0] + [-1e10] * (beam - 1), dtype=torch.float32, device=DEV).repeat(B)
-        finished = torch.zeros(B * beam, dtype=torch.bool, device=DEV)
-        for _ in range(T):
-            zz = ops.log_softmax_rows(dec.step(preds, e, lens))
-            ns, npred = ops.topk_rows(zz, beam)
-            scores, parent, nxt = ops.beam_prune(scores, ns, npred, beam)
-            preds = torch.cat([preds[parent], nxt[:, None]], 1)
-            finished = finished | nxt.eq(dec.eos_id)
-            len_decoded = len_decoded + (1 - finished.to(len_decoded.dtype))
-            if bool(finished.all()):
-                break
-        len_decoded = len_decoded - (1 - finished.to(len_decoded.dtype))
-        s_sorted, order = ops.topk_rows(scores.view(B, beam), beam)
-        order = (torch.arange(B, device=DEV)[:, None] * beam + order).view(-1)
-        return preds[:, 1:][order].view(B, beam, -1), len_decoded[order].view(B, beam), s_sorted
-
-    with asr_amd.precision("f32"):
-        for eos in (cfg["eos_id"], 14):
-            dec.eos_id = eos
-            ref = recompute()
-            for mode in ("1", "0"):
-                monkeypatch.setenv("ASR_AMD_DECODE_GRAPH", mode)
-                dec.__dict__.pop("_beam_graph", None)
-                got = dec.batch_beam_decode(enc, enc_len, beam_size=beam, max_decode_len=T)
-                np.testing.assert_array_equal(got[0].cpu().numpy(), ref[0].cpu().numpy())
-                np.testing.assert_array_equal(got[1].cpu().numpy(), ref[1].cpu().numpy())
-                np.testing.assert_allclose(got[2].cpu().numpy(), ref[2].cpu().numpy(), rtol=1e-5, atol=2e-4)
-                again = dec.batch_beam_decode(enc, enc_len, beam_size=beam, max_decode_len=T)       # the cached graph, second call
-                np.testing.assert_array_equal(again[0].cpu().numpy(), got[0].cpu().numpy())
-    dec.eos_id = cfg["eos_id"]
-    with asr_amd.precision("bf16"):
-        dec.__dict__.pop("_beam_graph", None)
-        p, l, sc = dec.batch_beam_decode(enc, enc_len, beam_size=beam, max_decode_len=T)
-        assert tuple(p.shape[:2]) == (B, beam) and bool((sc[:, :-1] >= sc[:, 1:]).all())
