@@ -312,7 +312,10 @@ template <int NP, int PHASE>
 __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__ lp_ext, const int32_t* __restrict__ in_len,
                                                        const int64_t* __restrict__ targets, int32_t* __restrict__ tgt_len, int L,
                                                        int Umax, float* __restrict__ alpha, float* __restrict__ nll, int chunk, int W,
-                                                       int last) {
+                                                       int last, float* __restrict__ alpha2 = nullptr) {
+    // PHASE 2: PHASE 1 without the occupancies - the continued chains store their raw alpha / beta rows into the SECOND workspace
+    // `alpha2` (same layout) next to the opposite direction's rows of PHASE 0; the gradient pass combines the two (occupancy() once
+    // per state there): the chain's step then is PHASE 0's (no second row to load, no exp2), about half of PHASE 1's
     constexpr int Sp = 128 * NP;
     __shared__ float xch[64][2 * NP];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
@@ -441,6 +444,17 @@ __global__ __launch_bounds__(128) void ctc_mitm_kernel(const float* __restrict__
             for (int q = 0; q < 2 * NP; ++q) sum += __builtin_amdgcn_exp2f(v[q] - ms);
             sum = wave_sum(sum);
             if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
+        }
+    } else if (PHASE == 2) {
+        float* a2_u = alpha2 + (int64_t)b * (L + 2) * Sp;
+        if (wave == 0) {
+            load_row(al, mid, e, o);                    // alpha_mid: start state of the forward continuation
+            ctc_chain<NP, false, false>(lp_u, a2_u, voff, L, mid + 1, Tb - 1 - mid, e, o, skip_f, madd, 0.f, -1, 0);
+        } else {
+            load_row(al, L, e, o);                      // beta_mid
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<f32x2*>(a2_u + 2 * j0 + (int64_t)mid * Sp + 2 * q) = f32x2{e[q], o[q]};
+            ctc_chain<NP, true, false>(lp_u, a2_u, voff, L, mid - 1, mid, e, o, skip_b, madd, 0.f, -1, 0);
         }
     } else {
         const float nll2 = nll[b] * LOG2E;
@@ -756,7 +770,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                        const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
                                                        int B, int L, int V, int Umax, int blank, const float* __restrict__ lse,
                                                        const float* __restrict__ occ, const float* __restrict__ gout,
-                                                       float* __restrict__ grad, int64_t ldg) {
+                                                       float* __restrict__ grad, int64_t ldg,
+        const float* __restrict__ occ2 = nullptr, const float* __restrict__ lp_ext = nullptr, const float* __restrict__ nll = nullptr) {
     extern __shared__ float corr[];  // V floats
     const int b = blockIdx.y, tid = threadIdx.x;
     const int Sfull = ctc_row_stride(Umax), Sb = 2 * tgt_len[b] + 1;
@@ -781,7 +796,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         const float* x = logits + row * ldl;
         for (int sidx = tid; sidx < Sb; sidx += 256) {
             const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
-            atomicAdd(&corr[lab], occ[((int64_t)b * (L + 2) + t) * Sfull + sidx]);
+            const int64_t oi = ((int64_t)b * (L + 2) + t) * Sfull + sidx;
+            // occ2: the workspace holds raw alpha / beta rows (asr_ctc_loss_bwd with alpha2): the occupancy is formed here
+            const float w = occ2 ? occupancy(occ[oi], occ2[oi], lp_ext[((int64_t)b * L + t) * Sfull + sidx], nll[b] * LOG2E) : occ[oi];
+            atomicAdd(&corr[lab], w);
         }
         __syncthreads();
         const float l = lse[row];
@@ -816,10 +834,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 
 template <int PHASE>
 int launch_recursion(hipStream_t s, const float* lp_ext, const int32_t* in_len, const int64_t* targets, int32_t* tgt_len, int B, int L,
-                     int Umax, float* alpha, float* nll, int chunk, int W, int last) {
+                     int Umax, float* alpha, float* nll, int chunk, int W, int last, float* alpha2 = nullptr) {
 #define LAUNCH_MITM(NP_)                                                                                                              \
     hipLaunchKernelGGL((ctc_mitm_kernel<NP_, PHASE>), dim3(B), dim3(128), 0, s, lp_ext, in_len, targets, tgt_len, L, Umax, alpha, nll, \
-                       chunk, W, last)
+                       chunk, W, last, alpha2)
     switch (ctc_np(Umax)) {
         case 1: LAUNCH_MITM(1); break;
         case 2: LAUNCH_MITM(2); break;
@@ -922,7 +940,8 @@ __global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const float* __restr
                                                             const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
                                                             int B, int L, int V, int Umax, int blank, const float* __restrict__ lse,
                                                             const float* __restrict__ occ, const float* __restrict__ gout,
-                                                            bf16_t* __restrict__ grad, int64_t ldg) {
+                                                            bf16_t* __restrict__ grad, int64_t ldg,
+        const float* __restrict__ occ2 = nullptr, const float* __restrict__ lp_ext = nullptr, const float* __restrict__ nll = nullptr) {
     extern __shared__ float corr[];  // V floats (+ up to 3 pad entries read by the last vector group)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int Sfull = ctc_row_stride(Umax), Sb = 2 * tgt_len[b] + 1;
@@ -941,7 +960,10 @@ __global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const float* __restr
         const float* x = logits + row * ldl;
         for (int sidx = tid; sidx < Sb; sidx += 256) {
             const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
-            atomicAdd(&corr[lab], occ[((int64_t)b * (L + 2) + t) * Sfull + sidx]);
+            const int64_t oi = ((int64_t)b * (L + 2) + t) * Sfull + sidx;
+            // occ2: the workspace holds raw alpha / beta rows (asr_ctc_loss_bwd with alpha2): the occupancy is formed here
+            const float w = occ2 ? occupancy(occ[oi], occ2[oi], lp_ext[((int64_t)b * L + t) * Sfull + sidx], nll[b] * LOG2E) : occ[oi];
+            atomicAdd(&corr[lab], w);
         }
         __syncthreads();
         const float l = lse[row];
@@ -978,9 +1000,11 @@ extern "C" int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_l
 
 extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                 int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
-                                const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg) {
+                                const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
+                                float* alpha2) {
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len && gout && grad, ASR_ERR_ARG,
                 "ctc_bwd: null pointer");
+    ASR_REQUIRE(!alpha2 || asr_aligned(alpha2, 16), ASR_ERR_ALIGN, "ctc_bwd: alpha2 must be 16-byte aligned");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && ldl >= V && ldg >= V, ASR_ERR_ARG, "ctc_bwd: bad sizes");
     ASR_REQUIRE(grad_dtype == ASR_F32 || grad_dtype == ASR_BF16, ASR_ERR_ARG, "ctc_bwd: bad grad_dtype");
     ASR_REQUIRE(grad_dtype == ASR_F32 || (ldg % 8 == 0 && ldl % 4 == 0 && asr_aligned(grad, 16) && asr_aligned(logits, 16)), ASR_ERR_ALIGN,
@@ -988,16 +1012,19 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE((size_t)(V + 4) * sizeof(float) <= 64 * 1024, ASR_ERR_UNSUPPORTED, "ctc_bwd: V=%d exceeds the LDS occupancy vector", V);
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_bwd: Umax too long");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
+    if (alpha2)
+        launch_recursion<2>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1, alpha2);
+    else
+        launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
     int rb = (2048 + B - 1) / B;  // ~2048 workgroups in flight
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
     if (grad_dtype == ASR_BF16)
         hipLaunchKernelGGL(ctc_grad_bf16_kernel, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, logits, ldl, in_len, targets,
-                           tgt_len, B, L, V, Umax, blank, lse, alpha, gout, reinterpret_cast<bf16_t*>(grad), ldg);
+                           tgt_len, B, L, V, Umax, blank, lse, alpha, gout, reinterpret_cast<bf16_t*>(grad), ldg, alpha2, lp_ext, nll);
     else
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(rb, B), dim3(256), (size_t)V * sizeof(float), s, logits, ldl, in_len, targets, tgt_len, B, L,
-                           V, Umax, blank, lse, alpha, gout, reinterpret_cast<float*>(grad), ldg);
+                           V, Umax, blank, lse, alpha, gout, reinterpret_cast<float*>(grad), ldg, alpha2, lp_ext, nll);
     ASR_LAUNCH_CHECK("ctc_loss_bwd");
     return 0;
 }

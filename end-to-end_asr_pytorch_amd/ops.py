@@ -355,6 +355,7 @@ _AUX = {}
 # recursion wavefronts of the same launch.  <= 1 = the two-launch form (pass, then recursion): 154-167 us at the north-star
 # shape against 133-139 fused with 32 chunks
 CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "32"))
+CTC_LAZY_OCC = os.environ.get("ASR_AMD_CTC_LAZY_OCC", "1") != "0"     # asr_ctc_loss_bwd with the second workspace (see asr_hip.h)
 
 
 def aux_stream(device, priority=0, slot=0):
@@ -422,10 +423,12 @@ def ctc_loss_bwd(st, gout, bf16=False):
             gbuf[:, :, st.V:].zero_()      # only the pad columns (the kernel writes every real one): not a 542 MB fill at S1
     grad = gbuf[:, :, :st.V]
     gout = gout.reshape(1).to(torch.float32).contiguous()
+    # second workspace: the recursion's second half stores raw rows, the gradient pass forms the occupancies (CTC_LAZY_OCC)
+    alpha2 = torch.empty_like(st.alpha) if CTC_LAZY_OCC else None
     with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), (4.0 + gbuf.element_size()) * st.B * st.L * st.V):
         check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax,
                                      st.blank, _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad),
-                                     dtype_code(gbuf), Vp), "asr_ctc_loss_bwd")
+                                     dtype_code(gbuf), Vp, _p(alpha2)), "asr_ctc_loss_bwd")
     return grad
 
 

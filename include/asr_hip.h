@@ -280,10 +280,14 @@ int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_len, int B, 
  * ldg elements.  bf16 (a gradient that only feeds bf16 MFMA GEMMs - those round an f32 image to the same values on load): rows
  * 16-byte aligned (ldg % 8 == 0, ldl % 4 == 0) and columns V .. ldg-1 are WRITTEN as zeros, so ldg can be the GEMM kernels'
  * padded row width (asr_gemm_nn / asr_gemm_tn below).
+ * alpha2 (optional, a second workspace of alpha's size): the recursion's second half then stores its raw rows there instead of
+ * turning alpha's rows into occupancies in place - a chain step without the second row load and the exp2, about half as long -
+ * and the gradient pass forms each occupancy from the two rows itself; alpha is left as the forward wrote it.
  */
 int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
-                     const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg);
+                     const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
+                     float* alpha2);
 
 /* Label-smoothed cross entropy (loss.py:5-31).  logits f32 [N,V] (row stride ldl), targets int64 [N] (0 = pad).
  * row_loss f32 [N] (0 on pad rows), lse f32 [N];  asr_ce_mean: loss[0] = sum(row_loss) / n_word, loss[1] = n_word
