@@ -49,7 +49,7 @@ __device__ __forceinline__ void row_stats(const f32x4 (&v)[4], float eps, float 
 __device__ __forceinline__ void finish_rows(float* __restrict__ accbuf, int* __restrict__ counter, const float* __restrict__ bias,
                                             const float* __restrict__ res, const f32x4* resv, const float* __restrict__ gamma,
                                             const float* __restrict__ beta, float* __restrict__ y32, bf16_t* __restrict__ y16, int row0,
-                                            int rows, int M, float eps, float (&red)[2][16][4]) {
+                                            int rows, int M, float eps, float (&red)[2][16][4], bf16_t* ylds = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q4 = lane >> 4;
     const int row = row0 + r16;
     const bool live = r16 < rows && row < M;
@@ -75,7 +75,12 @@ __device__ __forceinline__ void finish_rows(float* __restrict__ accbuf, int* __r
             *reinterpret_cast<f32x4*>(y32 + (int64_t)row * DM + c) = o;
             if (y16) *reinterpret_cast<bf16x4*>(y16 + (int64_t)row * DM + c) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
             *reinterpret_cast<f32x4*>(accbuf + (int64_t)row * DM + c) = f32x4{0, 0, 0, 0};
+            if (ylds) *reinterpret_cast<bf16x4*>(ylds + r16 * (DM + 8) + c) = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
         }
+    } else if (ylds) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<bf16x4*>(ylds + r16 * (DM + 8) + wave * 64 + 16 * j + 4 * q4) = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
     }
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -210,7 +215,9 @@ __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16_t* __r
                                                                bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache,
                                                                const int32_t* __restrict__ state, float* __restrict__ accbuf,
                                                                int* __restrict__ counters, float* __restrict__ y32, bf16_t* __restrict__ y16,
-                                                               int M, int h, int Tmax, float eps) {
+                                                               int M, int h, int Tmax, float eps, const bf16_t* __restrict__ Wq2,
+                                                               const float* __restrict__ bq2, bf16_t* __restrict__ q2_out, int Lq2, int h2,
+                                                               float q2_scale) {
     __shared__ float qs[16][64], ks[16][64], vs[16][64];          // this head's new q (scaled), k, v per row
     __shared__ __attribute__((aligned(16))) bf16_t O[16][64 + 8]; // attention output rows, the output projection's A operand
     __shared__ float red[2][16][4];
@@ -335,7 +342,33 @@ __global__ __launch_bounds__(256) void decode_self_attn_kernel(const bf16_t* __r
         }
     }
     if (!add_partial(accbuf, counters + blockIdx.y, a2, row0, ROWS, M, (int)gridDim.x, last_flag)) return;
-    finish_rows(accbuf, counters + blockIdx.y, bo, x32, nullptr, gamma, beta, y32, y16, row0, ROWS, M, eps, red);
+    // (the last workgroup is past the attention: the key staging buffer is free to hold its normalised rows)
+    bf16_t* ylds = Wq2 ? &Kst[0][0][0] : nullptr;
+    finish_rows(accbuf, counters + blockIdx.y, bo, x32, nullptr, gamma, beta, y32, y16, row0, ROWS, M, eps, red, ylds);
+    if (!Wq2) return;
+    // the NEXT sub-layer's query projection (the decoder's cross attention, attention.py:41 for its one new position per row) on the
+    // rows just normalised: q2 = (y Wq2^T + bq2) * q2_scale, stored head-major [M / Lq2, h2, Lq2, 64] like asr_proj_heads does
+    __syncthreads();
+    f32x4 qa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qa[j] = f32x4{0, 0, 0, 0};
+        u32x4 wr[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wr[s] = *reinterpret_cast<const u32x4*>(Wq2 + (int64_t)(wave * 64 + 16 * j + r16) * DM + s * 32 + q4 * 8);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) Mma<bf16_t>::run(wr[s], *reinterpret_cast<const u32x4*>(ylds + r16 * (DM + 8) + s * 32 + q4 * 8), qa[j]);
+    }
+    if (r16 < ROWS && row0 + r16 < M) {
+        const int row = row0 + r16, b = row / Lq2, jq = row - b * Lq2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wave * 64 + 16 * j + 4 * q4;              // column = head2 * 64 + d
+            const f32x4 v = (qa[j] + *reinterpret_cast<const f32x4*>(bq2 + c)) * q2_scale;
+            bf16_t* dst = q2_out + (((int64_t)b * h2 + (c >> 6)) * Lq2 + jq) * 64 + (c & 63);
+            *reinterpret_cast<bf16x4*>(dst) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+    }
 }
 
 }  // namespace
@@ -373,10 +406,13 @@ extern "C" int asr_decode_ffn(void* stream, const void* x16, const float* x32, c
 
 extern "C" int asr_decode_self_attn(void* stream, const void* x16, const float* x32, const void* Wqkv, const float* bqkv, const void* Wo,
                                     const float* bo, const float* gamma, const float* beta, void* k_cache, void* v_cache, const int32_t* state,
-                                    void* workspace, float* y32, void* y16, int M, int d_model, int h, int Tmax, float eps) {
+                                    void* workspace, float* y32, void* y16, int M, int d_model, int h, int Tmax, float eps, const void* next_Wq,
+                                    const float* next_bq, void* next_q, int next_Lq, float next_scale) {
     ASR_REQUIRE(x16 && x32 && Wqkv && bqkv && Wo && gamma && beta && k_cache && v_cache && state && workspace && y32 && M > 0 && Tmax > 0,
                 ASR_ERR_ARG, "decode_self_attn: null pointer / bad sizes");
     ASR_REQUIRE(d_model == DM && h >= 1 && h <= 16, ASR_ERR_UNSUPPORTED, "decode_self_attn: d_model %d / %d heads (256, 1..16 heads of 64)", d_model, h);
+    ASR_REQUIRE(!next_Wq || (next_bq && next_q && next_Lq > 0 && M % next_Lq == 0 && asr_aligned(next_Wq, 16) && asr_aligned(next_bq, 16) &&
+                             asr_aligned(next_q, 8)), ASR_ERR_ARG, "decode_self_attn: the next query projection needs weight, bias, output and Lq | M");
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(x32, 16) && asr_aligned(Wqkv, 16) && asr_aligned(Wo, 16) && asr_aligned(bqkv, 16) &&
                     (!bo || asr_aligned(bo, 16)) && asr_aligned(gamma, 16) && asr_aligned(beta, 16) && asr_aligned(workspace, 16) &&
                     asr_aligned(k_cache, 16) && asr_aligned(v_cache, 16) && asr_aligned(y32, 16) && (!y16 || asr_aligned(y16, 8)),
@@ -387,11 +423,13 @@ extern "C" int asr_decode_self_attn(void* stream, const void* x16, const float* 
     if (M <= 64)      // few rows: 4-row blocks, one row per wave
         hipLaunchKernelGGL(decode_self_attn_kernel<4>, dim3(h, (M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t*)x16,
                            x32, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wo, bo, gamma, beta, (bf16_t*)k_cache, (bf16_t*)v_cache, state, accbuf,
-                           counters, y32, (bf16_t*)y16, M, h, Tmax, eps);
+                           counters, y32, (bf16_t*)y16, M, h, Tmax, eps, (const bf16_t*)next_Wq, next_bq, (bf16_t*)next_q, next_Lq, DM / 64,
+                           next_scale);
     else
         hipLaunchKernelGGL(decode_self_attn_kernel<16>, dim3(h, rb), dim3(256), 0, static_cast<hipStream_t>(stream), (const bf16_t*)x16, x32,
                            (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wo, bo, gamma, beta, (bf16_t*)k_cache, (bf16_t*)v_cache, state, accbuf,
-                           counters, y32, (bf16_t*)y16, M, h, Tmax, eps);
+                           counters, y32, (bf16_t*)y16, M, h, Tmax, eps, (const bf16_t*)next_Wq, next_bq, (bf16_t*)next_q, next_Lq, DM / 64,
+                           next_scale);
     ASR_LAUNCH_CHECK("decode_self_attn");
     return 0;
 }

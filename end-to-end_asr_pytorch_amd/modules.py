@@ -307,10 +307,11 @@ class _Cached(nn.Module):
 
 class Act:
     """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
-    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad")
+    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q")
 
     def __init__(self, f32, b16, B, L):
         self.f32, self.b16, self.B, self.L, self.grad, self.needs_grad = f32, b16, B, L, None, False
+        self.next_q = None       # decode step: the next cross attention's projected queries, when the launch that made this produced them
 
     def mma(self):
         return self.b16 if (self.b16 is not None and _PRECISION == "bf16") else self.f32
@@ -364,7 +365,7 @@ class MultiheadAttention(_Cached):
         nn.init.xavier_normal_(self.fc.weight)
         self.dropout_rate = dropout
 
-    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None, attn_drop=None):
+    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None, attn_drop=None, q_pre=None):
         """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act.
         kv_pre = (k, v, dkv) when the caller has already projected the keys / values (_CrossKV: one GEMM for all decoder layers);
         dkv() -> (dk, dv) views the backward writes into, the K/V weight and input gradients are then the caller's business."""
@@ -377,7 +378,7 @@ class MultiheadAttention(_Cached):
             qkv = ops.proj_heads(xq.mma(), W, bias, 3, B, Lq, h, qscale)
             q, k, v = qkv[0], qkv[1], qkv[2]
         else:
-            q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
+            q = q_pre if q_pre is not None else ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
             if kv_pre is not None:
                 k, v = kv_pre[0], kv_pre[1]
             else:
@@ -448,27 +449,38 @@ class MultiheadAttention(_Cached):
         mine = (qkvw[:1] + qkvb[:1]) if dkv_pre is not None else (qkvw + qkvb)
         _TAPE.push(bw, mine + (fc.weight, fc.bias, ln.weight, ln.bias))
 
-    def _impl_ctx(self, xq, xkv, k_len, kv_pre):
+    def _impl_ctx(self, xq, xkv, k_len, kv_pre, q=None):
         """decode step only (eval, no tape): the attention output [B * Lq, h * 64] BEFORE the output projection - the caller runs
-        projection + residual + LayerNorm inside the next launch (PositionwiseFeedForward._impl_after_attention)"""
+        projection + residual + LayerNorm inside the next launch (PositionwiseFeedForward._impl_after_attention); q: the projected
+        queries when the launch in front has produced them already"""
         h, B, Lq = self.n_head, xq.B, xq.L
         qscale = _LOG2E / math.sqrt(self.d_k)
-        q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
+        if q is None:
+            q = ops.proj_heads(xq.mma(), self._w("q", (self.w_qs.weight,)), self._b("bq", (self.w_qs.bias,)), 1, B, Lq, h, qscale)[0]
         ctx, _ = ops.attention_fwd(q, kv_pre[0], kv_pre[1], k_len, False, need_lse=False, drop=None, drop_bits=None)
         return ctx.view(B * Lq, h * 64)
 
-    def _impl_cached_self(self, x, k_cache, v_cache, t, k_len):
+    def _impl_cached_self(self, x, k_cache, v_cache, t, k_len, next_attn=None, next_lq=1):
         """Self-attention of ONE new position t (x: Act [B*1, d]) against the cache (decoding): its key / value are projected and
         written into k_cache / v_cache [B, h, Tmax, 64] at position t, then the query attends to positions < k_len (= t + 1).
         bf16, d_model = 256, position on the device: the whole sub-layer is ONE launch (asr_decode_self_attn)."""
         h, B = self.n_head, x.B
         if (_DECODE_FUSED and _PRECISION == "bf16" and torch.is_tensor(t) and x.L == 1 and k_cache.dtype == torch.bfloat16 and
                 self.w_qs.weight.shape[0] == h * 64 and ops.decode_blocks_ok(x, heads=h)):
-            y32, y16 = ops.decode_self_attn(x.b16 if x.b16 is not None else ops.cast_bf16(x.f32), x.f32, self._w("qkv", (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight)),
-                                            self._b("bqkv", (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)), self._w("fc", (self.fc.weight,)),
-                                            self._b("bfc", (self.fc.bias,)), self.layer_norm.weight, self.layer_norm.bias, k_cache, v_cache, t,
-                                            self.layer_norm.eps)
-            return Act(y32, y16, B, 1)
+            # next_attn: the cross-attention module that follows - its query projection of the rows this launch normalises rides along
+            # (next_lq rows per utterance are the queries of one cross attention); the result is handed over in `y.next_q`
+            nq = None
+            if next_attn is not None and next_attn.w_qs.weight.shape == (256, 256) and next_attn.n_head == 4:
+                nq = (next_attn._w("q", (next_attn.w_qs.weight,)), next_attn._b("bq", (next_attn.w_qs.bias,)), int(next_lq),
+                      _LOG2E / math.sqrt(next_attn.d_k))
+            out = ops.decode_self_attn(x.b16 if x.b16 is not None else ops.cast_bf16(x.f32), x.f32, self._w("qkv", (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight)),
+                                       self._b("bqkv", (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)), self._w("fc", (self.fc.weight,)),
+                                       self._b("bfc", (self.fc.bias,)), self.layer_norm.weight, self.layer_norm.bias, k_cache, v_cache, t,
+                                       self.layer_norm.eps, next_q=nq)
+            y = Act(out[0], out[1], B, 1)
+            if nq is not None:
+                y.next_q = out[2]
+            return y
         kv = ops.proj_heads(x.mma(), self._w("kv", (self.w_ks.weight, self.w_vs.weight)), self._b("bkv", (self.w_ks.bias, self.w_vs.bias)),
                             2, B, 1, h, 1.0)
         if torch.is_tensor(t):                      # position in device memory (Decoder.batch_decode's captured step)
@@ -877,17 +889,17 @@ class DecoderLayer(nn.Module):
         self.enc_attn = MultiheadAttention(d_model, n_head, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
-    def _decode_cross_ffn(self, x, enc, enc_len, kv_pre, n_rows):
+    def _decode_cross_ffn(self, x, enc, enc_len, kv_pre, n_rows, q=None):
         """the cross-attention and feed-forward sub-layers of one decode step (x: Act [B, Lq] rows, Lq = 1 or the beam) -> Act
         [n_rows, 1]: query projection, attention, then output projection + LayerNorm + feed-forward in one launch when the step's
         rows fit the fused kernel (bf16, d_model 256, <= 64 rows), else the two sub-layers as usual"""
         ffn, att = self.pos_ffn, self.enc_attn
         if (_DECODE_FUSED and _PRECISION == "bf16" and _IN_DECODE_STEP and not ffn.training and att.fc.weight.shape[1] == 256 and
                 ops.decode_blocks_ok(x, d_ff=ffn.w_1.weight.shape[0])):
-            ctx = att._impl_ctx(x, enc, enc_len, kv_pre)
+            ctx = att._impl_ctx(x, enc, enc_len, kv_pre, q=q)
             y = ffn._impl_after_attention(ctx, att, x)
             return Act(y.f32, y.b16, n_rows, 1)
-        xq = att._impl(x, enc, enc_len, False, None, kv_pre=kv_pre)
+        xq = att._impl(x, enc, enc_len, False, None, kv_pre=kv_pre, q_pre=q)
         return ffn._impl(Act(xq.f32, xq.b16, n_rows, 1), None)
 
     def _impl(self, x, enc, dec_len, enc_len, kv_pre=None, attn_drop=(None, None)):
@@ -1167,9 +1179,9 @@ class Decoder(_Cached):
             x32, x16 = ops.decode_embed(cur, emb, pe, state, want_bf16=(_PRECISION == "bf16"))
             x = Act(x32, x16, N, 1)
             for i, layer in enumerate(self.layer_stack):
-                x = layer.slf_attn._impl_cached_self(x, cache[2 * i], cache[2 * i + 1], state, k_len)
+                x = layer.slf_attn._impl_cached_self(x, cache[2 * i], cache[2 * i + 1], state, k_len, next_attn=layer.enc_attn, next_lq=beam)
                 xq = Act(x.f32, x.b16, B, beam)               # the beams of an utterance: `beam` queries of one cross-attention
-                x = layer._decode_cross_ffn(xq, box["enc"], enc_len, box["cross"](i), N)
+                x = layer._decode_cross_ffn(xq, box["enc"], enc_len, box["cross"](i), N, q=x.next_q)
             # Decoder.step's log-probabilities, log_softmax again (decoder.py:118 + :191), top-k: one launch
             best, ids = ops.lsm_topk_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), beam, twice=True)
             ops.beam_step(scores, best, ids, preds, state, n_steps, parent, cur, beam)
@@ -1229,8 +1241,8 @@ class Decoder(_Cached):
             x32, x16 = ops.decode_embed(cur, emb, pe, state, want_bf16=(_PRECISION == "bf16"))
             x = Act(x32, x16, B, 1)
             for i, layer in enumerate(self.layer_stack):
-                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], state, k_len)
-                x = layer._decode_cross_ffn(x, box["enc"], enc_len, box["cross"](i), B)
+                x = layer.slf_attn._impl_cached_self(x, kc[i], vc[i], state, k_len, next_attn=layer.enc_attn, next_lq=1)
+                x = layer._decode_cross_ffn(x, box["enc"], enc_len, box["cross"](i), B, q=x.next_q)
             ops.argmax_rows(_vocab_proj(self, "prj", self.tgt_word_prj.weight, x), out=cur)      # argmax of log_softmax = argmax of the logits
             ops.decode_advance(cur, preds, state, k_len, finished, len_decoded, self.eos_id)
 

@@ -817,7 +817,9 @@ def decode_ffn(x16, x32, w1, b1, w2, b2, gamma, beta, eps, pre=None):
     return y32, y16
 
 
-def decode_self_attn(x16, x32, wqkv, bqkv, wo, bo, gamma, beta, k_cache, v_cache, state, eps):
+def decode_self_attn(x16, x32, wqkv, bqkv, wo, bo, gamma, beta, k_cache, v_cache, state, eps, next_q=None):
+    """the self-attention sub-layer of the decode step in one launch; next_q = (Wq bf16 [256, 256], bq, Lq, scale): also the next
+    sub-layer's query projection of the output rows -> third result, bf16 head-major [M / Lq, 4, Lq, 64] (asr_proj_heads' layout)"""
     _req_cuda(x16, x32, wqkv, bqkv, wo, gamma, beta, k_cache, v_cache, state)
     M, D = x32.shape
     N, h, Tmax, dk = k_cache.shape
@@ -826,9 +828,16 @@ def decode_self_attn(x16, x32, wqkv, bqkv, wo, bo, gamma, beta, k_cache, v_cache
     y32 = torch.empty((M, D), device=x32.device, dtype=torch.float32)
     y16 = torch.empty((M, D), device=x32.device, dtype=torch.bfloat16)
     ws = decode_block_workspace(M, x32.device)
+    wq2, bq2, q2, lq2, sc2 = None, None, None, 0, 0.0
+    if next_q is not None:
+        wq2, bq2, lq2, sc2 = next_q
+        _req_cuda(wq2, bq2)
+        assert wq2.dtype == torch.bfloat16 and tuple(wq2.shape) == (D, D) and M % lq2 == 0
+        q2 = torch.empty((M // lq2, D // 64, lq2, 64), device=x32.device, dtype=torch.bfloat16)
     check(lib().asr_decode_self_attn(_stream(), _p(x16), _p(x32), _p(wqkv), _p(bqkv), _p(wo), _p(bo), _p(gamma), _p(beta), _p(k_cache), _p(v_cache),
-                                     _p(state), _p(ws), _p(y32), _p(y16), M, D, h, Tmax, float(eps)), "asr_decode_self_attn")
-    return y32, y16
+                                     _p(state), _p(ws), _p(y32), _p(y16), M, D, h, Tmax, float(eps), _p(wq2), _p(bq2), _p(q2), int(lq2), float(sc2)),
+          "asr_decode_self_attn")
+    return (y32, y16, q2) if next_q is not None else (y32, y16)
 
 
 def beam_cat_frames(frames, state, beam, other=None, cur=None, emb=None, pe=None):

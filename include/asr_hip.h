@@ -390,14 +390,18 @@ int asr_decode_advance(void* stream, const int64_t* cur, int64_t* preds, int32_t
  *                       attention.py:58-60), x16 then holds the attention output ctx [M, 256] and x32 that sub-layer's input res
  * asr_decode_self_attn: MultiheadAttention.forward (attention.py:33-62) for ONE new position per row against that row's K / V cache
  *                       [M, h, Tmax, 64] bf16: q / k / v projections (Wqkv rows [q | k | v] x (h * 64)), k and v written into slot
- *                       t = state[0], softmax(q . K[0..t] / 8) V, output projection + bias + residual + LayerNorm */
+ *                       t = state[0], softmax(q . K[0..t] / 8) V, output projection + bias + residual + LayerNorm; with next_Wq
+ *                       also the NEXT sub-layer's query projection of the normalised rows, next_q = (y next_Wq^T + next_bq) *
+ *                       next_scale as bf16 head-major [M / next_Lq, 4, next_Lq, 64] (the decoder's cross attention, whose
+ *                       queries are the beams of an utterance: what asr_proj_heads would write) */
 int64_t asr_decode_block_workspace_bytes(int M);
 int asr_decode_ffn(void* stream, const void* x16, const float* x32, const void* W1, const float* b1, const void* W2, const float* b2,
                    const float* gamma, const float* beta, void* workspace, float* y32, void* y16, int M, int d_model, int d_ff, float eps,
                    const void* pre_Wo, const float* pre_bo, const float* pre_gamma, const float* pre_beta, float pre_eps);
 int asr_decode_self_attn(void* stream, const void* x16, const float* x32, const void* Wqkv, const float* bqkv, const void* Wo, const float* bo,
                          const float* gamma, const float* beta, void* k_cache, void* v_cache, const int32_t* state, void* workspace, float* y32,
-                         void* y16, int M, int d_model, int h, int Tmax, float eps);
+                         void* y16, int M, int d_model, int h, int Tmax, float eps, const void* next_Wq, const float* next_bq, void* next_q,
+                         int next_Lq, float next_scale);
 /* Beam search over integrated frames for B utterances at once (Decoder_CIF.recognize_beam, decoder.py:425-475, which decodes ONE
  * utterance with a Python loop over hypotheses; Decoder_CIF.step_forward_cache, decoder.py:477-496).  Hypothesis rows r = b * beam + j;
  * the step position t is state[0]; utterance b is live while t < n_steps[b] (its number of integrated frames).

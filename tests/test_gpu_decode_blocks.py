@@ -119,7 +119,14 @@ def test_fused_sub_layers_equal_the_separate_launches_on_module_weights(monkeypa
                 vc = (rnd(torch.Generator().manual_seed(6), N, 4, Tmax, 64)).bfloat16().to(DEV)
                 x = Act(x32.clone(), x32.bfloat16(), N, 1)
                 layer = dec.layer_stack[0]
-                y = layer.slf_attn._impl_cached_self(x, kc, vc, state, k_len)
+                y = layer.slf_attn._impl_cached_self(x, kc, vc, state, k_len, next_attn=layer.enc_attn, next_lq=beam)
+                if fused:      # the cross attention's queries produced by the same launch == asr_proj_heads on the output rows
+                    import math
+                    att = layer.enc_attn
+                    qref = ops.proj_heads(y.b16, att._w("q", (att.w_qs.weight,)), att._b("bq", (att.w_qs.bias,)), 1, B, beam, 4,
+                                          modules._LOG2E / math.sqrt(64))[0]
+                    assert tuple(y.next_q.shape) == tuple(qref.shape)
+                    np.testing.assert_allclose(y.next_q.float().cpu().numpy(), qref.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
                 z1 = layer._decode_cross_ffn(Act(y.f32, y.b16, N, 1), Act(enc.f32.view(B, 1, L, 256).expand(B, beam, L, 256).reshape(N * L, 256).contiguous(), None, N, L),
                                              enc_len.repeat_interleave(beam), tuple(None if c is None else c.repeat_interleave(beam, 0).contiguous() for c in cross(0)[:2]) + (None,), N)
                 z2 = layer._decode_cross_ffn(Act(y.f32, y.b16, B, beam), enc, enc_len, cross(0), N)
