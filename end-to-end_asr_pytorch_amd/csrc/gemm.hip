@@ -596,10 +596,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(const AT* __restrict__ A
 // projection of the d_model = 256 configs) the un-overlapped prologue + epilogue was most of a workgroup's life.
 // Tile order: hardware workgroup b sits on XCD b & 7 (round-robin dispatch); every XCD owns one contiguous range of tile ids
 // (n fastest), so the workgroups that share an A row-panel run on the same L2 at about the same time.
-template <typename Epi>
+template <typename Epi, bool KS1 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
-                                                             int64_t ldw, int M, int N, int K, int tiles_n, int ntiles, int ksplit,
+                                                             int64_t ldw, int M, int N, int K, int tiles_n, int ntiles, int ksplit_rt,
                                                              Epi epi) {
+    // KS1 (no split-K, the common case): the K-range arithmetic - 64-bit products and divisions by a run-time split count, several
+    // hundred scalar instructions per output tile in the listing, as many as a K = 256 tile's whole K loop - folds away
+    const int ksplit = KS1 ? 1 : ksplit_rt;
     // ksplit > 1 (host: few output tiles, long K, f32 C): `ntiles` counts (tile, K-split) pairs, split fastest; every pair is a
     // "tile" of the walk below with its own K range, and the epilogue adds atomically (epi.atomic()) into a zeroed C
     constexpr int KT = 64, TILE = BM * ROWB;  // 16 KiB per operand tile
@@ -825,10 +828,11 @@ __device__ __forceinline__ u32x4 tr_frag(const unsigned char* tile, int row0, in
     return u32x4{a[0], a[1], b[0], b[1]};
 }
 
-template <typename Epi>
+template <typename Epi, bool KS1 = false>
 __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ Bm,
-                                                           int64_t ldb, int M, int N, int K, int tiles_n, int ntiles, int ksplit,
+                                                           int64_t ldb, int M, int N, int K, int tiles_n, int ntiles, int ksplit_rt,
                                                            Epi epi) {
+    const int ksplit = KS1 ? 1 : ksplit_rt;     // (see gemm_nt_glds_kernel)
     constexpr int KT = 64, TILE = BM * ROWB;   // 16 KiB: A tile [128 m][64 k]; B tile [64 k][128 n]
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1157,8 +1161,12 @@ template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t ld
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n * ksplit;
     static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU (64 KiB of LDS each)
     const int nwg = ntiles < max_wg ? ntiles : max_wg;
-    hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
-                       reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, ntiles, ksplit, epi);
+    if (ksplit == 1)
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, true>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
+                           reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, ntiles, ksplit, epi);
+    else
+        hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, false>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
+                           reinterpret_cast<const bf16_t*>(W), ldw, M, N, K, tiles_n, ntiles, ksplit, epi);
     ASR_LAUNCH_CHECK("gemm_nt_glds");
     return 0;
 }
@@ -1308,8 +1316,14 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
         const int vtiles = nwg * sp;
         const int pwg = vtiles < max_wg ? vtiles : max_wg;
 #define LAUNCH_NN_TR(E)                                                                                                          \
-    hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E)>), dim3(pwg), dim3(NT), 0, s, (const bf16_t*)A, lda, (const bf16_t*)Bm, ldb, M, N, \
-                       K, tiles_n, vtiles, sp, E)
+    do {                                                                                                                         \
+        if (sp == 1)                                                                                                             \
+            hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E), true>), dim3(pwg), dim3(NT), 0, s, (const bf16_t*)A, lda,         \
+                               (const bf16_t*)Bm, ldb, M, N, K, tiles_n, vtiles, sp, E);                                         \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((gemm_nn_tr_kernel<decltype(E), false>), dim3(pwg), dim3(NT), 0, s, (const bf16_t*)A, lda,        \
+                               (const bf16_t*)Bm, ldb, M, N, K, tiles_n, vtiles, sp, E);                                         \
+    } while (0)
         const unsigned mode = epi.wide_ok ? dense_mode(epi) : 0xffu;
         if (mode == 4u) LAUNCH_NN_TR(dense_as<4u>(epi));                 // dX = dY . W + residual gradient (f32)
         else if (mode == (4u | 128u)) LAUNCH_NN_TR(dense_as<4u | 128u>(epi));   // ... split-K (decoder rows)
