@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 for (int i = 0; i < 4; ++i) {
                     const float p = __builtin_amdgcn_exp2f(sq[hf][4 * g + i]);
                     if (DROP) {
-                        sq[hf][4 * g + i] = drop_and(p * dsc, wq[hf], 8 * g + i);                                                // dropout(P), feeds dV
+                        sq[hf][4 * g + i] = drop_and(p, wq[hf], 8 * g + i);              // the kept P (dropout's 1 / keep factor is applied to dV once, at the store)
                         dp[hf][4 * g + i] = p * __builtin_fmaf(drop_and(dp[hf][4 * g + i], wq[hf], 8 * g + i), dsc, -d4[i]);     // dS
                     } else {
                         sq[hf][4 * g + i] = p;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     if (key < Lk) {   // keys in [kl, Lk) get exact zeros
         const int64_t off = ((int64_t)b * Lk + key) * ldkv + hd * 64;
         store_T(dk_out + off, dk0, dk1, hh, 0.6931471805599453f);   // dS is per natural-log score; q carries log2(e): dK = dS^T.q * ln 2
-        store_T(dv_out + off, dv0, dv1, hh, 1.f);
+        store_T(dv_out + off, dv0, dv1, hh, dsc);
     }
 }
 
