@@ -145,3 +145,33 @@ def test_fused_sub_layers_equal_the_separate_launches_on_module_weights(monkeypa
             res[fused] = dec.batch_decode(encoded, lens, max_decode_len=10)[0].cpu().numpy()
     assert res[True].shape == res[False].shape
     assert (res[True][:, :3] == res[False][:, :3]).mean() >= 0.75
+
+
+def test_beam_searches_with_fused_sub_layers(monkeypatch):
+    """d_model = 256 models (the fused launches' shape): Decoder.batch_beam_decode and Decoder_CIF.batch_recognize_beam with the
+    one-launch sub-layers against the separate launches - same shapes and lengths, first tokens of the best beam equal, scores close
+    (bf16 paths with different rounding order may part ways later at a near-tie)"""
+    import asr_amd
+    from asr_amd import modules
+    torch.manual_seed(7)
+    g = torch.Generator().manual_seed(21)
+    B, L, beam, T = 3, 60, 3, 8
+    dec = asr_amd.Decoder(2, 3, 40, 2, 4, 256, 512, dropout=0.1).to(DEV).eval()
+    encoded, lens = rnd(g, B, L, 256).to(DEV), torch.tensor([60, 41, 17], device=DEV)
+    dcif = asr_amd.Decoder_CIF(2, 40, 2, 4, 256, 512, dropout=0.1).to(DEV).eval()
+    frames, n_frames = rnd(g, B, 9, 256).to(DEV), torch.tensor([9, 4, 6], dtype=torch.int32, device=DEV)
+    res = {}
+    with asr_amd.precision("bf16"):
+        for fused in (True, False):
+            monkeypatch.setattr(modules, "_DECODE_FUSED", fused)
+            dec.__dict__.pop("_beam_graph", None)
+            dcif.__dict__.pop("_beam_graph", None)
+            p, l, sc = dec.batch_beam_decode(encoded, lens, beam_size=beam, max_decode_len=T)
+            hyp = dcif.batch_recognize_beam(frames, n_frames, beam, nbest=2)
+            res[fused] = (p.cpu().numpy(), l.cpu().numpy(), sc.cpu().numpy(), hyp)
+    a, b = res[True], res[False]
+    assert a[0].shape == b[0].shape and a[1].shape == b[1].shape
+    assert (a[0][:, 0, :2] == b[0][:, 0, :2]).mean() >= 0.66
+    np.testing.assert_allclose(a[2][:, 0], b[2][:, 0], rtol=0, atol=0.15)
+    for (ya, la), (yb, lb), n in zip(a[3], b[3], (9, 4, 6)):
+        assert la == lb == [n + 1, n + 1] and ya[0][:2] == yb[0][:2]
