@@ -534,6 +534,8 @@ class PositionwiseFeedForward(_Cached):
                                       self._w("w2", (self.w_2.weight,)), self._b("b2", (self.w_2.bias,)), self.layer_norm.weight,
                                       self.layer_norm.bias, self.layer_norm.eps)
             return Act(y32, y16, x.B, x.L)
+        if _PRECISION == "bf16" and ops.ffn_fused_ok(x.b16, x.f32, self._w("w1", (self.w_1.weight,)), self._w("w2", (self.w_2.weight,)), x.B, x.L):
+            return self._impl_fused(x, row_len, rec)
         # training: the ReLU mask travels to the backward as 1 sign bit per hidden unit (written by this GEMM's epilogue) - the
         # hidden gradient's GEMM then reads 8 MB instead of re-reading the 131 MB activation (S1 shape)
         use_bits = rec and _PRECISION == "bf16" and d_ff % 128 == 0 and x.mma().dtype == torch.bfloat16 and x.f32.shape[1] % 64 == 0
@@ -566,6 +568,29 @@ class PositionwiseFeedForward(_Cached):
                          else ops.gemm_nn(ds16, self._w("w2", (w2.weight,)), out_dtype=_cdtype(), relu_mask=hid))
                 _wg(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
                 _acc(x, ops.gemm_nn(d_hid, self._w("w1", (w1.weight,)), addend=ds))
+
+            _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
+        return y
+
+    def _impl_fused(self, x, row_len, rec):
+        """Encoder-sized rows at d_model = 256: the sub-layer is ONE forward launch (asr_ffn_fwd: both products, bias, ReLU, dropout,
+        residual, LayerNorm, row mask; the hidden activation is written once for the weight gradient, never read back in the forward)
+        and ONE data-gradient launch (asr_ffn_bwd: dH and dX); the two weight gradients stay GEMMs over the stored H / dH."""
+        ln, w1, w2 = self.layer_norm, self.w_1, self.w_2
+        w1m, w2m = self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,))
+        dp = _drop(self, "dropout")   # module.py:51
+        hid, bits, o, y32, y16, mean, rstd = ops.ffn_fwd(x.b16, x.f32, w1m, self._b("b1", (w1.bias,)), w2m, self._b("b2", (w2.bias,)),
+                                                         ln.weight, ln.bias, x.B, x.L, row_len=row_len, eps=ln.eps, train=rec, drop_x=dp)
+        y = Act(y32, y16, x.B, x.L)
+        if rec:
+            def bw():
+                ds, ds16 = _ln_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
+                                      dbias=w2.bias.grad, drop_x=dp)
+                y.grad = None
+                _wg(ds16, hid, out=w2.weight.grad, accumulate=True)
+                d_hid, dx = ops.ffn_bwd(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits)
+                _wg(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
+                _acc(x, dx)
 
             _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
         return y

@@ -268,6 +268,49 @@ def gemm_add_layernorm_small(a2d, w, bias, residual, gamma, beta, B, L, row_len=
 gemm_add_layernorm = gemm_add_layernorm_small      # one entry: picks the kernel by shape
 
 
+FUSED_FFN = os.environ.get("ASR_AMD_FUSED_FFN", "1") != "0"          # A/B: 0 = two GEMMs + LayerNorm / two data-gradient GEMMs
+FUSED_FFN_MIN_ROWS = int(os.environ.get("ASR_AMD_FUSED_FFN_ROWS", "4096"))     # below: a 128-token block per CU leaves most of the chip idle
+
+
+def ffn_fused_ok(x16, x32, w1, w2, B, L):
+    """Shapes asr_ffn_fwd / asr_ffn_bwd take: d_model = 256, d_ff a multiple of 64 up to 2048, bf16 operands, encoder-sized rows."""
+    return (FUSED_FFN and x16 is not None and x16.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16 and
+            x32.shape[1] == 256 and w1.shape[1] == 256 and w2.shape[0] == 256 and w1.shape[0] % 64 == 0 and 64 <= w1.shape[0] <= 2048 and
+            B * L >= FUSED_FFN_MIN_ROWS and B * L * w1.shape[0] * 2 < 2 ** 31 and x16.is_contiguous() and x32.is_contiguous() and
+            w1.is_contiguous() and w2.is_contiguous())
+
+
+def ffn_fwd(x16, x32, w1, b1, w2, b2, gamma, beta, B, L, row_len=None, eps=1e-5, train=False, drop_x=None, want_bf16=True):
+    """The whole position-wise feed-forward sub-layer in one launch (asr_hip.h: asr_ffn_fwd).
+    -> (hid bf16 [M,d_ff] or None, bits or None, s_sum [M,256] or None, y32, y16, mean, rstd); hid / bits / s_sum / mean / rstd with train."""
+    _req_cuda(x16, x32, w1, b1, w2, b2, gamma, beta, row_len)
+    M, dff, dev = B * L, w1.shape[0], x32.device
+    hid = torch.empty((M, dff), device=dev, dtype=torch.bfloat16) if train else None
+    bits = torch.empty((int(lib().asr_ffn_bits_words(M, dff)),), device=dev, dtype=torch.int32) if train else None
+    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32) if train else None
+    y32 = torch.empty((M, 256), device=dev, dtype=torch.float32)
+    y16 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16) if want_bf16 else None
+    mean = torch.empty(M, device=dev, dtype=torch.float32) if train else None
+    rstd = torch.empty(M, device=dev, dtype=torch.float32) if train else None
+    with _timed("ffn_fwd[%dx256x%d]" % (M, dff), 4.0 * M * 256 * dff):
+        check(lib().asr_ffn_fwd(_stream(), _p(x16), _p(x32), _p(w1), _p(b1), _p(w2), _p(b2), _p(gamma), _p(beta), _p(row_len), _p(hid),
+                                _p(bits), _p(s_sum), _p(y32), _p(y16), _p(mean), _p(rstd), B, L, 256, dff, float(eps), _d(drop_x)),
+              "asr_ffn_fwd")
+    return hid, bits, s_sum, y32, y16, mean, rstd
+
+
+def ffn_bwd(ds16, ds32, w1, w2, bits):
+    """(d_hid bf16 [M,d_ff], dx f32 [M,256]) = the sub-layer's data gradient in one launch (asr_hip.h: asr_ffn_bwd)."""
+    _req_cuda(ds16, ds32, w1, w2, bits)
+    M, dff = ds32.shape[0], w1.shape[0]
+    assert ds16.dtype == torch.bfloat16 and ds16.is_contiguous() and ds32.is_contiguous()
+    d_hid = torch.empty((M, dff), device=ds32.device, dtype=torch.bfloat16)
+    dx = torch.empty((M, 256), device=ds32.device, dtype=torch.float32)
+    with _timed("ffn_bwd[%dx256x%d]" % (M, dff), 4.0 * M * 256 * dff):
+        check(lib().asr_ffn_bwd(_stream(), _p(ds16), _p(ds32), _p(w1), _p(w2), _p(bits), _p(d_hid), _p(dx), M, 256, dff), "asr_ffn_bwd")
+    return d_hid, dx
+
+
 def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False,
                   drop_x=None, drop_y=None):
     """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd).

@@ -165,6 +165,27 @@ int asr_gemm_add_layernorm_small(void* stream, const void* A, int64_t lda, const
                                  const float* gamma, const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16,
                                  float* mean, float* rstd, int B, int L, int K, float eps, asr_dropout_t drop_x);
 
+/* The position-wise feed-forward sub-layer of an encoder layer in ONE launch (module.py:48-53 `layer_norm(dropout(w_2(relu(w_1(x)))) +
+ * residual)` followed by encoder.py:77 `enc_output *= non_pad_mask`), for d_model = 256 and d_ff a multiple of 64 (<= 2048):
+ *   h = relu(x16 . W1^T + b1);  s = dropout_x(h . W2^T + b2) + x32;  y = LayerNorm(s) * gamma + beta, rows t >= row_len[b] zeroed.
+ * x16 bf16 [M = B*L, 256] (the MFMA operand), x32 f32 [M, 256] (the residual); w1 bf16 [d_ff, 256], w2 bf16 [256, d_ff] as nn.Linear
+ * stores them.  The [M, d_ff] hidden activation stays on the chip between the two products.  Outputs as asr_add_layernorm_fwd
+ * leaves them: s_out (pre-norm sum, optional), y32, y16 (optional), mean / rstd (optional).  Training passes hid_out (bf16 [M, d_ff]:
+ * the activation, written once for the weight gradient dW2 = ds^T h) AND bits_out (asr_ffn_bits_words(M, d_ff) 32-bit words: 1 bit per
+ * hidden unit, set where h > 0; the layout is private to asr_ffn_fwd / asr_ffn_bwd); both NULL in inference. */
+int64_t asr_ffn_bits_words(int M, int d_ff);
+int asr_ffn_fwd(void* stream, const void* x16, const float* x32, const void* w1, const float* b1, const void* w2, const float* b2,
+                const float* gamma, const float* beta, const int32_t* row_len, void* hid_out, void* bits_out, float* s_out,
+                float* y32, void* y16, float* mean_out, float* rstd_out, int B, int L, int d_model, int d_ff, float eps,
+                asr_dropout_t drop_x);
+
+/* Data gradient of the same sub-layer in ONE launch (autograd of module.py:50-52 below the LayerNorm):
+ *   dH = (ds16 . W2) * [h > 0]  (bits from asr_ffn_fwd);   dx = dH . W1 + ds32.
+ * ds16 bf16 [M, 256]: the gradient wrt w_2's output (asr_add_layernorm_bwd's ds16); ds32 f32 [M, 256]: the gradient wrt the residual.
+ * dhid_out bf16 [M, d_ff] (written once, for dW1 = dH^T x and db1 = colsum dH), dx_out f32 [M, 256]. */
+int asr_ffn_bwd(void* stream, const void* ds16, const float* ds32, const void* w1, const void* w2, const void* bits, void* dhid_out,
+                float* dx_out, int M, int d_model, int d_ff);
+
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.
  * mean/rstd (f32 [M]) and s_out (f32 [M,D], the pre-norm sum x+residual; may alias x) are optional saves for backward.

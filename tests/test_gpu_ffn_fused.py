@@ -1,0 +1,126 @@
+"""The one-launch feed-forward sub-layer (csrc/ffn.hip: asr_ffn_fwd / asr_ffn_bwd; module.py:48-53 + encoder.py:77) against a
+torch-fp32 CPU evaluation of the reference's op sequence on the same bf16-rounded operands and the same dropout mask
+(oracle.dropout_mask), at shapes with ragged lengths and a partial last block; then the module in train mode against the separate
+launches it replaces and the whole encoder layer's gradients."""
+import numpy as np
+import pytest
+import torch
+
+import asr_amd
+from asr_amd import ops
+from oracle import asr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = lambda t: t.detach().float().cpu().numpy()
+THR = 6554   # p = 0.1
+
+
+def _case(B, L, dff, seed):
+    g = torch.Generator().manual_seed(seed)
+    M = B * L
+    x32 = torch.randn(M, 256, generator=g)
+    w1 = (torch.randn(dff, 256, generator=g) * 0.06).bfloat16()
+    w2 = (torch.randn(256, dff, generator=g) * 0.05).bfloat16()
+    b1 = torch.randn(dff, generator=g) * 0.2
+    b2 = torch.randn(256, generator=g) * 0.2
+    gam = torch.rand(256, generator=g) + 0.5
+    bet = torch.randn(256, generator=g) * 0.3
+    lens = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+    lens[0] = L
+    return x32, w1, b1, w2, b2, gam, bet, lens
+
+
+def _reference(x32, w1, b1, w2, b2, gam, bet, lens, B, L, mask):
+    """fp32 CPU: the reference's ops on the operands the kernel sees (x and the hidden activation rounded to bf16)."""
+    x16 = x32.bfloat16().float()
+    hid = torch.relu(x16 @ w1.float().t() + b1)
+    hid16 = hid.bfloat16().float().requires_grad_(True)
+    o = hid16 @ w2.float().t() + b2
+    s = (o * mask if mask is not None else o) + x32
+    y = torch.nn.functional.layer_norm(s, (256,), gam, bet, 1e-5)
+    keep = (torch.arange(L)[None, :] < lens[:, None]).reshape(-1, 1).float()
+    return hid16, s, y * keep
+
+
+@pytest.mark.parametrize("B,L,dff,drop", [(4, 37, 128, False), (3, 100, 2048, True), (2, 128, 256, True), (1, 5, 64, False), (5, 129, 512, True)])
+def test_ffn_fwd_against_torch_fp32(B, L, dff, drop):
+    x32, w1, b1, w2, b2, gam, bet, lens = _case(B, L, dff, seed=B * 1000 + L)
+    M = B * L
+    mask = torch.from_numpy(O.dropout_mask((B, L, 256), THR, 5, 9)).view(M, 256) if drop else None
+    hid_ref, s_ref, y_ref = _reference(x32, w1, b1, w2, b2, gam, bet, lens, B, L, mask)
+    d = lambda t: t.to(DEV).contiguous()
+    for train in (True, False):
+        hid, bits, s, y32, y16, mean, rstd = ops.ffn_fwd(d(x32.bfloat16()), d(x32), d(w1), d(b1), d(w2), d(b2), d(gam), d(bet), B, L,
+                                                         row_len=d(lens).int(), train=train, drop_x=ops.Dropout(THR, 5, 9) if drop else None)
+        np.testing.assert_allclose(N(y32), y_ref.detach().numpy(), atol=4e-3, rtol=2e-3)     # (fp32 sums of bf16 products in another order)
+        np.testing.assert_allclose(N(y16), N(y32), atol=2e-2, rtol=8e-3)
+        pad = (torch.arange(L)[None, :] >= lens[:, None]).reshape(-1)
+        assert float(N(y32)[pad.numpy()].__abs__().max() if pad.any() else 0.0) == 0.0                   # padded rows: exact zeros (encoder.py:77)
+        if train:
+            np.testing.assert_allclose(N(hid), hid_ref.detach().numpy(), atol=2e-2, rtol=8e-3)        # one bf16 ulp
+            np.testing.assert_allclose(N(s), s_ref.detach().numpy(), atol=4e-3, rtol=2e-3)
+            mu = s_ref.detach().mean(-1)
+            np.testing.assert_allclose(N(mean), mu.numpy(), atol=2e-4)
+            np.testing.assert_allclose(N(rstd), (1.0 / torch.sqrt(s_ref.detach().var(-1, unbiased=False) + 1e-5)).numpy(), rtol=1e-3)
+            if drop:        # the dropped positions are exactly the mask's (the pre-norm sum equals the residual there up to the kept part)
+                np.testing.assert_array_equal(N(s)[(mask == 0).numpy()], x32.numpy()[(mask == 0).numpy()])
+        else:
+            assert hid is None and bits is None and s is None
+
+
+@pytest.mark.parametrize("B,L,dff", [(4, 37, 128), (3, 100, 2048), (1, 5, 64), (5, 129, 512)])
+def test_ffn_bwd_against_torch_autograd(B, L, dff):
+    x32, w1, b1, w2, b2, gam, bet, lens = _case(B, L, dff, seed=7 * B + L)
+    M = B * L
+    g = torch.Generator().manual_seed(L)
+    d = lambda t: t.to(DEV).contiguous()
+    hid, bits, s, y32, y16, mean, rstd = ops.ffn_fwd(d(x32.bfloat16()), d(x32), d(w1), d(b1), d(w2), d(b2), d(gam), d(bet), B, L,
+                                                     row_len=d(lens).int(), train=True)
+    ds32 = torch.randn(M, 256, generator=g) * 0.05
+    ds16 = ds32.bfloat16()
+    # reference: autograd through x -> relu(x W1^T + b1) -> . W2^T with the upstream gradient ds16 (bf16 operands as the kernel sees
+    # them), masked by the KERNEL's own activation pattern (a unit whose pre-activation rounds across zero may differ by one ulp)
+    act = N(hid) > 0
+    dh = (ds16.float() @ w2.float()) * torch.from_numpy(act).float()
+    dh16 = dh.bfloat16().float()
+    dx = dh16 @ w1.float() + ds32
+    d_hid, dxg = ops.ffn_bwd(d(ds16), d(ds32), d(w1), d(w2), bits)
+    np.testing.assert_allclose(N(d_hid), dh16.numpy(), atol=2e-3, rtol=8e-3)
+    assert int(((N(d_hid) != 0) & ~act).sum()) == 0                       # exact zeros where the unit was off
+    np.testing.assert_allclose(N(dxg), dx.numpy(), atol=2e-3, rtol=2e-3)
+
+
+def test_module_with_fused_ffn_equals_separate_launches(monkeypatch):
+    """PositionwiseFeedForward forward + backward tape in train mode (dropout 0.1, ragged lengths): the fused sub-layer against the
+    GEMM + GEMM + LayerNorm forward and the two data-gradient GEMMs it replaces, under the same dropout mask."""
+    B, L = 3, 70
+    torch.manual_seed(3)
+    ffn = asr_amd.PositionwiseFeedForward(256, 512, dropout=0.1).to(DEV).train()
+    x = torch.randn(B, L, 256, device=DEV)
+    lens = torch.tensor([70, 61, 33], device=DEV)
+    dy = torch.randn(B * L, 256, device=DEV) * 0.1
+    from asr_amd import modules as Mo
+
+    def run(rows):
+        monkeypatch.setattr(ops, "FUSED_FFN_MIN_ROWS", rows)
+        asr_amd.manual_seed(11)
+        for p in ffn.parameters():
+            p.grad = torch.zeros_like(p)
+        with asr_amd.precision("bf16"), Mo.record() as tape:
+            xa = Mo._act(x)
+            xa.b16 = ops.cast_bf16(xa.f32)
+            y = ffn._impl(xa, ops.as_i32(lens, x.device))
+            y.grad = dy.clone()
+            tape.backward()
+        torch.cuda.synchronize()
+        return N(y.f32), N(xa.grad), {n: N(p.grad) for n, p in ffn.named_parameters()}
+
+    y0, dx0, g0 = run(1 << 30)       # separate launches
+    y1, dx1, g1 = run(1)             # fused
+    np.testing.assert_allclose(y1, y0, atol=3e-2, rtol=2e-2)
+    np.testing.assert_array_equal(y1[70 + 61:70 + 70], 0.0)       # utterance 1's padded rows
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))
+    assert rel(dx1, dx0) < 2e-2
+    for n in g0:
+        assert rel(g1[n], g0[n]) < 3e-2, n
