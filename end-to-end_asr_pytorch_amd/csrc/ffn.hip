@@ -38,6 +38,20 @@ __device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1)
 // 32 units of a chunk are numbered e = 16 t + j (t: 32-row tile, j: accumulator register)
 __device__ __forceinline__ int64_t bits_index(int chunk, int h, int Mp, int m) { return ((int64_t)(chunk * 2 + h)) * Mp + m; }
 
+// sum over the 64 lanes, the same value in every lane: four DPP adds inside the 16-lane rows, then the four row sums by v_readlane
+template <int CTRL> __device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_perm<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_perm<0x141>(v);     // row_half_mirror
+    v += dpp_perm<0x140>(v);     // row_mirror
+    const int iv = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
+}
+
 struct FfnFwdArgs {
     const bf16_t* x16;
     const float* x32;
@@ -58,10 +72,11 @@ struct FfnFwdArgs {
     int M, L, dff, Mp;
     float eps;
     asr_dropout_t drop;
-    int dbg;      // ASR_AMD_FFN_DBG (timing breakdowns only): 1 = no epilogue, 2 = no LDS-DMA in the loop
+    int dbg;      // ASR_AMD_FFN_DBG (timing breakdowns only): 1 = no epilogue
+    unsigned long long* stamps;      // diagnostic build (-DFFN_STAMP) only: per wave 4 cycle sums (first product, second product, wait + barrier, total)
 };
 
-template <bool TRAIN>
+template <bool TRAIN, bool DROP>
 __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     unsigned char* const w1s = smem;
@@ -69,6 +84,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     float* const b1s = reinterpret_cast<float*>(smem + 2 * W1BUF + 2 * W2BUF + HST_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FFN_STAMP
+    unsigned long long ts_entry;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_entry) :: "memory");
+#endif
     unsigned char* const hst = smem + 2 * W1BUF + 2 * W2BUF + wave * 4096;
     const int r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * FBM + wave * 32 + r;
@@ -94,17 +113,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             off2[k] = (unsigned)(d * dff * 2 + c * 16);
         }
     }
-    auto stage_w1 = [&](int buf, int chunk) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(w1s + buf * W1BUF + (wave * 8 + k) * 1024), 16, off1[k],
-                                                     chunk * (FHC * FD * 2), 0, 0);
+    // one 1-KiB piece (j = 0..7 of this wave's 8) of a chunk image; the loop deals the 16 pieces of an iteration over its first 16 steps,
+    // one behind each MFMA (an LDS-DMA instruction holds the wave's issue for tens of cycles: bunched in front of the MFMAs all of
+    // that time is exposed at one wave per SIMD)
+    auto dma_w1 = [&](int buf, int chunk, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(w1s + buf * W1BUF + (wave * 8 + j) * 1024), 16, off1[j], chunk * (FHC * FD * 2), 0, 0);
     };
-    auto stage_w2 = [&](int buf, int chunk) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_void*)(w2s + buf * W2BUF + (wave * 8 + k) * 1024), 16, off2[k],
-                                                     chunk * (FHC * 2), 0, 0);
+    auto dma_w2 = [&](int buf, int chunk, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_void*)(w2s + buf * W2BUF + (wave * 8 + j) * 1024), 16, off2[j], chunk * (FHC * 2), 0, 0);
     };
 
     // ---- fragment read addresses -----------------------------------------------------------------------------------------------
@@ -124,7 +140,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     }
     for (int i = tid * 4; i < dff; i += 1024) *reinterpret_cast<f32x4*>(b1s + i) = *reinterpret_cast<const f32x4*>(a.b1 + i);
 
-    stage_w1(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_w1(0, 0, j);
     f32x16 Y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -153,6 +170,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     //   steps  0..31  first product of chunk i:     MFMA k, then the LDS read of the fragment MFMA k + 8 will take (ring of 16)
     //   steps 32..63  second product of chunk i-1:  MFMA, LDS read 8 ahead, and one slice of chunk i's ReLU / pack / mask work
     bf16x8 A[16];
+    f32x4 res[32];      // the epilogue's residual rows, requested inside the LAST body
+    const int m0 = blockIdx.x * FBM + wave * 32;
     typedef __attribute__((ext_vector_type(2))) short s16x2_t;
     auto frag1 = [&](const unsigned char* w1, int k) {      // first product, MFMA k: k-step k >> 1, row tile k & 1
         const int ks = k >> 1, t = k & 1;
@@ -196,11 +215,14 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
         asm volatile("" ::: "memory");                                                                             \
     } while (0)
 
-    // one iteration: FIRST = no second product yet (chunk 0), LAST = no first product any more (after the last chunk)
+    // one iteration: FIRST = no second product yet (chunk 0), LAST = no first product any more (after the last chunk).
+    // VMEM order inside an iteration: 16 LDS-DMA pieces (steps 0..15: W1 of chunk i + 1, W2 of chunk i), THEN the stores (4 full-line
+    // stores of chunk i - 1's H tile, the mask word): the wait at the end leaves exactly the stores in flight.
     auto body = [&](int i, auto first_c, auto last_c) {
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const unsigned char* w1 = w1s + (i & 1) * W1BUF;
         const unsigned char* w2 = w2s + ((i - 1) & 1) * W2BUF;
+        const int nxt = i + 1 < NC ? i + 1 : NC - 1;       // (the last chunk's iteration re-reads its own W1 into the free buffer: no branch)
         f32x16 S[2];
         u32x4 Hn[4], Hout[4];
         uint32_t word = 0;
@@ -214,10 +236,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
                 S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
                 if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
                 else if (!FIRST) A[(k + 8) & 15] = frag2(w2, k + 8 - 32);
-                if (TRAIN && !FIRST) {      // chunk i - 1's tile: four row-wise reads, four full-line stores
-                    if (k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
-                    if (k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), 0);
+                if (k < 16) {
+                    if (k & 1) dma_w2(i & 1, i, k >> 1);
+                    else dma_w1((i + 1) & 1, nxt, k >> 1);
                 }
+                if (TRAIN && !FIRST && k >= 24 && k < 28) Hout[k - 24] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 24) * 1024);
                 FFN_STEP();
             }
         } else {
@@ -234,11 +257,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             if constexpr (!LAST) {
                 if ((k & 1) == 0) relu_pair(S, Hn, k >> 1);
                 else if (TRAIN) mask_pair(Hn, word, k >> 1);
+                if (TRAIN && !FIRST && (k & 7) == 0)       // chunk i - 1's tile (read back row-wise at steps 24..27): four full-line stores
+                    __builtin_amdgcn_raw_buffer_store_b128(Hout[k >> 3], rsh, hoff[k >> 3], (i - 1) * (FHC * 2), 0);
                 if (TRAIN && (k & 7) == 7)
                     *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 3) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 3];
-            } else if (TRAIN) {
-                if (k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
-                if (k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), 0);
+            } else {
+                if (TRAIN && k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
+                if (TRAIN && k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), 0);
+                const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;       // the epilogue's residual row k (see below)
+                res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
             }
             FFN_STEP();
         }
@@ -248,23 +275,56 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             for (int sg = 0; sg < 4; ++sg) Hf[sg] = Hn[sg];
         }
     };
-    {
-        if (NC > 1) stage_w1(1, 1);
-        stage_w2(0, 0);
-        asm volatile("" ::: "memory");
-        body(0, std::true_type{}, std::false_type{});
-        FFN_WAIT_STAGE(1);
-    }
+    body(0, std::true_type{}, std::false_type{});
+    FFN_WAIT_STAGE(1);
+#ifdef FFN_STAMP
+    unsigned long long t_body = 0, t_wait = 0, t0, t1, t2;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    const unsigned long long t_begin = t0;
+#endif
     for (int i = 1; i < NC; ++i) {
-        if (!(a.dbg & 2)) {
-            if (i + 1 < NC) stage_w1((i + 1) & 1, i + 1);
-            stage_w2(i & 1, i);
-        }
-        asm volatile("" ::: "memory");
         body(i, std::false_type{}, std::false_type{});
+#ifdef FFN_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         FFN_WAIT_STAGE(5);
+#ifdef FFN_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        t_body += t1 - t0; t_wait += t2 - t1; t0 = t2;
+#endif
+    }
+#ifdef FFN_STAMP
+    const unsigned long long ts_loop_end = t0;
+#endif
+    // The epilogue's residual rows (row layout: lane = 4 columns of a token row, 32 rows per wave) are requested from inside the LAST
+    // body, one per MFMA step - a half-iteration + barrier ahead of their use, all 32 in flight at once.  (Fetched batch by batch
+    // inside the epilogue every batch paid an HBM round trip queued behind the previous batch's stores.)  The row-mask bits too:
+    // a load of row_len[b] per row in the epilogue was a dependent global load + wait per row, ~1000 cycles each.
+    uint32_t keepmask = 0xffffffffu;
+    const int m0c = m0 < a.M ? m0 : a.M - 1;
+    const int b_first = m0c / a.L, t_first = m0c - b_first * a.L;      // (one division; rows advance from here)
+    if (a.row_len) {
+        keepmask = 0;
+        int bb = b_first, tt = t_first, len = a.row_len[bb];
+        for (int tr = 0; tr < 32; ++tr) {
+            keepmask |= (tt < len ? 1u : 0u) << tr;
+            if (++tt == a.L) {
+                tt = 0;
+                if (m0 + tr + 1 < a.M) len = a.row_len[++bb];
+            }
+        }
     }
     body(NC, std::false_type{}, std::true_type{});
+#ifdef FFN_STAMP
+    unsigned long long ts_last;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #undef FFN_WAIT_STAGE
 #undef FFN_STEP
 
@@ -277,65 +337,95 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
         if (acc == 123.456f) a.y32[0] = acc;
         return;
     }
-    // ---- epilogue: v = dropout(Y + b2) + x; LayerNorm over the row that lanes (r, 0) and (r, 1) hold together ---------------------------
-    const asr_dropout_t drop = drop_resolve(a.drop);
-    const int b = mc / a.L, tpos = mc - b * a.L;
-    const uint32_t sub = drop.thr16 ? drop_subkey(drop, (uint32_t)b) : 0u;
-    const float sc = drop_scale(drop);
-    const float* xres = a.x32 + (int64_t)mc * FD + 4 * h;
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = 32 * t + 8 * g;          // + 4 h
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b2 + d0 + 4 * h);
-            f32x4 v = {Y[t][4 * g] + bias[0], Y[t][4 * g + 1] + bias[1], Y[t][4 * g + 2] + bias[2], Y[t][4 * g + 3] + bias[3]};
-            if (drop.thr16) v = drop4(drop, sub, (uint32_t)tpos, FD >> 1, (uint32_t)(d0 + 4 * h), v, sc);
-            v += *reinterpret_cast<const f32x4*>(xres + d0);
-            if (a.s_out && valid) *reinterpret_cast<f32x4*>(a.s_out + (int64_t)m * FD + d0 + 4 * h) = v;
-            sum += (v[0] + v[1]) + (v[2] + v[3]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Y[t][4 * g + j] = v[j];
-        }
-    }
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.f / FD);
-    float q = 0.f;
+    // ---- epilogue: v = dropout(Y + b2) + x, LayerNorm, row mask --------------------------------------------------------------------
+    // A lane holds 128 values of ITS token (stores from here would touch 32 rows per instruction, 32 bytes each - measured 21 us of
+    // the eval launch, 40 us with the training outputs).  The weight images are free now: each wave parks its Y^T tile in 32 KiB of
+    // them ([32 tokens][256] f32, 16-byte piece p of token r in slot p ^ (r & 7): conflict-free both ways) and reads it back one
+    // token row per instruction - the residual load and the three stores are then whole 1-KiB / 512-byte rows, and the row
+    // arithmetic is add_layernorm_fwd_kernel's (lane = 4 columns of the row).
+    __syncthreads();
+    unsigned char* const tile = smem + wave * 32768;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float dlt = Y[t][j] - mean;
-            q += dlt * dlt;
-        }
-    q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.f / FD) + a.eps);
-    if (valid && h == 0) {
-        if (a.mean) a.mean[m] = mean;
-        if (a.rstd) a.rstd[m] = rstd;
-    }
-    const bool keep = a.row_len ? (tpos < a.row_len[b]) : true;
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(tile + r * 1024 + (((8 * t + 2 * g + h) ^ (r & 7)) << 4)) =
+                f32x4{Y[t][4 * g], Y[t][4 * g + 1], Y[t][4 * g + 2], Y[t][4 * g + 3]};
+    const asr_dropout_t drop = drop_resolve(a.drop);
+    const float sc = drop_scale(drop);
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * lane);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * lane), bt = *reinterpret_cast<const f32x4*>(a.beta + 4 * lane);
+    const auto rss = __builtin_amdgcn_make_buffer_rsrc(a.s_out, 0, a.s_out ? (int)((int64_t)a.M * FD * 4) : 0, 0x00020000);
+    const auto rsy = __builtin_amdgcn_make_buffer_rsrc(a.y32, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(a.y16, 0, a.y16 ? (int)((int64_t)a.M * FD * 2) : 0, 0x00020000);
+    const auto rsm = __builtin_amdgcn_make_buffer_rsrc(a.mean, 0, a.mean ? a.M * 4 : 0, 0x00020000);
+    const auto rsr = __builtin_amdgcn_make_buffer_rsrc(a.rstd, 0, a.rstd ? a.M * 4 : 0, 0x00020000);
+    int bb = b_first, tt = t_first;              // (utterance, position) of the row being hashed: uniform, advanced row by row
+    uint32_t sub = DROP ? drop_subkey(drop, (uint32_t)bb) : 0u;
+    float mean_l = 0.f, rstd_l = 0.f;            // lane tr keeps row tr's statistics: one 128-byte store each at the end
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int tr0 = 0; tr0 < 32; tr0 += 8) {
+        f32x4 v[8];
+        float part[8];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = 32 * t + 8 * g + 4 * h;
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + d0), bt = *reinterpret_cast<const f32x4*>(a.beta + d0);
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = keep ? (Y[t][4 * g + j] - mean) * rstd * gm[j] + bt[j] : 0.f;
-            if (valid) {
-                *reinterpret_cast<f32x4*>(a.y32 + (int64_t)m * FD + d0) = o;
-                if (a.y16) {
-                    const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-                    *reinterpret_cast<bf16x4*>(a.y16 + (int64_t)m * FD + d0) = ob;
+        for (int j = 0; j < 8; ++j) {      // eight rows at a time: their reductions interleave
+            const int tr = tr0 + j;
+            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (j & 7)) << 4));
+            f32x4 w = y + b2v;
+            if (DROP) {
+                w = drop4(drop, sub, (uint32_t)tt, FD >> 1, (uint32_t)(4 * lane), w, sc);
+                if (++tt == a.L) {
+                    tt = 0;
+                    sub = drop_subkey(drop, (uint32_t)++bb);
                 }
             }
+            v[j] = w + res[tr];
+            part[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mean[j] = wave_sum_dpp(part[j]) * (1.f / FD);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 dl = v[j] - mean[j];
+            part[j] = (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(wave_sum_dpp(part[j]) * (1.f / FD) + a.eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tr = tr0 + j, row = m0 + tr;
+            const bool rv = row < a.M;
+            const unsigned o16 = rv ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u;
+            if (TRAIN) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rss, o16, 0, 0);
+                mean_l = lane == tr ? mean[j] : mean_l;
+                rstd_l = lane == tr ? rstd[j] : rstd_l;
+            }
+            f32x4 o = (v[j] - mean[j]) * rstd[j] * gm + bt;
+            if (!((keepmask >> tr) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, o16, 0, 0);
+            const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsz, rv ? (unsigned)row * (FD * 2u) + 8u * lane : 0x80000000u, 0, 0);
         }
     }
+    if (TRAIN) {
+        const unsigned o4 = (lane < 32 && m0 + lane < a.M) ? (unsigned)(m0 + lane) * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mean_l), rsm, o4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rstd_l), rsr, o4, 0, 0);
+    }
+#ifdef FFN_STAMP
+    unsigned long long ts_issued, ts_done;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_issued) :: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_done) :: "memory");
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + (blockIdx.x * 4 + wave) * 8;
+        o[0] = t_body; o[1] = t_wait; o[2] = t_begin - ts_entry; o[3] = ts_loop_end - t_begin; o[4] = ts_last - ts_loop_end;
+        o[5] = ts_issued - ts_last; o[6] = ts_done - ts_issued; o[7] = ts_entry;
+    }
+#endif
 }
-
 
 // ---- data gradient: dH^T = (W2c^T . ds^T) * mask, dX^T += W1c^T . dH^T -----------------------------------------------------------
 // Same decomposition, same (lane, register) <-> (token, hidden unit) map as the forward, so a lane reads back exactly the mask words it
@@ -355,6 +445,28 @@ struct FfnBwdArgs {
     float* dx;
     int M, dff, Mp;
 };
+
+// LDS-DMA and the mask-word load as inline asm, counted by hand.  The compiler orders every LDS read it cannot disambiguate behind
+// ALL pending LDS-DMA: with the builtin form each ds_read_b64_tr_b16 of the loop got an s_waitcnt vmcnt(0) in front (the fused
+// backward ran 200 us instead of 90).  An asm statement's memory operations are invisible to that pass; the waits are the kernel's
+// own counted ones (vmcnt retires in order: DMA first, then the stores, exactly as in the forward).
+__device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {      // raw buffer descriptor: stride 0, `bytes` records
+    const uint64_t b = (uint64_t)base;
+    return u32x4{(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)p);
+}
+__device__ __forceinline__ void dma16_asm(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
+}
+__device__ __forceinline__ uint32_t load32_asm(u32x4 rsrc, unsigned voff, unsigned soff) {
+    uint32_t v;
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p, int second_off) {
@@ -377,8 +489,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
     const int mc = valid ? m : a.M - 1;
     const int dff = a.dff, NC = dff / FHC;
 
-    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w1), 0, dff * FD * 2, 0x00020000);
-    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w2), 0, dff * FD * 2, 0x00020000);
+    const u32x4 rs1 = rsrc_words(a.w1, (unsigned)(dff * FD * 2)), rs2 = rsrc_words(a.w2, (unsigned)(dff * FD * 2));
     unsigned off1[8], off2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -392,17 +503,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
             off2[k] = (unsigned)(d * dff * 2 + ((pc ^ (((d >> 1) & 1) << 2)) << 4));
         }
     }
-    auto stage_w1 = [&](int buf, int chunk) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(w1s + buf * W1BUF + (wave * 8 + k) * 1024), 16, off1[k],
-                                                     chunk * (FHC * FD * 2), 0, 0);
+    auto dma_w1 = [&](int buf, int chunk, int j) {      // one 1-KiB piece of a chunk image (see the forward)
+        dma16_asm(rs1, off1[j], chunk * (FHC * FD * 2), lds_addr_of(w1s + buf * W1BUF + (wave * 8 + j) * 1024));
     };
-    auto stage_w2 = [&](int buf, int chunk) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_void*)(w2s + buf * W2BUF + (wave * 8 + k) * 1024), 16, off2[k],
-                                                     chunk * (FHC * 2), 0, 0);
+    auto dma_w2 = [&](int buf, int chunk, int j) {
+        dma16_asm(rs2, off2[j], chunk * (FHC * 2), lds_addr_of(w2s + buf * W2BUF + (wave * 8 + j) * 1024));
     };
 
     // transposed-read addresses: within a 16-lane group, lane 4q + p supplies block row q, column quad p (first product: quad p')
@@ -423,7 +528,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) db[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
     }
-    stage_w2(0, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_w2(0, 0, j);
     f32x16 Y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -434,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
 
     u32x4 Hf[4];
     const auto rsh = __builtin_amdgcn_make_buffer_rsrc(a.dhid, 0, (int)((int64_t)a.M * dff * 2), 0x00020000);
-    const auto rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.bits), 0, (int)((int64_t)NC * 2 * a.Mp * 4), 0x00020000);
+    const u32x4 rsb = rsrc_words(a.bits, (unsigned)((int64_t)NC * 2 * a.Mp * 4));
     const unsigned boff = ((unsigned)h * a.Mp + mc) * 4u;
     const unsigned hwr = (unsigned)(r * 128), hrd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));      // as in the forward
     unsigned hoff[4];
@@ -445,6 +551,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
     }
 
     bf16x8 A[16];
+    f32x4 res[32];
+    const int m0 = blockIdx.x * FBM + wave * 32;
     auto frag1 = [&](const unsigned char* w2, int k) {      // first product, MFMA k: k-step k >> 1 (16 rows of the image), row tile k & 1
         return tr_pair(w2 + a1[k & 1] + (k >> 1) * 2048, 512);
     };
@@ -467,10 +575,12 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
         asm volatile("" ::: "memory");                                                \
     } while (0)
 
-    auto body = [&](int i, uint32_t word, auto first_c, auto last_c) {
+    auto body = [&](int i, uint32_t word_in, auto first_c, auto last_c) {
+        uint32_t word = word_in;
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const unsigned char* w2 = w2s + (i & 1) * W2BUF;
         const unsigned char* w1 = w1s + ((i - 1) & 1) * W1BUF;
+        const int nxt = i + 1 < NC ? i + 1 : NC - 1;
         f32x16 S[2];
         u32x4 Hn[4], Hout[4];
         if constexpr (!LAST) {
@@ -486,12 +596,15 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
                 S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], db[k >> 1], S[k & 1], 0, 0, 0);
                 if (k + 8 < 32) A[(k + 8) & 15] = frag1(w2, k + 8);
                 else if (!FIRST) A[(k + 8) & 15] = frag2(w1, k + 8 - 32);
-                if (!FIRST) {
-                    if (k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
-                    if (k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), 0);
+                if (k < 16) {      // this iteration's 16 LDS-DMA pieces, one per step: W2 of chunk i + 1, W1 of chunk i
+                    if (k & 1) dma_w1(i & 1, i, k >> 1);
+                    else dma_w2((i + 1) & 1, nxt, k >> 1);
                 }
+                if (!FIRST && k >= 24 && k < 28) Hout[k - 24] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 24) * 1024);
                 FFN_STEP();
             }
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(word));      // the mask word: older than this iteration's 16 DMA pieces
+            FFN_STEP();
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) A[k] = frag2(w1, k);
@@ -505,10 +618,14 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
             }
             if constexpr (!LAST) {
                 if ((k & 1) == 0) mask_pair(S, Hn, word, k >> 1);
+                if (!FIRST && (k & 7) == 0) __builtin_amdgcn_raw_buffer_store_b128(Hout[k >> 3], rsh, hoff[k >> 3], (i - 1) * (FHC * 2), 0);
                 if ((k & 7) == 7) *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 3) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 3];
             } else {
                 if (k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
                 if (k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), 0);
+                // the epilogue's ds32 row k (row layout: lane = 4 columns of a token row), requested a half-iteration ahead of its use
+                const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;
+                res[k] = *reinterpret_cast<const f32x4*>(a.ds32 + (int64_t)rowc * FD + 4 * lane);
             }
             FFN_STEP();
         }
@@ -518,20 +635,13 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
         }
     };
     {
-        const uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(rsb, boff, 0, 0);
-        if (NC > 1) stage_w2(1, 1);
-        stage_w1(0, 0);
-        asm volatile("" ::: "memory");
+        const uint32_t word = load32_asm(rsb, boff, 0);
         body(0, word, std::true_type{}, std::false_type{});
         FFN_WAIT_STAGE(0);
     }
     for (int i = 1; i < NC; ++i) {
-        // this chunk's mask word: issued BEFORE the LDS-DMA so that its wait (at the first use, half an iteration later) is a
-        // counted one that leaves the DMA in flight
-        const uint32_t word = __builtin_amdgcn_raw_buffer_load_b32(rsb, boff, i * (2 * a.Mp * 4), 0);
-        if (i + 1 < NC) stage_w2((i + 1) & 1, i + 1);
-        stage_w1(i & 1, i);
-        asm volatile("" ::: "memory");
+        // this chunk's mask word: issued BEFORE the iteration's LDS-DMA, waited for (vmcnt(16)) where the second product begins
+        const uint32_t word = load32_asm(rsb, boff, i * (2 * a.Mp * 4));
         body(i, word, std::false_type{}, std::false_type{});
         FFN_WAIT_STAGE(4);
     }
@@ -539,23 +649,30 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
 #undef FFN_WAIT_STAGE
 #undef FFN_STEP
 
-    // ---- epilogue: dx = dX + ds32 ------------------------------------------------------------------------------------------------
-    const float* res = a.ds32 + (int64_t)mc * FD + 4 * h;
+    // ---- epilogue: dx = dX + ds32, through the wave's 32-KiB LDS tile (see the forward) so that loads and stores are whole rows --------
+    __syncthreads();
+    unsigned char* const tile = smem + wave * 32768;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(tile + r * 1024 + (((8 * t + 2 * g + h) ^ (r & 7)) << 4)) =
+                f32x4{Y[t][4 * g], Y[t][4 * g + 1], Y[t][4 * g + 2], Y[t][4 * g + 3]};
     const auto rsx = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
-    const unsigned xoff = valid ? (unsigned)m * (FD * 4u) + 16u * h : 0x80000000u;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d0 = 32 * t + 8 * g;
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(res + d0);
-            const f32x4 v = {Y[t][4 * g] + rv[0], Y[t][4 * g + 1] + rv[1], Y[t][4 * g + 2] + rv[2], Y[t][4 * g + 3] + rv[3]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsx, xoff + d0 * 4, 0, 0);
-        }
+    for (int tr = 0; tr < 32; ++tr) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (tr & 7)) << 4));
+        const f32x4 v = y + res[tr];
+        const int row = m0 + tr;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsx, row < a.M ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u, 0, 0);
     }
 }
 
 }  // namespace
+
+static unsigned long long* g_ffn_stamps = nullptr;
+// diagnostic hook (not part of include/asr_hip.h; meaningful only in a -DFFN_STAMP build): per-wave cycle sums of the forward's loop
+extern "C" void asr_ffn_debug_stamps(void* buf) { g_ffn_stamps = (unsigned long long*)buf; }
 
 extern "C" int64_t asr_ffn_bits_words(int M, int d_ff) { return (int64_t)(d_ff / FHC) * 2 * ((M + FBM - 1) / FBM * FBM); }
 
@@ -569,18 +686,20 @@ extern "C" int asr_ffn_fwd(void* stream, const void* x16, const float* x32, cons
     ASR_REQUIRE(M64 > 0 && M64 * d_ff * 2 < (1ll << 31), -1, "asr_ffn_fwd: B * L out of range");
     ASR_REQUIRE(x16 && x32 && w1 && b1 && w2 && b2 && gamma && beta && y32, -1, "asr_ffn_fwd: null argument");
     ASR_REQUIRE((hid_out == nullptr) == (bits_out == nullptr), -1, "asr_ffn_fwd: hid_out and bits_out come together (training) or not at all");
+    ASR_REQUIRE(hid_out || (!s_out && !mean_out && !rstd_out), -1, "asr_ffn_fwd: s_out / mean_out / rstd_out are training outputs (pass hid_out and bits_out too)");
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(x32, 16) && asr_aligned(w1, 16) && asr_aligned(w2, 16) && asr_aligned(y32, 16) &&
                     asr_aligned(hid_out, 16) && asr_aligned(s_out, 16) && asr_aligned(y16, 8) && asr_aligned(b1, 16) && asr_aligned(b2, 16) &&
                     asr_aligned(gamma, 16) && asr_aligned(beta, 16), -1, "asr_ffn_fwd: 16-byte aligned buffers required");
     const int M = (int)M64;
     FfnFwdArgs a{(const bf16_t*)x16, x32, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gamma, beta, row_len, (bf16_t*)hid_out,
                  (uint32_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x,
-                 getenv("ASR_AMD_FFN_DBG") ? atoi(getenv("ASR_AMD_FFN_DBG")) : 0};
+                 getenv("ASR_AMD_FFN_DBG") ? atoi(getenv("ASR_AMD_FFN_DBG")) : 0, g_ffn_stamps};
     const dim3 grid((M + FBM - 1) / FBM), block(256);
-    if (hid_out)
-        hipLaunchKernelGGL(ffn_fwd_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(ffn_fwd_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+    const bool dr = drop_x.thr16 != 0;
+    if (hid_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (hid_out) hipLaunchKernelGGL((ffn_fwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
+    else if (dr) hipLaunchKernelGGL((ffn_fwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((ffn_fwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_ffn_fwd");
     return 0;
 }
