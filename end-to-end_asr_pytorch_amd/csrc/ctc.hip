@@ -859,8 +859,21 @@ static inline void ctc_chunking(int L, int n_chunks, int& W, int& nc) {
     nc = (steps + W - 1) / W;
 }
 
+// The fused form's recursion workgroups wait for pass workgroups of the same grid: they must never be able to occupy every slot
+// the pass workgroups could run in.  Two of a CU's eight slots at most: B <= 2 x (CUs of the CURRENT device - a partition or a
+// CU-masked run has fewer than 256).
+static inline int ctc_fused_max_batch() {
+    static int cached[64] = {0};      // per device ordinal (the attribute query is a driver call: once per device)
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;      // no device: the two-launch form
+    if (dev >= 0 && dev < 64 && cached[dev] > 0) return 2 * cached[dev];
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return 0;
+    if (dev >= 0 && dev < 64) cached[dev] = n_cu;
+    return 2 * n_cu;
+}
+
 extern "C" int64_t asr_ctc_counter_words(int B, int L, int n_chunks) {
-    if (n_chunks <= 1 || L < 64 || B <= 0 || B > 512) return 0;
+    if (n_chunks <= 1 || L < 64 || B <= 0 || B > ctc_fused_max_batch()) return 0;
     int W, nc;
     ctc_chunking(L, n_chunks, W, nc);
     return (int64_t)B * 2 * nc;
@@ -875,9 +888,9 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd: workspaces must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // The fused form's recursion workgroups (one per utterance, the grid's first blocks) WAIT for the pass workgroups behind them: they
-    // must never be able to fill the chip on their own.  Up to 512 utterances (2 of the 8 slots per CU on 256 CUs) they cannot; larger
-    // batches take the two-launch form.
-    if (n_chunks <= 1 || L < 64 || ctc_np(Umax) != 1 || B > 512) {   // two launches: one pass over the logits, then the two half-length chains
+    // must never be able to fill the chip on their own.  Up to 2 utterances per CU of the current device (2 of the 8 slots) they cannot;
+    // larger batches take the two-launch form.
+    if (n_chunks <= 1 || L < 64 || ctc_np(Umax) != 1 || B > ctc_fused_max_batch()) {   // two launches: one pass over the logits, then the two half-length chains
                                                           // (the fused form is written for one state pair per lane: U + 1 <= 64)
         hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
                            lp_ext);
@@ -911,11 +924,7 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     }
     // B recursion workgroups + persistent pass workgroups filling every remaining slot of the chip (7 or 8 per CU by the kernel's
     // LDS / register budget; more than fit would only queue)
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int n_cu = ctc_fused_max_batch() / 2;      // (of the current device)
     const int groups = nc * B * 2 * (W / rpb);
     int npass = n_cu * (ringp <= 8 ? 8 : 6) - B;      // (the 10-pair ring's 23 KiB round up past a seventh of the CU's LDS)
     if (npass > groups) npass = groups;

@@ -671,8 +671,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
 }  // namespace
 
 static unsigned long long* g_ffn_stamps = nullptr;
-// diagnostic hook (not part of include/asr_hip.h; meaningful only in a -DFFN_STAMP build): per-wave cycle sums of the forward's loop
+#ifdef FFN_STAMP
+// diagnostic hook of the -DFFN_STAMP build (tools/stamp_ffn.py; not part of the product library or of include/asr_hip.h): where the
+// forward's per-wave cycle stamps go
 extern "C" void asr_ffn_debug_stamps(void* buf) { g_ffn_stamps = (unsigned long long*)buf; }
+#endif
 
 extern "C" int64_t asr_ffn_bits_words(int M, int d_ff) { return (int64_t)(d_ff / FHC) * 2 * ((M + FBM - 1) / FBM * FBM); }
 

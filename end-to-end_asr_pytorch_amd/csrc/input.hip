@@ -52,6 +52,17 @@ __global__ __launch_bounds__(256) void spec_aug_stats_kernel(const float* __rest
 // r: uniform [0,1) draws in the reference's order - for every mask loop iteration k (first the frequency masks, then the time
 // masks) rand(B) for the width and rand(B) for the start: r[(2k + which) * B + b].
 //   width = (long)(max_width * r_w)            start = (long)((float)(extent - width) * r_s)      (utils.py:179-182,187-190)
+// x[b, s:s+w] as Python slices it: a negative bound counts from the END of the padded axis (an utterance shorter than the drawn
+// time-mask width gives start = (long)((len - w) * r) < 0 - utils.py:189-192 then writes a run ending at the padded T, or
+// nothing when the end wraps differently), bounds past the axis are clamped
+__device__ __forceinline__ bool in_py_slice(int64_t i, int64_t s, int64_t w, int64_t n) {
+    int64_t lo = s, hi = s + w;
+    if (lo < 0) lo = lo + n < 0 ? 0 : lo + n;
+    if (hi < 0) hi = hi + n < 0 ? 0 : hi + n;
+    if (hi > n) hi = n;
+    return i >= lo && i < hi;
+}
+
 __global__ __launch_bounds__(256) void spec_aug_apply_kernel(float* __restrict__ x, const int32_t* __restrict__ len, int B, int T, int V,
                                                              const float* __restrict__ fmean, const float* __restrict__ tsum,
                                                              const float* __restrict__ r, int n_freq, int freq_w, int n_time, int time_w) {
@@ -65,12 +76,12 @@ __global__ __launch_bounds__(256) void spec_aug_apply_kernel(float* __restrict__
         for (int k = 0; k < n_time; ++k) {
             const int64_t ts = (int64_t)((float)time_w * r[(int64_t)(2 * (n_freq + k)) * B + b]);
             const int64_t t0 = (int64_t)(((float)(len[b] - ts)) * r[(int64_t)(2 * (n_freq + k) + 1) * B + b]);
-            in_time = in_time || (t >= t0 && t < t0 + ts);
+            in_time = in_time || in_py_slice(t, t0, ts, T);
         }
         for (int k = 0; k < n_freq; ++k) {
             const int64_t fs = (int64_t)((float)freq_w * r[(int64_t)(2 * k) * B + b]);
             const int64_t f0 = (int64_t)(((float)(V - fs)) * r[(int64_t)(2 * k + 1) * B + b]);
-            in_freq = in_freq || (v >= f0 && v < f0 + fs);
+            in_freq = in_freq || in_py_slice(v, f0, fs, V);
         }
         // time masks are written after frequency masks (utils.py:176-192): a time mask wins where both cover an element
         if (in_time) x[i] = tsum[(int64_t)b * V + v] / lb;

@@ -465,8 +465,10 @@ class MultiheadAttention(_Cached):
         written into k_cache / v_cache [B, h, Tmax, 64] at position t, then the query attends to positions < k_len (= t + 1).
         bf16, d_model = 256, position on the device: the whole sub-layer is ONE launch (asr_decode_self_attn)."""
         h, B = self.n_head, x.B
-        if (_DECODE_FUSED and _PRECISION == "bf16" and torch.is_tensor(t) and x.L == 1 and k_cache.dtype == torch.bfloat16 and
-                self.w_qs.weight.shape[0] == h * 64 and ops.decode_blocks_ok(x, heads=h)):
+        # (eval semantics only: the one-launch form has no dropout, like _decode_cross_ffn's; a model left in train() takes the
+        # separate launches, whose _drop sites stay active in every sub-layer alike)
+        if (_DECODE_FUSED and _PRECISION == "bf16" and not self.training and torch.is_tensor(t) and x.L == 1 and
+                k_cache.dtype == torch.bfloat16 and self.w_qs.weight.shape[0] == h * 64 and ops.decode_blocks_ok(x, heads=h)):
             # next_attn: the cross-attention module that follows - its query projection of the rows this launch normalises rides along
             # (next_lq rows per utterance are the queries of one cross attention); the result is handed over in `y.next_q`
             nq = None

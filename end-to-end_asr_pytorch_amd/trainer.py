@@ -180,6 +180,7 @@ class Trainer:
             torch.distributed.broadcast(self.fp.flat, src=src, group=process_group)
             self.fp.sync_shadow()
         self._graph, self._graph_key, self._graph_out, self._graph_failed, self._eager_steps = None, None, None, None, 0
+        self._graph_in = None      # the input buffers the graph was captured against (step_graphed copies each batch into them)
         self._state, self._state_step = None, -1
         self.launch_mode, self.launch_timing = None, None      # step_auto's choice ("eager" | "graph") and what it measured
         self._nw_handle = None
@@ -428,19 +429,29 @@ class Trainer:
 
     def step_graphed(self, feats, lens, targets, noise=None, max_target_len=None):
         """`step` for a loader with fixed shapes: the first two calls run eagerly (allocator pools, code objects, side streams), the
-        third captures the step into a hipGraph, later calls with the same buffers replay it.  Falls back to `step` (and says why in
-        `self._graph_failed`) when the step cannot be captured."""
+        third captures the step into a hipGraph, later calls with inputs of the same shapes replay it (the batch is copied into the
+        buffers the graph was captured against).  Falls back to `step` (and says why in `self._graph_failed`) when the step cannot be
+        captured.  The returned (ctc, ce) tensors are the graph's own outputs: the next replay overwrites them."""
         if not self._graph_ok(feats, max_target_len):
             return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
-        key = (feats.data_ptr(), tuple(feats.shape), lens.data_ptr(), targets.data_ptr(), tuple(targets.shape), max_target_len,
-               self.model.training, self.overlap_ctc, self.wgrad_stream)
+        # The graph holds raw pointers, so it is captured against buffers the trainer owns and every call copies its batch into them
+        # (a loader hands out NEW tensors of the same shape each step: keyed on their addresses every call missed the key and
+        # re-captured the whole step).  The key is what fixes the graph's shape: shapes / dtypes of every input, the longest target.
+        sig = lambda t: None if t is None else (tuple(t.shape), t.dtype)
+        key = (sig(feats), sig(lens), sig(targets), sig(noise), max_target_len, self.model.training, self.overlap_ctc, self.wgrad_stream)
         if self._graph is None or self._graph_key != key:
             if self._eager_steps < 2:
                 self._eager_steps += 1
                 return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
-            self._capture(feats, lens, targets, noise, max_target_len, key)
+            self._graph_in = tuple(None if t is None else t.detach().clone() for t in (feats, lens, targets, noise))
+            self._capture(*self._graph_in, max_target_len, key)
             if self._graph is None:
+                self._graph_in = None
                 return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+            # (the capture pass above does not execute: the replay below is this call's step)
+        for dst, src in zip(self._graph_in, (feats, lens, targets, noise)):
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src, non_blocking=True)
         self._sync_state(feats.device)
         self._graph.replay()
         self.step_num += 1

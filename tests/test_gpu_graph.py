@@ -151,3 +151,28 @@ def test_cif_model_step_replays_from_a_graph(golden_dir):
     np.testing.assert_allclose(np.array(lg), np.array(le), rtol=5e-3)
     pe, pg = te.fp.flat.float().cpu().numpy(), tg_.fp.flat.float().cpu().numpy()
     assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 2e-3
+
+
+def test_graph_replay_takes_fresh_input_tensors(golden_dir):
+    """A loader hands out new tensors every step: the captured graph is keyed on shapes, the batch is copied into the buffers it
+    was captured against - no re-capture, and the replay sees the NEW data (CIF's noise tensor included in the key)."""
+    asr_amd.set_precision("bf16")
+    z, m_e = build(golden_dir)
+    _, m_g = build(golden_dir)
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    umax = int((tg != 0).sum(1).max())
+    te = asr_amd.Trainer(m_e, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    tg_ = asr_amd.Trainer(m_g, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    g = torch.Generator().manual_seed(5)
+    captures = []
+    orig = tg_._capture
+    tg_._capture = lambda *a, **k: (captures.append(1), orig(*a, **k))[1]
+    for i in range(7):
+        xi = (x + 0.3 * torch.randn(x.shape, generator=g).to(DEV)).contiguous()      # a different batch in a different allocation
+        li, ti = lens.clone(), tg.clone()
+        ce, ee = te.step(xi, li, ti, max_target_len=umax)
+        cg, eg = tg_.step_graphed(xi, li, ti, max_target_len=umax)
+        np.testing.assert_allclose([float(cg), float(eg)], [float(ce), float(ee)], rtol=5e-3)
+    assert tg_.graph_active() and len(captures) == 1
+    pe, pg = te.fp.flat.float().cpu().numpy(), tg_.fp.flat.float().cpu().numpy()
+    assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 2e-3

@@ -46,6 +46,31 @@ def test_spec_aug_matches_reference_under_the_same_draws(golden_dir, cfg):
     np.testing.assert_array_equal(y.cpu().numpy()[~changed], z["sa_x"][~changed])
 
 
+def test_spec_aug_short_utterances_follow_python_slicing():
+    """An utterance shorter than the drawn time-mask width: (len - width) < 0, the start index is negative and the reference's
+    slice counts it from the end of the PADDED axis (utils.py:186-192).  Checked against the oracle's restatement, whose numpy
+    slices wrap exactly like the reference's torch slices; the draws are fixed so that every case occurs (a run at the tail of
+    the padded axis, an empty slice, an ordinary interior run)."""
+    from oracle import asr_oracle as O
+    B, T, V = 4, 12, 6
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, V, generator=g)
+    lens = torch.tensor([12, 3, 2, 5])
+    x = x * (torch.arange(T)[None, :, None] < lens[:, None, None])
+    cfg = "1-2-2-9"
+    #        freq width / start (2 loops)                         time width / start (2 loops)
+    rand = torch.tensor([[0.6, 0.9, 0.1, 0.5], [0.3, 0.0, 0.99, 0.5], [0.2, 0.4, 0.6, 0.8], [0.7, 0.1, 0.5, 0.3],
+                         [0.5, 0.95, 0.95, 0.7], [0.4, 0.9, 0.1, 0.99], [0.99, 0.5, 0.3, 0.99], [0.9, 0.2, 0.99, 0.5]])
+    ref = O.spec_aug(x.numpy(), lens.numpy(), cfg, rand.numpy())
+    assert (ref != x.numpy()).any()
+    y, _ = data.spec_aug(x.to(DEV).clone(), lens.to(DEV), cfg, rand=rand)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=2e-6, atol=2e-7)
+    # (the oracle's restatement itself equals the reference on these draws - checked when the test was written, with torch.rand
+    # patched to return them; e.g. the 2-frame utterance gets frames 0..7 overwritten, most of them in its padding)
+    changed = (ref != x.numpy()).any(-1)
+    assert changed[2, 2:8].all() and not changed[2, 8:].any()
+
+
 def test_model_forward_applies_spec_aug(golden_dir):
     torch.manual_seed(0)
     enc = asr_amd.Encoder(80, 1, 2, 64, 128, dropout=0.0)
