@@ -92,6 +92,9 @@ class FlatParams:
                                    % (tuple(p.shape), off))
 
 
+GRAPH_EXEC = os.environ.get("ASR_AMD_GRAPH_EXEC", "1") != "0"      # A/B: 0 = replay the captured step with hipGraphLaunch
+
+
 class GradBuckets:
     """Bucketed gradient all-reduce over one flat buffer, overlapped with the backward.
 
@@ -181,6 +184,7 @@ class Trainer:
             self.fp.sync_shadow()
         self._graph, self._graph_key, self._graph_out, self._graph_failed, self._eager_steps = None, None, None, None, 0
         self._graph_in = None      # the input buffers the graph was captured against (step_graphed copies each batch into them)
+        self._graphx = None        # ops.GraphExec over the captured graph (multi-stream launch of its nodes), when available
         self._state, self._state_step = None, -1
         self.launch_mode, self.launch_timing = None, None      # step_auto's choice ("eager" | "graph") and what it measured
         self._nw_handle = None
@@ -453,7 +457,10 @@ class Trainer:
             if dst is not None and dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self._sync_state(feats.device)
-        self._graph.replay()
+        if self._graphx is not None:
+            self._graphx.launch()
+        else:
+            self._graph.replay()
         self.step_num += 1
         self._state_step = self.step_num
         modules.bump_param_epoch()
@@ -498,16 +505,25 @@ class Trainer:
         self.launch_mode = "graph" if t_graph < t_eager else "eager"
         self.launch_timing = {"eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3)}
         if self.launch_mode == "eager":
+            self._graphx = None
             self._graph = None                           # frees the graph's private pool
         return out
 
     def _capture(self, feats, lens, targets, noise, max_target_len, key):
         dev = feats.device
+        self._graphx = None
         self._graph = None
         self._sync_state(dev)
         modules.bump_param_epoch()             # derived weights are rebuilt inside the capture (and so at every replay)
         torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
+        # keep_graph: the captured hipGraph stays readable - its nodes are what the multi-stream executor launches (ops.GraphExec);
+        # a stack without that option (or a graph the executor does not take) replays through hipGraphLaunch
+        use_x = GRAPH_EXEC and self.world == 1
+        try:
+            g = torch.cuda.CUDAGraph(keep_graph=True) if use_x else torch.cuda.CUDAGraph()
+        except TypeError:
+            g, use_x = torch.cuda.CUDAGraph(), False
+        self._graphx = None
         modules._DROP_STATE["salt"] = self._state.data_ptr()
         try:
             with torch.cuda.graph(g):
@@ -515,6 +531,8 @@ class Trainer:
                 ctc, ce = self._fwd_bwd(feats, lens, targets, noise, max_target_len)
                 ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self._state, self.betas[0], self.betas[1], self.eps,
                                   grad_scale=1.0 / self.world, p16=self.fp.flat16)
+            if use_x:
+                self._graphx = ops.GraphExec.from_torch_graph(g)       # None (with a warning) when the executor does not take this graph
             self._graph, self._graph_key, self._graph_out = g, key, (ctc, ce)
         except Exception as e:      # not capturable on this stack: keep training eagerly, remember why
             self._graph_failed = "%s: %s" % (type(e).__name__, e)

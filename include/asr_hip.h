@@ -165,6 +165,19 @@ int asr_gemm_add_layernorm_small(void* stream, const void* A, int64_t lda, const
                                  const float* gamma, const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16,
                                  float* mean, float* rstd, int B, int L, int K, float eps, asr_dropout_t drop_x);
 
+/* Multi-stream executor for a captured HIP graph (csrc/graph_exec.hip; host runtime of the training / decoding step - the reference
+ * queues every op from Python and has no counterpart).  `hip_graph` is a hipGraph_t that stays owned by the caller and must
+ * outlive the executor (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph(); the caller also keeps the capture's memory pool).
+ * asr_graphx_create analyses it once: kernel, memset, memcpy and empty nodes, each placed on one of at most `max_streams` HIP streams
+ * (a node continues the stream of one of its predecessors when it can), cross-stream edges become events.  asr_graphx_launch queues
+ * one execution behind everything already queued on `stream` and joins the side streams back into it: the device sees free-running
+ * queues that overlap like the eager step's, the host pays ~1-2 us per node.  Other node types (host nodes, child graphs, kernels
+ * launched with an `extra` buffer) make create fail with a message - the caller then replays the graph with hipGraphLaunch. */
+int asr_graphx_create(void* hip_graph, int max_streams, void** out_handle);
+int asr_graphx_launch(void* handle, void* stream);
+int asr_graphx_info(void* handle, int* n_nodes, int* n_kernels, int* n_streams, int* n_events);
+int asr_graphx_destroy(void* handle);
+
 /* The position-wise feed-forward sub-layer of an encoder layer in ONE launch (module.py:48-53 `layer_norm(dropout(w_2(relu(w_1(x)))) +
  * residual)` followed by encoder.py:77 `enc_output *= non_pad_mask`), for d_model = 256 and d_ff a multiple of 64 (<= 2048):
  *   h = relu(x16 . W1^T + b1);  s = dropout_x(h . W2^T + b2) + x32;  y = LayerNorm(s) * gamma + beta, rows t >= row_len[b] zeroed.
