@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
-SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "graph_exec.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
+SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
            "backward.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
@@ -69,6 +69,8 @@ SIGNATURES = {
     "asr_conv_sub1_bwd_w_workspace_floats": [],
     "asr_conv_sub0_bwd_w": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],
+    "asr_vocab_proj_lse": [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i],
+    "asr_ctc_loss_fwd_lse": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "asr_ctc_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "asr_ctc_counter_words": [_i, _i, _i],
     "asr_ctc_mean": [_vp, _vp, _vp, _i, _vp],

@@ -148,3 +148,28 @@ __device__ __forceinline__ void transpose4x4_bf16(const u32x2 (&r)[4], u32x2 (&c
     c[2] = u32x2{__builtin_amdgcn_perm(r[1][1], r[0][1], 0x05040100u), __builtin_amdgcn_perm(r[3][1], r[2][1], 0x05040100u)};
     c[3] = u32x2{__builtin_amdgcn_perm(r[1][1], r[0][1], 0x07060302u), __builtin_amdgcn_perm(r[3][1], r[2][1], 0x07060302u)};
 }
+
+// ---- LDS-DMA / small loads as hand-counted inline asm (ffn.hip backward, vocab.hip) ---------------------------------------------
+// The compiler orders every LDS read it cannot disambiguate behind
+// ALL pending LDS-DMA: with the builtin form each ds_read_b64_tr_b16 of the loop got an s_waitcnt vmcnt(0) in front (the fused
+// backward ran 200 us instead of 90).  An asm statement's memory operations are invisible to that pass; the waits are the kernel's
+// own counted ones (vmcnt retires in order: DMA first, then the stores, exactly as in the forward).
+__device__ __forceinline__ u32x4 rsrc_words(const void* base, unsigned bytes) {      // raw buffer descriptor: stride 0, `bytes` records
+    const uint64_t b = (uint64_t)base;
+    return u32x4{(unsigned)b, (unsigned)(b >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const unsigned char*)p);
+}
+__device__ __forceinline__ void dma16_asm(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
+}
+__device__ __forceinline__ uint32_t load32_asm(u32x4 rsrc, unsigned voff, unsigned soff) {
+    uint32_t v;
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
+
+

@@ -1,0 +1,202 @@
+// Vocabulary projection of the CTC branch with the row log-sum-exp taken while the logits are still in the accumulators
+// (src/transformer/transformer.py:119,148 `ctc_fc`, a bias-free Linear d_model -> V, + the `F.log_softmax` of loss.py:41):
+//   logits[m, v] = x[m, :] . W[v, :]   (f32, written once, the CTC backward and the caller read them)
+//   lse[m]       = log sum_v exp(logits[m, v])
+// The CTC forward then never streams the 542 MB of logits (B 32 x L 1000 x V 4234) a second time: its table rows are a 103-entry
+// gather per frame (asr_ctc_loss_fwd_lse), the rest is the alpha / beta recursion.
+//
+// Same decomposition as the fused feed-forward's first product (ffn.hip): a workgroup owns 128 frames, each wave 32 of them as the
+// MFMA's B operand held in registers (x^T, K = d_model = 256); the weight streams through LDS in chunks of 64 vocabulary rows
+// (LDS-DMA, double-buffered, every workgroup reads the same 2 MB from its XCD's L2); S^T[64 vocab x 32 frames] per chunk and wave on
+// v_mfma_f32_32x32x16_bf16 with the frame on the LANE - so a frame's running (max, sum exp) is in-register work on the lane's own
+// 32 values of the chunk, the two lane halves meet once at the very end.  The chunk's logits leave through a per-wave LDS tile
+// ([32 frames][64 vocab] f32) read back 16 lanes per frame: a store instruction covers 4 frames x 256 contiguous bytes.
+// The statistics / store work of chunk i - 1 sits between the MFMAs of chunk i (pinned step by step, one wave per SIMD).
+#include <type_traits>
+
+#include "asr_common.h"
+
+namespace {
+
+constexpr int VBM = 128;             // frames per workgroup
+constexpr int VC = 64;               // vocabulary rows per chunk
+constexpr int VD = 256;              // d_model
+constexpr int VWBUF = VC * VD * 2;   // 32 KiB: [64 rows][256 k] bf16
+constexpr int VTILE = 32 * VC * 4;   // 8 KiB per wave: [32 frames][64 vocab] f32
+
+__device__ __forceinline__ int vswap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+struct VocabArgs {
+    const bf16_t* x16;
+    const bf16_t* w;
+    float* logits;
+    float* lse;
+    int M, V;
+    int64_t ldl;
+};
+
+__global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * VWBUF + 4 * VTILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const tile = smem + 2 * VWBUF + wave * VTILE;
+    const int r = lane & 31, h = lane >> 5;
+    const int m = blockIdx.x * VBM + wave * 32 + r;
+    const int mc = m < a.M ? m : a.M - 1;
+    const int V = a.V, NCH = (V + VC - 1) / VC;
+
+    // weight rows past V read as zeros (the descriptor's range check); their logits are masked out of the statistics and never stored
+    const u32x4 rsw = rsrc_words(a.w, (unsigned)((int64_t)V * VD * 2));
+    unsigned off[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {      // piece p: chunk rows 2p, 2p + 1; LDS slot pc of row u holds 16-byte chunk (pc & 16) | ((pc ^ u) & 15)
+        const int p = wave * 8 + k, u = 2 * p + (lane >> 5), pc = lane & 31;
+        off[k] = (unsigned)(u * VD * 2 + (((pc & 16) | ((pc ^ u) & 15)) << 4));
+    }
+    auto dma = [&](int buf, int chunk, int j) {
+        dma16_asm(rsw, off[j], (unsigned)chunk * (VC * VD * 2), lds_addr_of(smem + buf * VWBUF + (wave * 8 + j) * 1024));
+    };
+    const int u15 = vswap23(r) & 15;
+    unsigned a1[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) a1[kk] = (unsigned)(vswap23(r) * 512 + (((2 * kk + h) ^ u15) << 4));
+
+    bf16x8 xb[16];
+    {
+        const bf16_t* xr = a.x16 + (int64_t)mc * VD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma(0, 0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // the logits tile of a chunk in LDS: frame r's 64 values, 16-byte piece q (vocab 4q .. 4q + 3 of the chunk) in slot q ^ (r & 15);
+    // written by the lane that owns frame r (pieces 2 (4t + 2s + h') ...), read back by 16 lanes per frame
+    const auto rsl = __builtin_amdgcn_make_buffer_rsrc(a.logits, 0, (int)((int64_t)a.M * a.ldl * 4), 0x00020000);
+    unsigned soff[8];      // read-back pass ps: frame 4 ps + (lane >> 4), piece lane & 15
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int mt = blockIdx.x * VBM + wave * 32 + 4 * ps + (lane >> 4);
+        soff[ps] = mt < a.M ? (unsigned)((int64_t)mt * a.ldl * 4) + 16u * (lane & 15) : 0x80000000u;
+    }
+    const unsigned trow = (unsigned)((lane >> 4) * 256), tx0 = (unsigned)((lane & 15) ^ (lane >> 4));      // pass ps: slot tx0 ^ (4 ps & 15)
+
+    float mx = -INFINITY, sm = 0.f;      // this lane's running (max, sum exp(v - max)) over its half of the vocabulary
+    bf16x8 A[16];
+    f32x16 S[2], Sp[2];
+    u32x4 outv[8];
+#define VSTEP() __builtin_amdgcn_sched_barrier(0)
+    // statistics / store work of one finished chunk (values in Sp), dealt over 32 steps; `chunk` = its index
+    //   steps  0.. 7   the chunk's maximum (v_max3), masking the rows past V;  one tile write per step
+    //   step   8       move the running maximum, rescale the running sum
+    //   steps  8..23   sum += exp(v - max) two values per step;  steps 16..23 the tile's read-back, 24..31 its stores
+    float cm = -INFINITY, nmx = 0.f, nm2 = 0.f;
+    auto stat_step = [&](int chunk, int k) {
+        const int nvalid = V - chunk * VC;      // >= 64 except in the last chunk
+        if (k < 8) {
+            // values 4k .. 4k + 3 of the lane: tile t = k >> 2, registers 4 (k & 3) ..; vocab (in chunk) 32 t + 16 (j >> 3) + 8 h + (j & 7)
+            const int t = k >> 2, j0 = 4 * (k & 3);
+            float v4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e;
+                const int vloc = 32 * t + 16 * (j >> 3) + 8 * h + (j & 7);
+                v4[e] = vloc < nvalid ? Sp[t][j] : 0.f;          // what the pad columns of the row (V .. ldl - 1) receive
+                Sp[t][j] = vloc < nvalid ? Sp[t][j] : -INFINITY;  // what the statistics see
+            }
+            cm = fmaxf(cm, fmaxf(fmaxf(Sp[t][j0], Sp[t][j0 + 1]), fmaxf(Sp[t][j0 + 2], Sp[t][j0 + 3])));
+            // piece index within the frame's 64 values: vocab 32 t + 16 s + 8 h + 4 e' -> q = 8 t + 4 s + 2 h + e'  (s = j0 >> 3, e' = (j0 >> 2) & 1)
+            const int q = 8 * t + 4 * (j0 >> 3) + 2 * h + ((j0 >> 2) & 1);
+            *reinterpret_cast<f32x4*>(tile + r * 256 + ((q ^ (r & 15)) << 4)) = f32x4{v4[0], v4[1], v4[2], v4[3]};
+        }
+        if (k == 8) {
+            const float nm = fmaxf(mx, cm);
+            const float ref = nm == -INFINITY ? 0.f : nm;
+            sm *= __builtin_amdgcn_exp2f((mx - ref) * 1.4426950408889634f);      // (mx = -inf: the sum is still 0)
+            mx = nm;
+            nmx = ref;
+            nm2 = -ref * 1.4426950408889634f;
+            cm = -INFINITY;
+        }
+        if (k >= 8 && k < 24) {
+            const int e0 = 2 * (k - 8), t = e0 >> 4, j = e0 & 15;
+            sm += __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[t][j], 1.4426950408889634f, nm2)) +
+                  __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[t][j + 1], 1.4426950408889634f, nm2));
+        }
+        if (k >= 16 && k < 24)
+            outv[k - 16] = *reinterpret_cast<const u32x4*>(tile + (k - 16) * 1024 + trow + ((tx0 ^ (unsigned)((4 * (k - 16)) & 15)) << 4));
+        if (k >= 24) {
+            // columns at or past the row stride do not exist (the last chunk overhangs it): the range check drops them
+            const unsigned col = (unsigned)chunk * VC + 4u * (lane & 15);
+            const unsigned o = col < (unsigned)a.ldl ? soff[k - 24] : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(outv[k - 24], rsl, o, chunk * (VC * 4), 0);
+        }
+        (void)nmx;
+    };
+    auto body = [&](int i, auto first_c, auto last_c) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        const unsigned char* w = smem + (i & 1) * VWBUF;
+        const int nxt = i + 1 < NCH ? i + 1 : NCH - 1;
+        if constexpr (!LAST) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) S[t][j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) A[k] = *reinterpret_cast<const bf16x8*>(w + a1[(k >> 1) & 7] + (k & 1) * 16384 + ((k >> 1) >> 3) * 256);
+            VSTEP();
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if constexpr (!LAST) {
+                S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
+                if (k + 8 < 32) {
+                    const int k8 = k + 8, ks = k8 >> 1;
+                    A[k8 & 15] = *reinterpret_cast<const bf16x8*>(w + a1[ks & 7] + (k8 & 1) * 16384 + (ks >> 3) * 256);
+                }
+                if (k < 8) dma((i + 1) & 1, nxt, k);
+            }
+            if constexpr (!FIRST) stat_step(i - 1, k);
+            VSTEP();
+        }
+        if constexpr (!LAST) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) Sp[t] = S[t];
+        }
+    };
+#define VWAIT(NST)                                                                   \
+    do {                                                                             \
+        asm volatile("s_waitcnt vmcnt(" #NST ") lgkmcnt(0)" ::: "memory");           \
+        __builtin_amdgcn_s_barrier();                                                \
+        asm volatile("" ::: "memory");                                               \
+    } while (0)
+    body(0, std::true_type{}, std::false_type{});
+    VWAIT(0);
+    for (int i = 1; i < NCH; ++i) {
+        body(i, std::false_type{}, std::false_type{});
+        VWAIT(8);      // this iteration's 8 DMA pieces are older than its 8 stores
+    }
+    body(NCH, std::false_type{}, std::true_type{});
+#undef VWAIT
+#undef VSTEP
+    // the two lane halves hold disjoint parts of the frame's vocabulary
+    const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sm, 32, 64);
+    const float mm = fmaxf(mx, mo);
+    const float tot = sm * __expf(mx - mm) + so * __expf(mo - mm);
+    if (h == 0 && m < a.M) a.lse[m] = mm + logf(tot);
+}
+
+}  // namespace
+
+extern "C" int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16, float* logits, int64_t ldl, float* lse, int M, int V, int d_model) {
+    ASR_REQUIRE(d_model == VD, -1, "asr_vocab_proj_lse: d_model = %d (built for 256)", d_model);
+    ASR_REQUIRE(x16 && w16 && logits && lse && M > 0 && V > 0 && ldl >= V && ldl % 4 == 0, -1, "asr_vocab_proj_lse: bad arguments");
+    ASR_REQUIRE((int64_t)M * ldl * 4 < (1ll << 31), -1, "asr_vocab_proj_lse: M * ldl out of range");
+    ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(w16, 16) && asr_aligned(logits, 16), -1, "asr_vocab_proj_lse: 16-byte aligned buffers required");
+    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, logits, lse, M, V, ldl};
+    hipLaunchKernelGGL(vocab_proj_lse_kernel, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
+    ASR_LAUNCH_CHECK("asr_vocab_proj_lse");
+    return 0;
+}

@@ -935,18 +935,24 @@ class DecoderLayer(nn.Module):
         return self.pos_ffn._impl(x, dec_len)
 
 
-def _vocab_proj(mod, key, weight, x):
+def _vocab_proj(mod, key, weight, x, want_lse=False):
     """logits = x . W^T (no bias).  On the tape the gradient arrives through `mod._grad_slots[key]["g"]`, filled by the
-    trainer from the fused loss backward: a [.., V] view of a zero-padded buffer whose rows are 16-byte aligned."""
+    trainer from the fused loss backward: a [.., V] view of a zero-padded buffer whose rows are 16-byte aligned.
+    want_lse: -> (logits, lse or None): the rows' log-sum-exp from the projection's own launch when the shape takes it
+    (ops.vocab_proj_lse: encoder-sized rows, d_model 256, bf16) - the CTC forward then does not stream the logits again."""
     w16 = mod._w(key, (weight,))
+    lse = None
     # rows padded to a multiple of 8 floats: every row 16-byte aligned -> the GEMM's full-cache-line vector epilogue applies to any
     # vocabulary size (V = 4234: 295 -> ~150 us for the [32000, V] CTC projection); the loss kernels take the row stride
     xa = x.mma()
     M, V = xa.shape[0], weight.shape[0]
     Vp = (V + 7) // 8 * 8
-    buf = torch.empty((M, Vp), device=xa.device, dtype=torch.float32)
-    ops.gemm_nt_raw(xa, M, xa.shape[1], xa.shape[1], w16, None, out=buf, ldc=Vp)
-    logits = buf[:, :V]
+    if want_lse and _PRECISION == "bf16" and ops.vocab_proj_lse_ok(xa, w16):
+        logits, lse = ops.vocab_proj_lse(xa, w16)
+    else:
+        buf = torch.empty((M, Vp), device=xa.device, dtype=torch.float32)
+        ops.gemm_nt_raw(xa, M, xa.shape[1], xa.shape[1], w16, None, out=buf, ldc=Vp)
+        logits = buf[:, :V]
     if _TAPE is not None:
         slot = {"g": None, "shape": tuple(logits.shape)}
         mod.__dict__.setdefault("_grad_slots", {})[key] = slot
@@ -970,7 +976,7 @@ def _vocab_proj(mod, key, weight, x):
             slot["g"] = None
 
         _TAPE.push(bw, (weight,))
-    return logits
+    return (logits, lse) if want_lse else logits
 
 
 def _compact_targets(targets):

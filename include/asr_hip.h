@@ -301,6 +301,14 @@ int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const flo
  * zero_counters: NULL, or an int32 buffer of asr_ctc_counter_words(B, L, n_chunks) words that the CALLER has zeroed (e.g. a slice
  * of a per-step zero arena): the arrival counters then live there and the call queues no memset in front of its launch.
  */
+/* The CTC branch's vocabulary projection with the row log-sum-exp taken in the same launch (transformer.py:119,148 `ctc_fc`: Linear
+ * d_model -> V without bias, d_model = 256; loss.py:41 `F.log_softmax`): logits f32 [M, V] (row stride ldl floats, a multiple of 4; pad
+ * columns V .. ldl - 1 are written with zeros) = x16 [M, 256] . w16 [V, 256]^T and lse f32 [M] = log sum_v exp(logits[m, v]).
+ * asr_ctc_loss_fwd_lse is asr_ctc_loss_fwd for logits whose row lse is known already: its table rows are a gather of the blank's and the
+ * labels' logits per frame (the 17 KB frame is not read again), then the alpha / beta recursion; same workspaces, same outputs, U + 1 <= 64. */
+int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16, float* logits, int64_t ldl, float* lse, int M, int V, int d_model);
+int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t ldl, const float* lse, const int32_t* in_len, const int64_t* targets,
+                         int B, int L, int V, int Umax, int blank, float* lp_ext, float* alpha, float* nll, int32_t* tgt_len);
 int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
