@@ -322,7 +322,7 @@ def pmc_traffic(fam_kernel, prof_dir):
     return int(tot / n) if n else None
 
 
-FAMILY_KERNEL = {"ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_tr_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
+FAMILY_KERNEL = {"vocab_proj_lse": "vocab_proj_lse_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_tr_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
                  "attention_fwd": "attn_fwd_bf16_v2_kernel", "attention_bwd": "attn_bwd_fused_kernel",
                  "attention_bwd_dq": "attn_bwd_dq_kernel", "attention_bwd_dkv": "attn_bwd_dkv_kernel",
                  "add_layernorm": "add_layernorm_fwd_kernel", "add_layernorm_bwd": "add_layernorm_bwd_kernel",
@@ -520,6 +520,7 @@ def main():
                              "correction)" % os.path.relpath(prof_dir, ROOT))
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
+        vp_k = [k for k in kernels if k["name"].startswith("vocab_proj_lse")]
         what, mname = what_name(args, train), model_name()
         Lc = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
         ctc_iso = None
@@ -553,6 +554,11 @@ def main():
             "roofline": roofline,
             "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "fwd_GBps": ctc_k[0]["achieved"],
                      "fwd_frac_of_hbm_peak": round(ctc_k[0]["achieved"] / PEAK_HBM_GBS, 4),
+                     "fwd_form": ("label gather + alpha / beta recursion from the row log-sum-exp the ctc_fc projection took in its own launch "
+                                  "(vocab_proj_lse: %s ms/step for projection + lse); the forward reads ~52 logits per frame, its rate is "
+                                  "priced on the unfused op's bytes (the B x L x V x 4 logits read once), as SURVEY 8(d) allows"
+                                  % (vp_k[0]["ms_per_step"] if vp_k else "?")) if vp_k else
+                                 "one launch: persistent pass workgroups stream the logits, the recursion waves consume the table rows as they arrive",
                      "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
                      # bytes: the logits read twice (f32) + the gradient written (bf16 image in the trainer)
                      "fwd_bwd_GBps": (round((2 * 4.0 + (2.0 if trainer is not None else 4.0)) * CFG["B"] * Lc * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
@@ -560,9 +566,9 @@ def main():
                      "fwd_ms_standalone": (round(ctc_iso, 4) if ctc_iso else None),
                      "fwd_frac_of_hbm_peak_standalone": (round(4.0 * CFG["B"] * Lc * CFG["vocab_size"] / (ctc_iso * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
                                                          if ctc_iso else None),
-                     "note": "ms_per_step_fwd / fwd_frac_of_hbm_peak: inside the step, right behind the ctc_fc GEMM that wrote the logits - "
-                             "a bare streaming read of those 542 MB takes 0.138-0.145 ms in that situation (tools/micro/hbm_read.hip, "
-                             "DESIGN.md 4); *_standalone: the op alone on resident fp32 logits of the same shape, 30 launches back-to-back"}
+                     "note": "ms_per_step_fwd / fwd_frac_of_hbm_peak: the CTC forward inside the step (HIP events on its launch stream); "
+                             "*_standalone: the STREAMING form of the op alone (asr_ctc_loss_fwd on resident fp32 logits of the same shape, "
+                             "which it reads in full: 30 launches back-to-back) - the form every caller without a precomputed row lse gets"}
                     if ctc_k else None),
             "kernels": kernels[:12], "op_ms_total": round(sum(k["ms_per_step"] for k in kernels), 3),
             "families": sorted(({"family": n, "ms_per_step": round(f["ms"] / args.steps, 3),

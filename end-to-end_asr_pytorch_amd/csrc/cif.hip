@@ -36,6 +36,49 @@ namespace {
         integrate = s_ - f_;                                                                                                    \
     }
 
+// `alphas.sum(-1)` in the order torch's CPU kernel adds (SumKernel.cpp: cascade_sum -> vectorized_inner_sum -> row_sum -> multi_row_sum;
+// restated with its derivation in oracle.aten_row_sum_f32 and pinned bit for bit on torch's own sums, fixture G16): cif_model.py:95
+// ROUNDS this sum to the label count, so the last bit decides rows whose sum sits within an ulp of k + 0.5.  Four interleaved chains
+// of 8-lane vector adds = 32 independent fp32 chains, one per lane (lanes 0..31; rows shorter than 8: 4 scalar chains), a four-level
+// cascade inside each, then the chains, the tail elements and the 8 lanes added sequentially.  The row is read straight from
+// global memory (it is in L1 / L2: the scan has just read it); no multiply-add in sight, so nothing can be contracted.
+__device__ __forceinline__ float aten_row_sum_f32(const float* __restrict__ a, int n, int lane) {
+    const int W = n >= 8 ? 8 : 1;
+    const int vec = n / W, size_ilp = vec >> 2;
+    int lg = 0;
+    while ((1 << lg) < size_ilp) ++lg;                      // ceil(log2(size_ilp)), 0 for size_ilp <= 1
+    const int lp = max(4, lg / 4), step = 1 << lp, mask = step - 1;
+    const bool chain = lane < 4 * W;
+    const int k = chain ? lane / W : 0, v = chain ? lane % W : 0;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int i = 0;
+    while (i + step <= size_ilp) {
+        for (int j = 0; j < step; ++j, ++i) acc0 += a[(i * 4 + k) * W + v];
+        acc1 += acc0; acc0 = 0.f;
+        if ((i & (mask << lp)) == 0) {
+            acc2 += acc1; acc1 = 0.f;
+            if ((i & (mask << (2 * lp))) == 0) { acc3 += acc2; acc2 = 0.f; }
+        }
+    }
+    for (; i < size_ilp; ++i) acc0 += a[(i * 4 + k) * W + v];
+    acc0 += acc1;
+    acc0 += acc2;
+    acc0 += acc3;
+    for (int i2 = size_ilp * 4; i2 < vec; ++i2) {           // leftover vectors go to chain 0
+        const float x = a[i2 * W + v];
+        if (k == 0) acc0 += x;
+    }
+    for (int kk = 1; kk < 4; ++kk) {                        // chains 1, 2, 3 onto chain 0, in that order
+        const float o = __shfl(acc0, kk * W + v, 64);
+        if (k == 0) acc0 += o;
+    }
+    if (W == 1) return __shfl(acc0, 0, 64);
+    float fin = 0.f;
+    for (int e = vec * 8; e < n; ++e) fin += a[e];
+    for (int vv = 0; vv < 8; ++vv) fin += __shfl(acc0, vv, 64);
+    return fin;
+}
+
 constexpr int CIF_LDS_FRAMES = 8192;      // frames of one utterance staged in LDS per pass (32 KiB)
 
 __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ alpha, int L, float thr, float* __restrict__ cur_out,
@@ -47,7 +90,6 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
     const float* __restrict__ a = alpha + (int64_t)b * L;
     float integrate = 0.f;
     int n = 0;
-    double psum = 0.0;
     const float big = 0x1p100f, nthr_big = -thr * 0x1p100f;      // (thr * 2^100 is exact: a power-of-two scaling)
     for (int base = 0; base < L; base += CIF_LDS_FRAMES) {
         const int len = min(CIF_LDS_FRAMES, L - base);
@@ -64,7 +106,6 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
             for (int j = 0; j < 16; ++j) {
                 const int t = t0 + j * 64 + lane;
                 if (t < len) row[t] = v[j];
-                psum += (double)v[j];
             }
         }
         __syncthreads();
@@ -106,13 +147,11 @@ __global__ __launch_bounds__(64) void cif_scan_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    // round(sum alpha) (cif_model.py:95): the sum is taken in f64, so the label count is the rounding of the exact sum whatever
-    // order a float reduction would have used (torch's CPU and GPU reductions differ from each other in the last bits too)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) psum += __shfl_xor(psum, o, 64);
+    // round(sum alpha) (cif_model.py:95 `torch.round(alphas.sum(-1)).int()`): the reference's fp32 sum, in the reference's order
+    const float asum = aten_row_sum_f32(a, L, lane);
     if (lane == 0) {
         n_fire[b] = n;
-        n_label[b] = (int32_t)rint(psum);  // torch.round: half to even
+        n_label[b] = (int32_t)rintf(asum);  // torch.round: half to even
     }
 }
 

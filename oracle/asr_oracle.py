@@ -359,6 +359,56 @@ def decoder_cif_forward(sd, pfx, cif_out, target, n_layers, n_head, sos_id):
 # --------------------------------------------------------------------------------------
 # CIF  (src/transformer/cif_model.py:57-106)
 # --------------------------------------------------------------------------------------
+def aten_row_sum_f32(x):
+    """`x.sum(-1)` of a contiguous fp32 [.., n] tensor in the order torch's CPU kernel adds (aten/src/ATen/native/cpu/SumKernel.cpp,
+    `cascade_sum` -> `vectorized_inner_sum` -> `row_sum` -> `multi_row_sum`; torch 1.5 - 2.10, 8-float vectors): four interleaved
+    chains of 8-lane vector adds with a 4-level cascade (a level empties into the next every 2^level_power steps), the chains
+    added 1, 2, 3 onto chain 0, then - starting from zero - the n % 8 tail elements and the 8 lanes, all sequentially; rows shorter
+    than 8 take the same structure on scalars.  cif_model.py:95 ROUNDS this sum to the label count, so its last bit matters:
+    a row whose sum sits within an ulp of k + 0.5 gets another count from any other order.  Pinned bit for bit on torch's own
+    sums in tests/golden/g16_cif_label_count.npz (lengths 1 .. 2049; checked up to 20000 when the fixture was written)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=F32))
+    lead, n = x.shape[:-1], x.shape[-1]
+    rows = x.reshape(-1, n)
+    W = 8 if n >= 8 else 1
+    vec = n // W
+    V = rows[:, :vec * W].reshape(-1, vec, W)
+    ilp, levels = 4, 4
+    size_ilp = vec // ilp
+    lp = max(4, (0 if size_ilp <= 1 else int(np.ceil(np.log2(size_ilp)))) // levels)
+    step, mask = 1 << lp, (1 << lp) - 1
+    acc = np.zeros((levels, rows.shape[0], ilp, W), F32)
+    i = 0
+    while i + step <= size_ilp:
+        for _ in range(step):
+            acc[0] = acc[0] + V[:, i * ilp:(i + 1) * ilp]
+            i += 1
+        for j in range(1, levels):
+            acc[j] = acc[j] + acc[j - 1]
+            acc[j - 1] = 0
+            if i & (mask << (j * lp)):
+                break
+    while i < size_ilp:
+        acc[0] = acc[0] + V[:, i * ilp:(i + 1) * ilp]
+        i += 1
+    for j in range(1, levels):
+        acc[0] = acc[0] + acc[j]
+    part = acc[0]                                    # [rows, ilp, W]
+    for i2 in range(size_ilp * ilp, vec):
+        part[:, 0] = part[:, 0] + V[:, i2]
+    for k in range(1, ilp):
+        part[:, 0] = part[:, 0] + part[:, k]
+    lanes = part[:, 0]                               # [rows, W]
+    if W == 1:
+        return lanes[:, 0].reshape(lead)
+    out = np.zeros(rows.shape[0], F32)
+    for e in range(vec * W, n):
+        out = out + rows[:, e]
+    for v in range(W):
+        out = out + lanes[:, v]
+    return out.reshape(lead)
+
+
 def cif(hidden, alphas, threshold=0.95, max_label_len=None):
     """Sequential integrate-and-fire in the reference's exact fp32 operation order.
 
@@ -386,8 +436,8 @@ def cif(hidden, alphas, threshold=0.95, max_label_len=None):
         frame = frame + cur[:, None] * hidden[:, t, :]
         frames[:, t] = frame
         frame = np.where(fire[:, None], rem[:, None] * hidden[:, t, :], frame).astype(F32)
-    # torch.round is round-half-to-even, same as np.round; sum in fp32 like torch (pairwise-ish; pinned by fixture)
-    n_label = np.round(alphas.sum(-1, dtype=F32)).astype(np.int32)
+    # torch.round is round-half-to-even, same as np.round; the sum in torch's own fp32 order (aten_row_sum_f32, fixture G16)
+    n_label = np.round(aten_row_sum_f32(alphas)).astype(np.int32)
     umax = int(n_label.max()) if max_label_len is None else int(max_label_len)
     out = np.zeros((B, umax, H), dtype=F32)
     fire_idx = []

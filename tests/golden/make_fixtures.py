@@ -626,6 +626,123 @@ def g13_cif_recognize():
                         x=npy(x), lens=npy(lens), cases="|".join(cases), **out, **cfg_arrays())
 
 
+S15 = dict(S0, d_model=256, n_head=4, d_inner=512, n_layers_enc=1, n_layers_dec=2, d_assigner_hidden=64)
+# Two weight settings (the seeded output projection scaled by `scale`):
+#   "a": seed 133, x1.5 - next-token distributions as flat as random weights give them: varied token sequences, top-2 margins down to
+#        0.06.  The fixture stores the margins; a bf16 run is held to the reference's tokens up to the first step whose margin is small.
+#   "b": seed 115, x6   - sharp distributions (margins > 1): token-exact under bf16 rounding, beams and CIF n-best lists included.
+G15_SETS = (("a", 133, 16, 1.5), ("b", 115, 15, 6.0))
+
+
+def g15_decode_d256():
+    """The decode paths at the BENCHMARK width (d_model = 256, h = 4): there the bf16 product path runs its one-launch decode
+    sub-layers (csrc/decode_blocks.hip), which the d_model = 64 fixtures G9 / G12 / G13 cannot reach.  Reference outputs of
+    Decoder.batch_decode (decoder.py:138-164), Decoder.batch_beam_decode (:166-234) and CIF_Model.recognize (cif_model.py:108-131)
+    on a 1-layer encoder / 2-layer decoder with seeded weights."""
+    orig_mask = tdec.get_subsequent_mask
+    tdec.get_subsequent_mask = lambda seq: orig_mask(seq).bool()     # same harness shim as G9
+    out = {}
+    args = argparse.Namespace(**S15)
+    for tag, seed, bseed, scale in G15_SETS:
+        model = Conv_CTC_Transformer.create_model(args).eval()
+        ns, sd = load_seeded(model, seed=seed)
+        with torch.no_grad():
+            model.decoder.tgt_word_prj.weight.mul_(scale)
+        x, lens, tg = s0_batch(seed=bseed)
+        T = 10
+        with torch.no_grad():
+            conv_out, len_seq = model.conv_encoder(x, lens)
+            enc_out = model.encoder(conv_out, len_seq)
+            p0, l0, _ = model.decoder.batch_decode(enc_out, len_seq, max_decode_len=T)
+            # top-2 margin of every greedy decision (teacher-forced on the reference's own prefix)
+            marg = np.zeros((4, T), np.float32)
+            for t in range(T):
+                prefix = torch.cat([torch.full((4, 1), S15["sos_id"], dtype=torch.long), p0[:, :t]], 1)
+                top2 = torch.topk(model.decoder.step(prefix, enc_out, len_seq), 2, -1).values
+                marg[:, t] = npy(top2[:, 0] - top2[:, 1])
+            out[tag + "_greedy_preds"], out[tag + "_greedy_len"], out[tag + "_greedy_margin"] = npy(p0), npy(l0), marg
+            print("G15", tag, "greedy", npy(p0)[0].tolist(), "min margin %.3f" % marg.min())
+            eos2 = int(p0[0, 2])          # a token the model emits early: rows finish at different steps
+            model.decoder.eos_id = eos2
+            p1, l1, _ = model.decoder.batch_decode(enc_out, len_seq, max_decode_len=T)
+            out[tag + "_greedy_preds_eos2"], out[tag + "_greedy_len_eos2"], out[tag + "_eos2"] = npy(p1), npy(l1), np.asarray(eos2)
+            model.decoder.eos_id = S15["eos_id"]
+            prefix = torch.cat([torch.full((4, 1), S15["sos_id"], dtype=torch.long), p0[:, :4]], 1)
+            out[tag + "_step_prefix"], out[tag + "_step_scores"] = npy(prefix), npy(model.decoder.step(prefix, enc_out, len_seq))
+            beam_cases = ((3, 8, S15["eos_id"]), (2, 6, eos2), (5, 7, S15["eos_id"]))
+            for beam, Tb, eos in beam_cases:
+                model.decoder.eos_id = eos
+                p, l, sc = model.decoder.batch_beam_decode(enc_out, len_seq, beam_size=beam, max_decode_len=Tb)
+                k = "%s_beam_b%d_T%d_eos%d" % (tag, beam, Tb, eos)
+                out[k + "_preds"], out[k + "_len"], out[k + "_scores"] = npy(p), npy(l), npy(sc)
+                print("G15", k, npy(p)[0, 0].tolist(), npy(sc)[0].tolist())
+            model.decoder.eos_id = S15["eos_id"]
+        out.update({tag + "_names_shapes": names_shapes_to_json(ns), tag + "_seed": seed, tag + "_crc": crc_of(sd), tag + "_scale": scale,
+                    tag + "_x": npy(x), tag + "_lens": npy(lens), tag + "_enc_out": npy(enc_out), tag + "_enc_len": npy(len_seq),
+                    tag + "_beam_cases": "|".join("%d,%d,%d" % c for c in beam_cases)})
+    # ---- CIF_Model.recognize, one utterance at a time (as the reference calls it), sharp setting
+    import contextlib
+    import io
+    cif = CIF_Model.create_model(args).eval()
+    ns_c, sd_c = load_seeded(cif, seed=116)
+    with torch.no_grad():
+        cif.decoder.tgt_word_prj.weight.mul_(6.0)
+    x, lens, tg = s0_batch(seed=15)
+    chars = ["c%d" % i for i in range(S15["vocab_size"])]
+    cases = []
+    with torch.no_grad():
+        for u, beam, nbest, tnum in ((0, 3, 2, 7), (1, 1, 1, 6), (2, 4, 3, 5)):
+            Tu = int(lens[u])
+            dec_args = argparse.Namespace(beam_size=beam, nbest=nbest)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ys, ls = cif.recognize(x[u, :Tu], lens[u:u + 1], chars, dec_args, target_num=tnum)
+            k = "cif_u%d_b%d_n%d_t%d" % (u, beam, nbest, tnum)
+            cases.append("%d,%d,%d,%d" % (u, beam, nbest, tnum))
+            width = max(ls)
+            out[k + "_yseq"] = np.array([y + [-1] * (width - len(y)) for y in ys], np.int64)
+            out[k + "_len"] = np.array(ls, np.int64)
+            print("G15", k, ys[0])
+    tdec.get_subsequent_mask = orig_mask
+    out.update(cif_names_shapes=names_shapes_to_json(ns_c), cif_seed=116, cif_crc=crc_of(sd_c), cif_cases="|".join(cases), cif_scale=6.0,
+               cif_x=npy(x), cif_lens=npy(lens))
+    np.savez_compressed(os.path.join(HERE, "g15_decode_d256.npz"), **out, **{"cfg_%s" % k: np.asarray(v) for k, v in S15.items() if isinstance(v, (int, float))})
+
+
+def g16_cif_label_count():
+    """`torch.round(alphas.sum(-1)).int()` (cif_model.py:95) on rows built to sit ON the rounding boundary: for every length a random
+    row is shifted so that its fp32 sum, taken by torch, is k + 0.5 exactly, one ulp below and one ulp above (round-half-to-even and
+    the summation order both decide the count there), plus plain random rows.  The reference's `alphas.sum(-1)` itself is stored, so
+    the oracle's restatement of ATen's summation order is pinned bit for bit."""
+    g = torch.Generator().manual_seed(16)
+    out = {}
+    lengths = (1, 3, 7, 8, 9, 31, 64, 100, 250, 513, 1000, 2049)
+    for T in lengths:
+        rows = []
+        for trial in range(6):
+            a = torch.rand(T, generator=g) * (0.6 if T < 16 else 0.12)
+            rows.append(a.clone())
+            if T >= 3:
+                k = max(1, int(a.sum().item()))
+                for target in (k + 0.5, np.nextafter(np.float32(k + 0.5), np.float32(0)), np.nextafter(np.float32(k + 0.5), np.float32(1e9)),
+                               k + 1.5 if trial % 2 else k - 0.5):
+                    b = a.clone()
+                    for _ in range(60):          # nudge one element until torch's own fp32 sum hits the target bit pattern
+                        d = float(np.float32(target) - b.sum().numpy())
+                        if d == 0.0:
+                            break
+                        j = int(torch.argmax(b))
+                        b[j] = b[j] + torch.tensor(d, dtype=torch.float32)
+                    if float(b.min()) >= 0 and float(b.sum()) == float(np.float32(target)):
+                        rows.append(b)
+        A = torch.stack(rows)
+        out["alpha_T%d" % T] = npy(A)
+        out["sum_T%d" % T] = npy(A.sum(-1))
+        out["n_label_T%d" % T] = npy(torch.round(A.sum(-1)).int())
+        frac = A.sum(-1) - torch.floor(A.sum(-1))
+        print("G16 T=%d rows %d, on the .5 boundary %d" % (T, A.shape[0], int((frac == 0.5).sum())))
+    np.savez_compressed(os.path.join(HERE, "g16_cif_label_count.npz"), lengths=np.asarray(lengths), **out)
+
+
 def g14_collate():
     """The reference's AudioDataset + AudioDataLoader / LFRCollate / load_inputs_and_targets (utils/data.py:28-188) over a small
     corpus: features in a Kaldi ark written by THIS repo's writer (the reference reads arks through the third-party kaldi_io, absent
@@ -697,4 +814,6 @@ if __name__ == "__main__":
     g11_mask_lm()
     g12_beam_decode()
     g13_cif_recognize()
+    g15_decode_d256()
+    g16_cif_label_count()
     g14_collate()

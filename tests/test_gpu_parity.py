@@ -693,3 +693,13 @@ def test_ctc_large_batch_takes_the_two_launch_form():
     lp = torch.nn.functional.log_softmax(logits, -1).transpose(0, 1)
     ref = torch.nn.functional.ctc_loss(lp, tg, il, torch.full((B,), U), blank=V - 1, reduction="none")
     np.testing.assert_allclose(N(nll), ref.numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_cif_label_count_is_the_references_fp32_sum(golden_dir):
+    """n_label = torch.round(alphas.sum(-1)) (cif_model.py:95) on the boundary rows of fixture G16 (the sum at k + 0.5 and one ulp to
+    either side, generated by the reference): the scan kernel adds in ATen's own fp32 order (cif.hip: aten_row_sum_f32)."""
+    z = np.load(os.path.join(golden_dir, "g16_cif_label_count.npz"))
+    for T in z["lengths"]:
+        a = torch.from_numpy(z["alpha_T%d" % T]).to(DEV).contiguous()
+        n_label = ops.cif_scan(a, 0.95)[4]
+        np.testing.assert_array_equal(n_label.cpu().numpy(), z["n_label_T%d" % T], err_msg="T = %d" % T)
