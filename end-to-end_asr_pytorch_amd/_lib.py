@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
 SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "attention.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
-           "backward.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
+           "backward.hip", "wgrad.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "asr_ffn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dr, _dr],
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i],
+    "asr_gemm_tn_ws_bytes": [_i, _i, _i, _i],
+    "asr_gemm_tn_ws": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _i],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
     "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _dr],
     "asr_dropout_apply": [_vp, _vp, _vp, _i, _i, _i, _dr],
@@ -175,6 +177,7 @@ def lib():
             fn.restype = ctypes.c_int
         L.asr_attention_dropmask_words.restype = ctypes.c_int64
         L.asr_ffn_bits_words.restype = ctypes.c_int64
+        L.asr_gemm_tn_ws_bytes.restype = ctypes.c_int64
         L.asr_ctc_counter_words.restype = ctypes.c_int64
         L.asr_conv_sub1_bwd_w_workspace_floats.restype = ctypes.c_int64
         L.asr_decode_block_workspace_bytes.restype = ctypes.c_int64

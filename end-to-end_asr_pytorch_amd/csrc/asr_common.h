@@ -166,6 +166,11 @@ __device__ __forceinline__ void dma16_asm(u32x4 rsrc, unsigned voff, unsigned so
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff) : "memory");
 }
+__device__ __forceinline__ u32x4 load128_asm(u32x4 rsrc, unsigned voff, unsigned soff) {
+    u32x4 v;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    return v;
+}
 __device__ __forceinline__ uint32_t load32_asm(u32x4 rsrc, unsigned voff, unsigned soff) {
     uint32_t v;
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");

@@ -690,6 +690,25 @@ def _gemm_tn_f32(a2d, b2d, out, accumulate, colsum_out):
     return out
 
 
+# Workspaces of the slab-reduced weight gradient (csrc/wgrad.hip): one per destination buffer, so that launches queued on different
+# streams never share one, address-stable for graph capture.
+TN_SLAB = os.environ.get("ASR_AMD_TN_SLAB", "1") != "0"
+DETERMINISTIC = os.environ.get("ASR_AMD_DETERMINISTIC", "0") not in ("", "0")
+_tn_ws = {}
+
+
+def _tn_workspace(out, M, N, K, max_wgs):
+    need = int(lib().asr_gemm_tn_ws_bytes(M, N, K, int(max_wgs)))
+    if need <= 0:
+        return None
+    key = (out.data_ptr(), out.device.index)
+    ws = _tn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=out.device, dtype=torch.uint8)
+        _tn_ws[key] = ws
+    return ws
+
+
 def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     """dW[N,K] = A[M,N]^T . B[M,K]  (f32 result).  A/B f32 or bf16; rows may be strided (padded buffers).
     colsum (f32 [N]) += column sums of A (the bias gradient) in the same pass."""
@@ -702,6 +721,14 @@ def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     if out is None:
         out = torch.empty((N, K), device=a2d.device, dtype=torch.float32)
         accumulate = False
+    if TN_SLAB and a2d.dtype == torch.bfloat16 and b2d.dtype == torch.bfloat16 and K % 128 == 0 and M >= 64:
+        ws = _tn_workspace(out, M, N, K, max_wgs)
+        if ws is not None:
+            with _timed("gemm_tn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
+                check(lib().asr_gemm_tn_ws(_stream(), _p(a2d), a2d.stride(0), _p(b2d), b2d.stride(0), _p(out), out.stride(0), M, N, K,
+                                           1 if accumulate else 0, _p(colsum), int(max_wgs), _p(ws), ws.numel(),
+                                           1 if DETERMINISTIC else 0), "asr_gemm_tn_ws")
+            return out
     with _timed("gemm_tn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
         check(lib().asr_gemm_tn(_stream(), _p(a2d), dtype_code(a2d), a2d.stride(0), _p(b2d), dtype_code(b2d), b2d.stride(0), _p(out),
                                 out.stride(0), M, N, K,

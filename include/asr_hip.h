@@ -227,6 +227,17 @@ int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const f
  * GEMM beside other kernels (a weight-gradient side stream) passes 256 = one per CU, half the M-splits and atomics. */
 int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const void* Bm, int b_dtype, int64_t ldb, float* C,
                 int64_t ldc, int M, int N, int K, int zero_first, float* colsum, int max_workgroups);
+/* The same weight gradient with a caller-owned workspace (csrc/wgrad.hip; solver.py:119 loss.backward() -> every nn.Linear's
+ * weight.grad): bf16 A and B.  The M-splits' partial tiles go to the workspace with plain stores and a second small launch sums
+ * them in a fixed order - no float atomics on C (they retire at ~1.2 TB/s on MI355X, plain stores at > 4), no pre-zeroing, and a
+ * result that does not depend on timing.  accumulate != 0: C += the product.  colsum as above (float atomics over the K/128
+ * workgroups that share a column block); deterministic != 0: one writer per colsum element as well.
+ * workspace: asr_gemm_tn_ws_bytes(M, N, K, max_workgroups) bytes, 16-byte aligned, contents irrelevant, not shared by two launches
+ * that may run concurrently.  Shapes the kernel does not take (K % 128, rows not 16-byte aligned, M < 64, M * ld * 2 >= 2^31,
+ * workspace null or short) fall through to asr_gemm_tn. */
+int64_t asr_gemm_tn_ws_bytes(int M, int N, int K, int max_workgroups);
+int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const void* Bm, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                   int accumulate, float* colsum, int max_workgroups, void* workspace, int64_t workspace_bytes, int deterministic);
 /* Bias gradient out[n] (+)= sum_m A[m,n]. */
 int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first);
 /* Embedding backward: demb[ids[r], :] += dropout_mask(dy[r, :])  (f32 atomics; caller zeroes demb).  M = B*U rows. */

@@ -1,0 +1,67 @@
+"""The slab-reduced weight gradient (csrc/wgrad.hip: asr_gemm_tn_ws; solver.py:119 -> nn.Linear weight.grad of module.py:48-53,
+attention.py:33-60, transformer.py:148) against torch fp32 on the bf16-rounded operands: ragged M (a partial last 64-row step), an
+output that is not a multiple of the tile (padded dY rows), accumulate, the bias-gradient side product in both modes, repeated launches
+on one workspace (the arrival counters must come back to zero), bit-identical repeats, and the atomics kernel it replaces."""
+import numpy as np
+import pytest
+import torch
+
+from asr_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = lambda t: t.detach().float().cpu().numpy()
+
+
+def _ops(M, Nn, K, seed, lda=None):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, Nn, generator=g).bfloat16()
+    b = torch.randn(M, K, generator=g).bfloat16()
+    if lda:
+        buf = torch.full((M, lda), 3.0, dtype=torch.bfloat16)      # finite padding: only rows >= N of the (unwritten) output see it
+        buf[:, :Nn] = a
+        ad = buf.to(DEV)[:, :Nn]
+    else:
+        ad = a.to(DEV)
+    return a, b, ad, b.to(DEV)
+
+
+@pytest.mark.parametrize("M,Nn,K,lda", [(32000, 256, 2048, None), (32000, 2048, 256, None), (32000, 768, 256, None), (32000, 256, 256, None),
+                                        (1632, 256, 256, None), (1632, 2048, 256, None), (1000, 256, 2048, None), (4000, 4234, 256, 4352),
+                                        (64, 128, 128, None), (72, 384, 128, None), (8192, 128, 128, None)])
+def test_gemm_tn_slab(M, Nn, K, lda, monkeypatch):
+    a, b, ad, bd = _ops(M, Nn, K, M + Nn, lda)
+    ref = a.float().t() @ b.float()
+    tol = dict(atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+    cs = torch.zeros(Nn, device=DEV)
+    out = torch.full((Nn, K), 7.0, device=DEV)                       # not pre-zeroed: the kernel overwrites
+    ops.gemm_tn(ad, bd, out=out, colsum=cs, max_wgs=256)
+    np.testing.assert_allclose(N(out), ref.numpy(), **tol)
+    np.testing.assert_allclose(N(cs), a.float().sum(0).numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+    first = out.clone()
+    for _ in range(3):                                               # same workspace again: counters were left at zero
+        ops.gemm_tn(ad, bd, out=out, max_wgs=256)
+        assert torch.equal(out, first)                               # fixed summation order: bit-identical
+    ops.gemm_tn(ad, bd, out=out, accumulate=True, max_wgs=256)
+    np.testing.assert_allclose(N(out), 2 * ref.numpy(), atol=2 * tol["atol"], rtol=2e-3)
+    # deterministic bias gradient: one writer per element, bit-identical across launches
+    monkeypatch.setattr(ops, "DETERMINISTIC", True)
+    c1, c2 = torch.zeros(Nn, device=DEV), torch.zeros(Nn, device=DEV)
+    ops.gemm_tn(ad, bd, out=out, colsum=c1, max_wgs=256)
+    ops.gemm_tn(ad, bd, out=out, colsum=c2, max_wgs=256)
+    assert torch.equal(c1, c2)
+    np.testing.assert_allclose(N(c1), a.float().sum(0).numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+    # the atomics kernel computes the same product
+    monkeypatch.setattr(ops, "TN_SLAB", False)
+    old = ops.gemm_tn(ad, bd, max_wgs=256)
+    np.testing.assert_allclose(N(first), N(old), atol=tol["atol"] * 0.5, rtol=1e-3)
+
+
+def test_gemm_tn_slab_whole_chip_split():
+    """max_wgs = 0 (the launch has the chip to itself) and a second destination: separate workspaces."""
+    a, b, ad, bd = _ops(32000, 256, 2048, 5)
+    ref = (a.float().t() @ b.float()).numpy()
+    o1 = ops.gemm_tn(ad, bd)
+    o2 = ops.gemm_tn(ad, bd)
+    assert torch.equal(o1, o2)
+    np.testing.assert_allclose(N(o1), ref, atol=0.25, rtol=2e-3)
