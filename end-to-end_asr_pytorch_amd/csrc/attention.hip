@@ -415,19 +415,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
     uint32_t wk[2] = {0u, 0u}, wkn[2] = {0u, 0u};
     f32x16 sa[2], sb[2];
 
-    // prologue: mask words of tile 0, K0 V0 | K1 V1 K2 ; the first scores
+    // prologue: mask words of tile 0, K0 V0 K1 | V1 K2 ; the first scores.  Iteration 0 reads K(1) and V(0) with no wait of its own in
+    // front: both are among the requests the prologue waits for (iteration t >= 1 is covered by the wait that ends iteration t - 1).
     if (DROP) mask_words(0, wkn);
     stage(krs, 0, smem0);
     stage(vrs, 0, smem0 + 3 * 8192);
     stage(krs, 1, smem0 + 8192);
     stage(vrs, 1, smem0 + 4 * 8192);
     stage(krs, 2, smem0 + 2 * 8192);
-    if (PIECES == 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(wkn[0]), "+v"(wkn[1]), "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" : "+v"(wkn[0]), "+v"(wkn[1]), "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : : "memory");
+    if (PIECES == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(wkn[0]), "+v"(wkn[1]), "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" : "+v"(wkn[0]), "+v"(wkn[1]), "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : : "memory");
     __builtin_amdgcn_s_barrier();
     wk[0] = wkn[0] >> (4 * hh);
     wk[1] = wkn[1] >> (4 * hh);
     if (ntiles > 0) scores(sa, negm, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // iteration 0 requests K(3) into the slot these reads came from
 
     const int i16 = lane & 15, g16 = lane >> 4;
     auto body = [&](f32x16 (&st)[2], f32x16 (&sn)[2], int t) {

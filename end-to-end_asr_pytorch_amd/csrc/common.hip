@@ -14,3 +14,32 @@ void asr_set_error(const char* fmt, ...) {
 
 extern "C" int asr_version(void) { return 100; }
 extern "C" const char* asr_last_error(void) { return g_err; }
+
+// ---- test support: leave every CU's LDS full of bf16 / f32 NaN patterns -----------------------------------------------------------
+// A kernel that reads an LDS byte before anything it waits for has written it usually goes unnoticed - the bytes are what the previous
+// workgroup of the SAME kernel left there, finite and plausible - until another process shares the GPU (round 3: the pipelined
+// attention forward read K tile 1 one wait too early; two ranks on one GPU turned that into NaN parameters).  The parity tests run the
+// LDS-staged kernels once more behind this launch and require bit-identical results.
+namespace {
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned lds_dyn[];
+    const int words = 160 * 1024 / 4;
+    for (int i = threadIdx.x; i < words; i += 256) lds_dyn[i] = pattern;
+    __syncthreads();
+    if (lds_dyn[(threadIdx.x * 37) % words] != pattern) sink[0] = 1;     // (keeps the stores)
+}
+}  // namespace
+
+extern "C" int asr_debug_poison_lds(void* stream, void* scratch4) {
+    ASR_REQUIRE(scratch4, ASR_ERR_ARG, "debug_poison_lds: a 4-byte device scratch word is required");
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { asr_set_error("debug_poison_lds: %s", hipGetErrorString(e)); return (int)e; }
+        attr = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(2048), dim3(256), 160 * 1024, static_cast<hipStream_t>(stream), 0x7fc07fc0u,
+                       reinterpret_cast<unsigned*>(scratch4));
+    ASR_LAUNCH_CHECK("debug_poison_lds");
+    return 0;
+}

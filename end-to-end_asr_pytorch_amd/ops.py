@@ -690,6 +690,13 @@ def _gemm_tn_f32(a2d, b2d, out, accumulate, colsum_out):
     return out
 
 
+def poison_lds(device="cuda"):
+    """Test support (asr_debug_poison_lds): fill every CU's LDS with NaN patterns on the current stream."""
+    scratch = torch.zeros(1, device=device, dtype=torch.int32)
+    check(lib().asr_debug_poison_lds(_stream(), _p(scratch)), "asr_debug_poison_lds")
+    return scratch
+
+
 # Workspaces of the slab-reduced weight gradient (csrc/wgrad.hip): one per destination buffer, so that launches queued on different
 # streams never share one, address-stable for graph capture.
 TN_SLAB = os.environ.get("ASR_AMD_TN_SLAB", "1") != "0"
