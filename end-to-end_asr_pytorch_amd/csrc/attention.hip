@@ -388,16 +388,37 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
         w[0] = load32_asm(mrs, moff, (unsigned)(2 * t) * (unsigned)lqp * 4u);
         w[1] = load32_asm(mrs, moff, (unsigned)(2 * t + 1) * (unsigned)lqp * 4u);
     };
+    // lane offsets of the fragment reads inside a tile; per tile the ring slot's base is added once per offset and the sum is hidden
+    // from the compiler (which otherwise re-associates it into one add per READ: 70 of the 226 VALU instructions of a tile)
+    unsigned kofs[4], vofs[4];      // K: one per k-step (row = r; + 4096 for the second 32 keys); V^T: [dt][lo/hi] (+ 2048 per key group)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kofs[s] = (unsigned)(r * 128 + (((2 * s + hh) ^ swz2(r)) << 4));
+    {
+        const int i16 = lane & 15, g16 = lane >> 4;
+        const int kb = 4 * hh + (i16 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int col = dt * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+            const int c = col >> 3, sub = (col & 7) * 2;
+            vofs[2 * dt] = (unsigned)(kb * 128 + ((c ^ swz2(kb)) << 4) + sub);
+            vofs[2 * dt + 1] = (unsigned)((kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub);
+        }
+    }
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
     auto scores = [&](f32x16 (&st)[2], const f32x16& negm, int kslot) {
-        const unsigned char* Ks = smem + kslot * 8192;
+        const lds_u8* kp[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            unsigned a = smem0 + (unsigned)kslot * 8192u + kofs[s];
+            asm volatile("" : "+v"(a));
+            kp[s] = (const lds_u8*)(size_t)a;
+        }
         u32x4 kf[2][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int row = hf * 32 + r;
-                kf[hf][s] = *reinterpret_cast<const u32x4*>(Ks + row * 128 + (((2 * s + hh) ^ swz2(row)) << 4));
-            }
+            for (int hf = 0; hf < 2; ++hf)
+                kf[hf][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(kp[s] + hf * 4096);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -432,7 +453,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // iteration 0 requests K(3) into the slot these reads came from
 
-    const int i16 = lane & 15, g16 = lane >> 4;
     auto body = [&](f32x16 (&st)[2], f32x16 (&sn)[2], int t) {
         const int s0 = t % 3, s1 = (t + 1) % 3, s2 = (t + 2) % 3;      // ring slots of tiles t (= t+3), t+1, t+2
         if (DROP) mask_words(t + 1, wkn);
@@ -490,7 +510,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[hf][i] = drop_and(st[hf][i], wk[hf], 8 * (i >> 2) + (i & 3));
         }
-        const unsigned char* Vs = smem + (3 + s0) * 8192;
+        const lds_u8* vp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned a = smem0 + (unsigned)(3 + s0) * 8192u + vofs[i];
+            asm volatile("" : "+v"(a));
+            vp[i] = (const lds_u8*)(size_t)a;
+        }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -498,15 +524,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
                 bf16x8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[hf][8 * s2i + j];
-                const int kb = hf * 32 + 16 * s2i + 4 * hh + (i16 >> 2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const int col = dt * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
-                    const int c = col >> 3, sub = (col & 7) * 2;
-                    const unsigned char* p0 = Vs + kb * 128 + ((c ^ swz2(kb)) << 4) + sub;
-                    const unsigned char* p1 = Vs + (kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub;
-                    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
-                    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+                    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt] + (2 * hf + s2i) * 2048));
+                    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt + 1] + (2 * hf + s2i) * 2048));
                     const u32x2 a = __builtin_bit_cast(u32x2, v0), bb = __builtin_bit_cast(u32x2, v1);
                     const u32x4 vf = {a[0], a[1], bb[0], bb[1]};
                     if (dt == 0)
