@@ -322,8 +322,8 @@ def pmc_traffic(fam_kernel, prof_dir):
     return int(tot / n) if n else None
 
 
-FAMILY_KERNEL = {"vocab_proj_lse": "vocab_proj_lse_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_tr_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
-                 "attention_fwd": "attn_fwd_bf16_v2_kernel", "attention_bwd": "attn_bwd_fused_kernel",
+FAMILY_KERNEL = {"vocab_proj_lse": "vocab_proj_lse_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_v2_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
+                 "attention_fwd": "attn_fwd_bf16_v3_kernel", "attention_bwd": "attn_bwd_fused_kernel",
                  "attention_bwd_dq": "attn_bwd_dq_kernel", "attention_bwd_dkv": "attn_bwd_dkv_kernel",
                  "add_layernorm": "add_layernorm_fwd_kernel", "add_layernorm_bwd": "add_layernorm_bwd_kernel",
                  "ctc_loss_fwd": "ctc_fused_fwd_kernel", "ctc_loss_bwd": "ctc_grad_bf16_kernel", "proj_heads": "gemm_nt_glds_kernel"}

@@ -50,6 +50,7 @@ SIGNATURES = {
     "asr_add_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dr, _dr],
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i],
     "asr_debug_poison_lds": [_vp, _vp],
+    "asr_set_deterministic": [_i],
     "asr_gemm_tn_ws_bytes": [_i, _i, _i, _i],
     "asr_gemm_tn_ws": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _i],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],

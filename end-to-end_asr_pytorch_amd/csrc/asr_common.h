@@ -20,6 +20,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ---- error plumbing (thread-local message, no exceptions across the ABI) ------------------------------------
 void asr_set_error(const char* fmt, ...);
+int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
     do {                                  \
         if (!(cond)) {                    \

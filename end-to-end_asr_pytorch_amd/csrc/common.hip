@@ -1,6 +1,8 @@
 // Error string + version for libasr_hip.so.
 #include <stdarg.h>
 
+#include <stdlib.h>
+
 #include "asr_common.h"
 
 static thread_local char g_err[512] = "";
@@ -14,6 +16,15 @@ void asr_set_error(const char* fmt, ...) {
 
 extern "C" int asr_version(void) { return 100; }
 extern "C" const char* asr_last_error(void) { return g_err; }
+
+// deterministic mode: kernels that would otherwise combine partial results with float atomics in arrival order (the forward GEMMs'
+// split-K, the weight gradient's bias side product) take their single-writer form
+static int g_deterministic = -1;
+int asr_deterministic() {
+    if (g_deterministic < 0) { const char* e = getenv("ASR_AMD_DETERMINISTIC"); g_deterministic = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_deterministic;
+}
+extern "C" int asr_set_deterministic(int on) { const int old = asr_deterministic(); g_deterministic = on ? 1 : 0; return old; }
 
 // ---- test support: leave every CU's LDS full of bf16 / f32 NaN patterns -----------------------------------------------------------
 // A kernel that reads an LDS byte before anything it waits for has written it usually goes unnoticed - the bytes are what the previous

@@ -1148,7 +1148,7 @@ int pick_ksplit(const EpiDense& e, int ntiles, int K) {
     static const bool off = getenv("ASR_AMD_SPLITK") && atoi(getenv("ASR_AMD_SPLITK")) == 0;
     static const int max_tiles = getenv("ASR_AMD_SPLITK_TILES") ? atoi(getenv("ASR_AMD_SPLITK_TILES")) : 64;
     const int nk = K / 64;
-    if (off || !e.wide_ok || e.c_dtype != ASR_F32 || (e.flags & ASR_GEMM_RELU) || e.relu_mask || e.bits_in || e.bits_out ||
+    if (off || asr_deterministic() || !e.wide_ok || e.c_dtype != ASR_F32 || (e.flags & ASR_GEMM_RELU) || e.relu_mask || e.bits_in || e.bits_out ||
         e.N % BN != 0 || e.ldc != e.N || ntiles > max_tiles || nk < 8 || (const void*)e.addend == (const void*)e.C)
         return 1;
     int sp = nk / 4;                       // >= 4 K-tiles per split

@@ -344,6 +344,8 @@ static void tn_v2_plan(int M, int N, int K, int max_workgroups, int* tiles_out, 
     const int max_splits = (M + min_rows - 1) / min_rows;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
+    static const int one_rows = getenv("ASR_AMD_TN2_ONE") ? atoi(getenv("ASR_AMD_TN2_ONE")) : 2048;
+    if (M <= one_rows) splits = 1;        // a few dozen reduction steps (the decoder's 1632 rows): one launch, no slab, no second kernel
     if (splits >= 8) splits = splits / 8 * 8;
     const int mps = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (splits < 8) splits = (M + mps - 1) / mps;
@@ -373,7 +375,7 @@ extern "C" int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const vo
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bm; a.C = C; a.colsum = colsum;
     a.slab = reinterpret_cast<float*>(workspace);
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.tiles_k = K / 128;
-    a.accumulate = accumulate; a.cs_all = deterministic ? 1 : 0;
+    a.accumulate = accumulate; a.cs_all = (deterministic || asr_deterministic()) ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(gemm_tn_v2_kernel, dim3(tiles * a.splits), dim3(256), 0, s, a);
     ASR_LAUNCH_CHECK("gemm_tn_v2");

@@ -690,6 +690,13 @@ def _gemm_tn_f32(a2d, b2d, out, accumulate, colsum_out):
     return out
 
 
+def set_deterministic(on):
+    """asr_set_deterministic: single-writer forms instead of float atomics in arrival order (forward split-K GEMMs, bias gradients)."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    return bool(lib().asr_set_deterministic(1 if on else 0))
+
+
 def poison_lds(device="cuda"):
     """Test support (asr_debug_poison_lds): fill every CU's LDS with NaN patterns on the current stream."""
     scratch = torch.zeros(1, device=device, dtype=torch.int32)

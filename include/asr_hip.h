@@ -61,6 +61,10 @@ int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, in
 #define ASR_GEMM_C_IS_ZERO 4u   /* the caller's C is already all zeros: a split-K launch (few output tiles, long K) skips its zeroing kernel */
 
 int asr_version(void);
+/* Deterministic mode (also ASR_AMD_DETERMINISTIC=1 in the environment): the forward GEMMs stop splitting K across workgroups (float
+ * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
+ * (asr_gemm_tn_ws) is order-fixed in either mode.  Returns the previous setting. */
+int asr_set_deterministic(int on);
 /* Test support: one launch that leaves all 160 KiB of every CU's LDS filled with NaN bit patterns (0x7fc07fc0), so that a kernel
  * reading LDS bytes it has not yet been handed shows up deterministically (tests/test_gpu_lds_poison.py).  scratch4: 4 device bytes. */
 int asr_debug_poison_lds(void* stream, void* scratch4);

@@ -127,6 +127,19 @@ def test_model_full_size_utterances_do_not_interact():
         # the last bf16 bit of a few activations, varies from launch to launch - independence holds to that noise, not bit for bit
         assert torch.allclose(dec0[b], dec1[b], rtol=2e-2, atol=2e-2)
     assert not torch.equal(ctc0[5], ctc1[5]) and not torch.allclose(dec0[5], dec1[5], rtol=2e-2, atol=2e-2)
+    # deterministic mode (asr_set_deterministic): no split-K atomics - the decoder's logits are independent of the neighbours bit for bit
+    from asr_amd import ops
+    old = ops.set_deterministic(True)
+    try:
+        with torch.no_grad():
+            _, _, (d0, _) = model(x, lens, tg)
+            _, _, (d1, _) = model(x2, lens, tg)
+            _, _, (d2, _) = model(x, lens, tg)
+    finally:
+        ops.set_deterministic(old)
+    assert torch.equal(d0, d2)
+    for b in (0, 1, 2, 9):
+        assert torch.equal(d0[b], d1[b])
 
 
 @pytest.mark.parametrize("which", ["s1", "s2", "s1-fused-ffn"])
