@@ -87,6 +87,13 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // ds_read_b64_tr_b16 transposed reads of PV (4 consecutive keys x 64 bytes).  The DMA destination is lane-linear, so the swizzle is
 // applied to each lane's SOURCE chunk.  Keys past k_len are clamped to the last valid row (their probabilities are masked to 0).
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+#ifdef ATTN_STAMP
+// diagnostic build (tools/stamp_attn.py): per wave, cycle sums of the phases of the v3 forward's iterations
+__device__ unsigned long long* g_attn_stamps_dev = nullptr;
+#define ATTN_TS(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ATTN_TS(x) do { } while (0)
+#endif
 __device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
 // KS = 2 / 4 (few queries, many keys: the decoder's cross attention, Lq = 51 against Lk = 1000): the NW waves are NW/KS query groups x
@@ -419,6 +426,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
                 kf[hf][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(kp[s] + hf * 4096);
+        __builtin_amdgcn_sched_barrier(0);      // all 8 reads in flight before the first MFMA waits: one LDS round trip per tile, not four
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -453,12 +461,32 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // iteration 0 requests K(3) into the slot these reads came from
 
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;
+    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)acc_a; (void)acc_b; (void)acc_c; (void)acc_d;
     auto body = [&](f32x16 (&st)[2], f32x16 (&sn)[2], int t) {
         const int s0 = t % 3, s1 = (t + 1) % 3, s2 = (t + 2) % 3;      // ring slots of tiles t (= t+3), t+1, t+2
+        ATTN_TS(ts0);
         if (DROP) mask_words(t + 1, wkn);
         stage(krs, t + 3, smem0 + s0 * 8192);
         stage(vrs, t + 2, smem0 + (3 + s2) * 8192);
         scores(sn, negm, s1);       // (past the last tile: zeros / a dead slot, never looked at)
+        ATTN_TS(ts1);
+        const lds_u8* vp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned a = smem0 + (unsigned)(3 + s0) * 8192u + vofs[i];
+            asm volatile("" : "+v"(a));
+            vp[i] = (const lds_u8*)(size_t)a;
+        }
+        u32x2 va[4][2][2];          // V^T fragment halves [group (hf, s2)][dt][rows +0..3 / +8..11]: in flight under the softmax VALU
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi)
+                    va[g][dt][hi] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt + hi] + g * 2048)));
+        __builtin_amdgcn_sched_barrier(0);
         const int key0 = t * 64;
         float mloc = -INFINITY;
         if (key0 + 64 <= kl) {
@@ -476,9 +504,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
                     mloc = fmaxf(mloc, st[hf][i]);
                 }
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const bool move = (first && mloc > -INFINITY) || mloc > MAXLAG;
-        if (__builtin_amdgcn_ballot_w64(move)) {          // rare: the next tile's scores were formed against the old reference too
+        // mloc: the maximum over THIS lane's 32 keys; the other 32 of the query sit on lane ^ 32.  The exchange (an LDS round trip)
+        // happens only inside the rare branch: any lane whose half-maximum calls for a move takes the whole wave there
+        if (__builtin_amdgcn_ballot_w64((first && mloc > -INFINITY) || mloc > MAXLAG)) {
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const bool move = (first && mloc > -INFINITY) || mloc > MAXLAG;
             const float delta = move ? mloc : 0.f;
             const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
@@ -489,8 +519,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; negm[i] -= delta; }
             mref += delta;
+            first = first && !(mloc > -INFINITY);
         }
-        first = first && !(mloc > -INFINITY);
         f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
@@ -501,22 +531,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
                 st[hf][i + 1] = p1;
                 rs2 += f32x2{p0, p1};
             }
-        float rs = rs2[0] + rs2[1];
-        rs += __shfl_xor(rs, 32, 64);
-        l += rs;
+        l += rs2[0] + rs2[1];       // this lane's half of the row sum; the halves meet once, after the loop
         if (DROP) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[hf][i] = drop_and(st[hf][i], wk[hf], 8 * (i >> 2) + (i & 3));
         }
-        const lds_u8* vp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned a = smem0 + (unsigned)(3 + s0) * 8192u + vofs[i];
-            asm volatile("" : "+v"(a));
-            vp[i] = (const lds_u8*)(size_t)a;
-        }
+        ATTN_TS(ts2);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -526,20 +548,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[hf][8 * s2i + j];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt] + (2 * hf + s2i) * 2048));
-                    const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt + 1] + (2 * hf + s2i) * 2048));
-                    const u32x2 a = __builtin_bit_cast(u32x2, v0), bb = __builtin_bit_cast(u32x2, v1);
-                    const u32x4 vf = {a[0], a[1], bb[0], bb[1]};
+                    const int g = 2 * hf + s2i;
+                    const u32x4 vf = {va[g][dt][0][0], va[g][dt][0][1], va[g][dt][1][0], va[g][dt][1][1]};
                     if (dt == 0)
                         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
                     else
                         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
                 }
             }
-        // K(t+2), V(t+1) and the next mask words are older than this iteration's 2 * PIECES requests
+        ATTN_TS(ts3);
+        // the requests of iteration t - 1 (K(t+2), V(t+1)) and the next mask words are older than this iteration's 2 * PIECES requests
         if (PIECES == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
         __builtin_amdgcn_s_barrier();
+        ATTN_TS(ts4);
+#ifdef ATTN_STAMP
+        acc_a += ts1 - ts0; acc_b += ts2 - ts1; acc_c += ts3 - ts2; acc_d += ts4 - ts3;
+#endif
         wk[0] = wkn[0] >> (4 * hh);
         wk[1] = wkn[1] >> (4 * hh);
     };
@@ -548,7 +573,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
         if (t + 1 < ntiles) body(sb, sa, t + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // out-of-range requests of the last iterations: nothing may land after the workgroup's LDS is released
+#ifdef ATTN_STAMP
+    if (g_attn_stamps_dev && lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = g_attn_stamps_dev + (blockIdx.x * 4 + wave) * 4;
+        o[0] = acc_a; o[1] = acc_b; o[2] = acc_c; o[3] = acc_d;
+    }
+#endif
 
+    l += __shfl_xor(l, 32, 64);
     if (qrow < Lq) {
         const float inv = (DROP ? drop_scale(drop) : 1.f) / l;
         bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
@@ -640,6 +672,11 @@ template <int NW, int KS = 1> int launch_bf16(hipStream_t s, const void* q, cons
 }
 
 }  // namespace
+
+#ifdef ATTN_STAMP
+// diagnostic hook of the -DATTN_STAMP build (tools/stamp_attn.py; not part of the product library or of include/asr_hip.h)
+extern "C" void asr_attn_debug_stamps(void* buf) { hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps_dev), &buf, sizeof(buf)); }
+#endif
 
 extern "C" int64_t asr_attention_dropmask_words(int B, int h, int Lq, int Lk) { return 2 * drop_mk_words(B * h, Lq, Lk); }
 

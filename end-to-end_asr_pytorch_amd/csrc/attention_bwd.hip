@@ -134,6 +134,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     if (qok && hh == 0 && kh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
 
     f32x16 a0 = zero16(), a1 = zero16();
+    f32x16 neglse, zeros = zero16();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) neglse[i] = -my_lse2;
+    asm volatile("" : "+v"(neglse), "+v"(zeros));      // kept in registers: rematerialised they are the 64 v_mov again
     auto stage = [&](int buf, int it) {      // each key stream's waves stage their own tile
         const int t = it * KS + kh;
         dma_tile<PIECES>(smem + (buf * KS + kh) * 16384, Kb, 64, t * 64, kl, wave, lane);
@@ -156,14 +160,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
         const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32) && (q0 + wave * 32 + 31 < Lq);
         f32x16 st[2], dp[2];
         // the score accumulators start at -lse of this lane's query (-inf for a masked key on an edge tile): exp2 of the finished
-        // product is the probability, no subtraction and no select per element (the compiler had merged the interior / edge branches
-        // of the previous form into one path with a compare + select per element; both halves under ONE branch keeps it a branch)
-        if (interior) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) st[hf][i] = -my_lse2;
-        } else {
+        // product is the probability, no subtraction and no select per element.  On interior tiles that start value is the C operand
+        // of the first MFMA of each chain - a persistent register set (neglse, zero16) instead of 64 v_mov per tile in a VALU-bound loop
+        if (!interior) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -175,12 +174,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            dp[hf] = zero16();
             const int row = hf * 32 + r;
+            if (interior) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
-                dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Vs, row, s, hh), dof[s], dp[hf], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Ks, row, s, hh), qf[s], s == 0 ? neglse : st[hf], 0, 0, 0);
+                    dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Vs, row, s, hh), dof[s], s == 0 ? zeros : dp[hf], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Ks, row, s, hh), qf[s], st[hf], 0, 0, 0);
+                    dp[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows2(Vs, row, s, hh), dof[s], s == 0 ? zeros : dp[hf], 0, 0, 0);
+                }
             }
             if (DROP) {   // dP = dropout mask * (dO . V^T); the 1/keep scale rides on the fma below
 #pragma unroll

@@ -50,6 +50,44 @@ __global__ __launch_bounds__(256) void probe(int mode, int iters, unsigned long 
             c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
         }
         for (int i = 0; i < 4; ++i) acc0[i] += c0[i] + c1[i] + c2[i] + c3[i];
+    } else if (mode == 7) {      // mfma + 6 v_exp (independent destinations)
+        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        for (int i = 0; i < iters; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+            asm volatile("v_exp_f32 %0, %6\n\tv_exp_f32 %1, %6\n\tv_exp_f32 %2, %6\n\tv_exp_f32 %3, %6\n\tv_exp_f32 %4, %6\n\tv_exp_f32 %5, %6" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4), "=v"(e5) : "v"(x));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+            asm volatile("v_exp_f32 %0, %6\n\tv_exp_f32 %1, %6\n\tv_exp_f32 %2, %6\n\tv_exp_f32 %3, %6\n\tv_exp_f32 %4, %6\n\tv_exp_f32 %5, %6" : "=v"(e0), "=v"(e1), "=v"(e2), "=v"(e3), "=v"(e4), "=v"(e5) : "v"(x));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 8) {      // mfma + 12 independent v_add (6 chains of 2)
+        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        for (int i = 0; i < iters; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+            asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+            asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 9) {      // 24 independent v_add only (no mfma): the VALU-only cost of mode 8
+        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x));
+            asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 10) {      // phase-separated: 8 mfma back to back, then 48 independent v_add (attention v2's shape)
+        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        for (int i = 0; i < iters / 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
     } else {   // mode 3: MFMA with 6 independent VALU in its shadow
         for (int i = 0; i < iters; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
@@ -71,10 +109,10 @@ int main(int argc, char** argv) {
     unsigned long long* out; float* sink;
     hipMalloc(&out, blocks * 16); hipMalloc(&sink, 4);
     unsigned long long* h = (unsigned long long*)malloc(blocks * 16);
-    const char* names[] = {"mfma x2 (2 chains) / iter", "16 dependent v_add / iter", "16 v_exp / iter", "2 x (mfma + 6 v_add) / iter", "mfma x2 (1 chain) / iter", "mfma x4 (4 chains) / iter", "mfma16x16x32 x4 (4 chains)"};
+    const char* names[] = {"mfma x2 (2 chains) / iter", "16 dependent v_add / iter", "16 v_exp / iter", "2 x (mfma + 6 v_add) / iter", "mfma x2 (1 chain) / iter", "mfma x4 (4 chains) / iter", "mfma16x16x32 x4 (4 chains)", "2 x (mfma + 6 v_exp)", "2 x (mfma + 12 indep v_add)", "24 indep v_add", "[8 mfma, then 96 indep v_add] / 4 iters"};
     const int threads = argc > 2 ? atoi(argv[2]) : 256;
     for (int waves = 1; waves <= 2; ++waves)
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 11; ++mode) {
         const int iters = 20000;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 2; ++rep) {
