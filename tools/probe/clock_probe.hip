@@ -88,6 +88,56 @@ __global__ __launch_bounds__(256) void probe(int mode, int iters, unsigned long 
                 asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %6\n\tv_add_f32 %2, %2, %6\n\tv_add_f32 %3, %3, %6\n\tv_add_f32 %4, %4, %6\n\tv_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x));
         }
         y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 11) {
+        float e0 = 1, e1 = 2, e2 = 3, e3 = 4, e4 = 5, e5 = 6;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %6, %7\n\tv_max3_f32 %3, %3, %6, %7\n\tv_max3_f32 %4, %4, %6, %7\n\tv_max3_f32 %5, %5, %6, %7" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+            asm volatile("v_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %1, %1, %6, %7\n\tv_max3_f32 %2, %2, %6, %7\n\tv_max3_f32 %3, %3, %6, %7\n\tv_max3_f32 %4, %4, %6, %7\n\tv_max3_f32 %5, %5, %6, %7" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 12) {
+        float e0 = 1, e1 = 2, e2 = 3, e3 = 4, e4 = 5, e5 = 6;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_bfe_i32 %0, %0, 3, 1\n\tv_bfe_i32 %1, %1, 3, 1\n\tv_bfe_i32 %2, %2, 3, 1\n\tv_bfe_i32 %3, %3, 3, 1\n\tv_bfe_i32 %4, %4, 3, 1\n\tv_bfe_i32 %5, %5, 3, 1" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+            asm volatile("v_bfe_i32 %0, %0, 3, 1\n\tv_bfe_i32 %1, %1, 3, 1\n\tv_bfe_i32 %2, %2, 3, 1\n\tv_bfe_i32 %3, %3, 3, 1\n\tv_bfe_i32 %4, %4, 3, 1\n\tv_bfe_i32 %5, %5, 3, 1" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 13) {
+        float e0 = 1, e1 = 2, e2 = 3, e3 = 4, e4 = 5, e5 = 6;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_and_b32 %0, %0, %6\n\tv_and_b32 %1, %1, %6\n\tv_and_b32 %2, %2, %6\n\tv_and_b32 %3, %3, %6\n\tv_and_b32 %4, %4, %6\n\tv_and_b32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+            asm volatile("v_and_b32 %0, %0, %6\n\tv_and_b32 %1, %1, %6\n\tv_and_b32 %2, %2, %6\n\tv_and_b32 %3, %3, %6\n\tv_and_b32 %4, %4, %6\n\tv_and_b32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 14) {
+        float e0 = 1, e1 = 2, e2 = 3, e3 = 4, e4 = 5, e5 = 6;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_cvt_pk_bf16_f32 %0, %0, %6\n\tv_cvt_pk_bf16_f32 %1, %1, %6\n\tv_cvt_pk_bf16_f32 %2, %2, %6\n\tv_cvt_pk_bf16_f32 %3, %3, %6\n\tv_cvt_pk_bf16_f32 %4, %4, %6\n\tv_cvt_pk_bf16_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %0, %6\n\tv_cvt_pk_bf16_f32 %1, %1, %6\n\tv_cvt_pk_bf16_f32 %2, %2, %6\n\tv_cvt_pk_bf16_f32 %3, %3, %6\n\tv_cvt_pk_bf16_f32 %4, %4, %6\n\tv_cvt_pk_bf16_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 15) {
+        float e0 = 1, e1 = 2, e2 = 3, e3 = 4, e4 = 5, e5 = 6;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_mov_b32 %0, %6\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %6\n\tv_mov_b32 %4, %6\n\tv_mov_b32 %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+            asm volatile("v_mov_b32 %0, %6\n\tv_mov_b32 %1, %6\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %6\n\tv_mov_b32 %4, %6\n\tv_mov_b32 %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 16) {
+        float e0 = 1, e1 = 2, e2 = 3, e3 = 4, e4 = 5, e5 = 6;
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_fma_f32 %0, %0, %6, %7\n\tv_fma_f32 %1, %1, %6, %7\n\tv_fma_f32 %2, %2, %6, %7\n\tv_fma_f32 %3, %3, %6, %7\n\tv_fma_f32 %4, %4, %6, %7\n\tv_fma_f32 %5, %5, %6, %7" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+            asm volatile("v_fma_f32 %0, %0, %6, %7\n\tv_fma_f32 %1, %1, %6, %7\n\tv_fma_f32 %2, %2, %6, %7\n\tv_fma_f32 %3, %3, %6, %7\n\tv_fma_f32 %4, %4, %6, %7\n\tv_fma_f32 %5, %5, %6, %7" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(x), "v"(y));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 17) {
+        typedef __attribute__((ext_vector_type(2))) float f2;
+        f2 e0 = {1, 1}, e1 = {2, 2}, e2 = {3, 3}, e3 = {4, 4}, e4 = {5, 5}, e5 = {6, 6}, xx = {x, x};
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("v_pk_add_f32 %0, %0, %6\n\tv_pk_add_f32 %1, %1, %6\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %6\n\tv_pk_add_f32 %4, %4, %6\n\tv_pk_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(xx));
+            asm volatile("v_pk_add_f32 %0, %0, %6\n\tv_pk_add_f32 %1, %1, %6\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %6\n\tv_pk_add_f32 %4, %4, %6\n\tv_pk_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(xx));
+        }
+        y += e0[0] + e1[0] + e2[1] + e3[0] + e4[1] + e5[0];
     } else {   // mode 3: MFMA with 6 independent VALU in its shadow
         for (int i = 0; i < iters; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
@@ -109,10 +159,10 @@ int main(int argc, char** argv) {
     unsigned long long* out; float* sink;
     hipMalloc(&out, blocks * 16); hipMalloc(&sink, 4);
     unsigned long long* h = (unsigned long long*)malloc(blocks * 16);
-    const char* names[] = {"mfma x2 (2 chains) / iter", "16 dependent v_add / iter", "16 v_exp / iter", "2 x (mfma + 6 v_add) / iter", "mfma x2 (1 chain) / iter", "mfma x4 (4 chains) / iter", "mfma16x16x32 x4 (4 chains)", "2 x (mfma + 6 v_exp)", "2 x (mfma + 12 indep v_add)", "24 indep v_add", "[8 mfma, then 96 indep v_add] / 4 iters"};
+    const char* names[] = {"mfma x2 (2 chains) / iter", "16 dependent v_add / iter", "16 v_exp / iter", "2 x (mfma + 6 v_add) / iter", "mfma x2 (1 chain) / iter", "mfma x4 (4 chains) / iter", "mfma16x16x32 x4 (4 chains)", "2 x (mfma + 6 v_exp)", "2 x (mfma + 12 indep v_add)", "24 indep v_add", "[8 mfma, then 96 indep v_add] / 4 iters", "12 x v_max3_f32 (6 chains)", "12 x v_bfe_i32 (6 chains)", "12 x v_and_b32 (6 chains)", "12 x v_cvt_pk_bf16_f32 (6 chains)", "12 x v_mov_b32 (6 regs)", "12 x v_fma_f32 (6 chains, VOP3)", "12 x v_pk_add_f32 (6 chains)"};
     const int threads = argc > 2 ? atoi(argv[2]) : 256;
     for (int waves = 1; waves <= 2; ++waves)
-    for (int mode = 0; mode < 11; ++mode) {
+    for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < 18; ++mode) {
         const int iters = 20000;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 2; ++rep) {
