@@ -450,10 +450,15 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    rccl_ranks = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)          # every rank counted by the collective itself, not by the environment
+        rccl_ranks = {"ranks": int(ones.item()), "world_size": torch.distributed.get_world_size(),
+                      "backend": torch.distributed.get_backend()}
     graphed = bool(trainer is not None and trainer.graph_active() and (use_graph or (auto_graph and trainer.launch_mode == "graph")))
     launch_timing = trainer.launch_timing if trainer is not None else None
     losses = [float(v) for v in out]
@@ -544,7 +549,7 @@ def main():
             "metric": "fbank frames/sec (%s d256 h4 enc12/dec6, %s)" % (mname.split(":")[1].strip().split(" ")[0], what),
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": workload_name(args, train),
                        "global_batch": world * CFG["B"], "seq_len": CFG["T"], "parallelism": "dp%d" % world,
                        "launch": launch_name(args, graphed, trainer),

@@ -344,8 +344,8 @@ static void tn_v2_plan(int M, int N, int K, int max_workgroups, int* tiles_out, 
     const int max_splits = (M + min_rows - 1) / min_rows;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    static const int one_rows = getenv("ASR_AMD_TN2_ONE") ? atoi(getenv("ASR_AMD_TN2_ONE")) : 2048;
-    if (M <= one_rows) splits = 1;        // a few dozen reduction steps (the decoder's 1632 rows): one launch, no slab, no second kernel
+    // (one launch without a slab for the decoder's 1632 rows - splits = 1, 26 serial steps per workgroup - measured slower than
+    // 4 splits + the reduce launch: 17.1-17.6 vs 12.7-16.3 us)
     if (splits >= 8) splits = splits / 8 * 8;
     const int mps = ((M + splits - 1) / splits + 63) / 64 * 64;
     if (splits < 8) splits = (M + mps - 1) / mps;
