@@ -100,11 +100,9 @@ __device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | 
 // KS key streams - stream kh takes the key tiles t = KS it + kh - and the streams' (reference, row sum, O) states are merged through
 // LDS at the end.  One workgroup per (batch, head) then walks 8 / 4 dependent iterations instead of 16: the walk is pure latency
 // (128 workgroups of 2 waves on a 256-CU chip), so cutting it cuts the kernel.
-#ifndef ATTN_V2_MINB
-#define ATTN_V2_MINB 2
-#endif
+// (3 and 4 resident workgroups per CU instead of 2 - 159 / 128 VGPRs - measured within 1 % of this: the loop is not occupancy-bound)
 template <int NW, bool CAUSAL, bool DROP, int KS = 1>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && KS == 1) ? ATTN_V2_MINB : 2) void attn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                       const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
                                                                       float* __restrict__ lse, int h, int Lq, int Lk,
                                                                       const int32_t* __restrict__ k_len, int q_tiles,
