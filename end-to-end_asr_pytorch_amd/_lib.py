@@ -37,7 +37,6 @@ SIGNATURES = {
     "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr, _vp],
     "asr_attention_dropmask": [_vp, _dr, _i, _i, _i, _i, _vp],
     "asr_attention_dropmask_multi": [_vp, _i, _vp, _vp, _i, _i, _i, _i],
-    "asr_gemm_add_layernorm": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr],
     "asr_gemm_add_layernorm_small": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr],
     "asr_attention_dropmask_words": [_i, _i, _i, _i],
     "asr_graphx_create": [_vp, _i, _vp],

@@ -932,169 +932,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_nn_tr_kernel(const bf16_t* __restr
 }
 
 
-// ---- projection + bias + dropout + residual + LayerNorm in one kernel (N = 256 = d_model; attention.py:58-60, module.py:50-52) ----
-// A 64 x 256 tile gives a workgroup COMPLETE rows.  After the K loop the 64 x 64 accumulators become v = dropout(acc + bias) +
-// residual in place, the row sums meet in LDS across the four column waves (two passes: mean, then variance - like
-// add_layernorm_fwd_kernel), and the three outputs (pre-norm sum s, y32, y16) leave through run_epilogue's LDS-transposed
-// full-cache-line stores.  Against the GEMM + LayerNorm pair this never writes / re-reads the [M, 256] f32 GEMM output and is one
-// launch instead of two.  (Measured: 42 us against 15 + 30 us at K = 256, 102 against 58 + 30 us at K = 2048 - the epilogue is as
-// slow as the separate LayerNorm kernel, with 64-byte residual fragments and three store passes; a 128 x 256-tile, 8-wave version
-// with one workgroup per CU measured the same.  Parity-tested, not used by the models by default.)
-struct LnArgs {
-    const float* bias; const float* res; const float* gamma; const float* beta; const int32_t* row_len;
-    float* s_out; float* y32; bf16_t* y16; float* mean; float* rstd;
-    int L; float eps; asr_dropout_t drop_x;
-};
-// 64 x 256 tiles, 4 waves (one per 64-column quarter), K-tiles of 32 in 20 KiB stages, two workgroups per CU, persistent.
-__global__ __launch_bounds__(256, 2) void gemm_nt_ln64_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ W,
-                                                            int M, int K, int ntiles, LnArgs ln) {
-    ln.drop_x = drop_resolve(ln.drop_x);
-    constexpr int KT = 32, RB = 64, TA = 64 * RB, TW = 256 * RB, STAGE = TA + TW, D = 256;   // 4 + 16 KiB per stage (rows of 32 bf16)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-    __shared__ float red[2][64][4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = 0, wn = wave, r16 = lane & 15, q4 = lane >> 4;
-    const int nk = K / KT;
-    // staging: 20 one-KiB pieces (16 rows x 64 B) per stage, 5 per wave: pieces 0..3 = A rows, 4..19 = W rows; LDS slot (row, pc)
-    // holds the row's 16-byte chunk pc ^ ((row >> 1) & 3): 8 consecutive rows then fill 8 different 16-byte slots of a 256-byte bank row
-    const bf16_t* src[5];
-    int dst[5];
-    auto set_tile = [&](int tile) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int p = wave * 5 + i;
-            const bool isA = p < 4;
-            const int pr = isA ? p : p - 4;
-            const int row = 16 * pr + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 1) & 3);
-            src[i] = isA ? A + (int64_t)min(tile * 64 + row, M - 1) * lda + c * 8 : W + (int64_t)row * K + c * 8;
-            dst[i] = (isA ? 0 : TA) + pr * 1024;
-        }
-    };
-    auto stage = [&](int buf, int kt) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * KT),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + dst[i]), 16, 0, 0);
-    };
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    set_tile(tile);
-    stage(0, 0);
-    int cur = 0;
-    __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int m0 = tile * 64;
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-            const unsigned char* As = smem + cur * STAGE;
-            const unsigned char* Bs = As + TA;
-            {
-                u32x4 a[4], b[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int arow = i * 16 + r16;
-                    a[i] = *reinterpret_cast<const u32x4*>(As + arow * RB + ((q4 ^ ((arow >> 1) & 3)) << 4));
-                    const int brow = wn * 64 + i * 16 + r16;
-                    b[i] = *reinterpret_cast<const u32x4*>(Bs + brow * RB + ((q4 ^ ((brow >> 1) & 3)) << 4));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Mma<bf16_t>::run(b[j], a[i], acc[i][j]);
-            }
-            __syncthreads();
-            cur ^= 1;
-        }
-        // both stage buffers are free now: queue the next tile's first K-tile into `cur`, use the other one as store scratch
-        const bool more = tile + (int)gridDim.x < ntiles;
-        // ---- v = dropout(acc + bias) + residual, in place; row sums ----
-        const float scx = drop_scale(ln.drop_x);
-        float mean_r[4], rstd_r[4];
-        bool keep_r[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + r16, rr = min(row, M - 1);
-            const int b = rr / ln.L, t = rr - b * ln.L;
-            keep_r[i] = ln.row_len ? (t < ln.row_len[b]) : true;
-            const uint32_t subx = ln.drop_x.thr16 ? drop_subkey(ln.drop_x, (uint32_t)b) : 0u;
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = wn * 64 + 16 * j + 4 * q4;
-                f32x4 v = acc[i][j];
-                if (ln.bias) v += *reinterpret_cast<const f32x4*>(ln.bias + c);
-                if (ln.drop_x.thr16) v = drop4(ln.drop_x, subx, (uint32_t)t, D >> 1, c, v, scx);
-                if (ln.res) v += *reinterpret_cast<const f32x4*>(ln.res + (int64_t)rr * D + c);
-                acc[i][j] = v;
-                sum += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            if (q4 == 0) red[0][wm * 64 + i * 16 + r16][wn] = sum;
-        }
-        if (more) {
-            set_tile(tile + gridDim.x);
-            stage(cur, 0);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = wm * 64 + i * 16 + r16;
-            mean_r[i] = ((red[0][rl][0] + red[0][rl][1]) + (red[0][rl][2] + red[0][rl][3])) * (1.f / D);
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 d = acc[i][j] - mean_r[i];
-                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-            }
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
-            if (q4 == 0) red[1][rl][wn] = q;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = wm * 64 + i * 16 + r16, row = m0 + rl;
-            const float var = ((red[1][rl][0] + red[1][rl][1]) + (red[1][rl][2] + red[1][rl][3])) * (1.f / D);
-            rstd_r[i] = 1.0f / sqrtf(var + ln.eps);
-            if (wn == 0 && q4 == 0 && row < M) {
-                if (ln.mean) ln.mean[row] = mean_r[i];
-                if (ln.rstd) ln.rstd[row] = rstd_r[i];
-            }
-        }
-        // ---- outputs through the LDS-transposed wide stores: s (the pre-norm sum), then y in f32 and bf16 ----
-        unsigned char* scratch = smem + (cur ^ 1) * STAGE + wave * 4096;
-        EpiDense es{};
-        es.C = ln.s_out; es.c_dtype = ASR_F32; es.ldc = D; es.M = M; es.N = D; es.vec_ok = true; es.wide_ok = true;
-        run_epilogue(dense_as<0u>(es), acc, m0, 0, wm, wn, r16, q4, scratch);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = wn * 64 + 16 * j + 4 * q4;
-                const f32x4 g = *reinterpret_cast<const f32x4*>(ln.gamma + c), bt = *reinterpret_cast<const f32x4*>(ln.beta + c);
-                f32x4 o = (acc[i][j] - mean_r[i]) * rstd_r[i] * g + bt;
-                if (!keep_r[i]) o = f32x4{0, 0, 0, 0};
-                acc[i][j] = o;
-            }
-        es.C = ln.y32;
-        run_epilogue(dense_as<0u>(es), acc, m0, 0, wm, wn, r16, q4, scratch);
-        if (ln.y16) {
-            es.C = ln.y16; es.c_dtype = ASR_BF16;
-            run_epilogue(dense_as<16u>(es), acc, m0, 0, wm, wn, r16, q4, scratch);
-        }
-        if (more) __syncthreads();   // drains the DMA; scratch and `red` are free again
-    }
-}
-
-
 template <typename AT, typename CT, typename Epi>
 int launch_gemm(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K, const Epi& epi) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -1220,24 +1057,6 @@ extern "C" int asr_gemm_nt(void* stream, const void* A, int a_dtype, int64_t lda
     epi.wide_ok = dense_wide_ok(epi);
     epi.c_is_zero = (flags & ASR_GEMM_C_IS_ZERO) != 0;
     return dispatch(static_cast<hipStream_t>(stream), A, a_dtype, lda, W, w_dtype, ldw, M, N, K, epi);
-}
-
-extern "C" int asr_gemm_add_layernorm(void* stream, const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
-                                      const float* gamma, const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16,
-                                      float* mean, float* rstd, int B, int L, int K, float eps, asr_dropout_t drop_x) {
-    ASR_REQUIRE(A && W && gamma && beta && s_out && y32 && B > 0 && L > 0, ASR_ERR_ARG, "gemm_add_layernorm: null pointer / bad sizes");
-    ASR_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && lda >= K, ASR_ERR_ALIGN, "gemm_add_layernorm: K=%d must be a multiple of 64, lda of 8", K);
-    ASR_REQUIRE(drop_x.thr16 < 65536u, ASR_ERR_ARG, "gemm_add_layernorm: dropout thr16 must be < 65536");
-    ASR_REQUIRE(asr_aligned(A, 16) && asr_aligned(W, 16) && asr_aligned(s_out, 16) && asr_aligned(y32, 16) && asr_aligned(gamma, 16) &&
-                    asr_aligned(beta, 16) && (!bias || asr_aligned(bias, 16)) && (!residual || asr_aligned(residual, 16)) &&
-                    (!y16 || asr_aligned(y16, 16)), ASR_ERR_ALIGN, "gemm_add_layernorm: 16-byte alignment");
-    const int M = B * L, ntiles = (M + 127) / 128;
-    LnArgs ln{bias, residual, gamma, beta, row_len, s_out, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, L, eps, drop_x};
-    const int nt64 = (M + 63) / 64;
-    hipLaunchKernelGGL(gemm_nt_ln64_kernel, dim3(nt64 < 512 ? nt64 : 512), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(W), M, K, nt64, ln);
-    ASR_LAUNCH_CHECK("gemm_add_layernorm");
-    return 0;
 }
 
 extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype, int64_t ldw,

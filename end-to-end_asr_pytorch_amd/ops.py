@@ -240,17 +240,10 @@ def gemm_add_layernorm_small_ok(a2d, w, D, B, L):
             w.dtype == torch.bfloat16 and a2d.shape[1] % 32 == 0 and a2d.shape[1] <= 512 and a2d.is_contiguous() and w.is_contiguous())
 
 
-# the fused kernel for encoder-sized rows (gemm.hip: gemm_nt_ln64_kernel) is parity-tested but no faster than the GEMM + LayerNorm pair
-# yet (42 vs 45 us at K = 256, 102 vs 88 us at K = 2048), so the models use it only on request
-FUSED_LN = int(os.environ.get("ASR_AMD_FUSED_LN", "0"))        # 0: off (default); 1: every shape it takes; 2: K <= 512 only
-
-
 def gemm_add_layernorm_ok(a2d, w, D, B, L):
-    """Shapes the fused projection + LayerNorm kernels take: the small-M one (above) or the 128 x 256-tile one for any M."""
-    if gemm_add_layernorm_small_ok(a2d, w, D, B, L):
-        return True
-    return (FUSED_LN and (FUSED_LN == 1 or a2d.shape[1] <= 512) and B * L > SMALL_FUSED_MAX_ROWS and D == 256 and w.shape[0] == 256 and a2d.dtype == torch.bfloat16 and
-            w.dtype == torch.bfloat16 and a2d.shape[1] % 64 == 0 and a2d.is_contiguous() and w.is_contiguous())
+    """Shapes the fused projection + LayerNorm launch takes (decoder-sized rows; the encoder-sized variant of round 2 was slower than
+    the GEMM + LayerNorm pair and is gone - the encoder's feed-forward sub-layer is ffn_fwd)."""
+    return gemm_add_layernorm_small_ok(a2d, w, D, B, L)
 
 
 def gemm_add_layernorm_small(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=True, eps=1e-5, save_stats=False,
@@ -266,15 +259,15 @@ def gemm_add_layernorm_small(a2d, w, bias, residual, gamma, beta, B, L, row_len=
     y16 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16) if want_bf16 else None
     mean = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
     rstd = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
-    small = gemm_add_layernorm_small_ok(a2d, w, 256, B, L)
-    fn = lib().asr_gemm_add_layernorm_small if small else lib().asr_gemm_add_layernorm
-    with _timed("gemm_add_layernorm%s[%dx256x%d]" % ("_small" if small else "", M, K), 2.0 * M * 256 * K):
-        check(fn(_stream(), _p(a2d), K, _p(w), _p(bias), _p(residual), _p(gamma), _p(beta), _p(row_len),
-                 _p(s_sum), _p(y32), _p(y16), _p(mean), _p(rstd), B, L, K, float(eps), _d(drop_x)), "asr_gemm_add_layernorm")
+    assert gemm_add_layernorm_small_ok(a2d, w, 256, B, L), "gemm_add_layernorm_small: decoder-sized rows only (see gemm_add_layernorm_ok)"
+    with _timed("gemm_add_layernorm_small[%dx256x%d]" % (M, K), 2.0 * M * 256 * K):
+        check(lib().asr_gemm_add_layernorm_small(_stream(), _p(a2d), K, _p(w), _p(bias), _p(residual), _p(gamma), _p(beta), _p(row_len),
+                                                 _p(s_sum), _p(y32), _p(y16), _p(mean), _p(rstd), B, L, K, float(eps), _d(drop_x)),
+              "asr_gemm_add_layernorm_small")
     return s_sum, y32, y16, mean, rstd
 
 
-gemm_add_layernorm = gemm_add_layernorm_small      # one entry: picks the kernel by shape
+gemm_add_layernorm = gemm_add_layernorm_small
 
 
 FUSED_FFN = os.environ.get("ASR_AMD_FUSED_FFN", "1") != "0"          # A/B: 0 = two GEMMs + LayerNorm / two data-gradient GEMMs

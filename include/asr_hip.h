@@ -158,16 +158,13 @@ int asr_attention_bwd_f32(void* stream, const float* q, const float* k, const fl
                           const float* lse, float* dq, int64_t ldq, float* dk, float* dv, int64_t ldkv, int B, int h, int Lq, int Lk,
                           const int32_t* k_len, int causal, float scale);
 
-/* asr_gemm_add_layernorm: the same fused block as asr_gemm_add_layernorm_small below for any M (encoder-sized rows: a persistent
- * kernel of 128 x 256 tiles, K % 64 == 0, outputs through full-cache-line stores).
- * Decoder-sized rows (M = B*L of a few thousand): the projection and the residual + LayerNorm after it in ONE launch,
+/* Decoder-sized rows (M = B*L of a few thousand): the projection and the residual + LayerNorm after it in ONE launch,
  *   s = dropout_x(A . W^T + bias) + residual;  y = LayerNorm(s) * gamma + beta, rows t >= row_len[b] zeroed
  * (attention.py:58-60: fc -> dropout -> + residual -> layer_norm; module.py:50-52 likewise for w_2) for exactly 256 outputs.
  * A bf16 [M,K] (lda), W bf16 [256,K] as stored, K % 32 == 0.  Writes what asr_add_layernorm_fwd(save) writes: s_out (the pre-norm sum),
- * y32, y16 (optional), mean / rstd (optional).  One workgroup owns 16 complete rows and reads the whole weight: meant for M <~ 4096. */
-int asr_gemm_add_layernorm(void* stream, const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
-                           const float* gamma, const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16,
-                           float* mean, float* rstd, int B, int L, int K, float eps, asr_dropout_t drop_x);
+ * y32, y16 (optional), mean / rstd (optional).  One workgroup owns 16 complete rows and reads the whole weight: meant for M <~ 4096.
+ * (The encoder-sized variant of round 2, asr_gemm_add_layernorm, was slower than the GEMM + LayerNorm pair and is gone; the
+ * encoder's feed-forward sub-layer is asr_ffn_fwd.) */
 int asr_gemm_add_layernorm_small(void* stream, const void* A, int64_t lda, const void* W, const float* bias, const float* residual,
                                  const float* gamma, const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16,
                                  float* mean, float* rstd, int B, int L, int K, float eps, asr_dropout_t drop_x);
