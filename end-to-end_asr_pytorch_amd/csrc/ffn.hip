@@ -76,7 +76,10 @@ struct FfnFwdArgs {
     unsigned long long* stamps;      // diagnostic build (-DFFN_STAMP) only: per wave 4 cycle sums (first product, second product, wait + barrier, total)
 };
 
-template <bool TRAIN, bool DROP>
+// PROJ: the attention sub-layer's tail at encoder size (attention.py:58-60: fc -> dropout -> + residual -> layer_norm) on the same
+// prologue and epilogue - w1 = the [256][256] output projection, no activation, no second product: the four 64-row chunks of the first
+// product ARE the 256 outputs of a token, x16 = the attention context, x32 = the residual (the layer's input), b2 = fc's bias.
+template <bool TRAIN, bool DROP, bool PROJ = false>
 __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
     unsigned char* const w1s = smem;
@@ -124,10 +127,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     };
 
     // ---- fragment read addresses -----------------------------------------------------------------------------------------------
-    const int u15 = swap23(r) & 15;
+    const int ur = PROJ ? r : swap23(r);      // (PROJ: the accumulator rows are the outputs themselves, in natural order)
+    const int u15 = ur & 15;
     unsigned a1[8], a2[4];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) a1[kk] = (unsigned)(swap23(r) * 512 + (((2 * kk + h) ^ u15) << 4));
+    for (int kk = 0; kk < 8; ++kk) a1[kk] = (unsigned)(ur * 512 + (((2 * kk + h) ^ u15) << 4));
 #pragma unroll
     for (int sg = 0; sg < 4; ++sg) a2[sg] = (unsigned)(r * 128 + (((2 * sg + h) ^ ((r >> 1) & 7)) << 4));
 
@@ -138,7 +142,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
     }
-    for (int i = tid * 4; i < dff; i += 1024) *reinterpret_cast<f32x4*>(b1s + i) = *reinterpret_cast<const f32x4*>(a.b1 + i);
+    if (!PROJ)
+        for (int i = tid * 4; i < dff; i += 1024) *reinterpret_cast<f32x4*>(b1s + i) = *reinterpret_cast<const f32x4*>(a.b1 + i);
 
 #pragma unroll
     for (int j = 0; j < 8; ++j) dma_w1(0, 0, j);
@@ -275,6 +280,51 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             for (int sg = 0; sg < 4; ++sg) Hf[sg] = Hn[sg];
         }
     };
+    // The epilogue's residual rows (row layout: lane = 4 columns of a token row, 32 rows per wave) are requested from inside the LAST
+    // body, one per MFMA step - a half-iteration + barrier ahead of their use, all 32 in flight at once.  (Fetched batch by batch
+    // inside the epilogue every batch paid an HBM round trip queued behind the previous batch's stores.)  The row-mask bits too:
+    // a load of row_len[b] per row in the epilogue was a dependent global load + wait per row, ~1000 cycles each.
+    uint32_t keepmask = 0xffffffffu;
+    const int m0c = m0 < a.M ? m0 : a.M - 1;
+    const int b_first = m0c / a.L, t_first = m0c - b_first * a.L;      // (one division; rows advance from here)
+    if (a.row_len) {
+        keepmask = 0;
+        int bb = b_first, tt = t_first, len = a.row_len[bb];
+        for (int tr = 0; tr < 32; ++tr) {
+            keepmask |= (tt < len ? 1u : 0u) << tr;
+            if (++tt == a.L) {
+                tt = 0;
+                if (m0 + tr + 1 < a.M) len = a.row_len[++bb];
+            }
+        }
+    }
+    if constexpr (PROJ) {
+        // four chunks of the projection through the two W1 buffers: 128 MFMAs, 2 us of a launch that is its epilogue
+        auto chunk = [&](auto C) {
+            constexpr int c = decltype(C)::value;
+            const unsigned char* w1 = w1s + (c & 1) * W1BUF;
+            if constexpr (c + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dma_w1((c + 1) & 1, c + 1, j);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;
+                    res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                Y[2 * c + (k & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag1(w1, k), xb[k >> 1], Y[2 * c + (k & 1)], 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+    } else {
     body(0, std::true_type{}, std::false_type{});
     FFN_WAIT_STAGE(1);
 #ifdef FFN_STAMP
@@ -300,25 +350,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
 #ifdef FFN_STAMP
     const unsigned long long ts_loop_end = t0;
 #endif
-    // The epilogue's residual rows (row layout: lane = 4 columns of a token row, 32 rows per wave) are requested from inside the LAST
-    // body, one per MFMA step - a half-iteration + barrier ahead of their use, all 32 in flight at once.  (Fetched batch by batch
-    // inside the epilogue every batch paid an HBM round trip queued behind the previous batch's stores.)  The row-mask bits too:
-    // a load of row_len[b] per row in the epilogue was a dependent global load + wait per row, ~1000 cycles each.
-    uint32_t keepmask = 0xffffffffu;
-    const int m0c = m0 < a.M ? m0 : a.M - 1;
-    const int b_first = m0c / a.L, t_first = m0c - b_first * a.L;      // (one division; rows advance from here)
-    if (a.row_len) {
-        keepmask = 0;
-        int bb = b_first, tt = t_first, len = a.row_len[bb];
-        for (int tr = 0; tr < 32; ++tr) {
-            keepmask |= (tt < len ? 1u : 0u) << tr;
-            if (++tt == a.L) {
-                tt = 0;
-                if (m0 + tr + 1 < a.M) len = a.row_len[++bb];
-            }
-        }
-    }
     body(NC, std::false_type{}, std::true_type{});
+    }
 #ifdef FFN_STAMP
     unsigned long long ts_last;
     __builtin_amdgcn_sched_barrier(0);
@@ -682,6 +715,30 @@ extern "C" int asr_ffn_fwd(void* stream, const void* x16, const float* x32, cons
     else if (dr) hipLaunchKernelGGL((ffn_fwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((ffn_fwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_ffn_fwd");
+    return 0;
+}
+
+extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,
+                               const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16, float* mean_out,
+                               float* rstd_out, int B, int L, int d_model, float eps, asr_dropout_t drop_x) {
+    const int64_t M64 = (int64_t)B * L;
+    ASR_REQUIRE(d_model == FD, -1, "asr_proj_ln_fwd: d_model = %d (built for 256 = h * d_v inputs and 256 outputs)", d_model);
+    ASR_REQUIRE(M64 > 0 && M64 * FD * 4 < (1ll << 31), -1, "asr_proj_ln_fwd: B * L out of range");
+    ASR_REQUIRE(ctx16 && residual && w && bias && gamma && beta && y32, -1, "asr_proj_ln_fwd: null argument");
+    ASR_REQUIRE(s_out || (!mean_out && !rstd_out), -1, "asr_proj_ln_fwd: mean_out / rstd_out come with s_out (training)");
+    ASR_REQUIRE(asr_aligned(ctx16, 16) && asr_aligned(residual, 16) && asr_aligned(w, 16) && asr_aligned(y32, 16) && asr_aligned(s_out, 16) &&
+                    asr_aligned(y16, 8) && asr_aligned(bias, 16) && asr_aligned(gamma, 16) && asr_aligned(beta, 16), -1,
+                "asr_proj_ln_fwd: 16-byte aligned buffers required");
+    const int M = (int)M64;
+    FfnFwdArgs a{(const bf16_t*)ctx16, residual, (const bf16_t*)w, nullptr, nullptr, bias, gamma, beta, row_len, nullptr, nullptr, s_out, y32,
+                 (bf16_t*)y16, mean_out, rstd_out, M, L, FD, (M + FBM - 1) / FBM * FBM, eps, drop_x, 0, nullptr};
+    const dim3 grid((M + FBM - 1) / FBM), block(256);
+    const bool dr = drop_x.thr16 != 0;
+    if (s_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (s_out) hipLaunchKernelGGL((ffn_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (dr) hipLaunchKernelGGL((ffn_fwd_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((ffn_fwd_kernel<false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+    ASR_LAUNCH_CHECK("asr_proj_ln_fwd");
     return 0;
 }
 

@@ -400,6 +400,10 @@ class MultiheadAttention(_Cached):
             o, y32, y16, mean, rstd = ops.gemm_add_layernorm(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
                                                                    self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps,
                                                                    save_stats=rec, drop_x=dp_fc)
+        elif _PRECISION == "bf16" and ops.proj_ln_ok(ctx2, wfc, xq.f32.shape[1], B, Lq):      # the same at encoder size (csrc/ffn.hip, PROJ)
+            o, y32, y16, mean, rstd = ops.proj_ln(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
+                                                  self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps, save_stats=rec,
+                                                  drop_x=dp_fc)
         else:
             o = ops.gemm_nt(ctx2, wfc, self._b("bfc", (self.fc.bias,)))
             y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,

@@ -270,6 +270,33 @@ def gemm_add_layernorm_small(a2d, w, bias, residual, gamma, beta, B, L, row_len=
 gemm_add_layernorm = gemm_add_layernorm_small
 
 
+PROJ_LN = os.environ.get("ASR_AMD_PROJ_LN", "1") != "0"              # A/B: 0 = output projection GEMM + LayerNorm launch at encoder size
+
+
+def proj_ln_ok(a2d, w, D, B, L):
+    """Shapes asr_proj_ln_fwd takes: encoder-sized rows (the decoder's go through gemm_add_layernorm_small), 256 -> 256."""
+    return (PROJ_LN and B * L >= FUSED_FFN_MIN_ROWS and D == 256 and tuple(w.shape) == (256, 256) and a2d.dtype == torch.bfloat16 and
+            w.dtype == torch.bfloat16 and a2d.shape[1] == 256 and a2d.is_contiguous() and w.is_contiguous() and B * L * 1024 < 2 ** 31)
+
+
+def proj_ln(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=True, eps=1e-5, save_stats=False, drop_x=None):
+    """LayerNorm(dropout_x(A . W^T + bias) + residual) for encoder-sized rows in one launch (asr_hip.h: asr_proj_ln_fwd).
+    -> (s_sum [M,256] pre-norm sum or None, y32, y16 or None, mean, rstd): the tensors of the gemm_nt + add_layernorm pair."""
+    _req_cuda(a2d, w, bias, residual, gamma, beta, row_len)
+    M = a2d.shape[0]
+    assert M == B * L and residual.is_contiguous()
+    dev = a2d.device
+    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32) if save_stats else None
+    y32 = torch.empty((M, 256), device=dev, dtype=torch.float32)
+    y16 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16) if want_bf16 else None
+    mean = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
+    with _timed("proj_ln[%dx256x256]" % M, 2.0 * M * 256 * 256):
+        check(lib().asr_proj_ln_fwd(_stream(), _p(a2d), _p(residual), _p(w), _p(bias), _p(gamma), _p(beta), _p(row_len), _p(s_sum), _p(y32),
+                                    _p(y16), _p(mean), _p(rstd), B, L, 256, float(eps), _d(drop_x)), "asr_proj_ln_fwd")
+    return s_sum, y32, y16, mean, rstd
+
+
 FUSED_FFN = os.environ.get("ASR_AMD_FUSED_FFN", "1") != "0"          # A/B: 0 = two GEMMs + LayerNorm / two data-gradient GEMMs
 FUSED_FFN_MIN_ROWS = int(os.environ.get("ASR_AMD_FUSED_FFN_ROWS", "4096"))     # below: a 128-token block per CU leaves most of the chip idle
 

@@ -196,6 +196,14 @@ int asr_ffn_fwd(void* stream, const void* x16, const float* x32, const void* w1,
                 float* y32, void* y16, float* mean_out, float* rstd_out, int B, int L, int d_model, int d_ff, float eps,
                 asr_dropout_t drop_x);
 
+/* The attention sub-layer's tail at encoder size in one launch (attention.py:58-60: fc -> dropout -> + residual -> layer_norm;
+ * encoder.py:77's row mask): y = LayerNorm(dropout_x(ctx . W^T + bias) + residual) * gamma + beta, rows t >= row_len[b] zeroed.
+ * ctx16 bf16 [B*L, 256] (the attention context, h * d_v = 256), w bf16 [256, 256] as stored, residual f32 [B*L, 256].  Same workgroup
+ * shape, prologue and epilogue as asr_ffn_fwd (the projection is that kernel's first product over four 64-row chunks of w); writes
+ * what asr_add_layernorm_fwd(save) writes: s_out (pre-norm sum, training) / mean_out / rstd_out (training), y32, y16 (optional). */
+int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,
+                    const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16, float* mean_out, float* rstd_out,
+                    int B, int L, int d_model, float eps, asr_dropout_t drop_x);
 /* Data gradient of the same sub-layer in ONE launch (autograd of module.py:50-52 below the LayerNorm):
  *   dH = (ds16 . W2) * [h > 0]  (bits from asr_ffn_fwd);   dx = dH . W1 + ds32.
  * ds16 bf16 [M, 256]: the gradient wrt w_2's output (asr_add_layernorm_bwd's ds16); ds32 f32 [M, 256]: the gradient wrt the residual.

@@ -124,3 +124,37 @@ def test_module_with_fused_ffn_equals_separate_launches(monkeypatch):
     assert rel(dx1, dx0) < 2e-2
     for n in g0:
         assert rel(g1[n], g0[n]) < 3e-2, n
+
+
+@pytest.mark.parametrize("B,L,drop", [(32, 250, True), (5, 1000, False), (33, 129, True)])
+def test_proj_ln_equals_the_gemm_and_layernorm_pair(B, L, drop, monkeypatch):
+    """asr_proj_ln_fwd (attention.py:58-60 at encoder size: fc -> dropout -> + residual -> layer_norm, encoder.py:77 row mask) against
+    the two launches it replaces - same operands, same dropout site, ragged lengths, a partial last block - and the saved statistics."""
+    M = B * L
+    g = torch.Generator().manual_seed(B + L)
+    ctx = torch.randn(M, 256, generator=g).bfloat16().to(DEV)
+    res = torch.randn(M, 256, generator=g).to(DEV)
+    w = (torch.randn(256, 256, generator=g) * 0.06).bfloat16().to(DEV)
+    bias = (torch.randn(256, generator=g) * 0.2).to(DEV)
+    gam = (torch.rand(256, generator=g) + 0.5).to(DEV)
+    bet = (torch.randn(256, generator=g) * 0.3).to(DEV)
+    lens = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+    lens[0] = L
+    lens = lens.int().to(DEV)
+    d = ops.Dropout(THR, 7, 3) if drop else None
+    assert ops.proj_ln_ok(ctx, w, 256, B, L)
+    s1, y32a, y16a, mean1, rstd1 = ops.proj_ln(ctx, w, bias, res, gam, bet, B, L, row_len=lens, save_stats=True, drop_x=d)
+    o = ops.gemm_nt(ctx, w, bias)
+    y32b, y16b, mean2, rstd2 = ops.add_layernorm(o, res, gam, bet, B, L, row_len=lens, want_bf16=True, save_stats=True, drop_x=d)
+    np.testing.assert_allclose(N(s1), N(o), atol=2e-3, rtol=1e-3)          # (save mode leaves the pre-norm sum in o)
+    np.testing.assert_allclose(N(y32a), N(y32b), atol=3e-3, rtol=1e-3)
+    np.testing.assert_allclose(N(y16a), N(y16b), atol=2e-2, rtol=8e-3)
+    np.testing.assert_allclose(N(mean1), N(mean2), atol=2e-4)
+    np.testing.assert_allclose(N(rstd1), N(rstd2), rtol=1e-3)
+    pad = (torch.arange(L, device=DEV)[None, :] >= lens[:, None]).reshape(-1)
+    assert float(y32a[pad].abs().max() if pad.any() else 0.0) == 0.0
+    if drop:        # the dropped positions are the same ones: there the pre-norm sum is the residual itself
+        m = torch.from_numpy(O.dropout_mask((B, L, 256), THR, 7, 3)).view(M, 256).to(DEV)
+        assert torch.equal(s1[m == 0], res[m == 0])
+    s0, y32c, _, _, _ = ops.proj_ln(ctx, w, bias, res, gam, bet, B, L, row_len=lens, save_stats=False, drop_x=d)      # eval form
+    assert s0 is None and torch.equal(y32c, y32a)
