@@ -41,6 +41,8 @@ SIGNATURES = {
     "asr_attention_dropmask_words": [_i, _i, _i, _i],
     "asr_graphx_create": [_vp, _i, _vp],
     "asr_graphx_launch": [_vp, _vp],
+    "asr_graphx_set_rotation": [_vp, _i],
+    "asr_graphx_place_streams": [_vp, _vp, _i],
     "asr_graphx_info": [_vp, _vp, _vp, _vp, _vp],
     "asr_graphx_destroy": [_vp],
     "asr_ffn_bits_words": [_i, _i],
@@ -51,6 +53,7 @@ SIGNATURES = {
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i],
     "asr_debug_poison_lds": [_vp, _vp],
     "asr_set_deterministic": [_i],
+    "asr_streams_share_queue": [_vp, _vp, _vp],
     "asr_gemm_tn_ws_bytes": [_i, _i, _i, _i],
     "asr_gemm_tn_ws": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _i],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],

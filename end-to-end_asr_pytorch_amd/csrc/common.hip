@@ -54,3 +54,38 @@ extern "C" int asr_debug_poison_lds(void* stream, void* scratch4) {
     ASR_LAUNCH_CHECK("debug_poison_lds");
     return 0;
 }
+
+// ---- which streams share a hardware queue ---------------------------------------------------------------------------------------------
+// The HIP runtime multiplexes every stream of the process onto a few hardware queues (4 by default; 8 or 16 made every training step
+// slower here) and kernels of two streams on one queue do not overlap.  Which streams share is decided by creation order across the
+// whole process: the trainer's weight-gradient stream landing on the launch stream's queue cost up to 3 ms of a 7 ms step.  This probe
+// answers the question for one pair: a kernel that spins ~80 us on `a`, a kernel that stamps the time on `b`; on a shared queue the
+// stamp comes after the spin has ended.  Synchronises both streams: for set-up time, not for the step.
+namespace {
+__global__ void queue_probe_spin_kernel(unsigned long long* out, unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0) out[0] = __builtin_amdgcn_s_memrealtime();
+}
+__global__ void queue_probe_stamp_kernel(unsigned long long* out) {
+    if (threadIdx.x == 0) out[1] = __builtin_amdgcn_s_memrealtime();
+}
+}  // namespace
+
+extern "C" int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared) {
+    ASR_REQUIRE(shared, ASR_ERR_ARG, "streams_share_queue: null result pointer");
+    if (stream_a == stream_b) { *shared = 1; return 0; }
+    static thread_local unsigned long long* buf = nullptr;
+    hipError_t e;
+    if (!buf && (e = hipMalloc(reinterpret_cast<void**>(&buf), 16)) != hipSuccess) { asr_set_error("streams_share_queue: %s", hipGetErrorString(e)); return (int)e; }
+    hipStream_t a = static_cast<hipStream_t>(stream_a), b = static_cast<hipStream_t>(stream_b);
+    if ((e = hipStreamSynchronize(a)) != hipSuccess || (e = hipStreamSynchronize(b)) != hipSuccess) { asr_set_error("streams_share_queue: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(queue_probe_spin_kernel, dim3(1), dim3(64), 0, a, buf, 8000ull);      // 80 us of the 100 MHz counter
+    hipLaunchKernelGGL(queue_probe_stamp_kernel, dim3(1), dim3(64), 0, b, buf);
+    ASR_LAUNCH_CHECK("streams_share_queue");
+    unsigned long long h[2] = {0, 0};
+    if ((e = hipStreamSynchronize(a)) != hipSuccess || (e = hipStreamSynchronize(b)) != hipSuccess ||
+        (e = hipMemcpy(h, buf, 16, hipMemcpyDeviceToHost)) != hipSuccess) { asr_set_error("streams_share_queue: %s", hipGetErrorString(e)); return (int)e; }
+    *shared = h[1] >= h[0] ? 1 : 0;
+    return 0;
+}

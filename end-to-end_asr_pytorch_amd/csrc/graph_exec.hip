@@ -38,6 +38,8 @@ struct GraphX {
     std::vector<int> tail_event;   // per side stream: the event recorded after its last node (joined into stream 0 at the end)
     hipEvent_t begin = nullptr;
     int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_other = 0;
+    int rotation = 0;              // logical side stream i -> physical side stream (i + rotation) mod n (asr_graphx_set_rotation)
+    std::vector<int> map;          // explicit logical -> physical side-stream map (asr_graphx_place_streams); empty: the rotation
 };
 
 #define GX_CHECK(call)                                                                 \
@@ -257,6 +259,66 @@ extern "C" int asr_graphx_info(void* handle, int* n_nodes, int* n_kernels, int* 
     return 0;
 }
 
+// The HIP runtime multiplexes streams onto a few hardware queues (4 by default; more made every configuration slower here) and two
+// streams on one queue do not overlap: whether the executor's busiest side chain (the weight gradients) shares the launch stream's
+// queue was luck - S2 replayed in 6.6 or 10.0 ms depending on which stream index the chain had been given.  The plan's logical
+// streams can be rotated over the physical ones; Trainer.step_auto times the rotations and keeps the best.
+extern "C" int asr_graphx_set_rotation(void* handle, int rotation) {
+    GraphX* g = static_cast<GraphX*>(handle);
+    ASR_REQUIRE(g && rotation >= 0, -1, "graphx_set_rotation: bad arguments");
+    const int nside = (int)g->streams.size() - 1;
+    g->rotation = nside > 0 ? rotation % nside : 0;
+    return 0;
+}
+
+extern "C" int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared);
+
+// Place the plan's side streams by what the hardware queues look like (asr_streams_share_queue on every pair, ~30 probes of ~0.1 ms):
+// logical streams in order of their kernel count go, heaviest first, to the physical stream whose queue carries the least so far -
+// the launch stream's queue starts with the main chain's own weight, so it is taken last.  clear != 0: back to the rotation.
+extern "C" int asr_graphx_place_streams(void* handle, void* launch_stream, int clear) {
+    GraphX* g = static_cast<GraphX*>(handle);
+    ASR_REQUIRE(g, -1, "graphx_place_streams: null handle");
+    g->map.clear();
+    const int ns = (int)g->streams.size();
+    if (clear || ns <= 2) return 0;
+    // queue groups of the physical side streams: group 0 = the launch stream's queue
+    std::vector<int> group(ns, -1);
+    int ngroups = 1;
+    for (int p = 1; p < ns; ++p) {
+        int sh = 0;
+        if (int rc = asr_streams_share_queue(launch_stream, g->streams[p], &sh)) return rc;
+        if (sh) { group[p] = 0; continue; }
+        for (int q = 1; q < p && group[p] < 0; ++q) {
+            if (group[q] <= 0) continue;
+            if (int rc = asr_streams_share_queue(g->streams[q], g->streams[p], &sh)) return rc;
+            if (sh) group[p] = group[q];
+        }
+        if (group[p] < 0) group[p] = ngroups++;
+    }
+    std::vector<long> weight(ns, 0), load(ngroups, 0);
+    for (const XNode& x : g->nodes) weight[x.stream] += 1;
+    load[0] = weight[0];
+    std::vector<int> logical(ns - 1);
+    for (int i = 1; i < ns; ++i) logical[i - 1] = i;
+    std::sort(logical.begin(), logical.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+    std::vector<char> used(ns, 0);
+    std::vector<int> map(ns, 0);
+    for (int l : logical) {
+        int best = -1;
+        for (int p = 1; p < ns; ++p)
+            if (!used[p] && (best < 0 || load[group[p]] < load[group[best]])) best = p;
+        used[best] = 1;
+        map[l] = best;
+        load[group[best]] += weight[l];
+    }
+    g->map = map;
+    if (getenv("ASR_AMD_GRAPHX_DEBUG")) {
+        for (int l = 1; l < ns; ++l) fprintf(stderr, "graphx place: logical stream %d (%ld nodes) -> physical %d (queue group %d)\n", l, weight[l], map[l], group[map[l]]);
+    }
+    return 0;
+}
+
 extern "C" int asr_graphx_launch(void* handle, void* stream) {
     GraphX* g = static_cast<GraphX*>(handle);
     ASR_REQUIRE(g, -1, "graphx_launch: null handle");
@@ -267,8 +329,12 @@ extern "C" int asr_graphx_launch(void* handle, void* stream) {
         GX_CHECK(hipEventRecord(g->begin, main));
         for (size_t s = 1; s < g->streams.size(); ++s) GX_CHECK(hipStreamWaitEvent(g->streams[s], g->begin, 0));
     }
+    const int nside = (int)g->streams.size() - 1;
     for (XNode& x : g->nodes) {
-        hipStream_t st = g->streams[x.stream];
+        // logical side stream i runs on physical side stream (i + rotation) mod nside: which streams share a hardware queue with the
+        // launch stream is the runtime's choice (asr_graphx_set_rotation)
+        hipStream_t st = x.stream == 0 ? main
+                         : g->streams[g->map.empty() ? 1 + (x.stream - 1 + g->rotation) % nside : g->map[x.stream]];
         for (int e : x.wait_events) GX_CHECK(hipStreamWaitEvent(st, g->events[e], 0));
         switch (x.type) {
             case hipGraphNodeTypeKernel:

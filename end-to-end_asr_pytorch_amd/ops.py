@@ -430,13 +430,34 @@ CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "32"))
 CTC_LAZY_OCC = os.environ.get("ASR_AMD_CTC_LAZY_OCC", "1") != "0"     # asr_ctc_loss_bwd with the second workspace (see asr_hip.h)
 
 
+QUEUE_PROBE = os.environ.get("ASR_AMD_QUEUE_PROBE", "1") != "0"      # A/B: 0 = side streams as torch hands them out
+
+
+def streams_share_queue(a, b):
+    """Set-up time probe (asr_streams_share_queue): True when the two torch streams sit on one hardware queue (no overlap between them)."""
+    out = ctypes.c_int(0)
+    check(lib().asr_streams_share_queue(ctypes.c_void_p(a.cuda_stream), ctypes.c_void_p(b.cuda_stream), ctypes.byref(out)),
+          "asr_streams_share_queue")
+    return bool(out.value)
+
+
 def aux_stream(device, priority=0, slot=0):
     """A side stream per (device, priority, slot): -1 for latency-bound work beside an HBM-bound pass (pipelined CTC forward), 0 for
     bulk work that should fill the CUs a run of small kernels leaves idle (the trainer's CTC branch beside the decoder; slot 1:
-    the encoder's dropout-mask hashing beside its GEMMs)."""
+    the encoder's dropout-mask hashing beside its GEMMs).  The runtime multiplexes streams onto 4 hardware queues and two streams of one
+    queue never overlap, so a new side stream is chosen among a few candidates: one that shares its queue neither with the current
+    (launch) stream nor, if possible, with the side streams already handed out."""
     key = (torch.device(device).index, priority, slot)
     if key not in _AUX:
-        _AUX[key] = torch.cuda.Stream(device=device, priority=priority)
+        cand = [torch.cuda.Stream(device=device, priority=priority)]
+        if QUEUE_PROBE and torch.device(device).type == "cuda" and not torch.cuda.is_current_stream_capturing():
+            main = torch.cuda.current_stream(device)
+            taken = [s for k, s in _AUX.items() if k[0] == key[0]]
+            cand += [torch.cuda.Stream(device=device, priority=priority) for _ in range(7)]
+            free = [c for c in cand if not streams_share_queue(main, c)]
+            alone = [c for c in free if not any(streams_share_queue(t, c) for t in taken)]
+            cand = alone or free or cand
+        _AUX[key] = cand[0]
     return _AUX[key]
 
 
@@ -1242,6 +1263,15 @@ class GraphExec:
 
     def launch(self):
         check(lib().asr_graphx_launch(self._h, _stream()), "asr_graphx_launch")
+
+    def place_streams(self, clear=False):
+        """Explicit logical -> physical side-stream map from hardware-queue probes (asr_graphx_place_streams); clear: back to the rotation."""
+        check(lib().asr_graphx_place_streams(self._h, _stream(), 1 if clear else 0), "asr_graphx_place_streams")
+
+    def set_rotation(self, r):
+        """Logical side stream i -> physical side stream (i + r) mod n: streams share hardware queues, which ones is not ours to choose."""
+        check(lib().asr_graphx_set_rotation(self._h, int(r)), "asr_graphx_set_rotation")
+        self.rotation = int(r)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

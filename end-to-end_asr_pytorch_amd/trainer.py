@@ -502,8 +502,33 @@ class Trainer:
             self.launch_mode, self.launch_timing = "eager", {"eager_ms": round(t_eager, 3), "graph_ms": None}
             return out
         t_graph, out = timed(self.step_graphed)
+        rot = None
+        if self._graphx is not None and self._graphx.info["streams"] > 2:
+            # the executor's side streams share hardware queues with each other and with the launch stream; which ones do is the
+            # runtime's choice (creation order of every stream in the process) and decides whether the weight-gradient chain overlaps
+            # the main chain at all: time the rotations of the logical -> physical stream map, keep the best (real steps all of them)
+            rot = {0: round(t_graph, 3)}
+            best = 0
+            for r in range(1, min(4, self._graphx.info["streams"] - 1)):
+                self._graphx.set_rotation(r)
+                t_r, out = timed(self.step_graphed)
+                rot[r] = round(t_r, 3)
+                if t_r < t_graph:
+                    t_graph, best = t_r, r
+            self._graphx.set_rotation(best)
+            if ops.QUEUE_PROBE:          # ... and the placement computed from hardware-queue probes against the best rotation
+                torch.cuda.synchronize(dev)
+                self._graphx.place_streams()
+                t_p, out = timed(self.step_graphed)
+                rot["placed"] = round(t_p, 3)
+                if t_p < t_graph:
+                    t_graph = t_p
+                else:
+                    self._graphx.place_streams(clear=True)
         self.launch_mode = "graph" if t_graph < t_eager else "eager"
         self.launch_timing = {"eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3)}
+        if rot is not None:
+            self.launch_timing["graph_ms_by_stream_rotation"] = rot
         if self.launch_mode == "eager":
             self._graphx = None
             self._graph = None                           # frees the graph's private pool

@@ -65,6 +65,9 @@ int asr_version(void);
  * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
  * (asr_gemm_tn_ws) is order-fixed in either mode.  Returns the previous setting. */
 int asr_set_deterministic(int on);
+/* Set-up time probe: do two streams share a hardware queue (their kernels then never overlap)?  The runtime multiplexes all streams
+ * of the process onto a few queues in creation order; the trainer picks its side streams with this.  Synchronises both streams. */
+int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared);
 /* Test support: one launch that leaves all 160 KiB of every CU's LDS filled with NaN bit patterns (0x7fc07fc0), so that a kernel
  * reading LDS bytes it has not yet been handed shows up deterministically (tests/test_gpu_lds_poison.py).  scratch4: 4 device bytes. */
 int asr_debug_poison_lds(void* stream, void* scratch4);
@@ -179,6 +182,13 @@ int asr_gemm_add_layernorm_small(void* stream, const void* A, int64_t lda, const
  * launched with an `extra` buffer) make create fail with a message - the caller then replays the graph with hipGraphLaunch. */
 int asr_graphx_create(void* hip_graph, int max_streams, void** out_handle);
 int asr_graphx_launch(void* handle, void* stream);
+/* Rotate the plan's logical side streams over the physical ones (which streams share a hardware queue with the launch stream is the
+ * runtime's choice; a caller times the rotations 0 .. n_streams - 2 once and keeps the best). */
+int asr_graphx_set_rotation(void* handle, int rotation);
+/* Place the plan's side streams by probing which physical streams share a hardware queue (asr_streams_share_queue on the pairs, a few
+ * ms, synchronising): busiest logical stream first, onto the least loaded queue, the launch stream's queue last.  clear != 0 returns to
+ * the rotation.  launch_stream: the stream asr_graphx_launch will be given. */
+int asr_graphx_place_streams(void* handle, void* launch_stream, int clear);
 int asr_graphx_info(void* handle, int* n_nodes, int* n_kernels, int* n_streams, int* n_events);
 int asr_graphx_destroy(void* handle);
 

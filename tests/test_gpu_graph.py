@@ -109,16 +109,17 @@ def test_step_auto_calibrates_once_and_stays_on_the_eager_trajectory(golden_dir)
     umax = int((tg != 0).sum(1).max())
     te = asr_amd.Trainer(m_e, k=0.2, warmup_steps=50, label_smoothing=0.1)
     ta = asr_amd.Trainer(m_a, k=0.2, warmup_steps=50, label_smoothing=0.1)
-    ta.step_auto(x, lens, tg, max_target_len=umax, trials=2)          # calibration: 2 + 2 eager, 1 capture + replay, 2 replays
-    assert ta.launch_mode in ("eager", "graph") and ta.step_num == 7
+    ta.step_auto(x, lens, tg, max_target_len=umax, trials=2)          # calibration: 2 + 2 eager, 1 capture + replay, 2 replays, and 2 more
+    n_cal = ta.step_num                                               # per stream rotation / placement the executor is timed with
+    assert ta.launch_mode in ("eager", "graph") and n_cal >= 7 and (n_cal - 7) % 2 == 0
     assert ta.launch_timing["eager_ms"] > 0 and ta.launch_timing["graph_ms"] > 0
     assert ta.graph_active() == (ta.launch_mode == "graph")
-    for _ in range(7):
+    for _ in range(n_cal):
         ce = te.step(x, lens, tg, max_target_len=umax)
     for _ in range(3):
         ce = te.step(x, lens, tg, max_target_len=umax)
         ca = ta.step_auto(x, lens, tg, max_target_len=umax)
-    assert ta.step_num == te.step_num == 10
+    assert ta.step_num == te.step_num == n_cal + 3
     np.testing.assert_allclose([float(v) for v in ca], [float(v) for v in ce], rtol=5e-3)
     # a step that cannot be captured (no max_target_len: a host read in the middle) settles on eager without calibrating
     tb = asr_amd.Trainer(build(golden_dir)[1], k=0.2, warmup_steps=50, label_smoothing=0.1)

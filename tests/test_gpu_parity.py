@@ -410,8 +410,8 @@ def test_ctc_bf16_gradient_is_the_rounded_f32_gradient(B, L, V, U):
     assert float(whole[:, :, V:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,L,K,ragged,drop", [(32, 51, 256, True, True), (3, 17, 2048, True, False), (2, 8, 64, False, True), (5, 100, 512, True, True),
-                                               (8, 1000, 256, True, True), (5, 1000, 2048, True, False), (7, 700, 64, False, True)])   # > 4096 rows: the 128 x 256-tile kernel
+@pytest.mark.parametrize("B,L,K,ragged,drop", [(32, 51, 256, True, True), (3, 17, 512, True, False), (2, 8, 64, False, True), (5, 100, 512, True, True),
+                                               (8, 500, 256, True, True)])
 def test_gemm_add_layernorm_small_matches_the_unfused_pair(B, L, K, ragged, drop):
     """asr_gemm_add_layernorm_small (decoder-sized rows: projection + dropout + residual + LayerNorm in one launch) against
     asr_gemm_nt followed by asr_add_layernorm_fwd on the same inputs - every output tensor the backward consumes."""

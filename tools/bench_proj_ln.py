@@ -5,7 +5,7 @@ import torch
 import asr_amd
 from asr_amd import ops
 DEV = "cuda:0"
-B, L = 32, 1000
+B, L = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 M = B * L
 ctx = torch.randn(M, 256, device=DEV).bfloat16(); res = torch.randn(M, 256, device=DEV)
 w = (torch.randn(256, 256, device=DEV) * 0.06).bfloat16(); bias = torch.randn(256, device=DEV) * 0.1
