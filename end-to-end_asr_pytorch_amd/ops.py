@@ -1247,8 +1247,11 @@ class GraphExec:
         self._h, self._graph, self.info = handle, graph, info
 
     @classmethod
-    def from_torch_graph(cls, graph, max_streams=8):
-        """-> GraphExec, or None (with a warning that says why) when the graph holds nodes the executor does not launch."""
+    def from_torch_graph(cls, graph, max_streams=int(os.environ.get("ASR_AMD_GRAPHX_STREAMS", "4"))):
+        """-> GraphExec, or None (with a warning that says why) when the graph holds nodes the executor does not launch.
+        max_streams = 4: one per hardware queue of the runtime - with 8, two of the executor's streams shared each queue and three of the
+        four rotations of the stream map put the weight-gradient chain on the launch stream's queue (S1 13.6 vs 12.6 ms, S2 9-10 vs 6.9);
+        with 4 every rotation is good (12.35-12.45, 6.7)."""
         raw = graph.raw_cuda_graph()
         h = ctypes.c_void_p()
         rc = lib().asr_graphx_create(ctypes.c_void_p(int(raw)), int(max_streams), ctypes.byref(h))
