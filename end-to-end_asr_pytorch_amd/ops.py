@@ -1279,8 +1279,8 @@ class GraphExec:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            try:
+            try:      # (at interpreter shutdown the module's globals may be gone already: nothing left to release then)
                 torch.cuda.synchronize()
+                lib().asr_graphx_destroy(h)
             except Exception:
                 pass
-            lib().asr_graphx_destroy(h)
