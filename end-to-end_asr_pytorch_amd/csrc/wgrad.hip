@@ -48,18 +48,20 @@ __device__ __forceinline__ u32x2 tr8(const unsigned char* p) {
 }
 template <int I> struct IC { static constexpr int value = I; };
 
-__global__ __launch_bounds__(256, 1) void gemm_tn_v2_kernel(TnArgs a) {
+// bid / nblocks: this workgroup's index among the tiles x splits workgroups of ITS problem (the whole grid for a single launch, a slice
+// of it in a grouped one)
+__device__ __forceinline__ void tn_body(const TnArgs& a, const int bid, const int nblocks) {
     constexpr int STAGE = 16384;                        // one operand tile: 64 rows x 256 B
     __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE];   // A ring [4] | B ring [4]
-    const int tiles = gridDim.x / a.splits;
+    const int tiles = nblocks / a.splits;
     int tile, split;
     if ((a.splits & 7) == 0) {      // whole M-ranges per XCD: every row of dY and X is fetched into one L2 only
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int xcd = bid & 7, slot = bid >> 3;
         split = xcd * (a.splits >> 3) + slot / tiles;
         tile = slot - (slot / tiles) * tiles;
     } else {
-        split = blockIdx.x / tiles;
-        tile = blockIdx.x - split * tiles;
+        split = bid / tiles;
+        tile = bid - split * tiles;
     }
     const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
@@ -280,12 +282,29 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_v2_kernel(TnArgs a) {
     if (cs_on && tid < 128) my[16384 + tid] = cs_tile;
 }
 
+__global__ __launch_bounds__(256, 1) void gemm_tn_v2_kernel(TnArgs a) { tn_body(a, blockIdx.x, gridDim.x); }
+
+// Several weight gradients in one launch (the decoder's: 1632 rows each, a handful of tiles, 13-17 us apiece as single launches of
+// which 2 us are work): problem i owns the workgroups first[i] .. first[i+1] - 1.
+constexpr int TN_GROUP_MAX = 8;
+struct TnGroup {
+    int n;
+    int first[TN_GROUP_MAX + 1];       // main launch: first workgroup of each problem
+    int first_r[TN_GROUP_MAX + 1];     // reduce launch (tiles x 64 workgroups per problem with > 1 split, none otherwise)
+    TnArgs p[TN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256, 1) void gemm_tn_v2_group_kernel(TnGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    tn_body(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);
+}
+
 // dW tile = sum over the splits of the slab's partial tiles.  A workgroup owns 64 consecutive f32x4 of one tile (1 KiB: 4 output rows
 // x 2 x 32 columns); its 4 waves take the splits s = g, g + 4, ... (up to 16 loads in flight per lane), LDS adds the four group sums in
 // group order.  The first workgroup of a tile also sums the 128 column-sum partials.
-__global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a, int tiles) {
+__device__ __forceinline__ void tn_reduce_body(const TnArgs& a, const int tiles, const int bid) {
     __shared__ f32x4 part[3][64];
-    const int tile = blockIdx.x >> 6, blk = blockIdx.x & 63;
+    const int tile = bid >> 6, blk = bid & 63;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
@@ -326,6 +345,13 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a, int tiles) {
             else atomicAdd(a.colsum + n0 + col, c);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_kernel(TnArgs a, int tiles) { tn_reduce_body(a, tiles, blockIdx.x); }
+__global__ __launch_bounds__(256) void tn_reduce_group_kernel(TnGroup g) {
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.first_r[i + 1]) ++i;
+    tn_reduce_body(g.p[i], (g.first_r[i + 1] - g.first_r[i]) >> 6, (int)blockIdx.x - g.first_r[i]);
 }
 
 }  // namespace
@@ -382,6 +408,51 @@ extern "C" int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const vo
     if (a.splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(tiles * 64), dim3(256), 0, s, a, tiles);
         ASR_LAUNCH_CHECK("gemm_tn_reduce");
+    }
+    return 0;
+}
+
+// Up to 8 weight gradients in one pair of launches.  Every problem must be one asr_gemm_tn_ws itself takes (the same conditions; a
+// group with a problem that is not is refused with ASR_ERR_UNSUPPORTED - the caller issues them one by one then); each brings its own
+// workspace of asr_gemm_tn_ws_bytes(M, N, K, 0).  The chip's ~256 workgroup slots are shared out by output tiles.
+extern "C" int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t* pr, int deterministic) {
+    ASR_REQUIRE(pr && n >= 1 && n <= TN_GROUP_MAX, ASR_ERR_ARG, "gemm_tn_ws_group: 1..%d problems", TN_GROUP_MAX);
+    TnGroup g;
+    g.n = n;
+    int total_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const asr_tn_problem_t& q = pr[i];
+        ASR_REQUIRE(q.A && q.B && q.C && q.M > 0 && q.N > 0 && q.K > 0, ASR_ERR_ARG, "gemm_tn_ws_group: problem %d: bad args", i);
+        const bool n_ok = q.N % 128 == 0 || q.lda >= (int64_t)(q.N + 127) / 128 * 128;
+        const bool fits = (int64_t)q.M * q.lda * 2 < (1ll << 31) && (int64_t)q.M * q.ldb * 2 < (1ll << 31);
+        ASR_REQUIRE(q.workspace && asr_aligned(q.workspace, 16) && q.M >= 64 && n_ok && q.K % 128 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 &&
+                        asr_aligned(q.A, 16) && asr_aligned(q.B, 16) && fits && q.workspace_bytes >= asr_gemm_tn_ws_bytes(q.M, q.N, q.K, 0),
+                    ASR_ERR_UNSUPPORTED, "gemm_tn_ws_group: problem %d is not one the slab kernel takes", i);
+        total_tiles += ((q.N + 127) / 128) * (q.K / 128);
+    }
+    g.first[0] = 0;
+    g.first_r[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const asr_tn_problem_t& q = pr[i];
+        TnArgs& a = g.p[i];
+        int tiles;
+        const int my_tiles = ((q.N + 127) / 128) * (q.K / 128);
+        int share = (int)((int64_t)256 * my_tiles / total_tiles);
+        if (share < my_tiles) share = my_tiles;
+        tn_v2_plan(q.M, q.N, q.K, share, &tiles, &a.splits, &a.m_per_split);
+        a.A = (const bf16_t*)q.A; a.B = (const bf16_t*)q.B; a.C = q.C; a.colsum = q.colsum;
+        a.slab = reinterpret_cast<float*>(q.workspace);
+        a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.M = q.M; a.N = q.N; a.K = q.K; a.tiles_k = q.K / 128;
+        a.accumulate = q.accumulate; a.cs_all = (deterministic || asr_deterministic()) ? 1 : 0;
+        g.first[i + 1] = g.first[i] + tiles * a.splits;
+        g.first_r[i + 1] = g.first_r[i] + (a.splits > 1 ? tiles * 64 : 0);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gemm_tn_v2_group_kernel, dim3(g.first[n]), dim3(256), 0, s, g);
+    ASR_LAUNCH_CHECK("gemm_tn_v2_group");
+    if (g.first_r[n] > 0) {
+        hipLaunchKernelGGL(tn_reduce_group_kernel, dim3(g.first_r[n]), dim3(256), 0, s, g);
+        ASR_LAUNCH_CHECK("gemm_tn_reduce_group");
     }
     return 0;
 }

@@ -791,6 +791,41 @@ def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     return out
 
 
+class _TnProblem(ctypes.Structure):          # asr_hip.h: asr_tn_problem_t
+    _fields_ = [("A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("B", ctypes.c_void_p), ("ldb", ctypes.c_int64), ("C", ctypes.c_void_p),
+                ("ldc", ctypes.c_int64), ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("accumulate", ctypes.c_int),
+                ("colsum", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
+
+
+TN_GROUP = os.environ.get("ASR_AMD_TN_GROUP", "1") != "0"      # A/B: 0 = the decoder's weight gradients one launch pair each
+TN_GROUP_MAX_ROWS = 2048
+
+
+def gemm_tn_group_ok(a2d, b2d, out):
+    """A weight gradient the grouped launch takes: bf16 operands the slab kernel takes, decoder-sized row counts."""
+    return (TN_GROUP and TN_SLAB and not EXACT_F32 and out is not None and a2d.dtype == torch.bfloat16 and b2d.dtype == torch.bfloat16 and
+            64 <= a2d.shape[0] <= TN_GROUP_MAX_ROWS and b2d.shape[1] % 128 == 0 and a2d.stride(1) == 1 and b2d.stride(1) == 1 and
+            a2d.stride(0) % 8 == 0 and b2d.stride(0) % 8 == 0 and a2d.data_ptr() % 16 == 0 and b2d.data_ptr() % 16 == 0 and
+            (a2d.shape[1] % 128 == 0 or a2d.stride(0) >= (a2d.shape[1] + 127) // 128 * 128))
+
+
+def gemm_tn_group(problems):
+    """problems: up to 8 tuples (a2d, b2d, out, accumulate, colsum), each gemm_tn_group_ok - dW_i (+)= A_i^T . B_i in ONE pair of
+    launches (asr_hip.h: asr_gemm_tn_ws_group)."""
+    arr = (_TnProblem * len(problems))()
+    keep = []
+    for i, (a2d, b2d, out, accumulate, colsum) in enumerate(problems):
+        M, N = a2d.shape
+        K = b2d.shape[1]
+        ws = _tn_workspace(out, M, N, K, 0)
+        keep.append(ws)
+        arr[i] = _TnProblem(_p(a2d), a2d.stride(0), _p(b2d), b2d.stride(0), _p(out), out.stride(0), M, N, K, 1 if accumulate else 0,
+                            _p(colsum), _p(ws), ws.numel())
+    with _timed("gemm_tn_group[%d]" % len(problems), sum(2.0 * a.shape[0] * a.shape[1] * b.shape[1] for a, b, _, _, _ in problems)):
+        check(lib().asr_gemm_tn_ws_group(_stream(), len(problems), ctypes.cast(arr, ctypes.c_void_p), 1 if DETERMINISTIC else 0),
+              "asr_gemm_tn_ws_group")
+
+
 def colsum(a2d, out=None, accumulate=False):
     _req_cuda(a2d)
     M, N = a2d.shape

@@ -134,6 +134,7 @@ class GradBuckets:
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self.launch_order.append(bi)
+                modules.flush_wgrads()                     # (decoder-sized weight gradients still waiting for their grouped launch)
                 if self.world > 1:
                     a, b = self.ranges[bi]
                     if self.launch_stream is not None:     # gradients of this bucket are written on two streams: order after both
@@ -350,6 +351,7 @@ class Trainer:
             self.buckets.launch_stream = side
         try:
             self._backward(tape, st, logits, tg1, lse, loss2, d_num)
+            modules.flush_wgrads()
         finally:
             if wg:
                 torch.cuda.current_stream().wait_stream(side)      # before Adam reads the gradients (and before `keep` is dropped)

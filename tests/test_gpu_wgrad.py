@@ -65,3 +65,37 @@ def test_gemm_tn_slab_whole_chip_split():
     o2 = ops.gemm_tn(ad, bd)
     assert torch.equal(o1, o2)
     np.testing.assert_allclose(N(o1), ref, atol=0.25, rtol=2e-3)
+
+
+def test_grouped_weight_gradients_equal_single_launches():
+    """asr_gemm_tn_ws_group: the decoder's shapes (1632 rows; 256 / 768 / 2048 / 4234-in-4352 outputs, accumulate and overwrite, with and
+    without the bias side product) in one pair of launches against one asr_gemm_tn_ws each."""
+    M = 1632
+    shapes = [(256, 256), (768, 256), (2048, 256), (256, 2048), (256, 256), (4234, 256), (256, 256), (768, 256)]
+    g = torch.Generator().manual_seed(9)
+    probs, refs = [], []
+    for i, (Nn, K) in enumerate(shapes):
+        lda = 4352 if Nn == 4234 else None
+        a, b, ad, bd = _ops(M, Nn, K, 50 + i, lda)
+        acc = i % 2 == 1
+        out = (torch.randn(Nn, K, generator=g) if acc else torch.full((Nn, K), 3.0)).to(DEV)
+        cs = torch.zeros(Nn, device=DEV) if i % 3 == 0 else None
+        ref = a.float().t() @ b.float() + (out.cpu() if acc else 0.0)
+        assert ops.gemm_tn_group_ok(ad, bd, out)
+        probs.append((ad, bd, out, acc, cs))
+        refs.append((ref, a.float().sum(0) if cs is not None else None))
+    ops.gemm_tn_group(probs)
+    for (ad, bd, out, acc, cs), (ref, csr) in zip(probs, refs):
+        np.testing.assert_allclose(N(out), ref.numpy(), atol=6e-2, rtol=2e-3)
+        if cs is not None:
+            np.testing.assert_allclose(N(cs), csr.numpy(), atol=6e-2, rtol=2e-3)
+    first = [p[2].clone() for p in probs]
+    # again on the same workspaces, overwrite form: bit-identical to itself, and equal to the single launches
+    probs2 = [(ad, bd, torch.empty_like(out), False, None) for ad, bd, out, acc, cs in probs]
+    ops.gemm_tn_group(probs2)
+    probs3 = [(ad, bd, torch.empty_like(out), False, None) for ad, bd, out, acc, cs in probs]
+    ops.gemm_tn_group(probs3)
+    for p2, p3 in zip(probs2, probs3):
+        assert torch.equal(p2[2], p3[2])
+        single = ops.gemm_tn(p2[0], p2[1], max_wgs=256)
+        np.testing.assert_allclose(N(p2[2]), N(single), atol=2e-2, rtol=1e-3)
