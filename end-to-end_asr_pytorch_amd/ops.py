@@ -799,12 +799,15 @@ class _TnProblem(ctypes.Structure):          # asr_hip.h: asr_tn_problem_t
 
 TN_GROUP = os.environ.get("ASR_AMD_TN_GROUP", "1") != "0"      # A/B: 0 = the decoder's weight gradients one launch pair each
 TN_GROUP_MAX_ROWS = 2048
+TN_GROUP_SMALL_TILES = int(os.environ.get("ASR_AMD_TN_GROUP_TILES", "16"))     # > 0: weight gradients of at most this many output tiles join the groups at any row count
 
 
 def gemm_tn_group_ok(a2d, b2d, out):
     """A weight gradient the grouped launch takes: bf16 operands the slab kernel takes, decoder-sized row counts."""
     return (TN_GROUP and TN_SLAB and not EXACT_F32 and out is not None and a2d.dtype == torch.bfloat16 and b2d.dtype == torch.bfloat16 and
-            64 <= a2d.shape[0] <= TN_GROUP_MAX_ROWS and b2d.shape[1] % 128 == 0 and a2d.stride(1) == 1 and b2d.stride(1) == 1 and
+            (64 <= a2d.shape[0] <= TN_GROUP_MAX_ROWS or
+             (TN_GROUP_SMALL_TILES and ((a2d.shape[1] + 127) // 128) * (b2d.shape[1] // 128) <= TN_GROUP_SMALL_TILES and a2d.shape[0] >= 64)) and
+            b2d.shape[1] % 128 == 0 and a2d.stride(1) == 1 and b2d.stride(1) == 1 and
             a2d.stride(0) % 8 == 0 and b2d.stride(0) % 8 == 0 and a2d.data_ptr() % 16 == 0 and b2d.data_ptr() % 16 == 0 and
             (a2d.shape[1] % 128 == 0 or a2d.stride(0) >= (a2d.shape[1] + 127) // 128 * 128))
 
