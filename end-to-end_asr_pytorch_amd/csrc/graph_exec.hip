@@ -153,7 +153,14 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
                 if (reuse >= 0) st = reuse;
                 else if ((int)g->streams.size() < max_streams) {
                     hipStream_t ns;
-                    if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: stream"); return -2; }
+                    static const int side_prio = getenv("ASR_AMD_GRAPHX_PRIO") ? atoi(getenv("ASR_AMD_GRAPHX_PRIO")) : 0;   // A/B: 1 = side streams at the lowest priority, -1 = highest
+                    hipError_t ce;
+                    if (side_prio != 0) {
+                        int least = 0, greatest = 0;
+                        hipDeviceGetStreamPriorityRange(&least, &greatest);
+                        ce = hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, side_prio > 0 ? least : greatest);
+                    } else ce = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+                    if (ce != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: stream"); return -2; }
                     g->streams.push_back(ns);
                     tail_of_stream.push_back(-1);
                     st = (int)g->streams.size() - 1;
