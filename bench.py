@@ -523,6 +523,30 @@ def main():
                              "durations; `value` is measured with them); traffic = mean HBM bytes per launch from separate rocprofv3 "
                              "--pmc FETCH_SIZE / WRITE_SIZE passes (%s/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 "
                              "correction)" % os.path.relpath(prof_dir, ROOT))
+        if dom_name == "gemm_tn" and args.mode == "train":
+            # the dominant family's heaviest shape (the FFN weight gradients: 2 x 12 of the 88 calls, 60 % of the family's flops) back to
+            # back, 30 launches inside ONE event bracket: a per-op bracket costs 15-30 us of event handling on this stack, which the
+            # family number above carries 88 times per step
+            Mr, dff = CFG["B"] * (CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]), CFG["d_inner"]
+            g_ = torch.Generator(device="cpu").manual_seed(1)
+            da = torch.randn(Mr, 256, generator=g_).to(dev).bfloat16()
+            xb_ = torch.randn(Mr, dff, generator=g_).to(dev).bfloat16()
+            out_ = torch.empty(256, dff, device=dev)
+            for _ in range(3):
+                ops.gemm_tn(da, xb_, out=out_, max_wgs=256)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(30):
+                ops.gemm_tn(da, xb_, out=out_, max_wgs=256)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 30 * 1e3
+            tf = 2.0 * Mr * 256 * dff / (us * 1e-6) / 1e12
+            roofline["back_to_back"] = {"shape": [Mr, 256, dff], "us": round(us, 2), "achieved": round(tf, 1), "unit": "TFLOP/s",
+                                        "frac": round(tf / PEAK_MFMA_BF16_TFLOPS, 4),
+                                        "what": "the family's heaviest shape (FFN weight gradient, both launches of the op), 30 calls inside one event bracket"}
+            del da, xb_, out_
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
         vp_k = [k for k in kernels if k["name"].startswith("vocab_proj_lse")]
