@@ -138,6 +138,29 @@ __global__ __launch_bounds__(256) void probe(int mode, int iters, unsigned long 
             asm volatile("v_pk_add_f32 %0, %0, %6\n\tv_pk_add_f32 %1, %1, %6\n\tv_pk_add_f32 %2, %2, %6\n\tv_pk_add_f32 %3, %3, %6\n\tv_pk_add_f32 %4, %4, %6\n\tv_pk_add_f32 %5, %5, %6" : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(xx));
         }
         y += e0[0] + e1[0] + e2[1] + e3[0] + e4[1] + e5[0];
+    } else if (mode == 18) {      // mfma, then 12 VALU that READ the other (finished) accumulator - the attention loop's situation
+        float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0;
+        for (int i = 0; i < iters; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+            asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %7\n\tv_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\tv_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %7\n\tv_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\tv_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]), "v"(acc1[3]), "v"(acc1[4]), "v"(acc1[5]));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+            asm volatile("v_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %7\n\tv_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\tv_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11\n\tv_add_f32 %0, %0, %6\n\tv_add_f32 %1, %1, %7\n\tv_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %9\n\tv_add_f32 %4, %4, %10\n\tv_add_f32 %5, %5, %11"
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5) : "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]));
+        }
+        y += e0 + e1 + e2 + e3 + e4 + e5;
+    } else if (mode == 19) {      // the same with the 12 VALU WRITING the B operand of the next mfma (P -> PV)
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        u4 pb = {1, 2, 3, 4};
+        for (int i = 0; i < iters; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, pb), acc0, 0, 0, 0);
+            asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %3, %3, %7\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %3, %3, %7\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %3, %3, %7"
+                         : "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]) : "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]), "v"(acc1[3]));
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, pb), acc1, 0, 0, 0);
+            asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %3, %3, %7\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %3, %3, %7\n\tv_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_add_u32 %3, %3, %7"
+                         : "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]) : "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]));
+        }
+        y += (float)pb[0];
     } else {   // mode 3: MFMA with 6 independent VALU in its shadow
         for (int i = 0; i < iters; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
@@ -159,10 +182,10 @@ int main(int argc, char** argv) {
     unsigned long long* out; float* sink;
     hipMalloc(&out, blocks * 16); hipMalloc(&sink, 4);
     unsigned long long* h = (unsigned long long*)malloc(blocks * 16);
-    const char* names[] = {"mfma x2 (2 chains) / iter", "16 dependent v_add / iter", "16 v_exp / iter", "2 x (mfma + 6 v_add) / iter", "mfma x2 (1 chain) / iter", "mfma x4 (4 chains) / iter", "mfma16x16x32 x4 (4 chains)", "2 x (mfma + 6 v_exp)", "2 x (mfma + 12 indep v_add)", "24 indep v_add", "[8 mfma, then 96 indep v_add] / 4 iters", "12 x v_max3_f32 (6 chains)", "12 x v_bfe_i32 (6 chains)", "12 x v_and_b32 (6 chains)", "12 x v_cvt_pk_bf16_f32 (6 chains)", "12 x v_mov_b32 (6 regs)", "12 x v_fma_f32 (6 chains, VOP3)", "12 x v_pk_add_f32 (6 chains)"};
+    const char* names[] = {"mfma x2 (2 chains) / iter", "16 dependent v_add / iter", "16 v_exp / iter", "2 x (mfma + 6 v_add) / iter", "mfma x2 (1 chain) / iter", "mfma x4 (4 chains) / iter", "mfma16x16x32 x4 (4 chains)", "2 x (mfma + 6 v_exp)", "2 x (mfma + 12 indep v_add)", "24 indep v_add", "[8 mfma, then 96 indep v_add] / 4 iters", "12 x v_max3_f32 (6 chains)", "12 x v_bfe_i32 (6 chains)", "12 x v_and_b32 (6 chains)", "12 x v_cvt_pk_bf16_f32 (6 chains)", "12 x v_mov_b32 (6 regs)", "12 x v_fma_f32 (6 chains, VOP3)", "12 x v_pk_add_f32 (6 chains)", "2 x (mfma + 12 v_add reading the other accumulator)", "2 x (mfma + 12 VALU writing the next mfma B operand)"};
     const int threads = argc > 2 ? atoi(argv[2]) : 256;
     for (int waves = 1; waves <= 2; ++waves)
-    for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < 18; ++mode) {
+    for (int mode = (argc > 3 ? atoi(argv[3]) : 0); mode < 20; ++mode) {
         const int iters = 20000;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         for (int rep = 0; rep < 2; ++rep) {
