@@ -23,13 +23,46 @@ def _ngpu():
 
 
 def _run(script_args, nproc, port, gloo_one_gpu):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import signal
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONFAULTHANDLER="1")
     if gloo_one_gpu:
         env.update(ASR_AMD_DIST_BACKEND="gloo", ASR_AMD_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port)] + script_args
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stderr[-3000:]
+    # Several torchrun workers sharing ONE GPU over gloo (the development box's stand-in for one rank per GPU over RCCL) hang once in a
+    # few dozen runs for the 30 minutes of gloo's own timeout - seen twice in round 3, never with the ranks started by hand (8 of 8) and
+    # not reproduced under a debugger.  The rig is bounded instead: 300 s per attempt, the workers' Python stacks (faulthandler, SIGABRT)
+    # kept in gpurun_out/ for the post-mortem, one retry on another port.
+    last = ""
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port + 100 * attempt)] + script_args
+        p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=300)
+            assert p.returncode == 0, se[-3000:]
+            r_stdout = so
+            break
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGABRT)
+            time.sleep(3)
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            so, se = p.communicate()
+            last = se[-6000:]
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "dp_hang_attempt%d_port%d.txt" % (attempt, port)), "w") as f:
+                    f.write(se)
+            except OSError:
+                pass
+    else:
+        raise AssertionError("the %d-rank run hung twice (300 s each); stacks of the last attempt:\n%s" % (nproc, last))
+
+    class _R:
+        stdout = r_stdout
+    r = _R()
     out, dec = [], json.JSONDecoder()
     for line in r.stdout.splitlines():          # ranks share the pipe: two records can land on one line
         i = line.find("{")
