@@ -57,3 +57,19 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
     import torch
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         asr_amd.ops.gemm_nt(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+def test_host_side_size_queries_need_no_gpu():
+    """The workspace / image size entry points and the mode switch are pure host code: callable on the build box."""
+    L = asr_amd.lib()
+    tile_f = 128 * 128 + 128
+    # FFN-shaped weight gradient at S1: 32 output tiles x 8 M-splits of one slab tile each (csrc/wgrad.hip: tn_v2_plan)
+    assert L.asr_gemm_tn_ws_bytes(32000, 256, 2048, 256) == 16 + 8 * 32 * tile_f * 4
+    assert L.asr_gemm_tn_ws_bytes(32000, 256, 2048, 0) == L.asr_gemm_tn_ws_bytes(32000, 256, 2048, 256)
+    # the decoder's 1632 rows: at least 512 rows per split
+    assert L.asr_gemm_tn_ws_bytes(1632, 256, 256, 0) == 16 + 4 * 4 * tile_f * 4
+    assert L.asr_gemm_tn_ws_bytes(1632, 256, 200, 0) == 0              # K % 128: not a shape the slab kernel takes
+    assert L.asr_ffn_bits_words(32000, 2048) == 32 * 2 * 32000
+    assert L.asr_ffn_bits_words(130, 64) == 1 * 2 * 256                # rows padded to the 128-token block
+    old = L.asr_set_deterministic(1)
+    assert L.asr_set_deterministic(old) == 1
