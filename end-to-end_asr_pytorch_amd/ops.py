@@ -275,7 +275,7 @@ PROJ_LN = os.environ.get("ASR_AMD_PROJ_LN", "1") != "0"              # A/B: 0 = 
 
 def proj_ln_ok(a2d, w, D, B, L):
     """Shapes asr_proj_ln_fwd takes: encoder-sized rows (the decoder's go through gemm_add_layernorm_small), 256 -> 256."""
-    return (PROJ_LN and B * L >= FUSED_FFN_MIN_ROWS and D == 256 and tuple(w.shape) == (256, 256) and a2d.dtype == torch.bfloat16 and
+    return (PROJ_LN and B * L >= PROJ_LN_MIN_ROWS and D == 256 and tuple(w.shape) == (256, 256) and a2d.dtype == torch.bfloat16 and
             w.dtype == torch.bfloat16 and a2d.shape[1] == 256 and a2d.is_contiguous() and w.is_contiguous() and B * L * 1024 < 2 ** 31)
 
 
@@ -298,7 +298,11 @@ def proj_ln(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=T
 
 
 FUSED_FFN = os.environ.get("ASR_AMD_FUSED_FFN", "1") != "0"          # A/B: 0 = two GEMMs + LayerNorm / two data-gradient GEMMs
-FUSED_FFN_MIN_ROWS = int(os.environ.get("ASR_AMD_FUSED_FFN_ROWS", "4096"))     # below: a 128-token block per CU leaves most of the chip idle
+# below: a 128-token block per CU leaves most of the chip idle and the launch takes its ~75 us whatever the row count, while the GEMM +
+# GEMM + LayerNorm path scales with the rows (114 us at 32000): the crossover is near 20000 rows (S2 / CIF_Model, 8000 rows: 6.67 ->
+# 6.40 ms and 7.18 -> 6.71 ms per step on the separate launches)
+FUSED_FFN_MIN_ROWS = int(os.environ.get("ASR_AMD_FUSED_FFN_ROWS", "20000"))
+PROJ_LN_MIN_ROWS = int(os.environ.get("ASR_AMD_PROJ_LN_ROWS", "4096"))
 
 
 def ffn_fused_ok(x16, x32, w1, w2, B, L):
