@@ -20,6 +20,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // ---- error plumbing (thread-local message, no exceptions across the ABI) ------------------------------------
 void asr_set_error(const char* fmt, ...);
+// asr_proj_heads for encoder-sized bf16 rows (ffn.hip; called from gemm.hip): 0 = launched, -2 = not its shape
+int asr_proj_heads_rows(hipStream_t stream, const void* X, const void* W, const float* bias, void* out, int64_t proj_stride, int n_proj, int B,
+                        int L, int h, float scale_first);
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
     do {                                  \

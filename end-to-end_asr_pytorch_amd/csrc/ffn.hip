@@ -682,7 +682,180 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
     }
 }
 
+// ---- head-major projections on the same structure (attention.py:43-49: w_qs / w_ks / w_vs + view / permute / contiguous) ---------
+// out[p][b][head][l][0..64) = (x[b, l, :] . W[(p * h + head) * 64 + j, :] + bias) [* scale for p == 0]: a 64-unit chunk of the
+// feed-forward kernel's first product is exactly one head of one projection, and the lane-owned 16-byte pieces of the chunk leave
+// through the same per-wave LDS tile as the hidden activation does there - 128-byte token rows, consecutive tokens of an utterance
+// consecutive in memory.  x is read once for all n_proj * h chunks (the tiled GEMM re-reads it per column block), the weights stream
+// through a ring of THREE 32-KiB images (chunk c + 2 lands while c multiplies, so the fragment ring never drains at a chunk border)
+// and the launch is bound by its own stores.
+struct HeadsArgs {
+    const bf16_t* x16;
+    const bf16_t* w;
+    const float* bias;
+    bf16_t* out;
+    int M, L, h, nch, nscaled, N;
+    long long proj_stride;      // elements between projections
+    float scale;
+};
+constexpr int HEADS_MAX_N = 4096;
+constexpr int HEADS_SMEM = 3 * W1BUF + HST_BYTES + HEADS_MAX_N * 4;
+
+__global__ __launch_bounds__(256, 1) void proj_heads_rows_kernel(const HeadsArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[HEADS_SMEM];
+    unsigned char* const w1s = smem;
+    float* const b1s = reinterpret_cast<float*>(smem + 3 * W1BUF + HST_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const hst = smem + 3 * W1BUF + wave * 4096;
+    const int r = lane & 31, h = lane >> 5;
+    const int m = blockIdx.x * FBM + wave * 32 + r;
+    const int mc = m < a.M ? m : a.M - 1;
+    const int NC = a.nch;
+
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w), 0, a.N * FD * 2, 0x00020000);
+    unsigned off1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {       // (the feed-forward kernel's W1 image: piece p = rows 2p, 2p + 1 of the chunk; 16-byte slot pc of row u holds chunk (pc & 16) | ((pc ^ u) & 15))
+        const int p = wave * 8 + k, u = 2 * p + (lane >> 5), pc = lane & 31;
+        off1[k] = (unsigned)(u * FD * 2 + ((pc & 16) | ((pc ^ u) & 15)) * 16);
+    }
+    auto dma_w = [&](int buf, int chunk, int j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(w1s + buf * W1BUF + (wave * 8 + j) * 1024), 16, off1[j], chunk * (FHC * FD * 2), 0, 0);
+    };
+    const int ur = swap23(r), u15 = ur & 15;      // MFMA row r holds unit swap23(r) of the chunk: a lane's 16 accumulator registers are two runs of 8 consecutive units
+    unsigned a1[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) a1[kk] = (unsigned)(ur * 512 + (((2 * kk + h) ^ u15) << 4));
+
+    bf16x8 xb[16];
+    {
+        const bf16_t* xr = a.x16 + (int64_t)mc * FD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
+    }
+    for (int i = tid * 4; i < a.N; i += 1024)
+        *reinterpret_cast<f32x4*>(b1s + i) = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_w(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_w(1, NC > 1 ? 1 : 0, j);
+
+    // output addressing: token mt of this wave's store slot ps -> (b, l); one 128-byte row per (token, chunk)
+    const auto rso = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((int64_t)(NC / a.h) * a.proj_stride * 2), 0x00020000);
+    const unsigned hwr = (unsigned)(r * 128), hrd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
+    unsigned hoff[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int mt = blockIdx.x * FBM + wave * 32 + 8 * ps + (lane >> 3);
+        const int b = mt / a.L, l = mt - b * a.L;
+        hoff[ps] = mt < a.M ? ((unsigned)(b * a.h) * (unsigned)a.L + (unsigned)l) * 128u + 16u * (lane & 7) : 0x80000000u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto frag1 = [&](const unsigned char* w1, int k) {
+        const int ks = k >> 1, t = k & 1;
+        return *reinterpret_cast<const bf16x8*>(w1 + a1[ks & 7] + t * 16384 + (ks >> 3) * 256);
+    };
+    auto init_s = [&](int chunk, f32x16 (&S)[2]) {
+        const float* bb = b1s + chunk * FHC + 8 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(bb + 32 * t), q1 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 4);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 16), q3 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 20);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { S[t][j] = q0[j]; S[t][4 + j] = q1[j]; S[t][8 + j] = q2[j]; S[t][12 + j] = q3[j]; }
+        }
+    };
+    auto pack_pair = [&](const f32x16 (&S)[2], u32x4 (&Hn)[4], int P, float sc) {
+        const int t = P >> 3, p = P & 7;
+        uint32_t pk;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(S[t][2 * p] * sc), "v"(S[t][2 * p + 1] * sc));
+        Hn[2 * t + (p >> 2)][p & 3] = pk;
+    };
+    auto out_soff = [&](int chunk) {       // byte offset of (projection, head) = chunk
+        const int p = chunk / a.h, hd = chunk - p * a.h;
+        return (unsigned)((int64_t)p * a.proj_stride * 2 + (int64_t)hd * a.L * 128);
+    };
+#define HEADS_STEP() __builtin_amdgcn_sched_barrier(0)
+    bf16x8 A[16];
+    u32x4 Hn[4], Hout[4];
+    // chunk c: 32 MFMAs into Sc; beside them the previous chunk's accumulators Sp leave (pack: steps 0..15, tile: 3 / 7 / 11 / 15,
+    // row-wise read-back: 20..23, stores: 24 / 26 / 28 / 30).  VMEM order: 8 LDS-DMA pieces (chunk c + 2), then the 4 stores - the wait
+    // at the end leaves exactly the stores in flight.
+    auto body = [&](int c, f32x16 (&Sc)[2], f32x16 (&Sp)[2], auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const int bc = c % 3, bn = (c + 1) % 3, bd = (c + 2) % 3;
+        const unsigned char* wc = w1s + bc * W1BUF;
+        const unsigned char* wn = w1s + bn * W1BUF;
+        const int cd = c + 2 < NC ? c + 2 : NC - 1;
+        const float sc = (!FIRST && c - 1 < a.nscaled) ? a.scale : 1.0f;
+        const unsigned so = FIRST ? 0u : out_soff(c - 1);
+        init_s(c, Sc);
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) A[k] = frag1(wc, k);
+        }
+        HEADS_STEP();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            Sc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], Sc[k & 1], 0, 0, 0);
+            A[(k + 8) & 15] = k + 8 < 32 ? frag1(wc, k + 8) : frag1(wn, k + 8 - 32);
+            if (k < 16 && !(k & 1)) dma_w(bd, cd, k >> 1);
+            if constexpr (!FIRST) {
+                if (k < 16) pack_pair(Sp, Hn, k, sc);
+                if (k < 16 && (k & 3) == 3) *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 2) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 2];
+                if (k >= 20 && k < 24) Hout[k - 20] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 20) * 1024);
+                if (k >= 24 && !(k & 1)) __builtin_amdgcn_raw_buffer_store_b128(Hout[(k - 24) >> 1], rso, hoff[(k - 24) >> 1], so, 0);
+            }
+            HEADS_STEP();
+        }
+        if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    f32x16 SA[2], SB[2];
+    body(0, SA, SB, std::true_type{});
+    for (int c = 1; c < NC; ++c) {
+        if (c & 1) body(c, SB, SA, std::false_type{});
+        else body(c, SA, SB, std::false_type{});
+    }
+#undef HEADS_STEP
+    // the last chunk's accumulators
+    {
+        const float sc = NC - 1 < a.nscaled ? a.scale : 1.0f;
+        const unsigned so = out_soff(NC - 1);
+        auto drain = [&](f32x16 (&Sp)[2]) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                pack_pair(Sp, Hn, k, sc);
+                if ((k & 3) == 3) *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 2) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 2];
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) Hout[ps] = *reinterpret_cast<const u32x4*>(hst + hrd + ps * 1024);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) __builtin_amdgcn_raw_buffer_store_b128(Hout[ps], rso, hoff[ps], so, 0);
+        };
+        if ((NC - 1) & 1) drain(SB);
+        else drain(SA);
+    }
+}
+
 }  // namespace
+
+// asr_proj_heads's encoder-sized bf16 case (gemm.hip dispatches here): 0 = launched, -2 = not this kernel's shape
+int asr_proj_heads_rows(hipStream_t stream, const void* X, const void* W, const float* bias, void* out, int64_t proj_stride, int n_proj,
+                        int B, int L, int h, float scale_first) {
+    const int64_t M64 = (int64_t)B * L, N64 = (int64_t)n_proj * h * 64;
+    if (N64 > HEADS_MAX_N || M64 * h * 128 >= (1ll << 31) || (int64_t)n_proj * proj_stride * 2 >= (1ll << 31)) return -2;
+    HeadsArgs a{(const bf16_t*)X, (const bf16_t*)W, bias, (bf16_t*)out, (int)M64, L, h, n_proj * h, scale_first != 1.0f ? h : 0, (int)N64,
+                (long long)proj_stride, scale_first};
+    hipLaunchKernelGGL(proj_heads_rows_kernel, dim3((unsigned)((M64 + FBM - 1) / FBM)), dim3(256), 0, stream, a);
+    ASR_LAUNCH_CHECK("asr_proj_heads(rows)");
+    return 0;
+}
 
 static unsigned long long* g_ffn_stamps = nullptr;
 #ifdef FFN_STAMP

@@ -1093,6 +1093,16 @@ extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t 
         EpiHeads<float> epi{reinterpret_cast<float*>(out), proj_stride, bias, L, h, M, N, scale_first};
         return launch_gemm<float, float>(s, X, ldx, W, ldw, M, N, K, epi);
     }
+    if (x_dtype == ASR_BF16 && K == 256 && ldx == 256 && ldw == 256) {
+        // encoder-sized rows: the feed-forward kernel's structure (ffn.hip: x read once for all heads, store-bound); ASR_AMD_HEADS_ROWS=0
+        // switches it off, ASR_AMD_HEADS_MIN_ROWS moves the threshold (read per call: the parity test toggles them)
+        const char* e = getenv("ASR_AMD_HEADS_ROWS");
+        const char* mr = getenv("ASR_AMD_HEADS_MIN_ROWS");
+        if ((!e || atoi(e) != 0) && M >= (mr ? atoi(mr) : 16384)) {
+            const int rc = asr_proj_heads_rows(s, X, W, bias, out, proj_stride, n_proj, B, L, h, scale_first);
+            if (rc != -2) return rc;
+        }
+    }
     EpiHeads<bf16_t> epi{reinterpret_cast<bf16_t*>(out), proj_stride, bias, L, h, M, N, scale_first};
     if (x_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
     if (K % 64 == 0 && K >= (getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64) && getenv("ASR_AMD_NO_GLDS") == nullptr)

@@ -146,6 +146,44 @@ __global__ __launch_bounds__(256) void assigner_tail_kernel(const float* __restr
     if (lane == 0) alpha[row] = (t < len[b]) ? a : 0.f;
 }
 
+// Decoder.preprocess (src/transformer/decoder.py:42-58) as one launch: one wave per utterance strips the pad (0) entries of its
+// target row in order (ballot + prefix count), writes <sos> + tokens + 0-padding and tokens + <eos> + 0-padding, both [B, W], and the
+// row's lengths.  Tokens that do not fit (more than W - 1 non-pad entries) set *overflow.
+__global__ __launch_bounds__(256) void decoder_targets_kernel(const int64_t* __restrict__ targets, int64_t* __restrict__ ys_in,
+                                                              int64_t* __restrict__ ys_out, int32_t* __restrict__ in_len,
+                                                              int64_t* __restrict__ n_out, int32_t* __restrict__ overflow, int B, int U,
+                                                              int W, int64_t sos, int64_t eos) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t* row = targets + (int64_t)b * U;
+    int64_t* yi = ys_in + (int64_t)b * W;
+    int64_t* yo = ys_out + (int64_t)b * W;
+    int n = 0;
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        const int64_t v = u < U ? row[u] : 0;
+        const unsigned long long keep = __ballot(v != 0);
+        const int pos = n + __popcll(keep & ((1ull << lane) - 1ull));
+        if (v != 0 && pos < W - 1) {
+            yi[1 + pos] = v;
+            yo[pos] = v;
+        }
+        n += __popcll(keep);
+    }
+    const int nc = n < W - 1 ? n : W - 1;
+    if (lane == 0) {
+        yi[0] = sos;
+        yo[nc] = eos;
+        if (in_len) in_len[b] = (sos > 0 ? 1 : 0) + nc;      // what (ys_in > 0).sum(1) of decoder.py:83's non_pad_mask input counts (token ids are > 0)
+        if (n_out) n_out[b] = nc;
+        if (n > W - 1 && overflow) *overflow = 1;
+    }
+    for (int u = nc + 1 + lane; u < W; u += 64) {
+        yi[u] = 0;
+        yo[u] = 0;
+    }
+}
+
 }  // namespace
 
 extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
@@ -162,6 +200,16 @@ extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* 
     hipLaunchKernelGGL(add_layernorm_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, residual,
                        gamma, beta, pe, row_len, y32, reinterpret_cast<bf16_t*>(y16), mean, rstd, s_out, M, L, D, eps, drop_x, drop_y);
     ASR_LAUNCH_CHECK("add_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int asr_decoder_targets(void* stream, const int64_t* targets, int64_t* ys_in, int64_t* ys_out, int32_t* in_len, int64_t* n_out,
+                                   int32_t* overflow, int B, int U, int W, int64_t sos_id, int64_t eos_id) {
+    ASR_REQUIRE(targets && ys_in && ys_out, ASR_ERR_ARG, "decoder_targets: null pointer");
+    ASR_REQUIRE(B > 0 && U > 0 && W >= 1, ASR_ERR_ARG, "decoder_targets: B=%d U=%d W=%d", B, U, W);
+    hipLaunchKernelGGL(decoder_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), targets, ys_in, ys_out,
+                       in_len, n_out, overflow, B, U, W, sos_id, eos_id);
+    ASR_LAUNCH_CHECK("decoder_targets");
     return 0;
 }
 

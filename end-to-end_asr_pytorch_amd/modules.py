@@ -1057,11 +1057,19 @@ class Decoder(_Cached):
     def preprocess(self, targets, umax=None):
         """decoder.py:42-58 — strip pad(0), prepend <sos> / append <eos>, re-pad with 0.  `umax` = the longest target of the batch
         when the caller knows it (the data loader does): without it one host sync reads it back from the device."""
+        return self._preprocess(targets, umax)[:2]
+
+    def _preprocess(self, targets, umax=None):
+        """-> (ys_in, ys_out, number of positive entries per row of ys_in as int32)"""
         hint = self.__dict__.get("_pre_hint")      # the trainer pre-computes this before queueing the step (no mid-step host sync)
         if hint is not None and hint[0] is targets:
             if len(hint) > 2 and hint[2] is not None:          # computed on a side stream: order the consumer after it
                 torch.cuda.current_stream().wait_event(hint[2])
             return hint[1]
+        if targets.is_cuda and targets.dtype == torch.int64:
+            if umax is None:
+                umax = int((targets != 0).sum(1).max().item())
+            return ops.decoder_targets(targets, self.sos_id, self.eos_id, umax)      # one launch
         comp, n = _compact_targets(targets)
         if umax is None:
             umax = int(n.max().item())
@@ -1070,12 +1078,11 @@ class Decoder(_Cached):
         ys_in = torch.cat([torch.full((B, 1), self.sos_id, dtype=targets.dtype, device=targets.device), ys], 1)
         ys_out = torch.cat([ys, torch.zeros((B, 1), dtype=targets.dtype, device=targets.device)], 1)
         ys_out.scatter_(1, n[:, None], self.eos_id)
-        return ys_in, ys_out
+        return ys_in, ys_out, ((ys_in > 0).sum(1)).to(torch.int32)
 
     def _impl(self, targets, enc, enc_len):
-        ys_in, ys_out = self.preprocess(targets)
+        ys_in, ys_out, dec_len = self._preprocess(targets)
         B, U = ys_in.shape
-        dec_len = ((ys_in > 0).sum(1)).to(torch.int32)
         dp = _drop(self, "dropout")   # decoder.py:83
         x32, x16 = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U),
                                 want_bf16=(_PRECISION == "bf16"), drop=dp)

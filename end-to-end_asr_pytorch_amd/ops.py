@@ -366,6 +366,22 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
     return y32, y16, mean, rstd
 
 
+def decoder_targets(targets, sos_id, eos_id, umax, overflow=None):
+    """Decoder.preprocess (decoder.py:42-58) in one launch -> (ys_in [B, umax + 1], ys_out [B, umax + 1], in_len int32 [B]).
+    `umax` = the longest target (non-pad entries) of the batch; `overflow` (int32 [1], optional) is set if a row held more."""
+    _req_cuda(targets)
+    assert targets.dtype == torch.int64 and targets.dim() == 2
+    targets = targets.contiguous()
+    B, U = targets.shape
+    W = int(umax) + 1
+    ys_in = torch.empty((B, W), device=targets.device, dtype=torch.int64)
+    ys_out = torch.empty((B, W), device=targets.device, dtype=torch.int64)
+    in_len = torch.empty((B,), device=targets.device, dtype=torch.int32)
+    check(lib().asr_decoder_targets(_stream(), _p(targets), _p(ys_in), _p(ys_out), _p(in_len), None, _p(overflow), B, U, W,
+                                    int(sos_id), int(eos_id)), "asr_decoder_targets")
+    return ys_in, ys_out, in_len
+
+
 def embed_pe(ids, emb, pe, want_bf16=False, drop=None):
     _req_cuda(ids, emb, pe)
     B, U = ids.shape

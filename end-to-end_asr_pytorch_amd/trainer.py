@@ -281,13 +281,13 @@ class Trainer:
                 main, aux = torch.cuda.current_stream(), ops.aux_stream(targets.device, slot=4)
                 aux.wait_stream(main)
                 with torch.cuda.stream(aux):
-                    pre = model.decoder.preprocess(targets, umax=max_target_len)
+                    pre = model.decoder._preprocess(targets, umax=max_target_len)
                 for t in pre:
                     t.record_stream(main)
                 ev = torch.cuda.Event()
                 ev.record(aux)
             else:
-                pre = model.decoder.preprocess(targets, umax=max_target_len)
+                pre = model.decoder._preprocess(targets, umax=max_target_len)
             model.decoder.__dict__["_pre_hint"] = (targets, pre, ev)
             model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1], ev)
         cif_hint = isinstance(model, modules.CIF_Model) and max_target_len is not None

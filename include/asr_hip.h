@@ -289,6 +289,13 @@ int asr_step_tick(void* stream, uint32_t* state, float k, float init_lr, float w
 int asr_adam_step_dev(void* stream, float* p, const float* g, float* m, float* v, void* p16, int64_t n, const uint32_t* state,
                       float beta1, float beta2, float eps, float grad_scale);
 
+/* Decoder.preprocess (src/transformer/decoder.py:42-58) in one launch: per utterance strip the pad (0) entries of targets[b, 0..U)
+ * in order, ys_in[b] = <sos> tokens 0.. and ys_out[b] = tokens <eos> 0.., both [B, W] with W = longest target + 1 (the caller knows
+ * it - the loader does - or reads it back once).  Optional outputs: in_len[b] = number of positive entries of ys_in[b] (the decoder's
+ * non-pad length, decoder.py:83), n_out[b] = tokens kept, *overflow set to 1 if a row held more than W - 1 tokens (the rest dropped). */
+int asr_decoder_targets(void* stream, const int64_t* targets, int64_t* ys_in, int64_t* ys_out, int32_t* in_len, int64_t* n_out,
+                        int32_t* overflow, int B, int U, int W, int64_t sos_id, int64_t eos_id);
+
 /* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = dropout(emb[ids[b,u],:] + pe[u,:]). */
 int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16,
                      int B, int U, int D, int V, asr_dropout_t drop);

@@ -158,3 +158,31 @@ def test_proj_ln_equals_the_gemm_and_layernorm_pair(B, L, drop, monkeypatch):
         assert torch.equal(s1[m == 0], res[m == 0])
     s0, y32c, _, _, _ = ops.proj_ln(ctx, w, bias, res, gam, bet, B, L, row_len=lens, save_stats=False, drop_x=d)      # eval form
     assert s0 is None and torch.equal(y32c, y32a)
+
+
+@pytest.mark.parametrize("B,L,n_proj,h,scale", [(32, 1000, 3, 4, 0.125 * 1.4426950408889634), (32, 1000, 12, 4, 1.0), (33, 517, 1, 4, 1.0),
+                                                (17, 1001, 3, 1, 0.5), (2, 9000, 2, 4, 1.0)])
+def test_proj_heads_rows_kernel_equals_the_tiled_gemm(B, L, n_proj, h, scale, monkeypatch):
+    """asr_proj_heads at encoder size (ffn.hip: proj_heads_rows_kernel; attention.py:43-49) against the tiled GEMM it replaces and
+    against torch fp32 on the bf16-rounded operands: all projections / heads, the Q scale, a ragged last row block, odd chunk counts."""
+    g = torch.Generator().manual_seed(B * L + n_proj)
+    M, Nn = B * L, n_proj * h * 64
+    x = torch.randn(M, 256, generator=g).bfloat16()
+    w = (torch.randn(Nn, 256, generator=g) * 0.06).bfloat16()
+    bias = torch.randn(Nn, generator=g) * 0.1
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    monkeypatch.setenv("ASR_AMD_HEADS_ROWS", "0")
+    old = ops.proj_heads(xd, wd, bd, n_proj, B, L, h, scale)
+    monkeypatch.setenv("ASR_AMD_HEADS_ROWS", "1")
+    new = torch.full((n_proj, B, h, L, 64), float("nan"), device=DEV, dtype=torch.bfloat16)
+    new.copy_(ops.proj_heads(xd, wd, bd, n_proj, B, L, h, scale))
+    torch.cuda.synchronize()
+    ref = (x.float() @ w.float().t() + bias).view(B, L, n_proj, h, 64).permute(2, 0, 3, 1, 4).contiguous()
+    ref[0] *= scale
+    assert torch.isfinite(new.float()).all()
+    # against fp32: one bf16 rounding of a value of magnitude ~1
+    np.testing.assert_allclose(new.float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
+    # against the tiled GEMM: the same products summed in another order - at most one bf16 ulp apart, and almost everywhere equal
+    d = (new.float() - old.float()).abs().cpu()
+    assert float(d.max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+    assert float((d > 0).float().mean()) < 0.02

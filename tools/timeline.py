@@ -63,6 +63,24 @@ def main():
         else:
             for r in live:
                 own[short(r[2])] += (b - a) / len(live)
+    # idle intervals (nothing running): which kernel ended before and which starts after, summed by that pair of names
+    gaps = defaultdict(lambda: [0, 0])
+    biggest = []
+    end_sorted = sorted(step, key=lambda r: r[1])
+    cur_end, cur_name = None, None
+    for r in step_sorted:
+        if cur_end is not None and r[0] > cur_end:
+            g = r[0] - cur_end
+            gaps[(cur_name, short(r[2]))][0] += g; gaps[(cur_name, short(r[2]))][1] += 1
+            biggest.append((g, (cur_end - t0) / 1e6, cur_name, short(r[2])))
+        if cur_end is None or r[1] > cur_end:
+            cur_end, cur_name = r[1], short(r[2])
+    print("idle by (kernel that ended last -> kernel that starts): total us, count")
+    for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:25]:
+        print("  %8.1f us %3d  %s -> %s" % (v[0] / 1e3, v[1], k[0][:44], k[1][:44]))
+    print("largest idle intervals: us, at ms, between")
+    for g, at, a, b in sorted(biggest, reverse=True)[:15]:
+        print("  %8.1f us at %7.3f  %s -> %s" % (g / 1e3, at, a[:44], b[:44]))
     print("wall-clock share (time split equally among the kernels running at each instant):")
     for k, v in sorted(own.items(), key=lambda kv: -kv[1])[:28]:
         print("  %-62s %.3f ms" % (k, v / 1e6))
