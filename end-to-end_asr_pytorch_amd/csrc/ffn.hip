@@ -686,9 +686,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
 // out[p][b][head][l][0..64) = (x[b, l, :] . W[(p * h + head) * 64 + j, :] + bias) [* scale for p == 0]: a 64-unit chunk of the
 // feed-forward kernel's first product is exactly one head of one projection, and the lane-owned 16-byte pieces of the chunk leave
 // through the same per-wave LDS tile as the hidden activation does there - 128-byte token rows, consecutive tokens of an utterance
-// consecutive in memory.  x is read once for all n_proj * h chunks (the tiled GEMM re-reads it per column block), the weights stream
-// through a ring of THREE 32-KiB images (chunk c + 2 lands while c multiplies, so the fragment ring never drains at a chunk border)
-// and the launch is bound by its own stores.
+// consecutive in memory.  x is read once for all n_proj * h chunks (the tiled GEMM re-reads it per column block).  At one wave per
+// SIMD nothing hides a wait, so nothing in a chunk may wait: the weights stream through a ring of FOUR 32-KiB images requested three
+// chunks ahead (the fragment ring runs across chunk borders, and a chunk's stores have two chunk times to be acknowledged before a
+// wait counts them), the next chunk's bias is read into the MFMA C operand during this chunk, and the previous chunk's accumulators
+// leave beside this chunk's MFMAs.
 struct HeadsArgs {
     const bf16_t* x16;
     const bf16_t* w;
@@ -698,16 +700,18 @@ struct HeadsArgs {
     long long proj_stride;      // elements between projections
     float scale;
 };
-constexpr int HEADS_MAX_N = 4096;
-constexpr int HEADS_SMEM = 3 * W1BUF + HST_BYTES + HEADS_MAX_N * 4;
+constexpr int HEADS_MAX_N = 3072;
+constexpr int HEADS_SMEM = 4 * W1BUF + HST_BYTES + HEADS_MAX_N * 4;
 
+// ABL (timing diagnostics only, wrong results): 1 = no LDS-DMA in the loop, 2 = no fragment reads, 4 = nothing leaves, 8 = no MFMA
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 1) void proj_heads_rows_kernel(const HeadsArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[HEADS_SMEM];
     unsigned char* const w1s = smem;
-    float* const b1s = reinterpret_cast<float*>(smem + 3 * W1BUF + HST_BYTES);
+    float* const b1s = reinterpret_cast<float*>(smem + 4 * W1BUF + HST_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* const hst = smem + 3 * W1BUF + wave * 4096;
+    unsigned char* const hst = smem + 4 * W1BUF + wave * 4096;
     const int r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * FBM + wave * 32 + r;
     const int mc = m < a.M ? m : a.M - 1;
@@ -734,12 +738,14 @@ __global__ __launch_bounds__(256, 1) void proj_heads_rows_kernel(const HeadsArgs
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
     }
-    for (int i = tid * 4; i < a.N; i += 1024)
-        *reinterpret_cast<f32x4*>(b1s + i) = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid * 4; i < a.N; i += 1024) {      // (pre-scaled where the output is: the pack is one fma per register pair)
+        const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(b1s + i) = i < a.nscaled * FHC ? bv * a.scale : bv;
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_w(0, 0, j);
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_w(1, NC > 1 ? 1 : 0, j);
+        for (int j = 0; j < 8; ++j) dma_w(c, c < NC ? c : NC - 1, j);
 
     // output addressing: token mt of this wave's store slot ps -> (b, l); one 128-byte row per (token, chunk)
     const auto rso = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((int64_t)(NC / a.h) * a.proj_stride * 2), 0x00020000);
@@ -758,88 +764,118 @@ __global__ __launch_bounds__(256, 1) void proj_heads_rows_kernel(const HeadsArgs
         const int ks = k >> 1, t = k & 1;
         return *reinterpret_cast<const bf16x8*>(w1 + a1[ks & 7] + t * 16384 + (ks >> 3) * 256);
     };
-    auto init_s = [&](int chunk, f32x16 (&S)[2]) {
-        const float* bb = b1s + chunk * FHC + 8 * h;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(bb + 32 * t), q1 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 4);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 16), q3 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 20);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { S[t][j] = q0[j]; S[t][4 + j] = q1[j]; S[t][8 + j] = q2[j]; S[t][12 + j] = q3[j]; }
-        }
-    };
-    auto pack_pair = [&](const f32x16 (&S)[2], u32x4 (&Hn)[4], int P, float sc) {
-        const int t = P >> 3, p = P & 7;
-        uint32_t pk;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(S[t][2 * p] * sc), "v"(S[t][2 * p + 1] * sc));
-        Hn[2 * t + (p >> 2)][p & 3] = pk;
+    // piece i (0..7) of a chunk's bias in accumulator layout: tile i >> 2, registers 4 (i & 3) .. + 4 = register pairs 2 i, 2 i + 1
+    auto bias_piece = [&](int chunk, int i) {
+        return *reinterpret_cast<const f32x4*>(b1s + chunk * FHC + 8 * h + 32 * (i >> 2) + ((i & 3) >> 1) * 16 + (i & 1) * 4);
     };
     auto out_soff = [&](int chunk) {       // byte offset of (projection, head) = chunk
         const int p = chunk / a.h, hd = chunk - p * a.h;
         return (unsigned)((int64_t)p * a.proj_stride * 2 + (int64_t)hd * a.L * 128);
     };
 #define HEADS_STEP() __builtin_amdgcn_sched_barrier(0)
-    bf16x8 A[16];
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    bf16x8 A[8];        // fragment ring: MFMA k takes A[k & 7], which is requested again for MFMA k + 8 right behind it
     u32x4 Hn[4], Hout[4];
-    // chunk c: 32 MFMAs into Sc; beside them the previous chunk's accumulators Sp leave (pack: steps 0..15, tile: 3 / 7 / 11 / 15,
-    // row-wise read-back: 20..23, stores: 24 / 26 / 28 / 30).  VMEM order: 8 LDS-DMA pieces (chunk c + 2), then the 4 stores - the wait
-    // at the end leaves exactly the stores in flight.
+    f32x4 Bq[4];        // bias pieces on their way to the pack
+    // register pair P of a finished chunk: (acc * scale + bias * scale) -> two bf16 (the staged bias is pre-scaled).  Three stages, one
+    // step apart, so that no instruction of a step waits for another of the same step (at one wave per SIMD a dependent VALU pair
+    // costs its full latency: tools/probe/clock_probe.hip modes 22 / 25 - 34 against 44 cycles per one-MFMA step):
+    //   fetch: the pair into plain VGPRs (the accumulators live in AGPRs)   fma: * scale + bias   pack: cvt_pk into the tile word
+    float st0[16], st1[16];
+    f32x2_t fv[16];
+    auto pack_fetch = [&](const f32x16 (&S)[2], int P) {
+        st0[P] = S[P >> 3][2 * (P & 7)];
+        st1[P] = S[P >> 3][2 * (P & 7) + 1];
+        asm volatile("" : "+v"(st0[P]), "+v"(st1[P]));
+    };
+    auto pack_fma = [&](int P, f32x2_t sc2) {
+        const f32x4 bq = Bq[(P >> 1) & 3];
+        fv[P] = __builtin_elementwise_fma(f32x2_t{st0[P], st1[P]}, sc2, f32x2_t{bq[(P & 1) * 2], bq[(P & 1) * 2 + 1]});
+    };
+    auto pack_cvt = [&](int P) {
+        uint32_t pk;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(fv[P][0]), "v"(fv[P][1]));
+        Hn[P >> 2][P & 3] = pk;
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // chunk c: 32 MFMAs into Sc; beside them the previous chunk's accumulators Sp leave (pack: steps 0..15 with the bias pieces read
+    // two steps ahead, tile: 3 / 7 / 11 / 15, row-wise read-back: 20..23, stores: 24 / 26 / 28 / 30), and from step 24 the fragments
+    // requested are the next chunk's.  VMEM order: 8 LDS-DMA pieces (chunk c + 3), then the 4 stores.
+    // Register budget: everything here has to fit the 256 architectural VGPRs - what does not is parked in AGPRs and every
+    // v_accvgpr move runs in series with the MFMAs (measured: 160 of them per chunk cost more than the chunk's 32 MFMAs).
     auto body = [&](int c, f32x16 (&Sc)[2], f32x16 (&Sp)[2], auto first_c) {
         constexpr bool FIRST = decltype(first_c)::value;
-        const int bc = c % 3, bn = (c + 1) % 3, bd = (c + 2) % 3;
-        const unsigned char* wc = w1s + bc * W1BUF;
-        const unsigned char* wn = w1s + bn * W1BUF;
-        const int cd = c + 2 < NC ? c + 2 : NC - 1;
-        const float sc = (!FIRST && c - 1 < a.nscaled) ? a.scale : 1.0f;
+        const unsigned char* wc = w1s + (c & 3) * W1BUF;
+        const unsigned char* wn = w1s + ((c + 1) & 3) * W1BUF;
+        const int bd = (c + 3) & 3, cd = c + 3 < NC ? c + 3 : NC - 1;
         const unsigned so = FIRST ? 0u : out_soff(c - 1);
-        init_s(c, Sc);
-        if constexpr (FIRST) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) A[k] = frag1(wc, k);
-        }
-        HEADS_STEP();
+        const float sc = (!FIRST && c - 1 < a.nscaled) ? a.scale : 1.0f;
+        const f32x2_t sc2 = {sc, sc};
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
-            Sc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], Sc[k & 1], 0, 0, 0);
-            A[(k + 8) & 15] = k + 8 < 32 ? frag1(wc, k + 8) : frag1(wn, k + 8 - 32);
-            if (k < 16 && !(k & 1)) dma_w(bd, cd, k >> 1);
-            if constexpr (!FIRST) {
-                if (k < 16) pack_pair(Sp, Hn, k, sc);
-                if (k < 16 && (k & 3) == 3) *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 2) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 2];
-                if (k >= 20 && k < 24) Hout[k - 20] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 20) * 1024);
-                if (k >= 24 && !(k & 1)) __builtin_amdgcn_raw_buffer_store_b128(Hout[(k - 24) >> 1], rso, hoff[(k - 24) >> 1], so, 0);
+            if (!(ABL & 8)) Sc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 7], xb[k >> 1], k < 2 ? zero16 : Sc[k & 1], 0, 0, 0);
+            if (!(ABL & 2)) A[k & 7] = k + 8 < 32 ? frag1(wc, k + 8) : frag1(wn, k + 8 - 32);
+            if (k < 16 && !(k & 1) && !(ABL & 1)) dma_w(bd, cd, k >> 1);
+            if constexpr (!FIRST && !(ABL & 4)) {
+                if (k < 12 && !(k & 1)) Bq[((k >> 1) + 2) & 3] = bias_piece(c - 1, (k >> 1) + 2);
+                if (k == 0) pack_fetch(Sp, 0);
+                if (k >= 1 && k < 17) pack_cvt(k - 1);
+                if (k < 16) pack_fma(k, sc2);
+                if (k + 1 < 16) pack_fetch(Sp, k + 1);
+                if (k >= 4 && k < 17 && (k & 3) == 0 && !(ABL & 32)) *reinterpret_cast<u32x4*>(hst + hwr + ((((((k >> 2) - 1) * 2 + h)) ^ (r & 7)) << 4)) = Hn[(k >> 2) - 1];
+                if (k >= 20 && k < 24 && !(ABL & 32)) Hout[k - 20] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 20) * 1024);
+                if (k >= 24 && !(k & 1) && !(ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128((ABL & 32) ? Hn[(k - 24) >> 1] : Hout[(k - 24) >> 1], rso, hoff[(k - 24) >> 1], so, 0);
+                if ((ABL & 16) && k == 31) asm volatile("" :: "v"(Hout[0]), "v"(Hout[1]), "v"(Hout[2]), "v"(Hout[3]), "v"(Hn[0]), "v"(Hn[1]), "v"(Hn[2]), "v"(Hn[3]));
             }
+            if (k == 28 || k == 30) Bq[(k - 28) >> 1] = bias_piece(c, (k - 28) >> 1);      // the first two pieces of THIS chunk, for the next body
             HEADS_STEP();
         }
-        if (FIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // chunk c + 2's image (requested one chunk ago, read from step 24 of the next chunk) has to be there; everything younger may
+        // stay in flight: this chunk's 8 pieces and 4 stores, the previous chunk's 4 stores.  (Waiting for the stores themselves ran
+        // the launch at their latency.)
+        if constexpr (!FIRST && !(ABL & 21)) {
+            if (c == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else if constexpr (ABL != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
     f32x16 SA[2], SB[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) A[k] = frag1(w1s, k);
+    HEADS_STEP();
     body(0, SA, SB, std::true_type{});
-    for (int c = 1; c < NC; ++c) {
-        if (c & 1) body(c, SB, SA, std::false_type{});
-        else body(c, SA, SB, std::false_type{});
+    int c = 1;
+    for (; c + 1 < NC; c += 2) {
+        body(c, SB, SA, std::false_type{});
+        body(c + 1, SA, SB, std::false_type{});
     }
 #undef HEADS_STEP
     // the last chunk's accumulators
-    {
-        const float sc = NC - 1 < a.nscaled ? a.scale : 1.0f;
+    auto drain = [&](f32x16 (&Sp)[2]) {
         const unsigned so = out_soff(NC - 1);
-        auto drain = [&](f32x16 (&Sp)[2]) {
+        const float sc = NC - 1 < a.nscaled ? a.scale : 1.0f;
+        const f32x2_t sc2 = {sc, sc};
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                pack_pair(Sp, Hn, k, sc);
-                if ((k & 3) == 3) *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 2) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 2];
-            }
+        for (int k = 0; k < 16; ++k) {
+            if (!(k & 1)) Bq[(k >> 1) & 3] = bias_piece(NC - 1, k >> 1);
+            pack_fetch(Sp, k);
+            pack_fma(k, sc2);
+            pack_cvt(k);
+            if ((k & 3) == 3) *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 2) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 2];
+        }
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) Hout[ps] = *reinterpret_cast<const u32x4*>(hst + hrd + ps * 1024);
+        for (int ps = 0; ps < 4; ++ps) Hout[ps] = *reinterpret_cast<const u32x4*>(hst + hrd + ps * 1024);
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) __builtin_amdgcn_raw_buffer_store_b128(Hout[ps], rso, hoff[ps], so, 0);
-        };
-        if ((NC - 1) & 1) drain(SB);
-        else drain(SA);
+        for (int ps = 0; ps < 4; ++ps) __builtin_amdgcn_raw_buffer_store_b128(Hout[ps], rso, hoff[ps], so, 0);
+    };
+    if (c < NC) {
+        body(c, SB, SA, std::false_type{});
+        drain(SB);
+    } else {
+        drain(SA);
     }
 }
 
@@ -852,7 +888,14 @@ int asr_proj_heads_rows(hipStream_t stream, const void* X, const void* W, const 
     if (N64 > HEADS_MAX_N || M64 * h * 128 >= (1ll << 31) || (int64_t)n_proj * proj_stride * 2 >= (1ll << 31)) return -2;
     HeadsArgs a{(const bf16_t*)X, (const bf16_t*)W, bias, (bf16_t*)out, (int)M64, L, h, n_proj * h, scale_first != 1.0f ? h : 0, (int)N64,
                 (long long)proj_stride, scale_first};
-    hipLaunchKernelGGL(proj_heads_rows_kernel, dim3((unsigned)((M64 + FBM - 1) / FBM)), dim3(256), 0, stream, a);
+    const dim3 grid((unsigned)((M64 + FBM - 1) / FBM));
+    const int abl = getenv("ASR_AMD_HEADS_ABL") ? atoi(getenv("ASR_AMD_HEADS_ABL")) : 0;
+    switch (abl) {
+#define HEADS_CASE(V) case V: hipLaunchKernelGGL(proj_heads_rows_kernel<V>, grid, dim3(256), 0, stream, a); break
+        HEADS_CASE(1); HEADS_CASE(2); HEADS_CASE(4); HEADS_CASE(8); HEADS_CASE(3); HEADS_CASE(5); HEADS_CASE(6); HEADS_CASE(7); HEADS_CASE(14); HEADS_CASE(15); HEADS_CASE(16); HEADS_CASE(32); HEADS_CASE(48);
+#undef HEADS_CASE
+        default: hipLaunchKernelGGL(proj_heads_rows_kernel<0>, grid, dim3(256), 0, stream, a);
+    }
     ASR_LAUNCH_CHECK("asr_proj_heads(rows)");
     return 0;
 }
