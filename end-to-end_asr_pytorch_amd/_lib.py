@@ -153,8 +153,8 @@ def build_library(force=False, verbose=False):
         if not force and os.path.exists(o) and all(
                 os.path.getmtime(o) >= os.path.getmtime(d) for d in (s, deps[-2], deps[-1])):
             continue
-        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(s), []) + [
-            "-c", s, "-o", o]
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(s), []) + \
+            os.environ.get("ASR_AMD_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]      # (diagnostic builds: -DHEADS_ABLATE, -DFFN_STAMP ...)
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

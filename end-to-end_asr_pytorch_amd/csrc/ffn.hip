@@ -689,8 +689,14 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
 // consecutive in memory.  x is read once for all n_proj * h chunks (the tiled GEMM re-reads it per column block).  At one wave per
 // SIMD nothing hides a wait, so nothing in a chunk may wait: the weights stream through a ring of FOUR 32-KiB images requested three
 // chunks ahead (the fragment ring runs across chunk borders, and a chunk's stores have two chunk times to be acknowledged before a
-// wait counts them), the next chunk's bias is read into the MFMA C operand during this chunk, and the previous chunk's accumulators
-// leave beside this chunk's MFMAs.
+// wait counts them), the bias joins in the pack (one fma per value on the pre-scaled staged copy) and the previous chunk's
+// accumulators leave beside this chunk's MFMAs.  Measured at M = 32000: 22-23 us for Q/K/V (N = 768; tiled GEMM 24.8) and 72 us for
+// the decoder's 6-layer cross K/V (N = 3072; tiled 88-92) - the loop rebuilt with pieces left out (tools/ablate_heads.sh): MFMAs
+// alone 0.45 us per chunk (the matrix pipe's own time), + fragment ring and LDS-DMA 0.68, + pack / tile / stores 1.46: the parts
+// still add up.  (Tried: 8 waves, wave w and w + 4 on one SIMD taking turns - one multiplies chunk p while the other packs and
+// stores chunk p - 1, a workgroup barrier per phase: correct, but 27 / 81 us: a multiply phase alone takes 1.07 us and a pack phase
+// alone 0.95 us - per-phase latencies (exposed first fragments, LDS round trips of the tile, store issue, barrier) that overlap
+// only with the OTHER phase, so the matrix pipe is busy a third of a phase.)
 struct HeadsArgs {
     const bf16_t* x16;
     const bf16_t* w;
@@ -889,13 +895,17 @@ int asr_proj_heads_rows(hipStream_t stream, const void* X, const void* W, const 
     HeadsArgs a{(const bf16_t*)X, (const bf16_t*)W, bias, (bf16_t*)out, (int)M64, L, h, n_proj * h, scale_first != 1.0f ? h : 0, (int)N64,
                 (long long)proj_stride, scale_first};
     const dim3 grid((unsigned)((M64 + FBM - 1) / FBM));
+#ifdef HEADS_ABLATE      // timing ablation build (tools/ablate_heads.sh): the loop with pieces left out, wrong results on purpose
     const int abl = getenv("ASR_AMD_HEADS_ABL") ? atoi(getenv("ASR_AMD_HEADS_ABL")) : 0;
     switch (abl) {
 #define HEADS_CASE(V) case V: hipLaunchKernelGGL(proj_heads_rows_kernel<V>, grid, dim3(256), 0, stream, a); break
-        HEADS_CASE(1); HEADS_CASE(2); HEADS_CASE(4); HEADS_CASE(8); HEADS_CASE(3); HEADS_CASE(5); HEADS_CASE(6); HEADS_CASE(7); HEADS_CASE(14); HEADS_CASE(15); HEADS_CASE(16); HEADS_CASE(32); HEADS_CASE(48);
+        HEADS_CASE(1); HEADS_CASE(2); HEADS_CASE(4); HEADS_CASE(8); HEADS_CASE(5); HEADS_CASE(6); HEADS_CASE(7); HEADS_CASE(15); HEADS_CASE(16); HEADS_CASE(32); HEADS_CASE(48);
 #undef HEADS_CASE
         default: hipLaunchKernelGGL(proj_heads_rows_kernel<0>, grid, dim3(256), 0, stream, a);
     }
+#else
+    hipLaunchKernelGGL(proj_heads_rows_kernel<0>, grid, dim3(256), 0, stream, a);
+#endif
     ASR_LAUNCH_CHECK("asr_proj_heads(rows)");
     return 0;
 }
