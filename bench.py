@@ -38,8 +38,8 @@ CFG = dict(d_input=80, d_model=256, n_head=4, d_inner=2048, n_layers_enc=12, n_l
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--model", default="s1", choices=["s1", "s2", "cif"],

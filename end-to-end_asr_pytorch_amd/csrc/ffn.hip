@@ -784,8 +784,8 @@ __global__ __launch_bounds__(256, 1) void proj_heads_rows_kernel(const HeadsArgs
     u32x4 Hn[4], Hout[4];
     f32x4 Bq[4];        // bias pieces on their way to the pack
     // register pair P of a finished chunk: (acc * scale + bias * scale) -> two bf16 (the staged bias is pre-scaled).  Three stages, one
-    // step apart, so that no instruction of a step waits for another of the same step (at one wave per SIMD a dependent VALU pair
-    // costs its full latency: tools/probe/clock_probe.hip modes 22 / 25 - 34 against 44 cycles per one-MFMA step):
+    // step apart, so that no instruction of a step waits for another of the same step (at one wave per SIMD a dependent VALU group
+    // costs its latency: tools/probe/clock_probe.hip modes 22 / 25 - 34 against 44 cycles per one-MFMA step):
     //   fetch: the pair into plain VGPRs (the accumulators live in AGPRs)   fma: * scale + bias   pack: cvt_pk into the tile word
     float st0[16], st1[16];
     f32x2_t fv[16];

@@ -13,6 +13,7 @@ $T 300 python3 bench.py --steps 5 --warmup 1 --mode decode --no-also > $OUT/benc
 $T 300 python3 bench.py --steps 5 --warmup 1 --mode decode --beam 5 --no-also > $OUT/bench_decode_s1_beam5.json 2>> $OUT/bench_train.err
 $T 600 python3 tools/bench_ops.py > $OUT/bench_ops.jsonl 2>> $OUT/bench_train.err
 $T 300 python3 tools/bench_ffn.py > $OUT/bench_ffn.txt 2>> $OUT/bench_train.err
+$T 120 python3 tools/bench_heads.py > $OUT/bench_heads.txt 2>> $OUT/bench_train.err
 cd /tmp
 $T 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also > /dev/null 2>&1
 $T 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --graph 0 > /dev/null 2>&1
@@ -20,7 +21,7 @@ $T 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/
 $T 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/$OUT/pmc_attn -- python3 $R/tools/prof_attn.py > /dev/null 2>&1
 cd $R
 KS=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$KS" ] && cp $KS $OUT/bench_train_kernel_stats.csv
-KT=$(find $OUT/kt -name "*kernel_trace.csv" | head -1); [ -n "$KT" ] && python3 tools/timeline.py $KT adam_dev > $OUT/step_timeline.txt 2>&1
+KT=$(find $OUT/kt -name "*kernel_trace.csv" | head -1); [ -n "$KT" ] && python3 tools/timeline.py $KT adam_dev | cut -c1-160 > $OUT/step_timeline.txt 2>&1
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py $F $W $OUT/pmc_traffic_train_s1.json > $OUT/pmc_summary.txt 2>&1
 A=$(find $OUT/pmc_attn -name "*counter_collection.csv" | head -1); [ -n "$A" ] && cp $A $OUT/attn_counters.csv
