@@ -68,6 +68,7 @@ SIGNATURES = {
     "asr_add_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr, _dr],
     "asr_embed_pe_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _dr],
     "asr_decoder_targets": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _i64],
+    "asr_decoder_cif_targets": [_vp, _vp, _vp, _vp, _i, _i, _i64],
     "asr_conv_sub0_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
     "asr_conv_sub1_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "asr_conv_im2col": [_vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i],

@@ -184,6 +184,25 @@ __global__ __launch_bounds__(256) void decoder_targets_kernel(const int64_t* __r
     }
 }
 
+// Decoder_CIF.preprocess (src/transformer/decoder.py:356-366) + the decoder's lengths in one launch: ys_in[b, u] = (<sos>, target[b, :-1])[u]
+// where target[b, u] > 0, else 0; in_len[b] = number of positive targets.  One wave per utterance.
+__global__ __launch_bounds__(256) void decoder_cif_targets_kernel(const int64_t* __restrict__ target, int64_t* __restrict__ ys_in,
+                                                                  int32_t* __restrict__ in_len, int B, int U, int64_t sos) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t* row = target + (int64_t)b * U;
+    int n = 0;
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        const int u = u0 + lane;
+        const bool in = u < U;
+        const int64_t v = in ? row[u] : 0;
+        const int64_t prev = !in ? 0 : (u == 0 ? sos : row[u - 1]);
+        if (in) ys_in[(int64_t)b * U + u] = v > 0 ? prev : 0;
+        n += __popcll(__ballot(v > 0));
+    }
+    if (lane == 0 && in_len) in_len[b] = n;
+}
+
 }  // namespace
 
 extern "C" int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, const float* gamma, const float* beta,
@@ -210,6 +229,14 @@ extern "C" int asr_decoder_targets(void* stream, const int64_t* targets, int64_t
     hipLaunchKernelGGL(decoder_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), targets, ys_in, ys_out,
                        in_len, n_out, overflow, B, U, W, sos_id, eos_id);
     ASR_LAUNCH_CHECK("decoder_targets");
+    return 0;
+}
+
+extern "C" int asr_decoder_cif_targets(void* stream, const int64_t* target, int64_t* ys_in, int32_t* in_len, int B, int U, int64_t sos_id) {
+    ASR_REQUIRE(target && ys_in && B > 0 && U > 0, ASR_ERR_ARG, "decoder_cif_targets: bad args");
+    hipLaunchKernelGGL(decoder_cif_targets_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), target, ys_in, in_len,
+                       B, U, sos_id);
+    ASR_LAUNCH_CHECK("decoder_cif_targets");
     return 0;
 }
 

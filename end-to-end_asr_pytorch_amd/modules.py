@@ -27,6 +27,7 @@ from . import ops
 _PRECISION = os.environ.get("ASR_AMD_PRECISION", "bf16")
 _LOG2E = 1.4426950408889634
 _MASK_PREFETCH = os.environ.get("ASR_AMD_MASK_PREFETCH", "1") != "0"
+_MASK_GROUP = os.environ.get("ASR_AMD_MASK_GROUP", "1") != "0"      # short sequences: the encoder's attention-dropout masks 8 sites per launch
 
 
 def set_precision(p):
@@ -179,6 +180,21 @@ def _prefetch_attn_masks(sites, training, device):
     main, aux = torch.cuda.current_stream(), ops.aux_stream(device, slot=1)
     aux.wait_stream(main)      # fork from the main stream (ordering after the previous step's readers; required under graph capture)
     out = []
+    shapes = {(B, m.n_head, Lq, Lk) for m, B, Lq, Lk in sites}
+    (B0, h0, Lq0, Lk0) = next(iter(shapes))
+    # short sequences (L = T/4 behind the conv front end: ~5-10 us of hashing per site): up to 8 sites per launch and ONE event per
+    # group - a step of 6-7 ms is queued by the host about as fast as the GPU runs it, and 12 launches + 12 event pairs at its very
+    # start left the first two encoder layers waiting for the host (0.5 ms of idle GPU per CIF_Model step in tools/timeline.py)
+    if _MASK_GROUP and len(shapes) == 1 and all(d is not None and d.thr16 > 0 for d in drops) and B0 * h0 * Lq0 * Lk0 <= (1 << 24):
+        with torch.cuda.stream(aux):
+            for i in range(0, len(sites), 8):
+                bits_l = ops.attention_dropmask_multi(drops[i:i + 8], B0, h0, Lq0, Lk0, device)
+                ev = torch.cuda.Event()
+                ev.record(aux)
+                for d, bits in zip(drops[i:i + 8], bits_l):
+                    bits.record_stream(main)
+                    out.append((d, bits, ev))
+        return out
     with torch.cuda.stream(aux):
         for (m, B, Lq, Lk), d in zip(sites, drops):
             bits = ops.attention_dropmask(d, B, m.n_head, Lq, Lk, device)
@@ -1408,8 +1424,11 @@ class Decoder_CIF(_Cached):
         """cif_slot: {"g": tensor or None} - when the tape is recording, the gradient wrt `encoded_attentioned` is accumulated there."""
         B, U, D = encoded_attentioned.shape
         rec = _TAPE is not None and cif_slot is not None
-        ys_in = self.preprocess(target)
-        dec_len = (target > 0).sum(1).to(torch.int32)          # tail padding (every reference data path)
+        if target.is_cuda and target.dtype == torch.int64:
+            ys_in, dec_len = ops.decoder_cif_targets(target, self.sos_id)      # preprocess + lengths, one launch
+        else:
+            ys_in = self.preprocess(target)
+            dec_len = (target > 0).sum(1).to(torch.int32)          # tail padding (every reference data path)
         cif32 = encoded_attentioned.contiguous().float().view(B * U, D)
         dp = _drop(self, "dropout")   # decoder.py:385
         e32, _ = ops.embed_pe(ys_in, self.tgt_word_emb.weight.detach().float(), self.positional_encoding.rows(U), drop=dp)

@@ -382,6 +382,18 @@ def decoder_targets(targets, sos_id, eos_id, umax, overflow=None):
     return ys_in, ys_out, in_len
 
 
+def decoder_cif_targets(target, sos_id):
+    """Decoder_CIF.preprocess (decoder.py:356-366) + lengths in one launch -> (ys_in [B, U] int64, in_len int32 [B])."""
+    _req_cuda(target)
+    assert target.dtype == torch.int64 and target.dim() == 2
+    target = target.contiguous()
+    B, U = target.shape
+    ys_in = torch.empty_like(target)
+    in_len = torch.empty((B,), device=target.device, dtype=torch.int32)
+    check(lib().asr_decoder_cif_targets(_stream(), _p(target), _p(ys_in), _p(in_len), B, U, int(sos_id)), "asr_decoder_cif_targets")
+    return ys_in, in_len
+
+
 def embed_pe(ids, emb, pe, want_bf16=False, drop=None):
     _req_cuda(ids, emb, pe)
     B, U = ids.shape

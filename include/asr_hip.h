@@ -296,6 +296,10 @@ int asr_adam_step_dev(void* stream, float* p, const float* g, float* m, float* v
 int asr_decoder_targets(void* stream, const int64_t* targets, int64_t* ys_in, int64_t* ys_out, int32_t* in_len, int64_t* n_out,
                         int32_t* overflow, int B, int U, int W, int64_t sos_id, int64_t eos_id);
 
+/* Decoder_CIF.preprocess (src/transformer/decoder.py:356-366): ys_in[b, u] = (<sos>, target[b, 0..U-1))[u] * (target[b, u] > 0), and
+ * (optional) in_len[b] = number of positive targets of row b - the decoder's non-pad length. */
+int asr_decoder_cif_targets(void* stream, const int64_t* target, int64_t* ys_in, int32_t* in_len, int B, int U, int64_t sos_id);
+
 /* Embedding gather + positional encoding (decoder.py:83): out[b,u,:] = dropout(emb[ids[b,u],:] + pe[u,:]). */
 int asr_embed_pe_fwd(void* stream, const int64_t* ids, const float* emb, const float* pe, float* y32, void* y16,
                      int B, int U, int D, int V, asr_dropout_t drop);

@@ -52,3 +52,23 @@ def test_decoder_targets_overflow_flag():
     flag.zero_()
     ops.decoder_targets(tg, 2, 3, 3, overflow=flag)
     assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("B,U,seed", [(1, 1, 0), (3, 4, 1), (32, 50, 2), (7, 64, 3), (5, 65, 4), (33, 200, 5)])
+def test_decoder_cif_targets(B, U, seed):
+    """asr_decoder_cif_targets (Decoder_CIF.preprocess, decoder.py:356-366) against the oracle's two lines (oracle/asr_oracle.py:
+    decoder_cif_forward) and the module's torch expression: <sos> shifted in, positions whose target is pad zeroed, lengths."""
+    rng = np.random.default_rng(seed)
+    tg = rng.integers(1, 4000, size=(B, U)).astype(np.int64)
+    lens = rng.integers(0, U + 1, size=B)
+    for b in range(B):
+        tg[b, lens[b]:] = 0                     # tail padding
+    if B > 2:
+        tg[2, U // 2] = 0                       # and a pad entry in the middle of a row (the reference masks by position)
+    pad_mask = (tg > 0).astype(np.int64)
+    ref = np.concatenate([np.full((B, 1), 4232, dtype=np.int64), tg[:, :-1]], 1) * pad_mask
+    ys_in, in_len = ops.decoder_cif_targets(torch.from_numpy(tg).to(DEV), 4232)
+    np.testing.assert_array_equal(ys_in.cpu().numpy(), ref)
+    np.testing.assert_array_equal(in_len.cpu().numpy(), pad_mask.sum(1).astype(np.int32))
+    dec = asr_amd.Decoder_CIF(4232, 4233, 1, 2, 64, 128, dropout=0.0)
+    np.testing.assert_array_equal(dec.preprocess(torch.from_numpy(tg)).numpy(), ref)

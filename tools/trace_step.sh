@@ -1,12 +1,12 @@
 #!/bin/bash
 # One replayed training step's kernel timeline (gaps, shares): rocprofv3 kernel trace of the default bench, cut by tools/timeline.py.
 set -u
-OUT=gpurun_out/trace_step
+OUT=gpurun_out/${TRACE_OUT:-trace_step}
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp
-timeout -k 5 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also > $R/$OUT/bench.json 2> $R/$OUT/bench.err
+timeout -k 5 600 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also ${BENCH_ARGS:-} > $R/$OUT/bench.json 2> $R/$OUT/bench.err
 cd $R
 KT=$(find $OUT/kt -name "*kernel_trace.csv" | head -1)
 [ -n "$KT" ] && python3 tools/timeline.py $KT adam_dev > $OUT/step_timeline.txt 2>&1
