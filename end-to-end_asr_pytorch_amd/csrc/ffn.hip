@@ -24,6 +24,9 @@ namespace {
 #ifndef FFN_HID_POLICY
 #define FFN_HID_POLICY 0      // cache policy of the hidden-activation / hidden-gradient stores (A/B: 2 = non-temporal: forward 95 -> 89 us alone, the step unchanged)
 #endif
+#ifndef FFN_ABL
+#define FFN_ABL 0             // timing ablation of the forward loop (diagnostic builds only, wrong results): 1 no LDS-DMA, 2 no fragment reads, 4 no ReLU / mask / hidden stores, 8 no first-product MFMAs, 16 no second-product MFMAs
+#endif
 constexpr int FBM = 128;      // tokens per workgroup (4 waves x 32)
 constexpr int FHC = 64;       // hidden units per chunk
 constexpr int FD = 256;       // d_model
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             off2[k] = (unsigned)(d * dff * 2 + c * 16);
         }
     }
-    // one 1-KiB piece (j = 0..7 of this wave's 8) of a chunk image; the loop deals the 16 pieces of an iteration over its first 16 steps,
+    // one 1-KiB piece (j = 0..7 of this wave's 8) of a chunk image; the loop deals the 16 pieces of an iteration over its first 16 steps
+    // (one every 4th step over the whole iteration, hidden stores behind the last of them: 101 vs 104 us train, 83 vs 82 us eval - no change),
     // one behind each MFMA (an LDS-DMA instruction holds the wave's issue for tens of cycles: bunched in front of the MFMAs all of
     // that time is exposed at one wave per SIMD)
     auto dma_w1 = [&](int buf, int chunk, int j) {
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     do {                                                                                                           \
         /* the LDS-DMA of this iteration is older than its NST stores (vmcnt retires in order): wait for it only */ \
         /* (and every LDS read of the buffers the next iteration's DMA overwrites has returned) */                 \
-        if (TRAIN) asm volatile("s_waitcnt vmcnt(" #NST ") lgkmcnt(0)" ::: "memory");                              \
+        if (TRAIN && !FFN_ABL) asm volatile("s_waitcnt vmcnt(" #NST ") lgkmcnt(0)" ::: "memory");                  \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
         __builtin_amdgcn_s_barrier();                                                                              \
         asm volatile("" ::: "memory");                                                                             \
@@ -241,10 +245,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             FFN_STEP();
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
-                if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
+                if (!(FFN_ABL & 8)) S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
+                if (FFN_ABL & 2) {
+                } else if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
                 else if (!FIRST) A[(k + 8) & 15] = frag2(w2, k + 8 - 32);
-                if (k < 16) {
+                if (k < 16 && !(FFN_ABL & 1)) {
                     if (k & 1) dma_w2(i & 1, i, k >> 1);
                     else dma_w1((i + 1) & 1, nxt, k >> 1);
                 }
@@ -259,16 +264,18 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             if constexpr (!FIRST) {
-                Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
-                if (k + 8 < 32) A[(k + 8) & 15] = frag2(w2, k + 8);
+                if (!(FFN_ABL & 16)) Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
+                if (k + 8 < 32 && !(FFN_ABL & 2)) A[(k + 8) & 15] = frag2(w2, k + 8);
             }
             if constexpr (!LAST) {
+                if (!(FFN_ABL & 4)) {
                 if ((k & 1) == 0) relu_pair(S, Hn, k >> 1);
                 else if (TRAIN) mask_pair(Hn, word, k >> 1);
                 if (TRAIN && !FIRST && (k & 7) == 0)       // chunk i - 1's tile (read back row-wise at steps 24..27): four full-line stores
                     __builtin_amdgcn_raw_buffer_store_b128(Hout[k >> 3], rsh, hoff[k >> 3], (i - 1) * (FHC * 2), FFN_HID_POLICY);
                 if (TRAIN && (k & 7) == 7)
                     *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 3) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 3];
+                }
             } else {
                 if (TRAIN && k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
                 if (TRAIN && k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), FFN_HID_POLICY);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             FFN_STEP();
         }
         if constexpr (!LAST) {
-            if (TRAIN) __builtin_amdgcn_raw_buffer_store_b32(word, rsb, boff, i * (2 * a.Mp * 4), 0);
+            if (TRAIN && !(FFN_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(word, rsb, boff, i * (2 * a.Mp * 4), 0);
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) Hf[sg] = Hn[sg];
         }
