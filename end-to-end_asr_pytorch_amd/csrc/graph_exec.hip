@@ -31,6 +31,14 @@ struct XNode {
     int record_event;              // event recorded after this node (-1: none)
 };
 
+// Events between the executor's streams order work on ONE device: they need no system-scope fence.  A default HIP event performs one
+// when it is recorded (cache write-back and invalidation so that the host and other devices see the data) - measured ~6.5 us of
+// nothing between the recording kernel and the next kernel of its stream, 49 times per S1 step.  ASR_AMD_GRAPHX_SYSFENCE=1 restores it.
+unsigned graphx_event_flags() {
+    static const bool sysfence = getenv("ASR_AMD_GRAPHX_SYSFENCE") && atoi(getenv("ASR_AMD_GRAPHX_SYSFENCE")) != 0;
+    return hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
+}
+
 struct GraphX {
     std::vector<XNode> nodes;      // in launch (topological) order
     std::vector<hipStream_t> streams;
@@ -221,7 +229,7 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
             if (stream_of[p] != stream_of[u]) {
                 if (event_of[p] < 0) {
                     hipEvent_t e;
-                    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
+                    if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
                     event_of[p] = (int)g->events.size();
                     g->events.push_back(e);
                     g->nodes[pos_in_order[p]].record_event = event_of[p];
@@ -236,14 +244,14 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
         if (t < 0) continue;
         if (event_of[t] < 0) {
             hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
+            if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
             event_of[t] = (int)g->events.size();
             g->events.push_back(e);
             g->nodes[pos_in_order[t]].record_event = event_of[t];
         }
         g->tail_event[s] = event_of[t];
     }
-    if (hipEventCreateWithFlags(&g->begin, hipEventDisableTiming) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
+    if (hipEventCreateWithFlags(&g->begin, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
     if (getenv("ASR_AMD_GRAPHX_DEBUG")) {      // the launch plan, one line per node: position, stream, type / kernel name, waits, record
         for (size_t oi = 0; oi < n; ++oi) {
             const XNode& x = g->nodes[oi];
