@@ -225,16 +225,51 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
             asr_set_error("graphx_create: node type %d is not supported (kernel, memset, memcpy and empty nodes are)", (int)x.type);
             return -3;
         }
-        for (int p : deps[u])
-            if (stream_of[p] != stream_of[u]) {
-                if (event_of[p] < 0) {
+    }
+    // Events for the cross-stream edges.  A recorded event costs the recording stream ~5 us between two kernels (the marker packet),
+    // so a waiter on a SIDE stream is pointed at the latest node of the producer's stream that (a) records an event anyway and (b) is
+    // issued before the waiter: later in the producer's stream order than the node it needs, hence sufficient, and already queued when
+    // the wait is queued.  Producers left without a waiter record nothing.  (Waiters on the busiest stream - the step's main chain -
+    // keep their exact producer: they must not wait for more than they need.)  Waits that an earlier wait of the same stream on a
+    // later node of the same producer stream already implies are dropped.
+    {
+        static const bool coalesce = !(getenv("ASR_AMD_GRAPHX_COALESCE") && atoi(getenv("ASR_AMD_GRAPHX_COALESCE")) == 0);
+        const int ns = (int)g->streams.size();
+        std::vector<int> per_stream(ns, 0);
+        for (size_t i = 0; i < n; ++i) per_stream[stream_of[i]]++;
+        const int busiest = (int)(std::max_element(per_stream.begin(), per_stream.end()) - per_stream.begin());
+        std::vector<char> exact(n, 0);      // node is the producer of some cross-stream edge
+        for (size_t oi = 0; oi < n; ++oi)
+            for (int p : deps[order[oi]])
+                if (stream_of[p] != stream_of[order[oi]]) exact[p] = 1;
+        std::vector<std::vector<int>> targets(n);      // per node (by order position): the nodes whose events it waits for
+        std::vector<int> waiters(n, 0);
+        std::vector<int> waited(ns * ns, -1);           // [consumer stream][producer stream]: latest position already waited for
+        for (size_t oi = 0; oi < n; ++oi) {
+            const int u = order[oi], cs = stream_of[u];
+            for (int p : deps[u]) {
+                const int ps = stream_of[p];
+                if (ps == cs) continue;
+                int q = p;
+                if (coalesce && cs != busiest)
+                    for (size_t oj = (size_t)pos_in_order[p] + 1; oj < oi; ++oj)
+                        if (stream_of[order[oj]] == ps && exact[order[oj]]) q = order[oj];
+                if (pos_in_order[q] <= waited[cs * ns + ps]) continue;
+                waited[cs * ns + ps] = pos_in_order[q];
+                targets[oi].push_back(q);
+                waiters[q]++;
+            }
+        }
+        for (size_t oi = 0; oi < n; ++oi)
+            for (int q : targets[oi]) {
+                if (event_of[q] < 0) {
                     hipEvent_t e;
                     if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
-                    event_of[p] = (int)g->events.size();
+                    event_of[q] = (int)g->events.size();
                     g->events.push_back(e);
-                    g->nodes[pos_in_order[p]].record_event = event_of[p];
+                    g->nodes[pos_in_order[q]].record_event = event_of[q];
                 }
-                x.wait_events.push_back(event_of[p]);
+                g->nodes[oi].wait_events.push_back(event_of[q]);
             }
     }
     // every side stream is joined into the launch stream behind its last node

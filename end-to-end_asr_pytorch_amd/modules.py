@@ -637,8 +637,10 @@ class PositionwiseFeedForward(_Cached):
                 ds, ds16 = _ln_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
                                       dbias=w2.bias.grad, drop_x=dp)
                 y.grad = None
-                _wg(ds16, hid, out=w2.weight.grad, accumulate=True)
                 d_hid, dx = ops.ffn_bwd(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits)
+                # (both weight gradients behind the data gradient: the side stream then needs ONE event of the main chain per sub-layer,
+                # recorded after ffn_bwd - an event recorded between LayerNorm backward and ffn_bwd held the latter back ~5 us)
+                _wg(ds16, hid, out=w2.weight.grad, accumulate=True)
                 _wg(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
                 _acc(x, dx)
 
