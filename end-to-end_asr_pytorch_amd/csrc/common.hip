@@ -72,6 +72,29 @@ __global__ void queue_probe_stamp_kernel(unsigned long long* out) {
 }
 }  // namespace
 
+// Stream-ordering events without HIP's default system-scope fence at every record (asr_hip.h): for edges between streams of one device.
+extern "C" int asr_event_create(void** out_event) {
+    ASR_REQUIRE(out_event, ASR_ERR_ARG, "asr_event_create: null argument");
+    hipEvent_t e = nullptr;
+    ASR_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess, ASR_ERR_ARG,
+                "asr_event_create: hipEventCreateWithFlags failed");
+    *out_event = e;
+    return 0;
+}
+extern "C" int asr_stream_order_after(void* later_stream, void* earlier_stream, void* event) {
+    ASR_REQUIRE(event, ASR_ERR_ARG, "asr_stream_order_after: null event");
+    if (hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(earlier_stream)) != hipSuccess ||
+        hipStreamWaitEvent(static_cast<hipStream_t>(later_stream), static_cast<hipEvent_t>(event), 0) != hipSuccess) {
+        asr_set_error("asr_stream_order_after: record / wait failed");
+        return ASR_ERR_ARG;
+    }
+    return 0;
+}
+extern "C" int asr_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy(static_cast<hipEvent_t>(event));
+    return 0;
+}
+
 extern "C" int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared) {
     ASR_REQUIRE(shared, ASR_ERR_ARG, "streams_share_queue: null result pointer");
     if (stream_a == stream_b) { *shared = 1; return 0; }

@@ -130,9 +130,7 @@ def flush_wgrads():
         return
     pend, _WGRAD["pending"] = _WGRAD["pending"], []
     main, side = torch.cuda.current_stream(), _WGRAD["stream"]
-    ev = torch.cuda.Event()
-    ev.record(main)
-    side.wait_event(ev)
+    ops.order_after(side, main)
     with torch.cuda.stream(side):
         if len(pend) == 1:
             a, b, out, acc, cs = pend[0]
@@ -157,9 +155,7 @@ def _wg(a, b, **kw):
             flush_wgrads()
         return out
     main, side = torch.cuda.current_stream(), _WGRAD["stream"]
-    ev = torch.cuda.Event()
-    ev.record(main)
-    side.wait_event(ev)
+    ops.order_after(side, main)
     _WGRAD["keep"].append((a, b))
     with torch.cuda.stream(side):
         return ops.gemm_tn(a, b, max_wgs=256, **kw)      # one workgroup per CU: the main chain's kernels keep the other slot

@@ -366,6 +366,30 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
     return y32, y16, mean, rstd
 
 
+_ORDER_EVENTS = {"pool": [], "next": 0}
+LIGHT_EVENTS = os.environ.get("ASR_AMD_LIGHT_EVENTS", "1") != "0"      # A/B: 0 = torch events (system-scope fence at every record)
+
+
+def order_after(later, earlier):
+    """Everything queued on stream `earlier` so far happens before anything queued on stream `later` from now on (same device).
+    An event without the system-scope fence of a default HIP event (asr_hip.h: asr_stream_order_after) from a ring of 256: a wait
+    holds on to the record it was queued against, so an event can be recorded again while earlier waits on it are still queued."""
+    if not LIGHT_EVENTS or torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()      # (under stream capture torch's own events: their lifetime is tied to the capture)
+        ev.record(earlier)
+        later.wait_event(ev)
+        return
+    pool = _ORDER_EVENTS["pool"]
+    if len(pool) < 256:
+        h = ctypes.c_void_p()
+        check(lib().asr_event_create(ctypes.byref(h)), "asr_event_create")
+        pool.append(h)
+    i = _ORDER_EVENTS["next"] % len(pool)
+    _ORDER_EVENTS["next"] += 1
+    check(lib().asr_stream_order_after(ctypes.c_void_p(later.cuda_stream), ctypes.c_void_p(earlier.cuda_stream), pool[i]),
+          "asr_stream_order_after")
+
+
 def decoder_targets(targets, sos_id, eos_id, umax, overflow=None):
     """Decoder.preprocess (decoder.py:42-58) in one launch -> (ys_in [B, umax + 1], ys_out [B, umax + 1], in_len int32 [B]).
     `umax` = the longest target (non-pad entries) of the batch; `overflow` (int32 [1], optional) is set if a row held more."""

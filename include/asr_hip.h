@@ -65,6 +65,13 @@ int asr_version(void);
  * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
  * (asr_gemm_tn_ws) is order-fixed in either mode.  Returns the previous setting. */
 int asr_set_deterministic(int on);
+/* Ordering between two streams of ONE device without the system-scope fence a default HIP event performs at every record (cache
+ * write-back and invalidation: ~1-3 us of the recording stream's time per event, ~100 events per eagerly queued training step):
+ * asr_stream_order_after records `event` (from asr_event_create) on earlier_stream and makes later_stream wait for it - everything
+ * queued on earlier_stream so far happens before anything queued on later_stream from now on.  The event can be reused at once. */
+int asr_event_create(void** out_event);
+int asr_stream_order_after(void* later_stream, void* earlier_stream, void* event);
+int asr_event_destroy(void* event);
 /* Set-up time probe: do two streams share a hardware queue (their kernels then never overlap)?  The runtime multiplexes all streams
  * of the process onto a few queues in creation order; the trainer picks its side streams with this.  Synchronises both streams. */
 int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared);
