@@ -11,6 +11,7 @@
 // The graph stays owned by the caller (torch.cuda.CUDAGraph(keep_graph=True)): the executor reads the nodes' parameter blocks in
 // place, and the caller keeps the capture's memory pool alive.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -293,7 +294,12 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
             const XNode& x = g->nodes[oi];
             const char* name = x.type == hipGraphNodeTypeKernel ? hipKernelNameRefByPtr(x.k.func, nullptr)
                                : (x.type == hipGraphNodeTypeMemset ? "<memset>" : (x.type == hipGraphNodeTypeMemcpy ? "<memcpy>" : "<empty>"));
-            fprintf(stderr, "graphx %4zu s%d %.90s waits %zu rec %d\n", oi, x.stream, name ? name : "?", x.wait_events.size(), x.record_event);
+            char dl[160];
+            int off = 0;
+            dl[0] = 0;
+            for (int p : deps[order[oi]])
+                if (off < 140) off += snprintf(dl + off, sizeof(dl) - off, " %d", pos_in_order[p]);
+            fprintf(stderr, "graphx %4zu s%d %.90s waits %zu rec %d deps%s\n", oi, x.stream, name ? name : "?", x.wait_events.size(), x.record_event, dl);
         }
     }
     *out_handle = g;
