@@ -437,7 +437,10 @@ extern "C" int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t*
         TnArgs& a = g.p[i];
         int tiles;
         const int my_tiles = ((q.N + 127) / 128) * (q.K / 128);
-        int share = (int)((int64_t)256 * my_tiles / total_tiles);
+        // the grouped launch runs on the trainer's side stream beside the main chain: half the CUs (ASR_AMD_TN_GROUP_WGS; a slab
+        // workgroup takes a whole CU, see modules._WGRAD_SIDE_WGS)
+        static const int group_wgs = getenv("ASR_AMD_TN_GROUP_WGS") ? atoi(getenv("ASR_AMD_TN_GROUP_WGS")) : 128;
+        int share = (int)((int64_t)group_wgs * my_tiles / total_tiles);
         if (share < my_tiles) share = my_tiles;
         tn_v2_plan(q.M, q.N, q.K, share, &tiles, &a.splits, &a.m_per_split);
         a.A = (const bf16_t*)q.A; a.B = (const bf16_t*)q.B; a.C = q.C; a.colsum = q.colsum;

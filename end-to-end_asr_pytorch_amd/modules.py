@@ -120,6 +120,10 @@ def _drop(mod, suffix):
     return ops.Dropout(thr, k0, k1, _DROP_STATE["salt"])
 
 
+# Workgroups of a weight-gradient launch on the trainer's side stream: half the CUs.  A slab weight-gradient workgroup takes a whole CU
+# (512 registers per lane, 128 KiB of LDS), so with 256 of them the main chain's next kernel waits for CUs to come free; with 128 it
+# always finds half the chip (S1 replay 11.98-12.05 -> 11.84-11.91 ms on two boxes; 96: 11.92, 64: 12.16, 192: 11.96).
+_WGRAD_SIDE_WGS = int(os.environ.get("ASR_AMD_WGRAD_SIDE_WGS", "128"))
 _WGRAD = None      # set by Trainer.backward: {"stream": side stream, "keep": [operands kept alive until the streams join]}
 
 
@@ -134,7 +138,7 @@ def flush_wgrads():
     with torch.cuda.stream(side):
         if len(pend) == 1:
             a, b, out, acc, cs = pend[0]
-            ops.gemm_tn(a, b, out=out, accumulate=acc, colsum=cs, max_wgs=256)
+            ops.gemm_tn(a, b, out=out, accumulate=acc, colsum=cs, max_wgs=_WGRAD_SIDE_WGS)
         else:
             ops.gemm_tn_group(pend)
 
@@ -158,7 +162,7 @@ def _wg(a, b, **kw):
     ops.order_after(side, main)
     _WGRAD["keep"].append((a, b))
     with torch.cuda.stream(side):
-        return ops.gemm_tn(a, b, max_wgs=256, **kw)      # one workgroup per CU: the main chain's kernels keep the other slot
+        return ops.gemm_tn(a, b, max_wgs=_WGRAD_SIDE_WGS, **kw)
 
 
 def _prefetch_attn_masks(sites, training, device):
