@@ -854,7 +854,7 @@ class _TnProblem(ctypes.Structure):          # asr_hip.h: asr_tn_problem_t
 
 
 TN_GROUP = os.environ.get("ASR_AMD_TN_GROUP", "1") != "0"      # A/B: 0 = the decoder's weight gradients one launch pair each
-TN_GROUP_MAX_ROWS = 2048
+TN_GROUP_MAX_ROWS = int(os.environ.get("ASR_AMD_TN_GROUP_MAX_ROWS", "2048"))
 TN_GROUP_SMALL_TILES = int(os.environ.get("ASR_AMD_TN_GROUP_TILES", "16"))     # > 0: weight gradients of at most this many output tiles join the groups at any row count
 
 
