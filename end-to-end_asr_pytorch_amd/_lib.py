@@ -57,6 +57,9 @@ SIGNATURES = {
     "asr_event_create": [_vp],
     "asr_stream_order_after": [_vp, _vp, _vp],
     "asr_event_destroy": [_vp],
+    "asr_timer_create": [_vp],
+    "asr_timer_record": [_vp, _vp],
+    "asr_timer_elapsed_ms": [_vp, _vp, _vp],
     "asr_gemm_tn_ws_bytes": [_i, _i, _i, _i],
     "asr_gemm_tn_ws_group": [_vp, _i, _vp, _i],
     "asr_gemm_tn_ws": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _i],

@@ -95,6 +95,28 @@ extern "C" int asr_event_destroy(void* event) {
     return 0;
 }
 
+// Timing events without the system-scope fence (hip_runtime_api.h on hipEventDisableSystemFence: "can improve the accuracy of timing
+// measurements by avoiding the cost of cache writeback and invalidation, and the performance impact of those actions on the execution
+// of following work"): what bench.py's per-op pass brackets every op with.
+extern "C" int asr_timer_create(void** out_event) {
+    ASR_REQUIRE(out_event, ASR_ERR_ARG, "asr_timer_create: null argument");
+    hipEvent_t e = nullptr;
+    ASR_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableSystemFence) == hipSuccess, ASR_ERR_ARG, "asr_timer_create: hipEventCreateWithFlags failed");
+    *out_event = e;
+    return 0;
+}
+extern "C" int asr_timer_record(void* event, void* stream) {
+    ASR_REQUIRE(event, ASR_ERR_ARG, "asr_timer_record: null event");
+    ASR_REQUIRE(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)) == hipSuccess, ASR_ERR_ARG, "asr_timer_record failed");
+    return 0;
+}
+extern "C" int asr_timer_elapsed_ms(void* start, void* stop, float* ms) {
+    ASR_REQUIRE(start && stop && ms, ASR_ERR_ARG, "asr_timer_elapsed_ms: null argument");
+    ASR_REQUIRE(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)) == hipSuccess, ASR_ERR_ARG,
+                "asr_timer_elapsed_ms: events not complete (synchronise first)");
+    return 0;
+}
+
 extern "C" int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared) {
     ASR_REQUIRE(shared, ASR_ERR_ARG, "streams_share_queue: null result pointer");
     if (stream_a == stream_b) { *shared = 1; return 0; }

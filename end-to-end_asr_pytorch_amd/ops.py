@@ -59,6 +59,29 @@ def profile_start():
     _PROF = {}
 
 
+LIGHT_TIMERS = os.environ.get("ASR_AMD_LIGHT_TIMERS", "1") != "0"      # A/B: 0 = torch timing events (system-scope fence at every record)
+_TIMER_POOL = []
+
+
+def _timer():
+    """a timing event without the system-scope fence (asr_hip.h: asr_timer_create), recorded on the current stream"""
+    if _TIMER_POOL:
+        h = _TIMER_POOL.pop()
+    else:
+        h = ctypes.c_void_p()
+        check(lib().asr_timer_create(ctypes.byref(h)), "asr_timer_create")
+    check(lib().asr_timer_record(h, _stream()), "asr_timer_record")
+    return h
+
+
+def _elapsed_ms(a, b):
+    if isinstance(a, ctypes.c_void_p):
+        ms = ctypes.c_float()
+        check(lib().asr_timer_elapsed_ms(a, b, ctypes.byref(ms)), "asr_timer_elapsed_ms")
+        return float(ms.value)
+    return a.elapsed_time(b)
+
+
 def profile_stop():
     """-> {name: dict(calls, ms, work)} ; `work` = algorithmic FLOPs (MFMA kernels) or bytes (HBM kernels) summed."""
     global _PROF
@@ -66,7 +89,10 @@ def profile_stop():
     torch.cuda.synchronize()
     out = {}
     for name, recs in (prof or {}).items():
-        out[name] = dict(calls=len(recs), ms=sum(a.elapsed_time(b) for a, b, _ in recs), work=sum(w for _, _, w in recs))
+        out[name] = dict(calls=len(recs), ms=sum(_elapsed_ms(a, b) for a, b, _ in recs), work=sum(w for _, _, w in recs))
+        for a, b, _ in recs:
+            if isinstance(a, ctypes.c_void_p):
+                _TIMER_POOL.extend((a, b))
     return out
 
 
@@ -78,13 +104,19 @@ class _timed:
 
     def __enter__(self):
         if _PROF is not None:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+            if LIGHT_TIMERS:
+                self.a = _timer()
+            else:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.a.record()
 
     def __exit__(self, *exc):
         if _PROF is not None:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
+            if LIGHT_TIMERS:
+                b = _timer()
+            else:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record()
             _PROF.setdefault(self.name, []).append((self.a, b, self.work))
         return False
 

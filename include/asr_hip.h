@@ -72,6 +72,12 @@ int asr_set_deterministic(int on);
 int asr_event_create(void** out_event);
 int asr_stream_order_after(void* later_stream, void* earlier_stream, void* event);
 int asr_event_destroy(void* event);
+/* Timing events without the system-scope fence of a default HIP event (which writes back and invalidates the caches at every record: the
+ * op behind it starts cold and the bracket measures the fence too).  asr_timer_elapsed_ms needs both events complete (synchronise the
+ * stream or device first); destroy with asr_event_destroy. */
+int asr_timer_create(void** out_event);
+int asr_timer_record(void* event, void* stream);
+int asr_timer_elapsed_ms(void* start, void* stop, float* ms);
 /* Set-up time probe: do two streams share a hardware queue (their kernels then never overlap)?  The runtime multiplexes all streams
  * of the process onto a few queues in creation order; the trainer picks its side streams with this.  Synchronises both streams. */
 int asr_streams_share_queue(void* stream_a, void* stream_b, int* shared);
