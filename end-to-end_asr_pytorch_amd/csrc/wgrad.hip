@@ -153,14 +153,17 @@ __device__ __forceinline__ void tn_body(const TnArgs& a, const int bid, const in
         acc[cb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Fs[cb]), __builtin_bit_cast(bf16x8, Fs[4 + kb]),
                                                               acc[cb][kb], 0, 0, 0);
     };
+    // (the wave's pair of dY fragments picked by SELECT, not by branch: with the two products written once per branch the compiler
+    // merged the branches' accumulator tuples through 64 v_accvgpr_mov per call, in series with the MFMAs)
     auto colsum_mma = [&](const u32x4 (&Fs)[6]) {
-        if (th) {
-            cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Fs[2]), ones, cs[0], 0, 0, 0);
-            cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Fs[3]), ones, cs[1], 0, 0, 0);
-        } else {
-            cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Fs[0]), ones, cs[0], 0, 0, 0);
-            cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Fs[1]), ones, cs[1], 0, 0, 0);
+        u32x4 f0, f1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f0[j] = th ? Fs[2][j] : Fs[0][j];
+            f1[j] = th ? Fs[3][j] : Fs[1][j];
         }
+        cs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f0), ones, cs[0], 0, 0, 0);
+        cs[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f1), ones, cs[1], 0, 0, 0);
     };
     auto step = [&](auto S, int t) {
         constexpr int S0 = decltype(S)::value, S1 = (S0 + 1) & 3, S3 = (S0 + 3) & 3;
