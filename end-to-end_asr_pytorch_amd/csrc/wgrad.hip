@@ -50,6 +50,10 @@ template <int I> struct IC { static constexpr int value = I; };
 
 // bid / nblocks: this workgroup's index among the tiles x splits workgroups of ITS problem (the whole grid for a single launch, a slice
 // of it in a grouped one)
+__device__ __forceinline__ bool xcd_groups_ok(const TnArgs& a, int tiles) {      // the larger operand's blocks divide evenly over an M-range's XCDs
+    const int g = 8 / a.splits, tn_count = tiles / a.tiles_k;
+    return a.N >= a.K ? tn_count % g == 0 : a.tiles_k % g == 0;
+}
 __device__ __forceinline__ void tn_body(const TnArgs& a, const int bid, const int nblocks) {
     constexpr int STAGE = 16384;                        // one operand tile: 64 rows x 256 B
     __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE];   // A ring [4] | B ring [4]
@@ -59,6 +63,16 @@ __device__ __forceinline__ void tn_body(const TnArgs& a, const int bid, const in
         const int xcd = bid & 7, slot = bid >> 3;
         split = xcd * (a.splits >> 3) + slot / tiles;
         tile = slot - (slot / tiles) * tiles;
+    } else if (a.splits < 8 && (8 % a.splits) == 0 && (nblocks & 7) == 0 && xcd_groups_ok(a, tiles)) {
+        // fewer M-ranges than XCDs (the 128-workgroup launches beside the main chain: 4 ranges x 32 tiles): an M-range owns 8 / splits
+        // XCDs, and its tiles are dealt to them by the block index of the LARGER operand - column block of dY when N >= K, of X
+        // otherwise - so that every row of that operand still enters one L2 only (dealt by workgroup index the whole range was
+        // fetched into all eight: FETCH 272 MB per launch instead of the 147.5 MB the operands hold)
+        const int g = 8 / a.splits, xcd = bid & 7, slot = bid >> 3, tn_count = tiles / a.tiles_k;
+        const int sub = xcd % g;
+        split = xcd / g;
+        if (a.N >= a.K) tile = (sub + g * (slot / a.tiles_k)) * a.tiles_k + slot % a.tiles_k;
+        else tile = (slot % tn_count) * a.tiles_k + sub + g * (slot / tn_count);
     } else {
         split = bid / tiles;
         tile = bid - split * tiles;

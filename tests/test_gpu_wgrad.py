@@ -57,6 +57,22 @@ def test_gemm_tn_slab(M, Nn, K, lda, monkeypatch):
     np.testing.assert_allclose(N(first), N(old), atol=tol["atol"] * 0.5, rtol=1e-3)
 
 
+@pytest.mark.parametrize("M,Nn,K", [(32000, 2048, 256), (32000, 256, 2048), (8000, 2048, 256), (8000, 256, 2048), (32000, 768, 256), (16000, 512, 512)])
+@pytest.mark.parametrize("wgs", [128, 64, 32])
+def test_gemm_tn_slab_fewer_m_ranges_than_xcds(M, Nn, K, wgs):
+    """The side stream's launches (max_wgs = 128 and less: 1, 2 or 4 M-ranges): an M-range owns 8 / splits XCDs and its tiles are dealt
+    to them by the larger operand's block index - every (tile, split) pair must still be computed exactly once."""
+    a, b, ad, bd = _ops(M, Nn, K, M + Nn + wgs)
+    ref = a.float().t() @ b.float()
+    cs = torch.zeros(Nn, device=DEV)
+    out = torch.full((Nn, K), float("nan"), device=DEV)
+    ops.gemm_tn(ad, bd, out=out, colsum=cs, max_wgs=wgs)
+    np.testing.assert_allclose(N(out), ref.numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+    np.testing.assert_allclose(N(cs), a.float().sum(0).numpy(), atol=2e-2 * (M / 300) ** 0.5, rtol=2e-3)
+    same = ops.gemm_tn(ad, bd, max_wgs=256)
+    np.testing.assert_allclose(N(out), N(same), atol=1e-2 * (M / 300) ** 0.5, rtol=1e-3)
+
+
 def test_gemm_tn_slab_whole_chip_split():
     """max_wgs = 0 (the launch has the chip to itself) and a second destination: separate workspaces."""
     a, b, ad, bd = _ops(32000, 256, 2048, 5)
