@@ -50,32 +50,28 @@ template <int I> struct IC { static constexpr int value = I; };
 
 // bid / nblocks: this workgroup's index among the tiles x splits workgroups of ITS problem (the whole grid for a single launch, a slice
 // of it in a grouped one)
-__device__ __forceinline__ bool xcd_groups_ok(const TnArgs& a, int tiles) {      // the larger operand's blocks divide evenly over an M-range's XCDs
-    const int g = 8 / a.splits, tn_count = tiles / a.tiles_k;
-    return a.N >= a.K ? tn_count % g == 0 : a.tiles_k % g == 0;
-}
 __device__ __forceinline__ void tn_body(const TnArgs& a, const int bid, const int nblocks) {
     constexpr int STAGE = 16384;                        // one operand tile: 64 rows x 256 B
     __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE];   // A ring [4] | B ring [4]
     const int tiles = nblocks / a.splits;
     int tile, split;
-    if ((a.splits & 7) == 0) {      // whole M-ranges per XCD: every row of dY and X is fetched into one L2 only
-        const int xcd = bid & 7, slot = bid >> 3;
-        split = xcd * (a.splits >> 3) + slot / tiles;
-        tile = slot - (slot / tiles) * tiles;
-    } else if (a.splits < 8 && (8 % a.splits) == 0 && (nblocks & 7) == 0 && xcd_groups_ok(a, tiles)) {
-        // fewer M-ranges than XCDs (the 128-workgroup launches beside the main chain: 4 ranges x 32 tiles): an M-range owns 8 / splits
-        // XCDs, and its tiles are dealt to them by the block index of the LARGER operand - column block of dY when N >= K, of X
-        // otherwise - so that every row of that operand still enters one L2 only (dealt by workgroup index the whole range was
-        // fetched into all eight: FETCH 272 MB per launch instead of the 147.5 MB the operands hold)
-        const int g = 8 / a.splits, xcd = bid & 7, slot = bid >> 3, tn_count = tiles / a.tiles_k;
-        const int sub = xcd % g;
-        split = xcd / g;
-        if (a.N >= a.K) tile = (sub + g * (slot / a.tiles_k)) * a.tiles_k + slot % a.tiles_k;
-        else tile = (slot % tn_count) * a.tiles_k + sub + g * (slot / tn_count);
-    } else {
-        split = bid / tiles;
-        tile = bid - split * tiles;
+    {
+        // Workgroups go to the 8 XCDs round-robin (launched: nblocks rounded up to 8), and each XCD has its own L2: the (M-range, tile)
+        // pairs are dealt to the XCDs in CONTIGUOUS runs of the M-range-major order - with a multiple of 8 M-ranges whole ranges per
+        // XCD (every row of dY and X enters one L2 only), with fewer a run of one range's tiles, ordered by the block index of the
+        // LARGER operand (column block of dY when N >= K, of X otherwise) so that its rows still enter one L2 only.  (Dealt by
+        // workgroup index, 4 M-ranges were each fetched into all eight L2s: FETCH 272 MB per feed-forward weight gradient instead
+        // of the 147.5 MB the operands hold; the slices of a grouped launch start at multiples of 8 for the same reason.)
+        const int per = (nblocks + 7) >> 3;
+        const int p = (bid & 7) * per + (bid >> 3);
+        if (p >= nblocks) return;
+        split = p / tiles;
+        const int q = p - split * tiles;
+        if (a.N >= a.K) tile = q;
+        else {
+            const int tn_count = tiles / a.tiles_k, tkq = q / tn_count;
+            tile = (q - tkq * tn_count) * a.tiles_k + tkq;
+        }
     }
     const int tn = tile / a.tiles_k, tk = tile - tn * a.tiles_k;
     const int n0 = tn * 128, k0 = tk * 128;
@@ -299,21 +295,22 @@ __device__ __forceinline__ void tn_body(const TnArgs& a, const int bid, const in
     if (cs_on && tid < 128) my[16384 + tid] = cs_tile;
 }
 
-__global__ __launch_bounds__(256, 1) void gemm_tn_v2_kernel(TnArgs a) { tn_body(a, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256, 1) void gemm_tn_v2_kernel(TnArgs a, int nblocks) { tn_body(a, blockIdx.x, nblocks); }
 
 // Several weight gradients in one launch (the decoder's: 1632 rows each, a handful of tiles, 13-17 us apiece as single launches of
 // which 2 us are work): problem i owns the workgroups first[i] .. first[i+1] - 1.
 constexpr int TN_GROUP_MAX = 8;
 struct TnGroup {
     int n;
-    int first[TN_GROUP_MAX + 1];       // main launch: first workgroup of each problem
+    int first[TN_GROUP_MAX + 1];       // main launch: first workgroup of each problem (multiples of 8)
+    int count[TN_GROUP_MAX];           // ... and how many of its slice are real (tiles x splits)
     int first_r[TN_GROUP_MAX + 1];     // reduce launch (tiles x 64 workgroups per problem with > 1 split, none otherwise)
     TnArgs p[TN_GROUP_MAX];
 };
 __global__ __launch_bounds__(256, 1) void gemm_tn_v2_group_kernel(TnGroup g) {
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
-    tn_body(g.p[i], (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);
+    tn_body(g.p[i], (int)blockIdx.x - g.first[i], g.count[i]);
 }
 
 // dW tile = sum over the splits of the slab's partial tiles.  A workgroup owns 64 consecutive f32x4 of one tile (1 KiB: 4 output rows
@@ -420,7 +417,7 @@ extern "C" int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const vo
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.tiles_k = K / 128;
     a.accumulate = accumulate; a.cs_all = (deterministic || asr_deterministic()) ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(gemm_tn_v2_kernel, dim3(tiles * a.splits), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gemm_tn_v2_kernel, dim3((tiles * a.splits + 7) / 8 * 8), dim3(256), 0, s, a, tiles * a.splits);
     ASR_LAUNCH_CHECK("gemm_tn_v2");
     if (a.splits > 1) {
         hipLaunchKernelGGL(tn_reduce_kernel, dim3(tiles * 64), dim3(256), 0, s, a, tiles);
@@ -464,7 +461,8 @@ extern "C" int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t*
         a.slab = reinterpret_cast<float*>(q.workspace);
         a.lda = q.lda; a.ldb = q.ldb; a.ldc = q.ldc; a.M = q.M; a.N = q.N; a.K = q.K; a.tiles_k = q.K / 128;
         a.accumulate = q.accumulate; a.cs_all = (deterministic || asr_deterministic()) ? 1 : 0;
-        g.first[i + 1] = g.first[i] + tiles * a.splits;
+        g.count[i] = tiles * a.splits;
+        g.first[i + 1] = g.first[i] + (tiles * a.splits + 7) / 8 * 8;      // (a slice starts on XCD 0: tn_body's mapping)
         g.first_r[i + 1] = g.first_r[i] + (a.splits > 1 ? tiles * 64 : 0);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
