@@ -23,6 +23,9 @@ void asr_set_error(const char* fmt, ...);
 // asr_proj_heads for encoder-sized bf16 rows (ffn.hip; called from gemm.hip): 0 = launched, -2 = not its shape
 int asr_proj_heads_rows(hipStream_t stream, const void* X, const void* W, const float* bias, void* out, int64_t proj_stride, int n_proj, int B,
                         int L, int h, float scale_first);
+// the encoder's self-attention forward (attention_fwd4.hip; called from attention.hip): 0 = launched, -2 = not its case
+int asr_attention_fwd_v4(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B, int h, int Lq, int Lk,
+                         const int32_t* k_len, asr_dropout_t drop, const uint32_t* drop_bits);
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
     do {                                  \

@@ -720,6 +720,10 @@ template <int NW, int KS = 1> int launch_bf16(hipStream_t s, const void* q, cons
 #define LAUNCH_V2(C, D)                                                                                                        \
     hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D, KS>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,         \
                        (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits)
+        static const int v4 = getenv("ASR_AMD_ATTN_V4") ? atoi(getenv("ASR_AMD_ATTN_V4")) : 1;
+        if (v4 && !causal && KS == 1 && NW == 4 && Lq >= 128 &&
+            asr_attention_fwd_v4(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, drop, drop_bits) == 0)
+            return 0;
         static const int v3 = getenv("ASR_AMD_ATTN_V3") ? atoi(getenv("ASR_AMD_ATTN_V3")) : 1;
         if (v3 && !causal && KS == 1 && NW == 4) {
             if (drop.thr16)
