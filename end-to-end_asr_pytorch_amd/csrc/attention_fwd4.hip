@@ -320,12 +320,93 @@ __global__ __launch_bounds__(256, ATTN4_WPE) void attn_fwd_bf16_v4_kernel(const 
     store(ob0, ob1, lb, mb, qrowB);
 }
 
+// ---- the hand-scheduled form: the whole kernel body is one generated instruction stream (tools/gen_attn_fwd4.py) -------------
+// The C++ part only works out this workgroup's pointers and this lane's LDS / global offsets and hands them over in registers
+// outside the block's own (v0-v231, a0-a95, s34-s101).
+#ifndef ATTN4_INC
+#define ATTN4_INC "attention_fwd4_asm.inc"
+#endif
+#include ATTN4_INC
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_bf16_v4a_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                   const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
+                                                                   float* __restrict__ lse, int h, int Lq, int Lk,
+                                                                   const int32_t* __restrict__ k_len, int q_tiles, float dscale) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * 8192];   // K ring [4][8 KiB] | V ring [4][8 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    int qt, bh;
+    {
+        const int BH = gridDim.x / q_tiles;
+        if ((BH & 7) == 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+            bh = (slot / q_tiles) * 8 + xcd;
+            qt = slot % q_tiles;
+        } else {
+            qt = blockIdx.x % q_tiles;
+            bh = blockIdx.x / q_tiles;
+        }
+    }
+    const int b = bh / h, hd = bh - b * h;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int nt = (kl + 63) >> 6;
+    const int qrow = qt * 256 + wave * 64 + r;          // block A's row of this lane; block B's is 32 further
+    const unsigned smem0 = lds_addr_of(smem);
+    unsigned voff[2], kofs[4], vofs[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave * 2 + i) + (lane >> 3);
+        voff[i] = (unsigned)(row * 128 + (((lane & 7) ^ swz2(row)) << 4));
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kofs[s] = smem0 + (unsigned)(r * 128 + (((2 * s + hh) ^ swz2(r)) << 4));
+    {
+        const int i16 = lane & 15, g16 = lane >> 4;
+        const int kb = 4 * hh + (i16 >> 2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int col = dt * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+            const int c = col >> 3, sub = (col & 7) * 2;
+            vofs[2 * dt] = smem0 + 32768u + (unsigned)(kb * 128 + ((c ^ swz2(kb)) << 4) + sub);
+            vofs[2 * dt + 1] = smem0 + 32768u + (unsigned)((kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub);
+        }
+    }
+    const uint64_t kbp = (uint64_t)(K + (int64_t)bh * Lk * 64), vbp = (uint64_t)(V + (int64_t)bh * Lk * 64);
+    const uint64_t qbp = (uint64_t)(Q + (int64_t)bh * Lq * 64);
+    const uint64_t cbp = (uint64_t)(ctx + ((int64_t)b * Lq * h + hd) * 64);
+    const uint64_t lbp = (uint64_t)(lse ? lse + (int64_t)bh * Lq : nullptr);
+    const unsigned qoff = (unsigned)qrow * 128u + 16u * hh;
+    const unsigned ooff = (unsigned)qrow * (unsigned)(h * 128) + 8u * hh;
+    const unsigned lseoff = (unsigned)qrow * 4u;
+    const int thr = -4 * hh;
+    const unsigned kdst = smem0 + (unsigned)wave * 2048u;
+    const unsigned hrow = (unsigned)h * 128u * 32u, csize = (unsigned)Lq * (unsigned)(h * 128) - (unsigned)hd * 128u;
+    const unsigned lsz = lse ? (unsigned)Lq * 4u : 0u;
+    const unsigned dsc = __builtin_bit_cast(unsigned, dscale);
+    asm volatile(ATTN4_ASM_EVAL
+                 :
+                 : [voff0] "v"(voff[0]), [voff1] "v"(voff[1]), [kofs0] "v"(kofs[0]), [kofs1] "v"(kofs[1]), [kofs2] "v"(kofs[2]), [kofs3] "v"(kofs[3]),
+                   [vofs0] "v"(vofs[0]), [vofs1] "v"(vofs[1]), [vofs2] "v"(vofs[2]), [vofs3] "v"(vofs[3]), [qoff] "v"(qoff), [ooff] "v"(ooff),
+                   [lseoff] "v"(lseoff), [thr] "v"(thr), [lane] "v"(lane),
+                   [kb] "s"(kbp), [vb] "s"(vbp), [qb] "s"(qbp), [cb] "s"(cbp), [lb] "s"(lbp),
+                   [kl] "s"(kl), [nt] "s"(nt), [kdst] "s"(kdst), [dsc] "s"(dsc), [hrow] "s"(hrow), [lq] "s"(Lq), [csize] "s"(csize), [lsz] "s"(lsz)
+                 : ATTN4_ASM_CLOBBERS);
+}
+
 }  // namespace
 
 int asr_attention_fwd_v4(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B, int h, int Lq, int Lk,
                          const int32_t* k_len, asr_dropout_t drop, const uint32_t* drop_bits) {
     if (drop.thr16) return -2;
     const int q_tiles = (Lq + 255) / 256;
+    static const int form = getenv("ASR_AMD_ATTN_V4") ? atoi(getenv("ASR_AMD_ATTN_V4")) : 2;
+    if (form >= 2) {
+        hipLaunchKernelGGL(attn_fwd_bf16_v4a_kernel, dim3(B * h * q_tiles), dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, 1.f);
+        ASR_LAUNCH_CHECK("attention_fwd_bf16_v4a");
+        return 0;
+    }
     hipLaunchKernelGGL((attn_fwd_bf16_v4_kernel<false>), dim3(B * h * q_tiles), dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits);
     ASR_LAUNCH_CHECK("attention_fwd_bf16_v4");
