@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, ATTN4_WPE) void attn_fwd_bf16_v4_kernel(const 
 #endif
 #include ATTN4_INC
 
-__global__ __launch_bounds__(256, 1) void attn_fwd_bf16_v4a_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_v4a_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                    const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
                                                                    float* __restrict__ lse, int h, int Lq, int Lk,
                                                                    const int32_t* __restrict__ k_len, int q_tiles, float dscale) {
