@@ -23,6 +23,8 @@ The asm block owns v0-v159 (v64-v95 only after the inputs were read from there),
 import os
 import sys
 
+NW = 4      # waves per workgroup (64 query rows each): 8 / NW one-KiB LDS-DMA pieces per wave, operand and tile
+DMA_AT = "a1"   # where a step's LDS-DMA requests are issued: "a1" = phase A gaps 1.., "b12" = phase B gaps 12.., "tail" = after phase B's last gap
 ABL = 0     # timing-only builds (results are garbage): 1 no MFMA, 2 no softmax VALU, 4 no fragment reads, 8 no LDS-DMA, 16 no barrier / vmcnt wait;
             # any value != 0 also removes the range check's branch
 
@@ -35,14 +37,16 @@ KB, VB = 136, 140         # LDS addresses of the fragment reads in ring slot 0 (
 VOFF = 144                # LDS-DMA source offsets of this lane's two pieces
 LA, LB, MA, MB = 146, 147, 148, 149
 ACC0, ACC1, TL, TC = 150, 151, 152, 153
-THR, XADDR, OOFF, LSEOFF, QOFF, SPARE = 154, 155, 156, 157, 158, 159
+THR, QOFF, SPARE, E0, E1, E2 = 154, 155, 156, 157, 158, 159     # E*: scratch of the out-of-line pieces and the epilogue
 NV = 160
 OA, OB = 0, 32            # AGPR: O^T accumulators [2 x 16] per block
 QA, QB = 64, 80           # AGPR: Q fragments (4 x 4) per block
 S_KRS, S_VRS, S_QRS, S_CRS, S_LRS = 36, 40, 44, 48, 52
 S_KL, S_NT, S_T, S_KDST, S_VDST = 56, 57, 58, 59, 60
 S_KSOFF, S_VSOFF = 61, 62
-S_TMP, S_TMP2, S_DSC, S_HROW, S_MASKT, S_REM, S_LQ, S_CSIZE, S_CEN, S_SPECIAL = 70, 71, 72, 73, 74, 75, 76, 77, 78, 79
+S_TMP, S_TMP2, S_DSC, S_H128, S_MASKT, S_REM, S_LQ, S_CSIZE, S_CEN, S_SPECIAL = 70, 71, 72, 73, 74, 75, 76, 77, 78, 79
+S_STAGE, S_ROWOFF, S_LSE0, S_LK = 90, 91, 92, 93
+S_KLP = 94               # (pair) address of this batch element's k_len, or 0
 S_RET = 80                # return address of the out-of-line pieces
 S_SPEC_A, S_SPEC_B, S_RARE_A, S_RARE_B = 82, 84, 86, 88
 NINF = "0xff800000"
@@ -96,7 +100,8 @@ class Stream:
         if last >= 0:
             left = len(self.lds) - 1 - last
             assert left <= 15
-            self.raw("s_waitcnt lgkmcnt(%d)" % left, kind="wait")
+            if not (ABL & 64):
+                self.raw("s_waitcnt lgkmcnt(%d)" % left, kind="wait")
             self.lds = self.lds[last + 1:]
 
     def _mfma_pad(self, regs):
@@ -183,7 +188,7 @@ def emit_exp(st, X, i):
     if ABL & 2:
         return
     x = blk(X)
-    st.valu("v_exp_f32_e32 %s, %s" % (v(T + i % 8), v(x["S"] + i)), [x["S"] + i], [T + i % 8], kind="exp")
+    st.valu("%s %s, %s" % ("v_mov_b32_e32" if ABL & 128 else "v_exp_f32_e32", v(T + i % 8), v(x["S"] + i)), [x["S"] + i], [T + i % 8], kind="exp")
 
 
 def emit_sum_pack(st, X, k):
@@ -199,6 +204,39 @@ def emit_sum_pack(st, X, k):
         st.valu("v_add_f32_e32 %s, %s, %s" % (v(ACC0), v(ACC0), v(t0)), [ACC0, t0], [ACC0])
         st.valu("v_add_f32_e32 %s, %s, %s" % (v(ACC1), v(ACC1), v(t1)), [ACC1, t1], [ACC1])
     st.valu("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(x["P"] + k), v(t0), v(t1)), [t0, t1], [x["P"] + k], kind="cvt")
+
+
+def dma_piece(X, gap):
+    """the request (0 .. 2 PIECES - 1: K pieces first) issued in this gap, or None."""
+    if ABL & 8:
+        return None
+    n = 2 * (8 // NW)
+    if DMA_AT == "a1":
+        p = gap - 1 if X == "A" else -1
+    elif DMA_AT == "b12":
+        p = gap - (16 - n) if X == "B" else -1
+    elif DMA_AT == "a8":
+        p = gap - 8 if X == "A" else -1
+    else:
+        p = -1
+    return p if 0 <= p < n else None
+
+
+def emit_dma_m0(st, u, p):
+    # (an LDS-DMA load's immediate offset moves its LDS address as well as its source address: M0 takes it back out)
+    pieces = 8 // NW
+    if p < pieces:
+        st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_KDST), ((u + 3) & 3) * 8192 + p * 1024 - (p >> 1) * 2048 + 0x10000), kind="salu")
+    else:
+        q = p - pieces
+        st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_VDST), ((u + 2) & 3) * 8192 + q * 1024 - (q >> 1) * 2048 + 0x10000), kind="salu")
+
+
+def emit_dma_load(st, p):
+    pieces = 8 // NW
+    q = p % pieces                    # piece of this wave; pieces q and q + 2 differ by 16 rows = 2048 source bytes (same swizzle)
+    st.raw("buffer_load_dwordx4 %s, %s, %s offen offset:%d lds" % (v(VOFF + (q & 1)), s(S_KRS if p < pieces else S_VRS, 4),
+                                                                    s(S_KSOFF if p < pieces else S_VSOFF), (q >> 1) * 2048), kind="dma")
 
 
 def emit_phase(st, X, Y, u, uid):
@@ -226,23 +264,26 @@ def emit_phase(st, X, Y, u, uid):
             emit_k_read(st, gap - 4, k_slot * 8192)          # K fragments of this phase's scores, four gaps ahead
         else:
             emit_v_reads(st, gap - 12, v_next * 8192)        # V fragments 0..3 of the NEXT phase's P.V
-        dma = X == "A" and 1 <= gap <= 4 and not (ABL & 8)  # this step's LDS-DMA requests: K(t+3) -> slot (u+3)&3, V(t+2) -> slot (u+2)&3
-        if dma:
-            p = gap - 1
-            if p < 2:
-                st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_KDST), ((u + 3) & 3) * 8192 + p * 1024), kind="salu")
-            else:
-                st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_VDST), ((u + 2) & 3) * 8192 + (p - 2) * 1024), kind="salu")
+        dma = dma_piece(X, gap)                              # this step's LDS-DMA requests: K(t+3) -> slot (u+3)&3, V(t+2) -> slot (u+2)&3
+        if dma is not None:
+            emit_dma_m0(st, u, dma)
         emit_exp(st, X, 2 * gap)
-        if dma:
+        if dma is not None:
             if ABL & 2:
                 st.raw("s_nop 0", kind="nop")
-            st.raw("buffer_load_dwordx4 %s, %s, %s offen lds" % (v(VOFF + (p & 1)), s(S_KRS if p < 2 else S_VRS, 4), s(S_KSOFF if p < 2 else S_VSOFF)), kind="dma")
+            emit_dma_load(st, dma)
         emit_exp(st, X, 2 * gap + 1)
         if gap >= 1:
             emit_sum_pack(st, X, gap - 1)
     emit_sum_pack(st, X, 15)
+    if DMA_AT == "tail" and X == "B" and not (ABL & 8):
+        for p in range(2 * (8 // NW)):
+            emit_dma_m0(st, u, p)
+            st.raw("s_nop 0", kind="nop")
+            emit_dma_load(st, p)
     # tail: the lane's partial row sum must stay inside (2^-64, 2^64); anything else takes the whole wave through the re-centring
+    if ABL & 32:
+        return
     st.valu("v_add_f32_e32 %s, %s, %s" % (v(ACC0), v(ACC0), v(ACC1)), [ACC0, ACC1], [ACC0])
     st.valu("v_add_f32_e32 %s, %s, %s" % (v(TL), v(x["L"]), v(ACC0)), [x["L"], ACC0], [TL])
     st.valu("v_add_u32_e32 %s, 0xe0800000, %s" % (v(TC), v(TL)), [TL], [TC])
@@ -278,6 +319,14 @@ def emit_special(st, X):
     st.raw("s_setpc_b64 %s" % s(S_RET, 2))
 
 
+def emit_xaddr(st, reg):
+    """ds_bpermute address of the lane that holds the other half of this lane's query row: ((lane ^ 32) << 2)."""
+    st.raw("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(reg))
+    st.raw("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(reg), v(reg)))
+    st.raw("v_xor_b32_e32 %s, 32, %s" % (v(reg), v(reg)))
+    st.raw("v_lshlrev_b32_e32 %s, 2, %s" % (v(reg), v(reg)))
+
+
 def emit_rare(st, X):
     """out of line, at a phase's tail: re-centre block X (a change of reference, exact up to rounding) and redo its tile's numerators;
     returns with TL = the lane's new partial sum."""
@@ -290,8 +339,9 @@ def emit_rare(st, X):
         st.raw("v_max3_f32 %s, %s, %s, %s" % (v(R), v(R), v(S_ + i), v(S_ + i + 1)))
     st.raw("v_max_f32_e32 %s, %s, %s" % (v(R), v(R), v(S_ + 31)))
     st.raw("s_waitcnt lgkmcnt(0)")
-    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 1), v(XADDR), v(R)))
-    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 2), v(XADDR), v(x["L"])))
+    emit_xaddr(st, E0)
+    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 1), v(E0), v(R)))
+    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 2), v(E0), v(x["L"])))
     st.raw("s_waitcnt lgkmcnt(0)")
     st.raw("v_max_f32_e32 %s, %s, %s" % (v(R), v(R), v(R + 1)))                       # the row's maximum (relative to mref)
     st.raw("v_add_f32_e32 %s, %s, %s" % (v(R + 2), v(R + 2), v(x["L"])))              # the row's sum so far
@@ -335,9 +385,9 @@ def emit_rare(st, X):
 
 
 def emit_dma_now(st, rsrc, soff, dst_sgpr, imm, piece):
-    st.raw("s_add_u32 m0, %s, 0x%x" % (s(dst_sgpr), imm))
+    st.raw("s_add_u32 m0, %s, 0x%x" % (s(dst_sgpr), imm - (piece >> 1) * 2048 + 0x10000))
     st.raw("s_nop 0")
-    st.raw("buffer_load_dwordx4 %s, %s, %s offen lds" % (v(VOFF + piece), s(rsrc, 4), s(soff)))
+    st.raw("buffer_load_dwordx4 %s, %s, %s offen offset:%d lds" % (v(VOFF + (piece & 1)), s(rsrc, 4), s(soff), (piece >> 1) * 2048))
 
 
 def build(drop):
@@ -345,25 +395,49 @@ def build(drop):
     U = "%="
     st.comment("==== attention forward v4 (%s): generated by tools/gen_attn_fwd4.py - do not edit" % ("train: dropout" if drop else "eval"))
     st.comment("---- inputs (they sit in v64-v95 / low SGPRs) into the block's own registers")
+    st.raw("v_mov_b32_e32 %s, %%[qoff]" % v(QOFF))
+    st.raw("s_mov_b64 %s, %%[qb]" % s(S_QRS, 2))
+    st.raw("s_and_b32 %s, %s, 0xffff" % (s(S_QRS + 1), s(S_QRS + 1)))
+    st.raw("s_mov_b32 %s, 0x00020000" % s(S_QRS + 3))
+    st.raw("s_mov_b32 %s, %%[lq]" % s(S_LQ))
+    st.raw("s_lshl_b32 %s, %s, 7" % (s(S_QRS + 2), s(S_LQ)))
+    st.comment("---- first of all: this batch element's k_len and the Q fragments of both blocks (block B: 32 rows = 4096 bytes further)")
+    st.raw("s_mov_b64 %s, %%[klp]" % s(S_KLP, 2))
+    st.raw("s_mov_b32 %s, %%[lk]" % s(S_LK))
+    st.raw("s_mov_b32 %s, %s" % (s(S_KL), s(S_LK)))
+    st.raw("s_cmp_eq_u64 %s, 0" % s(S_KLP, 2))
+    st.raw("s_cbranch_scc1 .Lnoklen_%=")
+    st.raw("s_load_dword %s, %s, 0x0" % (s(S_KL), s(S_KLP, 2)))
+    st.label(".Lnoklen_%=")
+    st.raw("v_add_u32_e32 %s, 0x1000, %s" % (v(TL), v(QOFF)))
+    st.raw("s_nop 2")
+    for ks in range(4):
+        st.raw(("s_nop 0" if ABL & 512 else "buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (v(SA + 4 * ks, 4), v(QOFF), s(S_QRS, 4), 32 * ks)))
+    for ks in range(4):
+        st.raw(("s_nop 0" if ABL & 512 else "buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (v(SA + 16 + 4 * ks, 4), v(TL), s(S_QRS, 4), 32 * ks)))
     for name, reg in (("voff0", VOFF), ("voff1", VOFF + 1), ("kofs0", KB), ("kofs1", KB + 1), ("kofs2", KB + 2), ("kofs3", KB + 3),
-                      ("vofs0", VB), ("vofs1", VB + 1), ("vofs2", VB + 2), ("vofs3", VB + 3), ("qoff", QOFF), ("ooff", OOFF),
-                      ("lseoff", LSEOFF), ("thr", THR)):
+                      ("vofs0", VB), ("vofs1", VB + 1), ("vofs2", VB + 2), ("vofs3", VB + 3), ("thr", THR)):
         st.raw("v_mov_b32_e32 %s, %%[%s]" % (v(reg), name))
-    st.raw("v_xor_b32_e32 %s, 32, %%[lane]" % v(XADDR))
-    st.raw("v_lshlrev_b32_e32 %s, 2, %s" % (v(XADDR), v(XADDR)))
-    st.raw("v_lshlrev_b32_e32 %s, 4, %%[lane]" % v(TC))                  # lane * 16: this lane's bytes of a 1-KiB zero-fill row
-    for name, reg in (("kb", S_KRS), ("vb", S_VRS), ("qb", S_QRS), ("cb", S_CRS), ("lb", S_LRS)):
+    st.raw("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(TC))
+    st.raw("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(TC), v(TC)))
+    st.raw("v_lshlrev_b32_e32 %s, 4, %s" % (v(TC), v(TC)))                # lane * 16: this lane's bytes of a 1-KiB zero-fill row
+    for name, reg in (("kb", S_KRS), ("vb", S_VRS), ("cb", S_CRS), ("lb", S_LRS)):
         st.raw("s_mov_b64 %s, %%[%s]" % (s(reg, 2), name))
         st.raw("s_and_b32 %s, %s, 0xffff" % (s(reg + 1), s(reg + 1)))
         st.raw("s_mov_b32 %s, 0x00020000" % s(reg + 3))
-    for name, reg in (("kl", S_KL), ("nt", S_NT), ("kdst", S_KDST), ("dsc", S_DSC), ("hrow", S_HROW), ("lq", S_LQ), ("csize", S_CSIZE)):
+    for name, reg in (("kdst", S_KDST), ("dsc", S_DSC), ("h128", S_H128), ("csize", S_CSIZE), ("stage", S_STAGE), ("rowoff", S_ROWOFF), ("lse0", S_LSE0)):
         st.raw("s_mov_b32 %s, %%[%s]" % (s(reg), name))
     st.raw("s_mov_b32 %s, %%[lsz]" % s(S_LRS + 2))
+    st.raw("s_mov_b32 %s, %s" % (s(S_CRS + 2), s(S_CSIZE)))
+    st.raw("s_sub_u32 %s, %s, 0x10000" % (s(S_KDST), s(S_KDST)))          # (biased: the M0 sums add it back; keeps every immediate positive)
+    st.raw("s_add_u32 %s, %s, 0x8000" % (s(S_VDST), s(S_KDST)))
+    st.raw("s_waitcnt lgkmcnt(0)")                                        # k_len
+    st.raw("s_min_i32 %s, %s, %s" % (s(S_KL), s(S_KL), s(S_LK)))
+    st.raw("s_max_i32 %s, %s, 0" % (s(S_KL), s(S_KL)))
+    st.raw("s_add_u32 %s, %s, 63" % (s(S_NT), s(S_KL)))
+    st.raw("s_lshr_b32 %s, %s, 6" % (s(S_NT), s(S_NT)))
     st.raw("s_lshl_b32 %s, %s, 7" % (s(S_KRS + 2), s(S_KL)))             # K and V: k_len rows of 128 bytes (anything past them reads as zeros)
     st.raw("s_mov_b32 %s, %s" % (s(S_VRS + 2), s(S_KRS + 2)))
-    st.raw("s_lshl_b32 %s, %s, 7" % (s(S_QRS + 2), s(S_LQ)))
-    st.raw("s_mov_b32 %s, %s" % (s(S_CRS + 2), s(S_CSIZE)))
-    st.raw("s_add_u32 %s, %s, 0x8000" % (s(S_VDST), s(S_KDST)))
     st.raw("s_and_b32 %s, %s, 63" % (s(S_TMP), s(S_KL)))                  # the step that holds a ragged last tile (none: -1)
     st.raw("s_sub_u32 %s, %s, 1" % (s(S_MASKT), s(S_NT)))
     st.raw("s_cmp_eq_u32 %s, 0" % s(S_TMP))
@@ -379,16 +453,11 @@ def build(drop):
     for reg, lab in ((S_SPEC_A, ".Lspecial_A_"), (S_SPEC_B, ".Lspecial_B_"), (S_RARE_A, ".Lrare_A_"), (S_RARE_B, ".Lrare_B_")):
         st.raw("s_add_u32 %s, %s, %s%s-.Lhere_%s" % (s(reg), s(S_TMP), lab, U, U))
         st.raw("s_addc_u32 %s, %s, 0" % (s(reg + 1), s(S_TMP2)))
-    st.comment("---- Q fragments of both blocks (block B: 32 rows = 4096 bytes further), then K0 V0 K1 V1 K2 by LDS-DMA")
-    st.raw("v_add_u32_e32 %s, 0x1000, %s" % (v(TL), v(QOFF)))
+    st.comment("---- K0 V0 K1 V1 K2 by LDS-DMA")
     st.raw("s_nop 4")
-    for ks in range(4):
-        st.raw("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (v(SA + 4 * ks, 4), v(QOFF), s(S_QRS, 4), 32 * ks))
-    for ks in range(4):
-        st.raw("buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (v(SA + 16 + 4 * ks, 4), v(TL), s(S_QRS, 4), 32 * ks))
     for tile, which in ((0, "K"), (0, "V"), (1, "K"), (1, "V"), (2, "K")):
         st.raw("s_mov_b32 %s, 0x%x" % (s(S_TMP), tile * 8192))
-        for piece in range(2):
+        for piece in range(8 // NW if not (ABL & 1024) else 0):
             emit_dma_now(st, S_KRS if which == "K" else S_VRS, S_TMP, S_KDST if which == "K" else S_VDST, tile * 8192 + piece * 1024, piece)
     st.raw("s_mov_b32 %s, 0x%x" % (s(S_KSOFF), 3 * 8192))             # the requests of step 0: K(3), V(2)
     st.raw("s_mov_b32 %s, 0x%x" % (s(S_VSOFF), 2 * 8192))
@@ -400,13 +469,14 @@ def build(drop):
     for r in range(4):
         st.raw("v_mov_b32_e32 %s, 0" % v(T + r))
     st.raw("v_add_u32_e32 %s, %s, %s" % (v(TC), s(S_VDST), v(TC)))
-    st.raw("ds_write_b128 %s, %s offset:%d" % (v(TC), v(T, 4), 3 * 8192))
-    st.raw("ds_write_b128 %s, %s offset:%d" % (v(TC), v(T, 4), 3 * 8192 + 1024))
+    st.raw("v_add_u32_e32 %s, 0x10000, %s" % (v(TC), v(TC)))
+    for piece in range(8 // NW):
+        st.raw("ds_write_b128 %s, %s offset:%d" % (v(TC), v(T, 4), 3 * 8192 + piece * 1024))
     st.comment("---- Q into the accumulator file (B operands of every K.Q^T)")
-    st.raw("s_waitcnt vmcnt(10)")
+    st.raw("s_waitcnt vmcnt(%d)" % (5 * (8 // NW) if not (ABL & 1536) else 0))
     for i in range(32):
         st.raw("v_accvgpr_write_b32 %s, %s" % (a(QA + i), v(SA + i)))
-    st.raw("s_waitcnt vmcnt(8) lgkmcnt(0)")        # K0 landed (V0 K1 V1 K2 may be in flight); the zero fill is in LDS
+    st.raw("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (4 * (8 // NW) if not (ABL & 1536) else 0))        # K0 landed (V0 K1 V1 K2 may be in flight); the zero fill is in LDS
     st.raw("s_barrier")
     st.raw("s_cmp_eq_u32 %s, 0" % s(S_NT))
     st.raw("s_cbranch_scc1 .Lfinal_" + U)
@@ -441,7 +511,7 @@ def build(drop):
         for u in range(4):
             st.comment("==== step t, t & 3 == %d" % u)
             if not (ABL & 16):
-                st.raw("s_waitcnt vmcnt(4)", kind="wait")      # K(t+1) and V(t) have landed: everything but the previous step's four requests
+                st.raw("s_waitcnt vmcnt(%d)" % (2 * (8 // NW)), kind="wait")      # K(t+1) and V(t) have landed: everything but the previous step's four requests
                 st.raw("s_barrier", kind="salu")
             emit_phase(st, "A", "B", u, "a%d" % u)
             emit_phase(st, "B", "A", u, "b%d" % u)
@@ -476,11 +546,32 @@ def build(drop):
     st.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")             # (out-of-range requests of the last steps: nothing may land after the LDS is released)
     st.raw("s_nop 7", states=8)
     st.raw("s_nop 7", states=8)
-    st.comment("---- epilogue: O / l -> bf16 rows of ctx; lse = mref + log2(l)")
+    st.comment("---- epilogue: O / l -> bf16, through LDS (rows of 144 bytes: 128 + a pad that spreads the banks) to whole-row stores; lse = mref + log2(l)")
+    # every wave of the workgroup is past its last fragment read and its last LDS-DMA request has landed: the rings are free
+    st.raw("s_barrier")
+    LN, RR, WA, RA, SO, XA = T, T + 1, T + 2, T + 3, T + 4, T + 5
+    st.raw("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(LN))
+    st.raw("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(LN), v(LN)))
+    st.raw("v_and_b32_e32 %s, 31, %s" % (v(RR), v(LN)))                                  # r: the lane's query row inside a block
+    st.raw("v_lshrrev_b32_e32 %s, 5, %s" % (v(WA), v(LN)))                                # hh
+    st.raw("v_lshlrev_b32_e32 %s, 3, %s" % (v(WA), v(WA)))
+    st.raw("v_lshl_add_u32 %s, %s, 7, %s" % (v(WA), v(RR), v(WA)))
+    st.raw("v_lshl_add_u32 %s, %s, 4, %s" % (v(WA), v(RR), v(WA)))                      # + 144 r
+    st.raw("v_add_u32_e32 %s, %s, %s" % (v(WA), s(S_STAGE), v(WA)))                      # write address: row r, byte 8 hh (+ 64 dt + 16 g; block B 32 rows on)
+    st.raw("v_lshrrev_b32_e32 %s, 3, %s" % (v(RA), v(LN)))                                # row of the read-back: lane >> 3 (+ 8 per instruction)
+    st.raw("v_and_b32_e32 %s, 7, %s" % (v(SO), v(LN)))
+    st.raw("v_lshlrev_b32_e32 %s, 4, %s" % (v(SO), v(SO)))                                # 16-byte chunk lane & 7
+    st.raw("v_mul_lo_u32 %s, %s, %s" % (v(XA), v(RA), s(S_H128)))
+    st.raw("v_lshl_add_u32 %s, %s, 7, %s" % (v(SO + 2), v(RA), v(SO)))
+    st.raw("v_lshl_add_u32 %s, %s, 4, %s" % (v(RA), v(RA), v(SO + 2)))                  # 144 (lane >> 3) + chunk
+    st.raw("v_add_u32_e32 %s, %s, %s" % (v(RA), s(S_STAGE), v(RA)))                      # read address
+    st.raw("v_add3_u32 %s, %s, %s, %s" % (v(SO), v(XA), v(SO), s(S_ROWOFF)))             # ctx byte offset of (row, chunk)
+    st.raw("v_xor_b32_e32 %s, 32, %s" % (v(XA), v(LN)))
+    st.raw("v_lshlrev_b32_e32 %s, 2, %s" % (v(XA), v(XA)))
     R = SA            # the score registers are free now
-    for X in ("A", "B"):
+    for bi, X in enumerate(("A", "B")):
         x = blk(X)
-        st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R), v(XADDR), v(x["L"])))
+        st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R), v(XA), v(x["L"])))
         st.raw("s_waitcnt lgkmcnt(0)")
         st.raw("v_add_f32_e32 %s, %s, %s" % (v(R), v(R), v(x["L"])))
         st.raw("v_rcp_f32_e32 %s, %s" % (v(R + 1), v(R)))
@@ -489,9 +580,6 @@ def build(drop):
         if drop:
             st.raw("v_mul_f32_e32 %s, %s, %s" % (v(R + 1), s(S_DSC), v(R + 1)))
         st.raw("v_add_f32_e32 %s, %s, %s" % (v(R + 2), v(R + 2), v(x["M"])))
-        if X == "B":
-            st.raw("v_add_u32_e32 %s, %s, %s" % (v(OOFF), s(S_HROW), v(OOFF)))
-            st.raw("v_add_u32_e32 %s, 0x80, %s" % (v(LSEOFF), v(LSEOFF)))
         for dt in range(2):
             for g in range(4):
                 for j in range(4):
@@ -499,17 +587,27 @@ def build(drop):
                 st.raw("s_nop 0")
                 for j in range(4):
                     st.raw("v_mul_f32_e32 %s, %s, %s" % (v(R + 4 + j), v(R + 4 + j), v(R + 1)))
-                st.raw("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(R + 8 + 2 * (4 * dt + g)), v(R + 4), v(R + 5)))
-                st.raw("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(R + 9 + 2 * (4 * dt + g)), v(R + 6), v(R + 7)))
-        st.raw("s_nop 1", states=2)
-        for dt in range(2):
-            for g in range(4):
-                st.raw("buffer_store_dwordx2 %s, %s, %s, 0 offen offset:%d" % (v(R + 8 + 2 * (4 * dt + g), 2), v(OOFF), s(S_CRS, 4), 64 * dt + 16 * g))
-        st.raw("s_mov_b32 exec_hi, 0")                  # lanes 0..31 hold one row each
-        st.raw("buffer_store_dword %s, %s, %s, 0 offen" % (v(R + 2), v(LSEOFF), s(S_LRS, 4)))
+                st.raw("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(R + 8), v(R + 4), v(R + 5)))
+                st.raw("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(R + 9), v(R + 6), v(R + 7)))
+                st.raw("ds_write_b64 %s, %s offset:%d" % (v(WA), v(R + 8, 2), bi * 32 * 144 + 64 * dt + 16 * g))
+        # lse of the block's 32 rows: lanes 0..31 hold one row each
+        st.raw("v_lshlrev_b32_e32 %s, 2, %s" % (v(R + 3), v(RR)))
+        st.raw("v_add_u32_e32 %s, %s, %s" % (v(R + 3), s(S_LSE0), v(R + 3)))
+        st.raw("s_mov_b32 exec_hi, 0")
+        if not (ABL & 256):
+            st.raw("buffer_store_dword %s, %s, %s, 0 offen offset:%d" % (v(R + 2), v(R + 3), s(S_LRS, 4), 128 * bi))
         st.raw("s_mov_b32 exec_hi, -1")
         R = SB
-    st.raw("s_waitcnt vmcnt(0)")
+    st.raw("s_waitcnt lgkmcnt(0)")                     # the wave reads back only what it wrote itself: no barrier
+    for i in range(8):
+        st.raw("ds_read_b128 %s, %s offset:%d" % (v(SA + 4 * i, 4), v(RA), i * 8 * 144))
+    st.raw("s_mov_b32 %s, 0" % s(S_TMP))
+    st.raw("s_lshl_b32 %s, %s, 3" % (s(S_TMP2), s(S_H128)))                # 8 rows of ctx
+    for i in range(8):
+        st.raw("s_waitcnt lgkmcnt(%d)" % (7 - i))
+        if not (ABL & 256):
+            st.raw("buffer_store_dwordx4 %s, %s, %s, %s offen" % (v(SA + 4 * i, 4), v(SO), s(S_CRS, 4), s(S_TMP)))
+        st.raw("s_add_u32 %s, %s, %s" % (s(S_TMP), s(S_TMP), s(S_TMP2)))
     st.raw("s_endpgm")
     for X in ("A", "B"):
         emit_special(st, X)
@@ -518,21 +616,30 @@ def build(drop):
 
 
 def main():
-    global ABL
+    global ABL, NW, DMA_AT
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(os.path.dirname(here), "end-to-end_asr_pytorch_amd", "csrc", "attention_fwd4_asm.inc")
-    if len(sys.argv) > 3 and sys.argv[1] == "--abl":        # tools/abl_attn4.sh: python tools/gen_attn_fwd4.py --abl 3 /tmp/x.inc
-        ABL = int(sys.argv[2])
-        out = sys.argv[3]
+    args = sys.argv[1:]
+    while args and args[0].startswith("--"):          # tools/abl_attn4.sh: python tools/gen_attn_fwd4.py --abl 3 --dma tail --out /tmp/x.inc
+        if args[0] == "--abl":
+            ABL = int(args[1])
+        elif args[0] == "--dma":
+            DMA_AT = args[1]
+        elif args[0] == "--out":
+            out = args[1]
+        args = args[2:]
     with open(out, "w") as f:
         f.write("// generated by tools/gen_attn_fwd4.py - do not edit (edit the generator and run it again)\n")
-        for drop in (False,):
-            st, counts, nops = build(drop)
-            f.write("#define ATTN4_ASM_%s \\\n" % ("TRAIN" if drop else "EVAL"))
-            for line in st.out:
-                f.write('    "%s\\n" \\\n' % line.replace("\\", "\\\\").replace('"', '\\"'))
-            f.write('    ""\n')
-            sys.stderr.write("%s: %d lines; per trip of 4 steps: %s; s_nop states padded in the loop: %d\n" % ("train" if drop else "eval", len(st.out), counts, nops))
+        for nw in (2, 4):
+            NW = nw
+            for drop in (False,):
+                st, counts, nops = build(drop)
+                f.write("#define ATTN4_ASM_%s_NW%d \\\n" % ("TRAIN" if drop else "EVAL", nw))
+                for line in st.out:
+                    f.write('    "%s\\n" \\\n' % line.replace("\\", "\\\\").replace('"', '\\"'))
+                f.write('    ""\n')
+                sys.stderr.write("NW %d %s: %d lines; per trip of 4 steps: %s; s_nop states padded in the loop: %d\n" %
+                                 (nw, "train" if drop else "eval", len(st.out), counts, nops))
         regs = ["v%d" % i for i in list(range(64)) + list(range(96, NV))] + ["a%d" % i for i in range(96)] + ["s%d" % i for i in range(34, 100)] + ["vcc", "memory"]
         f.write("#define ATTN4_ASM_CLOBBERS %s\n" % ", ".join('"%s"' % r for r in regs))
 
