@@ -328,11 +328,12 @@ __global__ __launch_bounds__(256, ATTN4_WPE) void attn_fwd_bf16_v4_kernel(const 
 #endif
 #include ATTN4_INC
 
-template <int NW>
+template <int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v4a_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
                                                                        float* __restrict__ lse, int h, int Lq, int Lk,
-                                                                       const int32_t* __restrict__ k_len, int q_tiles, float dscale) {
+                                                                       const int32_t* __restrict__ k_len, int q_tiles, float dscale,
+                                                                       const uint32_t* __restrict__ drop_bits) {
     constexpr int PIECES = 8 / NW;                      // 1-KiB LDS-DMA pieces per wave, operand and tile
     __shared__ __attribute__((aligned(16))) unsigned char smem[8 * 8192];   // K ring [4][8 KiB] | V ring [4][8 KiB]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -379,20 +380,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v4a_kernel(const bf1
     const uint64_t lbp = (uint64_t)(lse ? lse + (int64_t)bh * Lq : nullptr);
     const uint64_t klp = (uint64_t)(k_len ? k_len + b : nullptr);
     const unsigned qoff = (unsigned)qrow * 128u + 16u * hh;
-    const int thr = -4 * hh;
+    const unsigned sh4 = 4u * hh;
+    // dropout: the Mk keep-bit image of this (batch, head): [key / 32][query] words (asr_common.h)
+    const unsigned lqp4 = (unsigned)drop_pad128(Lq) * 4u, msz = DROP ? (unsigned)(drop_pad128(Lk) / 32) * lqp4 : 0u;
+    const uint64_t mbp = (uint64_t)(DROP ? drop_bits + (int64_t)bh * (drop_pad128(Lk) / 32) * drop_pad128(Lq) : nullptr);
     const unsigned kdst = smem0 + (unsigned)(wave * PIECES) * 1024u;
     const unsigned stage = smem0 + (unsigned)wave * 9216u;          // the epilogue's 64 rows of 144 bytes
-    const unsigned h128 = (unsigned)h * 128u, rowoff = (unsigned)q0w * h128, lse0 = (unsigned)q0w * 4u;
+    const unsigned h128 = (unsigned)h * 128u, lse0 = (unsigned)q0w * 4u;
     const unsigned csize = (unsigned)Lq * h128 - (unsigned)hd * 128u;
-    const unsigned lsz = lse ? (unsigned)Lq * 4u : 0u;
     const unsigned dsc = __builtin_bit_cast(unsigned, dscale);
 #define ATTN4_OPERANDS                                                                                                                     \
     [voff0] "v"(voff[0]), [voff1] "v"(voff[1]), [kofs0] "v"(kofs[0]), [kofs1] "v"(kofs[1]), [kofs2] "v"(kofs[2]), [kofs3] "v"(kofs[3]),    \
-        [vofs0] "v"(vofs[0]), [vofs1] "v"(vofs[1]), [vofs2] "v"(vofs[2]), [vofs3] "v"(vofs[3]), [qoff] "v"(qoff), [thr] "v"(thr),          \
+        [vofs0] "v"(vofs[0]), [vofs1] "v"(vofs[1]), [vofs2] "v"(vofs[2]), [vofs3] "v"(vofs[3]), [qoff] "v"(qoff), [sh4] "v"(sh4),          \
         [kb] "s"(kbp), [vb] "s"(vbp), [qb] "s"(qbp), [cb] "s"(cbp), [lb] "s"(lbp), [klp] "s"(klp), [lk] "s"(Lk), [kdst] "s"(kdst),         \
-        [dsc] "s"(dsc), [h128] "s"(h128), [lq] "s"(Lq), [csize] "s"(csize), [lsz] "s"(lsz), [stage] "s"(stage), [rowoff] "s"(rowoff),      \
-        [lse0] "s"(lse0)
-    if constexpr (NW == 4) asm volatile(ATTN4_ASM_EVAL_NW4 : : ATTN4_OPERANDS : ATTN4_ASM_CLOBBERS);
+        [dsc] "s"(dsc), [h128] "s"(h128), [lq] "s"(Lq), [csize] "s"(csize), [stage] "s"(stage), [lse0] "s"(lse0), [mb] "s"(mbp),           \
+        [msz] "s"(msz), [lqp4] "s"(lqp4)
+    if constexpr (NW == 4 && DROP) asm volatile(ATTN4_ASM_TRAIN_NW4 : : ATTN4_OPERANDS : ATTN4_ASM_CLOBBERS);
+    else if constexpr (NW == 4) asm volatile(ATTN4_ASM_EVAL_NW4 : : ATTN4_OPERANDS : ATTN4_ASM_CLOBBERS);
+    else if constexpr (DROP) asm volatile(ATTN4_ASM_TRAIN_NW2 : : ATTN4_OPERANDS : ATTN4_ASM_CLOBBERS);
     else asm volatile(ATTN4_ASM_EVAL_NW2 : : ATTN4_OPERANDS : ATTN4_ASM_CLOBBERS);
 #undef ATTN4_OPERANDS
 }
@@ -401,23 +406,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v4a_kernel(const bf1
 
 int asr_attention_fwd_v4(hipStream_t s, const void* q, const void* k, const void* v, void* ctx, float* lse, int B, int h, int Lq, int Lk,
                          const int32_t* k_len, asr_dropout_t drop, const uint32_t* drop_bits) {
-    if (drop.thr16) return -2;
     static const int form = getenv("ASR_AMD_ATTN_V4") ? atoi(getenv("ASR_AMD_ATTN_V4")) : 2;
     if (form >= 2) {
-        // waves per workgroup (64 query rows each): the more, the fewer LDS-DMA requests per wave and K / V bytes through L2 per row -
-        // as long as the grid still covers the chip (two workgroups of four waves, or one of eight, per CU)
+        // waves per workgroup (64 query rows each): four when that still gives the chip two workgroups per CU, else two
         static const int nw_env = getenv("ASR_AMD_ATTN_NW") ? atoi(getenv("ASR_AMD_ATTN_NW")) : 0;
         const int64_t rows64 = (int64_t)B * h * ((Lq + 63) / 64);
-        int nw = nw_env ? nw_env : (rows64 >= 2048 ? 4 : 2);
-#define ATTN4_LAUNCH(N)                                                                                                              \
-    hipLaunchKernelGGL((attn_fwd_bf16_v4a_kernel<N>), dim3(B * h * ((Lq + 64 * N - 1) / (64 * N))), dim3(64 * N), 0, s, (const bf16_t*)q, \
-                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, (Lq + 64 * N - 1) / (64 * N), 1.f)
-        if (nw >= 4) ATTN4_LAUNCH(4);
-        else ATTN4_LAUNCH(2);
+        const int nw = nw_env ? nw_env : (rows64 >= 2048 ? 4 : 2);
+        const float dsc = drop.thr16 ? 65536.f / (float)(65536u - drop.thr16) : 1.f;
+#define ATTN4_LAUNCH(N, D)                                                                                                              \
+    hipLaunchKernelGGL((attn_fwd_bf16_v4a_kernel<N, D>), dim3(B * h * ((Lq + 64 * N - 1) / (64 * N))), dim3(64 * N), 0, s, (const bf16_t*)q, \
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, (Lq + 64 * N - 1) / (64 * N), dsc, drop_bits)
+        if (nw >= 4) { if (drop.thr16) ATTN4_LAUNCH(4, true); else ATTN4_LAUNCH(4, false); }
+        else         { if (drop.thr16) ATTN4_LAUNCH(2, true); else ATTN4_LAUNCH(2, false); }
 #undef ATTN4_LAUNCH
         ASR_LAUNCH_CHECK("attention_fwd_bf16_v4a");
         return 0;
     }
+    if (drop.thr16) return -2;
     const int q_tiles = (Lq + 255) / 256;
     hipLaunchKernelGGL((attn_fwd_bf16_v4_kernel<false>), dim3(B * h * q_tiles), dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits);

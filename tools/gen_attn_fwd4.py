@@ -37,7 +37,8 @@ KB, VB = 136, 140         # LDS addresses of the fragment reads in ring slot 0 (
 VOFF = 144                # LDS-DMA source offsets of this lane's two pieces
 LA, LB, MA, MB = 146, 147, 148, 149
 ACC0, ACC1, TL, TC = 150, 151, 152, 153
-THR, QOFF, SPARE, E0, E1, E2 = 154, 155, 156, 157, 158, 159     # E*: scratch of the out-of-line pieces and the epilogue
+SH4, QOFF, WKA, WKB = 154, 155, 156, 158    # SH4 = 4 hh; QOFF doubles as the mask image's lane offset (MOFF) once Q is requested;
+MOFF = QOFF                                  # WKA / WKB: the two keep-bit words (32 keys each) of a block's tile, dropout only
 NV = 160
 OA, OB = 0, 32            # AGPR: O^T accumulators [2 x 16] per block
 QA, QB = 64, 80           # AGPR: Q fragments (4 x 4) per block
@@ -47,6 +48,8 @@ S_KSOFF, S_VSOFF = 61, 62
 S_TMP, S_TMP2, S_DSC, S_H128, S_MASKT, S_REM, S_LQ, S_CSIZE, S_CEN, S_SPECIAL = 70, 71, 72, 73, 74, 75, 76, 77, 78, 79
 S_STAGE, S_ROWOFF, S_LSE0, S_LK = 90, 91, 92, 93
 S_KLP = 94               # (pair) address of this batch element's k_len, or 0
+S_MRS, S_M0, S_M1, S_LQP4 = 64, 68, 69, 96     # dropout: the Mk keep-bit image of this (batch, head), offsets of the next tile's two words
+DROP = False
 S_RET = 80                # return address of the out-of-line pieces
 S_SPEC_A, S_SPEC_B, S_RARE_A, S_RARE_B = 82, 84, 86, 88
 NINF = "0xff800000"
@@ -147,8 +150,8 @@ class Stream:
 
 
 def blk(X):
-    return dict(S=SA, P=PA, L=LA, M=MA, O=OA, Q=QA, SPEC=S_SPEC_A, RARE=S_RARE_A) if X == "A" else \
-        dict(S=SB, P=PB, L=LB, M=MB, O=OB, Q=QB, SPEC=S_SPEC_B, RARE=S_RARE_B)
+    return dict(S=SA, P=PA, L=LA, M=MA, O=OA, Q=QA, SPEC=S_SPEC_A, RARE=S_RARE_A, WK=WKA, MIMM=0) if X == "A" else \
+        dict(S=SB, P=PB, L=LB, M=MB, O=OB, Q=QB, SPEC=S_SPEC_B, RARE=S_RARE_B, WK=WKB, MIMM=128)
 
 
 # ---- pieces of a phase -----------------------------------------------------------------------------------------------------------
@@ -203,7 +206,27 @@ def emit_sum_pack(st, X, k):
     else:
         st.valu("v_add_f32_e32 %s, %s, %s" % (v(ACC0), v(ACC0), v(t0)), [ACC0, t0], [ACC0])
         st.valu("v_add_f32_e32 %s, %s, %s" % (v(ACC1), v(ACC1), v(t1)), [ACC1, t1], [ACC1])
+    if DROP:         # attention.py:83: the kept probabilities go on to P.V (1 / keep is folded into the final normalisation); the sums above are of all
+        for e, t, m in ((2 * k, t0, TC), (2 * k + 1, t1, TL)):
+            hf, i = e >> 4, e & 15
+            st.valu("v_bfe_i32 %s, %s, %d, 1" % (v(m), v(x["WK"] + hf), 8 * (i >> 2) + (i & 3)), [x["WK"] + hf], [m], kind="drop")
+            st.valu("v_and_b32_e32 %s, %s, %s" % (v(t), v(t), v(m)), [t, m], [t], kind="drop")
     st.valu("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(x["P"] + k), v(t0), v(t1)), [t0, t1], [x["P"] + k], kind="cvt")
+
+
+def emit_mask_loads(st, X):
+    """the two keep-bit words of block X's next tile (32 keys each, this lane's query), requested a whole step ahead."""
+    x = blk(X)
+    st.raw("buffer_load_dword %s, %s, %s, %s offen offset:%d" % (v(x["WK"]), v(MOFF), s(S_MRS, 4), s(S_M0), x["MIMM"]), kind="mload")
+    st.raw("buffer_load_dword %s, %s, %s, %s offen offset:%d" % (v(x["WK"] + 1), v(MOFF), s(S_MRS, 4), s(S_M1), x["MIMM"]), kind="mload")
+
+
+def emit_mask_ready(st, X, outstanding):
+    x = blk(X)
+    if outstanding is not None:
+        st.raw("s_waitcnt vmcnt(%d)" % outstanding, kind="wait")
+    st.raw("v_lshrrev_b32_e32 %s, %s, %s" % (v(x["WK"]), v(SH4), v(x["WK"])), kind="drop")          # this lane's keys: bits 8 g + 4 hh + x
+    st.raw("v_lshrrev_b32_e32 %s, %s, %s" % (v(x["WK"] + 1), v(SH4), v(x["WK"] + 1)), kind="drop")
 
 
 def dma_piece(X, gap):
@@ -253,6 +276,8 @@ def emit_phase(st, X, Y, u, uid):
     st.raw("s_cbranch_scc0 .Lplain_%s_%s" % (uid, "%="), kind="salu")
     st.raw("s_swappc_b64 %s, %s" % (s(S_RET, 2), s(x["SPEC"], 2)), kind="salu")
     st.label(".Lplain_%s_%s" % (uid, "%="))
+    if DROP:
+        emit_mask_ready(st, X, None if X == "A" else 2 * (8 // NW) + 2)      # (phase A's words: the step's wait in front of the barrier covers them)
     for gap in range(16):
         if gap < 8:
             emit_pv_mfma(st, Y, gap)
@@ -283,6 +308,8 @@ def emit_phase(st, X, Y, u, uid):
             emit_dma_load(st, p)
     # tail: the lane's partial row sum must stay inside (2^-64, 2^64); anything else takes the whole wave through the re-centring
     if ABL & 32:
+        if DROP:
+            emit_mask_loads(st, X)
         return
     st.valu("v_add_f32_e32 %s, %s, %s" % (v(ACC0), v(ACC0), v(ACC1)), [ACC0, ACC1], [ACC0])
     st.valu("v_add_f32_e32 %s, %s, %s" % (v(TL), v(x["L"]), v(ACC0)), [x["L"], ACC0], [TL])
@@ -293,6 +320,8 @@ def emit_phase(st, X, Y, u, uid):
         st.raw("s_swappc_b64 %s, %s" % (s(S_RET, 2), s(x["RARE"], 2)), kind="salu")
         st.label(".Lfine_%s_%s" % (uid, "%="))
     st.valu("v_mov_b32_e32 %s, %s" % (v(x["L"]), v(TL)), [TL], [x["L"]])
+    if DROP:
+        emit_mask_loads(st, X)
 
 
 def emit_special(st, X):
@@ -308,13 +337,13 @@ def emit_special(st, X):
     st.label(".Lnocen_%s_%s" % (X, "%="))
     st.raw("s_cmp_eq_u32 %s, %s" % (s(S_T), s(S_MASKT)))
     st.raw("s_cbranch_scc0 .Lnomask_%s_%s" % (X, "%="))
-    st.raw("v_add_u32_e32 %s, %s, %s" % (v(TC), s(S_REM), v(THR)))            # keys of this tile that exist, minus 4 hh
-    st.raw("v_mov_b32_e32 %s, %s" % (v(SPARE), NINF))
+    st.raw("v_sub_u32_e32 %s, %s, %s" % (v(TC), s(S_REM), v(SH4)))            # keys of this tile that exist, minus 4 hh
+    st.raw("v_mov_b32_e32 %s, %s" % (v(T + 7), NINF))
     for hf in range(2):
         for i in range(16):
             key = 32 * hf + (i & 3) + 8 * (i >> 2)
             st.raw("v_cmp_lt_i32_e32 vcc, %d, %s" % (key, v(TC)))
-            st.raw("v_cndmask_b32_e32 %s, %s, %s, vcc" % (v(x["S"] + 16 * hf + i), v(SPARE), v(x["S"] + 16 * hf + i)))
+            st.raw("v_cndmask_b32_e32 %s, %s, %s, vcc" % (v(x["S"] + 16 * hf + i), v(T + 7), v(x["S"] + 16 * hf + i)))
     st.label(".Lnomask_%s_%s" % (X, "%="))
     st.raw("s_setpc_b64 %s" % s(S_RET, 2))
 
@@ -339,9 +368,9 @@ def emit_rare(st, X):
         st.raw("v_max3_f32 %s, %s, %s, %s" % (v(R), v(R), v(S_ + i), v(S_ + i + 1)))
     st.raw("v_max_f32_e32 %s, %s, %s" % (v(R), v(R), v(S_ + 31)))
     st.raw("s_waitcnt lgkmcnt(0)")
-    emit_xaddr(st, E0)
-    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 1), v(E0), v(R)))
-    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 2), v(E0), v(x["L"])))
+    emit_xaddr(st, R + 10)
+    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 1), v(R + 10), v(R)))
+    st.raw("ds_bpermute_b32 %s, %s, %s" % (v(R + 2), v(R + 10), v(x["L"])))
     st.raw("s_waitcnt lgkmcnt(0)")
     st.raw("v_max_f32_e32 %s, %s, %s" % (v(R), v(R), v(R + 1)))                       # the row's maximum (relative to mref)
     st.raw("v_add_f32_e32 %s, %s, %s" % (v(R + 2), v(R + 2), v(x["L"])))              # the row's sum so far
@@ -377,6 +406,11 @@ def emit_rare(st, X):
         else:
             st.raw("v_add_f32_e32 %s, %s, %s" % (v(ACC0), v(ACC0), v(R + 8)))
             st.raw("v_add_f32_e32 %s, %s, %s" % (v(ACC0), v(ACC0), v(R + 9)))
+        if DROP:
+            for e, t in ((2 * k, R + 8), (2 * k + 1, R + 9)):
+                hf, i = e >> 4, e & 15
+                st.raw("v_bfe_i32 %s, %s, %d, 1" % (v(R + 10), v(x["WK"] + hf), 8 * (i >> 2) + (i & 3)))
+                st.raw("v_and_b32_e32 %s, %s, %s" % (v(t), v(t), v(R + 10)))
         st.raw("v_cvt_pk_bf16_f32 %s, %s, %s" % (v(x["P"] + k), v(R + 8), v(R + 9)))
     st.raw("v_add_f32_e32 %s, %s, %s" % (v(TL), v(R + 6), v(ACC0)))
     st.raw("s_mov_b32 %s, 1" % s(S_CEN))
@@ -416,7 +450,7 @@ def build(drop):
     for ks in range(4):
         st.raw(("s_nop 0" if ABL & 512 else "buffer_load_dwordx4 %s, %s, %s, 0 offen offset:%d" % (v(SA + 16 + 4 * ks, 4), v(TL), s(S_QRS, 4), 32 * ks)))
     for name, reg in (("voff0", VOFF), ("voff1", VOFF + 1), ("kofs0", KB), ("kofs1", KB + 1), ("kofs2", KB + 2), ("kofs3", KB + 3),
-                      ("vofs0", VB), ("vofs1", VB + 1), ("vofs2", VB + 2), ("vofs3", VB + 3), ("thr", THR)):
+                      ("vofs0", VB), ("vofs1", VB + 1), ("vofs2", VB + 2), ("vofs3", VB + 3), ("sh4", SH4)):
         st.raw("v_mov_b32_e32 %s, %%[%s]" % (v(reg), name))
     st.raw("v_mbcnt_lo_u32_b32 %s, -1, 0" % v(TC))
     st.raw("v_mbcnt_hi_u32_b32 %s, -1, %s" % (v(TC), v(TC)))
@@ -425,9 +459,21 @@ def build(drop):
         st.raw("s_mov_b64 %s, %%[%s]" % (s(reg, 2), name))
         st.raw("s_and_b32 %s, %s, 0xffff" % (s(reg + 1), s(reg + 1)))
         st.raw("s_mov_b32 %s, 0x00020000" % s(reg + 3))
-    for name, reg in (("kdst", S_KDST), ("dsc", S_DSC), ("h128", S_H128), ("csize", S_CSIZE), ("stage", S_STAGE), ("rowoff", S_ROWOFF), ("lse0", S_LSE0)):
+    for name, reg in (("kdst", S_KDST), ("dsc", S_DSC), ("h128", S_H128), ("csize", S_CSIZE), ("stage", S_STAGE), ("lse0", S_LSE0)):
         st.raw("s_mov_b32 %s, %%[%s]" % (s(reg), name))
-    st.raw("s_mov_b32 %s, %%[lsz]" % s(S_LRS + 2))
+    st.raw("s_lshr_b32 %s, %s, 2" % (s(S_TMP), s(S_LSE0)))
+    st.raw("s_mul_i32 %s, %s, %s" % (s(S_ROWOFF), s(S_TMP), s(S_H128)))       # ctx byte offset of this wave's first row
+    st.raw("s_lshl_b32 %s, %s, 2" % (s(S_LRS + 2), s(S_LQ)))
+    st.raw("s_cmp_eq_u64 %s, 0" % s(S_LRS, 2))                                # no lse wanted: an empty buffer drops the stores
+    st.raw("s_cselect_b32 %s, 0, %s" % (s(S_LRS + 2), s(S_LRS + 2)))
+    if DROP:
+        st.raw("s_mov_b64 %s, %%[mb]" % s(S_MRS, 2))
+        st.raw("s_and_b32 %s, %s, 0xffff" % (s(S_MRS + 1), s(S_MRS + 1)))
+        st.raw("s_mov_b32 %s, %%[msz]" % s(S_MRS + 2))
+        st.raw("s_mov_b32 %s, 0x00020000" % s(S_MRS + 3))
+        st.raw("s_mov_b32 %s, %%[lqp4]" % s(S_LQP4))
+        st.raw("v_lshrrev_b32_e32 %s, 7, %s" % (v(MOFF), v(QOFF)))             # (the Q loads are out: QOFF becomes 4 * query row)
+        st.raw("v_lshlrev_b32_e32 %s, 2, %s" % (v(MOFF), v(MOFF)))
     st.raw("s_mov_b32 %s, %s" % (s(S_CRS + 2), s(S_CSIZE)))
     st.raw("s_sub_u32 %s, %s, 0x10000" % (s(S_KDST), s(S_KDST)))          # (biased: the M0 sums add it back; keeps every immediate positive)
     st.raw("s_add_u32 %s, %s, 0x8000" % (s(S_VDST), s(S_KDST)))
@@ -459,6 +505,14 @@ def build(drop):
         st.raw("s_mov_b32 %s, 0x%x" % (s(S_TMP), tile * 8192))
         for piece in range(8 // NW if not (ABL & 1024) else 0):
             emit_dma_now(st, S_KRS if which == "K" else S_VRS, S_TMP, S_KDST if which == "K" else S_VDST, tile * 8192 + piece * 1024, piece)
+    if DROP:
+        st.raw("s_mov_b32 %s, 0" % s(S_M0))
+        st.raw("s_mov_b32 %s, %s" % (s(S_M1), s(S_LQP4)))
+        st.raw("s_nop 2")
+        emit_mask_loads(st, "A")
+        emit_mask_loads(st, "B")
+        st.raw("s_lshl_b32 %s, %s, 1" % (s(S_M0), s(S_LQP4)))             # next: tile 1's words (key groups 2 and 3)
+        st.raw("s_add_u32 %s, %s, %s" % (s(S_M1), s(S_M0), s(S_LQP4)))
     st.raw("s_mov_b32 %s, 0x%x" % (s(S_KSOFF), 3 * 8192))             # the requests of step 0: K(3), V(2)
     st.raw("s_mov_b32 %s, 0x%x" % (s(S_VSOFF), 2 * 8192))
     st.comment("---- state: O = 0, l = 0, mref = 0, P of block B = 0, V ring slot 3 = 0 (the first phase multiplies it by that P)")
@@ -473,10 +527,10 @@ def build(drop):
     for piece in range(8 // NW):
         st.raw("ds_write_b128 %s, %s offset:%d" % (v(TC), v(T, 4), 3 * 8192 + piece * 1024))
     st.comment("---- Q into the accumulator file (B operands of every K.Q^T)")
-    st.raw("s_waitcnt vmcnt(%d)" % (5 * (8 // NW) if not (ABL & 1536) else 0))
+    st.raw("s_waitcnt vmcnt(%d)" % ((5 * (8 // NW) if not (ABL & 1536) else 0) + (4 if DROP else 0)))
     for i in range(32):
         st.raw("v_accvgpr_write_b32 %s, %s" % (a(QA + i), v(SA + i)))
-    st.raw("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (4 * (8 // NW) if not (ABL & 1536) else 0))        # K0 landed (V0 K1 V1 K2 may be in flight); the zero fill is in LDS
+    st.raw("s_waitcnt vmcnt(%d) lgkmcnt(0)" % ((4 * (8 // NW) if not (ABL & 1536) else 0) + (4 if DROP else 0)))        # K0 landed (V0 K1 V1 K2 may be in flight); the zero fill is in LDS
     st.raw("s_barrier")
     st.raw("s_cmp_eq_u32 %s, 0" % s(S_NT))
     st.raw("s_cbranch_scc1 .Lfinal_" + U)
@@ -511,7 +565,7 @@ def build(drop):
         for u in range(4):
             st.comment("==== step t, t & 3 == %d" % u)
             if not (ABL & 16):
-                st.raw("s_waitcnt vmcnt(%d)" % (2 * (8 // NW)), kind="wait")      # K(t+1) and V(t) have landed: everything but the previous step's four requests
+                st.raw("s_waitcnt vmcnt(%d)" % (2 if DROP else 2 * (8 // NW)), kind="wait")      # (dropout: all but block B's two mask words) K(t+1) and V(t) have landed: everything but the previous step's four requests
                 st.raw("s_barrier", kind="salu")
             emit_phase(st, "A", "B", u, "a%d" % u)
             emit_phase(st, "B", "A", u, "b%d" % u)
@@ -519,6 +573,9 @@ def build(drop):
             st.raw("s_add_u32 %s, %s, 0x2000" % (s(S_KSOFF), s(S_KSOFF)), kind="salu")
             st.raw("s_add_u32 %s, %s, 0x2000" % (s(S_VSOFF), s(S_VSOFF)), kind="salu")
             st.raw("s_sub_u32 %s, %s, 64" % (s(S_REM), s(S_REM)), kind="salu")
+            if DROP:
+                st.raw("s_lshl1_add_u32 %s, %s, %s" % (s(S_M0), s(S_LQP4), s(S_M0)), kind="salu")
+                st.raw("s_lshl1_add_u32 %s, %s, %s" % (s(S_M1), s(S_LQP4), s(S_M1)), kind="salu")
             st.raw("s_cmp_eq_u32 %s, %s" % (s(S_T), s(S_MASKT)), kind="salu")
             st.raw("s_cselect_b32 %s, 1, %s" % (s(S_SPECIAL), s(S_CEN)), kind="salu")
             st.raw("s_cmp_lt_u32 %s, %s" % (s(S_T), s(S_NT)), kind="salu")
@@ -616,7 +673,7 @@ def build(drop):
 
 
 def main():
-    global ABL, NW, DMA_AT
+    global ABL, NW, DMA_AT, DROP
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(os.path.dirname(here), "end-to-end_asr_pytorch_amd", "csrc", "attention_fwd4_asm.inc")
     args = sys.argv[1:]
@@ -632,7 +689,8 @@ def main():
         f.write("// generated by tools/gen_attn_fwd4.py - do not edit (edit the generator and run it again)\n")
         for nw in (2, 4):
             NW = nw
-            for drop in (False,):
+            for drop in (False, True):
+                DROP = drop
                 st, counts, nops = build(drop)
                 f.write("#define ATTN4_ASM_%s_NW%d \\\n" % ("TRAIN" if drop else "EVAL", nw))
                 for line in st.out:
