@@ -95,3 +95,13 @@ def test_dropout_keys_match_the_oracle_restatement():
     for seed, name, call in ((0, "encoder.dropout", 1), (606, "decoder.layer_stack.1.enc_attn.attention.dropout", 3), (2**63 + 5, "x", 10**6)):
         assert asr_amd.dropout_site_keys(seed, name, call) == O.dropout_site_keys(seed, name, call)
     assert asr_amd.dropout_thr16(0.1) == 6554 and asr_amd.dropout_thr16(0.0) == 0
+
+
+def test_generated_attention_stream_is_current():
+    """csrc/attention_fwd4_asm.inc is the output of tools/gen_attn_fwd4.py: an edit of one without the other must not go unnoticed."""
+    import subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "x.inc")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "gen_attn_fwd4.py"), "--out", out], check=True, stderr=subprocess.DEVNULL)
+        assert open(out).read() == open(os.path.join(root, "end-to-end_asr_pytorch_amd", "csrc", "attention_fwd4_asm.inc")).read()
