@@ -35,6 +35,7 @@ SIGNATURES = {
     "asr_attention_bwd_dq": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr, _vp],
     "asr_attention_bwd_dkv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _dr, _vp],
     "asr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _i, _f, _dr, _vp],
+    "asr_attention_bwd_workspace_floats": [_i, _i, _i],
     "asr_attention_dropmask": [_vp, _dr, _i, _i, _i, _i, _vp],
     "asr_attention_dropmask_multi": [_vp, _i, _vp, _vp, _i, _i, _i, _i],
     "asr_gemm_add_layernorm_small": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr],
@@ -190,6 +191,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         L.asr_attention_dropmask_words.restype = ctypes.c_int64
+        L.asr_attention_bwd_workspace_floats.restype = ctypes.c_int64
         L.asr_ffn_bits_words.restype = ctypes.c_int64
         L.asr_gemm_tn_ws_bytes.restype = ctypes.c_int64
         L.asr_ctc_counter_words.restype = ctypes.c_int64

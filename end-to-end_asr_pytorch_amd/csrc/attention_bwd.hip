@@ -19,6 +19,7 @@
 
 namespace {
 constexpr float LN2F = 0.6931471805599453f;
+__host__ __device__ __forceinline__ int bwd_pad64(int n) { return (n + 63) & ~63; }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
     bf16x8 r;
@@ -131,7 +132,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const bf16_t* _
     }
     dl += __shfl_xor(dl, 32, 64);
     const float my_lse2 = qok ? lse[(int64_t)bh * Lq + qrow] : 0.f;   // base-2, like the scores (q carries log2(e)/sqrt(d_k))
-    if (qok && hh == 0 && kh == 0) delta[(int64_t)bh * Lq + qrow] = dl;
+    // the per-row scalars the dK / dV kernel starts its accumulators from, NEGATED and padded to whole 64-query tiles (asr_hip.h):
+    // [0] -delta (0 in the padding), [1] -lse (-inf in the padding: a padded query's probability is exactly 0)
+    {
+        const int lqp = bwd_pad64(Lq);
+        float* nd = delta + (int64_t)bh * lqp;
+        float* nl = delta + ((int64_t)(gridDim.x / q_tiles) + bh) * lqp;
+        if (hh == 0 && kh == 0 && qrow < lqp) {
+            nd[qrow] = qok ? -dl : 0.f;
+            nl[qrow] = qok ? -my_lse2 : -INFINITY;
+        }
+        if (hh == 0 && kh == 0 && qt == q_tiles - 1)         // (a grid of 32-row tiles can end short of the 64-row padding)
+            for (int qq = qrow + QB; qq < lqp; qq += QB) { nd[qq] = 0.f; nl[qq] = -INFINITY; }
+    }
 
     f32x16 a0 = zero16(), a1 = zero16();
     f32x16 neglse, zeros = zero16();
@@ -277,14 +290,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const int q0 = t * 64;
         dma_tile<2>(smem + buf * 16384, Qb, 64, q0, Lq, wave, lane);
         dma_tile<2>(smem + buf * 16384 + 8192, dOb, ldo, q0, Lq, wave, lane);
-        // per-row scalars of the tile: waves 0 / 1 DMA 64 floats of lse / delta (4 bytes per lane), rows clamped
+        // per-row scalars of the tile: waves 0 / 1 DMA 64 floats of -lse / -delta (4 bytes per lane; padded to whole tiles by the dQ kernel)
         float* sc = reinterpret_cast<float*>(smem + 32768) + buf * 128;
-        const int q = min(q0 + lane, Lq - 1);
+        const int lqp = bwd_pad64(Lq);
+        const int q = q0 + lane;
         if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lse + (int64_t)bh * Lq + q),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + ((int64_t)(gridDim.x / k_tiles) + bh) * lqp + q),
                                              (__attribute__((address_space(3))) void*)sc, 4, 0, 0);
         else if (wave == 1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + (int64_t)bh * Lq + q),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(delta + (int64_t)bh * lqp + q),
                                              (__attribute__((address_space(3))) void*)(sc + 64), 4, 0, 0);
     };
     if (qt_first < nqt) stage(0, qt_first);
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + hf * 32 + 8 * g + 4 * hh);   // base-2
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sq[hf][4 * g + i] = -l4[i];
+                    for (int i = 0; i < 4; ++i) sq[hf][4 * g + i] = l4[i];
                 }
             } else {
 #pragma unroll
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                     for (int i = 0; i < 4; ++i) {
                         const int q = q0 + ql + i;
                         const bool bad = !kok || q >= Lq || (CAUSAL && key > q);
-                        sq[hf][4 * g + i] = bad ? -INFINITY : -l4[i];
+                        sq[hf][4 * g + i] = bad ? -INFINITY : l4[i];
                     }
                 }
             }
@@ -357,10 +371,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                     const float p = __builtin_amdgcn_exp2f(sq[hf][4 * g + i]);
                     if (DROP) {
                         sq[hf][4 * g + i] = drop_and(p, wq[hf], 8 * g + i);              // the kept P (dropout's 1 / keep factor is applied to dV once, at the store)
-                        dp[hf][4 * g + i] = p * __builtin_fmaf(drop_and(dp[hf][4 * g + i], wq[hf], 8 * g + i), dsc, -d4[i]);     // dS
+                        dp[hf][4 * g + i] = p * __builtin_fmaf(drop_and(dp[hf][4 * g + i], wq[hf], 8 * g + i), dsc, d4[i]);     // dS
                     } else {
                         sq[hf][4 * g + i] = p;
-                        dp[hf][4 * g + i] = p * (dp[hf][4 * g + i] - d4[i]);
+                        dp[hf][4 * g + i] = p * (dp[hf][4 * g + i] + d4[i]);
                     }
                 }
             }
@@ -435,6 +449,8 @@ __global__ __launch_bounds__(256) void attn_bwd_f32_kernel(const float* __restri
 }
 
 }  // namespace
+
+extern "C" int64_t asr_attention_bwd_workspace_floats(int B, int h, int Lq) { return 2 * (int64_t)B * h * bwd_pad64(Lq); }
 
 extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                                     const float* lse, float* delta, void* dq, int64_t ldq, int B, int h, int Lq, int Lk,

@@ -958,7 +958,7 @@ def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out
         return
     assert q.dtype == torch.bfloat16 and ctx.is_contiguous() and d_ctx.is_contiguous() and d_ctx.dtype == torch.bfloat16
     assert dk_out.stride(0) == dv_out.stride(0) and dq_out.stride(1) == 1 and dk_out.stride(1) == 1
-    delta = torch.empty((B, h, Lq), device=q.device, dtype=torch.float32)
+    delta = torch.empty((int(lib().asr_attention_bwd_workspace_floats(B, h, Lq)),), device=q.device, dtype=torch.float32)
     if drop_bits is None:
         drop_bits = attention_dropmask(drop, B, h, Lq, Lk, q.device)
     # two kernels, timed separately (algorithmic FLOPs on the 5-product count 10*B*h*64*Lq*Lk: dq owns dQ + one of the two

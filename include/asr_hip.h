@@ -151,10 +151,12 @@ int asr_attention_dropmask(void* stream, asr_dropout_t drop, int B, int h, int L
 int asr_attention_dropmask_multi(void* stream, int n, const asr_dropout_t* drops, uint32_t* const* bits, int B, int h, int Lq, int Lk);
 
 /* Backward of asr_attention_fwd (bf16 only).  q,k,v as in the forward; o = the forward's ctx and d_o = its gradient, both
- * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 [B,h,Lq] workspace.  Outputs are token-major bf16:
+ * token-major bf16 [B,Lq,h*64]; lse from the forward.  delta: f32 workspace of asr_attention_bwd_workspace_floats(B, h, Lq) floats (the dQ
+ * kernel leaves -rowsum(dO o O) and -lse there, padded to whole 64-query tiles, for the dK / dV kernel).  Outputs are token-major bf16:
  * dq[(b*Lq+i)*ldq + head*64 + d] (gradient wrt the UNSCALED query times `scale` = 1/sqrt(d_k), i.e. what the Q projection's
  * backward consumes; the log2(e) in q cancels against the base-2 softmax), dk / dv at
  * [(b*Lk+j)*ldkv + head*64 + d] - i.e. directly the A operands of the projection GEMMs' backward. */
+int64_t asr_attention_bwd_workspace_floats(int B, int h, int Lq);
 int asr_attention_bwd(void* stream, const void* q, const void* k, const void* v, const void* o, const void* d_o,
                       const float* lse, float* delta, void* dq, int64_t ldq, void* dk, void* dv, int64_t ldkv, int B, int h,
                       int Lq, int Lk, const int32_t* k_len, int causal, float scale, asr_dropout_t drop, const uint32_t* drop_bits);
