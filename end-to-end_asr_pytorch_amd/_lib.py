@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
-SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
+SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "attention_bwd4.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
            "backward.hip", "wgrad.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
@@ -149,7 +149,8 @@ def existing_sources():
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -shared -fPIC csrc/*.hip -o csrc/libasr_hip.so (rebuilt only when stale)."""
     srcs = [os.path.join(CSRC, s) for s in existing_sources()]
-    deps = srcs + [os.path.join(CSRC, "asr_common.h"), HEADER]
+    incs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc"))     # generated instruction streams (tools/gen_attn_*.py)
+    deps = srcs + incs + [os.path.join(CSRC, "asr_common.h"), HEADER]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     objs = []
@@ -159,7 +160,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(CSRC, "build", os.path.basename(s) + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(
-                os.path.getmtime(o) >= os.path.getmtime(d) for d in (s, deps[-2], deps[-1])):
+                os.path.getmtime(o) >= os.path.getmtime(d) for d in [s, deps[-2], deps[-1]] + incs):
             continue
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(s), []) + \
             os.environ.get("ASR_AMD_EXTRA_HIPCC_FLAGS", "").split() + ["-c", s, "-o", o]      # (diagnostic builds: -DHEADS_ABLATE, -DFFN_STAMP ...)

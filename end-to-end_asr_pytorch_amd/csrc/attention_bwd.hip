@@ -495,6 +495,7 @@ extern "C" int asr_attention_bwd_dkv(void* stream, const void* q, const void* k,
                     asr_aligned(dv, 8) && ldkv % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dkv: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *dO = (const bf16_t*)d_o;
+    if (!causal && asr_attention_bwd_dkv_v4(s, q, k, v, d_o, delta, dk, dv, ldkv, B, h, Lq, Lk, k_len, drop, drop_bits) == 0) return 0;
     const int k_tiles = (Lk + 127) / 128;
 #define LAUNCH_DKV(C, D)                                                                                                         \
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<C, D>), dim3(B * h * k_tiles), dim3(256), 0, s, Q, K, V, dO, lse, delta, (bf16_t*)dk, \
