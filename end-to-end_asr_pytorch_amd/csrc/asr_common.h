@@ -29,6 +29,9 @@ int asr_attention_fwd_v4(hipStream_t s, const void* q, const void* k, const void
 int asr_attention_bwd_dkv_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* d_o, const float* nscal, void* dk,
                              void* dv, int64_t ldkv, int B, int h, int Lq, int Lk, const int32_t* k_len, asr_dropout_t drop,
                              const uint32_t* drop_bits);     // attention_bwd4.hip: 0 = launched, -2 = not its case
+int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                            float* nscal, void* dq, int64_t ldq, int B, int h, int Lq, int Lk, const int32_t* k_len, float scale,
+                            asr_dropout_t drop, const uint32_t* drop_bits);
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
     do {                                  \

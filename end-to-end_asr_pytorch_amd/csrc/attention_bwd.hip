@@ -462,6 +462,7 @@ extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, 
     ASR_REQUIRE(asr_aligned(q, 16) && asr_aligned(k, 16) && asr_aligned(v, 16) && asr_aligned(o, 16) && asr_aligned(d_o, 16) &&
                     asr_aligned(dq, 8) && ldq % 4 == 0, ASR_ERR_ALIGN, "attention_bwd_dq: alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!causal && asr_attention_bwd_dq_v4(s, q, k, v, o, d_o, lse, delta, dq, ldq, B, h, Lq, Lk, k_len, scale, drop, drop_bits) == 0) return 0;
     const bf16_t *Q = (const bf16_t*)q, *K = (const bf16_t*)k, *V = (const bf16_t*)v, *O = (const bf16_t*)o, *dO = (const bf16_t*)d_o;
 #define LAUNCH_DQ2(NW, C, D, KS)                                                                                          \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, C, D, KS>), dim3(B * h * q_tiles), dim3(NW * 64), 0, s, Q, K, V, O, dO, lse, delta, \

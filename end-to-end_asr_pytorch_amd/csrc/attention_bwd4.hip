@@ -84,14 +84,105 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_v4_kernel(const bf16_t* _
 #undef ATTN_BWD_OPERANDS
 }
 
+#include "attention_bwd_dq_asm.inc"
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_v4_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ O,
+                                                                const bf16_t* __restrict__ dO, const float* __restrict__ lse,
+                                                                float* __restrict__ nscal, bf16_t* __restrict__ dq_out, int64_t ldq, int h,
+                                                                int Lq, int Lk, const int32_t* __restrict__ k_len, int q_tiles, float scale,
+                                                                float dscale, const uint32_t* __restrict__ drop_bits) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 16384];   // ring of 4 slots: K tile 8192 | V tile 8192
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    int qt, bh;
+    const int BH = gridDim.x / q_tiles;
+    if ((BH & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        bh = (slot / q_tiles) * 8 + xcd;
+        qt = slot % q_tiles;
+    } else {
+        qt = blockIdx.x % q_tiles;
+        bh = blockIdx.x / q_tiles;
+    }
+    const int b = bh / h, hd = bh - b * h;
+    const int kl = k_len ? min(k_len[b], Lk) : Lk;
+    const int row0 = qt * 128 + wave * 32;
+    const unsigned smem0 = lds_addr_of(smem);
+    const unsigned h128 = (unsigned)h * 128u;
+    unsigned voff[2], rb[4], tb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave * 2 + i) + (lane >> 3);
+        voff[i] = (unsigned)row * 128u + (unsigned)(((lane & 7) ^ swz2(row)) << 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rb[s] = smem0 + (unsigned)(r * 128 + (((2 * s + hh) ^ swz2(r)) << 4));
+    {
+        const int i16 = lane & 15, g16 = lane >> 4;
+        const int kb = 4 * hh + (i16 >> 2);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = cb * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+            const int c = col >> 3, sub = (col & 7) * 2;
+            tb[2 * cb] = smem0 + (unsigned)(kb * 128 + ((c ^ swz2(kb)) << 4) + sub);
+            tb[2 * cb + 1] = smem0 + (unsigned)((kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub);
+        }
+    }
+    const unsigned vo = voff[0] | (voff[1] << 16), rb01 = rb[0] | (rb[1] << 16), rb23 = rb[2] | (rb[3] << 16);
+    const unsigned tb01 = tb[0] | (tb[1] << 16), tb23 = tb[2] | (tb[3] << 16);
+    const unsigned qoff = (unsigned)(row0 + r) * 128u + 16u * hh, tokoff = (unsigned)(row0 + r) * h128 + 16u * hh;
+    const int lqp = bwd_pad64(Lq);
+    const uint64_t kbp = (uint64_t)(K + (int64_t)bh * Lk * 64), vbp = (uint64_t)(V + (int64_t)bh * Lk * 64);
+    const uint64_t qbp = (uint64_t)(Q + (int64_t)bh * Lq * 64);
+    const uint64_t dobp = (uint64_t)(dO + ((int64_t)b * Lq * h + hd) * 64), obp = (uint64_t)(O + ((int64_t)b * Lq * h + hd) * 64);
+    const uint64_t lbp = (uint64_t)(lse + (int64_t)bh * Lq), wbp = (uint64_t)(nscal + (int64_t)bh * lqp);
+    const uint64_t dqbp = (uint64_t)(dq_out + (int64_t)b * Lq * ldq + hd * 64);
+    const unsigned nloff = (unsigned)BH * (unsigned)lqp * 4u, ldq2 = (unsigned)ldq * 2u;
+    const unsigned dsc = __builtin_bit_cast(unsigned, dscale), scl = __builtin_bit_cast(unsigned, scale);
+    const int lqp128 = drop_pad128(Lq);
+    const uint64_t mkbp = (uint64_t)(DROP ? drop_bits + (int64_t)bh * (drop_pad128(Lk) / 32) * lqp128 : nullptr);
+    const unsigned msz = DROP ? (unsigned)(drop_pad128(Lk) / 32) * (unsigned)lqp128 * 4u : 0u, lqp4 = (unsigned)lqp128 * 4u;
+#define ATTN_BWD_DQ_OPERANDS                                                                                                             \
+    [voff] "v"(vo), [rb01] "v"(rb01), [rb23] "v"(rb23), [tb01] "v"(tb01), [tb23] "v"(tb23), [qoff] "v"(qoff), [tokoff] "v"(tokoff),        \
+        [kb] "s"(kbp), [vb] "s"(vbp), [qb] "s"(qbp), [dob] "s"(dobp), [ob] "s"(obp), [lb] "s"(lbp), [wb] "s"(wbp), [dqb] "s"(dqbp),        \
+        [kl] "s"(kl), [lq] "s"(Lq), [h128] "s"(h128), [ldq2] "s"(ldq2), [dsc] "s"(dsc), [scale] "s"(scl), [row0] "s"(row0),                \
+        [nloff] "s"(nloff), [wave] "s"(wave), [smem0] "s"(smem0), [mkb] "s"(mkbp), [msz] "s"(msz), [lqp4] "s"(lqp4)
+    if constexpr (DROP) asm volatile(ATTN_BWD_DQ_ASM_TRAIN : : ATTN_BWD_DQ_OPERANDS : ATTN_BWD_DQ_ASM_CLOBBERS);
+    else asm volatile(ATTN_BWD_DQ_ASM_EVAL : : ATTN_BWD_DQ_OPERANDS : ATTN_BWD_DQ_ASM_CLOBBERS);
+#undef ATTN_BWD_DQ_OPERANDS
+}
+
 }  // namespace
+
+// 0 = launched, -2 = not this kernel's case.  nscal: the backward's workspace (asr_attention_bwd_workspace_floats), filled here
+int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                            float* nscal, void* dq, int64_t ldq, int B, int h, int Lq, int Lk, const int32_t* k_len, float scale,
+                            asr_dropout_t drop, const uint32_t* drop_bits) {
+    static const int on = getenv("ASR_AMD_ATTN_BWD_V4") ? atoi(getenv("ASR_AMD_ATTN_BWD_V4")) : 3;     // bit 0: dK / dV, bit 1: dQ
+    if (!(on & 2) || Lq < 128) return -2;
+    const int q_tiles = (Lq + 127) / 128;
+    const float dsc = drop.thr16 ? 65536.f / (float)(65536u - drop.thr16) : 1.f;
+    if (drop.thr16)
+        hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<true>), dim3(B * h * q_tiles), dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o, lse, nscal, (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles,
+                           scale, dsc, drop_bits);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_v4_kernel<false>), dim3(B * h * q_tiles), dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o, lse, nscal, (bf16_t*)dq, ldq, h, Lq, Lk, k_len, q_tiles,
+                           scale, dsc, drop_bits);
+    ASR_LAUNCH_CHECK("attention_bwd_dq_v4");
+    return 0;
+}
 
 // 0 = launched, -2 = not this kernel's case.  nscal: the workspace the dQ kernel filled (-delta, -lse; padded to whole 64-query tiles)
 int asr_attention_bwd_dkv_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* d_o, const float* nscal, void* dk,
                              void* dv, int64_t ldkv, int B, int h, int Lq, int Lk, const int32_t* k_len, asr_dropout_t drop,
                              const uint32_t* drop_bits) {
-    static const int on = getenv("ASR_AMD_ATTN_BWD_V4") ? atoi(getenv("ASR_AMD_ATTN_BWD_V4")) : 1;
-    if (!on || Lq < 128 || (uint64_t)h * 128u * 64u > 0xffffu * 64u) return -2;
+    static const int on = getenv("ASR_AMD_ATTN_BWD_V4") ? atoi(getenv("ASR_AMD_ATTN_BWD_V4")) : 3;     // bit 0: dK / dV, bit 1: dQ
+    if (!(on & 1) || Lq < 128) return -2;
     const int k_tiles = (Lk + 127) / 128;
     const float dsc = drop.thr16 ? 65536.f / (float)(65536u - drop.thr16) : 1.f;
     if (drop.thr16)

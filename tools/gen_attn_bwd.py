@@ -32,8 +32,8 @@ T = 80                                # 8 rotating temporaries
 RB, TB = 96, 100                      # LDS read addresses: row fragments per k-step; transposed fragments [d half][lo / hi]
 LSB = 104                             # -lse / -delta read address
 VOFFQ, VOFFD = 105, 107               # LDS-DMA source offsets of this lane's two pieces (Q rows of 128 bytes; dO rows of h * 128)
-WQA, WQB, SH4, TC, TD, MOFF, SMOFF, KFOFF = 109, 110, 111, 112, 113, 114, 115, 116
-E0 = 117                              # epilogue / scratch 117..127
+WQA, WQB, SH4, TC, TD, MOFF, SMOFF, KFOFF = 109, 110, 111, 112, 113, 114, 115, 116     # (WQA + 8, WQB + 8: the words of the next tile)
+E0 = 119                              # epilogue / scratch 119..127
 DK, DV, KFR, VFR, RF, TF = 0, 32, 64, 80, 96, 112      # AGPRs
 S_QRS, S_DORS, S_KRS, S_VRS, S_SMRS, S_DKRS, S_DVRS, S_MQRS = 36, 40, 44, 48, 52, 56, 60, 64
 S_T, S_NQT, S_KL, S_LQ, S_H128, S_LDKV, S_KDST, S_SDST = 68, 69, 70, 71, 72, 73, 74, 75
@@ -129,11 +129,13 @@ def emit_exp(st, X, i):
     st.valu("v_exp_f32_e32 %s, %s" % (v(ta), v(x["S"] + i)), [x["S"] + i], [ta], kind="exp")
 
 
-def emit_elem(st, X, i):
+def emit_elem(st, X, i, wq=None):
     """P and dS of element i (its exp was issued a gap earlier); on odd i the pair is packed in place."""
     if ABL & 2:
         return
-    x = half(X)
+    x = dict(half(X))
+    if wq is not None:
+        x["WQ"] = wq
     ta, tb = T + (2 * i) % 8, T + (2 * i + 1) % 8
     dp = x["DP"] + i
     if DROP:
@@ -152,16 +154,21 @@ def emit_elem(st, X, i):
 
 def emit_phase(st, X, Y, u, uid):
     """vector port: half X of tile t -> (P, dS).  matrix pipe: out-products of half Y (tile t-1 for Y = B, t for Y = A), then S and dP of
-    half Y's next tile (t for Y = B, t+1 for Y = A).  u = t & 3."""
+    half Y's next tile (t for Y = B, t+1 for Y = A).  u = t & 3.  Phase B also carries this tile's five LDS-DMA requests, one every third gap
+    (issued in one burst behind the barrier they held the wave for ~100 cycles each)."""
     x, y = half(X), half(Y)
     st.comment("---- phase %s: (P, dS) of half %s | out-products and next (S, dP) of half %s" % (uid, X, Y))
     if X == "A":
         s_out, s_nxt, s_pre, s_db = (u + 3) & 3, u, u, u            # out-products of B(t-1); S/dP of B(t); next phase's fragments: A(t); delta of B(t)
     else:
         s_out, s_nxt, s_pre, s_db = u, (u + 1) & 3, u, (u + 1) & 3   # out-products of A(t); S/dP of A(t+1); next: B(t); delta of A(t+1)
-    if DROP:         # this half's keep bits (requested a step ahead): this lane's queries are bits 8 g + 4 hh + x
+    wq = x["WQ"] + 8 * (u & 1)            # the keep bits of this tile's half (two registers per half, alternating by tile)
+    if DROP:         # requested a step ahead; this lane's queries are bits 8 g + 4 hh + x; then the request of the next tile's word
         st.raw("s_waitcnt vmcnt(6)", kind="wait")
-        st.raw("v_lshrrev_b32_e32 %s, %s, %s" % (v(x["WQ"]), v(SH4), v(x["WQ"])), kind="drop")
+        st.raw("v_lshrrev_b32_e32 %s, %s, %s" % (v(wq), v(SH4), v(wq)), kind="drop")
+        st.raw("buffer_load_dword %s, %s, %s, %s offen" % (v(x["WQ"] + 8 * ((u + 1) & 1)), v(MOFF), s(S_MQRS, 4), s(S_MQOFF)), kind="mload")
+        st.raw("s_add_u32 %s, %s, %s" % (s(S_MQOFF), s(S_MQOFF), s(S_LKP4)), kind="salu")
+    dma_at = {2: 0, 5: 1, 8: 2, 11: 3, 14: 4} if (X == "B" and not (ABL & 8)) else {}
     for gap in range(16):
         if gap < 8:
             emit_outprod(st, Y, gap)
@@ -180,33 +187,54 @@ def emit_phase(st, X, Y, u, uid):
                 emit_cinit_read(st, Y, wh, g, s_nxt * SLOT)
         if DROP and gap in (5, 9, 13):                                # -delta of the half the vector port takes NEXT (its registers free up in groups)
             emit_db_read(st, Y, (gap - 5) // 4, s_db * SLOT)
+        if gap in dma_at:
+            emit_dma_m0(st, dma_at[gap], ((u + 3) & 3) * SLOT)
         emit_exp(st, X, gap)
+        if gap in dma_at:
+            if ABL & 2:
+                st.raw("s_nop 0", kind="nop")
+            emit_dma_load(st, dma_at[gap])
         if gap >= 1:
-            emit_elem(st, X, gap - 1)
-    emit_elem(st, X, 15)
+            emit_elem(st, X, gap - 1, wq)
+    emit_elem(st, X, 15, wq)
     if DROP:
         emit_db_read(st, Y, 3, s_db * SLOT)
-        # the keep bits of this half's next tile
-        st.raw("buffer_load_dword %s, %s, %s, %s offen" % (v(x["WQ"]), v(MOFF), s(S_MQRS, 4), s(S_MQOFF)), kind="mload")
-        st.raw("s_add_u32 %s, %s, %s" % (s(S_MQOFF), s(S_MQOFF), s(S_LKP4)), kind="salu")
+    if dma_at:
+        emit_dma_advance(st)
 
 
-def emit_dma_group(st, u_slot_imm=None, dyn=None):
-    """one tile's requests of this wave: 2 Q pieces, 2 dO pieces, one 256-byte run of -lse or -delta."""
-    if ABL & 8:
-        return
-    for which, base, voff, soff, rs in ((0, S_KDST, VOFFQ, S_QSOFF, S_QRS), (1, S_KDST, VOFFD, S_DSOFF, S_DORS)):
-        for p in range(2):
-            st.raw("s_add_u32 m0, %s, 0x%x" % (s(base), u_slot_imm + 8192 * which + p * 1024 + 0x10000), kind="salu")
-            st.raw("s_nop 0", kind="nop")
-            st.raw("buffer_load_dwordx4 %s, %s, %s offen lds" % (v(voff + p), s(rs, 4), s(soff)), kind="dma")
-    st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_SDST), (u_slot_imm // SLOT) * SSLOT + 0x10000), kind="salu")
-    st.raw("s_nop 0", kind="nop")
-    st.raw("buffer_load_dword %s, %s, %s offen lds" % (v(SMOFF), s(S_SMRS, 4), s(S_SSOFF)), kind="dma")
+def emit_dma_m0(st, p, slot_imm):
+    """request p of a tile's five: Q pieces 0, 1; dO pieces 2, 3; 4 = the 256-byte run of -lse or -delta."""
+    if p < 4:
+        st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_KDST), slot_imm + 8192 * (p >> 1) + (p & 1) * 1024 + 0x10000), kind="salu")
+    else:
+        st.raw("s_add_u32 m0, %s, 0x%x" % (s(S_SDST), (slot_imm // SLOT) * SSLOT + 0x10000), kind="salu")
+
+
+def emit_dma_load(st, p):
+    if p < 4:
+        st.raw("buffer_load_dwordx4 %s, %s, %s offen lds" % (v((VOFFQ if p < 2 else VOFFD) + (p & 1)), s(S_QRS if p < 2 else S_DORS, 4),
+                                                              s(S_QSOFF if p < 2 else S_DSOFF)), kind="dma")
+    else:
+        st.raw("buffer_load_dword %s, %s, %s offen lds" % (v(SMOFF), s(S_SMRS, 4), s(S_SSOFF)), kind="dma")
+
+
+def emit_dma_advance(st):
     st.raw("s_add_u32 %s, %s, 0x2000" % (s(S_QSOFF), s(S_QSOFF)), kind="salu")
     st.raw("s_lshl_b32 %s, %s, 6" % (s(S_TMP), s(S_H128)), kind="salu")
     st.raw("s_add_u32 %s, %s, %s" % (s(S_DSOFF), s(S_DSOFF), s(S_TMP)), kind="salu")
     st.raw("s_add_u32 %s, %s, 0x100" % (s(S_SSOFF), s(S_SSOFF)), kind="salu")
+
+
+def emit_dma_group(st, u_slot_imm=None, dyn=None):
+    """one tile's requests of this wave in one go (prologue): 2 Q pieces, 2 dO pieces, one 256-byte run of -lse or -delta."""
+    if ABL & 8:
+        return
+    for p in range(5):
+        emit_dma_m0(st, p, u_slot_imm)
+        st.raw("s_nop 0", kind="nop")
+        emit_dma_load(st, p)
+    emit_dma_advance(st)
 
 
 def build(drop):
@@ -369,7 +397,6 @@ def build(drop):
             if not (ABL & 16):
                 st.raw("s_waitcnt vmcnt(%d)" % (5 + (2 if drop else 0)), kind="wait")     # tile t+1 has landed: everything but the last group (and 2 mask words)
                 st.raw("s_barrier", kind="salu")
-            emit_dma_group(st, u_slot_imm=((u + 3) & 3) * SLOT)                         # tile t+3 into the slot tile t-1 just left
             emit_phase(st, "B", "A", u, "b%d" % u)
             st.raw("s_add_u32 %s, %s, 1" % (s(S_T), s(S_T)), kind="salu")
             st.raw("s_cmp_lt_u32 %s, %s" % (s(S_T), s(S_NQT)), kind="salu")
