@@ -291,7 +291,14 @@ def oracle_parity(asr_amd, model, x, lens, tg, n_utt=2):
     was_training = model.training
     model.eval()
     with torch.no_grad():
-        if CFG["n_conv_layers"]:
+        if CFG.get("cif"):
+            # CIF_Model (cif_model.py:24-55) with a recorded noise vector; also the integrate-and-fire boundaries (north_star: "CIF firing
+            # boundaries"): the frames at which the accumulated weight crosses the threshold must be the oracle's, exactly
+            noise = torch.rand(n_utt, generator=torch.Generator().manual_seed(1))
+            cfg.update(n_assigner_layers=3, w_context=3)
+            ref_ctc, _, _, _, ref_logits, _, _, ref_fire = O.cif_model_forward(sd, xs, ls, ts, cfg, noise.numpy())
+            cl, _, _, _, lg = model(x[:n_utt], lens[:n_utt], tg[:n_utt], noise=noise.to(x.device))
+        elif CFG["n_conv_layers"]:
             ref_ctc, _, ref_logits = O.conv_ctc_transformer_forward(sd, xs, ls, ts, cfg)[:3]
             cl, _, lg, _ = model(x[:n_utt], lens[:n_utt], tg[:n_utt])
         else:

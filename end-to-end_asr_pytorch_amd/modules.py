@@ -1803,6 +1803,7 @@ def cif_forward(hidden, alphas, threshold, max_label_len=None):
 
 class CIF_Model(_Cached):
     """src/transformer/cif_model.py:8-106 — returns (ctc_logits, len, _num, num, logits)."""
+    draws_noise = True      # forward() draws torch.rand(B) when no noise is passed (cif_model.py:47): Trainer.step_graphed feeds it in from outside the graph
 
     def __init__(self, conv_encoder, encoder, assigner, decoder, spec_aug_cfg=None):
         super().__init__()

@@ -440,6 +440,11 @@ class Trainer:
         captured.  The returned (ctc, ce) tensors are the graph's own outputs: the next replay overwrites them."""
         if not self._graph_ok(feats, max_target_len):
             return self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+        if noise is None and getattr(self.model, "draws_noise", False):
+            # CIF_Model's per-utterance noise (cif_model.py:47) is drawn HERE, outside the graph, and fed in like the batch: a torch.rand
+            # inside the captured step replays with the capture-time generator state under the executor (torch's own replay advances
+            # the philox offset in its prologue, asr_graphx_launch does not) and every step would see the same vector
+            noise = torch.rand(feats.size(0), device=feats.device)
         # The graph holds raw pointers, so it is captured against buffers the trainer owns and every call copies its batch into them
         # (a loader hands out NEW tensors of the same shape each step: keyed on their addresses every call missed the key and
         # re-captured the whole step).  The key is what fixes the graph's shape: shapes / dtypes of every input, the longest target.

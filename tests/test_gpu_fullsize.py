@@ -142,7 +142,7 @@ def test_model_full_size_utterances_do_not_interact():
         assert torch.equal(d0[b], d1[b])
 
 
-@pytest.mark.parametrize("which", ["s1", "s2", "s1-fused-ffn"])
+@pytest.mark.parametrize("which", ["s1", "s2", "s1-fused-ffn", "cif"])
 def test_full_size_logits_match_the_oracle_on_two_utterances(which, monkeypatch):
     """The benchmark models at their full dimensions (d256/h4/enc12/dec6, V=4234, T=1000; S2 = with the conv front end, L=250)
     against the numpy oracle on 2 utterances of the benchmark batch - the check bench.py prints as `parity_vs_oracle_max_abs`,
@@ -153,7 +153,9 @@ def test_full_size_logits_match_the_oracle_on_two_utterances(which, monkeypatch)
     # 2 x 1000 rows through it as well, the other cases hold the two-GEMM + LayerNorm path
     monkeypatch.setattr(ops, "FUSED_FFN_MIN_ROWS", 1 if which.endswith("fused-ffn") else 1 << 30)
     try:
-        bench.CFG["n_conv_layers"] = 2 if which == "s2" else 0
+        bench.CFG["n_conv_layers"] = 2 if which in ("s2", "cif") else 0
+        if which == "cif":          # BASELINE configs[3] in-model: conv front end, 3-layer assigner, integrate-and-fire, Decoder_CIF (bench.py --model cif)
+            bench.CFG["cif"] = True
         asr_amd.set_precision("bf16")
         model = bench.build_model(asr_amd, torch.device(DEV), 0.1, train=False)
         x, lens, tg = bench.make_batch(torch.device(DEV), seed=0, ragged=True)

@@ -177,3 +177,29 @@ def test_graph_replay_takes_fresh_input_tensors(golden_dir):
     assert tg_.graph_active() and len(captures) == 1
     pe, pg = te.fp.flat.float().cpu().numpy(), tg_.fp.flat.float().cpu().numpy()
     assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 2e-3
+
+
+def test_cif_model_replays_draw_fresh_noise(golden_dir):
+    """the executor-launched graph skips torch's replay prologue, so a torch.rand INSIDE the captured step would repeat the
+    capture-time vector.  step_graphed draws CIF_Model's noise (cif_model.py:47) outside the graph and copies it in: replayed steps
+    with noise=None see a fresh vector each."""
+    import argparse
+    z = np.load(os.path.join(golden_dir, "g4_cif_model.npz"))
+    sd = make_state_dict(names_shapes_from_json(z["names_shapes"]), int(z["seed"]))
+    cfg = {k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")}
+    asr_amd.set_precision("bf16")
+    m = asr_amd.CIF_Model.create_model(argparse.Namespace(spec_aug_cfg=None, **cfg))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    m = m.to(DEV).train()
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    umax = int((tg != 0).sum(1).max())
+    tr = asr_amd.Trainer(m, k=0.2, warmup_steps=50, label_smoothing=0.1, lambda_qua=0.001)
+    seen = []
+    for _ in range(6):
+        tr.step_graphed(x, lens, tg, max_target_len=umax)
+        if tr.graph_active():
+            torch.cuda.synchronize()
+            seen.append(tr._graph_in[3].clone())
+    assert tr.graph_active() and len(seen) >= 3, tr._graph_failed
+    assert all(not torch.equal(seen[i], seen[i + 1]) for i in range(len(seen) - 1))
+    assert all(float(v.min()) >= 0.0 and float(v.max()) < 1.0 for v in seen)
