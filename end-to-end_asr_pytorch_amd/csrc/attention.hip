@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------
 // bf16 MFMA flash kernel
 // ---------------------------------------------------------------------------------------------------------
+// (timing ablations of these loops - which piece's removal buys how much - are round-3 history: git log, DESIGN / HISTORY.md)
 // ---- v2: LDS-DMA staging + hardware-transposed V reads -----------------------------------------------------------------------
 // K and V tiles are copied ROW-MAJOR ([64 keys][64 d], 128-byte rows) straight into a double-buffered LDS image by
 // global_load_lds_dwordx4 (no staging VGPRs, no register transposes, one barrier per tile, the next tile's DMA in flight during
@@ -86,17 +87,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // f(r) = (((r>>1)&1)<<2) | ((r>>2)&3): conflict-free for the ds_read_b128 row reads of QK^T (16 rows x one chunk) and for the
 // ds_read_b64_tr_b16 transposed reads of PV (4 consecutive keys x 64 bytes).  The DMA destination is lane-linear, so the swizzle is
 // applied to each lane's SOURCE chunk.  Keys past k_len are clamped to the last valid row (their probabilities are masked to 0).
-#ifndef ATTN_ABL
-#define ATTN_ABL 0      // diagnostic builds (tools/ablate_attn.sh): bit mask of pieces of the v2 forward loop left out
-#endif
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-#ifdef ATTN_STAMP
-// diagnostic build (tools/stamp_attn.py): per wave, cycle sums of the phases of the v3 forward's iterations
-__device__ unsigned long long* g_attn_stamps_dev = nullptr;
-#define ATTN_TS(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define ATTN_TS(x) do { } while (0)
-#endif
 __device__ __forceinline__ int swz2(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
 // KS = 2 / 4 (few queries, many keys: the decoder's cross attention, Lq = 51 against Lk = 1000): the NW waves are NW/KS query groups x
@@ -184,9 +175,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
             wk[0] = mkp[(int64_t)(2 * t) * lqp] >> (4 * hh);
             wk[1] = mkp[(int64_t)(2 * t + 1) * lqp] >> (4 * hh);
         }
-#if !(ATTN_ABL & 16)
         if (it + 1 < niter) stage(cur ^ 1, it + 1);
-#endif
         const unsigned char* Ks = smem + (cur * KS + kh) * 2 * 8192;
         const unsigned char* Vs = Ks + 8192;
         const int key0 = t * 64;
@@ -199,17 +188,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
                 const int row = hf * 32 + r;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-#if (ATTN_ABL & 8)
-                    const u32x4 kf = qf[s];
-#else
                     const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + row * 128 + (((2 * s + hh) ^ swz2(row)) << 4));
-#endif
-#if (ATTN_ABL & 1)
-                    st[hf][s] += __builtin_bit_cast(float, kf[0] & 0x3f800000u);
-#else
                     st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
                                                                      __builtin_bit_cast(bf16x8, qf[s]), st[hf], 0, 0, 0);
-#endif
                 }
             }
             const bool interior = (key0 + 64 <= kl) && (!CAUSAL || key0 + 63 <= q0 + wave * 32);
@@ -251,11 +232,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
             for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
-#if (ATTN_ABL & 4)
-                    const float p0 = st[hf][i] * 0.5f, p1 = st[hf][i + 1] * 0.5f;
-#else
                     const float p0 = __builtin_amdgcn_exp2f(st[hf][i]), p1 = __builtin_amdgcn_exp2f(st[hf][i + 1]);
-#endif
                     st[hf][i] = p0;
                     st[hf][i + 1] = p1;
                     rs2 += f32x2{p0, p1};
@@ -287,30 +264,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
                         const int c = col >> 3, sub = (col & 7) * 2;
                         const unsigned char* p0 = Vs + kb * 128 + ((c ^ swz2(kb)) << 4) + sub;
                         const unsigned char* p1 = Vs + (kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub;
-#if (ATTN_ABL & 8)
-                        (void)p0; (void)p1;
-                        const u32x4 vf = qf[dt];
-#else
                         const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
                         const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
                         const u32x2 a = __builtin_bit_cast(u32x2, v0), bb = __builtin_bit_cast(u32x2, v1);
                         const u32x4 vf = {a[0], a[1], bb[0], bb[1]};
-#endif
-#if (ATTN_ABL & 2)
-                        if (dt == 0) o0[hf * 2 + s2] += __builtin_bit_cast(float, vf[0] & 0x3f800000u) * (float)pf[0];
-                        else o1[hf * 2 + s2] += __builtin_bit_cast(float, vf[1] & 0x3f800000u) * (float)pf[1];
-#else
                         if (dt == 0)
                             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
                         else
                             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
-#endif
                     }
                 }
         }
-#if !(ATTN_ABL & 32)
         __syncthreads();   // next tile's DMA has landed (barrier fence drains vmcnt) and `cur` may be overwritten
-#endif
     }
 
     if (KS > 1) {   // merge the key streams: stream 1 parks its state in LDS (the operand tiles are dead), stream 0 folds it in
@@ -455,24 +420,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
-#if (ATTN_ABL & 8)
-                kf[hf][s] = qf[s];
-#else
                 kf[hf][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(kp[s] + hf * 4096);
-#endif
-#if !(ATTN_ABL & 64)
         __builtin_amdgcn_sched_barrier(0);
-#endif      // all 8 reads in flight before the first MFMA waits: one LDS round trip per tile, not four
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf)
-#if (ATTN_ABL & 1)
-                st[hf][s] = (s == 0 ? negm[s] : st[hf][s]) + __builtin_bit_cast(float, kf[hf][s][0] & 0x3f800000u);
-#else
                 st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[hf][s]), __builtin_bit_cast(bf16x8, qf[s]),
                                                                  s == 0 ? negm : st[hf], 0, 0, 0);
-#endif
     };
 
     f32x16 o0, o1, negm;
@@ -501,18 +456,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // iteration 0 requests K(3) into the slot these reads came from
 
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, acc_a = 0, acc_b = 0, acc_c = 0, acc_d = 0;
-    (void)ts0; (void)ts1; (void)ts2; (void)ts3; (void)ts4; (void)acc_a; (void)acc_b; (void)acc_c; (void)acc_d;
     auto body = [&](f32x16 (&st)[2], f32x16 (&sn)[2], int t) {
         const int s0 = t % 3, s1 = (t + 1) % 3, s2 = (t + 2) % 3;      // ring slots of tiles t (= t+3), t+1, t+2
-        ATTN_TS(ts0);
         if (DROP) mask_words(t + 1, wkn);
-#if !(ATTN_ABL & 16)
         stage(krs, t + 3, smem0 + s0 * 8192);
         stage(vrs, t + 2, smem0 + (3 + s2) * 8192);
-#endif
         scores(sn, negm, s1);       // (past the last tile: zeros / a dead slot, never looked at)
-        ATTN_TS(ts1);
         const lds_u8* vp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -528,17 +477,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int hi = 0; hi < 2; ++hi) {
-#if (ATTN_ABL & 8)
-                    const u32x2 v = {qf[g][hi], qf[dt][hi + 2]};
-#else
                     const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt + hi] + g * 2048)));
-#endif
                     vfr[g][dt][2 * hi] = v[0];
                     vfr[g][dt][2 * hi + 1] = v[1];
                 }
-#if !(ATTN_ABL & 64)
         __builtin_amdgcn_sched_barrier(0);
-#endif
         const int key0 = t * 64;
         float mloc = -INFINITY;
         if (key0 + 64 <= kl) {
@@ -590,7 +533,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[hf][i] = drop_and(st[hf][i], wk[hf], 8 * (i >> 2) + (i & 3));
         }
-        ATTN_TS(ts2);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -602,32 +544,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
                 for (int dt = 0; dt < 2; ++dt) {
                     const int g = 2 * hf + s2i;
                     const u32x4 vf = vfr[g][dt];
-#if (ATTN_ABL & 2)
-                    if (dt == 0) o0[g] += __builtin_bit_cast(float, (vf[0] ^ vf[2]) & 0x3f800000u) * (float)pf[0];
-                    else o1[g] += __builtin_bit_cast(float, (vf[1] ^ vf[3]) & 0x3f800000u) * (float)pf[1];
-#else
                     if (dt == 0)
                         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
                     else
                         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
-#endif
                 }
             }
-        ATTN_TS(ts3);
         // the requests of iteration t - 1 (K(t+2), V(t+1)) and the next mask words are older than this iteration's 2 * PIECES requests
-#if (ATTN_ABL & 16)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
-#else
         if (PIECES == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
         else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
-#endif
-#if !(ATTN_ABL & 32)
         __builtin_amdgcn_s_barrier();
-#endif
-        ATTN_TS(ts4);
-#ifdef ATTN_STAMP
-        acc_a += ts1 - ts0; acc_b += ts2 - ts1; acc_c += ts3 - ts2; acc_d += ts4 - ts3;
-#endif
         wk[0] = wkn[0] >> (4 * hh);
         wk[1] = wkn[1] >> (4 * hh);
     };
@@ -641,12 +567,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16
     }
     if (t < ntiles) body(sa, sb, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // out-of-range requests of the last iterations: nothing may land after the workgroup's LDS is released
-#ifdef ATTN_STAMP
-    if (g_attn_stamps_dev && lane == 0 && blockIdx.x < 1024) {
-        unsigned long long* o = g_attn_stamps_dev + (blockIdx.x * 4 + wave) * 4;
-        o[0] = acc_a; o[1] = acc_b; o[2] = acc_c; o[3] = acc_d;
-    }
-#endif
 
     l += __shfl_xor(l, 32, 64);
     if (qrow < Lq) {
@@ -745,10 +665,6 @@ template <int NW, int KS = 1> int launch_bf16(hipStream_t s, const void* q, cons
 
 }  // namespace
 
-#ifdef ATTN_STAMP
-// diagnostic hook of the -DATTN_STAMP build (tools/stamp_attn.py; not part of the product library or of include/asr_hip.h)
-extern "C" void asr_attn_debug_stamps(void* buf) { hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps_dev), &buf, sizeof(buf)); }
-#endif
 
 extern "C" int64_t asr_attention_dropmask_words(int B, int h, int Lq, int Lk) { return 2 * drop_mk_words(B * h, Lq, Lk); }
 

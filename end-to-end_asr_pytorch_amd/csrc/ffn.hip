@@ -24,9 +24,6 @@ namespace {
 #ifndef FFN_HID_POLICY
 #define FFN_HID_POLICY 0      // cache policy of the hidden-activation / hidden-gradient stores (A/B: 2 = non-temporal: forward 95 -> 89 us alone, the step unchanged)
 #endif
-#ifndef FFN_ABL
-#define FFN_ABL 0             // timing ablation of the forward loop (diagnostic builds only, wrong results): 1 no LDS-DMA, 2 no fragment reads, 4 no ReLU / mask / hidden stores, 8 no first-product MFMAs, 16 no second-product MFMAs
-#endif
 constexpr int FBM = 128;      // tokens per workgroup (4 waves x 32)
 constexpr int FHC = 64;       // hidden units per chunk
 constexpr int FD = 256;       // d_model
@@ -79,7 +76,6 @@ struct FfnFwdArgs {
     float eps;
     asr_dropout_t drop;
     int dbg;      // ASR_AMD_FFN_DBG (timing breakdowns only): 1 = no epilogue
-    unsigned long long* stamps;      // diagnostic build (-DFFN_STAMP) only: per wave 4 cycle sums (first product, second product, wait + barrier, total)
 };
 
 // PROJ: the attention sub-layer's tail at encoder size (attention.py:58-60: fc -> dropout -> + residual -> layer_norm) on the same
@@ -93,10 +89,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     float* const b1s = reinterpret_cast<float*>(smem + 2 * W1BUF + 2 * W2BUF + HST_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef FFN_STAMP
-    unsigned long long ts_entry;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_entry) :: "memory");
-#endif
     unsigned char* const hst = smem + 2 * W1BUF + 2 * W2BUF + wave * 4096;
     const int r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * FBM + wave * 32 + r;
@@ -221,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     do {                                                                                                           \
         /* the LDS-DMA of this iteration is older than its NST stores (vmcnt retires in order): wait for it only */ \
         /* (and every LDS read of the buffers the next iteration's DMA overwrites has returned) */                 \
-        if (TRAIN && !FFN_ABL) asm volatile("s_waitcnt vmcnt(" #NST ") lgkmcnt(0)" ::: "memory");                  \
+        if (TRAIN) asm volatile("s_waitcnt vmcnt(" #NST ") lgkmcnt(0)" ::: "memory");                  \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
         __builtin_amdgcn_s_barrier();                                                                              \
         asm volatile("" ::: "memory");                                                                             \
@@ -245,11 +237,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             FFN_STEP();
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                if (!(FFN_ABL & 8)) S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
-                if (FFN_ABL & 2) {
-                } else if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
+                S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
+                if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
                 else if (!FIRST) A[(k + 8) & 15] = frag2(w2, k + 8 - 32);
-                if (k < 16 && !(FFN_ABL & 1)) {
+                if (k < 16) {
                     if (k & 1) dma_w2(i & 1, i, k >> 1);
                     else dma_w1((i + 1) & 1, nxt, k >> 1);
                 }
@@ -264,18 +255,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             if constexpr (!FIRST) {
-                if (!(FFN_ABL & 16)) Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
-                if (k + 8 < 32 && !(FFN_ABL & 2)) A[(k + 8) & 15] = frag2(w2, k + 8);
+                Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
+                if (k + 8 < 32) A[(k + 8) & 15] = frag2(w2, k + 8);
             }
             if constexpr (!LAST) {
-                if (!(FFN_ABL & 4)) {
                 if ((k & 1) == 0) relu_pair(S, Hn, k >> 1);
                 else if (TRAIN) mask_pair(Hn, word, k >> 1);
                 if (TRAIN && !FIRST && (k & 7) == 0)       // chunk i - 1's tile (read back row-wise at steps 24..27): four full-line stores
                     __builtin_amdgcn_raw_buffer_store_b128(Hout[k >> 3], rsh, hoff[k >> 3], (i - 1) * (FHC * 2), FFN_HID_POLICY);
                 if (TRAIN && (k & 7) == 7)
                     *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 3) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 3];
-                }
             } else {
                 if (TRAIN && k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
                 if (TRAIN && k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), FFN_HID_POLICY);
@@ -285,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             FFN_STEP();
         }
         if constexpr (!LAST) {
-            if (TRAIN && !(FFN_ABL & 4)) __builtin_amdgcn_raw_buffer_store_b32(word, rsb, boff, i * (2 * a.Mp * 4), 0);
+            if (TRAIN) __builtin_amdgcn_raw_buffer_store_b32(word, rsb, boff, i * (2 * a.Mp * 4), 0);
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) Hf[sg] = Hn[sg];
         }
@@ -337,37 +326,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     } else {
     body(0, std::true_type{}, std::false_type{});
     FFN_WAIT_STAGE(1);
-#ifdef FFN_STAMP
-    unsigned long long t_body = 0, t_wait = 0, t0, t1, t2;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
-    const unsigned long long t_begin = t0;
-#endif
     for (int i = 1; i < NC; ++i) {
         body(i, std::false_type{}, std::false_type{});
-#ifdef FFN_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         FFN_WAIT_STAGE(5);
-#ifdef FFN_STAMP
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        t_body += t1 - t0; t_wait += t2 - t1; t0 = t2;
-#endif
     }
-#ifdef FFN_STAMP
-    const unsigned long long ts_loop_end = t0;
-#endif
     body(NC, std::false_type{}, std::true_type{});
     }
-#ifdef FFN_STAMP
-    unsigned long long ts_last;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_last) :: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
 #undef FFN_WAIT_STAGE
 #undef FFN_STEP
 
@@ -457,17 +421,6 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mean_l), rsm, o4, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rstd_l), rsr, o4, 0, 0);
     }
-#ifdef FFN_STAMP
-    unsigned long long ts_issued, ts_done;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_issued) :: "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_done) :: "memory");
-    if (a.stamps && lane == 0) {
-        unsigned long long* o = a.stamps + (blockIdx.x * 4 + wave) * 8;
-        o[0] = t_body; o[1] = t_wait; o[2] = t_begin - ts_entry; o[3] = ts_loop_end - t_begin; o[4] = ts_last - ts_loop_end;
-        o[5] = ts_issued - ts_last; o[6] = ts_done - ts_issued; o[7] = ts_entry;
-    }
-#endif
 }
 
 // ---- data gradient: dH^T = (W2c^T . ds^T) * mask, dX^T += W1c^T . dH^T -----------------------------------------------------------
@@ -902,27 +855,11 @@ int asr_proj_heads_rows(hipStream_t stream, const void* X, const void* W, const 
     HeadsArgs a{(const bf16_t*)X, (const bf16_t*)W, bias, (bf16_t*)out, (int)M64, L, h, n_proj * h, scale_first != 1.0f ? h : 0, (int)N64,
                 (long long)proj_stride, scale_first};
     const dim3 grid((unsigned)((M64 + FBM - 1) / FBM));
-#ifdef HEADS_ABLATE      // timing ablation build (tools/ablate_heads.sh): the loop with pieces left out, wrong results on purpose
-    const int abl = getenv("ASR_AMD_HEADS_ABL") ? atoi(getenv("ASR_AMD_HEADS_ABL")) : 0;
-    switch (abl) {
-#define HEADS_CASE(V) case V: hipLaunchKernelGGL(proj_heads_rows_kernel<V>, grid, dim3(256), 0, stream, a); break
-        HEADS_CASE(1); HEADS_CASE(2); HEADS_CASE(4); HEADS_CASE(8); HEADS_CASE(5); HEADS_CASE(6); HEADS_CASE(7); HEADS_CASE(15); HEADS_CASE(16); HEADS_CASE(32); HEADS_CASE(48);
-#undef HEADS_CASE
-        default: hipLaunchKernelGGL(proj_heads_rows_kernel<0>, grid, dim3(256), 0, stream, a);
-    }
-#else
     hipLaunchKernelGGL(proj_heads_rows_kernel<0>, grid, dim3(256), 0, stream, a);
-#endif
     ASR_LAUNCH_CHECK("asr_proj_heads(rows)");
     return 0;
 }
 
-static unsigned long long* g_ffn_stamps = nullptr;
-#ifdef FFN_STAMP
-// diagnostic hook of the -DFFN_STAMP build (tools/stamp_ffn.py; not part of the product library or of include/asr_hip.h): where the
-// forward's per-wave cycle stamps go
-extern "C" void asr_ffn_debug_stamps(void* buf) { g_ffn_stamps = (unsigned long long*)buf; }
-#endif
 
 extern "C" int64_t asr_ffn_bits_words(int M, int d_ff) { return (int64_t)(d_ff / FHC) * 2 * ((M + FBM - 1) / FBM * FBM); }
 
@@ -943,7 +880,7 @@ extern "C" int asr_ffn_fwd(void* stream, const void* x16, const float* x32, cons
     const int M = (int)M64;
     FfnFwdArgs a{(const bf16_t*)x16, x32, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gamma, beta, row_len, (bf16_t*)hid_out,
                  (uint32_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x,
-                 getenv("ASR_AMD_FFN_DBG") ? atoi(getenv("ASR_AMD_FFN_DBG")) : 0, g_ffn_stamps};
+                 getenv("ASR_AMD_FFN_DBG") ? atoi(getenv("ASR_AMD_FFN_DBG")) : 0};
     const dim3 grid((M + FBM - 1) / FBM), block(256);
     const bool dr = drop_x.thr16 != 0;
     if (hid_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
@@ -967,7 +904,7 @@ extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* res
                 "asr_proj_ln_fwd: 16-byte aligned buffers required");
     const int M = (int)M64;
     FfnFwdArgs a{(const bf16_t*)ctx16, residual, (const bf16_t*)w, nullptr, nullptr, bias, gamma, beta, row_len, nullptr, nullptr, s_out, y32,
-                 (bf16_t*)y16, mean_out, rstd_out, M, L, FD, (M + FBM - 1) / FBM * FBM, eps, drop_x, 0, nullptr};
+                 (bf16_t*)y16, mean_out, rstd_out, M, L, FD, (M + FBM - 1) / FBM * FBM, eps, drop_x, 0};
     const dim3 grid((M + FBM - 1) / FBM), block(256);
     const bool dr = drop_x.thr16 != 0;
     if (s_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, a);
