@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--model", default="s1", choices=["s1", "s2", "cif"],
+    ap.add_argument("--model", default="s1", choices=["s1", "s2", "cif", "aishell"],
                     help="s1: CTC_Transformer on raw fbank (BASELINE configs[1]); s2: Conv_CTC_Transformer (configs[2], L = T/4); cif: CIF_Model "
                          "(configs[3] in-model: conv front end, 3-layer assigner, integrate-and-fire, Decoder_CIF; --mode train only)")
     ap.add_argument("--mode", default="train", choices=["train", "fwd", "decode"],
@@ -94,14 +94,17 @@ def what_name(args, train):
 
 
 def model_name():
+    if CFG.get("aishell"):
+        return "AISHELL recipe width: CTC_Transformer on LFR-stacked fbank (LFR_m=4, LFR_n=3: 320-d frames, T=%d)" % CFG["T"]
     if CFG.get("cif"):
         return "S3-in-model: CIF_Model (2 conv layers, L=%d, 3-layer assigner, threshold 0.95, loss = 0.001 qua + ctc + ce)" % (CFG["T"] // 4)
     return ("S2: Conv_CTC_Transformer (2 conv layers, L=%d)" % (CFG["T"] // 4)) if CFG["n_conv_layers"] else "S1: CTC_Transformer"
 
 
 def workload_name(args, train):
-    return "%s d_model=256 h=4 d_inner=2048 enc12/dec6 V=4234, per-GPU B=32 x T=1000 x 80 fbank%s, U=50, %s" % (
-        model_name(), " (ragged lengths)" if args.ragged else "", what_name(args, train))
+    return "%s d_model=%d h=%d d_inner=%d enc%d/dec%d V=%d, per-GPU B=%d x T=%d x %d fbank%s, U=%d, %s" % (
+        model_name(), CFG["d_model"], CFG["n_head"], CFG["d_inner"], CFG["n_layers_enc"], CFG["n_layers_dec"], CFG["vocab_size"], CFG["B"],
+        CFG["T"], CFG["d_input"], " (ragged lengths)" if args.ragged else "", CFG["U"], what_name(args, train))
 
 
 def launch_name(args, graphed, trainer=None):
@@ -113,7 +116,7 @@ def launch_name(args, graphed, trainer=None):
 
 
 ALSO_LEGS = (("s2", ["--model", "s2", "--mode", "train"]), ("cif", ["--model", "cif", "--mode", "train"]),
-             ("decode_s1", ["--model", "s1", "--mode", "decode"]))
+             ("decode_s1", ["--model", "s1", "--mode", "decode"]), ("aishell", ["--model", "aishell", "--mode", "train"]))
 
 
 def run_also_legs(args):
@@ -354,6 +357,10 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     if args.model in ("s2", "cif"):
         CFG["n_conv_layers"] = 2
+    if args.model == "aishell":
+        # the width the reference ships (egs/aishell/recipes/transformer.sh:18-53: d_model 512, 8 heads, 6 + 6 layers, d_inner 2048, LFR 4 / 3
+        # stacking of 80-d fbank: 320-d frames at a third of the rate), same 32 x 1000 raw frames per GPU
+        CFG.update(aishell=True, d_model=512, n_head=8, n_layers_enc=6, n_layers_dec=6, d_input=320, T=334, raw_T=1000)    # (frames/s counts the 80-d frames)
     if args.model == "cif":
         CFG["cif"] = True
         args.beam = args.beam or 5
@@ -474,7 +481,7 @@ def main():
     # headline value above is measured without them; eager launches, one stream: per-op durations are then uncontended) ----
     if args.brief:
         if rank == 0:
-            frames = world * CFG["B"] * CFG["T"] * args.steps
+            frames = world * CFG["B"] * CFG.get("raw_T", CFG["T"]) * args.steps
             print(json.dumps({"metric": "fbank frames/sec", "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                               "losses_last_step": losses, "settle_ms": [round(v, 3) for v in settle],
@@ -493,7 +500,7 @@ def main():
     prof = ops.profile_stop()
 
     if rank == 0:
-        frames = world * CFG["B"] * CFG["T"] * args.steps
+        frames = world * CFG["B"] * CFG.get("raw_T", CFG["T"]) * args.steps
         kernels, fams = [], {}
         hbm_ops = ("add_layernorm", "ctc_loss", "ce_loss", "cif_", "adam")
         for name, r in prof.items():
@@ -577,7 +584,7 @@ def main():
             ctc_iso = e0.elapsed_time(e1) / 30
             del lg_
         result = {
-            "metric": "fbank frames/sec (%s d256 h4 enc12/dec6, %s)" % (mname.split(":")[1].strip().split(" ")[0], what),
+            "metric": "fbank frames/sec (%s d%d h%d enc%d/dec%d, %s)" % (mname.split(":")[1].strip().split(" ")[0], CFG["d_model"], CFG["n_head"], CFG["n_layers_enc"], CFG["n_layers_dec"], what),
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic", "rccl_ranks": rccl_ranks,
