@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
-SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "attention_bwd4.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
+SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "collective.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "attention_bwd4.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
            "backward.hip", "wgrad.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
@@ -46,6 +46,16 @@ SIGNATURES = {
     "asr_graphx_place_streams": [_vp, _vp, _i],
     "asr_graphx_info": [_vp, _vp, _vp, _vp, _vp],
     "asr_graphx_destroy": [_vp],
+    "asr_rccl_load": [ctypes.c_char_p],
+    "asr_rccl_version": [_vp],
+    "asr_rccl_unique_id": [_vp],
+    "asr_rccl_comm_create": [_vp, _i, _i, _vp],
+    "asr_rccl_comm_destroy": [_vp],
+    "asr_rccl_all_reduce_f32": [_vp, _vp, ctypes.c_longlong, _vp],
+    "asr_rccl_comm_check": [_vp],
+    "asr_collective_mark": [_vp, ctypes.c_longlong, _i, _vp],
+    "asr_graphx_set_collective": [_vp, _vp, _vp, _vp],
+    "asr_graphx_collectives": [_vp, _vp, _vp],
     "asr_ffn_bits_words": [_i, _i],
     "asr_ffn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _dr],
     "asr_proj_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr],

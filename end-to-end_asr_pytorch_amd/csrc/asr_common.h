@@ -32,6 +32,8 @@ int asr_attention_bwd_dkv_v4(hipStream_t s, const void* q, const void* k, const 
 int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                             float* nscal, void* dq, int64_t ldq, int B, int h, int Lq, int Lk, const int32_t* k_len, float scale,
                             asr_dropout_t drop, const uint32_t* drop_bits);
+// collective.hip: the function of the bucket-ready marker node (graph_exec.hip turns such a node into an all-reduce call) and the call
+const void* asr_collective_marker_func();
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
     do {                                  \

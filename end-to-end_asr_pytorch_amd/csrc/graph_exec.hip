@@ -30,6 +30,11 @@ struct XNode {
     int stream;                    // index into GraphX::streams (0 = the launch stream)
     std::vector<int> wait_events;  // events of cross-stream predecessors
     int record_event;              // event recorded after this node (-1: none)
+    // a bucket-ready marker (collective.hip): the launch loop queues the all-reduce of cbuf[0..ccount) on this node's stream instead
+    bool collective = false;
+    float* cbuf = nullptr;
+    long long ccount = 0;
+    int ctag = 0;
 };
 
 // Events between the executor's streams order work on ONE device: they need no system-scope fence.  A default HIP event performs one
@@ -47,7 +52,10 @@ struct GraphX {
     std::vector<hipEvent_t> events;
     std::vector<int> tail_event;   // per side stream: the event recorded after its last node (joined into stream 0 at the end)
     hipEvent_t begin = nullptr;
-    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_other = 0;
+    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_other = 0, n_collective = 0;
+    void* comm = nullptr;          // RCCL communicator of the collective nodes (asr_graphx_set_collective)
+    asr_collective_fn coll_fn = nullptr;   // ... or the caller's own all-reduce (a test rig's gloo ranks sharing one GPU)
+    void* coll_ctx = nullptr;
     int rotation = 0;              // logical side stream i -> physical side stream (i + rotation) mod n (asr_graphx_set_rotation)
     std::vector<int> map;          // explicit logical -> physical side-stream map (asr_graphx_place_streams); empty: the rotation
 };
@@ -202,6 +210,13 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
                 return -3;
             }
             g->n_kernel++;
+            if (x.k.func == asr_collective_marker_func()) {      // values, not pointers into the node: the block is the graph's
+                x.collective = true;
+                x.cbuf = *static_cast<float**>(x.k.kernelParams[0]);
+                x.ccount = *static_cast<long long*>(x.k.kernelParams[1]);
+                x.ctag = *static_cast<int*>(x.k.kernelParams[2]);
+                g->n_collective++;
+            }
         } else if (x.type == hipGraphNodeTypeMemset) {
             GX_CHECK(hipGraphMemsetNodeGetParams(sorted_raw[u], &x.ms));
             g->n_memset++;
@@ -306,6 +321,26 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
     return 0;
 }
 
+extern "C" int asr_graphx_set_collective(void* handle, void* rccl_comm, asr_collective_fn fn, void* ctx) {
+    GraphX* g = static_cast<GraphX*>(handle);
+    ASR_REQUIRE(g, -1, "graphx_set_collective: null handle");
+    g->comm = rccl_comm;
+    g->coll_fn = fn;
+    g->coll_ctx = ctx;
+    return 0;
+}
+
+extern "C" int asr_graphx_collectives(void* handle, int* n_collective, long long* total_count) {
+    GraphX* g = static_cast<GraphX*>(handle);
+    ASR_REQUIRE(g, -1, "graphx_collectives: null handle");
+    long long tot = 0;
+    for (const XNode& x : g->nodes)
+        if (x.collective) tot += x.ccount;
+    if (n_collective) *n_collective = g->n_collective;
+    if (total_count) *total_count = tot;
+    return 0;
+}
+
 extern "C" int asr_graphx_info(void* handle, int* n_nodes, int* n_kernels, int* n_streams, int* n_events) {
     GraphX* g = static_cast<GraphX*>(handle);
     ASR_REQUIRE(g, -1, "graphx_info: null handle");
@@ -395,6 +430,18 @@ extern "C" int asr_graphx_launch(void* handle, void* stream) {
         for (int e : x.wait_events) GX_CHECK(hipStreamWaitEvent(st, g->events[e], 0));
         switch (x.type) {
             case hipGraphNodeTypeKernel:
+                if (x.collective) {
+                    // the bucket's gradients are final in this stream's order (the waits above): sum them over the ranks right here
+                    int rc;
+                    if (g->coll_fn) rc = g->coll_fn(g->coll_ctx, x.cbuf, x.ccount, x.ctag, st);
+                    else {
+                        ASR_REQUIRE(g->comm, -5, "graphx_launch: the step holds %d gradient all-reduce node(s) and no communicator "
+                                                 "(asr_graphx_set_collective)", g->n_collective);
+                        rc = asr_rccl_all_reduce_f32(g->comm, x.cbuf, x.ccount, st);
+                    }
+                    if (rc != 0) return rc;
+                    break;
+                }
                 GX_CHECK(hipLaunchKernel(x.k.func, x.k.gridDim, x.k.blockDim, x.k.kernelParams, x.k.sharedMemBytes, st));
                 break;
             case hipGraphNodeTypeMemset: {

@@ -1365,6 +1365,113 @@ def cif_bwd(hidden, cur, rem, tok, n_fire, d_out):
     return d_hidden, d_alpha
 
 
+# ---- gradient all-reduce from the C launch loop (asr_hip.h: asr_rccl_*, asr_collective_mark; csrc/collective.hip) ----------------------
+_RCCL = {"loaded": False, "comms": {}}
+_COLLECTIVE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p)
+
+
+def rccl_load():
+    """Bind RCCL's C API inside libasr_hip.so: the librccl torch has already mapped (one RCCL per process), else ROCm's."""
+    if not _RCCL["loaded"]:
+        cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"]
+        path = next((c for c in cands if os.path.exists(c)), None)
+        check(lib().asr_rccl_load(path.encode() if path else None), "asr_rccl_load")
+        _RCCL["loaded"] = True
+
+
+class RcclComm:
+    """An RCCL communicator owned by libasr_hip.so (not torch's): what the graph executor's collective nodes all-reduce through."""
+
+    def __init__(self, handle, world, rank):
+        self.handle, self.world, self.rank = handle, world, rank
+
+    def all_reduce_(self, t):
+        """t (f32, contiguous, cuda) <- sum over ranks, queued on the current stream"""
+        _req_cuda(t)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("RcclComm.all_reduce_: a contiguous float32 tensor is required")
+        check(lib().asr_rccl_all_reduce_f32(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), _stream()), "asr_rccl_all_reduce_f32")
+        return t
+
+    def check(self):
+        check(lib().asr_rccl_comm_check(self.handle), "asr_rccl_comm_check")
+
+    def destroy(self):
+        h, self.handle = self.handle, None
+        if h:
+            lib().asr_rccl_comm_destroy(h)
+
+
+def rccl_comm(group=None, device=None):
+    """The RcclComm over the ranks of `group` (default group when None; a 1-rank communicator when torch.distributed is not
+    initialised).  Collective over the group on first use: rank 0's unique id travels through torch.distributed (bootstrap only)."""
+    import torch.distributed as dist
+    key = id(group) if group is not None else 0
+    if key in _RCCL["comms"]:
+        return _RCCL["comms"][key]
+    rccl_load()
+    world, rank = 1, 0
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    uid = (ctypes.c_char * 128)()
+    if rank == 0:
+        check(lib().asr_rccl_unique_id(uid), "asr_rccl_unique_id")
+    if world > 1:
+        box = [bytes(uid.raw)]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(lib().asr_rccl_comm_create(uid, world, rank, ctypes.byref(h)), "asr_rccl_comm_create")
+    comm = RcclComm(h, world, rank)
+    if world > 1:      # pre-flight: the sum of (rank + 1) over the ranks, through the communicator the step will use
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            probe = torch.full((256,), float(rank + 1), device="cuda")
+            comm.all_reduce_(probe)
+            got = float(probe[0])
+        if got != world * (world + 1) / 2:
+            raise RuntimeError("asr_amd: RCCL pre-flight all-reduce returned %r over %d ranks" % (got, world))
+    _RCCL["comms"][key] = comm
+    return comm
+
+
+def collective_mark(t, tag=0):
+    """Bucket-ready marker for t (a contiguous f32 view) on the current stream: a no-op kernel that a CAPTURED step's executor turns
+    into the all-reduce of t (asr_collective_mark)."""
+    _req_cuda(t)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("collective_mark: a contiguous float32 tensor is required")
+    check(lib().asr_collective_mark(ctypes.c_void_p(t.data_ptr()), t.numel(), int(tag), _stream()), "asr_collective_mark")
+
+
+def torch_collective_fn(tensors, group):
+    """An asr_collective_fn that all-reduces through torch.distributed (the test rig: gloo ranks sharing one GPU, which RCCL does not
+    accept as peers).  tensors: the f32 buffers the marked views live in.  The host blocks in each call - a rig, not the product path."""
+    import torch.distributed as dist
+    state = {"error": None}
+
+    def fn(ctx, buf, count, tag, stream):
+        try:
+            for t in tensors:
+                off = (buf - t.data_ptr()) // 4
+                if 0 <= off and off + count <= t.numel() and (buf - t.data_ptr()) % 4 == 0:
+                    # (ctypes hands the null stream over as None.  It is torch's default stream and must be named as that: work queued
+                    # through ExternalStream(0) was seen to overtake kernels the C loop had launched on the null stream before it,
+                    # once a hipGraphLaunch had run on that stream - tools/probe/external_stream_order.py)
+                    s = torch.cuda.ExternalStream(stream, device=t.device) if stream else torch.cuda.default_stream(t.device)
+                    with torch.cuda.stream(s):
+                        dist.all_reduce(t.view(-1)[off:off + count], group=group)
+                    return 0
+            raise RuntimeError("collective node buffer %#x (+%d floats) is in none of the registered tensors" % (buf, count))
+        except Exception as e:      # (an exception cannot cross the C loop)
+            state["error"] = e
+            return -1
+    cb = _COLLECTIVE_CB(fn)
+    cb.state = state
+    return cb
+
+
 class GraphExec:
     """Multi-stream executor over a captured HIP graph (asr_hip.h: asr_graphx_*).  Keeps the torch graph (the hipGraph_t, the nodes'
     parameter blocks and the capture's memory pool live in it) and launches its nodes itself on a few free-running streams."""
@@ -1388,10 +1495,24 @@ class GraphExec:
             return None
         n = [ctypes.c_int() for _ in range(4)]
         lib().asr_graphx_info(h, *[ctypes.byref(v) for v in n])
-        return cls(h, graph, dict(nodes=n[0].value, kernels=n[1].value, streams=n[2].value, events=n[3].value))
+        nc, tot = ctypes.c_int(), ctypes.c_longlong()
+        lib().asr_graphx_collectives(h, ctypes.byref(nc), ctypes.byref(tot))
+        return cls(h, graph, dict(nodes=n[0].value, kernels=n[1].value, streams=n[2].value, events=n[3].value, collectives=nc.value,
+                                  collective_floats=tot.value))
+
+    def set_collective(self, comm=None, fn=None):
+        """What the plan's collective nodes call: an RcclComm, or an asr_collective_fn callback (torch_collective_fn)."""
+        self._comm, self._fn = comm, fn      # (kept alive with the executor)
+        check(lib().asr_graphx_set_collective(self._h, comm.handle if comm is not None else None,
+                                              ctypes.cast(fn, ctypes.c_void_p) if fn is not None else None, None), "asr_graphx_set_collective")
 
     def launch(self):
-        check(lib().asr_graphx_launch(self._h, _stream()), "asr_graphx_launch")
+        rc = lib().asr_graphx_launch(self._h, _stream())
+        fn = getattr(self, "_fn", None)
+        if rc != 0 and fn is not None and fn.state["error"] is not None:
+            err, fn.state["error"] = fn.state["error"], None
+            raise err
+        check(rc, "asr_graphx_launch")
 
     def place_streams(self, clear=False):
         """Explicit logical -> physical side-stream map from hardware-queue probes (asr_graphx_place_streams); clear: back to the rotation."""

@@ -106,6 +106,8 @@ class GradBuckets:
     def __init__(self, flat_grad, params, offsets, numel, n_buckets=4, group=None):
         self.flat_grad, self.group = flat_grad, group
         self.launch_stream = None      # when set: all-reduces are issued from this stream, after an event of the current one
+        self.mark_stream = None        # when set (a step being captured for the graph executor): a bucket's ready point is a marker node
+                                       # ... on this stream instead of an all-reduce
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(group)
@@ -135,7 +137,17 @@ class GradBuckets:
             if self._pending[bi] == 0:
                 self.launch_order.append(bi)
                 modules.flush_wgrads()                     # (decoder-sized weight gradients still waiting for their grouped launch)
-                if self.world > 1:
+                if self.mark_stream is not None:
+                    # captured step: the collective is a node of its own chain (the comm stream), ordered after every stream that
+                    # wrote this bucket; the executor's C loop makes the RCCL call there (ops.collective_mark)
+                    a, b = self.ranges[bi]
+                    cur = torch.cuda.current_stream()
+                    self.mark_stream.wait_stream(cur)
+                    if self.launch_stream is not None:
+                        self.mark_stream.wait_stream(self.launch_stream)
+                    with torch.cuda.stream(self.mark_stream):
+                        ops.collective_mark(self.flat_grad[a:b], tag=bi)
+                elif self.world > 1:
                     a, b = self.ranges[bi]
                     if self.launch_stream is not None:     # gradients of this bucket are written on two streams: order after both
                         ev = torch.cuda.Event()
@@ -147,6 +159,8 @@ class GradBuckets:
                         self._handles.append(torch.distributed.all_reduce(self.flat_grad[a:b], group=self.group, async_op=True))
 
     def finish(self):
+        if self.mark_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.mark_stream)
         for h in self._handles:
             h.wait()
         if any(c != 0 for c in self._pending):
@@ -158,10 +172,13 @@ class Trainer:
     (optimizer.py:24-29); betas / eps as configured at train.py:166-170."""
 
     def __init__(self, model, k=0.2, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-9, label_smoothing=0.1, n_buckets=8,
-                 process_group=None, lambda_qua=0.001, overlap_ctc=None, exact_global_mean=True):
+                 process_group=None, lambda_qua=0.001, overlap_ctc=None, exact_global_mean=True, force_collective=None):
         self.model = model
         self.group = process_group
         self.exact_global_mean = exact_global_mean
+        # collective nodes in the captured step even with one rank (a 1-rank RCCL communicator: the executor's all-reduce plumbing,
+        # measurable on a 1-GPU box; tools/rccl_sanity.py, tests/test_gpu_graph.py)
+        self.force_collective = (os.environ.get("ASR_AMD_FORCE_COLLECTIVE", "0") == "1") if force_collective is None else bool(force_collective)
         # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); ASR_AMD_OVERLAP_CTC=0 serialises it
         self.overlap_ctc = (os.environ.get("ASR_AMD_OVERLAP_CTC", "1") != "0") if overlap_ctc is None else bool(overlap_ctc)
         self.wgrad_stream = os.environ.get("ASR_AMD_WGRAD_STREAM", "1") != "0"     # weight-gradient GEMMs on a side stream (backward())
@@ -184,6 +201,7 @@ class Trainer:
             torch.distributed.broadcast(self.fp.flat, src=src, group=process_group)
             self.fp.sync_shadow()
         self._graph, self._graph_key, self._graph_out, self._graph_failed, self._eager_steps = None, None, None, None, 0
+        self._nw_marked = None
         self._graph_in = None      # the input buffers the graph was captured against (step_graphed copies each batch into them)
         self._graphx = None        # ops.GraphExec over the captured graph (multi-stream launch of its nodes), when available
         self._state, self._state_step = None, -1
@@ -330,9 +348,17 @@ class Trainer:
             V = logits.shape[-1]
             loss2, row_loss, lse, tg1 = ops.ce_loss_fwd(logits.reshape(-1, V), teos.reshape(-1), self.smoothing)
             self._nw_handle = None
-            if self.world > 1 and self.exact_global_mean:
+            if (self.world > 1 or self.buckets.mark_stream is not None) and self.exact_global_mean:
                 nw = loss2[1:2].clone()
-                self._nw_handle = (torch.distributed.all_reduce(nw, group=self.group, async_op=True), nw)
+                if self.buckets.mark_stream is not None:      # captured for the executor: a collective node on the comm stream
+                    ms = self.buckets.mark_stream
+                    ms.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(ms):
+                        ops.collective_mark(nw, tag=-1)
+                    nw.record_stream(ms)
+                    self._nw_handle, self._nw_marked = (None, nw), nw
+                else:
+                    self._nw_handle = (torch.distributed.all_reduce(nw, group=self.group, async_op=True), nw)
         return ctc, loss2[0], (tape, st, logits, tg1, lse, loss2, d_num)
 
     def backward(self, state):
@@ -375,7 +401,10 @@ class Trainer:
             ce_seed = one
             if self._nw_handle is not None:    # gradient of the global-batch CE mean: seed = world * n_word_local / n_word_global
                 h, nw = self._nw_handle
-                h.wait()
+                if h is None:
+                    torch.cuda.current_stream().wait_stream(self.buckets.mark_stream)
+                else:
+                    h.wait()
                 ce_seed = loss2[1:2] * (float(self.world) / nw)
                 self._nw_handle = None
             model.decoder._grad_slots["prj"]["g"] = ops.ce_loss_bwd(logits.reshape(-1, V), tg1, self.smoothing, lse, loss2, ce_seed, bf16=(modules.get_precision() == "bf16"))
@@ -420,8 +449,8 @@ class Trainer:
     def _graph_ok(self, feats, max_target_len):
         if self._graph_failed is not None or not feats.is_cuda or max_target_len is None:
             return False
-        if self.world > 1 and os.environ.get("ASR_AMD_GRAPH_DP", "0") != "1":
-            return False          # collectives inside a captured step are opt-in (not measurable on the 1-GPU development box)
+        if self.world > 1 and (not GRAPH_EXEC or os.environ.get("ASR_AMD_GRAPH_DP", "1") == "0"):
+            return False          # with N > 1 the step is captured only for the executor (its C loop makes the RCCL calls); =0: eager
         m = self.model
         return isinstance(m, (modules.CTC_Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"
 
@@ -499,14 +528,32 @@ class Trainer:
             for _ in range(trials):
                 out = fn(feats, lens, targets, noise=noise, max_target_len=max_target_len)
             torch.cuda.synchronize(dev)
-            return (time.perf_counter() - t0) / trials * 1e3, out
+            ms = (time.perf_counter() - t0) / trials * 1e3
+            if self.world > 1:      # one decision for all ranks (a rank replaying while another queues eagerly would wait on different communicators)
+                t = torch.tensor([ms], device=dev)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
+                ms = float(t)
+            return ms, out
+
+        def host_us(fn):
+            """the host's own queueing time of one step: the call's duration with the device idle at its start (with work queued
+            ahead the call would mostly measure the runtime's back-pressure)"""
+            tot = 0.0
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                fn(feats, lens, targets, noise=noise, max_target_len=max_target_len)
+                tot += time.perf_counter() - t0
+            torch.cuda.synchronize(dev)
+            return round(tot / 3 * 1e6, 1)
         for _ in range(2):                               # pools, code objects, side streams
             self.step(feats, lens, targets, noise=noise, max_target_len=max_target_len)
         t_eager, out = timed(self.step)
+        h_eager = host_us(self.step)
         self._eager_steps = 2
         out = self.step_graphed(feats, lens, targets, noise=noise, max_target_len=max_target_len)      # captures and replays once
         if not self.graph_active():
-            self.launch_mode, self.launch_timing = "eager", {"eager_ms": round(t_eager, 3), "graph_ms": None}
+            self.launch_mode, self.launch_timing = "eager", {"eager_ms": round(t_eager, 3), "graph_ms": None, "eager_host_us": h_eager}
             return out
         t_graph, out = timed(self.step_graphed)
         rot = None
@@ -533,7 +580,10 @@ class Trainer:
                 else:
                     self._graphx.place_streams(clear=True)
         self.launch_mode = "graph" if t_graph < t_eager else "eager"
-        self.launch_timing = {"eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3)}
+        self.launch_timing = {"eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3), "eager_host_us": h_eager,
+                              "graph_host_us": host_us(self.step_graphed)}
+        if self._graphx is not None and self._graphx.info.get("collectives"):
+            self.launch_timing["collective_nodes"] = self._graphx.info["collectives"]
         if rot is not None:
             self.launch_timing["graph_ms_by_stream_rotation"] = rot
         if self.launch_mode == "eager":
@@ -550,7 +600,11 @@ class Trainer:
         torch.cuda.synchronize(dev)
         # keep_graph: the captured hipGraph stays readable - its nodes are what the multi-stream executor launches (ops.GraphExec);
         # a stack without that option (or a graph the executor does not take) replays through hipGraphLaunch
-        use_x = GRAPH_EXEC and self.world == 1
+        use_x = GRAPH_EXEC
+        # With more than one rank (or force_collective) the gradient all-reduces are NODES of the captured step: GradBuckets marks each
+        # bucket's ready point on a comm stream of its own, the executor's launch loop calls RCCL there (csrc/collective.hip).  Such a
+        # step only replays through the executor - under hipGraphLaunch the markers would be no-ops and the ranks would drift apart.
+        collective = self.world > 1 or self.force_collective
         try:
             g = torch.cuda.CUDAGraph(keep_graph=True) if use_x else torch.cuda.CUDAGraph()
         except TypeError:
@@ -558,6 +612,16 @@ class Trainer:
         self._graphx = None
         modules._DROP_STATE["salt"] = self._state.data_ptr()
         try:
+            comm, comm_fn = None, None
+            if collective:
+                if not use_x:
+                    raise RuntimeError("a data-parallel step is captured for the graph executor only (ASR_AMD_GRAPH_EXEC=0 or no keep_graph)")
+                # (communicator set-up is itself a collective and queues GPU work: before the capture begins)
+                if self.world > 1 and torch.distributed.get_backend(self.group) != "nccl":
+                    comm_fn = ops.torch_collective_fn([self.fp.grad], self.group)      # the rig: gloo ranks sharing one GPU
+                else:
+                    comm = ops.rccl_comm(self.group, dev)
+                self.buckets.mark_stream = ops.aux_stream(dev, slot=3)
             with torch.cuda.graph(g):
                 ops.step_tick(self._state, self.k, self.init_lr, self.warmup, self.betas[0], self.betas[1])
                 ctc, ce = self._fwd_bwd(feats, lens, targets, noise, max_target_len)
@@ -565,9 +629,19 @@ class Trainer:
                                   grad_scale=1.0 / self.world, p16=self.fp.flat16)
             if use_x:
                 self._graphx = ops.GraphExec.from_torch_graph(g)       # None (with a warning) when the executor does not take this graph
+            if collective:
+                if self._graphx is None:
+                    raise RuntimeError("the graph executor did not take the data-parallel step")
+                if self._graphx.info["collectives"] < len(self.buckets.ranges):
+                    raise RuntimeError("the executor found %d collective nodes for %d gradient buckets" %
+                                       (self._graphx.info["collectives"], len(self.buckets.ranges)))
+                if comm_fn is not None and self._nw_marked is not None:
+                    comm_fn = ops.torch_collective_fn([self.fp.grad, self._nw_marked], self.group)
+                self._graphx.set_collective(comm=comm, fn=comm_fn)
             self._graph, self._graph_key, self._graph_out = g, key, (ctc, ce)
         except Exception as e:      # not capturable on this stack: keep training eagerly, remember why
             self._graph_failed = "%s: %s" % (type(e).__name__, e)
+            self._graphx = None
             import warnings
             warnings.warn("asr_amd.Trainer: hipGraph capture of the step failed, running eagerly (%s)" % self._graph_failed)
             try:
@@ -576,3 +650,12 @@ class Trainer:
                 pass
         finally:
             modules._DROP_STATE["salt"] = None
+            self.buckets.mark_stream = None
+        if self.world > 1:
+            # every rank replays, or none does: a rank that fell back to the eager step would all-reduce through torch's communicator
+            # while the others wait in the executor's
+            ok = torch.tensor([1.0 if self._graph is not None else 0.0], device=dev)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN, group=self.group)
+            if float(ok) == 0.0 and self._graph is not None:
+                self._graph, self._graphx = None, None
+                self._graph_failed = "another rank could not capture the step"

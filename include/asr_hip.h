@@ -207,6 +207,30 @@ int asr_graphx_place_streams(void* handle, void* launch_stream, int clear);
 int asr_graphx_info(void* handle, int* n_nodes, int* n_kernels, int* n_streams, int* n_events);
 int asr_graphx_destroy(void* handle);
 
+/* Gradient all-reduce of the data-parallel step (csrc/collective.hip; SURVEY §8(e) - the reference trains on one GPU, solver.py:80-96,
+ * and has no counterpart: each rank runs the whole step on its shard of the global batch and the flat f32 gradient is summed bucket
+ * by bucket).  RCCL is bound at run time: asr_rccl_load(path) (NULL: the librccl already mapped into the process, e.g. torch's).
+ * asr_rccl_unique_id fills ASR_RCCL_ID_BYTES bytes on ONE rank; the caller carries them to the others (bootstrap only) and every rank
+ * calls asr_rccl_comm_create(id, nranks, rank) with its device current.  asr_rccl_all_reduce_f32 queues buf <- sum over ranks, in
+ * place, on `stream`.  asr_rccl_comm_check returns the communicator's asynchronous error state (0 = healthy). */
+#define ASR_RCCL_ID_BYTES 128
+int asr_rccl_load(const char* path);
+int asr_rccl_version(int* version);
+int asr_rccl_unique_id(void* out_id);
+int asr_rccl_comm_create(const void* id, int nranks, int rank, void** out_comm);
+int asr_rccl_comm_destroy(void* comm);
+int asr_rccl_all_reduce_f32(void* comm, float* buf, long long count, void* stream);
+int asr_rccl_comm_check(void* comm);
+/* The ready point of a gradient bucket: a no-op kernel node on `stream` carrying (buf, count, tag).  Launched while a step is being
+ * captured it becomes a COLLECTIVE node of the executor: asr_graphx_launch queues the all-reduce of buf[0..count) on that node's stream
+ * from its own C loop, ordered by the node's edges like any kernel - through the RCCL communicator given to asr_graphx_set_collective,
+ * or through `fn(ctx, buf, count, tag, stream)` when one is given (a rig whose ranks are not RCCL peers; 0 = queued).  A plan with
+ * collective nodes and neither fails at launch.  asr_graphx_collectives: how many such nodes the plan holds, and their total count. */
+typedef int (*asr_collective_fn)(void* ctx, float* buf, long long count, int tag, void* stream);
+int asr_collective_mark(float* buf, long long count, int tag, void* stream);
+int asr_graphx_set_collective(void* handle, void* rccl_comm, asr_collective_fn fn, void* ctx);
+int asr_graphx_collectives(void* handle, int* n_collective, long long* total_count);
+
 /* The position-wise feed-forward sub-layer of an encoder layer in ONE launch (module.py:48-53 `layer_norm(dropout(w_2(relu(w_1(x)))) +
  * residual)` followed by encoder.py:77 `enc_output *= non_pad_mask`), for d_model = 256 and d_ff a multiple of 64 (<= 2048):
  *   h = relu(x16 . W1^T + b1);  s = dropout_x(h . W2^T + b2) + x32;  y = LayerNorm(s) * gamma + beta, rows t >= row_len[b] zeroed.

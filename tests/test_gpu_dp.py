@@ -95,6 +95,20 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
     _check_equiv(_run([os.path.join(ROOT, "tools", "dp_equiv.py")], 2, 29543, True), 2)
 
 
+def test_two_ranks_through_the_graph_executor_equal_one_rank():
+    """The same equivalence with each rank's step CAPTURED and replayed by the multi-stream executor, whose launch loop calls the
+    all-reduce at the buckets' collective nodes (csrc/collective.hip; the gloo rig passes torch.distributed's all-reduce as the
+    node's callback - RCCL does not take two ranks on one GPU)."""
+    lines = _run([os.path.join(ROOT, "tools", "dp_equiv.py"), "--graph"], 2, 29551, True)
+    _check_equiv(lines, 2)
+    assert all(o["executor"]["collectives"] >= 2 for o in lines), lines
+
+
+def test_eight_ranks_through_the_graph_executor_equal_one_rank():
+    lines = _run([os.path.join(ROOT, "tools", "dp_equiv.py"), "--graph"], 8, 29553, True)
+    _check_equiv(lines, 8)
+
+
 def test_eight_ranks_equal_one_rank_on_the_concatenated_batch():
     """The world size of BASELINE.json configs[4] (8 shards of the utterance batch, 8 gradient buckets each), still over gloo on one GPU."""
     _check_equiv(_run([os.path.join(ROOT, "tools", "dp_equiv.py")], 8, 29549, True), 8)

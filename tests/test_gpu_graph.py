@@ -110,9 +110,10 @@ def test_step_auto_calibrates_once_and_stays_on_the_eager_trajectory(golden_dir)
     te = asr_amd.Trainer(m_e, k=0.2, warmup_steps=50, label_smoothing=0.1)
     ta = asr_amd.Trainer(m_a, k=0.2, warmup_steps=50, label_smoothing=0.1)
     ta.step_auto(x, lens, tg, max_target_len=umax, trials=2)          # calibration: 2 + 2 eager, 1 capture + replay, 2 replays, and 2 more
-    n_cal = ta.step_num                                               # per stream rotation / placement the executor is timed with
-    assert ta.launch_mode in ("eager", "graph") and n_cal >= 7 and (n_cal - 7) % 2 == 0
+    n_cal = ta.step_num                                               # per stream rotation / placement the executor is timed with;
+    assert ta.launch_mode in ("eager", "graph") and n_cal >= 13 and (n_cal - 13) % 2 == 0      # 3 + 3 for the host's queueing time
     assert ta.launch_timing["eager_ms"] > 0 and ta.launch_timing["graph_ms"] > 0
+    assert 0 < ta.launch_timing["graph_host_us"] < ta.launch_timing["eager_host_us"]          # (the C loop against ~600 Python calls)
     assert ta.graph_active() == (ta.launch_mode == "graph")
     for _ in range(n_cal):
         ce = te.step(x, lens, tg, max_target_len=umax)
@@ -203,3 +204,68 @@ def test_cif_model_replays_draw_fresh_noise(golden_dir):
     assert tr.graph_active() and len(seen) >= 3, tr._graph_failed
     assert all(not torch.equal(seen[i], seen[i + 1]) for i in range(len(seen) - 1))
     assert all(float(v.min()) >= 0.0 and float(v.max()) < 1.0 for v in seen)
+
+
+def test_executor_runs_the_gradient_all_reduce_itself(golden_dir):
+    """The data-parallel step's collectives as nodes of the captured step (csrc/collective.hip): with force_collective a 1-rank RCCL
+    communicator stands in for the ranks, so every gradient bucket (and the CE word count) is all-reduced by the executor's own C
+    loop - same trajectory as the step without them (the sum over one rank is the identity)."""
+    asr_amd.set_precision("bf16")
+    z, m_a = build(golden_dir)
+    _, m_b = build(golden_dir)
+    x, lens, tg = (torch.from_numpy(z[k]).to(DEV) for k in ("x", "lens", "targets"))
+    umax = int((tg != 0).sum(1).max())
+    ta = asr_amd.Trainer(m_a, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    tb = asr_amd.Trainer(m_b, k=0.2, warmup_steps=50, label_smoothing=0.1, force_collective=True)
+    la, lb = [], []
+    for i in range(8):
+        c, e = ta.step_graphed(x, lens, tg, max_target_len=umax)
+        la.append((float(c), float(e)))
+        c, e = tb.step_graphed(x, lens, tg, max_target_len=umax)
+        lb.append((float(c), float(e)))
+    assert tb.graph_active() and tb._graphx is not None, tb._graph_failed
+    info = tb._graphx.info
+    assert info["collectives"] == len(tb.buckets.ranges) + 1, info               # every bucket + the CE word count
+    assert info["collective_floats"] == tb.fp.grad.numel() + 1, info              # ... the whole flat gradient, once
+    assert ta._graphx.info["collectives"] == 0
+    np.testing.assert_allclose(np.array(lb), np.array(la), rtol=5e-3)
+    pa, pb = ta.fp.flat.float().cpu().numpy(), tb.fp.flat.float().cpu().numpy()
+    assert np.linalg.norm(pb - pa) / np.linalg.norm(pa) < 2e-3
+    from asr_amd import ops
+    ops.rccl_comm().check()
+
+
+def test_collective_nodes_without_a_communicator_fail_loudly(golden_dir):
+    asr_amd.set_precision("bf16")
+    from asr_amd import ops
+    buf = torch.ones(1024, device=DEV)
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(g):
+        buf.mul_(2.0)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.collective_mark(buf[:512], tag=3)
+        torch.cuda.current_stream().wait_stream(side)
+        buf.add_(1.0)
+    gx = ops.GraphExec.from_torch_graph(g)
+    assert gx is not None and gx.info["collectives"] == 1 and gx.info["collective_floats"] == 512
+    with pytest.raises(RuntimeError, match="no communicator"):
+        gx.launch()
+    torch.cuda.synchronize()
+    # ... with a callback in the node's place: called once, on the node's stream, between its predecessor and its successor
+    seen = []
+    buf.fill_(1.0)
+
+    def fn(ctx, ptr, count, tag, stream):
+        seen.append((ptr, count, tag))
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream) if stream else torch.cuda.default_stream()):
+            buf[:512].mul_(10.0)        # stands in for the sum over ranks
+        return 0
+    cb = ops._COLLECTIVE_CB(fn)
+    cb.state = {"error": None}
+    gx.set_collective(fn=cb)
+    gx.launch()
+    torch.cuda.synchronize()
+    assert seen == [(buf.data_ptr(), 512, 3)]
+    assert float(buf[0]) == 21.0 and float(buf[600]) == 3.0      # (1 * 2) * 10 + 1 ; (1 * 2) + 1

@@ -42,6 +42,8 @@ def main():
     tg = tg * (torch.arange(U)[None, :] < ul[:, None])
     x, lens, tg = x.to(dev), lens.to(dev), tg.to(dev)
 
+    out = {}
+
     def build():
         torch.manual_seed(0)
         m = asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 2, 64, 128, dropout=0.0),
@@ -53,13 +55,28 @@ def main():
         torch.cuda.synchronize()
         return {n: p.grad.detach().float().clone() / trainer.world for n, p in trainer.model.named_parameters()}
 
+    def grads_graphed(trainer, xs, ls, ts, umax):
+        """--graph: the same gradient out of a CAPTURED step replayed by the multi-stream executor, whose C loop makes the all-reduce
+        calls at the buckets' marker nodes (RCCL; the gloo rig hands it torch.distributed's all-reduce as a callback).  The flat
+        gradient still holds the summed gradient after the step: Adam reads it, the next step zeroes it."""
+        trainer._eager_steps = 2                 # (skip the two eager warm-up steps: one step on both sides)
+        trainer.step_graphed(xs, ls, ts, max_target_len=umax)
+        torch.cuda.synchronize()
+        assert trainer.graph_active() and trainer._graphx is not None, trainer._graph_failed
+        assert trainer._graphx.info["collectives"] >= len(trainer.buckets.ranges), trainer._graphx.info
+        out["executor"] = trainer._graphx.info
+        return {n: p.grad.detach().float().clone() / trainer.world for n, p in trainer.model.named_parameters()}
+
+    graphed = "--graph" in sys.argv
+    if graphed:
+        asr_amd.set_precision("bf16")
     ref = grads(asr_amd.Trainer(build(), process_group=solo), x, lens, tg, U)
     sl = slice(rank * (B // world), (rank + 1) * (B // world))
-    out = {"rank": rank, "world": world}
+    out.update({"rank": rank, "world": world})
     for exact in (True, False):
         tr = asr_amd.Trainer(build(), exact_global_mean=exact)
         assert tr.world == world
-        got = grads(tr, x[sl].contiguous(), lens[sl].contiguous(), tg[sl].contiguous(), int(ul[sl].max()))
+        got = (grads_graphed if graphed else grads)(tr, x[sl].contiguous(), lens[sl].contiguous(), tg[sl].contiguous(), int(ul[sl].max()))
         worst, name = 0.0, ""
         for n, g in got.items():
             d = float((g - ref[n]).norm() / (ref[n].norm() + 1e-12))
