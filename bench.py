@@ -450,6 +450,13 @@ def main():
             step()
         torch.cuda.synchronize()
         settle.append((time.perf_counter() - t0) / 5 * 1e3)
+        if world > 1:
+            # ONE decision for all ranks: every step holds collectives, so a rank that settled a group earlier than its peers left them
+            # waiting in an all-reduce it never joined while it sat in the barrier below - the "hangs once in a few dozen runs" of
+            # the multi-rank rig (tools/dp_hang_hunt.py: 6 of 80 runs; Python stacks: one rank in barrier(), the other in step())
+            t = torch.tensor([settle[-1]], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            settle[-1] = float(t)
         if len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= 0.02 * settle[-2]:
             break
     for _ in range(args.warmup):
