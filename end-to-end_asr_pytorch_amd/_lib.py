@@ -99,6 +99,7 @@ SIGNATURES = {
     "asr_vocab_proj_lse": [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i],
     "asr_ctc_loss_fwd_lse": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "asr_ctc_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "asr_ctc_loss_mean_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "asr_ctc_counter_words": [_i, _i, _i],
     "asr_ctc_mean": [_vp, _vp, _vp, _i, _vp],
     "asr_ctc_loss_bwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp],

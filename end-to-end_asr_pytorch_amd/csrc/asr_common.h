@@ -118,6 +118,7 @@ __device__ __forceinline__ f32x4 drop4(const asr_dropout_t& d, uint32_t sub, uin
 
 // online (max, sum-exp) pair combine
 __device__ __forceinline__ void lse_combine(float& m, float& s, float m2, float s2) {
+#pragma clang fp contract(off)      // (one rounding per operation wherever this is inlined: callers compare forms of one op bit for bit)
     float mn = fmaxf(m, m2);
     if (mn == -INFINITY) { s = 0.f; m = mn; return; }
     s = s * __expf(m - mn) + s2 * __expf(m2 - mn);

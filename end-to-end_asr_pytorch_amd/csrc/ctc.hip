@@ -537,11 +537,26 @@ __device__ __forceinline__ void ctc_step1(float& e, float& o, const f32x2 c, flo
 // published (the caller has seen their arrival counters complete: a row that is read before its producer has written it would
 // stay in this XCD's L2 and be served again, stale, when it is read for real).  skip0: frame `first` is the chain's initial
 // state - its step is not taken (it only keeps the row pairs aligned to the chunk grid).  ring: this wavefront's LDS ring.
+// avail / W: the chain runs as ONE pipeline over the whole direction and never reads ahead of the arrivals: `avail` is an LDS word in
+// which a polling wavefront of the same workgroup keeps the number of COMPLETE chunks (W rows each) of this direction (-1: a producer
+// never arrived); a pair's DMA is issued only once its chunk is complete, and the wavefront waits right there, its ring still primed -
+// where a chain cut into runs at chunk boundaries drained and refilled its ring (a DMA round trip) at every boundary it reached in time.
+// Returns false when the producer side failed.
 template <bool DIRB, int P>
-__device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ctc_rsrc_t ral, int lane, char* ring, int first, int nsteps,
-                                              bool skip0, float& e, float& o, float skip_add, int dbg = 0) {
+__device__ __forceinline__ bool ctc_lds_chain(const float* __restrict__ lp_u, ctc_rsrc_t ral, int lane, char* ring, int first, int nsteps,
+                                              bool skip0, float& e, float& o, float skip_add, const volatile int* avail, int W) {
     const int npairs = nsteps >> 1;
-    if (npairs <= 0) return;
+    if (npairs <= 0) return true;
+    int avail_pairs = 0;
+    bool alive = true;
+    auto gate = [&](int q) {            // pair q (steps 2q, 2q + 1: one chunk, W is even) has arrived
+        while (q >= avail_pairs) {
+            const int a = __builtin_amdgcn_readfirstlane(*avail);
+            if (a < 0) { alive = false; return; }
+            avail_pairs = a * (W >> 1);
+            if (q >= avail_pairs) __builtin_amdgcn_s_sleep(2);
+        }
+    };
     const char* src_lane = reinterpret_cast<const char*>(lp_u) + lane * 16;
     const unsigned rd = (unsigned)reinterpret_cast<uintptr_t>((lds_void_t*)ring) + lane * 8;   // LDS byte address of this lane's column
     // pair q = steps 2q, 2q+1.  alpha: rows (first + 2q, + 1);  beta: rows (first - 2q - 1, first - 2q): the LOWER row sits in the
@@ -550,6 +565,7 @@ __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ct
     // the count of vector-memory operations between a pair's DMA and its wait constant.
     auto dma = [&](int q, int slot) {
         const bool real = q < npairs;
+        if (real) gate(q);
         const int qq = real ? q : 0;
         const int lo = DIRB ? first - 2 * qq - 1 : first + 2 * qq;
         __builtin_amdgcn_global_load_lds((global_cvoid_t*)(src_lane + (int64_t)lo * 512), (lds_void_t*)(ring + (real ? slot : P) * 1024), 16, 0, 16);
@@ -560,6 +576,7 @@ __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ct
     };
 #pragma unroll
     for (int j = 0; j < P; ++j) dma(j, j);
+    if (!alive) return false;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // the pair read ahead: lower / upper table row.  Every asm statement takes them in-out ("+v"): one live range in one register
     // pair from the ds_read to the wait - a fresh output per read would let the compiler place a register copy (a loop phi) between
@@ -579,6 +596,7 @@ __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ct
                              : [a] "=&v"(clo), [b] "=&v"(chi), [l] "+v"(nlo), [h] "+v"(nhi)::"memory");
                 const f32x2 c0 = DIRB ? chi : clo, c1 = DIRB ? clo : chi;      // step 2q, step 2q + 1
                 dma(q + P, j);                                                   // slot j has just been read: refill it
+                if (!alive) return false;
                 asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * P - 3) : "memory");  // pair q + 1 has landed
                 if (j + 1 < P)
                     asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
@@ -592,6 +610,7 @@ __device__ __forceinline__ void ctc_lds_chain(const float* __restrict__ lp_u, ct
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nlo), "+v"(nhi)::"memory");      // (the read-ahead of a pair nobody consumes)
+    return true;
 }
 
 template <int P>
@@ -600,15 +619,35 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
                                                                float* __restrict__ lse_out, float* __restrict__ lp_ext,
                                                                float* __restrict__ alpha, float* __restrict__ nll,
                                                                int32_t* __restrict__ tgt_len, int W, int nchunks, int* __restrict__ arrivals,
-                                                               int64_t arr_stride, int dbg) {
+                                                               int64_t arr_stride, int* __restrict__ extra, float* __restrict__ mean_loss,
+                                                               int dbg) {
     constexpr int Sp = 128;
     __shared__ __attribute__((aligned(16))) char ring[2][(P + 1) * 1024];
-    const int RPB = dbg >> 8;                                // table rows per pass workgroup (W is a multiple of it)
+    // extra[8]: finished recursion workgroups (extra[0..7] spare)
+    const int RPB = (dbg >> 8) & 0xff;                       // table rows per pass workgroup (W is a multiple of it)
+    // dbg bit 7 (timeline experiment, needs the counters in a buffer of their own): every workgroup leaves its start / end time (100 MHz
+    // counter, low words) in the spare row L + 1 of the alpha workspace - tools/ctc_timeline.py
+    unsigned* stamp = (dbg & 128) ? reinterpret_cast<unsigned*>(alpha + ((int64_t)(blockIdx.x >> 6) * (L + 2) + (L + 1)) * Sp) + (blockIdx.x & 63) * 2
+                                  : nullptr;
+    unsigned long long stamp_t0 = 0;
+    if (stamp && threadIdx.x == 0) {      // word 0: where it runs (HW_ID low 16 bits | XCC_ID << 16) - start times differ by < 5 us
+        stamp_t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        stamp[0] = (hw & 0xffff) | ((xcc & 0xf) << 16);
+    }
     if ((int)blockIdx.x >= Bn) {
         // ---- PASS workgroup (persistent): walks row groups gid = pid, pid + npass, ... in chunk-major order; a group = RPB consecutive
         // rows of one (chunk, utterance, direction).  Only wave 0 stores (64 state pairs + the row's lse), so the group's arrival is
         // signalled by wave 0 alone, and not by draining its stores on the spot: vector-memory operations retire in order, so once
         // the NEXT group's first row has landed in wave 0's registers every older store has left - the add costs no wait at all.
+        // Tried on this walk in round 4 and dropped (tools/ctc_timeline.py stamps every workgroup's end: equal shares of 16 rows finish
+        // 30 us apart, the chains 12-14 us after the last of them): utterance b's rows produced on XCD b mod 8 (neutral: 133 / 130 and
+        // 143 / 146 us); the last partial round dealt row by row (neutral); groups, single rows, or the last half of the walk handed out
+        // by queue heads, device-scope or per XCD (170-400 us: a returning atomic per unit under a saturated memory system costs more
+        // than the imbalance); the row by LDS-DMA into the idle ring with the next row's DMA in flight during the reduction (mean
+        // workgroup 6 % faster, slowest 8 % slower: 151 against 141 us); the label gather issued behind the row's own loads (155 / 143).
+        if (dbg & 32) return;      // (bit 5: timing experiment - the chains alone)
         const int G = W / RPB, npass = gridDim.x - Bn, total = nchunks * Bn * 2 * G;
         const bool w0 = threadIdx.x < 64;
         int* pending = nullptr;
@@ -654,12 +693,14 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (threadIdx.x == 0) __hip_atomic_fetch_add(pending, pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (stamp && threadIdx.x == 0) stamp[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
         return;
     }
     // ---- RECURSION workgroup: one utterance; wave 0 runs alpha, wave 1 beta, waves 2 / 3 only keep the barriers company ----
     if (dbg & 4) return;       // (timing experiment: the pass alone)
     __shared__ float xch[64][2];
     __shared__ int failed;
+    __shared__ volatile int avail_sh[2];      // complete chunks of the alpha / beta direction (-1: a producer never arrived)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
@@ -668,17 +709,29 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
     const int Tb = min(in_len[b], L), mid = Tb >> 1;
     if (threadIdx.x == 0) {
         failed = 0;
+        avail_sh[0] = avail_sh[1] = 0;
         tgt_len[b] = U;
         if (Tb <= 0) nll[b] = (U == 0) ? 0.f : INFINITY;
     }
+    __syncthreads();
     const float* lp_u = lp_ext + (int64_t)b * L * Sp;
     float* al_u = alpha + (int64_t)b * (L + 2) * Sp;
     float e = -INFINITY, o = -INFINITY;
     bool ok = true;
+    if (Tb > 0 && wv >= 2) {
+        // POLLING wavefronts (2: alpha's chunks, 3: beta's): the device-scope counter reads stay out of the chains' hand-counted
+        // vector-memory queue; a chain asks LDS
+        const int d = wv - 2, klast_d = d == 0 ? mid : Tb - 2 - mid;
+        const int* arr_d = arrivals + (int64_t)b * arr_stride + d * nchunks;
+        for (int c = 0; c * W <= klast_d; ++c) {
+            const bool got = (dbg & 16) ? true : ctc_wait_rows(arr_d + c, min(c * W + W, klast_d + 1) - c * W);      // (bit 4: never wait - timing only)
+            if (lane == 0) avail_sh[d] = got ? c + 1 : -1;
+            if (!got) break;
+        }
+    }
     if (Tb > 0 && wv < 2) {
         __builtin_amdgcn_s_setprio(3);                    // the chains outrank the pass workgroups sharing this CU's SIMDs
         const ctc_rsrc_t ral = ctc_rsrc(al_u, (int64_t)(L + 2) * Sp * 4);
-        const int* arr = arrivals + (int64_t)b * arr_stride + wv * nchunks;      // this direction's chunk counters
         const f32x2* lpl = reinterpret_cast<const f32x2*>(lp_u) + lane;           // this lane's (blank, label) column
         auto row_sc1 = [&](int t) {      // a published row read around the L1 (8-byte agent-scope load)
             const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(lpl + (int64_t)t * 64), __ATOMIC_RELAXED,
@@ -693,41 +746,43 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
         const int f0 = wv == 0 ? 0 : Tb - 1, dir = wv == 0 ? 1 : -1;
         const float skip = wv == 0 ? (((lane >= 1 && lane < U) && (tg[lane] != tg[lane - 1])) ? 0.f : -INFINITY)      // s-2 -> s, s = 2 lane + 1
                                    : (((lane + 1 < U) && (tg[lane] != tg[lane + 1])) ? 0.f : -INFINITY);            // s -> s+2
-        auto rows_of = [&](int c) { return min(c * W + W, klast + 1) - c * W; };
         auto init_state = [&](int t) {
             const f32x2 r0 = row_sc1(t);
             if (wv == 0) { e = (lane == 0) ? r0[0] : -INFINITY; o = (lane == 0) ? r0[1] : -INFINITY; }
             else { e = (lane == U) ? r0[0] : -INFINITY; o = (lane == U - 1) ? r0[1] : -INFINITY; }
         };
-        int c = 0;
-        while (c * W <= klast && ok) {
-            ok = ctc_wait_rows(arr + c, rows_of(c));
-            if (!ok) break;
-            // every later chunk that is complete already joins this run: one pipeline fill for all of them (a chain that lags the
-            // pass never stops at a chunk boundary; one that is ahead waits for data anyway)
-            int ce = c + 1;
-            while (ce * W <= klast && __hip_atomic_load(arr + ce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rows_of(ce)) ++ce;
-            const int ka = c * W, kb = min(ce * W, klast + 1);      // steps [ka, kb)
-            if (c == 0) init_state(f0);
-            const int n = kb - ka, neven = n & ~1;
-            f32x2 tail = {0.f, 0.f};
-            if (n & 1) tail = row_sc1(f0 + dir * (kb - 1));         // an odd run ends the direction: its last row comes by itself
-            if (wv == 0) ctc_lds_chain<false, P>(lp_u, ral, lane, ring[0], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
-            else ctc_lds_chain<true, P>(lp_u, ral, lane, ring[1], f0 + dir * ka, neven, c == 0, e, o, skip, dbg);
-            if (n & 1) {
-                if (!(c == 0 && n == 1)) {
-                    if (wv == 0) ctc_step1<false>(e, o, tail, skip);
-                    else ctc_step1<true>(e, o, tail, skip);
-                }
-                store_row(f0 + dir * (kb - 1));
+        // one pipeline over the whole direction, gated on the chunk counts the polling wavefronts keep in LDS (below)
+        const volatile int* av = &avail_sh[wv];
+        auto wait_chunk = [&](const volatile int* a, int c) {      // chunk c of that direction is complete
+            for (;;) {
+                const int v = __builtin_amdgcn_readfirstlane(*a);
+                if (v < 0) return false;
+                if (v > c) return true;
+                __builtin_amdgcn_s_sleep(2);
             }
-            c = ce;
+        };
+        const int n = klast + 1;                                  // steps 0 .. klast; step 0 is the initial state
+        if (n > 0) {
+            ok = wait_chunk(av, 0);
+            if (ok) {
+                init_state(f0);
+                if (wv == 0) ok = ctc_lds_chain<false, P>(lp_u, ral, lane, ring[0], f0, n & ~1, true, e, o, skip, av, W);
+                else ok = ctc_lds_chain<true, P>(lp_u, ral, lane, ring[1], f0, n & ~1, true, e, o, skip, av, W);
+            }
+            if (ok && (n & 1)) {                                  // an odd direction ends on a row that comes by itself
+                ok = wait_chunk(av, (n - 1) / W);
+                if (ok) {
+                    if (n > 1) {
+                        const f32x2 tail = row_sc1(f0 + dir * (n - 1));
+                        if (wv == 0) ctc_step1<false>(e, o, tail, skip);
+                        else ctc_step1<true>(e, o, tail, skip);
+                    }
+                    store_row(f0 + dir * (n - 1));
+                }
+            }
         }
         if (wv == 1) {          // beta onto the meeting frame (stored as row L); its row belongs to forward chunk mid / W
-            if (ok) {
-                const int cm = mid / W;
-                ok = ctc_wait_rows(arrivals + (int64_t)b * arr_stride + cm, min(cm * W + W, mid + 1) - cm * W);
-            }
+            if (ok) ok = wait_chunk(&avail_sh[0], mid / W);
             if (ok) {
                 if (klast < 0) init_state(mid);        // Tb == 1: beta starts on the meeting frame itself
                 else ctc_step1<true>(e, o, row_sc1(mid), skip);
@@ -741,21 +796,49 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
     __syncthreads();                                      // (failed initialised; beta's states visible)
     if (!ok && lane == 0) failed = 1;                     // a producer never arrived (cannot happen unless the pass faulted)
     __syncthreads();
-    if (Tb <= 0 || wv != 0) return;
-    if (failed) {                                         // fail loudly, never hang
-        if (lane == 0) nll[b] = __builtin_nanf("");
-        return;
+    if (wv != 0) return;
+    if (Tb > 0) {
+        if (failed) {                                     // fail loudly, never hang
+            if (lane == 0) nll[b] = __builtin_nanf("");
+        } else {
+            // log p(l|x) = lse_s( alpha_mid(s) + beta_mid(s) - lp_mid(s) )   (table columns >= 2U+1 are -inf: dead states drop out)
+            const unsigned long long rv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(lp_u + (int64_t)mid * Sp + 2 * lane),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const f32x2 r = __builtin_bit_cast(f32x2, rv);
+            const float v0 = (r[0] == -INFINITY) ? -INFINITY : e + xch[lane][0] - r[0];
+            const float v1 = (r[1] == -INFINITY) ? -INFINITY : o + xch[lane][1] - r[1];
+            const float m = wave_max(fmaxf(v0, v1));
+            const float ms = fmaxf(m, NEG_BIG);
+            const float sum = wave_sum(__builtin_amdgcn_exp2f(v0 - ms) + __builtin_amdgcn_exp2f(v1 - ms));
+            if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
+        }
     }
-    // log p(l|x) = lse_s( alpha_mid(s) + beta_mid(s) - lp_mid(s) )   (table columns >= 2U+1 are -inf: dead states drop out)
-    const unsigned long long rv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(lp_u + (int64_t)mid * Sp + 2 * lane),
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const f32x2 r = __builtin_bit_cast(f32x2, rv);
-    const float v0 = (r[0] == -INFINITY) ? -INFINITY : e + xch[lane][0] - r[0];
-    const float v1 = (r[1] == -INFINITY) ? -INFINITY : o + xch[lane][1] - r[1];
-    const float m = wave_max(fmaxf(v0, v1));
-    const float ms = fmaxf(m, NEG_BIG);
-    const float sum = wave_sum(__builtin_amdgcn_exp2f(v0 - ms) + __builtin_amdgcn_exp2f(v1 - ms));
-    if (lane == 0) nll[b] = -(ms + __builtin_amdgcn_logf(sum)) * LN2;
+    // ---- the last utterance to finish closes the op: the batch mean (loss.py:41-43, what ctc_mean_kernel computes, same order) and the
+    // counters back to zero - every arrival has landed by then (each chain waited for all of its own), so a caller can keep ONE
+    // counter buffer per stream, zeroed once, and the op is one launch with no memset in front and no reduction kernel behind
+    if (stamp && lane == 0) stamp[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    int last = 0;
+    if (lane == 0) {
+        __threadfence();                                  // nll[b] / tgt_len[b] before the count
+        last = __hip_atomic_fetch_add(extra + 8, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == Bn - 1;
+    }
+    last = __shfl(last, 0, 64);
+    if (!last) return;
+    if (mean_loss) {
+        float acc = 0.f;
+        for (int i = lane; i < Bn; i += 64) {
+            const float nl = __hip_atomic_load(nll + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int tl = __hip_atomic_load(tgt_len + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc += nl / (float)max(tl, 1);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) mean_loss[0] = acc / (float)Bn;
+    }
+    for (int i = lane; i < Bn * 2 * nchunks; i += 64) {
+        const int ub = i / (2 * nchunks);
+        __hip_atomic_store(arrivals + (int64_t)ub * arr_stride + (i - ub * 2 * nchunks), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) __hip_atomic_store(extra + 8, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the queue heads reset themselves)
 }
 
 __global__ void ctc_mean_kernel(const float* __restrict__ nll, const int32_t* __restrict__ tgt_len, int B, float* __restrict__ loss) {
@@ -876,7 +959,7 @@ extern "C" int64_t asr_ctc_counter_words(int B, int L, int n_chunks) {
     if (n_chunks <= 1 || L < 64 || B <= 0 || B > ctc_fused_max_batch()) return 0;
     int W, nc;
     ctc_chunking(L, n_chunks, W, nc);
-    return (int64_t)B * 2 * nc;
+    return (int64_t)B * 2 * nc + 16;      // arrival counters + the pass workgroups' queue heads (8) + the finished-utterance count
 }
 
 // ---- forward from a known row log-sum-exp (asr_vocab_proj_lse took it while the projection's accumulators held the logits) ----
@@ -917,9 +1000,9 @@ extern "C" int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t l
     return 0;
 }
 
-extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
-                                int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
-                                int32_t* tgt_len, void* zero_counters, int n_chunks) {
+static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
+                             int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
+                             int32_t* tgt_len, void* zero_counters, int n_chunks, float* mean_loss) {
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len, ASR_ERR_ARG, "ctc_fwd: null pointer");
     ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && blank >= 0 && blank < V && ldl >= V, ASR_ERR_ARG, "ctc_fwd: bad sizes");
     ASR_REQUIRE(Umax + 1 <= 512, ASR_ERR_UNSUPPORTED, "ctc_fwd: Umax=%d too long (U+1 must be <= 512)", Umax);
@@ -933,6 +1016,7 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
         hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(B * L), dim3(256), 0, s, logits, ldl, in_len, targets, L, V, Umax, blank, lse,
                            lp_ext);
         launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, 0, L, 1);
+        if (mean_loss) hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, tgt_len, B, mean_loss);
         ASR_LAUNCH_CHECK("ctc_loss_fwd");
         return 0;
     }
@@ -940,21 +1024,23 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     // the alpha workspace), recursion workgroups of the same grid consume them as they arrive
     // knobs for A/B runs (defaults are the measured best): ASR_AMD_CTC_RPB rows per pass workgroup, ASR_AMD_CTC_RING ring pairs,
     // ASR_AMD_CTC_DBG bit 2: pass only (no recursion: timing experiment, results invalid)
-    static const int rpb = [] { const char* e = getenv("ASR_AMD_CTC_RPB"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : (v == 2 ? 2 : 4); }();
+    static const int rpb = [] { const char* e = getenv("ASR_AMD_CTC_RPB"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : (v == 2 ? 2 : (v == 1 ? 1 : 4)); }();
     static const int ringp = [] { const char* e = getenv("ASR_AMD_CTC_RING"); return e ? atoi(e) : 8; }();
     static const int dbg = [] { const char* e = getenv("ASR_AMD_CTC_DBG"); return e ? atoi(e) : 0; }();
     int W, nc;
     ctc_chunking(L, n_chunks, W, nc);
     const int Sp = ctc_row_stride(Umax);
-    ASR_REQUIRE(2 * nc <= Sp, ASR_ERR_UNSUPPORTED, "ctc_fwd: too many chunks (%d) for the counter row", nc);
     // arrival counters: 2 * nc words per utterance - in a caller-zeroed buffer when one is handed in (the trainer's per-step zero
     // arena: no memset node in front of the launch), else in row L + 1 of the alpha workspace, zeroed here
+    ASR_REQUIRE(2 * nc + 16 <= Sp, ASR_ERR_UNSUPPORTED, "ctc_fwd: too many chunks (%d) for the counter row", nc);
     int* arrivals = reinterpret_cast<int*>(zero_counters);
     int64_t arr_stride = 2 * nc;
-    if (!arrivals) {
+    int* extra = arrivals ? arrivals + (int64_t)B * 2 * nc : nullptr;      // queue heads + finished count: behind the arrival counters,
+    if (!arrivals) {                                                        // ... or behind utterance 0's in its workspace row
         arrivals = reinterpret_cast<int*>(alpha + (int64_t)(L + 1) * Sp);
         arr_stride = (int64_t)(L + 2) * Sp;
-        hipError_t e__ = hipMemset2DAsync(arrivals, (size_t)arr_stride * sizeof(float), 0, (size_t)2 * nc * sizeof(int), B, s);
+        extra = arrivals + 2 * nc;
+        hipError_t e__ = hipMemset2DAsync(arrivals, (size_t)arr_stride * sizeof(float), 0, (size_t)(2 * nc + 16) * sizeof(int), B, s);
         if (e__ != hipSuccess) {
             asr_set_error("ctc_loss_fwd: %s", hipGetErrorString(e__));
             return (int)e__;
@@ -971,12 +1057,29 @@ extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, 
     const int kdbg = (dbg & 0xff) | (rpb << 8);
     if (ringp <= 8)
         hipLaunchKernelGGL(ctc_fused_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
-                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, kdbg);
+                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, extra, mean_loss, kdbg);
     else
         hipLaunchKernelGGL(ctc_fused_fwd_kernel<10>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
-                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, kdbg);
+                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, extra, mean_loss, kdbg);
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
+}
+
+extern "C" int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
+                                int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
+                                int32_t* tgt_len, void* zero_counters, int n_chunks) {
+    return ctc_loss_fwd_impl(stream, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext, alpha, nll, tgt_len, zero_counters,
+                             n_chunks, nullptr);
+}
+
+// asr_ctc_loss_fwd + asr_ctc_mean as ONE op: loss[0] = mean_b nll[b] / max(tgt_len[b], 1) comes out of the same launch (fused form: the
+// last utterance to finish reduces the batch; otherwise the reduction kernel is queued here).
+extern "C" int asr_ctc_loss_mean_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
+                                     int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
+                                     int32_t* tgt_len, void* zero_counters, int n_chunks, float* loss) {
+    ASR_REQUIRE(loss, ASR_ERR_ARG, "ctc_loss_mean_fwd: null loss pointer");
+    return ctc_loss_fwd_impl(stream, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext, alpha, nll, tgt_len, zero_counters,
+                             n_chunks, loss);
 }
 
 // bf16 gradient (the trainer's path: the gradient is consumed by bf16 MFMA GEMMs only, which would round the f32 image on load to

@@ -515,6 +515,7 @@ _AUX = {}
 # recursion wavefronts of the same launch.  <= 1 = the two-launch form (pass, then recursion): 154-167 us at the north-star
 # shape against 133-139 fused with 32 chunks
 CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "32"))
+_CTC_COUNTERS = {}
 CTC_LAZY_OCC = os.environ.get("ASR_AMD_CTC_LAZY_OCC", "1") != "0"     # asr_ctc_loss_bwd with the second workspace (see asr_hip.h)
 
 
@@ -608,12 +609,19 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None, lse=None):
         if off + nwords <= _ARENA["buf"].numel():
             _ARENA["off"] = _ARENA["dirty"] = off + nwords
             counters = _ARENA["buf"][off:off + nwords]
-    with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
-        check(lib().asr_ctc_loss_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
-                                     _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len),
-                                     _p(counters), nck), "asr_ctc_loss_fwd")
+    if counters is None and Umax + 1 <= 64 and not torch.cuda.is_current_stream_capturing():
+        # outside a step's zero arena: one counter buffer per (device, stream), zeroed once - the kernel hands it back zeroed
+        nw = int(lib().asr_ctc_counter_words(B, L, nck))
+        if nw:
+            key = (dev.index, _stream().value, nw)
+            if key not in _CTC_COUNTERS:
+                _CTC_COUNTERS[key] = torch.zeros(nw, device=dev, dtype=torch.int32)
+            counters = _CTC_COUNTERS[key]
     loss = torch.empty(1, device=dev, dtype=torch.float32)
-    check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
+    with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
+        check(lib().asr_ctc_loss_mean_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
+                                          _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len),
+                                          _p(counters), nck, _p(loss)), "asr_ctc_loss_mean_fwd")
     return loss, st.nll, st
 
 

@@ -393,8 +393,11 @@ int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const flo
  * stores + per-chunk arrival counters kept in the alpha workspace) and the two recursion wavefronts of every utterance, resident
  * in the same grid, consume each piece as it arrives through an LDS ring: the HBM-bound pass and the latency-bound alpha / beta
  * recursion overlap.  <= 1: two launches (pass, then recursion).  Results are bit-identical.
- * zero_counters: NULL, or an int32 buffer of asr_ctc_counter_words(B, L, n_chunks) words that the CALLER has zeroed (e.g. a slice
- * of a per-step zero arena): the arrival counters then live there and the call queues no memset in front of its launch.
+ * zero_counters: NULL, or an int32 buffer of asr_ctc_counter_words(B, L, n_chunks) words that are ZERO when the kernel starts (a slice of
+ * a per-step zero arena, or a buffer zeroed once): the arrival counters, the pass workgroups' queue heads and the finished-utterance
+ * count then live there and the call queues no memset in front of its launch.  The kernel leaves the words zero again when it ends
+ * (the last utterance to finish clears them), so ONE buffer per stream serves every call on that stream.
+ * asr_ctc_loss_mean_fwd is the same call with the batch reduction of asr_ctc_mean folded in (loss.py:41-43 in one launch).
  */
 /* The CTC branch's vocabulary projection with the row log-sum-exp taken in the same launch (transformer.py:119,148 `ctc_fc`: Linear
  * d_model -> V without bias, d_model = 256; loss.py:41 `F.log_softmax`): logits f32 [M, V] (row stride ldl floats, a multiple of 4; pad
@@ -408,6 +411,9 @@ int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
                      int32_t* tgt_len, void* zero_counters, int n_chunks);
+int asr_ctc_loss_mean_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
+                          int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
+                          int32_t* tgt_len, void* zero_counters, int n_chunks, float* loss);
 /* number of 32-bit words of the optional caller-zeroed counter buffer of the fused forward (0: the call would not take the fused form) */
 int64_t asr_ctc_counter_words(int B, int L, int n_chunks);
 /* mean_b(nll_b / max(tgt_len_b,1))  — reduction='mean' of F.ctc_loss.  loss: f32 [1]. */
