@@ -440,6 +440,20 @@ struct FfnBwdArgs {
     bf16_t* dhid;
     float* dx;
     int M, dff, Mp;
+    // LNB: dx is the gradient wrt a LayerNorm output and nothing else reads it - the backward of that LayerNorm
+    // (asr_add_layernorm_bwd's arithmetic) is the epilogue, on the rows as they leave the accumulators
+    const float* ln_s;
+    const float* ln_mean;
+    const float* ln_rstd;
+    const float* ln_gamma;
+    const int32_t* row_len;
+    int L;
+    float* ds_out;
+    bf16_t* ds16_out;
+    float* dgamma;
+    float* dbeta;
+    float* dbias;
+    asr_dropout_t drop_x;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -450,6 +464,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p, int second_off
     return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
 }
 
+template <bool LNB>
 __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * W1BUF + 2 * W2BUF + HST_BYTES];
     unsigned char* const w2s = smem;                    // first product's weights here
@@ -632,13 +647,96 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<f32x4*>(tile + r * 1024 + (((8 * t + 2 * g + h) ^ (r & 7)) << 4)) =
                 f32x4{Y[t][4 * g], Y[t][4 * g + 1], Y[t][4 * g + 2], Y[t][4 * g + 3]};
-    const auto rsx = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
+    if constexpr (!LNB) {
+        const auto rsx = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
 #pragma unroll
-    for (int tr = 0; tr < 32; ++tr) {
-        const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (tr & 7)) << 4));
-        const f32x4 v = y + res[tr];
-        const int row = m0 + tr;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsx, row < a.M ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u, 0, 0);
+        for (int tr = 0; tr < 32; ++tr) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (tr & 7)) << 4));
+            const f32x4 v = y + res[tr];
+            const int row = m0 + tr;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsx, row < a.M ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u, 0, 0);
+        }
+    } else {
+        // ---- ... and the backward of the LayerNorm whose output this sub-layer read (attention.py:60 in the encoder layer): a row lies
+        // across the wave exactly as add_layernorm_bwd_kernel holds it (lane = 4 columns), so this is that kernel's arithmetic on rows
+        // that never went to memory as dx:  d = dx (0 for masked rows);  xh = (s - mean) * rstd;  g = d * gamma;
+        //   ds = (g - mean(g) - xh * mean(g * xh)) * rstd;   dgamma += d * xh, dbeta += d, dbias += dropout_x(ds)   (column sums)
+        // The 32 rows of the pre-norm sum are requested up front (the accumulators' registers are free now).
+        f32x4 srow[32];
+#pragma unroll
+        for (int tr = 0; tr < 32; ++tr) {
+            const int rowc = m0 + tr < a.M ? m0 + tr : a.M - 1;
+            srow[tr] = *reinterpret_cast<const f32x4*>(a.ln_s + (int64_t)rowc * FD + 4 * lane);
+        }
+        const int myrow = m0 + r < a.M ? m0 + r : a.M - 1;                    // lane (and lane + 32) keep row r's statistics
+        const float mu_l = a.ln_mean[myrow], rs_l = a.ln_rstd[myrow];
+        const int b_l = myrow / a.L, t_l = myrow - b_l * a.L;
+        const int keep_l = (m0 + r < a.M && t_l < (a.row_len ? a.row_len[b_l] : a.L)) ? 1 : 0;
+        const f32x4 gam = *reinterpret_cast<const f32x4*>(a.ln_gamma + 4 * lane);
+        const asr_dropout_t drop = drop_resolve(a.drop_x);
+        const float scx = drop_scale(drop);
+        const auto rso = __builtin_amdgcn_make_buffer_rsrc(a.ds_out, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
+        const auto rsh16 = __builtin_amdgcn_make_buffer_rsrc(a.ds16_out, 0, (int)((int64_t)a.M * FD * 2), 0x00020000);
+        f32x4 ag = {0, 0, 0, 0}, ab = {0, 0, 0, 0}, as = {0, 0, 0, 0};
+        int bb = m0 / a.L, tt = m0 - bb * a.L;                                 // (utterance, frame) of row m0 + tr, kept in step
+        constexpr int RW = 4;                                                 // rows in flight together: their reductions interleave
+#pragma unroll
+        for (int tp = 0; tp < 32; tp += RW) {
+            f32x4 d[RW], xh[RW], g[RW];
+            float s1[RW], s2[RW], rs[RW];
+#pragma unroll
+            for (int u = 0; u < RW; ++u) {
+                const int tr = tp + u;
+                const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (tr & 7)) << 4));
+                const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mu_l), tr));
+                rs[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs_l), tr));
+                const bool keep = __builtin_amdgcn_readlane(keep_l, tr) != 0;
+                d[u] = keep ? y + res[tr] : f32x4{0, 0, 0, 0};
+                xh[u] = (srow[tr] - mu) * rs[u];
+                ag += d[u] * xh[u];
+                ab += d[u];
+                g[u] = d[u] * gam;
+                const f32x4 gx = g[u] * xh[u];
+                s1[u] = (g[u][0] + g[u][1]) + (g[u][2] + g[u][3]);
+                s2[u] = (gx[0] + gx[1]) + (gx[2] + gx[3]);
+            }
+#pragma unroll
+            for (int u = 0; u < RW; ++u) {
+                s1[u] = wave_sum_dpp(s1[u]);
+                s2[u] = wave_sum_dpp(s2[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RW; ++u) {
+                const int row = m0 + tp + u;
+                const float m1 = s1[u] * (1.f / FD), m2 = s2[u] * (1.f / FD);
+                f32x4 o = (g[u] - m1 - xh[u] * m2) * rs[u];
+                const unsigned off = row < a.M ? (unsigned)row * FD : 0x20000000u;      // (in elements; past the buffer for a row that is not there)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rso, off * 4u + 16u * lane, 0, 0);     // gradient wrt the residual
+                if (drop.thr16)                                                         // gradient wrt the projection's output (dropout's input)
+                    o = drop4(drop, drop_subkey(drop, (uint32_t)bb), (uint32_t)tt, FD >> 1, 4 * lane, o, scx);
+                as += o;
+                const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsh16, off * 2u + 8u * lane, 0, 0);
+                if (++tt == a.L) { tt = 0; ++bb; }
+            }
+        }
+        // column sums: the four waves' partials meet in LDS (the tiles are done with), one atomic per column and workgroup
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[(0 * 4 + wave) * FD + 4 * lane + k] = ag[k];
+            red[(1 * 4 + wave) * FD + 4 * lane + k] = ab[k];
+            red[(2 * 4 + wave) * FD + 4 * lane + k] = as[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int which = 0; which < 3; ++which) {
+            float* dst = which == 0 ? a.dgamma : (which == 1 ? a.dbeta : a.dbias);
+            if (!dst) continue;
+            const float v = (red[(which * 4 + 0) * FD + tid] + red[(which * 4 + 1) * FD + tid]) + (red[(which * 4 + 2) * FD + tid] + red[(which * 4 + 3) * FD + tid]);
+            atomicAdd(dst + tid, v);
+        }
     }
 }
 
@@ -923,9 +1021,33 @@ extern "C" int asr_ffn_bwd(void* stream, const void* ds16, const float* ds32, co
     ASR_REQUIRE(ds16 && ds32 && w1 && w2 && bits && dhid_out && dx_out, -1, "asr_ffn_bwd: null argument");
     ASR_REQUIRE(asr_aligned(ds16, 16) && asr_aligned(ds32, 16) && asr_aligned(w1, 16) && asr_aligned(w2, 16) && asr_aligned(dhid_out, 16) &&
                     asr_aligned(dx_out, 16), -1, "asr_ffn_bwd: 16-byte aligned buffers required");
-    FfnBwdArgs a{(const bf16_t*)ds16, ds32, (const bf16_t*)w1, (const bf16_t*)w2, (const uint32_t*)bits, (bf16_t*)dhid_out, dx_out, M, d_ff,
-                 (M + FBM - 1) / FBM * FBM};
-    hipLaunchKernelGGL(ffn_bwd_kernel, dim3((M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, a);
+    FfnBwdArgs a{};
+    a.ds16 = (const bf16_t*)ds16; a.ds32 = ds32; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.bits = (const uint32_t*)bits;
+    a.dhid = (bf16_t*)dhid_out; a.dx = dx_out; a.M = M; a.dff = d_ff; a.Mp = (M + FBM - 1) / FBM * FBM;
+    hipLaunchKernelGGL(ffn_bwd_kernel<false>, dim3((M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_ffn_bwd");
+    return 0;
+}
+
+extern "C" int asr_ffn_bwd_ln(void* stream, const void* ds16, const float* ds32, const void* w1, const void* w2, const void* bits,
+                              void* dhid_out, int B, int L, int d_model, int d_ff, const float* ln_s, const float* ln_mean,
+                              const float* ln_rstd, const float* ln_gamma, const int32_t* row_len, float* ds_out, void* ds16_out,
+                              float* dgamma, float* dbeta, float* dbias, asr_dropout_t drop_x) {
+    ASR_REQUIRE(d_model == FD, -1, "asr_ffn_bwd_ln: d_model = %d (the fused sub-layer is built for 256)", d_model);
+    ASR_REQUIRE(d_ff >= FHC && d_ff % FHC == 0 && d_ff <= FFN_MAX_DFF, -1, "asr_ffn_bwd_ln: d_ff = %d (a multiple of 64 up to %d)", d_ff, FFN_MAX_DFF);
+    ASR_REQUIRE(B > 0 && L > 0 && (int64_t)B * L * d_ff * 2 < (1ll << 31), -1, "asr_ffn_bwd_ln: B * L out of range");
+    const int M = B * L;
+    ASR_REQUIRE(ds16 && ds32 && w1 && w2 && bits && dhid_out && ln_s && ln_mean && ln_rstd && ln_gamma && ds_out && ds16_out && dgamma && dbeta,
+                -1, "asr_ffn_bwd_ln: null argument");
+    ASR_REQUIRE(asr_aligned(ds16, 16) && asr_aligned(ds32, 16) && asr_aligned(w1, 16) && asr_aligned(w2, 16) && asr_aligned(dhid_out, 16) &&
+                    asr_aligned(ln_s, 16) && asr_aligned(ln_gamma, 16) && asr_aligned(ds_out, 16) && asr_aligned(ds16_out, 16),
+                -1, "asr_ffn_bwd_ln: 16-byte aligned buffers required");
+    FfnBwdArgs a{};
+    a.ds16 = (const bf16_t*)ds16; a.ds32 = ds32; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.bits = (const uint32_t*)bits;
+    a.dhid = (bf16_t*)dhid_out; a.dx = nullptr; a.M = M; a.dff = d_ff; a.Mp = (M + FBM - 1) / FBM * FBM;
+    a.ln_s = ln_s; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_gamma = ln_gamma; a.row_len = row_len; a.L = L;
+    a.ds_out = ds_out; a.ds16_out = (bf16_t*)ds16_out; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.drop_x = drop_x;
+    hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3((M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, a);
+    ASR_LAUNCH_CHECK("asr_ffn_bwd_ln");
     return 0;
 }

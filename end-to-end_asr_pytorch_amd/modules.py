@@ -26,6 +26,11 @@ from . import ops
 
 _PRECISION = os.environ.get("ASR_AMD_PRECISION", "bf16")
 _LOG2E = 1.4426950408889634
+# 1 = the attention sub-layer's LayerNorm backward inside the feed-forward sub-layer's data-gradient launch (asr_ffn_bwd_ln).  Off: measured
+# neutral at S1 (11.19 / 11.29 against 11.12 / 11.28 ms) - the launch grows by 24.5 us (129.4 against 104.9) where it saves a 19 us kernel
+# and a 5 us gap: ffn_bwd is ONE round of 250 workgroups at one wave per SIMD, so the 82 MB the epilogue still moves (s in, ds and
+# ds16 out) go through a chip that is doing nothing else, while the stand-alone kernel runs beside the weight-gradient stream.
+_FOLD_LN = os.environ.get("ASR_AMD_FOLD_LN", "0") == "1"
 _MASK_PREFETCH = os.environ.get("ASR_AMD_MASK_PREFETCH", "1") != "0"
 _MASK_GROUP = os.environ.get("ASR_AMD_MASK_GROUP", "1") != "0"      # short sequences: the encoder's attention-dropout masks 8 sites per launch
 
@@ -351,10 +356,13 @@ class _Cached(nn.Module):
 
 class Act:
     """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
-    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q")
+    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q", "ln_ctx", "ln_done")
 
     def __init__(self, f32, b16, B, L):
         self.f32, self.b16, self.B, self.L, self.grad, self.needs_grad = f32, b16, B, L, None, False
+        # a LayerNorm output whose ONLY reader may run that LayerNorm's backward in its own data-gradient launch (asr_ffn_bwd_ln):
+        # ln_ctx = what the backward needs (set by the producer), ln_done = (ds, ds16) once a reader has done it
+        self.ln_ctx = self.ln_done = None
         self.next_q = None       # decode step: the next cross attention's projected queries, when the launch that made this produced them
 
     def mma(self):
@@ -467,9 +475,15 @@ class MultiheadAttention(_Cached):
         qkvw = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight)
         qkvb = (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)
 
+        y.ln_ctx = (s_sum, mean, rstd, ln, row_len, fc.bias, dp_fc)
+
         def bw():
-            ds, ds16 = _ln_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
-                                  dbias=fc.bias.grad, drop_x=dp_fc)
+            if y.ln_done is not None:          # the feed-forward sub-layer behind this one ran the LayerNorm's backward in its own launch
+                ds, ds16 = y.ln_done
+                y.ln_done = None
+            else:
+                ds, ds16 = _ln_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
+                                      dbias=fc.bias.grad, drop_x=dp_fc)
             y.grad = None
             _wg(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
             gdt = _cdtype()
@@ -637,12 +651,23 @@ class PositionwiseFeedForward(_Cached):
                 ds, ds16 = _ln_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
                                       dbias=w2.bias.grad, drop_x=dp)
                 y.grad = None
-                d_hid, dx = ops.ffn_bwd(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits)
+                fold = _FOLD_LN and x.ln_ctx is not None and x.grad is None and _PRECISION == "bf16"
+                if fold:
+                    # x is a LayerNorm output that only this sub-layer read (encoder.py:74-76): dx goes through that LayerNorm's
+                    # backward in ffn_bwd's epilogue instead of through memory and a launch of its own
+                    p_s, p_mean, p_rstd, p_ln, p_len, p_bias, p_drop = x.ln_ctx
+                    d_hid, p_ds, p_ds16 = ops.ffn_bwd_ln(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits, x.B, x.L,
+                                                         p_s, p_mean, p_rstd, p_ln.weight, p_len, p_ln.weight.grad, p_ln.bias.grad,
+                                                         dbias=p_bias.grad, drop_x=p_drop)
+                    x.ln_done = (p_ds, p_ds16)
+                else:
+                    d_hid, dx = ops.ffn_bwd(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits)
                 # (both weight gradients behind the data gradient: the side stream then needs ONE event of the main chain per sub-layer,
                 # recorded after ffn_bwd - an event recorded between LayerNorm backward and ffn_bwd held the latter back ~5 us)
                 _wg(ds16, hid, out=w2.weight.grad, accumulate=True)
                 _wg(d_hid, x.mma(), out=w1.weight.grad, accumulate=True, colsum=w1.bias.grad)
-                _acc(x, dx)
+                if not fold:
+                    _acc(x, dx)
 
             _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
         return y

@@ -376,6 +376,23 @@ def ffn_bwd(ds16, ds32, w1, w2, bits):
     return d_hid, dx
 
 
+def ffn_bwd_ln(ds16, ds32, w1, w2, bits, B, L, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, dgamma, dbeta, dbias=None, drop_x=None):
+    """ffn_bwd whose dx goes straight through the backward of the LayerNorm that produced the sub-layer's input (asr_ffn_bwd_ln):
+    -> (d_hid bf16 [M,d_ff], ds f32 [M,256], ds16 bf16 [M,256]) with ds / ds16 as add_layernorm_bwd(dy=dx, ...) returns them;
+    dgamma / dbeta / dbias accumulated in place."""
+    _req_cuda(ds16, ds32, w1, w2, bits, ln_s, ln_mean, ln_rstd, ln_gamma, dgamma, dbeta)
+    M, dff = ds32.shape[0], w1.shape[0]
+    assert M == B * L and ds16.dtype == torch.bfloat16 and ds16.is_contiguous() and ds32.is_contiguous() and ln_s.is_contiguous()
+    d_hid = torch.empty((M, dff), device=ds32.device, dtype=torch.bfloat16)
+    ds = torch.empty((M, 256), device=ds32.device, dtype=torch.float32)
+    ds_b = torch.empty((M, 256), device=ds32.device, dtype=torch.bfloat16)
+    with _timed("ffn_bwd[%dx256x%d]" % (M, dff), 4.0 * M * 256 * dff):
+        check(lib().asr_ffn_bwd_ln(_stream(), _p(ds16), _p(ds32), _p(w1), _p(w2), _p(bits), _p(d_hid), B, L, 256, dff, _p(ln_s), _p(ln_mean),
+                                   _p(ln_rstd), _p(ln_gamma), _p(row_len), _p(ds), _p(ds_b), _p(dgamma), _p(dbeta), _p(dbias), _d(drop_x)),
+              "asr_ffn_bwd_ln")
+    return d_hid, ds, ds_b
+
+
 def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf16=False, eps=1e-5, save_stats=False,
                   drop_x=None, drop_y=None):
     """y = LN(x [+ residual]) [+ pe[t]] [masked to t < row_len[b]] -> (y32 [B*L,D], y16 or None, mean, rstd).

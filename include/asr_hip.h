@@ -259,6 +259,15 @@ int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, cons
  * dhid_out bf16 [M, d_ff] (written once, for dW1 = dH^T x and db1 = colsum dH), dx_out f32 [M, 256]. */
 int asr_ffn_bwd(void* stream, const void* ds16, const float* ds32, const void* w1, const void* w2, const void* bits, void* dhid_out,
                 float* dx_out, int M, int d_model, int d_ff);
+/* asr_ffn_bwd with the backward of the LayerNorm that produced the sub-layer's input folded into its epilogue (encoder.py:74-76: the
+ * feed-forward sub-layer is the only reader of the attention sub-layer's output, attention.py:60): dx never goes to memory; the launch
+ * leaves what asr_add_layernorm_bwd(dy = dx, s = ln_s, ln_mean, ln_rstd, ln_gamma, row_len, drop_x) leaves - ds_out (f32, gradient wrt
+ * that LayerNorm's residual), ds16_out (bf16, gradient wrt the normalised projection's output, dropout-masked), and dgamma / dbeta /
+ * dbias (optional) ACCUMULATED into - with the same arithmetic per row (a row lies across a wave in both kernels).  M = B * L. */
+int asr_ffn_bwd_ln(void* stream, const void* ds16, const float* ds32, const void* w1, const void* w2, const void* bits, void* dhid_out,
+                   int B, int L, int d_model, int d_ff, const float* ln_s, const float* ln_mean, const float* ln_rstd,
+                   const float* ln_gamma, const int32_t* row_len, float* ds_out, void* ds16_out, float* dgamma, float* dbeta,
+                   float* dbias, asr_dropout_t drop_x);
 
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.

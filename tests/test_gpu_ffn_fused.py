@@ -186,3 +186,39 @@ def test_proj_heads_rows_kernel_equals_the_tiled_gemm(B, L, n_proj, h, scale, mo
     d = (new.float() - old.float()).abs().cpu()
     assert float(d.max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
     assert float((d > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("B,L,dff,drop", [(4, 37, 128, False), (3, 100, 2048, True), (1, 5, 64, True), (5, 129, 512, True)])
+def test_ffn_bwd_with_the_layernorm_backward_folded_in(B, L, dff, drop):
+    """asr_ffn_bwd_ln = asr_ffn_bwd followed by asr_add_layernorm_bwd on its dx (the LayerNorm that produced the sub-layer's input,
+    attention.py:60): the same ds / ds16 / column sums, without dx in memory.  Same arithmetic per row, so the f32 outputs agree to the
+    last bits (the column sums to float-atomic order); ragged lengths, a partial last block, dropout on the projection's gradient."""
+    x32, w1, b1, w2, b2, gam, bet, lens = _case(B, L, dff, seed=11 * B + L)
+    M = B * L
+    g = torch.Generator().manual_seed(L + 1)
+    d = lambda t: t.to(DEV).contiguous()
+    hid, bits, s, y32, y16, mean, rstd = ops.ffn_fwd(d(x32.bfloat16()), d(x32), d(w1), d(b1), d(w2), d(b2), d(gam), d(bet), B, L,
+                                                     row_len=d(lens).int(), train=True)
+    ds32 = d(torch.randn(M, 256, generator=g) * 0.05)
+    ds16 = ds32.bfloat16()
+    # the LayerNorm in front of the sub-layer: its saved pre-norm sum / statistics, its own parameters and row mask
+    p_s = d(torch.randn(M, 256, generator=g))
+    p_mean, p_var = p_s.mean(-1), p_s.var(-1, unbiased=False)
+    p_rstd = 1.0 / torch.sqrt(p_var + 1e-5)
+    p_gam = d(torch.rand(256, generator=g) + 0.5)
+    lens_d = d(lens).int()
+    dp = ops.Dropout(THR, 3, 4) if drop else None
+    dg0, db0, dbias0 = (torch.zeros(256, device=DEV) for _ in range(3))
+    d_hid0, dx = ops.ffn_bwd(ds16, ds32, d(w1), d(w2), bits)
+    ds_ref, ds16_ref = ops.add_layernorm_bwd(dx, p_s, p_mean, p_rstd, p_gam, lens_d, B, L, dg0, db0, want_bf16=True, dbias=dbias0, drop_x=dp)
+    dg1, db1, dbias1 = (torch.zeros(256, device=DEV) for _ in range(3))
+    d_hid1, ds_f, ds16_f = ops.ffn_bwd_ln(ds16, ds32, d(w1), d(w2), bits, B, L, p_s, p_mean, p_rstd, p_gam, lens_d, dg1, db1, dbias=dbias1,
+                                          drop_x=dp)
+    np.testing.assert_array_equal(N(d_hid1), N(d_hid0))
+    np.testing.assert_allclose(N(ds_f), N(ds_ref), atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(N(ds16_f), N(ds16_ref), atol=1e-6, rtol=1e-2)      # (a bf16 ulp where the f32 value sits on a rounding boundary)
+    pad = (torch.arange(L)[None, :] >= lens[:, None]).reshape(-1).numpy()
+    if pad.any():
+        assert float(np.abs(N(ds_f)[pad]).max()) == 0.0                           # masked rows: no gradient
+    for a, b in ((dg1, dg0), (db1, db0), (dbias1, dbias0)):
+        np.testing.assert_allclose(N(a), N(b), atol=2e-4, rtol=1e-4)
