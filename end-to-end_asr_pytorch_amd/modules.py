@@ -356,13 +356,14 @@ class _Cached(nn.Module):
 
 class Act:
     """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
-    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q", "ln_ctx", "ln_done")
+    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q", "ln_ctx", "ln_done", "lazy_grad")
 
     def __init__(self, f32, b16, B, L):
         self.f32, self.b16, self.B, self.L, self.grad, self.needs_grad = f32, b16, B, L, None, False
         # a LayerNorm output whose ONLY reader may run that LayerNorm's backward in its own data-gradient launch (asr_ffn_bwd_ln):
         # ln_ctx = what the backward needs (set by the producer), ln_done = (ds, ds16) once a reader has done it
         self.ln_ctx = self.ln_done = None
+        self.lazy_grad = None    # a callable that adds a gradient contribution computed elsewhere (the trainer's CTC side branch) into .grad
         self.next_q = None       # decode step: the next cross attention's projected queries, when the launch that made this produced them
 
     def mma(self):
@@ -1140,7 +1141,9 @@ class Decoder(_Cached):
             _TAPE.push(bw_emb, (emb.weight,))
         cross = self._cross_kv(enc)
         # the decoder's small attention masks: one launch for all self-attention calls, one for all cross-attention calls (queueing
-        # them ahead on a side stream like the encoder's measured neutral; 12 launches on this latency-bound chain are 12 x ~5 us)
+        # them ahead on a side stream like the encoder's measured neutral; 12 launches on this latency-bound chain are 12 x ~5 us.
+        # Round 4, under the executor: forked in front of the cross K / V projection so that the 55 us of hashing run beside that
+        # 78 us GEMM - 11.18-11.54 against 11.12-11.17 ms per step: the extra chain's events cost more than the overlap gives)
         n = len(self.layer_stack)
         m_self = m_cross = [None] * n
         if self.training and x32.is_cuda and n <= 8:
@@ -1417,6 +1420,8 @@ class Decoder(_Cached):
         def bw():   # pushed before the layers -> runs after all of them have written their dK / dV columns
             dkv = box.pop("dkv")
             _wg(dkv, enc.mma(), out=_gcat(ws), accumulate=True, colsum=_gcat(bs))
+            if enc.lazy_grad is not None:
+                enc.lazy_grad()      # (the CTC branch's gradient: it becomes this GEMM's addend)
             enc.grad = ops.gemm_nn(dkv, W, addend=enc.grad)
 
         _TAPE.push(bw, tuple(ws) + tuple(bs))

@@ -272,6 +272,15 @@ class Trainer:
                 e2 = torch.cuda.Event(enable_timing=True)
                 e2.record(torch.cuda.current_stream())
                 seg.append(("enc_bwd_begin", e2))
+            take()
+
+        def take():
+            """the side branch's gradient wrt the encoder output joins enc.grad: here at the latest, or earlier from whoever adds the
+            next contribution (Decoder._cross_kv's data-gradient GEMM takes enc.grad as its addend: no add launch of its own over
+            the [B*L, d_model] gradient)"""
+            if enc.lazy_grad is None:
+                return
+            enc.lazy_grad = None
             main_now = torch.cuda.current_stream()
             main_now.wait_stream(aux)
             g = proxy.grad
@@ -279,6 +288,7 @@ class Trainer:
             modules._acc(enc, g)
             proxy.grad = None
 
+        enc.lazy_grad = take
         modules._TAPE.push(join, params)
         ctc.record_stream(main)
         return logits
