@@ -355,7 +355,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void add_layernorm_bwd_kernel(const
                                                                 const float* __restrict__ gamma, const int32_t* __restrict__ row_len,
                                                                 float* __restrict__ ds, void* __restrict__ ds16, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ dbias, int M, int L, int D,
-                                                                asr_dropout_t drop_x_in, asr_dropout_t drop_y_in) {
+                                                                asr_dropout_t drop_x_in, asr_dropout_t drop_y_in,
+                                                                const float* __restrict__ beta_y = nullptr) {
     __shared__ float red[3][LNB_WAVES][256 * MAXJ];
     const asr_dropout_t drop_x = drop_resolve(drop_x_in), drop_y = drop_resolve(drop_y_in);
     const float scx = drop_scale(drop_x), scy = drop_scale(drop_y);
@@ -431,7 +432,15 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void add_layernorm_bwd_kernel(const
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXJ; ++j) {
-            cur.xh[r][j] = (cur.xh[r][j] - cur.mu[r]) * cur.rs[r];
+            // beta_y: `s` is the LayerNorm's OUTPUT y (the forward did not keep the pre-norm sum): x^ = (y - beta) / gamma
+            if (beta_y) {
+                const int c = lane * 4 + 256 * j;
+                const f32x4 bt = (c < D) ? *reinterpret_cast<const f32x4*>(beta_y + c) : f32x4{0, 0, 0, 0};
+                const bool keepr = cur.live[r] && cur.t[r] < cur.len[r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur.xh[r][j][e] = (keepr && gam[j][e] != 0.f) ? (cur.xh[r][j][e] - bt[e]) / gam[j][e] : 0.f;
+            } else
+                cur.xh[r][j] = (cur.xh[r][j] - cur.mu[r]) * cur.rs[r];
             ag[j] += cur.d[r][j] * cur.xh[r][j];
             ab[j] += cur.d[r][j];
             const f32x4 g = cur.d[r][j] * gam[j];
@@ -679,6 +688,29 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
     ASR_LAUNCH_CHECK("add_layernorm_bwd");
+    return 0;
+}
+
+// asr_add_layernorm_bwd for a forward that kept the LayerNorm's OUTPUT instead of its pre-norm sum (the output stays alive anyway: it is
+// the next sub-layer's input and residual): x^ = (y - beta) / gamma (0 where gamma is 0 and in masked rows), everything else as above.
+extern "C" int asr_add_layernorm_bwd_y(void* stream, const float* dy, const float* y, const float* rstd, const float* gamma,
+                                       const float* beta, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
+                                       float* dbias, int B, int L, int D, asr_dropout_t drop_x) {
+    ASR_REQUIRE(dy && y && rstd && gamma && beta && ds && dgamma && dbeta, ASR_ERR_ARG, "layernorm_bwd_y: null pointer");
+    ASR_REQUIRE(drop_x.thr16 < 65536u, ASR_ERR_ARG, "layernorm_bwd_y: dropout thr16 must be < 65536");
+    ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd_y: D=%d", D);
+    const int M = B * L;
+    int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
+    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 256;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const asr_dropout_t none{0, 0, 0, nullptr};
+    if (D <= 256)
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, y, rstd, rstd, gamma,
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, none, beta);
+    else
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, y, rstd, rstd, gamma,
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, none, beta);
+    ASR_LAUNCH_CHECK("add_layernorm_bwd_y");
     return 0;
 }
 

@@ -446,6 +446,7 @@ struct FfnBwdArgs {
     const float* ln_mean;
     const float* ln_rstd;
     const float* ln_gamma;
+    const float* ln_beta;     // non-null: ln_s holds the LayerNorm's output y, x^ = (y - beta) / gamma
     const int32_t* row_len;
     int L;
     float* ds_out;
@@ -669,10 +670,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
             srow[tr] = *reinterpret_cast<const f32x4*>(a.ln_s + (int64_t)rowc * FD + 4 * lane);
         }
         const int myrow = m0 + r < a.M ? m0 + r : a.M - 1;                    // lane (and lane + 32) keep row r's statistics
-        const float mu_l = a.ln_mean[myrow], rs_l = a.ln_rstd[myrow];
+        const float mu_l = a.ln_mean ? a.ln_mean[myrow] : 0.f, rs_l = a.ln_rstd[myrow];
         const int b_l = myrow / a.L, t_l = myrow - b_l * a.L;
         const int keep_l = (m0 + r < a.M && t_l < (a.row_len ? a.row_len[b_l] : a.L)) ? 1 : 0;
         const f32x4 gam = *reinterpret_cast<const f32x4*>(a.ln_gamma + 4 * lane);
+        const f32x4 betav = a.ln_beta ? *reinterpret_cast<const f32x4*>(a.ln_beta + 4 * lane) : f32x4{0, 0, 0, 0};
         const asr_dropout_t drop = drop_resolve(a.drop_x);
         const float scx = drop_scale(drop);
         const auto rso = __builtin_amdgcn_make_buffer_rsrc(a.ds_out, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
@@ -692,7 +694,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
                 rs[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rs_l), tr));
                 const bool keep = __builtin_amdgcn_readlane(keep_l, tr) != 0;
                 d[u] = keep ? y + res[tr] : f32x4{0, 0, 0, 0};
-                xh[u] = (srow[tr] - mu) * rs[u];
+                if (a.ln_beta) {      // ln_s is the LayerNorm's OUTPUT (the forward kept no pre-norm sum): x^ = (y - beta) / gamma
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xh[u][e] = (keep && gam[e] != 0.f) ? (srow[tr][e] - betav[e]) / gam[e] : 0.f;
+                } else
+                    xh[u] = (srow[tr] - mu) * rs[u];
                 ag += d[u] * xh[u];
                 ab += d[u];
                 g[u] = d[u] * gam;
@@ -996,7 +1002,7 @@ extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* res
     ASR_REQUIRE(d_model == FD, -1, "asr_proj_ln_fwd: d_model = %d (built for 256 = h * d_v inputs and 256 outputs)", d_model);
     ASR_REQUIRE(M64 > 0 && M64 * FD * 4 < (1ll << 31), -1, "asr_proj_ln_fwd: B * L out of range");
     ASR_REQUIRE(ctx16 && residual && w && bias && gamma && beta && y32, -1, "asr_proj_ln_fwd: null argument");
-    ASR_REQUIRE(s_out || (!mean_out && !rstd_out), -1, "asr_proj_ln_fwd: mean_out / rstd_out come with s_out (training)");
+    const bool train = s_out || mean_out || rstd_out;      // (s_out alone may be NULL in training: the backward then takes x^ from y32)
     ASR_REQUIRE(asr_aligned(ctx16, 16) && asr_aligned(residual, 16) && asr_aligned(w, 16) && asr_aligned(y32, 16) && asr_aligned(s_out, 16) &&
                     asr_aligned(y16, 8) && asr_aligned(bias, 16) && asr_aligned(gamma, 16) && asr_aligned(beta, 16), -1,
                 "asr_proj_ln_fwd: 16-byte aligned buffers required");
@@ -1005,8 +1011,8 @@ extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* res
                  (bf16_t*)y16, mean_out, rstd_out, M, L, FD, (M + FBM - 1) / FBM * FBM, eps, drop_x, 0};
     const dim3 grid((M + FBM - 1) / FBM), block(256);
     const bool dr = drop_x.thr16 != 0;
-    if (s_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, a);
-    else if (s_out) hipLaunchKernelGGL((ffn_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, a);
+    if (train && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (train) hipLaunchKernelGGL((ffn_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, a);
     else if (dr) hipLaunchKernelGGL((ffn_fwd_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((ffn_fwd_kernel<false, false, true>), grid, block, 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_proj_ln_fwd");
@@ -1031,13 +1037,13 @@ extern "C" int asr_ffn_bwd(void* stream, const void* ds16, const float* ds32, co
 
 extern "C" int asr_ffn_bwd_ln(void* stream, const void* ds16, const float* ds32, const void* w1, const void* w2, const void* bits,
                               void* dhid_out, int B, int L, int d_model, int d_ff, const float* ln_s, const float* ln_mean,
-                              const float* ln_rstd, const float* ln_gamma, const int32_t* row_len, float* ds_out, void* ds16_out,
-                              float* dgamma, float* dbeta, float* dbias, asr_dropout_t drop_x) {
+                              const float* ln_rstd, const float* ln_gamma, const float* ln_beta, const int32_t* row_len, float* ds_out,
+                              void* ds16_out, float* dgamma, float* dbeta, float* dbias, asr_dropout_t drop_x) {
     ASR_REQUIRE(d_model == FD, -1, "asr_ffn_bwd_ln: d_model = %d (the fused sub-layer is built for 256)", d_model);
     ASR_REQUIRE(d_ff >= FHC && d_ff % FHC == 0 && d_ff <= FFN_MAX_DFF, -1, "asr_ffn_bwd_ln: d_ff = %d (a multiple of 64 up to %d)", d_ff, FFN_MAX_DFF);
     ASR_REQUIRE(B > 0 && L > 0 && (int64_t)B * L * d_ff * 2 < (1ll << 31), -1, "asr_ffn_bwd_ln: B * L out of range");
     const int M = B * L;
-    ASR_REQUIRE(ds16 && ds32 && w1 && w2 && bits && dhid_out && ln_s && ln_mean && ln_rstd && ln_gamma && ds_out && ds16_out && dgamma && dbeta,
+    ASR_REQUIRE(ds16 && ds32 && w1 && w2 && bits && dhid_out && ln_s && (ln_mean || ln_beta) && ln_rstd && ln_gamma && ds_out && ds16_out && dgamma && dbeta,
                 -1, "asr_ffn_bwd_ln: null argument");
     ASR_REQUIRE(asr_aligned(ds16, 16) && asr_aligned(ds32, 16) && asr_aligned(w1, 16) && asr_aligned(w2, 16) && asr_aligned(dhid_out, 16) &&
                     asr_aligned(ln_s, 16) && asr_aligned(ln_gamma, 16) && asr_aligned(ds_out, 16) && asr_aligned(ds16_out, 16),
@@ -1045,7 +1051,7 @@ extern "C" int asr_ffn_bwd_ln(void* stream, const void* ds16, const float* ds32,
     FfnBwdArgs a{};
     a.ds16 = (const bf16_t*)ds16; a.ds32 = ds32; a.w1 = (const bf16_t*)w1; a.w2 = (const bf16_t*)w2; a.bits = (const uint32_t*)bits;
     a.dhid = (bf16_t*)dhid_out; a.dx = nullptr; a.M = M; a.dff = d_ff; a.Mp = (M + FBM - 1) / FBM * FBM;
-    a.ln_s = ln_s; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_gamma = ln_gamma; a.row_len = row_len; a.L = L;
+    a.ln_s = ln_s; a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.row_len = row_len; a.L = L;
     a.ds_out = ds_out; a.ds16_out = (bf16_t*)ds16_out; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.drop_x = drop_x;
     hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3((M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_ffn_bwd_ln");

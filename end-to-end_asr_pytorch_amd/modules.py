@@ -31,6 +31,11 @@ _LOG2E = 1.4426950408889634
 # and a 5 us gap: ffn_bwd is ONE round of 250 workgroups at one wave per SIMD, so the 82 MB the epilogue still moves (s in, ds and
 # ds16 out) go through a chip that is doing nothing else, while the stand-alone kernel runs beside the weight-gradient stream.
 _FOLD_LN = os.environ.get("ASR_AMD_FOLD_LN", "0") == "1"
+# 1 = the one-launch sub-layers at encoder size (asr_ffn_fwd, asr_proj_ln_fwd) do not store the pre-norm sum: the LayerNorm's backward takes
+# x^ = (y - beta) / gamma from the OUTPUT, which stays alive anyway (33 MB less to write and to hold per LayerNorm, 24 of them per S1 step:
+# 0.8 GB of activations).  Off by default: a memory option, not a faster step (11.27-11.50 against 11.22-11.26 ms on one box).
+_LN_FROM_Y = os.environ.get("ASR_AMD_LN_FROM_Y", "0") == "1"
+_FOLD_LN_QKV = os.environ.get("ASR_AMD_FOLD_LN_QKV", "1") != "0"     # A/B: 0 = the feed-forward sub-layer's LayerNorm backward as its own launch
 _MASK_PREFETCH = os.environ.get("ASR_AMD_MASK_PREFETCH", "1") != "0"
 _MASK_GROUP = os.environ.get("ASR_AMD_MASK_GROUP", "1") != "0"      # short sequences: the encoder's attention-dropout masks 8 sites per launch
 
@@ -456,7 +461,7 @@ class MultiheadAttention(_Cached):
         elif _PRECISION == "bf16" and ops.proj_ln_ok(ctx2, wfc, xq.f32.shape[1], B, Lq):      # the same at encoder size (csrc/ffn.hip, PROJ)
             o, y32, y16, mean, rstd = ops.proj_ln(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
                                                   self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps, save_stats=rec,
-                                                  drop_x=dp_fc)
+                                                  drop_x=dp_fc, save_s=not _LN_FROM_Y)
         else:
             o = ops.gemm_nt(ctx2, wfc, self._b("bfc", (self.fc.bias,)))
             y32, y16, mean, rstd = ops.add_layernorm(o, xq.f32, self.layer_norm.weight, self.layer_norm.bias, B, Lq, row_len=row_len,
@@ -476,15 +481,17 @@ class MultiheadAttention(_Cached):
         qkvw = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight)
         qkvb = (self.w_qs.bias, self.w_ks.bias, self.w_vs.bias)
 
-        y.ln_ctx = (s_sum, mean, rstd, ln, row_len, fc.bias, dp_fc)
+        from_y = s_sum is None         # (the forward kept no pre-norm sum: x^ comes from the output, ops.add_layernorm_bwd(beta=))
+        ln_in, ln_beta = (y.f32, ln.bias) if from_y else (s_sum, None)
+        y.ln_ctx = (ln_in, mean, rstd, ln, row_len, fc.bias, dp_fc, ln_beta)
 
         def bw():
             if y.ln_done is not None:          # the feed-forward sub-layer behind this one ran the LayerNorm's backward in its own launch
                 ds, ds16 = y.ln_done
                 y.ln_done = None
             else:
-                ds, ds16 = _ln_bwd(y.grad, s_sum, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
-                                      dbias=fc.bias.grad, drop_x=dp_fc)
+                ds, ds16 = _ln_bwd(y.grad, ln_in, mean, rstd, ln.weight, row_len, B, Lq, ln.weight.grad, ln.bias.grad,
+                                      dbias=fc.bias.grad, drop_x=dp_fc, beta=ln_beta)
             y.grad = None
             _wg(ds16, ctx.view(B * Lq, hd), out=fc.weight.grad, accumulate=True)
             gdt = _cdtype()
@@ -494,7 +501,15 @@ class MultiheadAttention(_Cached):
                 ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dqkv[:, :hd], dqkv[:, hd:2 * hd], dqkv[:, 2 * hd:],
                                   drop=dp_attn, drop_bits=dbits)
                 _wg(dqkv, xq.mma(), out=_gcat(qkvw), accumulate=True, colsum=_gcat(qkvb))
-                _acc(xq, ops.gemm_nn(dqkv, self._w("qkv", qkvw), addend=ds))
+                wqkv = self._w("qkv", qkvw)
+                if _FOLD_LN_QKV and xq.ln_ctx is not None and xq.grad is None and ops.dgrad_rows_ok(dqkv, wqkv):
+                    # xq is a LayerNorm output that only this sub-layer read (encoder.py:74-77): its gradient goes through that
+                    # LayerNorm's backward in the data-gradient launch itself (asr_dgrad_rows_ln) - no dx in memory, no launch of its own
+                    p_s, p_mean, p_rstd, p_ln, p_len, p_bias, p_drop, p_beta = xq.ln_ctx
+                    xq.ln_done = ops.gemm_nn_ln(dqkv, wqkv, ds, B, Lq, p_s, p_mean, p_rstd, p_ln.weight, p_len, p_ln.weight.grad,
+                                                p_ln.bias.grad, dbias=p_bias.grad, drop_x=p_drop, ln_beta=p_beta)
+                else:
+                    _acc(xq, ops.gemm_nn(dqkv, wqkv, addend=ds))
             else:
                 dq = torch.empty((B * Lq, hd), device=ds.device, dtype=gdt)
                 if dkv_pre is not None:
@@ -645,21 +660,29 @@ class PositionwiseFeedForward(_Cached):
         w1m, w2m = self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,))
         dp = _drop(self, "dropout")   # module.py:51
         hid, bits, o, y32, y16, mean, rstd = ops.ffn_fwd(x.b16, x.f32, w1m, self._b("b1", (w1.bias,)), w2m, self._b("b2", (w2.bias,)),
-                                                         ln.weight, ln.bias, x.B, x.L, row_len=row_len, eps=ln.eps, train=rec, drop_x=dp)
+                                                         ln.weight, ln.bias, x.B, x.L, row_len=row_len, eps=ln.eps, train=rec, drop_x=dp,
+                                                         save_s=not _LN_FROM_Y)
         y = Act(y32, y16, x.B, x.L)
         if rec:
+            ln_in, ln_beta = (y32, ln.bias) if o is None else (o, None)
+            y.ln_ctx = (ln_in, mean, rstd, ln, row_len, w2.bias, dp, ln_beta)
+
             def bw():
-                ds, ds16 = _ln_bwd(y.grad, o, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
-                                      dbias=w2.bias.grad, drop_x=dp)
+                if y.ln_done is not None:      # the next layer's attention sub-layer ran this LayerNorm's backward in its data-gradient launch
+                    ds, ds16 = y.ln_done
+                    y.ln_done = None
+                else:
+                    ds, ds16 = _ln_bwd(y.grad, ln_in, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
+                                          dbias=w2.bias.grad, drop_x=dp, beta=ln_beta)
                 y.grad = None
                 fold = _FOLD_LN and x.ln_ctx is not None and x.grad is None and _PRECISION == "bf16"
                 if fold:
                     # x is a LayerNorm output that only this sub-layer read (encoder.py:74-76): dx goes through that LayerNorm's
                     # backward in ffn_bwd's epilogue instead of through memory and a launch of its own
-                    p_s, p_mean, p_rstd, p_ln, p_len, p_bias, p_drop = x.ln_ctx
+                    p_s, p_mean, p_rstd, p_ln, p_len, p_bias, p_drop, p_beta = x.ln_ctx
                     d_hid, p_ds, p_ds16 = ops.ffn_bwd_ln(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits, x.B, x.L,
                                                          p_s, p_mean, p_rstd, p_ln.weight, p_len, p_ln.weight.grad, p_ln.bias.grad,
-                                                         dbias=p_bias.grad, drop_x=p_drop)
+                                                         dbias=p_bias.grad, drop_x=p_drop, ln_beta=p_beta)
                     x.ln_done = (p_ds, p_ds16)
                 else:
                     d_hid, dx = ops.ffn_bwd(ds16, ds, self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits)

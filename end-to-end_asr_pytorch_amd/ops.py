@@ -311,14 +311,14 @@ def proj_ln_ok(a2d, w, D, B, L):
             w.dtype == torch.bfloat16 and a2d.shape[1] == 256 and a2d.is_contiguous() and w.is_contiguous() and B * L * 1024 < 2 ** 31)
 
 
-def proj_ln(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=True, eps=1e-5, save_stats=False, drop_x=None):
+def proj_ln(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=True, eps=1e-5, save_stats=False, drop_x=None, save_s=True):
     """LayerNorm(dropout_x(A . W^T + bias) + residual) for encoder-sized rows in one launch (asr_hip.h: asr_proj_ln_fwd).
     -> (s_sum [M,256] pre-norm sum or None, y32, y16 or None, mean, rstd): the tensors of the gemm_nt + add_layernorm pair."""
     _req_cuda(a2d, w, bias, residual, gamma, beta, row_len)
     M = a2d.shape[0]
     assert M == B * L and residual.is_contiguous()
     dev = a2d.device
-    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32) if save_stats else None
+    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32) if (save_stats and save_s) else None
     y32 = torch.empty((M, 256), device=dev, dtype=torch.float32)
     y16 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16) if want_bf16 else None
     mean = torch.empty(M, device=dev, dtype=torch.float32) if save_stats else None
@@ -345,14 +345,14 @@ def ffn_fused_ok(x16, x32, w1, w2, B, L):
             w1.is_contiguous() and w2.is_contiguous())
 
 
-def ffn_fwd(x16, x32, w1, b1, w2, b2, gamma, beta, B, L, row_len=None, eps=1e-5, train=False, drop_x=None, want_bf16=True):
+def ffn_fwd(x16, x32, w1, b1, w2, b2, gamma, beta, B, L, row_len=None, eps=1e-5, train=False, drop_x=None, want_bf16=True, save_s=True):
     """The whole position-wise feed-forward sub-layer in one launch (asr_hip.h: asr_ffn_fwd).
     -> (hid bf16 [M,d_ff] or None, bits or None, s_sum [M,256] or None, y32, y16, mean, rstd); hid / bits / s_sum / mean / rstd with train."""
     _req_cuda(x16, x32, w1, b1, w2, b2, gamma, beta, row_len)
     M, dff, dev = B * L, w1.shape[0], x32.device
     hid = torch.empty((M, dff), device=dev, dtype=torch.bfloat16) if train else None
     bits = torch.empty((int(lib().asr_ffn_bits_words(M, dff)),), device=dev, dtype=torch.int32) if train else None
-    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32) if train else None
+    s_sum = torch.empty((M, 256), device=dev, dtype=torch.float32) if (train and save_s) else None      # (save_s=False: the backward takes x^ from y32)
     y32 = torch.empty((M, 256), device=dev, dtype=torch.float32)
     y16 = torch.empty((M, 256), device=dev, dtype=torch.bfloat16) if want_bf16 else None
     mean = torch.empty(M, device=dev, dtype=torch.float32) if train else None
@@ -376,11 +376,12 @@ def ffn_bwd(ds16, ds32, w1, w2, bits):
     return d_hid, dx
 
 
-def ffn_bwd_ln(ds16, ds32, w1, w2, bits, B, L, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, dgamma, dbeta, dbias=None, drop_x=None):
+def ffn_bwd_ln(ds16, ds32, w1, w2, bits, B, L, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, dgamma, dbeta, dbias=None, drop_x=None,
+               ln_beta=None):
     """ffn_bwd whose dx goes straight through the backward of the LayerNorm that produced the sub-layer's input (asr_ffn_bwd_ln):
     -> (d_hid bf16 [M,d_ff], ds f32 [M,256], ds16 bf16 [M,256]) with ds / ds16 as add_layernorm_bwd(dy=dx, ...) returns them;
     dgamma / dbeta / dbias accumulated in place."""
-    _req_cuda(ds16, ds32, w1, w2, bits, ln_s, ln_mean, ln_rstd, ln_gamma, dgamma, dbeta)
+    _req_cuda(ds16, ds32, w1, w2, bits, ln_s, ln_rstd, ln_gamma, dgamma, dbeta)
     M, dff = ds32.shape[0], w1.shape[0]
     assert M == B * L and ds16.dtype == torch.bfloat16 and ds16.is_contiguous() and ds32.is_contiguous() and ln_s.is_contiguous()
     d_hid = torch.empty((M, dff), device=ds32.device, dtype=torch.bfloat16)
@@ -388,7 +389,8 @@ def ffn_bwd_ln(ds16, ds32, w1, w2, bits, B, L, ln_s, ln_mean, ln_rstd, ln_gamma,
     ds_b = torch.empty((M, 256), device=ds32.device, dtype=torch.bfloat16)
     with _timed("ffn_bwd[%dx256x%d]" % (M, dff), 4.0 * M * 256 * dff):
         check(lib().asr_ffn_bwd_ln(_stream(), _p(ds16), _p(ds32), _p(w1), _p(w2), _p(bits), _p(d_hid), B, L, 256, dff, _p(ln_s), _p(ln_mean),
-                                   _p(ln_rstd), _p(ln_gamma), _p(row_len), _p(ds), _p(ds_b), _p(dgamma), _p(dbeta), _p(dbias), _d(drop_x)),
+                                   _p(ln_rstd), _p(ln_gamma), _p(ln_beta), _p(row_len), _p(ds), _p(ds_b), _p(dgamma), _p(dbeta), _p(dbias),
+                                   _d(drop_x)),
               "asr_ffn_bwd_ln")
     return d_hid, ds, ds_b
 
@@ -786,6 +788,36 @@ def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=No
     return out
 
 
+DGRAD_ROWS = os.environ.get("ASR_AMD_DGRAD_ROWS", "1") != "0"      # A/B: 0 = the tiled GEMM for every data gradient
+DGRAD_ROWS_MIN = int(os.environ.get("ASR_AMD_DGRAD_ROWS_MIN", "8192"))
+DGRAD_ROWS_MIN_K = int(os.environ.get("ASR_AMD_DGRAD_ROWS_MIN_K", "512"))      # (K = 256, the attention output projection: 20.4 against the tiled GEMM's 18.6 us)
+
+
+def dgrad_rows_ok(a2d, w, K=None, lda=None):
+    """Shapes asr_dgrad_rows is used for: bf16 dY [M >= DGRAD_ROWS_MIN, K % 64 == 0, K >= DGRAD_ROWS_MIN_K] (row stride % 8 == 0) against
+    W bf16 [K, 256]."""
+    K = a2d.shape[1] if K is None else K
+    lda = a2d.stride(0) if lda is None else lda
+    return (DGRAD_ROWS and a2d.is_cuda and a2d.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] == 256 and
+            w.is_contiguous() and w.shape[0] == K and K % 64 == 0 and K >= DGRAD_ROWS_MIN_K and a2d.shape[0] >= DGRAD_ROWS_MIN and lda % 8 == 0 and a2d.stride(1) == 1 and
+            a2d.data_ptr() % 16 == 0)
+
+
+def gemm_nn_ln(a2d, w, addend, B, L, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, dgamma, dbeta, dbias=None, drop_x=None, ln_beta=None):
+    """gemm_nn(a2d, w, addend=addend) followed by add_layernorm_bwd on its result, in one launch (asr_dgrad_rows_ln; dgrad_rows_ok
+    shapes): -> (ds f32 [M,256], ds16 bf16 [M,256]); dgamma / dbeta / dbias accumulated in place."""
+    _req_cuda(a2d, w, addend, ln_s, ln_rstd, ln_gamma, dgamma, dbeta)
+    M, K = a2d.shape
+    assert M == B * L and dgrad_rows_ok(a2d, w) and ln_s.is_contiguous() and (addend is None or addend.is_contiguous())
+    ds = torch.empty((M, 256), device=a2d.device, dtype=torch.float32)
+    ds_b = torch.empty((M, 256), device=a2d.device, dtype=torch.bfloat16)
+    with _timed("gemm_nn[%dx256x%d]" % (M, K), 2.0 * M * 256 * K):
+        check(lib().asr_dgrad_rows_ln(_stream(), _p(a2d), a2d.stride(0), _p(w), _p(addend), B, L, K, 256, _p(ln_s), _p(ln_mean), _p(ln_rstd),
+                                      _p(ln_gamma), _p(ln_beta), _p(row_len), _p(ds), _p(ds_b), _p(dgamma), _p(dbeta), _p(dbias), _d(drop_x)),
+              "asr_dgrad_rows_ln")
+    return ds, ds_b
+
+
 def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=None, K=None, relu_bits=None):
     """dX[M,in] = A[M,out] . W[out,in]  (W bf16 as stored).  Optional f32 addend [M,in] and bf16 relu_mask [M,in] - or, instead
     of the latter, relu_bits uint8 [M, in/8] (the sign-bit image gemm_nt_ex wrote).
@@ -809,6 +841,12 @@ def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=No
             out = relu_mask_mul(out, relu_mask.contiguous(), out=out)
         return out if out_dtype == torch.float32 else out.to(out_dtype)
     assert w.is_contiguous() and w.dtype == torch.bfloat16 and w.shape[0] >= K and a2d.stride(1) == 1
+    if dgrad_rows_ok(a2d, w, K, lda) and relu_mask is None and relu_bits is None and out_dtype in (torch.float32, torch.bfloat16):
+        # encoder-sized rows into d_model = 256: the row-block kernel (asr_dgrad_rows) - whole rows per workgroup, W streamed through LDS
+        out = torch.empty((M, N), device=a2d.device, dtype=out_dtype)
+        with _timed("gemm_nn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
+            check(lib().asr_dgrad_rows(_stream(), _p(a2d), lda, _p(w), _p(addend), _p(out), dtype_code(out), M, K, N), "asr_dgrad_rows")
+        return out
     out = _arena_take(M, N, K, a2d.device) if (out_dtype == torch.float32 and relu_mask is None and relu_bits is None) else None
     zero_flag = 2 if out is not None else 0
     if out is None:
@@ -954,14 +992,21 @@ def colsum(a2d, out=None, accumulate=False):
 
 
 def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, want_bf16=False, dbias=None, drop_x=None,
-                      drop_y=None):
-    """-> (ds f32 [M,D], ds16 or None); dgamma/dbeta (and dbias += colsum(ds) when given) accumulated in place."""
-    _req_cuda(dy, s, mean, rstd, gamma, row_len, dgamma, dbeta)
+                      drop_y=None, beta=None):
+    """-> (ds f32 [M,D], ds16 or None); dgamma/dbeta (and dbias += colsum(ds) when given) accumulated in place.
+    beta given: `s` is the LayerNorm's OUTPUT y (the forward kept no pre-norm sum; asr_add_layernorm_bwd_y), mean is not read."""
+    _req_cuda(dy, s, rstd, gamma, row_len, dgamma, dbeta)
     D = s.shape[-1]
     assert dy.is_contiguous() and s.is_contiguous()
     ds = torch.empty((B * L, D), device=s.device, dtype=torch.float32)
     ds16 = torch.empty((B * L, D), device=s.device, dtype=torch.bfloat16) if want_bf16 else None
     nbytes = B * L * D * (4 + 4 + 4 + (2 if want_bf16 else 0))
+    if beta is not None:
+        assert drop_y is None
+        with _timed("add_layernorm_bwd[%dx%d]" % (B * L, D), float(nbytes)):
+            check(lib().asr_add_layernorm_bwd_y(_stream(), _p(dy), _p(s), _p(rstd), _p(gamma), _p(beta), _p(row_len), _p(ds), _p(ds16),
+                                                _p(dgamma), _p(dbeta), _p(dbias), B, L, D, _d(drop_x)), "asr_add_layernorm_bwd_y")
+        return ds, ds16
     with _timed("add_layernorm_bwd[%dx%d]" % (B * L, D), float(nbytes)):
         check(lib().asr_add_layernorm_bwd(_stream(), _p(dy), _p(s), _p(mean), _p(rstd), _p(gamma), _p(row_len), _p(ds), _p(ds16),
                                           _p(dgamma), _p(dbeta), _p(dbias), B, L, D, _d(drop_x), _d(drop_y)), "asr_add_layernorm_bwd")

@@ -249,7 +249,8 @@ int asr_ffn_fwd(void* stream, const void* x16, const float* x32, const void* w1,
  * encoder.py:77's row mask): y = LayerNorm(dropout_x(ctx . W^T + bias) + residual) * gamma + beta, rows t >= row_len[b] zeroed.
  * ctx16 bf16 [B*L, 256] (the attention context, h * d_v = 256), w bf16 [256, 256] as stored, residual f32 [B*L, 256].  Same workgroup
  * shape, prologue and epilogue as asr_ffn_fwd (the projection is that kernel's first product over four 64-row chunks of w); writes
- * what asr_add_layernorm_fwd(save) writes: s_out (pre-norm sum, training) / mean_out / rstd_out (training), y32, y16 (optional). */
+ * what asr_add_layernorm_fwd(save) writes: s_out (pre-norm sum, training; may be NULL with mean_out / rstd_out given - the backward then
+ * takes x^ from y32, asr_add_layernorm_bwd_y) / mean_out / rstd_out (training), y32, y16 (optional). */
 int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,
                     const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16, float* mean_out, float* rstd_out,
                     int B, int L, int d_model, float eps, asr_dropout_t drop_x);
@@ -264,10 +265,26 @@ int asr_ffn_bwd(void* stream, const void* ds16, const float* ds32, const void* w
  * leaves what asr_add_layernorm_bwd(dy = dx, s = ln_s, ln_mean, ln_rstd, ln_gamma, row_len, drop_x) leaves - ds_out (f32, gradient wrt
  * that LayerNorm's residual), ds16_out (bf16, gradient wrt the normalised projection's output, dropout-masked), and dgamma / dbeta /
  * dbias (optional) ACCUMULATED into - with the same arithmetic per row (a row lies across a wave in both kernels).  M = B * L. */
+/* Data gradient of an nn.Linear whose input is d_model = 256 wide, as a row-block kernel (csrc/dgrad_rows.hip): a workgroup owns 128
+ * complete rows of  dX[M, 256] = dY[M, K] . W[K, 256] (+ addend),  W bf16 as nn.Linear stores it ([out = K][in = 256]), dY bf16 with row
+ * stride ldy elements (a column slice of a wider buffer is fine), K a multiple of 64.  Autograd of attention.py:43-49 (w_qs / w_ks / w_vs),
+ * attention.py:58 (fc) and the decoder's cross K / V projections at encoder size, where a tiled GEMM is all prologue and epilogue.
+ * asr_dgrad_rows: out f32 (ASR_F32, addend optional) or bf16 (ASR_BF16) [M, 256].
+ * asr_dgrad_rows_ln: dX + addend is the dy of the LayerNorm that produced the projection's input and nothing else reads it: the launch
+ * leaves what asr_add_layernorm_bwd(dy, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, drop_x) leaves - ds_out f32, ds16_out bf16,
+ * dgamma / dbeta / dbias (optional) accumulated into - and dx never goes to memory (M = B * L).  ln_beta non-null (here and in
+ * asr_ffn_bwd_ln): ln_s holds that LayerNorm's OUTPUT y instead of its pre-norm sum, x^ = (y - beta) / gamma, ln_mean is not read -
+ * asr_add_layernorm_bwd_y's convention, for a forward that did not store the pre-norm sum. */
+int asr_dgrad_rows(void* stream, const void* dy, int64_t ldy, const void* w, const float* addend, void* out, int out_dtype, int M, int K,
+                   int d_model);
+int asr_dgrad_rows_ln(void* stream, const void* dy, int64_t ldy, const void* w, const float* addend, int B, int L, int K, int d_model,
+                      const float* ln_s, const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta,
+                      const int32_t* row_len, float* ds_out, void* ds16_out, float* dgamma, float* dbeta, float* dbias,
+                      asr_dropout_t drop_x);
 int asr_ffn_bwd_ln(void* stream, const void* ds16, const float* ds32, const void* w1, const void* w2, const void* bits, void* dhid_out,
                    int B, int L, int d_model, int d_ff, const float* ln_s, const float* ln_mean, const float* ln_rstd,
-                   const float* ln_gamma, const int32_t* row_len, float* ds_out, void* ds16_out, float* dgamma, float* dbeta,
-                   float* dbias, asr_dropout_t drop_x);
+                   const float* ln_gamma, const float* ln_beta, const int32_t* row_len, float* ds_out, void* ds16_out, float* dgamma,
+                   float* dbeta, float* dbias, asr_dropout_t drop_x);
 
 /* y = LayerNorm(x [+ residual]) * gamma + beta [+ pe[t]] ; rows with t >= row_len[b] are zeroed when row_len given.
  * (attention.py:60, module.py:52, encoder.py:48-50,74,77).  x, residual, y32 f32 [M = B*L, D]; y16 optional bf16 copy.
@@ -285,6 +302,11 @@ int asr_add_layernorm_fwd(void* stream, const float* x, const float* residual, c
  * receives colsum(ds) = the bias gradient of the projection whose output was normalised.
  * drop_y (the forward's) masks dy first.  With drop_x, ds (f32) stays the gradient wrt the residual while ds16 and dbias carry
  * the gradient wrt x = dropout-masked ds (the operand of the projection's backward GEMMs). */
+/* asr_add_layernorm_bwd for a forward that kept no pre-norm sum: y is the LayerNorm's OUTPUT (alive anyway as the next sub-layer's input
+ * and residual), x^ = (y - beta) / gamma (0 where gamma is 0 and in masked rows); rstd from the forward.  No drop_y form. */
+int asr_add_layernorm_bwd_y(void* stream, const float* dy, const float* y, const float* rstd, const float* gamma, const float* beta,
+                            const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta, float* dbias, int B, int L,
+                            int D, asr_dropout_t drop_x);
 int asr_add_layernorm_bwd(void* stream, const float* dy, const float* s, const float* mean, const float* rstd,
                           const float* gamma, const int32_t* row_len, float* ds, void* ds16, float* dgamma, float* dbeta,
                           float* dbias, int B, int L, int D, asr_dropout_t drop_x, asr_dropout_t drop_y);
