@@ -526,8 +526,8 @@ def main():
         dom_name, dom = max(((n, f) for n, f in fams.items() if f["work"] > 0), key=lambda nf: nf[1]["ms"])
         ach = dom["work"] / (dom["ms"] * 1e-3) / (1e9 if dom["hbm"] else 1e12)
         peak = PEAK_HBM_GBS if dom["hbm"] else PEAK_MFMA_BF16_TFLOPS
-        prof_dir = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r3", "r2", "r1"))
-                         if os.path.exists(os.path.join(d, "pmc_traffic_train_s1.json"))), os.path.join(ROOT, "profiles", "r3"))
+        prof_dir = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r4", "r3", "r2", "r1"))
+                         if os.path.exists(os.path.join(d, "pmc_traffic_train_s1.json"))), os.path.join(ROOT, "profiles", "r4"))
         traffic = pmc_traffic(FAMILY_KERNEL.get(dom_name, dom_name), prof_dir)
         roofline = dict(kernel="%s (%s, all shapes)" % (dom_name, FAMILY_KERNEL.get(dom_name, dom_name)),
                         bound="hbm" if dom["hbm"] else "mfma", achieved=round(ach, 2), peak=peak,

@@ -14,6 +14,11 @@ $T 300 python3 bench.py --steps 5 --warmup 1 --mode decode --beam 5 --no-also > 
 $T 600 python3 tools/bench_ops.py > $OUT/bench_ops.jsonl 2>> $OUT/bench_train.err
 $T 300 python3 tools/bench_ffn.py > $OUT/bench_ffn.txt 2>> $OUT/bench_train.err
 $T 120 python3 tools/bench_heads.py > $OUT/bench_heads.txt 2>> $OUT/bench_train.err
+$T 120 python3 tools/bench_dgrad_rows.py > $OUT/bench_dgrad_rows.txt 2>> $OUT/bench_train.err
+$T 120 python3 tools/ctc_timeline.py > $OUT/ctc_timeline.txt 2>> $OUT/bench_train.err
+$T 300 python3 tools/rccl_sanity.py --exec 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids\|socket.cpp" > $OUT/rccl_executor_world1.txt
+$T 600 python3 tools/dp_hang_hunt.py --runs 16 --limit 90 > $OUT/dp_hang_hunt.txt 2>&1
+bash tools/kt_ctc.sh default > $OUT/ctc_kernel_trace.txt 2>&1
 cd /tmp
 $T 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also > /dev/null 2>&1
 $T 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-also --graph 0 > /dev/null 2>&1
@@ -25,6 +30,7 @@ $T 300 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/kt_attn_train -- 
 cd $R
 KS=$(find $OUT/kt -name "*kernel_stats.csv" | head -1); [ -n "$KS" ] && cp $KS $OUT/bench_train_kernel_stats.csv
 KT=$(find $OUT/kt -name "*kernel_trace.csv" | head -1); [ -n "$KT" ] && python3 tools/timeline.py $KT adam_dev | cut -c1-160 > $OUT/step_timeline.txt 2>&1
+python3 tools/decoder_segment.py $OUT/kt --list > $OUT/decoder_segment.txt 2>&1
 F=$(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_write -name "*counter_collection.csv" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 tools/pmc_summary.py $F $W $OUT/pmc_traffic_train_s1.json > $OUT/pmc_summary.txt 2>&1
 ( python3 tools/pmc_kernel.py $OUT/pmc_attn attn 48; python3 tools/pmc_kernel.py $OUT/pmc_attn2 attn 48 ) > $OUT/attn_counters.txt 2>&1
