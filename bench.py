@@ -111,7 +111,10 @@ def launch_name(args, graphed, trainer=None):
     if args.mode == "decode":
         return "per-token step replayed as a hip-graph, encoder eager" if os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0" else "eager"
     if graphed and trainer is not None and getattr(trainer, "_graphx", None) is not None:
-        return "captured step launched by the multi-stream graph executor (%(nodes)d nodes on %(streams)d streams, %(events)d events)" % trainer._graphx.info
+        info = trainer._graphx.info
+        tail = ", %d gradient all-reduce nodes called from its launch loop" % info["collectives"] if info.get("collectives") else ""
+        return "captured step launched by the multi-stream graph executor (%d nodes on %d streams, %d events%s)" % (
+            info["nodes"], info["streams"], info["events"], tail)
     return "hip-graph replay" if graphed else "eager"
 
 

@@ -411,11 +411,28 @@ extern "C" int asr_graphx_place_streams(void* handle, void* launch_stream, int c
     return 0;
 }
 
+static int graphx_launch_nodes(GraphX* g, hipStream_t main);
+
 extern "C" int asr_graphx_launch(void* handle, void* stream) {
     GraphX* g = static_cast<GraphX*>(handle);
     ASR_REQUIRE(g, -1, "graphx_launch: null handle");
     hipStream_t main = static_cast<hipStream_t>(stream);
     g->streams[0] = main;
+    // A plan with collective nodes and nothing to run them is refused BEFORE anything is queued; any later failure (a launch the
+    // runtime rejects, a collective that errors) leaves a half-queued step: the side streams are drained then, so that the caller's
+    // stream order still covers everything that was queued, and the error is returned.
+    if (g->n_collective > 0 && !g->coll_fn && !g->comm) {
+        asr_set_error("graphx_launch: the step holds %d gradient all-reduce node(s) and no communicator (asr_graphx_set_collective)",
+                      g->n_collective);
+        return -5;
+    }
+    const int rc = graphx_launch_nodes(g, main);
+    if (rc != 0)
+        for (size_t s = 1; s < g->streams.size(); ++s) (void)hipStreamSynchronize(g->streams[s]);
+    return rc;
+}
+
+static int graphx_launch_nodes(GraphX* g, hipStream_t main) {
     // side streams start behind everything already queued on the launch stream
     if (g->streams.size() > 1) {
         GX_CHECK(hipEventRecord(g->begin, main));

@@ -627,7 +627,7 @@ class Trainer:
                 if not use_x:
                     raise RuntimeError("a data-parallel step is captured for the graph executor only (ASR_AMD_GRAPH_EXEC=0 or no keep_graph)")
                 # (communicator set-up is itself a collective and queues GPU work: before the capture begins)
-                if self.world > 1 and torch.distributed.get_backend(self.group) != "nccl":
+                if self.world > 1 and torch.distributed.get_backend(self.group) != "nccl" and os.environ.get("ASR_AMD_DP_COMM", "") != "rccl":
                     comm_fn = ops.torch_collective_fn([self.fp.grad], self.group)      # the rig: gloo ranks sharing one GPU
                 else:
                     comm = ops.rccl_comm(self.group, dev)

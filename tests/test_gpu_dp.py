@@ -98,6 +98,16 @@ def test_two_ranks_through_the_graph_executor_equal_one_rank():
     assert all(o["executor"]["collectives"] >= 2 for o in lines), lines
 
 
+def test_rccl_communicator_refused_means_every_rank_steps_eagerly(monkeypatch):
+    """ASR_AMD_DP_COMM=rccl makes the gloo rig ask for the executor's OWN RCCL communicator: the unique id travels over
+    torch.distributed, ncclCommInitRank refuses two ranks on one GPU - on both ranks.  The capture is abandoned, the ranks agree on
+    it (an all-reduced flag) and train eagerly; bench.py's parameter checksums still match."""
+    monkeypatch.setenv("ASR_AMD_DP_COMM", "rccl")
+    out = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], 2, 29555, True)[-1]
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "eager" in out["config"]["launch"] or "queued" in out["config"]["launch"], out["config"]["launch"]
+
+
 def test_eight_ranks_through_the_graph_executor_equal_one_rank():
     lines = _run([os.path.join(ROOT, "tools", "dp_equiv.py"), "--graph"], 8, 29553, True)
     _check_equiv(lines, 8)
