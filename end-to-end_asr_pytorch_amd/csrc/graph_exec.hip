@@ -132,6 +132,10 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
     ASR_REQUIRE(order.size() == n, -1, "graphx_create: the graph has a cycle (%zu of %zu nodes ordered)", order.size(), n);
 
     GraphX* g = new GraphX();
+    struct Guard {       // every early return below (GX_CHECK, ASR_REQUIRE) releases the half-built plan: streams, events, cloned sub-graphs
+        GraphX* g;
+        ~Guard() { if (g) asr_graphx_destroy(g); }
+    } guard{g};
     g->streams.push_back(nullptr);     // slot 0: the stream handed to asr_graphx_launch
     std::vector<int> stream_of(n, -1), tail_of_stream(1, -1), event_of(n, -1);
     std::vector<int> pos_in_order(n);
@@ -178,7 +182,7 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
                         hipDeviceGetStreamPriorityRange(&least, &greatest);
                         ce = hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, side_prio > 0 ? least : greatest);
                     } else ce = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
-                    if (ce != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: stream"); return -2; }
+                    if (ce != hipSuccess) { asr_set_error("graphx: stream"); return -2; }
                     g->streams.push_back(ns);
                     tail_of_stream.push_back(-1);
                     st = (int)g->streams.size() - 1;
@@ -205,9 +209,17 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
         if (x.type == hipGraphNodeTypeKernel) {
             GX_CHECK(hipGraphKernelNodeGetParams(sorted_raw[u], &x.k));
             if (x.k.kernelParams == nullptr || x.k.extra != nullptr) {
-                asr_graphx_destroy(g);
                 asr_set_error("graphx_create: a kernel node passes its arguments through `extra` (not a hipLaunchKernel-style launch)");
                 return -3;
+            }
+            {   // a node captured from hipModuleLaunchKernel carries a hipFunction_t, not a host stub: hipLaunchKernel would only fail at
+                // launch time, with earlier nodes already queued - refuse the graph here instead (the caller replays it with hipGraphLaunch)
+                hipFuncAttributes fa;
+                if (hipFuncGetAttributes(&fa, x.k.func) != hipSuccess) {
+                    (void)hipGetLastError();
+                    asr_set_error("graphx_create: a kernel node's function is not a host-side kernel stub");
+                    return -3;
+                }
             }
             g->n_kernel++;
             if (x.k.func == asr_collective_marker_func()) {      // values, not pointers into the node: the block is the graph's
@@ -238,7 +250,6 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
         } else if (x.type == hipGraphNodeTypeEmpty) {
             g->n_other++;
         } else {
-            asr_graphx_destroy(g);
             asr_set_error("graphx_create: node type %d is not supported (kernel, memset, memcpy and empty nodes are)", (int)x.type);
             return -3;
         }
@@ -281,7 +292,7 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
             for (int q : targets[oi]) {
                 if (event_of[q] < 0) {
                     hipEvent_t e;
-                    if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
+                    if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_set_error("graphx: event"); return -2; }
                     event_of[q] = (int)g->events.size();
                     g->events.push_back(e);
                     g->nodes[pos_in_order[q]].record_event = event_of[q];
@@ -296,14 +307,14 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
         if (t < 0) continue;
         if (event_of[t] < 0) {
             hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
+            if (hipEventCreateWithFlags(&e, graphx_event_flags()) != hipSuccess) { asr_set_error("graphx: event"); return -2; }
             event_of[t] = (int)g->events.size();
             g->events.push_back(e);
             g->nodes[pos_in_order[t]].record_event = event_of[t];
         }
         g->tail_event[s] = event_of[t];
     }
-    if (hipEventCreateWithFlags(&g->begin, graphx_event_flags()) != hipSuccess) { asr_graphx_destroy(g); asr_set_error("graphx: event"); return -2; }
+    if (hipEventCreateWithFlags(&g->begin, graphx_event_flags()) != hipSuccess) { asr_set_error("graphx: event"); return -2; }
     if (getenv("ASR_AMD_GRAPHX_DEBUG")) {      // the launch plan, one line per node: position, stream, type / kernel name, waits, record
         for (size_t oi = 0; oi < n; ++oi) {
             const XNode& x = g->nodes[oi];
@@ -317,6 +328,7 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
             fprintf(stderr, "graphx %4zu s%d %.90s waits %zu rec %d deps%s\n", oi, x.stream, name ? name : "?", x.wait_events.size(), x.record_event, dl);
         }
     }
+    guard.g = nullptr;      // (built: the caller owns it now)
     *out_handle = g;
     return 0;
 }
