@@ -1136,7 +1136,12 @@ class Decoder(_Cached):
         if targets.is_cuda and targets.dtype == torch.int64:
             if umax is None:
                 umax = int((targets != 0).sum(1).max().item())
-            return ops.decoder_targets(targets, self.sos_id, self.eos_id, umax)      # one launch
+            # a caller-supplied `umax` that is too small truncates a target (the launch forces <eos> at the end): the kernel leaves a flag
+            # in a word this module keeps - read it at a sync point with target_overflow() (the trainer does after its calibration)
+            ov = self.__dict__.get("_overflow")
+            if ov is None or ov.device != targets.device:
+                ov = self.__dict__["_overflow"] = torch.zeros(1, dtype=torch.int32, device=targets.device)
+            return ops.decoder_targets(targets, self.sos_id, self.eos_id, umax, overflow=ov)      # one launch
         comp, n = _compact_targets(targets)
         if umax is None:
             umax = int(n.max().item())
@@ -1146,6 +1151,11 @@ class Decoder(_Cached):
         ys_out = torch.cat([ys, torch.zeros((B, 1), dtype=targets.dtype, device=targets.device)], 1)
         ys_out.scatter_(1, n[:, None], self.eos_id)
         return ys_in, ys_out, ((ys_in > 0).sum(1)).to(torch.int32)
+
+    def target_overflow(self):
+        """True if some preprocess call since the module was built was handed a `umax` smaller than a target's length (host sync)."""
+        ov = self.__dict__.get("_overflow")
+        return bool(int(ov)) if ov is not None else False
 
     def _impl(self, targets, enc, enc_len):
         ys_in, ys_out, dec_len = self._preprocess(targets)

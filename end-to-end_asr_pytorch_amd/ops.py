@@ -903,10 +903,15 @@ DETERMINISTIC = os.environ.get("ASR_AMD_DETERMINISTIC", "0") not in ("", "0")
 _tn_ws = {}
 
 
-def _tn_workspace(out, M, N, K, max_wgs):
+def _tn_workspace(out, M, N, K, max_wgs, persistent=True):
+    """persistent: `out` is a destination the caller keeps (a weight.grad view): its workspace is cached under its address.  A result
+    gemm_tn allocated itself gets a workspace of its own that lives as long as the launch's stream order needs it (the caching
+    allocator's) - cached under a fresh address every call it would never be evicted."""
     need = int(lib().asr_gemm_tn_ws_bytes(M, N, K, int(max_wgs)))
     if need <= 0:
         return None
+    if not persistent:
+        return torch.empty(need, device=out.device, dtype=torch.uint8)
     key = (out.data_ptr(), out.device.index)
     ws = _tn_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -924,11 +929,12 @@ def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     assert a2d.stride(1) == 1 and b2d.stride(1) == 1 and b2d.shape[0] == M
     if EXACT_F32:
         return _gemm_tn_f32(a2d, b2d, out, accumulate, colsum)
-    if out is None:
+    own_out = out is None
+    if own_out:
         out = torch.empty((N, K), device=a2d.device, dtype=torch.float32)
         accumulate = False
     if TN_SLAB and a2d.dtype == torch.bfloat16 and b2d.dtype == torch.bfloat16 and K % 128 == 0 and M >= 64:
-        ws = _tn_workspace(out, M, N, K, max_wgs)
+        ws = _tn_workspace(out, M, N, K, max_wgs, persistent=not own_out)
         if ws is not None:
             with _timed("gemm_tn[%dx%dx%d]" % (M, N, K), 2.0 * M * N * K):
                 check(lib().asr_gemm_tn_ws(_stream(), _p(a2d), a2d.stride(0), _p(b2d), b2d.stride(0), _p(out), out.stride(0), M, N, K,

@@ -589,6 +589,9 @@ class Trainer:
                     t_graph = t_p
                 else:
                     self._graphx.place_streams(clear=True)
+        dec = getattr(self.model, "decoder", None)
+        if dec is not None and hasattr(dec, "target_overflow") and dec.target_overflow():
+            raise RuntimeError("asr_amd.Trainer: max_target_len=%r is smaller than the longest target of the batch (a target was truncated)" % (max_target_len,))
         self.launch_mode = "graph" if t_graph < t_eager else "eager"
         self.launch_timing = {"eager_ms": round(t_eager, 3), "graph_ms": round(t_graph, 3), "eager_host_us": h_eager,
                               "graph_host_us": host_us(self.step_graphed)}

@@ -72,3 +72,15 @@ def test_decoder_cif_targets(B, U, seed):
     np.testing.assert_array_equal(in_len.cpu().numpy(), pad_mask.sum(1).astype(np.int32))
     dec = asr_amd.Decoder_CIF(4232, 4233, 1, 2, 64, 128, dropout=0.0)
     np.testing.assert_array_equal(dec.preprocess(torch.from_numpy(tg)).numpy(), ref)
+
+
+def test_decoder_module_remembers_a_truncated_target():
+    """Decoder._preprocess with a caller-supplied `umax` that is too small (a loader passing a wrong max_target_len inside a captured
+    step, where nothing else would notice): the module's overflow word is set and target_overflow() reports it."""
+    import asr_amd
+    dec = asr_amd.Decoder(2, 3, 50, 1, 2, 64, 128).to(DEV)
+    tg = torch.tensor([[5, 6, 7, 8, 0, 0], [9, 10, 0, 0, 0, 0]], device=DEV)
+    dec._preprocess(tg, umax=4)
+    assert not dec.target_overflow()
+    dec._preprocess(tg, umax=3)
+    assert dec.target_overflow()
