@@ -635,7 +635,10 @@ class Trainer:
                 else:
                     comm = ops.rccl_comm(self.group, dev)
                 self.buckets.mark_stream = ops.aux_stream(dev, slot=3)
-            with torch.cuda.graph(g):
+            # (N > 1: torch's process group has a watchdog thread that queries events while this thread captures; its calls must not
+            # invalidate the capture)
+            cap_kw = {"capture_error_mode": "thread_local"} if self.world > 1 else {}
+            with torch.cuda.graph(g, **cap_kw):
                 ops.step_tick(self._state, self.k, self.init_lr, self.warmup, self.betas[0], self.betas[1])
                 ctc, ce = self._fwd_bwd(feats, lens, targets, noise, max_target_len)
                 ops.adam_step_dev(self.fp.flat, self.fp.grad, self.m, self.v, self._state, self.betas[0], self.betas[1], self.eps,
