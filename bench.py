@@ -107,6 +107,26 @@ def workload_name(args, train):
         CFG["T"], CFG["d_input"], " (ragged lengths)" if args.ragged else "", CFG["U"], what_name(args, train))
 
 
+def settle_groups(timed_group, world, dev, max_groups=8, rel=0.02):
+    """Run `timed_group()` (one group of steps -> ms per step) until two consecutive groups agree to `rel`, at most `max_groups` times; ->
+    the list of group times.  With world > 1 every rank sees the MAX over ranks of each group time, so ALL ranks run the same number of
+    groups: every step holds collectives, and a rank that settled a group earlier than its peers left them waiting in an all-reduce
+    it never joined while it sat in the next barrier - the "hangs once in a few dozen runs" of the multi-rank rig
+    (tools/dp_hang_hunt.py: 6 of 80 runs; Python stacks: one rank in barrier(), the other in step())."""
+    import torch
+    out = []
+    for _ in range(max_groups):
+        ms = timed_group()
+        if world > 1:
+            t = torch.tensor([ms], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            ms = float(t)
+        out.append(ms)
+        if len(out) >= 2 and abs(out[-1] - out[-2]) <= rel * out[-2]:
+            break
+    return out
+
+
 def launch_name(args, graphed, trainer=None):
     if args.mode == "decode":
         return "per-token step replayed as a hip-graph, encoder eager" if os.environ.get("ASR_AMD_DECODE_GRAPH", "1") != "0" else "eager"
@@ -446,22 +466,13 @@ def main():
     torch.cuda.synchronize()
     # a fresh box keeps speeding up for a while (clocks, page tables, the allocator's pools): groups of 5 steps until two consecutive
     # groups agree to 2 % (at most 8 groups), THEN the contract's W warm-up steps and the K timed ones
-    settle = []
-    for _ in range(8):
+    def timed_group():
         t0 = time.perf_counter()
         for _ in range(5):
             step()
         torch.cuda.synchronize()
-        settle.append((time.perf_counter() - t0) / 5 * 1e3)
-        if world > 1:
-            # ONE decision for all ranks: every step holds collectives, so a rank that settled a group earlier than its peers left them
-            # waiting in an all-reduce it never joined while it sat in the barrier below - the "hangs once in a few dozen runs" of
-            # the multi-rank rig (tools/dp_hang_hunt.py: 6 of 80 runs; Python stacks: one rank in barrier(), the other in step())
-            t = torch.tensor([settle[-1]], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            settle[-1] = float(t)
-        if len(settle) >= 2 and abs(settle[-1] - settle[-2]) <= 0.02 * settle[-2]:
-            break
+        return (time.perf_counter() - t0) / 5 * 1e3
+    settle = settle_groups(timed_group, world, dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -83,3 +83,32 @@ def test_never_ready_bucket_is_an_error():
         assert False, "expected an error"
     except RuntimeError as e:
         assert "never became ready" in str(e)
+
+
+def _settle_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    # rank 0 would settle after two groups on its own timings, rank 1 after four: the collective decision makes both run four
+    mine = {0: [10.0, 10.05, 10.0, 10.0, 10.0], 1: [12.0, 11.0, 10.5, 10.45, 10.4]}[rank]
+    calls = []
+
+    def group():
+        calls.append(1)
+        dist.all_reduce(torch.zeros(1))          # (every step of the real loop holds collectives: an uneven count would hang right here)
+        return mine[len(calls) - 1]
+    seen = bench.settle_groups(group, world, torch.device("cpu"))
+    out[rank] = (len(calls), seen)
+    dist.destroy_process_group()
+
+
+def test_bench_settle_loop_runs_the_same_number_of_groups_on_every_rank():
+    """bench.py's warm-up settles on the MAX over ranks of each group's time (round 4: the per-rank decision was the multi-rank hang)."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_settle_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = dict(out)
+    assert res[0][0] == res[1][0] == 4
+    assert res[0][1] == res[1][1] == [12.0, 11.0, 10.5, 10.45]
