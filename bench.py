@@ -61,6 +61,10 @@ def parse_args():
     ap.add_argument("--ragged", action="store_true", help="per-utterance lengths U{T/2..T} (max forced to T) and targets U{U/2..U}")
     ap.add_argument("--brief", action="store_true",
                     help="headline timing only: no per-kernel pass, no CPU baseline, no extra legs (what the `also` children of the default run use)")
+    ap.add_argument("--per-op", default="both", choices=["both", "in_step"],
+                    help="the per-op timing passes after the timed region: both = one with the step's side streams (in step) and one with "
+                         "everything inlined on one stream (alone); in_step = only the first, so that EVERY step of the process ran with its "
+                         "side streams - the run tools/profile_r5.sh puts under rocprofv3 for kernel_stats.csv")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the extra legs of the default 1-GPU run (S2, CIF_Model, greedy decode: BASELINE configs[2] / [3] and SURVEY 8(f)1)")
     return ap.parse_args()
@@ -337,7 +341,8 @@ def oracle_parity(asr_amd, model, x, lens, tg, n_utt=2):
 
 # ---- kernel families: which device kernel an op name runs on (for the dominant-KERNEL pick and the PMC lookup) -------------------
 def family(op_name):
-    return op_name.split("[", 1)[0]
+    f = op_name.split("[", 1)[0]
+    return "gemm_tn" if f == "gemm_tn_group" else f        # (a grouped launch = up to 8 weight gradients in one launch pair: same kernels)
 
 
 def pmc_traffic(fam_kernel, prof_dir):
@@ -356,10 +361,16 @@ def pmc_traffic(fam_kernel, prof_dir):
 
 
 FAMILY_KERNEL = {"vocab_proj_lse": "vocab_proj_lse_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_v2_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
-                 "attention_fwd": "attn_fwd_bf16_v3_kernel", "attention_bwd": "attn_bwd_fused_kernel",
-                 "attention_bwd_dq": "attn_bwd_dq_kernel", "attention_bwd_dkv": "attn_bwd_dkv_kernel",
+                 "attention_fwd": "attn_fwd_bf16_v4a_kernel", "attention_bwd_dq": "attn_bwd_dq_v4_kernel", "attention_bwd_dkv": "attn_bwd_dkv_v4_kernel",
                  "add_layernorm": "add_layernorm_fwd_kernel", "add_layernorm_bwd": "add_layernorm_bwd_kernel",
-                 "ctc_loss_fwd": "ctc_fused_fwd_kernel", "ctc_loss_bwd": "ctc_grad_bf16_kernel", "proj_heads": "gemm_nt_glds_kernel"}
+                 "ctc_loss_fwd": "ctc_fused_fwd_kernel", "ctc_loss_bwd": "ctc_grad_bf16_kernel", "proj_heads": "proj_heads_rows_kernel"}
+# every device kernel an op family launches, as rocprofv3's kernel_stats.csv names them (substring match): what tools/roofline_from_csv.py
+# sums to recompute a family's in-step rate from profiles/rN/bench_train_kernel_stats.csv
+FAMILY_CSV_KERNELS = {"gemm_tn": ["gemm_tn_v2_kernel", "gemm_tn_v2_group_kernel", "tn_reduce_kernel", "tn_reduce_group_kernel", "gemm_tn_kernel"],
+                      "ffn_fwd": ["ffn_fwd_kernel"], "ffn_bwd": ["ffn_bwd_kernel"], "attention_fwd": ["attn_fwd_bf16_v4a_kernel", "attn_fwd_bf16_v2_kernel"],
+                      "attention_bwd_dq": ["attn_bwd_dq_v4_kernel", "attn_bwd_dq_kernel"], "attention_bwd_dkv": ["attn_bwd_dkv_v4_kernel", "attn_bwd_dkv_kernel"],
+                      "vocab_proj_lse": ["vocab_proj_lse_kernel"], "ctc_loss_fwd": ["ctc_fused_fwd_kernel", "ctc_gather_lse_kernel", "ctc_mitm_kernel"],
+                      "ctc_loss_bwd": ["ctc_grad_bf16_kernel", "ctc_grad_kernel", "ctc_mitm_kernel"]}
 
 
 def main():
@@ -414,7 +425,10 @@ def main():
 
     lens_host = [int(v) for v in lens.tolist()]
 
+    n_steps = [0]
+
     def step():
+        n_steps[0] += 1
         if trainer is not None:
             if use_graph:
                 return trainer.step_graphed(x, lens, tg, max_target_len=CFG["U"])
@@ -511,14 +525,33 @@ def main():
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    # Two more passes over the same steps, eager, every C-ABI call bracketed by HIP timing events on the stream it is launched on:
+    #  (1) IN STEP: the step exactly as it was timed above - CTC branch, weight gradients and dropout-mask hashing on their side
+    #      streams - so every bracket holds the kernel's duration WITH its neighbours on the chip (what rocprofv3's kernel_stats.csv of
+    #      this command averages; tools/roofline_from_csv.py recomputes roofline.frac_in_step from that file);
+    #  (2) ALONE: the same launches, same kernels, all on one stream - the side branches inlined, the masks hashed in line - so
+    #      every bracket holds the kernel by itself.  (Round 4 ran this pass with the mask stream still live - twelve 60 us hashing
+    #      launches landing inside ffn_fwd's brackets: 222 us for a 97-115 us kernel - and with the streaming CTC forward instead of
+    #      the projection + lse form the step runs.)
+    prof_in_step = None
     if trainer is not None:
         use_graph = auto_graph = False
-        trainer.wgrad_stream = False
-        trainer.overlap_ctc = False
-    ops.profile_start()
-    for _ in range(args.steps):
-        step()
-    prof = ops.profile_stop()
+        ops.profile_start()
+        for _ in range(args.steps):
+            step()
+        prof_in_step = ops.profile_stop()
+        from asr_amd import modules as _modules
+        if args.per_op == "both":
+            trainer.wgrad_stream = False
+            trainer.side_inline = True              # the CTC branch's own kernels (vocab_proj_lse, gather + recursion, gradient) on the launch stream
+            _modules._MASK_PREFETCH = False
+    if prof_in_step is not None and args.per_op == "in_step":
+        prof = prof_in_step
+    else:
+        ops.profile_start()
+        for _ in range(args.steps):
+            step()
+        prof = ops.profile_stop()
 
     if rank == 0:
         frames = world * CFG["B"] * CFG.get("raw_T", CFG["T"]) * args.steps
@@ -536,16 +569,29 @@ def main():
             f["work"] += r["work"]
             f["calls"] += r["calls"]
         kernels.sort(key=lambda k: -k["ms_per_step"])
+        fams_in = {}
+        for name, r in (prof_in_step or {}).items():
+            f = fams_in.setdefault(family(name), dict(ms=0.0, work=0.0, calls=0, hbm=name.startswith(hbm_ops)))
+            f["ms"] += r["ms"]
+            f["work"] += r["work"]
+            f["calls"] += r["calls"]
         # dominant KERNEL = the family (all shapes of one device kernel) with the most time in the step
         dom_name, dom = max(((n, f) for n, f in fams.items() if f["work"] > 0), key=lambda nf: nf[1]["ms"])
         ach = dom["work"] / (dom["ms"] * 1e-3) / (1e9 if dom["hbm"] else 1e12)
         peak = PEAK_HBM_GBS if dom["hbm"] else PEAK_MFMA_BF16_TFLOPS
+        dom_in = fams_in.get(dom_name)
+        ach_in = (dom_in["work"] / (dom_in["ms"] * 1e-3) / (1e9 if dom["hbm"] else 1e12)) if dom_in and dom_in["ms"] > 0 else None
         prof_dir = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r4", "r3", "r2", "r1"))
                          if os.path.exists(os.path.join(d, "pmc_traffic_train_s1.json"))), os.path.join(ROOT, "profiles", "r4"))
         traffic = pmc_traffic(FAMILY_KERNEL.get(dom_name, dom_name), prof_dir)
         roofline = dict(kernel="%s (%s, all shapes)" % (dom_name, FAMILY_KERNEL.get(dom_name, dom_name)),
                         bound="hbm" if dom["hbm"] else "mfma", achieved=round(ach, 2), peak=peak,
                         unit="GB/s" if dom["hbm"] else "TFLOP/s", frac=round(ach / peak, 4),
+                        frac_in_step=(round(ach_in / peak, 4) if ach_in else None),
+                        achieved_in_step=(round(ach_in, 2) if ach_in else None),
+                        ms_per_step_in_step=(round(dom_in["ms"] / args.steps, 3) if dom_in else None),
+                        algorithmic_work_per_step=dom["work"] / args.steps,
+                        csv_kernels=FAMILY_CSV_KERNELS.get(dom_name, [FAMILY_KERNEL.get(dom_name, dom_name)]),
                         launches_per_step=dom["calls"] / args.steps, ms_per_step=round(dom["ms"] / args.steps, 3),
                         avg_launch_us=round(dom["ms"] / dom["calls"] * 1e3, 2),
                         traffic=traffic,
@@ -553,9 +599,12 @@ def main():
                                         "%s/pmc_traffic_train_s1.json: a committed profile of this same command (rocprofv3 --pmc FETCH_SIZE and "
                                         "--pmc WRITE_SIZE in separate passes), NOT measured in this run" % os.path.relpath(prof_dir, ROOT)),
                         note="dominant kernel = the op family (one device kernel, all shapes summed) with the most time per step; "
-                             "achieved = algorithmic FLOPs (or bytes) of all its launches / their summed duration from HIP events on the "
-                             "launch stream, in a second eager pass of the same steps without side streams (uncontended per-op "
-                             "durations; `value` is measured with them); traffic = mean HBM bytes per launch from separate rocprofv3 "
+                             "achieved / frac = algorithmic FLOPs (or bytes) of all its launches / their summed duration from HIP events on the "
+                             "launch stream, in an eager pass of the same steps with every side branch inlined on one stream (each kernel "
+                             "alone on the chip); achieved_in_step / frac_in_step = the same from an eager pass WITH the step's side streams "
+                             "(each kernel beside its neighbours, as `value` is measured) - recompute it from rocprofv3's kernel_stats.csv of "
+                             "this command: algorithmic_work_per_step x steps / total duration of csv_kernels (tools/roofline_from_csv.py); "
+                             "traffic = mean HBM bytes per launch from separate rocprofv3 "
                              "--pmc FETCH_SIZE / WRITE_SIZE passes (%s/pmc_traffic_train_s1.json; FETCH doubled per the gfx950 "
                              "correction)" % os.path.relpath(prof_dir, ROOT))
         if dom_name == "gemm_tn" and args.mode == "train":
@@ -604,6 +653,40 @@ def main():
             torch.cuda.synchronize()
             ctc_iso = e0.elapsed_time(e1) / 30
             del lg_
+        ctc_block = None
+        if ctc_k:
+            logit_bytes = 4.0 * CFG["B"] * Lc * CFG["vocab_size"]
+
+            def pick(profd, prefix):
+                r = [(n, v) for n, v in (profd or {}).items() if n.startswith(prefix)]
+                return (sum(v["ms"] for _, v in r) / max(1, sum(v["calls"] for _, v in r))) if r else None
+            grad_bytes = (2.0 if trainer is not None else 4.0) * CFG["B"] * Lc * CFG["vocab_size"]
+            branch = {}
+            for tag, profd in (("alone", prof), ("in_step", prof_in_step)):
+                vp, fw, bw = pick(profd, "vocab_proj_lse"), pick(profd, "ctc_loss_fwd"), pick(profd, "ctc_loss_bwd")
+                if fw is None:
+                    continue
+                branch[tag] = {"vocab_proj_lse_ms": None if vp is None else round(vp, 4), "ctc_fwd_ms": round(fw, 4),
+                               "ctc_bwd_ms": None if bw is None else round(bw, 4),
+                               # forward priced on the unfused op's bytes (the B x L x V x 4 logits read once), SURVEY 8(d)
+                               "fwd_frac_of_hbm_peak": round(logit_bytes / (fw * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                               "fwd_bwd_GBps": (round((2 * logit_bytes + grad_bytes) / ((fw + bw) * 1e-3) / 1e9, 1) if bw else None)}
+            ctc_block = {
+                "form_in_step": ("the projection writes the logits AND their row log-sum-exp (vocab_proj_lse_kernel); the CTC forward behind it "
+                                 "gathers ~52 logits per frame and runs the alpha / beta chains (ctc_gather_lse_kernel + ctc_mitm_kernel); the "
+                                 "backward streams the logits once and writes the bf16 gradient image (ctc_mitm_kernel + ctc_grad_bf16_kernel) - "
+                                 "all on the trainer's side stream beside the decoder" if vp_k else
+                                 "one launch: persistent pass workgroups stream the logits, the recursion waves consume the table rows as they arrive"),
+                "branch_ms_per_call": branch,
+                "ms_per_step_fwd": ctc_k[0]["ms_per_step"], "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
+                "fwd_ms_standalone": (round(ctc_iso, 4) if ctc_iso else None),
+                "fwd_GBps_standalone": (round(logit_bytes / (ctc_iso * 1e-3) / 1e9, 1) if ctc_iso else None),
+                "fwd_frac_of_hbm_peak_standalone": (round(logit_bytes / (ctc_iso * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if ctc_iso else None),
+                "note": "branch_ms_per_call: the CTC branch's ops as the timed step runs them (HIP events on their launch stream), `in_step` = on "
+                        "the side stream beside the decoder, `alone` = the same launches inlined on one stream; *_standalone: the STREAMING "
+                        "form of the op by itself (asr_ctc_loss_mean_fwd on resident fp32 logits of the same shape, which it reads in full: one "
+                        "launch, 30 back-to-back) - the form every caller without a precomputed row lse gets, and the one the north-star's "
+                        "HBM-roofline fraction is quoted on (algorithmic bytes = B x L x V x 4, SURVEY 8(d))"}
         result = {
             "metric": "fbank frames/sec (%s d%d h%d enc%d/dec%d, %s)" % (mname.split(":")[1].strip().split(" ")[0], CFG["d_model"], CFG["n_head"], CFG["n_layers_enc"], CFG["n_layers_dec"], what),
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -615,29 +698,19 @@ def main():
                        "launch_calibration_ms": launch_timing,       # step_auto's own eager vs replay timing (4 steps each, during initialisation)
                        "settle_ms": [round(v, 3) for v in settle]},   # ms/step of the 5-step groups run until steady, before the W warm-up steps
             "losses_last_step": losses,
+            # training steps this process executed in all (initialisation + launch calibration + settle groups + warm-up + timed + per-op
+            # passes): the divisor for per-step figures taken from a rocprofv3 kernel_stats.csv of this command
+            "steps_executed": (int(trainer.step_num) if trainer is not None else n_steps[0]),
             "roofline": roofline,
-            "ctc": ({"ms_per_step_fwd": ctc_k[0]["ms_per_step"], "fwd_GBps": ctc_k[0]["achieved"],
-                     "fwd_frac_of_hbm_peak": round(ctc_k[0]["achieved"] / PEAK_HBM_GBS, 4),
-                     "fwd_form": ("label gather + alpha / beta recursion from the row log-sum-exp the ctc_fc projection took in its own launch "
-                                  "(vocab_proj_lse: %s ms/step for projection + lse); the forward reads ~52 logits per frame, its rate is "
-                                  "priced on the unfused op's bytes (the B x L x V x 4 logits read once), as SURVEY 8(d) allows"
-                                  % (vp_k[0]["ms_per_step"] if vp_k else "?")) if vp_k else
-                                 "one launch: persistent pass workgroups stream the logits, the recursion waves consume the table rows as they arrive",
-                     "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),
-                     # bytes: the logits read twice (f32) + the gradient written (bf16 image in the trainer)
-                     "fwd_bwd_GBps": (round((2 * 4.0 + (2.0 if trainer is not None else 4.0)) * CFG["B"] * Lc * CFG["vocab_size"] / ((ctc_k[0]["ms_per_call"] + ctc_b[0]["ms_per_call"]) * 1e-3) / 1e9, 1)
-                                      if ctc_b else None),
-                     "fwd_ms_standalone": (round(ctc_iso, 4) if ctc_iso else None),
-                     "fwd_frac_of_hbm_peak_standalone": (round(4.0 * CFG["B"] * Lc * CFG["vocab_size"] / (ctc_iso * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
-                                                         if ctc_iso else None),
-                     "note": "ms_per_step_fwd / fwd_frac_of_hbm_peak: the CTC forward inside the step (HIP events on its launch stream); "
-                             "*_standalone: the STREAMING form of the op alone (asr_ctc_loss_fwd on resident fp32 logits of the same shape, "
-                             "which it reads in full: 30 launches back-to-back) - the form every caller without a precomputed row lse gets"}
-                    if ctc_k else None),
+            "ctc": ctc_block,
             "kernels": kernels[:12], "op_ms_total": round(sum(k["ms_per_step"] for k in kernels), 3),
             "families": sorted(({"family": n, "ms_per_step": round(f["ms"] / args.steps, 3),
                                  "achieved": round(f["work"] / (f["ms"] * 1e-3) / (1e9 if f["hbm"] else 1e12), 1) if f["work"] else None,
                                  "unit": "GB/s" if f["hbm"] else "TFLOP/s"} for n, f in fams.items()), key=lambda d: -d["ms_per_step"])[:8],
+            # the same table from the in-step pass (kernels beside their neighbours on the side streams): what kernel_stats.csv shows
+            "families_in_step": sorted(({"family": n, "ms_per_step": round(f["ms"] / args.steps, 3),
+                                         "achieved": round(f["work"] / (f["ms"] * 1e-3) / (1e9 if f["hbm"] else 1e12), 1) if f["work"] else None,
+                                         "unit": "GB/s" if f["hbm"] else "TFLOP/s"} for n, f in fams_in.items()), key=lambda d: -d["ms_per_step"])[:8],
         }
         if also is not None:
             # the other workloads BASELINE.json names, measured by this same command (child processes that ran before this one touched the GPU)

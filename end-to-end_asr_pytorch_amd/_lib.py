@@ -51,6 +51,7 @@ SIGNATURES = {
     "asr_rccl_unique_id": [_vp],
     "asr_rccl_comm_create": [_vp, _i, _i, _vp],
     "asr_rccl_comm_destroy": [_vp],
+    "asr_rccl_comm_abort": [_vp],
     "asr_rccl_all_reduce_f32": [_vp, _vp, ctypes.c_longlong, _vp],
     "asr_rccl_comm_check": [_vp],
     "asr_collective_mark": [_vp, ctypes.c_longlong, _i, _vp],

@@ -116,6 +116,15 @@ extern "C" int asr_rccl_comm_destroy(void* comm) {
     return 0;
 }
 
+// Tear the communicator down WITHOUT waiting for outstanding collectives (ncclCommAbort): peers blocked in a collective with this rank
+// get an asynchronous error.  For a rank that cannot complete a step it has partly queued (asr_graphx_launch does this itself).
+extern "C" int asr_rccl_comm_abort(void* comm) {
+    if (!comm || !api.dl) return 0;
+    if (!api.CommAbort) return asr_rccl_comm_destroy(comm);
+    RCCL_CHECK(api.CommAbort(static_cast<ncclComm_t>(comm)));
+    return 0;
+}
+
 // buf <- sum over ranks of buf (f32, in place), queued on `stream`; returns once it is queued.
 extern "C" int asr_rccl_all_reduce_f32(void* comm, float* buf, long long count, void* stream) {
     ASR_REQUIRE(api.dl && comm && buf && count > 0, -1, "rccl_all_reduce: bad arguments");

@@ -148,6 +148,68 @@ __device__ __forceinline__ void ctc_row_finish(const float* __restrict__ x, cons
     }
 }
 
+// The fused forward's form of ctc_row_finish: the row's labels are gathered from an LDS image of the row instead of being loaded a
+// second time.  Why: with 8 pass workgroups per CU streaming 17 KB rows, 32 CUs x 8 x 17 KB = 4.3 MB are in flight per XCD - the size
+// of its L2 - so by the time a row's (max, sum) are reduced its lines are gone and each of the ~52 distinct gathered labels is one more
+// 64-byte sector from the fabric: 52 x 64 B = 3.3 KB per 16.9 KB row, the 1.23 x FETCH_SIZE the round-4 counters showed (705 MB against
+// 574).  The image is written from the registers the row was loaded into (16-byte stores, lane-consecutive: conflict-free) into the
+// LDS the launch holds anyway for its recursion workgroups' rings and a pass workgroup never used.  Two barriers per row, as before:
+// one before the image is overwritten (the previous row's gathers are done; it also covers sm / ss / sn), one before it is read -
+// every thread then combines the four wave partials itself (same order, same bits as thread 0 did).
+// rowbuf: >= 16 * ceil(V / 4) + 32 bytes, 16-byte aligned.  Same table bits as ctc_row_finish.
+__device__ __forceinline__ void ctc_row_finish_lds(const CtcRowRegs& r, const float* __restrict__ x, const int64_t* __restrict__ targets,
+                                                   int V, int Umax, int blank, float* __restrict__ lse_out, float* __restrict__ lp_ext,
+                                                   int b, int row, float m, float s, float* __restrict__ rowbuf, bool no_gather) {
+    const int tid = threadIdx.x;
+    const int mis = (int)((reinterpret_cast<uintptr_t>(x) >> 2) & 3);
+    const int peel = min((4 - mis) & 3, V);
+    const int nv4 = (V - peel) >> 2;
+    const int tail0 = peel + nv4 * 4;
+    __shared__ float sm[4], ss[4];
+    __shared__ int sn[4];
+    __syncthreads();                                  // the previous row's readers are done with the image and the partials
+    f32x4* img4 = reinterpret_cast<f32x4*>(rowbuf);
+    float* imgx = rowbuf + (size_t)((V + 3) >> 2) * 4;   // head / tail elements, as thread tid holds them in r.xe
+#pragma unroll
+    for (int j = 0; j < LSE_UNR; ++j) {
+        const int i = tid + 256 * j;
+        if (i < nv4) img4[i] = r.v[j];
+    }
+    if (tid < 8) imgx[tid] = r.xe;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+        lse_combine(m, s, m2, s2);
+    }
+    int nlab = 0;
+    for (int i = tid; i < Umax; i += 256) nlab += targets[(int64_t)b * Umax + i] != 0 ? 1 : 0;
+    nlab = (int)wave_sum((float)nlab);
+    if ((tid & 63) == 0) { sm[tid >> 6] = m; ss[tid >> 6] = s; sn[tid >> 6] = nlab; }
+    __syncthreads();
+    float M = sm[0], S = ss[0];
+    for (int w = 1; w < 4; ++w) lse_combine(M, S, sm[w], ss[w]);
+    const float lse = M + logf(S);
+    if (tid == 0) lse_out[row] = lse;
+    const int Ub = sn[0] + sn[1] + sn[2] + sn[3];
+    const int Sp = ctc_row_stride(Umax), Sb = 2 * Ub + 1;
+    auto gather = [&](int sidx) {
+        float v = -INFINITY;
+        if (sidx < Sb) {
+            int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
+            lab = min(max(lab, 0), V - 1);
+            const int p = lab - peel;
+            const float xv = no_gather ? 0.f : (lab < peel ? imgx[lab] : (p < nv4 * 4 ? rowbuf[p] : imgx[peel + lab - tail0]));
+            v = (xv - lse) * LOG2E;
+        }
+        return v;
+    };
+    for (int pr = tid; pr < Sp / 2; pr += 256) {
+        const f32x2 v2 = {gather(2 * pr), gather(2 * pr + 1)};
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(lp_ext + (int64_t)row * Sp + 2 * pr),
+                           __builtin_bit_cast(unsigned long long, v2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // one table row (b, t): log-sum-exp over the vocabulary, then the gather of the extended labels' base-2 log-probs
 __device__ __forceinline__ void ctc_lse_row(const float* __restrict__ logits, int64_t ldl, const int64_t* __restrict__ targets, int L, int V,
                                             int Umax, int blank, float* __restrict__ lse_out, float* __restrict__ lp_ext, int b, int t,
@@ -650,6 +712,8 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
         if (dbg & 32) return;      // (bit 5: timing experiment - the chains alone)
         const int G = W / RPB, npass = gridDim.x - Bn, total = nchunks * Bn * 2 * G;
         const bool w0 = threadIdx.x < 64;
+        // (dbg bit 1: the round-4 gather by a second global load of each label - A/B and the FETCH_SIZE attribution; bit 3: no gather, timing only)
+        const bool stage = !(dbg & 2) && ctc_row_fits_regs(V) && (size_t)((V + 3) >> 2) * 16 + 32 <= sizeof(ring);
         int* pending = nullptr;
         int pending_count = 0;
         for (int gid = blockIdx.x - Bn; gid < total; gid += npass) {
@@ -672,6 +736,19 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
                 const int t = t0 + tstep * r, row = b * L + t;
                 const float* x = logits + (int64_t)row * ldl;
                 float m, sx;
+                if (stage) {                             // labels gathered from an LDS image of the row (ctc_row_finish_lds)
+                    CtcRowRegs rr;
+                    ctc_row_load(x, V, rr);
+                    ctc_row_reduce(rr, m, sx);
+                    if (pending && w0) {                 // (this row's loads are back: the previous group's stores retired before them)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (threadIdx.x == 0) __hip_atomic_fetch_add(pending, pending_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    pending = nullptr;
+                    ctc_row_finish_lds(rr, x, targets, V, Umax, blank, lse_out, lp_ext, b, row, m, sx, reinterpret_cast<float*>(&ring[0][0]),
+                                       (dbg & 8) != 0);
+                    continue;
+                }
                 if (ctc_row_fits_regs(V)) {
                     CtcRowRegs rr;
                     ctc_row_load(x, V, rr);

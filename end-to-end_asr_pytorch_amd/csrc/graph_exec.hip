@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "asr_common.h"
@@ -439,8 +440,19 @@ extern "C" int asr_graphx_launch(void* handle, void* stream) {
         return -5;
     }
     const int rc = graphx_launch_nodes(g, main);
-    if (rc != 0)
+    if (rc != 0) {
+        // A step with collective nodes that failed part-way is fatal for the JOB, not only for this rank: the peers have queued (or will
+        // queue) the matching ncclAllReduce calls and would wait for this rank forever.  Abort the communicator so that they fail fast
+        // with an asynchronous error (asr_rccl_comm_check) instead; the message of the original failure is kept.
+        if (g->n_collective > 0 && g->comm) {
+            const std::string first = asr_last_error();
+            (void)asr_rccl_comm_abort(g->comm);
+            g->comm = nullptr;
+            asr_set_error("%s [the step's RCCL communicator was aborted: peers fail fast instead of waiting in an all-reduce this rank never joins]",
+                          first.c_str());
+        }
         for (size_t s = 1; s < g->streams.size(); ++s) (void)hipStreamSynchronize(g->streams[s]);
+    }
     return rc;
 }
 

@@ -4,7 +4,9 @@ Every function here takes torch CUDA tensors, passes raw device pointers + torch
 libasr_hip.so and returns torch tensors that own the outputs.  torch is plumbing only (allocation, streams);
 no arithmetic on the product path is done by torch ops.  There is no CPU fallback: CPU tensors raise.
 """
+import atexit
 import ctypes
+import weakref
 import os
 
 import torch
@@ -535,6 +537,16 @@ _AUX = {}
 # shape against 133-139 fused with 32 chunks
 CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "32"))
 _CTC_COUNTERS = {}
+_CTC_DBG = int(os.environ.get("ASR_AMD_CTC_DBG", "0") or 0) & 0xff
+
+
+def ctc_reset_counters():
+    """Forget the cached arrival-counter buffers of the one-launch CTC forward.  The launch hands its counters back zeroed when it ends
+    cleanly; after anything else - a NaN loss from its bounded wait (a producer that never arrived), a device fault, an aborted
+    stream - a caller that reads the loss back and finds it non-finite calls this, so that the next call starts from zeroed words instead of passing its
+    gates early on stale arrivals."""
+    _CTC_COUNTERS.clear()
+
 CTC_LAZY_OCC = os.environ.get("ASR_AMD_CTC_LAZY_OCC", "1") != "0"     # asr_ctc_loss_bwd with the second workspace (see asr_hip.h)
 
 
@@ -633,9 +645,14 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None, lse=None):
         nw = int(lib().asr_ctc_counter_words(B, L, nck))
         if nw:
             key = (dev.index, _stream().value, nw)
-            if key not in _CTC_COUNTERS:
-                _CTC_COUNTERS[key] = torch.zeros(nw, device=dev, dtype=torch.int32)
-            counters = _CTC_COUNTERS[key]
+            if _CTC_DBG:
+                # a diagnostic build of the launch (ASR_AMD_CTC_DBG: pass only, chains only, ...) does not end by handing the counters
+                # back zeroed: never let such a call share the cached buffer with a later one
+                counters = torch.zeros(nw, device=dev, dtype=torch.int32)
+            else:
+                if key not in _CTC_COUNTERS:
+                    _CTC_COUNTERS[key] = torch.zeros(nw, device=dev, dtype=torch.int32)
+                counters = _CTC_COUNTERS[key]
     loss = torch.empty(1, device=dev, dtype=torch.float32)
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):
         check(lib().asr_ctc_loss_mean_fwd(_stream(), _p(logits), st.ldl, _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank, _p(st.lse),
@@ -1442,15 +1459,43 @@ def cif_bwd(hidden, cur, rem, tok, n_fire, d_out):
 
 
 # ---- gradient all-reduce from the C launch loop (asr_hip.h: asr_rccl_*, asr_collective_mark; csrc/collective.hip) ----------------------
-_RCCL = {"loaded": False, "comms": {}}
+class _DefaultGroupKey:
+    pass
+
+
+_DEFAULT_GROUP_KEY = _DefaultGroupKey()
+_RCCL = {"loaded": False, "comms": weakref.WeakKeyDictionary()}
+
+
+def _rccl_teardown():
+    """atexit: ncclCommDestroy for every communicator the library created (before the runtime goes away)"""
+    try:
+        for c in list(_RCCL["comms"].values()):
+            c.destroy()
+    except Exception:
+        pass
+
+
+atexit.register(_rccl_teardown)
 _COLLECTIVE_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p)
 
 
 def rccl_load():
     """Bind RCCL's C API inside libasr_hip.so: the librccl torch has already mapped (one RCCL per process), else ROCm's."""
     if not _RCCL["loaded"]:
-        cands = [os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"]
-        path = next((c for c in cands if os.path.exists(c)), None)
+        # one RCCL per process: whatever librccl is ALREADY mapped (torch's own copy, under whatever file name) is the one to bind -
+        # by its mapped path, so that the loader cannot bring in a second copy under another name
+        mapped = None
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    if "librccl" in line and "/" in line:
+                        mapped = line[line.index("/"):].strip()
+                        break
+        except OSError:
+            pass
+        cands = [mapped, os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so.1"]
+        path = next((c for c in cands if c and os.path.exists(c)), None)
         check(lib().asr_rccl_load(path.encode() if path else None), "asr_rccl_load")
         _RCCL["loaded"] = True
 
@@ -1482,7 +1527,9 @@ def rccl_comm(group=None, device=None):
     """The RcclComm over the ranks of `group` (default group when None; a 1-rank communicator when torch.distributed is not
     initialised).  Collective over the group on first use: rank 0's unique id travels through torch.distributed (bootstrap only)."""
     import torch.distributed as dist
-    key = id(group) if group is not None else 0
+    # keyed on the group OBJECT (weakly): id() of a destroyed group can be handed to a new one, which would then get a communicator
+    # over the old group's ranks
+    key = group if group is not None else _DEFAULT_GROUP_KEY
     if key in _RCCL["comms"]:
         return _RCCL["comms"][key]
     rccl_load()

@@ -246,8 +246,10 @@ class Trainer:
         encoder's backward begins - adds in.  Called from the model's forward through `_ctc_hook`."""
         model = self.model
         main = torch.cuda.current_stream()
-        aux = ops.aux_stream(enc.f32.device)
-        aux.wait_stream(main)
+        # (side_inline: the same launches in the same order on the launch stream itself - bench.py's kernel-alone timing pass)
+        aux = main if getattr(self, "side_inline", False) else ops.aux_stream(enc.f32.device)
+        if aux is not main:
+            aux.wait_stream(main)
         if pre_event is not None:
             aux.wait_event(pre_event)
             ctc_targets.record_stream(aux)
@@ -282,7 +284,8 @@ class Trainer:
                 return
             enc.lazy_grad = None
             main_now = torch.cuda.current_stream()
-            main_now.wait_stream(aux)
+            if aux is not main_now:
+                main_now.wait_stream(aux)
             g = proxy.grad
             g.record_stream(main_now)               # allocated on the side stream, last read here
             modules._acc(enc, g)
@@ -349,9 +352,14 @@ class Trainer:
                 out = model(feats, lens, targets)
                 if isinstance(model, modules.Conv_CTC_Transformer):
                     ctc_logits, ctc_len, logits, teos = out
-                else:
+                elif isinstance(model, modules.CTC_Transformer):
                     ctc_len, ctc_logits, (logits, teos) = out
-            if self._side is not None:     # already computed (and differentiated) on the side stream
+                else:
+                    # attention-only family (Transformer_Solver, solver.py:26-31): loss = cal_ce_loss(logits, targets_eos) alone
+                    (logits, teos), ctc_logits = out, None
+            if ctc_logits is None:
+                ctc, st = torch.zeros((), device=logits.device), None
+            elif self._side is not None:     # already computed (and differentiated) on the side stream
                 ctc, st = self._side["ctc"], None
             else:
                 ctc, nll, st = ops.ctc_loss_fwd(ctc_logits, ops.as_i32(ctc_len, ctc_logits.device), teos)
@@ -459,8 +467,11 @@ class Trainer:
     def _graph_ok(self, feats, max_target_len):
         if self._graph_failed is not None or not feats.is_cuda or max_target_len is None:
             return False
-        if self.world > 1 and (not GRAPH_EXEC or os.environ.get("ASR_AMD_GRAPH_DP", "1") == "0"):
-            return False          # with N > 1 the step is captured only for the executor (its C loop makes the RCCL calls); =0: eager
+        if self.world > 1 and (not GRAPH_EXEC or os.environ.get("ASR_AMD_GRAPH_DP", "0") != "1"):
+            # with N > 1 the step is captured only for the executor (its C loop makes the RCCL calls), and only on request: the
+            # library-owned communicator has run at world = 1 and through the gloo rig, never on N > 1 GPUs - until it has,
+            # N > 1 steps are queued eagerly and all-reduced through torch.distributed
+            return False
         m = self.model
         return isinstance(m, (modules.CTC_Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"
 
@@ -489,6 +500,15 @@ class Trainer:
         # re-captured the whole step).  The key is what fixes the graph's shape: shapes / dtypes of every input, the longest target.
         sig = lambda t: None if t is None else (tuple(t.shape), t.dtype)
         key = (sig(feats), sig(lens), sig(targets), sig(noise), max_target_len, self.model.training, self.overlap_ctc, self.wgrad_stream)
+        if self._graph is not None and self._graph_key != key and self.world > 1 and self._graphx is not None:
+            # A re-capture is a collective act (the communicator bootstrap and the MIN "ok" all-reduce of _capture run through
+            # torch.distributed) while the peers that still hold a matching graph sit in the executor's all-reduces on the library's own
+            # communicator: the two sides would wait on different communicators forever.  Fixed shapes on every rank are the contract of
+            # the captured data-parallel step; anything else has to say so loudly.
+            raise RuntimeError("Trainer.step_graphed with world_size %d: the batch signature changed after the step was captured (%r -> %r). "
+                               "The captured data-parallel step needs the same shapes and max_target_len on every rank and every step - "
+                               "bucket the loader to fixed shapes, or step eagerly (Trainer.step / ASR_AMD_GRAPH_DP=0)."
+                               % (self.world, self._graph_key, key))
         if self._graph is None or self._graph_key != key:
             if self._eager_steps < 2:
                 self._eager_steps += 1

@@ -212,13 +212,16 @@ int asr_graphx_destroy(void* handle);
  * by bucket).  RCCL is bound at run time: asr_rccl_load(path) (NULL: the librccl already mapped into the process, e.g. torch's).
  * asr_rccl_unique_id fills ASR_RCCL_ID_BYTES bytes on ONE rank; the caller carries them to the others (bootstrap only) and every rank
  * calls asr_rccl_comm_create(id, nranks, rank) with its device current.  asr_rccl_all_reduce_f32 queues buf <- sum over ranks, in
- * place, on `stream`.  asr_rccl_comm_check returns the communicator's asynchronous error state (0 = healthy). */
+ * place, on `stream`.  asr_rccl_comm_check returns the communicator's asynchronous error state (0 = healthy).  asr_rccl_comm_abort tears
+ * a communicator down without waiting for outstanding collectives (peers see an asynchronous error instead of waiting forever);
+ * asr_graphx_launch does that itself when a step with collective nodes fails part-way - such a failure is fatal for the job. */
 #define ASR_RCCL_ID_BYTES 128
 int asr_rccl_load(const char* path);
 int asr_rccl_version(int* version);
 int asr_rccl_unique_id(void* out_id);
 int asr_rccl_comm_create(const void* id, int nranks, int rank, void** out_comm);
 int asr_rccl_comm_destroy(void* comm);
+int asr_rccl_comm_abort(void* comm);
 int asr_rccl_all_reduce_f32(void* comm, float* buf, long long count, void* stream);
 int asr_rccl_comm_check(void* comm);
 /* The ready point of a gradient bucket: a no-op kernel node on `stream` carrying (buf, count, tag).  Launched while a step is being

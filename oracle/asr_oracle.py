@@ -581,6 +581,14 @@ def cal_ctc_qua_ce_loss(logits_ctc, len_logits_ctc, _number, number, logits_ce, 
 # --------------------------------------------------------------------------------------
 # model wrappers  (return-tuple conventions of SURVEY §8a row 18)
 # --------------------------------------------------------------------------------------
+def transformer_forward(sd, features, len_features, targets, cfg):
+    """src/transformer/transformer.py:21-35 - the attention-only family: (logits, targets_eos) (+ the encoder output)."""
+    enc = encoder_forward(sd, "encoder.", features, len_features, cfg["n_layers_enc"], cfg["n_head"])
+    logits, teos = decoder_forward(sd, "decoder.", targets, enc, len_features, cfg["n_layers_dec"],
+                                   cfg["n_head"], cfg["sos_id"], cfg["eos_id"])
+    return logits, teos, enc
+
+
 def ctc_transformer_forward(sd, features, len_features, targets, cfg):
     """src/transformer/transformer.py:108-124 — (ctc_len, ctc_logits, (logits, targets_eos))."""
     enc = encoder_forward(sd, "encoder.", features, len_features, cfg["n_layers_enc"], cfg["n_head"])

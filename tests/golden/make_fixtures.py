@@ -39,7 +39,7 @@ torch.Tensor.cuda = lambda self, *a, **k: self
 import transformer.decoder as tdec  # noqa: E402
 
 tdec.pad_list = lambda xs, v: uu.pad_list(xs, v)[0]
-from transformer.transformer import Conv_CTC_Transformer, CTC_Transformer  # noqa: E402
+from transformer.transformer import Conv_CTC_Transformer, CTC_Transformer, Transformer  # noqa: E402
 from transformer.cif_model import CIF_Model  # noqa: E402
 from transformer.encoder import Encoder  # noqa: E402
 from transformer.decoder import Decoder  # noqa: E402
@@ -157,6 +157,41 @@ def g1_ctc_transformer():
                         ctc_loss=npy(ctc), ce_loss_s01=npy(ce), lr_step1=np.float64(opt.optimizer.param_groups[0]["lr"]),
                         **grads, **gnorm, **deltas, **cfg_arrays())
     print("G1 ctc", float(ctc), "ce", float(ce))
+
+
+def g17_transformer():
+    """The attention-only family: `Transformer` (transformer.py:7-35) stepped as `Transformer_Solver` does it (solver.py:26-35):
+    logits, targets_eos = model(x, lens, targets); loss = cal_ce_loss(logits, targets_eos, smoothing); zero_grad; backward; step."""
+    enc = Encoder(80, 2, 2, 64, 128, dropout=0.0)
+    dec = Decoder(2, 3, 50, 2, 2, 64, 128, dropout=0.0)
+    model = Transformer(enc, dec).eval()
+    ns, sd = load_seeded(model, seed=117)
+    x, lens, tg = s0_batch(seed=17)
+    x = x[:, :56].contiguous()
+    lens = torch.tensor([56, 41, 30, 9])
+    logits, teos = model(x, lens, tg)
+    enc_out = model.encoder(x, lens)
+    ce = cal_ce_loss(logits, teos, smoothing=0.1)
+    ce0 = cal_ce_loss(logits, teos, smoothing=0.0)
+    opt = TransformerOptimizer(torch.optim.Adam(model.parameters(), betas=(0.9, 0.98), eps=1e-9), 0.2, 64, 4000)
+    opt.zero_grad()
+    ce.backward()
+    grads = {"grad:" + k: npy(p.grad).astype(np.float32) for k, p in model.named_parameters()}
+    before = {k: npy(p).copy() for k, p in model.named_parameters()}
+    opt.step()
+    deltas = {"delta:" + k: (npy(p) - before[k]) for k, p in model.named_parameters()
+              if k in ("decoder.tgt_word_prj.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight", "decoder.layer_stack.1.enc_attn.w_vs.bias",
+                       "encoder.layer_norm_in.weight", "decoder.tgt_word_emb.weight", "encoder.layer_stack.1.pos_ffn.w_2.weight")}
+    # the loss after that step (a second forward of the updated model): pins the whole step, not only five tensors
+    with torch.no_grad():
+        logits2, _ = model(x, lens, tg)
+        ce_after = cal_ce_loss(logits2, teos, smoothing=0.1)
+    np.savez_compressed(os.path.join(HERE, "g17_transformer.npz"), names_shapes=names_shapes_to_json(ns), seed=117,
+                        crc=crc_of(sd), x=npy(x), lens=npy(lens), targets=npy(tg), enc_out=npy(enc_out),
+                        logits=npy(logits), targets_eos=npy(teos), ce_loss_s01=npy(ce), ce_loss_s0=npy(ce0),
+                        ce_loss_s01_after_step=npy(ce_after), lr_step1=np.float64(opt.optimizer.param_groups[0]["lr"]),
+                        **grads, **deltas, **cfg_arrays())
+    print("G17 ce", float(ce), "ce0", float(ce0), "after one step", float(ce_after))
 
 
 def g2_ctc():
@@ -817,3 +852,4 @@ if __name__ == "__main__":
     g15_decode_d256()
     g16_cif_label_count()
     g14_collate()
+    g17_transformer()

@@ -175,12 +175,19 @@ def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
     dkv = torch.zeros(B * Lk, 2 * h * 64, device=DEV, dtype=torch.bfloat16)
     ops.attention_bwd(qd, kd, vd, ctx_d, dctx.to(DEV).bfloat16(), lse, kl, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:])
     to_tok = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0] * t.shape[2], h * 64)
-    # bf16 operands / outputs on sums over up to Lq (dK, dV) or Lk (dQ) terms: the absolute error grows ~ sqrt(L)
-    # (6e-2: with the round-4 forward one dK element in 102 400 of the 200 x 200 case sits at 0.055 - the bf16 rounding of O moved, and with it delta)
-    tol = dict(atol=6e-2 * max(1.0, (max(Lq, Lk) / 250.0) ** 0.5), rtol=3e-2)
-    np.testing.assert_allclose(N(dq), (to_tok(q.grad) * 0.125).numpy(), **tol)
-    np.testing.assert_allclose(N(dkv[:, :h * 64]), to_tok(k.grad).numpy(), **tol)
-    np.testing.assert_allclose(N(dkv[:, h * 64:]), to_tok(v.grad).numpy(), **tol)
+    # bf16 operands (P, dS, dO rounded to bf16 before their products) and bf16 outputs, fp32 accumulation.  A parity bound must not
+    # grow with what the kernel happens to need, so it is stated relative to the gradient itself: per tensor the relative L2 error
+    # is <= 1.5e-2 (measured 3-6e-3), and every element is within 4e-2 of its token row's largest |gradient| (the rounding noise of
+    # a row's 64..1000-term sums scales with the row's magnitude, not with each element's)
+    for name, got, ref in (("dq", N(dq), (to_tok(q.grad) * 0.125).numpy()), ("dk", N(dkv[:, :h * 64]), to_tok(k.grad).numpy()),
+                           ("dv", N(dkv[:, h * 64:]), to_tok(v.grad).numpy())):
+        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert rel <= 1.5e-2, (name, rel)
+        rowmax = np.abs(ref).max(axis=1, keepdims=True)
+        worst = (np.abs(got - ref) / (rowmax + 1e-6 * np.abs(ref).max() + 1e-30)).max()
+        assert worst <= 4e-2, (name, worst)
+        # rows whose reference gradient is exactly zero (keys past k_len) are exactly zero
+        assert np.all(got[(rowmax == 0).ravel()] == 0), name
 
 
 def test_adam_step_matches_torch():

@@ -27,7 +27,9 @@ def _run(script_args, nproc, port, gloo_one_gpu):
     import time
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONFAULTHANDLER="1")
     if gloo_one_gpu:
-        env.update(ASR_AMD_DIST_BACKEND="gloo", ASR_AMD_DEVICE="0")
+        # (ASR_AMD_GRAPH_DP=1: the captured data-parallel step is opt-in until it has run on N > 1 GPUs; the rig asks for it so that
+        # bench.py's step_auto and dp_equiv.py --graph exercise the executor's collective nodes)
+        env.update(ASR_AMD_DIST_BACKEND="gloo", ASR_AMD_DEVICE="0", ASR_AMD_GRAPH_DP=env.get("ASR_AMD_GRAPH_DP", "1"))
     # One attempt, bounded.  (Round 3 retried here: the rig "hung once in a few dozen runs".  tools/dp_hang_hunt.py reproduced it - 6 of
     # 80 runs - and the workers' Python stacks showed one rank in bench.py's barrier and the other still stepping: bench.py ended its
     # settle loop on each rank's OWN timings, so the ranks ran different numbers of steps, i.e. of all-reduces.  The decision is
@@ -96,6 +98,7 @@ def test_two_ranks_through_the_graph_executor_equal_one_rank():
     lines = _run([os.path.join(ROOT, "tools", "dp_equiv.py"), "--graph"], 2, 29551, True)
     _check_equiv(lines, 2)
     assert all(o["executor"]["collectives"] >= 2 for o in lines), lines
+    assert all(o.get("recapture_refused") for o in lines), lines
 
 
 def test_rccl_communicator_refused_means_every_rank_steps_eagerly(monkeypatch):

@@ -1,5 +1,6 @@
-"""Size-independent properties at the BASELINE.json shapes (B=32, T=1000, U=50, V=4234, d_model=256): the oracle cannot run
-these sizes in seconds, so the kernels are held to identities the arithmetic must satisfy at any size."""
+"""The BASELINE.json shapes (B=32, T=1000, U=50, V=4234, d_model=256): the CTC op against aten's `F.log_softmax + F.ctc_loss` on
+the host for all 32 utterances (0.4 s of CPU), and - where the numpy oracle cannot run the size in seconds - identities the
+arithmetic must satisfy at any size."""
 import os
 
 import numpy as np
@@ -51,6 +52,64 @@ def test_ctc_full_size_properties():
     lp = torch.log_softmax(logits[7:8, :int(il[7])].double().cpu(), -1).transpose(0, 1)
     ref = torch.nn.functional.ctc_loss(lp, tg[7:8, :1].cpu(), il[7:8].cpu(), torch.tensor([1]), blank=V - 1, reduction="none")
     np.testing.assert_allclose(nll_h[7], float(ref), rtol=1e-5)
+
+
+@pytest.mark.parametrize("repeats", [False, True])
+def test_ctc_full_size_against_aten_all_utterances(repeats):
+    """SURVEY §8(d) S2 stand-alone CTC shape, every utterance: per-utterance nll, the mean loss and the FULL gradient against
+    `F.log_softmax` + `F.ctc_loss` (blank = V-1, reduction 'mean', loss.py:41-43) in fp32 - what the reference computes - and
+    against the same in float64 as the arbiter of which fp32 result is nearer the truth.  Ragged input lengths, two short
+    targets, a 20 %-repeats variant."""
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(5 + int(repeats))
+    logits = torch.randn(B, T, V, generator=g)
+    tg = torch.randint(1, V - 1, (B, U), generator=g)
+    if repeats:
+        rep = torch.rand(B, U, generator=g) < 0.2
+        rep[:, 0] = False
+        for u in range(1, U):
+            tg[:, u] = torch.where(rep[:, u], tg[:, u - 1], tg[:, u])
+    tg[3, 30:] = 0
+    tg[7, 1:] = 0
+    il = torch.randint(2 * U + 2, T + 1, (B,), generator=g)
+    il[0], il[1] = T, T
+    tl = tg.ne(0).int().sum(1)
+
+    def aten(dtype):
+        lg = logits.detach().clone().to(dtype).requires_grad_(True)
+        lp = F.log_softmax(lg, -1).transpose(0, 1)
+        nll = F.ctc_loss(lp, tg, il, tl, blank=V - 1, reduction="none")
+        loss = F.ctc_loss(lp, tg, il, tl, blank=V - 1)
+        loss.backward()
+        return nll.detach(), loss.detach(), lg.grad
+    nll32, loss32, g32 = aten(torch.float32)
+    nll64, loss64, g64 = aten(torch.float64)
+    ld = logits.to(DEV).requires_grad_(True)
+    loss, nll = asr_amd.ctc_loss(ld, il.to(DEV), tg.to(DEV))
+    loss.backward()
+    nll_h, grad = nll.cpu(), ld.grad.cpu()
+    # losses: rel 1e-5 vs the reference's fp32 (SURVEY §8(d) tolerance), and no further from float64 than that
+    np.testing.assert_allclose(nll_h.numpy(), nll32.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(nll_h.double().numpy(), nll64.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(float(loss), float(loss32), rtol=1e-5)
+    # gradient, every element of [32, 1000, 4234].  float64 aten is the arbiter: aten's OWN fp32 gradient is 8.4e-5 away from it at
+    # this shape (utterance 7 has one label: its occupancies are exp of fp32 log-domain sums of magnitude ~8 T, gradient scale
+    # 1 / (B * 1) = 0.031), i.e. 1.15 x (1e-5 + 2e-3 |g|) - so the bound that means something is "no further from the truth than
+    # the reference's arithmetic is": elementwise 1e-5 + 4e-3 |g| against float64, worst element <= 2 x aten-fp32's worst, and
+    # 1e-5 + 6e-3 |g| between the two fp32 results (each carries its own 2-3e-3)
+    d64 = (grad.double() - g64).abs()
+    assert bool((d64 <= 1e-5 + 4e-3 * g64.abs()).all()), float((d64 / (1e-5 + 4e-3 * g64.abs())).max())
+    e_ours, e_aten = float(d64.max()), float((g32.double() - g64).abs().max())
+    print("ctc full-size gradient: max |ours - f64| = %.3e, max |aten f32 - f64| = %.3e" % (e_ours, e_aten))
+    assert e_ours <= 2.0 * e_aten + 1e-7, (e_ours, e_aten)
+    d32 = (grad - g32).abs()
+    assert bool((d32 <= 1e-5 + 6e-3 * g32.abs()).all()), float(d32.max())
+    # utterances with the north-star target length (50 labels): SURVEY's abs <= 1e-5 holds outright
+    long_rows = (tl >= 30).nonzero().flatten()
+    assert float(d32[long_rows].max()) <= 1e-5 and float(d64[long_rows].max()) <= 1e-5
+    # frames past in_len: exactly zero
+    t_idx = torch.arange(T)[None, :]
+    assert float(grad[(t_idx >= il[:, None])].abs().max()) == 0.0
 
 
 def test_cif_full_size_conservation():

@@ -3,6 +3,7 @@ import argparse
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import asr_amd
@@ -97,11 +98,13 @@ def test_dropout_keys_match_the_oracle_restatement():
     assert asr_amd.dropout_thr16(0.1) == 6554 and asr_amd.dropout_thr16(0.0) == 0
 
 
-def test_generated_attention_stream_is_current():
-    """csrc/attention_fwd4_asm.inc is the output of tools/gen_attn_fwd4.py: an edit of one without the other must not go unnoticed."""
+@pytest.mark.parametrize("gen,inc", [("gen_attn_fwd4.py", "attention_fwd4_asm.inc"), ("gen_attn_bwd.py", "attention_bwd_asm.inc"),
+                                     ("gen_attn_bwd_dq.py", "attention_bwd_dq_asm.inc")])
+def test_generated_attention_streams_are_current(gen, inc):
+    """csrc/attention_*_asm.inc are the output of tools/gen_attn_*.py: an edit of one without the other must not go unnoticed."""
     import subprocess, sys, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "x.inc")
-        subprocess.run([sys.executable, os.path.join(root, "tools", "gen_attn_fwd4.py"), "--out", out], check=True, stderr=subprocess.DEVNULL)
-        assert open(out).read() == open(os.path.join(root, "end-to-end_asr_pytorch_amd", "csrc", "attention_fwd4_asm.inc")).read()
+        subprocess.run([sys.executable, os.path.join(root, "tools", gen), "--out", out], check=True, stderr=subprocess.DEVNULL)
+        assert open(out).read() == open(os.path.join(root, "end-to-end_asr_pytorch_amd", "csrc", inc)).read()

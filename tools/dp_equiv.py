@@ -65,7 +65,16 @@ def main():
         assert trainer.graph_active() and trainer._graphx is not None, trainer._graph_failed
         assert trainer._graphx.info["collectives"] >= len(trainer.buckets.ranges), trainer._graphx.info
         out["executor"] = trainer._graphx.info
-        return {n: p.grad.detach().float().clone() / trainer.world for n, p in trainer.model.named_parameters()}
+        res = {n: p.grad.detach().float().clone() / trainer.world for n, p in trainer.model.named_parameters()}
+        # a rank whose batch signature changes after the capture must fail loudly, not re-capture (its peers would be waiting in the
+        # executor's all-reduces on another communicator - ADVICE r4); raised before anything is queued, on every rank alike
+        try:
+            trainer.step_graphed(xs, ls, ts, max_target_len=umax + 1)
+            raise AssertionError("a changed batch signature re-captured the data-parallel step silently")
+        except RuntimeError as e:
+            assert "batch signature changed" in str(e), e
+            out["recapture_refused"] = True
+        return res
 
     graphed = "--graph" in sys.argv
     if graphed:
