@@ -176,18 +176,26 @@ def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
     ops.attention_bwd(qd, kd, vd, ctx_d, dctx.to(DEV).bfloat16(), lse, kl, causal, 0.125, dq, dkv[:, :h * 64], dkv[:, h * 64:])
     to_tok = lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0] * t.shape[2], h * 64)
     # bf16 operands (P, dS, dO rounded to bf16 before their products) and bf16 outputs, fp32 accumulation.  A parity bound must not
-    # grow with what the kernel happens to need, so it is stated relative to the gradient itself: per tensor the relative L2 error
-    # is <= 1.5e-2 (measured 3-6e-3), and every element is within 4e-2 of its token row's largest |gradient| (the rounding noise of
-    # a row's 64..1000-term sums scales with the row's magnitude, not with each element's)
+    # grow with what the kernel happens to need, so it is stated relative to the gradient itself (see attn_bwd_errors): per tensor the
+    # relative L2 error, and every element against the tensor's largest |gradient| (the noise of a row comes from sums of products
+    # |P| |dP| that cancel in dS = P (dP - delta): it scales with the tensor's magnitude, not with the element's or the row's own)
     for name, got, ref in (("dq", N(dq), (to_tok(q.grad) * 0.125).numpy()), ("dk", N(dkv[:, :h * 64]), to_tok(k.grad).numpy()),
                            ("dv", N(dkv[:, h * 64:]), to_tok(v.grad).numpy())):
-        rel = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
-        assert rel <= 1.5e-2, (name, rel)
-        rowmax = np.abs(ref).max(axis=1, keepdims=True)
-        worst = (np.abs(got - ref) / (rowmax + 1e-6 * np.abs(ref).max() + 1e-30)).max()
-        assert worst <= 4e-2, (name, worst)
+        rel, worst = attn_bwd_errors(got, ref)
+        assert rel <= ATTN_BWD_REL_L2, (name, rel, worst)
+        assert worst <= ATTN_BWD_ELEM, (name, rel, worst)
         # rows whose reference gradient is exactly zero (keys past k_len) are exactly zero
-        assert np.all(got[(rowmax == 0).ravel()] == 0), name
+        assert np.all(got[(np.abs(ref).max(axis=1) == 0)] == 0), name
+
+
+ATTN_BWD_REL_L2 = 1.5e-2     # per tensor: ||got - ref|| / ||ref||
+ATTN_BWD_ELEM = 3e-2         # per element: |got - ref| / max |ref| over the tensor
+
+
+def attn_bwd_errors(got, ref):
+    rel = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+    worst = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+    return rel, worst
 
 
 def test_adam_step_matches_torch():

@@ -6,15 +6,17 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 R=$PWD
 T="timeout -k 5"
-$T 900 python3 -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
+$T 900 python3 -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
 tail -5 $OUT/pytest.log
 $T 120 python3 tools/probe_bf16_split.py > $OUT/bf16_split.txt 2>&1
-for v in 0 2 8 4 6; do echo "== ASR_AMD_CTC_DBG=$v"; ASR_AMD_CTC_DBG=$v $T 120 python3 tools/ab_ctc.py; done > $OUT/ctc_ab.txt 2>&1
-( bash tools/kt_ctc.sh default ASR_AMD_CTC_DBG=2 ASR_AMD_CTC_DBG=8 ) > $OUT/ctc_kernel_trace.txt 2>&1
+$T 300 python3 tools/attn_bwd_stats.py > $OUT/attn_bwd_stats.txt 2>&1
+for v in 0 2 4 6; do echo "== ASR_AMD_CTC_DBG=$v"; ASR_AMD_CTC_DBG=$v $T 120 python3 tools/ab_ctc.py; done > $OUT/ctc_ab.txt 2>&1
+for hs in 0 2 4 6 8 12 16 24; do echo "== ASR_AMD_CTC_HEADSTART=$hs"; ASR_AMD_CTC_HEADSTART=$hs $T 120 python3 tools/ab_ctc.py; done >> $OUT/ctc_ab.txt 2>&1
+( bash tools/kt_ctc.sh default ASR_AMD_CTC_DBG=2 ASR_AMD_CTC_HEADSTART=6 ASR_AMD_CTC_HEADSTART=12 ) > $OUT/ctc_kernel_trace.txt 2>&1
 cd /tmp
 for v in 0 2 8; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $R/$OUT/pmc_$c_$v
+    rm -rf $R/$OUT/pmc_${c}_$v
     ( export ASR_AMD_CTC_DBG=$v; $T 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$OUT/pmc_${c}_$v -- python3 $R/tools/ab_ctc.py > /dev/null 2>&1 )
   done
 done
