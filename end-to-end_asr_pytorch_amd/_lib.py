@@ -78,6 +78,7 @@ SIGNATURES = {
     "asr_timer_elapsed_ms": [_vp, _vp, _vp],
     "asr_gemm_tn_ws_bytes": [_i, _i, _i, _i],
     "asr_gemm_tn_ws_group": [_vp, _i, _vp, _i],
+    "asr_gemm_tn_ws_group_wgs": [_vp, _i, _vp, _i, _i],
     "asr_gemm_tn_ws": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _i],
     "asr_colsum": [_vp, _vp, _i, _i64, _i, _i, _vp, _i],
     "asr_embed_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _dr],

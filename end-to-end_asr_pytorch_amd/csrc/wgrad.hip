@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_v2_kernel(TnArgs a, int nblock
 
 // Several weight gradients in one launch (the decoder's: 1632 rows each, a handful of tiles, 13-17 us apiece as single launches of
 // which 2 us are work): problem i owns the workgroups first[i] .. first[i+1] - 1.
-constexpr int TN_GROUP_MAX = 8;
+constexpr int TN_GROUP_MAX = 16;
 struct TnGroup {
     int n;
     int first[TN_GROUP_MAX + 1];       // main launch: first workgroup of each problem (multiples of 8)
@@ -429,7 +429,16 @@ extern "C" int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const vo
 // Up to 8 weight gradients in one pair of launches.  Every problem must be one asr_gemm_tn_ws itself takes (the same conditions; a
 // group with a problem that is not is refused with ASR_ERR_UNSUPPORTED - the caller issues them one by one then); each brings its own
 // workspace of asr_gemm_tn_ws_bytes(M, N, K, 0).  The chip's ~256 workgroup slots are shared out by output tiles.
+extern "C" int asr_gemm_tn_ws_group_wgs(void* stream, int n, const asr_tn_problem_t* pr, int deterministic, int group_workgroups);
 extern "C" int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t* pr, int deterministic) {
+    return asr_gemm_tn_ws_group_wgs(stream, n, pr, deterministic, 0);
+}
+
+// group_workgroups: the launch's workgroup budget, shared out by output tiles (0: ASR_AMD_TN_GROUP_WGS, default 128 = half the CUs for
+// a launch beside the main chain).  A problem never gets fewer workgroups than it has tiles: with budget <= total tiles every
+// problem runs UNSPLIT - one workgroup walks all M rows of its tile and writes dW itself, no slab, no reduce launch (the batched form
+// of a whole encoder layer's, or two layers', weight gradients: modules._wg).
+extern "C" int asr_gemm_tn_ws_group_wgs(void* stream, int n, const asr_tn_problem_t* pr, int deterministic, int group_workgroups) {
     ASR_REQUIRE(pr && n >= 1 && n <= TN_GROUP_MAX, ASR_ERR_ARG, "gemm_tn_ws_group: 1..%d problems", TN_GROUP_MAX);
     TnGroup g;
     g.n = n;
@@ -453,7 +462,8 @@ extern "C" int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t*
         const int my_tiles = ((q.N + 127) / 128) * (q.K / 128);
         // the grouped launch runs on the trainer's side stream beside the main chain: half the CUs (ASR_AMD_TN_GROUP_WGS; a slab
         // workgroup takes a whole CU, see modules._WGRAD_SIDE_WGS)
-        static const int group_wgs = getenv("ASR_AMD_TN_GROUP_WGS") ? atoi(getenv("ASR_AMD_TN_GROUP_WGS")) : 128;
+        static const int env_group_wgs = getenv("ASR_AMD_TN_GROUP_WGS") ? atoi(getenv("ASR_AMD_TN_GROUP_WGS")) : 128;
+        const int group_wgs = group_workgroups > 0 ? group_workgroups : env_group_wgs;
         int share = (int)((int64_t)group_wgs * my_tiles / total_tiles);
         if (share < my_tiles) share = my_tiles;
         tn_v2_plan(q.M, q.N, q.K, share, &tiles, &a.splits, &a.m_per_split);

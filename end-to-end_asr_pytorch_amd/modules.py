@@ -150,7 +150,12 @@ def flush_wgrads():
             a, b, out, acc, cs = pend[0]
             ops.gemm_tn(a, b, out=out, accumulate=acc, colsum=cs, max_wgs=_WGRAD_SIDE_WGS)
         else:
-            ops.gemm_tn_group(pend)
+            # A batch that holds encoder-sized problems (>= ~an encoder layer's 80 output tiles) gets ONE workgroup per tile: every
+            # problem unsplit over M, dW written by the workgroup that summed it - no partial-tile slabs, no reduce launch; the
+            # decoder-sized groups keep the library's default budget (M-splits: their tiles alone would leave the chip empty).
+            tiles = sum(ops.tn_tiles(p[0], p[1]) for p in pend)
+            big = ops.TN_BATCH and tiles >= 64 and max(p[0].shape[0] for p in pend) > ops.TN_GROUP_MAX_ROWS
+            ops.gemm_tn_group(pend, group_wgs=(ops.TN_BATCH_WGS or tiles) if big else 0)
 
 
 def _wg(a, b, **kw):
@@ -160,12 +165,20 @@ def _wg(a, b, **kw):
     if _WGRAD is None:
         return ops.gemm_tn(a, b, **kw)
     out = kw.get("out")
-    if ops.gemm_tn_group_ok(a, b, out) and set(kw) <= {"out", "accumulate", "colsum"}:
+    if (ops.gemm_tn_group_ok(a, b, out) or ops.gemm_tn_batch_ok(a, b, out)) and set(kw) <= {"out", "accumulate", "colsum"}:
         _WGRAD["keep"].append((a, b))
-        if any(p[2].data_ptr() == out.data_ptr() for p in _WGRAD.get("pending", ())):
+        pend = _WGRAD.setdefault("pending", [])
+        if any(p[2].data_ptr() == out.data_ptr() for p in pend):
             flush_wgrads()        # the same destination twice (tied weights): two problems of one launch would race on it and its workspace
-        _WGRAD.setdefault("pending", []).append((a, b, out, bool(kw.get("accumulate", False)), kw.get("colsum")))
-        if len(_WGRAD["pending"]) >= 8:
+            pend = _WGRAD.setdefault("pending", [])
+        small = a.shape[0] <= ops.TN_GROUP_MAX_ROWS
+        if pend and (pend[0][0].shape[0] <= ops.TN_GROUP_MAX_ROWS) != small:
+            flush_wgrads()        # decoder-sized and encoder-sized problems go in launches of their own (different workgroup budgets)
+            pend = _WGRAD.setdefault("pending", [])
+        pend.append((a, b, out, bool(kw.get("accumulate", False)), kw.get("colsum")))
+        # decoder-sized problems: eight per launch, as before; encoder-sized: until ~two layers' output tiles are pending (or 16 problems)
+        if (small and len(pend) >= 8) or len(pend) >= ops.TN_GROUP_MAX or \
+                (not small and ops.TN_BATCH and sum(ops.tn_tiles(p[0], p[1]) for p in pend) >= ops.TN_BATCH_TILES):
             flush_wgrads()
         return out
     main, side = torch.cuda.current_stream(), _WGRAD["stream"]

@@ -986,9 +986,29 @@ def gemm_tn_group_ok(a2d, b2d, out):
             (a2d.shape[1] % 128 == 0 or a2d.stride(0) >= (a2d.shape[1] + 127) // 128 * 128))
 
 
-def gemm_tn_group(problems):
-    """problems: up to 8 tuples (a2d, b2d, out, accumulate, colsum), each gemm_tn_group_ok - dW_i (+)= A_i^T . B_i in ONE pair of
-    launches (asr_hip.h: asr_gemm_tn_ws_group)."""
+TN_BATCH = os.environ.get("ASR_AMD_TN_BATCH", "1") != "0"       # A/B: 0 = the encoder's feed-forward weight gradients one launch pair each
+TN_BATCH_TILES = int(os.environ.get("ASR_AMD_TN_BATCH_TILES", "160"))   # pending output tiles at which a batch is issued (an encoder layer has 80)
+TN_BATCH_WGS = int(os.environ.get("ASR_AMD_TN_BATCH_WGS", "0"))        # workgroup budget of a batch (0: one per output tile = every problem unsplit over M)
+TN_GROUP_MAX = 16
+
+
+def tn_tiles(a2d, b2d):
+    return ((a2d.shape[1] + 127) // 128) * (b2d.shape[1] // 128)
+
+
+def gemm_tn_batch_ok(a2d, b2d, out):
+    """A weight gradient the batched launch takes: what gemm_tn_group_ok takes at any row count and tile count (the encoder's feed-forward
+    weights too)."""
+    return (TN_BATCH and TN_GROUP and TN_SLAB and not EXACT_F32 and out is not None and a2d.dtype == torch.bfloat16 and b2d.dtype == torch.bfloat16 and
+            a2d.shape[0] >= 64 and b2d.shape[1] % 128 == 0 and a2d.stride(1) == 1 and b2d.stride(1) == 1 and
+            a2d.stride(0) % 8 == 0 and b2d.stride(0) % 8 == 0 and a2d.data_ptr() % 16 == 0 and b2d.data_ptr() % 16 == 0 and
+            (a2d.shape[1] % 128 == 0 or a2d.stride(0) >= (a2d.shape[1] + 127) // 128 * 128))
+
+
+def gemm_tn_group(problems, group_wgs=0):
+    """problems: up to 16 tuples (a2d, b2d, out, accumulate, colsum), each gemm_tn_group_ok / gemm_tn_batch_ok - dW_i (+)= A_i^T . B_i in
+    ONE pair of launches (asr_hip.h: asr_gemm_tn_ws_group_wgs).  group_wgs: the launch's workgroup budget (0: the library's default);
+    <= the problems' total output tiles means every problem runs unsplit over M and there is no reduce launch."""
     arr = (_TnProblem * len(problems))()
     keep = []
     for i, (a2d, b2d, out, accumulate, colsum) in enumerate(problems):
@@ -999,8 +1019,8 @@ def gemm_tn_group(problems):
         arr[i] = _TnProblem(_p(a2d), a2d.stride(0), _p(b2d), b2d.stride(0), _p(out), out.stride(0), M, N, K, 1 if accumulate else 0,
                             _p(colsum), _p(ws), ws.numel())
     with _timed("gemm_tn_group[%d]" % len(problems), sum(2.0 * a.shape[0] * a.shape[1] * b.shape[1] for a, b, _, _, _ in problems)):
-        check(lib().asr_gemm_tn_ws_group(_stream(), len(problems), ctypes.cast(arr, ctypes.c_void_p), 1 if DETERMINISTIC else 0),
-              "asr_gemm_tn_ws_group")
+        check(lib().asr_gemm_tn_ws_group_wgs(_stream(), len(problems), ctypes.cast(arr, ctypes.c_void_p), 1 if DETERMINISTIC else 0,
+                                             int(group_wgs)), "asr_gemm_tn_ws_group_wgs")
 
 
 def colsum(a2d, out=None, accumulate=False):

@@ -333,9 +333,12 @@ int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda, const voi
 int64_t asr_gemm_tn_ws_bytes(int M, int N, int K, int max_workgroups);
 int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const void* Bm, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
                    int accumulate, float* colsum, int max_workgroups, void* workspace, int64_t workspace_bytes, int deterministic);
-/* Up to 8 of those weight gradients in ONE pair of launches (the decoder's weights: 1632 rows each, a single launch is 13-17 us of
- * which ~2 are work).  Every problem must satisfy asr_gemm_tn_ws's own conditions for the slab kernel (else ASR_ERR_UNSUPPORTED and
- * nothing is launched: issue them one by one) and brings a workspace of asr_gemm_tn_ws_bytes(M, N, K, 0) bytes. */
+/* Up to 16 of those weight gradients in ONE pair of launches (the decoder's weights: 1632 rows each, a single launch is 13-17 us of
+ * which ~2 are work; or all weight gradients of one or two encoder layers).  Every problem must satisfy asr_gemm_tn_ws's own
+ * conditions for the slab kernel (else ASR_ERR_UNSUPPORTED and nothing is launched: issue them one by one) and brings a workspace of
+ * asr_gemm_tn_ws_bytes(M, N, K, 0) bytes.  _wgs: with an explicit workgroup budget for the launch, shared out by output tiles (0 = the
+ * default, half the CUs); a problem never gets fewer workgroups than tiles, so a budget <= the tile total runs every problem
+ * unsplit over M - no partial tiles, no reduce launch. */
 typedef struct {
     const void* A; int64_t lda;      /* dY [M, lda] bf16 */
     const void* B; int64_t ldb;      /* X  [M, ldb] bf16 */
@@ -345,6 +348,7 @@ typedef struct {
     void* workspace; int64_t workspace_bytes;
 } asr_tn_problem_t;
 int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t* problems, int deterministic);
+int asr_gemm_tn_ws_group_wgs(void* stream, int n, const asr_tn_problem_t* problems, int deterministic, int group_workgroups);
 /* Bias gradient out[n] (+)= sum_m A[m,n]. */
 int asr_colsum(void* stream, const void* A, int a_dtype, int64_t lda, int M, int N, float* out, int zero_first);
 /* Embedding backward: demb[ids[r], :] += dropout_mask(dy[r, :])  (f32 atomics; caller zeroes demb).  M = B*U rows. */
