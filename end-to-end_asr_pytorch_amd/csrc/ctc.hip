@@ -716,15 +716,9 @@ __global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(co
         const bool stage = !(dbg & 2) && ctc_row_fits_regs(V) && (size_t)((V + 3) >> 2) * 16 + 32 <= sizeof(ring);
         int* pending = nullptr;
         int pending_count = 0;
-        // Head start for chunk 0 (dbg bits 16..23, units of ~1 us; ASR_AMD_CTC_HEADSTART): the chains cannot take their first step
-        // before chunk 0 of their direction is complete, and with every pass workgroup starting at once the first ROUND (all of them
-        // sharing the memory system) ends ~30 us in - for 100-115 us of chain behind it.  The workgroups whose first item is not of
-        // chunk 0 start a few microseconds late instead: the Bn * 2 * G chunk-0 items have the memory system to themselves.
-        {
-            const int hs = (dbg >> 16) & 0xff;
-            if (hs > 0 && (int)blockIdx.x - Bn >= Bn * 2 * G)
-                for (int i = 0; i < hs; ++i) __builtin_amdgcn_s_sleep(32);
-        }
+        // (Round 5, measured and dropped: a head start for chunk 0 - the workgroups whose first item is not of chunk 0 sleeping 2..24 us so
+        // that the chains' first chunk has the memory system to itself: 135 us without, 146 / 147 / 148 / 151 / 154 / 158 us with
+        // 2 / 4 / 6 / 12 / 16 / 24 us - the kernel simply ends that much later, the pass is what it waits for.)
         for (int gid = blockIdx.x - Bn; gid < total; gid += npass) {
             int bid = gid;
             const int chunk = bid / (Bn * 2 * G);
@@ -1140,8 +1134,7 @@ static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, con
     if (npass > groups) npass = groups;
     if (npass < 1) npass = 1;
     const int grid = B + npass;
-    static const int headstart = [] { const char* e = getenv("ASR_AMD_CTC_HEADSTART"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 255 ? 255 : v); }();
-    const int kdbg = (dbg & 0xff) | (rpb << 8) | (headstart << 16);
+    const int kdbg = (dbg & 0xff) | (rpb << 8);
     if (ringp <= 8)
         hipLaunchKernelGGL(ctc_fused_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
                            alpha, nll, tgt_len, W, nc, arrivals, arr_stride, extra, mean_loss, kdbg);

@@ -184,8 +184,10 @@ def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
         rel, worst = attn_bwd_errors(got, ref)
         assert rel <= ATTN_BWD_REL_L2, (name, rel, worst)
         assert worst <= ATTN_BWD_ELEM, (name, rel, worst)
-        # rows whose reference gradient is exactly zero (keys past k_len) are exactly zero
-        assert np.all(got[(np.abs(ref).max(axis=1) == 0)] == 0), name
+        # keys past k_len: exactly zero gradient (dq has analytically-zero rows too - a causal query that sees one key - which the
+        # bf16 kernel only reproduces to rounding)
+        if name != "dq":
+            assert np.all(got[(np.abs(ref).max(axis=1) == 0)] == 0), name
 
 
 ATTN_BWD_REL_L2 = 1.5e-2     # per tensor: ||got - ref|| / ||ref||
