@@ -987,8 +987,8 @@ def gemm_tn_group_ok(a2d, b2d, out):
 
 
 TN_BATCH = os.environ.get("ASR_AMD_TN_BATCH", "1") != "0"       # A/B: 0 = the encoder's feed-forward weight gradients one launch pair each
-TN_BATCH_TILES = int(os.environ.get("ASR_AMD_TN_BATCH_TILES", "160"))   # pending output tiles at which a batch is issued (an encoder layer has 80)
-TN_BATCH_WGS = int(os.environ.get("ASR_AMD_TN_BATCH_WGS", "0"))        # workgroup budget of a batch (0: one per output tile = every problem unsplit over M)
+TN_BATCH_TILES = int(os.environ.get("ASR_AMD_TN_BATCH_TILES", "80"))   # pending output tiles at which a batch is issued (an encoder layer has 80)
+TN_BATCH_WGS = int(os.environ.get("ASR_AMD_TN_BATCH_WGS", "0"))        # workgroup budget of a batch (0: 256, or one per output tile if that is more)
 TN_GROUP_MAX = 16
 
 

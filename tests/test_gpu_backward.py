@@ -190,8 +190,8 @@ def test_attention_bwd(B, h, Lq, Lk, causal, ragged):
             assert np.all(got[(np.abs(ref).max(axis=1) == 0)] == 0), name
 
 
-ATTN_BWD_REL_L2 = 1.5e-2     # per tensor: ||got - ref|| / ||ref||
-ATTN_BWD_ELEM = 3e-2         # per element: |got - ref| / max |ref| over the tensor
+ATTN_BWD_REL_L2 = 8e-3       # per tensor: ||got - ref|| / ||ref||   (measured 2.2-3.9e-3 over the nine shapes: tools/attn_bwd_stats.py)
+ATTN_BWD_ELEM = 1.5e-2       # per element: |got - ref| / max |ref| over the tensor   (measured 2.1-6.8e-3)
 
 
 def attn_bwd_errors(got, ref):
