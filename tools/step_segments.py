@@ -16,6 +16,7 @@ model = bench.build_model(asr_amd, dev, 0.1, train=True)
 asr_amd.manual_seed(1234)
 x, lens, tg = bench.make_batch(dev, seed=0)
 tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+tr.side_inline = os.environ.get("SIDE_INLINE") == "1"      # the CTC branch queued on the launch stream itself (no overlap with the decoder)
 step = tr.step
 for _ in range(6):
     step(x, lens, tg, max_target_len=bench.CFG["U"])
