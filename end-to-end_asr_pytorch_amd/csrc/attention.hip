@@ -319,273 +319,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v2_kernel(const bf16
     }
 }
 
-// ---- v3: the encoder's self attention (non-causal, one key stream), software-pipelined -----------------------------------------
-// Same tiles, swizzle and ownership as v2; what changes is WHEN things are issued:
-//   * the score MFMAs of tile t+1 are issued before the softmax VALU of tile t (which does not depend on them), the PV MFMAs of
-//     tile t after it: the matrix pipe works under the exp / max / convert stream of the SAME wave instead of waiting for the other
-//     resident wave to happen to be in its VALU phase;
-//   * K and V tiles live in two rings of three 8-KiB slots and are requested two tiles ahead (K(t+3), V(t+2) in iteration t);
-//   * the DMA and the two dropout words are issued through inline asm with ONE hand-counted s_waitcnt vmcnt(4) per iteration, right
-//     before the barrier: written with the builtins the compiler drains vmcnt to 0 in front of the first transposing LDS read of
-//     every iteration (it cannot tell which LDS bytes the DMA in flight targets) - the whole L2 latency, once per tile;
-//   * the accumulator's initial value -mref is a persistent 16-register C operand instead of 32 v_mov per tile;
-//   * rows past k_len come back as zeros through the buffer descriptor's range check (no clamp arithmetic).
-template <int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16_v3_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                                      const bf16_t* __restrict__ V, bf16_t* __restrict__ ctx,
-                                                                      float* __restrict__ lse, int h, int Lq, int Lk,
-                                                                      const int32_t* __restrict__ k_len, int q_tiles,
-                                                                      asr_dropout_t drop, const uint32_t* __restrict__ drop_bits) {
-    constexpr int QB = NW * 32, PIECES = 8 / NW;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * 8192];   // K ring [3][8 KiB] | V ring [3][8 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, hh = lane >> 5;
-    int qt, bh;
-    {
-        const int BH = gridDim.x / q_tiles;
-        if ((BH & 7) == 0) {
-            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-            bh = (slot / q_tiles) * 8 + xcd;
-            qt = slot % q_tiles;
-        } else {
-            qt = blockIdx.x % q_tiles;
-            bh = blockIdx.x / q_tiles;
-        }
-    }
-    const int b = bh / h, hd = bh - b * h;
-    const int q0 = qt * QB;
-    const int kl = k_len ? min(k_len[b], Lk) : Lk;
-    const int ntiles = (kl + 63) >> 6;
-    const int qrow = q0 + wave * 32 + r;
-    const int lqp = drop_pad128(Lq), kwords = drop_pad128(Lk) / 32;
-    const u32x4 krs = rsrc_words(K + (int64_t)bh * Lk * 64, (unsigned)kl * 128u);
-    const u32x4 vrs = rsrc_words(V + (int64_t)bh * Lk * 64, (unsigned)kl * 128u);
-    const u32x4 mrs = rsrc_words(DROP ? drop_bits + (int64_t)bh * kwords * lqp : nullptr, DROP ? (unsigned)(kwords * lqp) * 4u : 0u);
-    const unsigned smem0 = lds_addr_of(smem);
-
-    // the query fragments, requested like everything else in this kernel through asm (so that the one counted wait of the prologue
-    // covers them; rows past Lq read as zeros through the descriptor)
-    u32x4 qf[4];
-    {
-        const u32x4 qrs = rsrc_words(Q + (int64_t)bh * Lq * 64, (unsigned)Lq * 128u);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = load128_asm(qrs, (unsigned)qrow * 128u + 32u * s + 16u * hh, 0u);
-    }
-
-    // this lane's source offset inside a tile for each piece it stages (piece p = tile rows 8p..8p+7, destination lane-linear)
-    unsigned voff[PIECES];
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int row = 8 * (wave * PIECES + i) + (lane >> 3);
-        voff[i] = (unsigned)(row * 128 + (((lane & 7) ^ swz2(row)) << 4));
-    }
-    auto stage = [&](const u32x4& rs, int t, unsigned slot_addr) {   // tile t -> the 8-KiB slot at LDS address slot_addr
-        const unsigned soff = t < ntiles ? (unsigned)t * 8192u : 0x7f000000u;   // past the end: out of range, no fetch (still counted)
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) dma16_asm(rs, voff[i], soff, slot_addr + (wave * PIECES + i) * 1024);
-    };
-    const unsigned moff = (unsigned)qrow * 4u;
-    auto mask_words = [&](int t, uint32_t (&w)[2]) {
-        w[0] = load32_asm(mrs, moff, (unsigned)(2 * t) * (unsigned)lqp * 4u);
-        w[1] = load32_asm(mrs, moff, (unsigned)(2 * t + 1) * (unsigned)lqp * 4u);
-    };
-    // lane offsets of the fragment reads inside a tile; per tile the ring slot's base is added once per offset and the sum is hidden
-    // from the compiler (which otherwise re-associates it into one add per READ: 70 of the 226 VALU instructions of a tile)
-    unsigned kofs[4], vofs[4];      // K: one per k-step (row = r; + 4096 for the second 32 keys); V^T: [dt][lo/hi] (+ 2048 per key group)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kofs[s] = (unsigned)(r * 128 + (((2 * s + hh) ^ swz2(r)) << 4));
-    {
-        const int i16 = lane & 15, g16 = lane >> 4;
-        const int kb = 4 * hh + (i16 >> 2);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int col = dt * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
-            const int c = col >> 3, sub = (col & 7) * 2;
-            vofs[2 * dt] = (unsigned)(kb * 128 + ((c ^ swz2(kb)) << 4) + sub);
-            vofs[2 * dt + 1] = (unsigned)((kb + 8) * 128 + ((c ^ swz2(kb + 8)) << 4) + sub);
-        }
-    }
-    typedef __attribute__((address_space(3))) unsigned char lds_u8;
-    auto scores = [&](f32x16 (&st)[2], const f32x16& negm, int kslot) {
-        const lds_u8* kp[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            unsigned a = smem0 + (unsigned)kslot * 8192u + kofs[s];
-            asm volatile("" : "+v"(a));
-            kp[s] = (const lds_u8*)(size_t)a;
-        }
-        u32x4 kf[2][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-                kf[hf][s] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(kp[s] + hf * 4096);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-                st[hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[hf][s]), __builtin_bit_cast(bf16x8, qf[s]),
-                                                                 s == 0 ? negm : st[hf], 0, 0, 0);
-    };
-
-    f32x16 o0, o1, negm;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; negm[i] = 0.f; }
-    constexpr float MAXLAG = 8.f;
-    float mref = 0.f, l = 0.f;
-    bool first = true;
-    uint32_t wk[2] = {0u, 0u}, wkn[2] = {0u, 0u};
-    f32x16 sa[2], sb[2];
-
-    // prologue: mask words of tile 0, K0 V0 K1 | V1 K2 ; the first scores.  Iteration 0 reads K(1) and V(0) with no wait of its own in
-    // front: both are among the requests the prologue waits for (iteration t >= 1 is covered by the wait that ends iteration t - 1).
-    if (DROP) mask_words(0, wkn);
-    stage(krs, 0, smem0);
-    stage(vrs, 0, smem0 + 3 * 8192);
-    stage(krs, 1, smem0 + 8192);
-    stage(vrs, 1, smem0 + 4 * 8192);
-    stage(krs, 2, smem0 + 2 * 8192);
-    if (PIECES == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(wkn[0]), "+v"(wkn[1]), "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : : "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" : "+v"(wkn[0]), "+v"(wkn[1]), "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) : : "memory");
-    __builtin_amdgcn_s_barrier();
-    wk[0] = wkn[0] >> (4 * hh);
-    wk[1] = wkn[1] >> (4 * hh);
-    if (ntiles > 0) scores(sa, negm, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();       // iteration 0 requests K(3) into the slot these reads came from
-
-    auto body = [&](f32x16 (&st)[2], f32x16 (&sn)[2], int t) {
-        const int s0 = t % 3, s1 = (t + 1) % 3, s2 = (t + 2) % 3;      // ring slots of tiles t (= t+3), t+1, t+2
-        if (DROP) mask_words(t + 1, wkn);
-        stage(krs, t + 3, smem0 + s0 * 8192);
-        stage(vrs, t + 2, smem0 + (3 + s2) * 8192);
-        scores(sn, negm, s1);       // (past the last tile: zeros / a dead slot, never looked at)
-        const lds_u8* vp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned a = smem0 + (unsigned)(3 + s0) * 8192u + vofs[i];
-            asm volatile("" : "+v"(a));
-            vp[i] = (const lds_u8*)(size_t)a;
-        }
-        u32x4 vfr[4][2];            // V^T fragments [group (hf, s2)][dt] (two transposing reads each, straight into the halves of the
-                                    // operand's register quad): in flight under the softmax VALU
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int hi = 0; hi < 2; ++hi) {
-                    const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vp[2 * dt + hi] + g * 2048)));
-                    vfr[g][dt][2 * hi] = v[0];
-                    vfr[g][dt][2 * hi + 1] = v[1];
-                }
-        __builtin_amdgcn_sched_barrier(0);
-        const int key0 = t * 64;
-        float mloc = -INFINITY;
-        if (key0 + 64 <= kl) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, st[hf][i]);
-        } else {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = key0 + hf * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    st[hf][i] = key >= kl ? -INFINITY : st[hf][i];
-                    mloc = fmaxf(mloc, st[hf][i]);
-                }
-        }
-        // mloc: the maximum over THIS lane's 32 keys; the other 32 of the query sit on lane ^ 32.  The exchange (an LDS round trip)
-        // happens only inside the rare branch: any lane whose half-maximum calls for a move takes the whole wave there
-        if (__builtin_amdgcn_ballot_w64((first && mloc > -INFINITY) || mloc > MAXLAG)) {
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const bool move = (first && mloc > -INFINITY) || mloc > MAXLAG;
-            const float delta = move ? mloc : 0.f;
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { st[hf][i] -= delta; sn[hf][i] -= delta; }
-            l *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; negm[i] -= delta; }
-            mref += delta;
-            first = first && !(mloc > -INFINITY);
-        }
-        f32x2 rs2 = {0.f, 0.f};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(st[hf][i]), p1 = __builtin_amdgcn_exp2f(st[hf][i + 1]);
-                st[hf][i] = p0;
-                st[hf][i + 1] = p1;
-                rs2 += f32x2{p0, p1};
-            }
-        l += rs2[0] + rs2[1];       // this lane's half of the row sum; the halves meet once, after the loop
-        if (DROP) {
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) st[hf][i] = drop_and(st[hf][i], wk[hf], 8 * (i >> 2) + (i & 3));
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int s2i = 0; s2i < 2; ++s2i) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[hf][8 * s2i + j];
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int g = 2 * hf + s2i;
-                    const u32x4 vf = vfr[g][dt];
-                    if (dt == 0)
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o0, 0, 0, 0);
-                    else
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o1, 0, 0, 0);
-                }
-            }
-        // the requests of iteration t - 1 (K(t+2), V(t+1)) and the next mask words are older than this iteration's 2 * PIECES requests
-        if (PIECES == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" : "+v"(wkn[0]), "+v"(wkn[1]) : : "memory");
-        __builtin_amdgcn_s_barrier();
-        wk[0] = wkn[0] >> (4 * hh);
-        wk[1] = wkn[1] >> (4 * hh);
-    };
-    // two tiles per trip with the score arrays swapping roles; the odd last tile outside the loop - with a conditional second body in
-    // the loop the compiler merged the two role assignments through 66 register copies PER TRIP (10 us of a 54 us launch, found by
-    // leaving pieces of the loop out: tools/ablate_attn.sh)
-    int t = 0;
-    for (; t + 1 < ntiles; t += 2) {
-        body(sa, sb, t);
-        body(sb, sa, t + 1);
-    }
-    if (t < ntiles) body(sa, sb, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // out-of-range requests of the last iterations: nothing may land after the workgroup's LDS is released
-
-    l += __shfl_xor(l, 32, 64);
-    if (qrow < Lq) {
-        const float inv = (DROP ? drop_scale(drop) : 1.f) / l;
-        bf16_t* op = ctx + ((int64_t)b * Lq + qrow) * (h * 64) + hd * 64;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 8 * g + 4 * hh;
-            bf16x4 a = {(bf16_t)(o0[4 * g] * inv), (bf16_t)(o0[4 * g + 1] * inv), (bf16_t)(o0[4 * g + 2] * inv),
-                        (bf16_t)(o0[4 * g + 3] * inv)};
-            bf16x4 c = {(bf16_t)(o1[4 * g] * inv), (bf16_t)(o1[4 * g + 1] * inv), (bf16_t)(o1[4 * g + 2] * inv),
-                        (bf16_t)(o1[4 * g + 3] * inv)};
-            *reinterpret_cast<bf16x4*>(op + d) = a;
-            *reinterpret_cast<bf16x4*>(op + 32 + d) = c;
-        }
-        if (lse && hh == 0) lse[(int64_t)bh * Lq + qrow] = mref + __builtin_amdgcn_logf(l);   // base-2
-    }
-}
-
 // ---- dropout keep bits of one attention call, both images (asr_common.h) ----
 // A wave owns 32 queries x 64 keys with the forward kernel's element ownership (lane = query r, half hh; keys hf*32 + 8g + 4hh + x),
 // hashes its 16 words, and assembles: its nibbles -> with lane ^ 32 the two full 32-key words of query r (Mk); a 5-step 32 x 32 bit
@@ -640,21 +373,11 @@ template <int NW, int KS = 1> int launch_bf16(hipStream_t s, const void* q, cons
 #define LAUNCH_V2(C, D)                                                                                                        \
     hipLaunchKernelGGL((attn_fwd_bf16_v2_kernel<NW, C, D, KS>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k,         \
                        (const bf16_t*)v, (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits)
-        static const int v4 = getenv("ASR_AMD_ATTN_V4") ? atoi(getenv("ASR_AMD_ATTN_V4")) : 1;
-        if (v4 && !causal && KS == 1 && NW == 4 && Lq >= 128 &&
+        // the encoder's shape (non-causal, >= 128 queries, one key stream): the generated two-blocks-per-wave kernel (attention_fwd4.hip);
+        // it declines (non-zero) what it was not built for and the v2 kernel below takes it
+        if (!causal && KS == 1 && NW == 4 && Lq >= 128 &&
             asr_attention_fwd_v4(s, q, k, v, ctx, lse, B, h, Lq, Lk, k_len, drop, drop_bits) == 0)
             return 0;
-        static const int v3 = getenv("ASR_AMD_ATTN_V3") ? atoi(getenv("ASR_AMD_ATTN_V3")) : 1;
-        if (v3 && !causal && KS == 1 && NW == 4) {
-            if (drop.thr16)
-                hipLaunchKernelGGL((attn_fwd_bf16_v3_kernel<4, true>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                                   (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits);
-            else
-                hipLaunchKernelGGL((attn_fwd_bf16_v3_kernel<4, false>), grid, block, 0, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                                   (bf16_t*)ctx, lse, h, Lq, Lk, k_len, q_tiles, drop, drop_bits);
-            ASR_LAUNCH_CHECK("attention_fwd_bf16_v3");
-            return 0;
-        }
         if (causal) { if (drop.thr16) LAUNCH_V2(true, true); else LAUNCH_V2(true, false); }
         else        { if (drop.thr16) LAUNCH_V2(false, true); else LAUNCH_V2(false, false); }
 #undef LAUNCH_V2

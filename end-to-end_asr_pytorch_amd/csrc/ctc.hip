@@ -1246,7 +1246,11 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
         launch_recursion<2>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1, alpha2);
     else
         launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
-    int rb = (2048 + B - 1) / B;  // ~2048 workgroups in flight
+    // workgroups in flight: 8 per CU fill every wave slot of the chip (4 waves each, 8 waves per SIMD) - right for the op by itself, but
+    // in the training step this launch runs on the side stream beside the decoder's small kernels, which then cannot place a single
+    // wave until it ends; ASR_AMD_CTC_GRAD_WGS_PER_CU leaves slots free (experiment knob)
+    static const int per_cu = [] { const char* e = getenv("ASR_AMD_CTC_GRAD_WGS_PER_CU"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+    int rb = (256 * per_cu + B - 1) / B;
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
     if (grad_dtype == ASR_BF16)
