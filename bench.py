@@ -452,7 +452,6 @@ def main():
     use_graph = args.graph == 1 and trainer is not None
     auto_graph = args.graph < 0 and trainer is not None
 
-    lens_host = [int(v) for v in lens.tolist()]
 
     n_steps = [0]
 
@@ -467,11 +466,7 @@ def main():
         if args.mode == "decode" and CFG.get("cif"):
             # the reference's CIF inference (cif_model.py:108-131) for the whole padded batch: one batched beam search; `target_num` = U
             # tokens per utterance (the random-init assigner would otherwise fire on about every second frame)
-            if os.environ.get("ASR_AMD_CIF_PER_UTT") == "1":      # the reference's call shape: one utterance at a time
-                dargs = argparse.Namespace(beam_size=args.beam, nbest=1)
-                res = [model.recognize(x[u, :lens_host[u]], lens[u:u + 1], None, dargs, target_num=CFG["U"]) for u in range(x.shape[0])]
-            else:
-                res = model.batch_recognize(x, lens, args.beam, 1, target_num=CFG["U"])
+            res = model.batch_recognize(x, lens, args.beam, 1, target_num=CFG["U"])
             t_ = torch.tensor(sum(ls[0] - 1 for ys, ls in res) / float(x.shape[0]))
             return t_, t_
         if args.mode == "decode":

@@ -431,7 +431,7 @@ extern "C" int asr_attention_fwd(void* stream, const void* q, const void* k, con
         return 0;
     }
     ASR_REQUIRE(dtype == ASR_BF16, ASR_ERR_ARG, "attention: bad dtype %d", dtype);
-    static const int xks = getenv("ASR_AMD_XATTN_KS") ? atoi(getenv("ASR_AMD_XATTN_KS")) : 4;
+    constexpr int xks = 4;      // key streams per workgroup of the few-query kernels (1 / 2: step +0.2 / +0.1 ms)
     if (Lq <= 32) {
         // a handful of queries against a long key sequence (the decode step's cross attention: Lq = 1 or the beam, Lk = the encoder
         // length): one query group, four key streams - a quarter of the dependent walk

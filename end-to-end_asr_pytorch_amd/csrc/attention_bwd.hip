@@ -473,7 +473,7 @@ extern "C" int asr_attention_bwd_dq(void* stream, const void* q, const void* k, 
         if (causal) { if (drop.thr16) LAUNCH_DQ2(NW, true, true, KS); else LAUNCH_DQ2(NW, true, false, KS); }  \
         else { if (drop.thr16) LAUNCH_DQ2(NW, false, true, KS); else LAUNCH_DQ2(NW, false, false, KS); }       \
     } while (0)
-    static const int xks = getenv("ASR_AMD_XATTN_KS") ? atoi(getenv("ASR_AMD_XATTN_KS")) : 4;
+    constexpr int xks = 4;
     if (Lq <= 32) LAUNCH_DQ(1, 1);
     else if (xks >= 4 && Lq <= 64 && Lk >= 512 && !causal) LAUNCH_DQ(8, 4);      // the decoder's cross attention: several key streams per workgroup
     else if (xks >= 2 && Lq <= 64 && Lk >= 256 && !causal) LAUNCH_DQ(4, 2);

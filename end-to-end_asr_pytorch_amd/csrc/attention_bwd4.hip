@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_v4_kernel(const bf16_t* __
 int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                             float* nscal, void* dq, int64_t ldq, int B, int h, int Lq, int Lk, const int32_t* k_len, float scale,
                             asr_dropout_t drop, const uint32_t* drop_bits) {
-    static const int on = getenv("ASR_AMD_ATTN_BWD_V4") ? atoi(getenv("ASR_AMD_ATTN_BWD_V4")) : 3;     // bit 0: dK / dV, bit 1: dQ
+    constexpr int on = 3;      // bit 0: dK / dV, bit 1: dQ on the generated streams
     if (!(on & 2) || Lq < 128) return -2;
     const int q_tiles = (Lq + 127) / 128;
     const float dsc = drop.thr16 ? 65536.f / (float)(65536u - drop.thr16) : 1.f;
@@ -181,7 +181,7 @@ int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const v
 int asr_attention_bwd_dkv_v4(hipStream_t s, const void* q, const void* k, const void* v, const void* d_o, const float* nscal, void* dk,
                              void* dv, int64_t ldkv, int B, int h, int Lq, int Lk, const int32_t* k_len, asr_dropout_t drop,
                              const uint32_t* drop_bits) {
-    static const int on = getenv("ASR_AMD_ATTN_BWD_V4") ? atoi(getenv("ASR_AMD_ATTN_BWD_V4")) : 3;     // bit 0: dK / dV, bit 1: dQ
+    constexpr int on = 3;      // bit 0: dK / dV, bit 1: dQ on the generated streams
     if (!(on & 1) || Lq < 128) return -2;
     const int k_tiles = (Lk + 127) / 128;
     const float dsc = drop.thr16 ? 65536.f / (float)(65536u - drop.thr16) : 1.f;

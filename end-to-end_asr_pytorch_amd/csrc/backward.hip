@@ -606,18 +606,16 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
             if (e != hipSuccess) { asr_set_error("gemm_tn memset2d: %s", hipGetErrorString(e)); return (int)e; }
         }
     }
-    static const bool no_tr = getenv("ASR_AMD_NO_TR") != nullptr;   // A/B switch
     // N need not be a multiple of 128 when A's rows can be READ up to the next one (lda covers it: a padded gradient buffer)
     const bool n_ok = N % 128 == 0 || lda >= (int64_t)(N + 127) / 128 * 128;
-    if (!no_tr && a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 8 == 0 && M >= 64 && n_ok && K % 128 == 0 && lda % 8 == 0 &&
+    if (a_dtype == ASR_BF16 && b_dtype == ASR_BF16 && M % 8 == 0 && M >= 64 && n_ok && K % 128 == 0 && lda % 8 == 0 &&
         ldb % 8 == 0 && asr_aligned(A, 16) && asr_aligned(Bm, 16)) {
         const int tiles_n = (N + 127) / 128, tiles_k = K / 128, tiles = tiles_n * tiles_k;
-        static const int env_wgs = getenv("ASR_AMD_TN_WGS") ? atoi(getenv("ASR_AMD_TN_WGS")) : 0;
         // 512 = 2 resident per CU when the kernel has the chip to itself; a caller that runs it BESIDE other kernels (the trainer's
         // weight-gradient stream) asks for 256: one per CU and half the M-splits (half the atomic epilogue) - 14.54 -> 14.18 ms per step
-        const int target_wgs = env_wgs > 0 ? env_wgs : (max_workgroups > 0 ? max_workgroups : 512);
+        const int target_wgs = max_workgroups > 0 ? max_workgroups : 512;
         int splits = (target_wgs + tiles - 1) / tiles;
-        static const int min_rows = getenv("ASR_AMD_TN_MINROWS") ? atoi(getenv("ASR_AMD_TN_MINROWS")) : 512;
+        constexpr int min_rows = 512;
         const int max_splits = (M + min_rows - 1) / min_rows;
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
@@ -679,7 +677,7 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 256;
+    constexpr int max_blocks = 256;      // persistent workgroups (192 .. 384 measured: +0.1 .. 0.8 ms per step either side)
     if (blocks > max_blocks) blocks = max_blocks;
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
@@ -701,7 +699,7 @@ extern "C" int asr_add_layernorm_bwd_y(void* stream, const float* dy, const floa
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd_y: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    static const int max_blocks = getenv("ASR_AMD_LNB_WGS") ? atoi(getenv("ASR_AMD_LNB_WGS")) : 256;
+    constexpr int max_blocks = 256;      // persistent workgroups (192 .. 384 measured: +0.1 .. 0.8 ms per step either side)
     if (blocks > max_blocks) blocks = max_blocks;
     const asr_dropout_t none{0, 0, 0, nullptr};
     if (D <= 256)

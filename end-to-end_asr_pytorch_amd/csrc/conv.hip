@@ -736,8 +736,7 @@ extern "C" int asr_conv_sub1_fwd(void* stream, const void* x, const float* w, co
     int blocks = (n_tiles + 3) / 4;
     if (blocks > 1024) blocks = 1024;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool no_lds = getenv("ASR_AMD_CONV_NO_LDS") != nullptr;      // A/B switch
-    if (dtype == ASR_BF16 && !no_lds && Fout <= 48 && Fin <= 50) {
+    if (dtype == ASR_BF16 && Fout <= 48 && Fin <= 50) {
         constexpr int TT = 4;
         const int chunks_per_b = (Tout + TT - 1) / TT, n_chunks = B * chunks_per_b;
         hipLaunchKernelGGL(conv_sub1_lds_kernel<TT>, dim3(n_chunks < 1280 ? n_chunks : 1280), dim3(256), 0, s, (const bf16_t*)x, w, b, (bf16_t*)y,
@@ -762,8 +761,7 @@ extern "C" int asr_conv_sub1_bwd_x(void* stream, const void* dy, const float* w,
     const int fblocks = (Fin + 15) / 16;
     const int64_t tiles = (int64_t)B * Tin * fblocks;
     ASR_REQUIRE(tiles < (int64_t)1 << 31, ASR_ERR_UNSUPPORTED, "conv_sub1_bwd_x: too many tiles");
-    static const bool no_lds = getenv("ASR_AMD_CONV_NO_LDS") != nullptr;
-    if (!no_lds && Fout <= 48 && Fin <= 50 && Tin <= 2 * Tout + 1) {
+    if (Fout <= 48 && Fin <= 50 && Tin <= 2 * Tout + 1) {
         constexpr int TT = 4;
         const int chunks_per_b = (Tin + 2 * TT - 1) / (2 * TT), n_chunks = B * chunks_per_b;
         hipLaunchKernelGGL(conv_sub1_bwd_x_lds_kernel<TT>, dim3(n_chunks < 1280 ? n_chunks : 1280), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -676,7 +676,7 @@ __device__ __forceinline__ bool ctc_lds_chain(const float* __restrict__ lp_u, ct
 }
 
 template <int P>
-__global__ __launch_bounds__(256, (P <= 8 ? 8 : 7)) void ctc_fused_fwd_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
+__global__ __launch_bounds__(256, 8) void ctc_fused_fwd_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
                                                                const int64_t* __restrict__ targets, int Bn, int L, int V, int Umax, int blank,
                                                                float* __restrict__ lse_out, float* __restrict__ lp_ext,
                                                                float* __restrict__ alpha, float* __restrict__ nll,
@@ -1102,10 +1102,11 @@ static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, con
     }
     // fused: ONE launch - pass workgroups publish table rows chunk by chunk (write-through stores + arrival counters in row L+1 of
     // the alpha workspace), recursion workgroups of the same grid consume them as they arrive
-    // knobs for A/B runs (defaults are the measured best): ASR_AMD_CTC_RPB rows per pass workgroup, ASR_AMD_CTC_RING ring pairs,
-    // ASR_AMD_CTC_DBG bit 2: pass only (no recursion: timing experiment, results invalid)
-    static const int rpb = [] { const char* e = getenv("ASR_AMD_CTC_RPB"); const int v = e ? atoi(e) : 4; return v == 8 ? 8 : (v == 2 ? 2 : (v == 1 ? 1 : 4)); }();
-    static const int ringp = [] { const char* e = getenv("ASR_AMD_CTC_RING"); return e ? atoi(e) : 8; }();
+    // ASR_AMD_CTC_DBG: timing / attribution builds of the launch (results invalid): bit 1 the labels gathered by a second global load
+    // (round 4's form: FETCH_SIZE 705 MB against 562), bit 2 pass only, bit 3 no gather, bit 4 chains never wait, bit 5 chains only,
+    // bit 7 workgroup end stamps (tools/ctc_timeline.py)
+    constexpr int rpb = 4;          // table rows per pass workgroup and item (1 / 2 / 8: 151 / 147 / 154 us against 144)
+    constexpr int ringp = 8;        // row pairs in the recursion's LDS ring (10: 23 KiB -> 6 workgroups per CU, 0.19 ms)
     static const int dbg = [] { const char* e = getenv("ASR_AMD_CTC_DBG"); return e ? atoi(e) : 0; }();
     int W, nc;
     ctc_chunking(L, n_chunks, W, nc);
@@ -1130,17 +1131,13 @@ static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, con
     // LDS / register budget; more than fit would only queue)
     const int n_cu = ctc_fused_max_batch() / 2;      // (of the current device)
     const int groups = nc * B * 2 * (W / rpb);
-    int npass = n_cu * (ringp <= 8 ? 8 : 6) - B;      // (the 10-pair ring's 23 KiB round up past a seventh of the CU's LDS)
+    int npass = n_cu * 8 - B;      // 8 per CU: the kernel's LDS (ring of 8 row pairs, 18.6 KB) and register budget (<= 64)
     if (npass > groups) npass = groups;
     if (npass < 1) npass = 1;
     const int grid = B + npass;
     const int kdbg = (dbg & 0xff) | (rpb << 8);
-    if (ringp <= 8)
-        hipLaunchKernelGGL(ctc_fused_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
-                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, extra, mean_loss, kdbg);
-    else
-        hipLaunchKernelGGL(ctc_fused_fwd_kernel<10>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
-                           alpha, nll, tgt_len, W, nc, arrivals, arr_stride, extra, mean_loss, kdbg);
+    hipLaunchKernelGGL(ctc_fused_fwd_kernel<ringp>, dim3(grid), dim3(256), 0, s, logits, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext,
+                       alpha, nll, tgt_len, W, nc, arrivals, arr_stride, extra, mean_loss, kdbg);
     ASR_LAUNCH_CHECK("ctc_loss_fwd");
     return 0;
 }
@@ -1246,11 +1243,11 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
         launch_recursion<2>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1, alpha2);
     else
         launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
-    // workgroups in flight: 8 per CU fill every wave slot of the chip (4 waves each, 8 waves per SIMD) - right for the op by itself, but
-    // in the training step this launch runs on the side stream beside the decoder's small kernels, which then cannot place a single
-    // wave until it ends; ASR_AMD_CTC_GRAD_WGS_PER_CU leaves slots free (experiment knob)
-    static const int per_cu = [] { const char* e = getenv("ASR_AMD_CTC_GRAD_WGS_PER_CU"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
-    int rb = (256 * per_cu + B - 1) / B;
+    // ~2048 workgroups in flight (8 per CU: every wave slot).  In the training step this launch runs on the side stream beside the
+    // decoder's small kernels; leaving slots free for them (6 / 5 / 4 per CU, with and without the branch's GEMMs at one workgroup per
+    // CU) does not shorten the decoder segment - 2.51-2.53 ms either way, tools/step_segments.py: what the small kernels wait for is
+    // the memory system this branch saturates, not a place to run.
+    int rb = (2048 + B - 1) / B;
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
     if (grad_dtype == ASR_BF16)

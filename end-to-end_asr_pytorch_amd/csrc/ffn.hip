@@ -75,7 +75,7 @@ struct FfnFwdArgs {
     int M, L, dff, Mp;
     float eps;
     asr_dropout_t drop;
-    int dbg;      // ASR_AMD_FFN_DBG (timing breakdowns only): 1 = no epilogue
+    int dbg;      // timing breakdowns only (tools build with it set): 1 = no epilogue
 };
 
 // PROJ: the attention sub-layer's tail at encoder size (attention.py:58-60: fc -> dropout -> + residual -> layer_norm) on the same
@@ -984,7 +984,7 @@ extern "C" int asr_ffn_fwd(void* stream, const void* x16, const float* x32, cons
     const int M = (int)M64;
     FfnFwdArgs a{(const bf16_t*)x16, x32, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gamma, beta, row_len, (bf16_t*)hid_out,
                  (uint32_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x,
-                 getenv("ASR_AMD_FFN_DBG") ? atoi(getenv("ASR_AMD_FFN_DBG")) : 0};
+                 0};
     const dim3 grid((M + FBM - 1) / FBM), block(256);
     const bool dr = drop_x.thr16 != 0;
     if (hid_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);

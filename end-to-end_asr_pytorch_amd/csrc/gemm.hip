@@ -950,8 +950,7 @@ bool dense_vec_ok(const EpiDense& e) {
 }
 
 bool dense_wide_ok(const EpiDense& e) {
-    static const bool off = getenv("ASR_AMD_NO_WIDE_EPI") != nullptr;   // A/B switch
-    if (off || !e.vec_ok) return false;
+    if (!e.vec_ok) return false;
     return e.c_dtype == ASR_F32 ? true : (e.ldc % 8 == 0 && asr_aligned(e.C, 16));
 }
 
@@ -982,10 +981,9 @@ int zero_c(hipStream_t s, void* C, int64_t n) {   // n floats, n % 4 == 0, C 16-
     return 0;
 }
 int pick_ksplit(const EpiDense& e, int ntiles, int K) {
-    static const bool off = getenv("ASR_AMD_SPLITK") && atoi(getenv("ASR_AMD_SPLITK")) == 0;
-    static const int max_tiles = getenv("ASR_AMD_SPLITK_TILES") ? atoi(getenv("ASR_AMD_SPLITK_TILES")) : 64;
+    constexpr int max_tiles = 64;      // (no split-K at all: step +0.24 ms; 128 tiles: +-0 .. +0.1 ms on S2)
     const int nk = K / 64;
-    if (off || asr_deterministic() || !e.wide_ok || e.c_dtype != ASR_F32 || (e.flags & ASR_GEMM_RELU) || e.relu_mask || e.bits_in || e.bits_out ||
+    if (asr_deterministic() || !e.wide_ok || e.c_dtype != ASR_F32 || (e.flags & ASR_GEMM_RELU) || e.relu_mask || e.bits_in || e.bits_out ||
         e.N % BN != 0 || e.ldc != e.N || ntiles > max_tiles || nk < 8 || (const void*)e.addend == (const void*)e.C)
         return 1;
     int sp = nk / 4;                       // >= 4 K-tiles per split
@@ -996,7 +994,7 @@ int pick_ksplit(const EpiDense& e, int ntiles, int K) {
 template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t lda, const void* W, int64_t ldw, int M, int N, int K,
                                         const Epi& epi, int ksplit = 1) {
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n * ksplit;
-    static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU (64 KiB of LDS each)
+    constexpr int max_wg = 512;   // 2 per CU (64 KiB of LDS each); 384 .. 768: +0.1 .. 0.8 ms per step
     const int nwg = ntiles < max_wg ? ntiles : max_wg;
     if (ksplit == 1)
         hipLaunchKernelGGL((gemm_nt_glds_kernel<Epi, true>), dim3(nwg), dim3(NT), 0, s, reinterpret_cast<const bf16_t*>(A), lda,
@@ -1010,12 +1008,10 @@ template <typename Epi> int launch_glds(hipStream_t s, const void* A, int64_t ld
 
 template <typename Epi> int dispatch(hipStream_t s, const void* A, int a_dtype, int64_t lda, const void* W, int w_dtype,
                                      int64_t ldw, int M, int N, int K, const Epi& epi) {
-    static const bool no_glds = getenv("ASR_AMD_NO_GLDS") != nullptr;   // A/B switch for benchmarking the staging paths
     // (A/B on one MI355X after the epilogue / addressing diet: LDS-DMA double buffering +10..26 % at K = 2048, roughly neutral at
     // K = 256 (-7 % on the [32000,2048,256] FFN1 shape, +10 % on the narrow-N ones, whole train step 1-2 % faster), so it is the
-    // default whenever K % 64 == 0; ASR_AMD_GLDS_MINK raises the threshold for experiments)
-    static const int glds_min_k = getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64;
-    if (!no_glds && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0 && K >= glds_min_k) {
+    // default whenever K % 64 == 0)
+    if (a_dtype == ASR_BF16 && w_dtype == ASR_BF16 && K % 64 == 0) {
         if constexpr (std::is_same<Epi, EpiDense>::value) {
             const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
             if (const int sp = pick_ksplit(epi, tiles, K); sp > 1) {
@@ -1072,7 +1068,7 @@ extern "C" int asr_gemm_nt_ex(void* stream, const void* A, int a_dtype, int64_t 
     if (relu_bits_out) {
         // sign bits are produced by the LDS-transposed epilogue of the LDS-DMA kernel only: full 128-column tiles, bf16 x bf16
         ASR_REQUIRE(epi.wide_ok && c_dtype == ASR_BF16 && N % 128 == 0 && ld_bits == N / 8 && a_dtype == ASR_BF16 && w_dtype == ASR_BF16 &&
-                        K % 64 == 0 && (flags & ASR_GEMM_RELU) && getenv("ASR_AMD_NO_GLDS") == nullptr,
+                        K % 64 == 0 && (flags & ASR_GEMM_RELU),
                     ASR_ERR_UNSUPPORTED, "gemm_ex: relu_bits_out needs bf16 operands/output, ReLU, N %% 128 == 0, K %% 64 == 0, aligned rows");
         epi.bits_out = reinterpret_cast<unsigned char*>(relu_bits_out);
         epi.ld_bits = ld_bits;
@@ -1095,17 +1091,16 @@ extern "C" int asr_proj_heads(void* stream, const void* X, int x_dtype, int64_t 
     }
     if (x_dtype == ASR_BF16 && K == 256 && ldx == 256 && ldw == 256) {
         // encoder-sized rows: the feed-forward kernel's structure (ffn.hip: x read once for all heads, store-bound); ASR_AMD_HEADS_ROWS=0
-        // switches it off, ASR_AMD_HEADS_MIN_ROWS moves the threshold (read per call: the parity test toggles them)
+        // switches it off (read per call: the parity test compares the two kernels)
         const char* e = getenv("ASR_AMD_HEADS_ROWS");
-        const char* mr = getenv("ASR_AMD_HEADS_MIN_ROWS");
-        if ((!e || atoi(e) != 0) && M >= (mr ? atoi(mr) : 16384)) {
+        if ((!e || atoi(e) != 0) && M >= 16384) {
             const int rc = asr_proj_heads_rows(s, X, W, bias, out, proj_stride, n_proj, B, L, h, scale_first);
             if (rc != -2) return rc;
         }
     }
     EpiHeads<bf16_t> epi{reinterpret_cast<bf16_t*>(out), proj_stride, bias, L, h, M, N, scale_first};
     if (x_dtype == ASR_F32) return launch_gemm<float, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
-    if (K % 64 == 0 && K >= (getenv("ASR_AMD_GLDS_MINK") ? atoi(getenv("ASR_AMD_GLDS_MINK")) : 64) && getenv("ASR_AMD_NO_GLDS") == nullptr)
+    if (K % 64 == 0)
         return launch_glds(s, X, ldx, W, ldw, M, N, K, epi);
     return launch_gemm<bf16_t, bf16_t>(s, X, ldx, W, ldw, M, N, K, epi);
 }
@@ -1127,15 +1122,15 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     mask_is_bits &= 1;
     if (mask_is_bits && relu_mask) {
         ASR_REQUIRE(epi.wide_ok && a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) &&
-                        ld_mask == N / 8 && getenv("ASR_AMD_NO_TR") == nullptr,
+                        ld_mask == N / 8,
                     ASR_ERR_UNSUPPORTED, "gemm_nn: a sign-bit mask needs the LDS-DMA kernel's shapes (bf16 A, K %% 64 == 0, N %% 128 == 0)");
         epi.bits_in = reinterpret_cast<const unsigned char*>(relu_mask);
         epi.ld_bits = ld_mask;
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16) && getenv("ASR_AMD_NO_TR") == nullptr) {
-        static const int max_wg = getenv("ASR_AMD_GEMM_WGS") ? atoi(getenv("ASR_AMD_GEMM_WGS")) : 512;   // 2 per CU, persistent
+    if (a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16)) {
+        constexpr int max_wg = 512;   // 2 per CU, persistent
         const int sp = pick_ksplit(epi, nwg, K);
         if (sp > 1) {
             if (!epi.c_is_zero)

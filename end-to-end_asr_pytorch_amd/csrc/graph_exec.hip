@@ -42,7 +42,7 @@ struct XNode {
 // when it is recorded (cache write-back and invalidation so that the host and other devices see the data) - measured ~6.5 us of
 // nothing between the recording kernel and the next kernel of its stream, 49 times per S1 step.  ASR_AMD_GRAPHX_SYSFENCE=1 restores it.
 unsigned graphx_event_flags() {
-    static const bool sysfence = getenv("ASR_AMD_GRAPHX_SYSFENCE") && atoi(getenv("ASR_AMD_GRAPHX_SYSFENCE")) != 0;
+    constexpr bool sysfence = false;      // (true: HIP's default system-scope fence at every record, S1 replay +0.1-0.2 ms)
     // (hipEventReleaseToDevice instead: 12.06 against 11.99 ms; both flags together are rejected by the runtime)
     return hipEventDisableTiming | (sysfence ? 0u : hipEventDisableSystemFence);
 }
@@ -176,13 +176,9 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
                 if (reuse >= 0) st = reuse;
                 else if ((int)g->streams.size() < max_streams) {
                     hipStream_t ns;
-                    static const int side_prio = getenv("ASR_AMD_GRAPHX_PRIO") ? atoi(getenv("ASR_AMD_GRAPHX_PRIO")) : 0;   // A/B: 1 = side streams at the lowest priority, -1 = highest
-                    hipError_t ce;
-                    if (side_prio != 0) {
-                        int least = 0, greatest = 0;
-                        hipDeviceGetStreamPriorityRange(&least, &greatest);
-                        ce = hipStreamCreateWithPriority(&ns, hipStreamNonBlocking, side_prio > 0 ? least : greatest);
-                    } else ce = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+                    // (side streams of another priority get hardware queues of their own, and cross-queue ordering is what costs: S1
+                    // replay 23.8 / 19.3 ms at the lowest / highest priority against 12.4)
+                    const hipError_t ce = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
                     if (ce != hipSuccess) { asr_set_error("graphx: stream"); return -2; }
                     g->streams.push_back(ns);
                     tail_of_stream.push_back(-1);
@@ -262,7 +258,7 @@ extern "C" int asr_graphx_create(void* hip_graph, int max_streams, void** out_ha
     // keep their exact producer: they must not wait for more than they need.)  Waits that an earlier wait of the same stream on a
     // later node of the same producer stream already implies are dropped.
     {
-        static const bool coalesce = !(getenv("ASR_AMD_GRAPHX_COALESCE") && atoi(getenv("ASR_AMD_GRAPHX_COALESCE")) == 0);
+        constexpr bool coalesce = true;
         const int ns = (int)g->streams.size();
         std::vector<int> per_stream(ns, 0);
         for (size_t i = 0; i < n; ++i) per_stream[stream_of[i]]++;

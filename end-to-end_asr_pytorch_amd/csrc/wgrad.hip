@@ -375,10 +375,9 @@ extern "C" int asr_gemm_tn(void* stream, const void* A, int a_dtype, int64_t lda
 
 // the M-split this kernel would use: splits x tiles ~ one workgroup per CU, ranges of whole 64-row steps, at least `min_rows` rows each
 static void tn_v2_plan(int M, int N, int K, int max_workgroups, int* tiles_out, int* splits_out, int* mps_out) {
-    static const int env_wgs = getenv("ASR_AMD_TN2_WGS") ? atoi(getenv("ASR_AMD_TN2_WGS")) : 0;
-    static const int min_rows = getenv("ASR_AMD_TN2_MINROWS") ? atoi(getenv("ASR_AMD_TN2_MINROWS")) : 512;
+    constexpr int min_rows = 512;
     const int tiles = ((N + 127) / 128) * (K / 128);
-    int target = env_wgs > 0 ? env_wgs : 256;
+    int target = 256;
     if (max_workgroups > 0 && max_workgroups < target) target = max_workgroups;
     int splits = (target + tiles / 2) / tiles;
     const int max_splits = (M + min_rows - 1) / min_rows;
@@ -403,10 +402,9 @@ extern "C" int asr_gemm_tn_ws(void* stream, const void* A, int64_t lda, const vo
                               int K, int accumulate, float* colsum, int max_workgroups, void* workspace, int64_t workspace_bytes,
                               int deterministic) {
     ASR_REQUIRE(A && Bm && C && M > 0 && N > 0 && K > 0, ASR_ERR_ARG, "gemm_tn_ws: bad args");
-    static const bool off = getenv("ASR_AMD_NO_TN2") != nullptr;     // A/B switch
     const bool n_ok = N % 128 == 0 || lda >= (int64_t)(N + 127) / 128 * 128;
     const bool fits = (int64_t)M * lda * 2 < (1ll << 31) && (int64_t)M * ldb * 2 < (1ll << 31);
-    if (off || !workspace || !asr_aligned(workspace, 16) || M < 64 || !n_ok || K % 128 || lda % 8 || ldb % 8 || !asr_aligned(A, 16) ||
+    if (!workspace || !asr_aligned(workspace, 16) || M < 64 || !n_ok || K % 128 || lda % 8 || ldb % 8 || !asr_aligned(A, 16) ||
         !asr_aligned(Bm, 16) || !fits || workspace_bytes < asr_gemm_tn_ws_bytes(M, N, K, max_workgroups))
         return asr_gemm_tn(stream, A, ASR_BF16, lda, Bm, ASR_BF16, ldb, C, ldc, M, N, K, accumulate ? 0 : 1, colsum, max_workgroups);
     TnArgs a;
@@ -462,8 +460,7 @@ extern "C" int asr_gemm_tn_ws_group_wgs(void* stream, int n, const asr_tn_proble
         const int my_tiles = ((q.N + 127) / 128) * (q.K / 128);
         // the grouped launch runs on the trainer's side stream beside the main chain: half the CUs (ASR_AMD_TN_GROUP_WGS; a slab
         // workgroup takes a whole CU, see modules._WGRAD_SIDE_WGS)
-        static const int env_group_wgs = getenv("ASR_AMD_TN_GROUP_WGS") ? atoi(getenv("ASR_AMD_TN_GROUP_WGS")) : 128;
-        const int group_wgs = group_workgroups > 0 ? group_workgroups : env_group_wgs;
+        const int group_wgs = group_workgroups > 0 ? group_workgroups : 128;      // (96 / 160 / 192 / 256 / 64 on the side stream: S1 step +0.19 / -0.03 / -0.03 / +0.06 / +0.29 ms)
         int share = (int)((int64_t)group_wgs * my_tiles / total_tiles);
         if (share < my_tiles) share = my_tiles;
         tn_v2_plan(q.M, q.N, q.K, share, &tiles, &a.splits, &a.m_per_split);

@@ -30,14 +30,14 @@ _LOG2E = 1.4426950408889634
 # neutral at S1 (11.19 / 11.29 against 11.12 / 11.28 ms) - the launch grows by 24.5 us (129.4 against 104.9) where it saves a 19 us kernel
 # and a 5 us gap: ffn_bwd is ONE round of 250 workgroups at one wave per SIMD, so the 82 MB the epilogue still moves (s in, ds and
 # ds16 out) go through a chip that is doing nothing else, while the stand-alone kernel runs beside the weight-gradient stream.
-_FOLD_LN = os.environ.get("ASR_AMD_FOLD_LN", "0") == "1"
+_FOLD_LN = False
 # 1 = the one-launch sub-layers at encoder size (asr_ffn_fwd, asr_proj_ln_fwd) do not store the pre-norm sum: the LayerNorm's backward takes
 # x^ = (y - beta) / gamma from the OUTPUT, which stays alive anyway (33 MB less to write and to hold per LayerNorm, 24 of them per S1 step:
 # 0.8 GB of activations).  Off by default: a memory option, not a faster step (11.27-11.50 against 11.22-11.26 ms on one box).
 _LN_FROM_Y = os.environ.get("ASR_AMD_LN_FROM_Y", "0") == "1"
-_FOLD_LN_QKV = os.environ.get("ASR_AMD_FOLD_LN_QKV", "1") != "0"     # A/B: 0 = the feed-forward sub-layer's LayerNorm backward as its own launch
-_MASK_PREFETCH = os.environ.get("ASR_AMD_MASK_PREFETCH", "1") != "0"
-_MASK_GROUP = os.environ.get("ASR_AMD_MASK_GROUP", "1") != "0"      # short sequences: the encoder's attention-dropout masks 8 sites per launch
+_FOLD_LN_QKV = True      # the feed-forward sub-layer's LayerNorm backward as the epilogue of the next layer's Q/K/V data gradient (asr_dgrad_rows_ln)
+_MASK_PREFETCH = True      # (bench.py's kernel-alone timing pass sets this False: the masks are then hashed in line)
+_MASK_GROUP = True      # short sequences: the encoder's attention-dropout masks 8 sites per launch
 
 
 def set_precision(p):
@@ -133,7 +133,7 @@ def _drop(mod, suffix):
 # Workgroups of a weight-gradient launch on the trainer's side stream: half the CUs.  A slab weight-gradient workgroup takes a whole CU
 # (512 registers per lane, 128 KiB of LDS), so with 256 of them the main chain's next kernel waits for CUs to come free; with 128 it
 # always finds half the chip (S1 replay 11.98-12.05 -> 11.84-11.91 ms on two boxes; 96: 11.92, 64: 12.16, 192: 11.96).
-_WGRAD_SIDE_WGS = int(os.environ.get("ASR_AMD_WGRAD_SIDE_WGS", "128"))
+_WGRAD_SIDE_WGS = 128
 _WGRAD = None      # set by Trainer.backward: {"stream": side stream, "keep": [operands kept alive until the streams join]}
 
 
@@ -150,14 +150,7 @@ def flush_wgrads():
             a, b, out, acc, cs = pend[0]
             ops.gemm_tn(a, b, out=out, accumulate=acc, colsum=cs, max_wgs=_WGRAD_SIDE_WGS)
         else:
-            # A batch of encoder-sized problems (an encoder layer's four weight gradients = 80 output tiles) gets a workgroup budget of
-            # its own, shared out by tiles; the decoder-sized groups keep the library's default.  (One workgroup per tile - every problem
-            # unsplit over M, no slabs, no reduce launch - measured 317 us per layer alone on the chip against 133 us with 256
-            # workgroups: a workgroup that walks 32 000 rows by itself misses L2 on every operand tile and its three-step prefetch ring
-            # does not cover an HBM round trip; M-ranges shared by the tiles of one XCD do - tools/bench_wgrad_batch.py.)
-            tiles = sum(ops.tn_tiles(p[0], p[1]) for p in pend)
-            big = ops.TN_BATCH and tiles >= 64 and max(p[0].shape[0] for p in pend) > ops.TN_GROUP_MAX_ROWS
-            ops.gemm_tn_group(pend, group_wgs=(ops.TN_BATCH_WGS or max(256, tiles)) if big else 0)
+            ops.gemm_tn_group(pend)
 
 
 def _wg(a, b, **kw):
@@ -167,22 +160,20 @@ def _wg(a, b, **kw):
     if _WGRAD is None:
         return ops.gemm_tn(a, b, **kw)
     out = kw.get("out")
-    if (ops.gemm_tn_group_ok(a, b, out) or ops.gemm_tn_batch_ok(a, b, out)) and set(kw) <= {"out", "accumulate", "colsum"}:
+    if ops.gemm_tn_group_ok(a, b, out) and set(kw) <= {"out", "accumulate", "colsum"}:
         _WGRAD["keep"].append((a, b))
-        pend = _WGRAD.setdefault("pending", [])
-        if any(p[2].data_ptr() == out.data_ptr() for p in pend):
+        if any(p[2].data_ptr() == out.data_ptr() for p in _WGRAD.get("pending", ())):
             flush_wgrads()        # the same destination twice (tied weights): two problems of one launch would race on it and its workspace
-            pend = _WGRAD.setdefault("pending", [])
-        small = a.shape[0] <= ops.TN_GROUP_MAX_ROWS
-        if pend and (pend[0][0].shape[0] <= ops.TN_GROUP_MAX_ROWS) != small:
-            flush_wgrads()        # decoder-sized and encoder-sized problems go in launches of their own (different workgroup budgets)
-            pend = _WGRAD.setdefault("pending", [])
-        pend.append((a, b, out, bool(kw.get("accumulate", False)), kw.get("colsum")))
-        # decoder-sized problems: eight per launch, as before; encoder-sized: until ~two layers' output tiles are pending (or 16 problems)
-        if (small and len(pend) >= 8) or len(pend) >= ops.TN_GROUP_MAX or \
-                (not small and ops.TN_BATCH and sum(ops.tn_tiles(p[0], p[1]) for p in pend) >= ops.TN_BATCH_TILES):
+        _WGRAD.setdefault("pending", []).append((a, b, out, bool(kw.get("accumulate", False)), kw.get("colsum")))
+        if len(_WGRAD["pending"]) >= 8:
             flush_wgrads()
         return out
+    # (Round 5, measured and not kept: ALL of an encoder layer's weight gradients - or two layers' - as one grouped launch with a
+    # workgroup budget of its own, ops.gemm_tn_group(group_wgs=).  Alone on the chip the batch wins - 133 us per layer at 256 workgroups
+    # against 173 us for the four launch pairs, tools/bench_wgrad_batch.py - but in the step every variant lost 0.1-0.25 ms (11.20-11.36
+    # against 11.06-11.13 ms): one long launch holds its CUs against the main chain longer than four short ones do.  Unsplit over M
+    # - one workgroup per output tile, no slabs, no reduce launch - is slower still, 317 us per layer: a workgroup that walks all
+    # 32 000 rows alone misses L2 on every operand tile and its three-step prefetch ring does not cover an HBM round trip.)
     main, side = torch.cuda.current_stream(), _WGRAD["stream"]
     ops.order_after(side, main)
     _WGRAD["keep"].append((a, b))
@@ -236,8 +227,8 @@ def _prefetch_attn_masks(sites, training, device):
 # into parameter gradients (written straight into `p.grad`, which the trainer points into one flat buffer) and input
 # gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
 _TAPE = None
-_DIRECT_CONV_BWD = os.environ.get("ASR_AMD_DIRECT_CONV_BWD", "1") != "0"    # A/B: 0 = the patch-matrix backward of the conv layers
-_DECODE_FUSED = os.environ.get("ASR_AMD_DECODE_FUSED", "1") != "0"     # one-launch sub-layers in the per-token decode steps (decode_blocks.hip)
+_DIRECT_CONV_BWD = True     # the conv layers' direct backward kernels (bf16); the patch-matrix route stays as the f32 parity path
+_DECODE_FUSED = True      # one-launch sub-layers in the per-token decode steps (decode_blocks.hip)
 _IN_DECODE_STEP = False    # set while a per-token decode step is being queued / captured (rows = hypotheses, one position each)
 
 

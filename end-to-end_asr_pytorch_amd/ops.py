@@ -61,7 +61,7 @@ def profile_start():
     _PROF = {}
 
 
-LIGHT_TIMERS = os.environ.get("ASR_AMD_LIGHT_TIMERS", "1") != "0"      # A/B: 0 = torch timing events (system-scope fence at every record)
+LIGHT_TIMERS = True      # timing events without the system-scope fence (False: torch timing events, ~2 us more per bracketed op)
 _TIMER_POOL = []
 
 
@@ -135,15 +135,13 @@ def as_i32(t, device=None):
 # does).  The trainer zeroes ONE arena at the start of the step instead; GEMM outputs of split-K shape are cut from it and the
 # library is told (ASR_GEMM_C_IS_ZERO).  Every slice is handed out once per reset, so it is still zero when the GEMM runs.
 _ARENA = {"buf": None, "off": 0, "live": False, "dirty": 0}
-SPLITK_TILES = int(os.environ.get("ASR_AMD_SPLITK_TILES", "64"))     # gemm.hip pick_ksplit: output tiles up to which K is split
+SPLITK_TILES = 64     # gemm.hip pick_ksplit: output tiles up to which K is split
 GEMM_C_IS_ZERO = 4
 
 
 def arena_reset(device, nbytes=64 << 20):
     """Zero the arena (one fill launch) and make its slices available until the next reset.  Call once per step, on the stream
     the GEMMs will run on."""
-    if os.environ.get("ASR_AMD_ZERO_ARENA", "1") == "0":
-        return
     device = torch.device(device)
     if _ARENA["buf"] is None or _ARENA["buf"].device != device or _ARENA["buf"].numel() * 4 < nbytes:
         _ARENA["buf"] = torch.zeros(nbytes // 4, device=device, dtype=torch.float32)
@@ -263,7 +261,7 @@ def attention_fwd(q, k, v, k_len=None, causal=False, need_lse=False, drop=None, 
     return ctx, lse
 
 
-SMALL_FUSED_MAX_ROWS = int(os.environ.get("ASR_AMD_FUSED_SMALL_ROWS", "4096"))     # 0 switches the fused small-M block off
+SMALL_FUSED_MAX_ROWS = 4096     # 0 switches the fused small-M block off
 
 
 def gemm_add_layernorm_small_ok(a2d, w, D, B, L):
@@ -304,7 +302,7 @@ def gemm_add_layernorm_small(a2d, w, bias, residual, gamma, beta, B, L, row_len=
 gemm_add_layernorm = gemm_add_layernorm_small
 
 
-PROJ_LN = os.environ.get("ASR_AMD_PROJ_LN", "1") != "0"              # A/B: 0 = output projection GEMM + LayerNorm launch at encoder size
+PROJ_LN = True           # the attention output projection + residual + LayerNorm as one launch at encoder size (+8 us per layer as two)
 
 
 def proj_ln_ok(a2d, w, D, B, L):
@@ -331,12 +329,12 @@ def proj_ln(a2d, w, bias, residual, gamma, beta, B, L, row_len=None, want_bf16=T
     return s_sum, y32, y16, mean, rstd
 
 
-FUSED_FFN = os.environ.get("ASR_AMD_FUSED_FFN", "1") != "0"          # A/B: 0 = two GEMMs + LayerNorm / two data-gradient GEMMs
+FUSED_FFN = True         # the one-launch feed-forward sub-layer (False: two GEMMs + LayerNorm / two data-gradient GEMMs, step +1.9 ms)
 # below: a 128-token block per CU leaves most of the chip idle and the launch takes its ~75 us whatever the row count, while the GEMM +
 # GEMM + LayerNorm path scales with the rows (114 us at 32000): the crossover is near 20000 rows (S2 / CIF_Model, 8000 rows: 6.67 ->
 # 6.40 ms and 7.18 -> 6.71 ms per step on the separate launches)
-FUSED_FFN_MIN_ROWS = int(os.environ.get("ASR_AMD_FUSED_FFN_ROWS", "20000"))
-PROJ_LN_MIN_ROWS = int(os.environ.get("ASR_AMD_PROJ_LN_ROWS", "4096"))
+FUSED_FFN_MIN_ROWS = 20000
+PROJ_LN_MIN_ROWS = 4096
 
 
 def ffn_fused_ok(x16, x32, w1, w2, B, L):
@@ -420,7 +418,7 @@ def add_layernorm(x, residual, gamma, beta, B, L, pe=None, row_len=None, want_bf
 
 
 _ORDER_EVENTS = {"pool": [], "next": 0}
-LIGHT_EVENTS = os.environ.get("ASR_AMD_LIGHT_EVENTS", "1") != "0"      # A/B: 0 = torch events (system-scope fence at every record)
+LIGHT_EVENTS = True      # cross-stream ordering on events without the system-scope fence (False: torch events, step +0.1 ms)
 
 
 def order_after(later, earlier):
@@ -535,7 +533,7 @@ _AUX = {}
 # chunks of the fused CTC forward (asr_hip.h: asr_ctc_loss_fwd n_chunks): the hand-off granularity between the streaming pass and the
 # recursion wavefronts of the same launch.  <= 1 = the two-launch form (pass, then recursion): 154-167 us at the north-star
 # shape against 133-139 fused with 32 chunks
-CTC_CHUNKS = int(os.environ.get("ASR_AMD_CTC_CHUNKS", "32"))
+CTC_CHUNKS = 32
 _CTC_COUNTERS = {}
 _CTC_DBG = int(os.environ.get("ASR_AMD_CTC_DBG", "0") or 0) & 0xff
 
@@ -547,10 +545,10 @@ def ctc_reset_counters():
     gates early on stale arrivals."""
     _CTC_COUNTERS.clear()
 
-CTC_LAZY_OCC = os.environ.get("ASR_AMD_CTC_LAZY_OCC", "1") != "0"     # asr_ctc_loss_bwd with the second workspace (see asr_hip.h)
+CTC_LAZY_OCC = True     # asr_ctc_loss_bwd with the second workspace (see asr_hip.h)
 
 
-QUEUE_PROBE = os.environ.get("ASR_AMD_QUEUE_PROBE", "1") != "0"      # A/B: 0 = side streams as torch hands them out
+QUEUE_PROBE = True      # side streams picked by hardware-queue probes (False: as torch hands them out - S1 +1 ms, S2 +3 ms in a quarter to three quarters of the runs)
 
 
 def streams_share_queue(a, b):
@@ -581,7 +579,7 @@ def aux_stream(device, priority=0, slot=0):
     return _AUX[key]
 
 
-FUSED_VOCAB_LSE = os.environ.get("ASR_AMD_VOCAB_LSE", "1") != "0"      # A/B: 0 = plain GEMM, the CTC forward streams the logits itself
+FUSED_VOCAB_LSE = True      # ctc_fc with the row log-sum-exp from its own launch (False: plain GEMM, the CTC forward streams the logits itself, +70 us)
 
 
 def vocab_proj_lse_ok(x16, w16):
@@ -805,9 +803,9 @@ def gemm_nt_ex(a2d, w, bias=None, out_dtype=torch.float32, relu=False, addend=No
     return out
 
 
-DGRAD_ROWS = os.environ.get("ASR_AMD_DGRAD_ROWS", "1") != "0"      # A/B: 0 = the tiled GEMM for every data gradient
-DGRAD_ROWS_MIN = int(os.environ.get("ASR_AMD_DGRAD_ROWS_MIN", "8192"))
-DGRAD_ROWS_MIN_K = int(os.environ.get("ASR_AMD_DGRAD_ROWS_MIN_K", "512"))      # (K = 256, the attention output projection: 20.4 against the tiled GEMM's 18.6 us)
+DGRAD_ROWS = True      # the row-block data gradient (False: the tiled GEMM for every data gradient)
+DGRAD_ROWS_MIN = 8192
+DGRAD_ROWS_MIN_K = 512      # (K = 256, the attention output projection: 20.4 against the tiled GEMM's 18.6 us)
 
 
 def dgrad_rows_ok(a2d, w, K=None, lda=None):
@@ -915,7 +913,7 @@ def poison_lds(device="cuda"):
 
 # Workspaces of the slab-reduced weight gradient (csrc/wgrad.hip): one per destination buffer, so that launches queued on different
 # streams never share one, address-stable for graph capture.
-TN_SLAB = os.environ.get("ASR_AMD_TN_SLAB", "1") != "0"
+TN_SLAB = True      # the slab-reduced weight gradient (False: the float-atomics kernel it replaced; tests/test_gpu_wgrad.py compares the two)
 DETERMINISTIC = os.environ.get("ASR_AMD_DETERMINISTIC", "0") not in ("", "0")
 _tn_ws = {}
 
@@ -971,9 +969,9 @@ class _TnProblem(ctypes.Structure):          # asr_hip.h: asr_tn_problem_t
                 ("colsum", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
-TN_GROUP = os.environ.get("ASR_AMD_TN_GROUP", "1") != "0"      # A/B: 0 = the decoder's weight gradients one launch pair each
-TN_GROUP_MAX_ROWS = int(os.environ.get("ASR_AMD_TN_GROUP_MAX_ROWS", "2048"))
-TN_GROUP_SMALL_TILES = int(os.environ.get("ASR_AMD_TN_GROUP_TILES", "16"))     # > 0: weight gradients of at most this many output tiles join the groups at any row count
+TN_GROUP = True      # the decoder's weight gradients eight per launch pair (False: one pair each, +0.1 ms)
+TN_GROUP_MAX_ROWS = 2048
+TN_GROUP_SMALL_TILES = 16     # > 0: weight gradients of at most this many output tiles join the groups at any row count
 
 
 def gemm_tn_group_ok(a2d, b2d, out):
@@ -986,27 +984,13 @@ def gemm_tn_group_ok(a2d, b2d, out):
             (a2d.shape[1] % 128 == 0 or a2d.stride(0) >= (a2d.shape[1] + 127) // 128 * 128))
 
 
-TN_BATCH = os.environ.get("ASR_AMD_TN_BATCH", "1") != "0"       # A/B: 0 = the encoder's feed-forward weight gradients one launch pair each
-TN_BATCH_TILES = int(os.environ.get("ASR_AMD_TN_BATCH_TILES", "80"))   # pending output tiles at which a batch is issued (an encoder layer has 80)
-TN_BATCH_WGS = int(os.environ.get("ASR_AMD_TN_BATCH_WGS", "0"))        # workgroup budget of a batch (0: 256, or one per output tile if that is more)
-TN_GROUP_MAX = 16
-
-
 def tn_tiles(a2d, b2d):
+    """128 x 128 output tiles of dW = a2d^T . b2d"""
     return ((a2d.shape[1] + 127) // 128) * (b2d.shape[1] // 128)
 
 
-def gemm_tn_batch_ok(a2d, b2d, out):
-    """A weight gradient the batched launch takes: what gemm_tn_group_ok takes at any row count and tile count (the encoder's feed-forward
-    weights too)."""
-    return (TN_BATCH and TN_GROUP and TN_SLAB and not EXACT_F32 and out is not None and a2d.dtype == torch.bfloat16 and b2d.dtype == torch.bfloat16 and
-            a2d.shape[0] >= 64 and b2d.shape[1] % 128 == 0 and a2d.stride(1) == 1 and b2d.stride(1) == 1 and
-            a2d.stride(0) % 8 == 0 and b2d.stride(0) % 8 == 0 and a2d.data_ptr() % 16 == 0 and b2d.data_ptr() % 16 == 0 and
-            (a2d.shape[1] % 128 == 0 or a2d.stride(0) >= (a2d.shape[1] + 127) // 128 * 128))
-
-
 def gemm_tn_group(problems, group_wgs=0):
-    """problems: up to 16 tuples (a2d, b2d, out, accumulate, colsum), each gemm_tn_group_ok / gemm_tn_batch_ok - dW_i (+)= A_i^T . B_i in
+    """problems: up to 16 tuples (a2d, b2d, out, accumulate, colsum), each what asr_gemm_tn_ws takes - dW_i (+)= A_i^T . B_i in
     ONE pair of launches (asr_hip.h: asr_gemm_tn_ws_group_wgs).  group_wgs: the launch's workgroup budget (0: the library's default);
     <= the problems' total output tiles means every problem runs unsplit over M and there is no reduce launch."""
     arr = (_TnProblem * len(problems))()
@@ -1623,7 +1607,7 @@ class GraphExec:
         self._h, self._graph, self.info = handle, graph, info
 
     @classmethod
-    def from_torch_graph(cls, graph, max_streams=int(os.environ.get("ASR_AMD_GRAPHX_STREAMS", "4"))):
+    def from_torch_graph(cls, graph, max_streams=4):
         """-> GraphExec, or None (with a warning that says why) when the graph holds nodes the executor does not launch.
         max_streams = 4: one per hardware queue of the runtime - with 8, two of the executor's streams shared each queue and three of the
         four rotations of the stream map put the weight-gradient chain on the launch stream's queue (S1 13.6 vs 12.6 ms, S2 9-10 vs 6.9);

@@ -92,7 +92,7 @@ class FlatParams:
                                    % (tuple(p.shape), off))
 
 
-GRAPH_EXEC = os.environ.get("ASR_AMD_GRAPH_EXEC", "1") != "0"      # A/B: 0 = replay the captured step with hipGraphLaunch
+GRAPH_EXEC = True      # the captured step launched by the multi-stream executor (False: hipGraphLaunch, which runs a graph's branches level by level: +1.5-2.5 ms)
 
 
 class GradBuckets:
@@ -178,10 +178,10 @@ class Trainer:
         self.exact_global_mean = exact_global_mean
         # collective nodes in the captured step even with one rank (a 1-rank RCCL communicator: the executor's all-reduce plumbing,
         # measurable on a 1-GPU box; tools/rccl_sanity.py, tests/test_gpu_graph.py)
-        self.force_collective = (os.environ.get("ASR_AMD_FORCE_COLLECTIVE", "0") == "1") if force_collective is None else bool(force_collective)
+        self.force_collective = bool(force_collective)
         # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); ASR_AMD_OVERLAP_CTC=0 serialises it
-        self.overlap_ctc = (os.environ.get("ASR_AMD_OVERLAP_CTC", "1") != "0") if overlap_ctc is None else bool(overlap_ctc)
-        self.wgrad_stream = os.environ.get("ASR_AMD_WGRAD_STREAM", "1") != "0"     # weight-gradient GEMMs on a side stream (backward())
+        self.overlap_ctc = True if overlap_ctc is None else bool(overlap_ctc)
+        self.wgrad_stream = True     # weight-gradient GEMMs on a side stream (backward()); bench.py's kernel-alone pass sets it False
         self.lambda_qua = lambda_qua      # CIF models: loss = lambda_qua * qua + ctc + ce (solver.py:153, train.py:64)
         dev = next(model.parameters()).device
         self.fp = FlatParams(model, dev)
@@ -648,7 +648,7 @@ class Trainer:
             comm, comm_fn = None, None
             if collective:
                 if not use_x:
-                    raise RuntimeError("a data-parallel step is captured for the graph executor only (ASR_AMD_GRAPH_EXEC=0 or no keep_graph)")
+                    raise RuntimeError("a data-parallel step is captured for the graph executor only (trainer.GRAPH_EXEC off or no keep_graph)")
                 # (communicator set-up is itself a collective and queues GPU work: before the capture begins)
                 if self.world > 1 and torch.distributed.get_backend(self.group) != "nccl" and os.environ.get("ASR_AMD_DP_COMM", "") != "rccl":
                     comm_fn = ops.torch_collective_fn([self.fp.grad], self.group)      # the rig: gloo ranks sharing one GPU

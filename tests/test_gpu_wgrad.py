@@ -118,10 +118,11 @@ def test_grouped_weight_gradients_equal_single_launches():
 
 
 def test_batched_unsplit_weight_gradients_of_an_encoder_layer():
-    """asr_gemm_tn_ws_group_wgs with a budget of one workgroup per output tile: the four weight gradients of an encoder layer (Q/K/V
-    [768 x 256], output projection [256 x 256], feed-forward [2048 x 256] and [256 x 2048]; module.py:48-53, attention.py:33-60) over
-    8 000 ragged rows in ONE launch, every problem unsplit over M (no slab, no reduce launch), accumulate and overwrite, with the bias
-    side products - against fp32 matmuls of the same bf16 operands, bit-identical to itself, and equal to the single launches."""
+    """asr_gemm_tn_ws_group_wgs with an explicit workgroup budget: the four weight gradients of two encoder layers (Q/K/V [768 x 256],
+    output projection [256 x 256], feed-forward [2048 x 256] and [256 x 2048]; module.py:48-53, attention.py:33-60) over 8 037 rows in
+    ONE launch - budget = tiles: every problem unsplit over M (no slab, no reduce launch); budget = 2 x tiles: M-splits - accumulate
+    and overwrite, with the bias side products, against fp32 matmuls of the same bf16 operands, bit-identical to itself, and equal
+    to the single launches."""
     M = 8000 + 37
     shapes = [(768, 256), (256, 256), (2048, 256), (256, 2048)] * 2
     g = torch.Generator().manual_seed(19)
@@ -132,7 +133,6 @@ def test_batched_unsplit_weight_gradients_of_an_encoder_layer():
         out = (torch.randn(Nn, K, generator=g) if acc else torch.full((Nn, K), 3.0)).to(DEV)
         cs = torch.zeros(Nn, device=DEV) if i % 4 in (0, 2) else None
         ref = a.float().t() @ b.float() + (out.cpu() if acc else 0.0)
-        assert ops.gemm_tn_batch_ok(ad, bd, out)
         probs.append((ad, bd, out, acc, cs))
         refs.append((ref, a.float().sum(0) if cs is not None else None))
     tiles = sum(ops.tn_tiles(p[0], p[1]) for p in probs)
@@ -146,6 +146,10 @@ def test_batched_unsplit_weight_gradients_of_an_encoder_layer():
     ops.gemm_tn_group(again, group_wgs=tiles)
     again2 = [(ad, bd, torch.empty_like(out), False, None) for ad, bd, out, acc, cs in probs]
     ops.gemm_tn_group(again2, group_wgs=tiles)
+    split = [(ad, bd, torch.empty_like(out), False, None) for ad, bd, out, acc, cs in probs]
+    ops.gemm_tn_group(split, group_wgs=2 * tiles)
+    for p2, ps in zip(again, split):
+        np.testing.assert_allclose(N(p2[2]), N(ps[2]), atol=3e-2, rtol=1e-3)
     for p2, p3 in zip(again, again2):
         assert torch.equal(p2[2], p3[2])
         single = ops.gemm_tn(p2[0], p2[1], max_wgs=256)

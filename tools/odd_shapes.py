@@ -16,6 +16,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         tl = torch.randint(max(1, U // 2), U + 1, (B,)); tl[0] = U
         for b in range(B): tg[b, int(tl[b]):] = 0
         tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+        if os.environ.get("ODD_SERIAL") == "1":      # everything on one stream, masks hashed in line
+            from asr_amd import modules
+            tr.overlap_ctc = tr.wgrad_stream = False
+            modules._MASK_PREFETCH = False
         vals = []
         for _ in range(3):
             o = tr.step(x, lens, tg, max_target_len=U)
@@ -25,7 +29,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("RESULT " + json.dumps(out))
 else:
     res = []
-    for env in ({}, {"ASR_AMD_OVERLAP_CTC": "0", "ASR_AMD_MASK_PREFETCH": "0", "ASR_AMD_SPLITK": "0", "ASR_AMD_WGRAD_STREAM": "0"}):
+    for env in ({}, {"ODD_SERIAL": "1"}):
         e = dict(os.environ); e.update(env)
         p = subprocess.run([sys.executable, __file__, "child"], env=e, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
