@@ -109,6 +109,9 @@ SIGNATURES = {
     "asr_ctc_counter_words": [_i, _i, _i],
     "asr_ctc_mean": [_vp, _vp, _vp, _i, _vp],
     "asr_ctc_loss_bwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp],
+    "asr_ctc_loss_bwd_ex": [_vp, _vp, _i, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp],
+    "asr_vocab_proj_ctc": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i],
+    "asr_ctc_loss_fwd_table": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "asr_ce_loss_fwd": [_vp, _vp, _i64, _vp, _i, _i, _f, _vp, _vp],
     "asr_ce_mean": [_vp, _vp, _vp, _i, _vp],
     "asr_ce_mean_masked": [_vp, _vp, _vp, _vp, _i, _vp],

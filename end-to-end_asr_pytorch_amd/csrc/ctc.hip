@@ -13,6 +13,8 @@
 // atomics and the gradient row is produced by one coalesced stream.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "asr_common.h"
 
 namespace {
@@ -1080,6 +1082,21 @@ extern "C" int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t l
     return 0;
 }
 
+// ---- forward from finished table rows (asr_vocab_proj_ctc wrote them while the projection's logits passed through LDS): the two
+// half-length alpha / beta chains and the batch mean, nothing else - no pass over logits at all
+extern "C" int asr_ctc_loss_fwd_table(void* stream, const float* lp_ext, const int32_t* in_len, const int64_t* targets, int B, int L, int Umax,
+                                      float* alpha, float* nll, int32_t* tgt_len, float* mean_loss) {
+    ASR_REQUIRE(lp_ext && in_len && targets && alpha && nll && tgt_len, ASR_ERR_ARG, "ctc_fwd_table: null pointer");
+    ASR_REQUIRE(B > 0 && L > 0 && Umax > 0, ASR_ERR_ARG, "ctc_fwd_table: bad sizes");
+    ASR_REQUIRE(ctc_np(Umax) == 1, ASR_ERR_UNSUPPORTED, "ctc_fwd_table: Umax = %d (one state pair per lane: U + 1 <= 64)", Umax);
+    ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd_table: workspaces must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, 0, L, 1);
+    if (mean_loss) hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, tgt_len, B, mean_loss);
+    ASR_LAUNCH_CHECK("ctc_loss_fwd_table");
+    return 0;
+}
+
 static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                              int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
                              int32_t* tgt_len, void* zero_counters, int n_chunks, float* mean_loss) {
@@ -1163,7 +1180,9 @@ extern "C" int asr_ctc_loss_mean_fwd(void* stream, const float* logits, int64_t 
 // exactly these values - half the write here, half the read in both of ctc_fc's backward GEMMs).  Rows are 16-byte aligned on
 // both sides (ldl % 4 == 0, ldg % 8 == 0, host-checked); columns V .. ldg-1 are written as zeros: ldg is chosen by the caller
 // so that the GEMM kernels can treat the rows as padded to their tile width.
-__global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const float* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
+// LT = bf16_t: the logits are the bf16 image asr_vocab_proj_ctc wrote (ldl % 8 == 0; half the read).
+template <typename LT>
+__global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const LT* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
                                                             const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
                                                             int B, int L, int V, int Umax, int blank, const float* __restrict__ lse,
                                                             const float* __restrict__ occ, const float* __restrict__ gout,
@@ -1184,7 +1203,7 @@ __global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const float* __restr
             for (int i = tid; i < ng; i += 256) g4[i] = bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
             continue;
         }
-        const float* x = logits + row * ldl;
+        const LT* x = logits + row * ldl;
         for (int sidx = tid; sidx < Sb; sidx += 256) {
             const int lab = (sidx & 1) ? (int)targets[(int64_t)b * Umax + (sidx >> 1)] : blank;
             const int64_t oi = ((int64_t)b * (L + 2) + t) * Sfull + sidx;
@@ -1194,18 +1213,20 @@ __global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const float* __restr
         }
         __syncthreads();
         const float l = lse[row];
-        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        typedef typename std::conditional<std::is_same<LT, float>::value, f32x4, bf16x4>::type x4_t;
+        const x4_t* x4 = reinterpret_cast<const x4_t*>(x);
         for (int i = tid; i < ng; i += 256) {
             const int c = i * 4;
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if (c + 4 <= V) {
-                const f32x4 v = x4[i];
+                const x4_t xv = x4[i];
+                const f32x4 v = {(float)xv[0], (float)xv[1], (float)xv[2], (float)xv[3]};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = scale * (__expf(v[j] - l) - corr[c + j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (c + j < V) o[j] = scale * (__expf(x[c + j] - l) - corr[c + j]);
+                    if (c + j < V) o[j] = scale * (__expf((float)x[c + j] - l) - corr[c + j]);
             }
             g4[i] = bf16x4{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
         }
@@ -1225,10 +1246,26 @@ extern "C" int asr_ctc_mean(void* stream, const float* nll, const int32_t* tgt_l
     return 0;
 }
 
+extern "C" int asr_ctc_loss_bwd_ex(void* stream, const void* logits, int logits_dtype, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
+                                   int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
+                                   const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
+                                   float* alpha2);
 extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                 int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
                                 const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
                                 float* alpha2) {
+    return asr_ctc_loss_bwd_ex(stream, logits, ASR_F32, ldl, in_len, targets, B, L, V, Umax, blank, lse, lp_ext, alpha, nll, tgt_len, gout, grad,
+                               grad_dtype, ldg, alpha2);
+}
+
+// logits_dtype = ASR_BF16: the bf16 logits image of asr_vocab_proj_ctc (bf16 gradient only; ldl % 8 == 0).
+extern "C" int asr_ctc_loss_bwd_ex(void* stream, const void* logits_v, int logits_dtype, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
+                                   int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
+                                   const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
+                                   float* alpha2) {
+    const float* logits = static_cast<const float*>(logits_v);
+    ASR_REQUIRE(logits_dtype == ASR_F32 || (logits_dtype == ASR_BF16 && grad_dtype == ASR_BF16 && ldl % 8 == 0), ASR_ERR_ARG,
+                "ctc_bwd: bf16 logits need a bf16 gradient and ldl %% 8 == 0");
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len && gout && grad, ASR_ERR_ARG,
                 "ctc_bwd: null pointer");
     ASR_REQUIRE(!alpha2 || asr_aligned(alpha2, 16), ASR_ERR_ALIGN, "ctc_bwd: alpha2 must be 16-byte aligned");
@@ -1250,8 +1287,11 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
     int rb = (2048 + B - 1) / B;
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
-    if (grad_dtype == ASR_BF16)
-        hipLaunchKernelGGL(ctc_grad_bf16_kernel, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, logits, ldl, in_len, targets,
+    if (grad_dtype == ASR_BF16 && logits_dtype == ASR_BF16)
+        hipLaunchKernelGGL(ctc_grad_bf16_kernel<bf16_t>, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, static_cast<const bf16_t*>(logits_v),
+                           ldl, in_len, targets, tgt_len, B, L, V, Umax, blank, lse, alpha, gout, reinterpret_cast<bf16_t*>(grad), ldg, alpha2, lp_ext, nll);
+    else if (grad_dtype == ASR_BF16)
+        hipLaunchKernelGGL(ctc_grad_bf16_kernel<float>, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, logits, ldl, in_len, targets,
                            tgt_len, B, L, V, Umax, blank, lse, alpha, gout, reinterpret_cast<bf16_t*>(grad), ldg, alpha2, lp_ext, nll);
     else
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(rb, B), dim3(256), (size_t)V * sizeof(float), s, logits, ldl, in_len, targets, tgt_len, B, L,

@@ -29,14 +29,28 @@ __device__ __forceinline__ int vswap23(int r) { return (r & ~12) | ((r & 4) << 1
 struct VocabArgs {
     const bf16_t* x16;
     const bf16_t* w;
-    float* logits;
+    float* logits;       // f32 logits [M, ldl]             (CTC = false)
     float* lse;
     int M, V;
     int64_t ldl;
+    // CTC = true: bf16 logits + the CTC table rows
+    bf16_t* logits16;    // [M, ldl] bf16 (ldl % 8 == 0)
+    float* lp_ext;       // [M, 128]: (x[label] - lse) log2 e of the extended label sequence, -inf beyond 2 U_b + 1 (ctc.hip's table)
+    const int64_t* targets;      // [B, Umax]
+    int B, L, Umax, blank;
 };
+constexpr int GLC = 64;              // CTC: gathered logits per frame in LDS - columns 0 .. Umax - 1 the labels, column 63 the blank
+constexpr int VGLAB = VBM * GLC * 4; // 32 KiB
 
+// CTC = true (asr_vocab_proj_ctc): the logits leave as bf16 (the only later reader is the CTC gradient pass, whose output is a bf16
+// image anyway) and the CTC forward's table rows are produced HERE - every logit passes through the per-wave LDS tile in fp32 on
+// its way out, so the ~52 an utterance's extended label sequence needs are picked up there instead of being gathered from the 542 MB
+// in a launch of its own: per chunk a lane reads the tile entries of the labels that fall into the chunk (the utterance's labels
+// sorted by vocabulary index at kernel entry, one running pointer per lane) into a [128 frames][64] LDS table, and once the row's
+// log-sum-exp is known the workgroup writes its 128 table rows, 512 contiguous bytes each.  Same table bits as ctc.hip's gather.
+template <bool CTC>
 __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * VWBUF + 4 * VTILE];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * VWBUF + 4 * VTILE + (CTC ? VGLAB + 2 * 64 * 4 + 16 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* const tile = smem + 2 * VWBUF + wave * VTILE;
@@ -44,6 +58,39 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
     const int m = blockIdx.x * VBM + wave * 32 + r;
     const int mc = m < a.M ? m : a.M - 1;
     const int V = a.V, NCH = (V + VC - 1) / VC;
+    // ---- CTC: the (at most two) utterances this block's frames belong to, their labels sorted by vocabulary index -------------
+    float* const glab = reinterpret_cast<float*>(smem + 2 * VWBUF + 4 * VTILE);                    // [128][GLC]
+    int* const skey = reinterpret_cast<int*>(smem + 2 * VWBUF + 4 * VTILE + VGLAB);               // [2][64]: vocab id << 8 | column
+    int* const snum = skey + 128;                                                                   // [2]: entries (U_b + 1)
+    int ub = 0, ptr = 0, nent = 0;
+    if constexpr (CTC) {
+        const int b0 = (blockIdx.x * VBM) / a.L;
+        if (tid < 128) {
+            const int u = tid >> 6, t = tid & 63, b = b0 + u;
+            // entry t < U_b: label t (the first U_b = #nonzero entries of the row, loss.py:40); entry U_b: the blank
+            int nl = 0, lab = 0;
+            if (b < a.B) {
+                const int64_t* tgr = a.targets + (int64_t)b * a.Umax;
+                const int mine = t < a.Umax ? (tgr[t] != 0 ? 1 : 0) : 0;
+                nl = __builtin_popcountll(__ballot(mine));
+                lab = t < nl ? (int)tgr[t] : a.blank;
+                lab = min(max(lab, 0), V - 1);
+            }
+            const int n = b < a.B ? nl + 1 : 0;
+            const int key = (lab << 8) | (t < nl ? t : (GLC - 1));
+            // rank sort inside the wave (keys are unique per live entry: the column is part of the key)
+            int rank = 0;
+            for (int o = 0; o < n; ++o) {
+                const int ko = __shfl(key, o, 64);
+                rank += (ko < key) ? 1 : 0;
+            }
+            if (t < n) skey[u * 64 + rank] = key;
+            if (t == 0) snum[u] = n;
+        }
+        __syncthreads();
+        ub = (mc / a.L) - b0;
+        nent = snum[ub];
+    }
 
     // weight rows past V read as zeros (the descriptor's range check); their logits are masked out of the statistics and never stored
     const u32x4 rsw = rsrc_words(a.w, (unsigned)((int64_t)V * VD * 2));
@@ -74,12 +121,14 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
 
     // the logits tile of a chunk in LDS: frame r's 64 values, 16-byte piece q (vocab 4q .. 4q + 3 of the chunk) in slot q ^ (r & 15);
     // written by the lane that owns frame r (pieces 2 (4t + 2s + h') ...), read back by 16 lanes per frame
-    const auto rsl = __builtin_amdgcn_make_buffer_rsrc(a.logits, 0, (int)((int64_t)a.M * a.ldl * 4), 0x00020000);
+    constexpr unsigned EB = CTC ? 2u : 4u;      // bytes per stored logit
+    const auto rsl = CTC ? __builtin_amdgcn_make_buffer_rsrc(a.logits16, 0, (int)((int64_t)a.M * a.ldl * 2), 0x00020000)
+                         : __builtin_amdgcn_make_buffer_rsrc(a.logits, 0, (int)((int64_t)a.M * a.ldl * 4), 0x00020000);
     unsigned soff[8];      // read-back pass ps: frame 4 ps + (lane >> 4), piece lane & 15
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         const int mt = blockIdx.x * VBM + wave * 32 + 4 * ps + (lane >> 4);
-        soff[ps] = mt < a.M ? (unsigned)((int64_t)mt * a.ldl * 4) + 16u * (lane & 15) : 0x80000000u;
+        soff[ps] = mt < a.M ? (unsigned)((int64_t)mt * a.ldl * EB) + 4u * EB * (lane & 15) : 0x80000000u;
     }
     const unsigned trow = (unsigned)((lane >> 4) * 256), tx0 = (unsigned)((lane & 15) ^ (lane >> 4));      // pass ps: slot tx0 ^ (4 ps & 15)
 
@@ -125,13 +174,38 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
             sm += __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[t][j], 1.4426950408889634f, nm2)) +
                   __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[t][j + 1], 1.4426950408889634f, nm2));
         }
+        if constexpr (CTC) {
+            if (k == 9) {
+                // the chunk's tile is complete (steps 0..7, this wave's own LDS writes): pick up the labels that live in it.  The two
+                // lane halves of a frame walk the same sorted list and take alternate entries.
+                const int hi = (chunk + 1) * VC;
+                const int* sk = skey + ub * 64;
+                while (ptr < nent) {
+                    const int key = sk[ptr];
+                    const int lab = key >> 8;
+                    if (lab >= hi) break;
+                    if ((ptr & 1) == h) {
+                        const int vloc = lab - chunk * VC, q = vloc >> 2;
+                        const float v = *reinterpret_cast<const float*>(tile + r * 256 + ((q ^ (r & 15)) << 4) + (vloc & 3) * 4);
+                        glab[(wave * 32 + r) * GLC + (key & 255)] = v;
+                    }
+                    ++ptr;
+                }
+            }
+        }
         if (k >= 16 && k < 24)
             outv[k - 16] = *reinterpret_cast<const u32x4*>(tile + (k - 16) * 1024 + trow + ((tx0 ^ (unsigned)((4 * (k - 16)) & 15)) << 4));
         if (k >= 24) {
             // columns at or past the row stride do not exist (the last chunk overhangs it): the range check drops them
             const unsigned col = (unsigned)chunk * VC + 4u * (lane & 15);
             const unsigned o = col < (unsigned)a.ldl ? soff[k - 24] : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(outv[k - 24], rsl, o, chunk * (VC * 4), 0);
+            if constexpr (CTC) {
+                const f32x4 f = __builtin_bit_cast(f32x4, outv[k - 24]);
+                const bf16x4 b4 = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b4), rsl, o, chunk * (VC * 2), 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(outv[k - 24], rsl, o, chunk * (VC * 4), 0);
+            }
         }
         (void)nmx;
     };
@@ -185,7 +259,25 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
     const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sm, 32, 64);
     const float mm = fmaxf(mx, mo);
     const float tot = sm * __expf(mx - mm) + so * __expf(mo - mm);
-    if (h == 0 && m < a.M) a.lse[m] = mm + logf(tot);
+    const float lse = mm + logf(tot);
+    if (h == 0 && m < a.M) a.lse[m] = lse;
+    if constexpr (CTC) {
+        // table rows of this wave's 32 frames: state pair (2 lane, 2 lane + 1) = (blank, label `lane`) per lane, 512 bytes per frame
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's own glab writes)
+        const int Sb = 2 * (nent - 1) + 1;                       // 2 U_b + 1 live states of the LANE's utterance (uniform per frame)
+        constexpr float L2E = 1.4426950408889634f;
+#pragma unroll 4
+        for (int f = 0; f < 32; ++f) {
+            const int mf = blockIdx.x * VBM + wave * 32 + f;
+            if (mf >= a.M) break;
+            const float lf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lse), f));
+            const int sbf = __builtin_amdgcn_readlane(Sb, f);
+            const float* g = glab + (wave * 32 + f) * GLC;
+            const float vb = g[GLC - 1], vl = g[lane];
+            const f32x2 o = {(2 * lane < sbf) ? (vb - lf) * L2E : -INFINITY, (2 * lane + 1 < sbf) ? (vl - lf) * L2E : -INFINITY};
+            *reinterpret_cast<f32x2*>(a.lp_ext + (int64_t)mf * 128 + 2 * lane) = o;
+        }
+    }
 }
 
 }  // namespace
@@ -195,8 +287,27 @@ extern "C" int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16
     ASR_REQUIRE(x16 && w16 && logits && lse && M > 0 && V > 0 && ldl >= V && ldl % 4 == 0, -1, "asr_vocab_proj_lse: bad arguments");
     ASR_REQUIRE((int64_t)M * ldl * 4 < (1ll << 31), -1, "asr_vocab_proj_lse: M * ldl out of range");
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(w16, 16) && asr_aligned(logits, 16), -1, "asr_vocab_proj_lse: 16-byte aligned buffers required");
-    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, logits, lse, M, V, ldl};
-    hipLaunchKernelGGL(vocab_proj_lse_kernel, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
+    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, logits, lse, M, V, ldl, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL(vocab_proj_lse_kernel<false>, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_vocab_proj_lse");
+    return 0;
+}
+
+extern "C" int asr_vocab_proj_ctc(void* stream, const void* x16, const void* w16, void* logits16, int64_t ldl, float* lse, float* lp_ext,
+                                  const int64_t* targets, int B, int L, int V, int Umax, int blank, int d_model) {
+    ASR_REQUIRE(d_model == VD, ASR_ERR_UNSUPPORTED, "asr_vocab_proj_ctc: d_model = %d (built for 256)", d_model);
+    ASR_REQUIRE(x16 && w16 && logits16 && lse && lp_ext && targets && B > 0 && L > 0 && V > 0 && ldl >= V && ldl % 8 == 0, ASR_ERR_ARG,
+                "asr_vocab_proj_ctc: bad arguments");
+    ASR_REQUIRE(L >= VBM, ASR_ERR_UNSUPPORTED, "asr_vocab_proj_ctc: L = %d (a 128-frame block must not span more than two utterances)", L);
+    ASR_REQUIRE(Umax >= 1 && Umax + 1 <= 64, ASR_ERR_UNSUPPORTED, "asr_vocab_proj_ctc: Umax = %d (one state pair per lane: U + 1 <= 64)", Umax);
+    ASR_REQUIRE(blank >= 0 && blank < V && V < (1 << 22), ASR_ERR_ARG, "asr_vocab_proj_ctc: blank / V out of range");
+    const int64_t M64 = (int64_t)B * L;
+    ASR_REQUIRE(M64 * ldl * 2 < (1ll << 31) && M64 < (1ll << 24), ASR_ERR_UNSUPPORTED, "asr_vocab_proj_ctc: B * L * ldl out of range");
+    ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(w16, 16) && asr_aligned(logits16, 16) && asr_aligned(lp_ext, 16), ASR_ERR_ALIGN,
+                "asr_vocab_proj_ctc: 16-byte aligned buffers required");
+    const int M = (int)M64;
+    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, nullptr, lse, M, V, ldl, (bf16_t*)logits16, lp_ext, targets, B, L, Umax, blank};
+    hipLaunchKernelGGL(vocab_proj_lse_kernel<true>, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
+    ASR_LAUNCH_CHECK("asr_vocab_proj_ctc");
     return 0;
 }

@@ -1040,7 +1040,7 @@ class DecoderLayer(nn.Module):
         return self.pos_ffn._impl(x, dec_len)
 
 
-def _vocab_proj(mod, key, weight, x, want_lse=False):
+def _vocab_proj(mod, key, weight, x, want_lse=False, ctc=None):
     """logits = x . W^T (no bias).  On the tape the gradient arrives through `mod._grad_slots[key]["g"]`, filled by the
     trainer from the fused loss backward: a [.., V] view of a zero-padded buffer whose rows are 16-byte aligned.
     want_lse: -> (logits, lse or None): the rows' log-sum-exp from the projection's own launch when the shape takes it
@@ -1052,7 +1052,13 @@ def _vocab_proj(mod, key, weight, x, want_lse=False):
     xa = x.mma()
     M, V = xa.shape[0], weight.shape[0]
     Vp = (V + 7) // 8 * 8
-    if want_lse and _PRECISION == "bf16" and ops.vocab_proj_lse_ok(xa, w16):
+    if (ctc is not None and _PRECISION == "bf16" and ops.FUSED_VOCAB_LSE and xa.shape[0] >= 4096 and
+            ops.vocab_proj_ctc_ok(xa, w16, x.B, x.L, ctc[0].shape[1])):
+        # the training step's CTC branch: bf16 logits, row lse and the CTC table rows from ONE launch, then the recursion on the table
+        # (ctc = (targets, input lengths)) -> lse slot carries (loss, nll, state) instead of the row lse
+        logits, c_loss, c_nll, c_st = ops.vocab_proj_ctc(xa, w16, ctc[0], ctc[1], x.B, x.L)
+        lse = ("ctc", c_loss, c_nll, c_st)
+    elif want_lse and _PRECISION == "bf16" and ops.vocab_proj_lse_ok(xa, w16):
         logits, lse = ops.vocab_proj_lse(xa, w16)
     else:
         buf = torch.empty((M, Vp), device=xa.device, dtype=torch.float32)

@@ -601,6 +601,45 @@ def vocab_proj_lse(x16, w16):
     return buf[:, :V], lse
 
 
+def vocab_proj_ctc_ok(x16, w16, B, L, Umax):
+    """shapes asr_vocab_proj_ctc takes (the caller decides from which row count it is worth it)"""
+    V = w16.shape[0]
+    return (x16 is not None and x16.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and x16.dim() == 2 and x16.shape[1] == 256 and
+            w16.shape[1] == 256 and x16.is_contiguous() and w16.is_contiguous() and L >= 128 and 1 <= Umax and Umax + 1 <= 64 and
+            x16.shape[0] == B * L and B * L < (1 << 24) and B * L * _pad8(V) * 2 < 2 ** 31 and V < (1 << 22))
+
+
+def vocab_proj_ctc(x16, w16, targets, in_len, B, L, blank=None):
+    """The training step's CTC branch forward in two launches (asr_hip.h: asr_vocab_proj_ctc + asr_ctc_loss_fwd_table): the projection
+    writes bf16 logits, the rows' log-sum-exp and the CTC table rows; the alpha / beta recursion runs on the table.
+    -> (logits bf16 [B*L, V] view of rows padded to 8, loss [1], nll [B], state for ctc_loss_bwd)"""
+    _req_cuda(x16, w16, targets)
+    M, V = x16.shape[0], w16.shape[0]
+    Umax = targets.shape[1]
+    Vp = _pad8(V)
+    dev = x16.device
+    st = CtcState()
+    st.targets = targets.to(torch.int64).contiguous()
+    st.in_len = as_i32(in_len)
+    st.blank = V - 1 if blank is None else blank
+    buf = torch.empty((M, Vp), device=dev, dtype=torch.bfloat16)
+    st.logits, st.ldl, st.B, st.L, st.V, st.Umax = buf.view(B, L, Vp)[:, :, :V], Vp, B, L, V, Umax
+    S = lib().asr_ctc_workspace_stride(Umax)
+    st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
+    st.lp_ext = torch.empty((B, L, S), device=dev, dtype=torch.float32)
+    st.alpha = torch.empty((B, L + 2, S), device=dev, dtype=torch.float32)
+    st.nll = torch.empty(B, device=dev, dtype=torch.float32)
+    st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    with _timed("vocab_proj_lse[%dx%dx256]" % (M, V), 2.0 * M * V * 256):
+        check(lib().asr_vocab_proj_ctc(_stream(), _p(x16), _p(w16), _p(buf), Vp, _p(st.lse), _p(st.lp_ext), _p(st.targets), B, L, V, Umax,
+                                       st.blank, 256), "asr_vocab_proj_ctc")
+    with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):      # (priced on the unfused op's bytes, SURVEY 8(d))
+        check(lib().asr_ctc_loss_fwd_table(_stream(), _p(st.lp_ext), _p(st.in_len), _p(st.targets), B, L, Umax, _p(st.alpha), _p(st.nll),
+                                           _p(st.tgt_len), _p(loss)), "asr_ctc_loss_fwd_table")
+    return buf[:, :V], loss, st.nll, st
+
+
 def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None, lse=None):
     """logits f32 [B,L,V] (last dim contiguous, rows may be strided), in_len int32 [B], targets int64 [B,Umax].
     lse: the rows' log-sum-exp [B*L] when the producer of the logits has taken it already (vocab_proj_lse): the forward is then a
@@ -667,7 +706,7 @@ def ctc_loss_bwd(st, gout, bf16=False):
     """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,Vp] buffer (rows 16-byte aligned so the gradient is directly a
     GEMM operand).  Consumes st.alpha.  bf16=True (a gradient that only feeds the projection's backward GEMMs, which run on bf16
     MFMA anyway): half the bytes, Vp = roundup(V, 128) so that both GEMMs take their LDS-DMA kernels, pad written by the kernel."""
-    if bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0:
+    if bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0 or st.logits.dtype == torch.bfloat16:
         Vp = (st.V + 127) // 128 * 128
         gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.bfloat16)
     else:
@@ -680,9 +719,9 @@ def ctc_loss_bwd(st, gout, bf16=False):
     # second workspace: the recursion's second half stores raw rows, the gradient pass forms the occupancies (CTC_LAZY_OCC)
     alpha2 = torch.empty_like(st.alpha) if CTC_LAZY_OCC else None
     with _timed("ctc_loss_bwd[B%d L%d V%d U%d]" % (st.B, st.L, st.V, st.Umax), (4.0 + gbuf.element_size()) * st.B * st.L * st.V):
-        check(lib().asr_ctc_loss_bwd(_stream(), _p(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V, st.Umax,
-                                     st.blank, _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout), _p(grad),
-                                     dtype_code(gbuf), Vp, _p(alpha2)), "asr_ctc_loss_bwd")
+        check(lib().asr_ctc_loss_bwd_ex(_stream(), _p(st.logits), dtype_code(st.logits), st.ldl, _p(st.in_len), _p(st.targets), st.B, st.L, st.V,
+                                        st.Umax, st.blank, _p(st.lse), _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len), _p(gout),
+                                        _p(grad), dtype_code(gbuf), Vp, _p(alpha2)), "asr_ctc_loss_bwd")
     return grad
 
 

@@ -445,6 +445,17 @@ int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const flo
 int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16, float* logits, int64_t ldl, float* lse, int M, int V, int d_model);
 int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t ldl, const float* lse, const int32_t* in_len, const int64_t* targets,
                          int B, int L, int V, int Umax, int blank, float* lp_ext, float* alpha, float* nll, int32_t* tgt_len);
+/* The same projection for the training step's CTC branch (loss.py:41-43 behind transformer.py:148), with the logits never read back
+ * for the forward: logits16 bf16 [B*L, ldl] (ldl % 8 == 0, pad columns zero) - their only later reader is asr_ctc_loss_bwd_ex, whose
+ * output is a bf16 image anyway -, lse f32 [B*L], and lp_ext f32 [B*L, 128]: the CTC table rows asr_ctc_loss_fwd builds by a pass over
+ * the logits ((x[blank or label] - lse) log2 e per state of the utterance's extended label sequence, -inf beyond), taken here from
+ * the fp32 accumulators as each 64-column chunk passes through LDS - bit-identical to that pass on f32 logits.  targets int64
+ * [B, Umax] (0 = pad); L >= 128, Umax + 1 <= 64, d_model = 256.  asr_ctc_loss_fwd_table then runs the alpha / beta recursion on the
+ * finished table (workspaces and outputs of asr_ctc_loss_fwd; loss: optional f32 [1] batch mean). */
+int asr_vocab_proj_ctc(void* stream, const void* x16, const void* w16, void* logits16, int64_t ldl, float* lse, float* lp_ext,
+                       const int64_t* targets, int B, int L, int V, int Umax, int blank, int d_model);
+int asr_ctc_loss_fwd_table(void* stream, const float* lp_ext, const int32_t* in_len, const int64_t* targets, int B, int L, int Umax,
+                           float* alpha, float* nll, int32_t* tgt_len, float* loss);
 int asr_ctc_workspace_stride(int Umax);
 int asr_ctc_loss_fwd(void* stream, const float* logits, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                      int B, int L, int V, int Umax, int blank, float* lse, float* lp_ext, float* alpha, float* nll,
@@ -469,6 +480,11 @@ int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32
                      int B, int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
                      const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
                      float* alpha2);
+/* ... with the logits' element type given: ASR_BF16 = the image asr_vocab_proj_ctc wrote (ldl % 8 == 0, bf16 gradient only). */
+int asr_ctc_loss_bwd_ex(void* stream, const void* logits, int logits_dtype, int64_t ldl, const int32_t* in_len, const int64_t* targets,
+                        int B, int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
+                        const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
+                        float* alpha2);
 
 /* Label-smoothed cross entropy (loss.py:5-31).  logits f32 [N,V] (row stride ldl), targets int64 [N] (0 = pad).
  * row_loss f32 [N] (0 on pad rows), lse f32 [N];  asr_ce_mean: loss[0] = sum(row_loss) / n_word, loss[1] = n_word

@@ -1,0 +1,97 @@
+"""The training step's CTC branch forward as two launches (csrc/vocab.hip: asr_vocab_proj_ctc - ctc_fc's projection writing bf16
+logits, the rows' log-sum-exp AND the CTC table rows picked out of the fp32 accumulators on their way through LDS; csrc/ctc.hip:
+asr_ctc_loss_fwd_table - the alpha / beta recursion on the finished table; transformer.py:119,148 + loss.py:41-43):
+  * bit for bit against the forms it replaces on the same operands - the f32 projection with lse (asr_vocab_proj_lse) and the
+    streaming CTC forward on those f32 logits: lse, every live table row, nll, loss;
+  * against aten's F.log_softmax + F.ctc_loss on the CPU;
+  * the gradient pass on the bf16 logits image against the one on f32 logits;
+with blocks that straddle utterances, labels on chunk boundaries, repeated labels, empty and full-length targets, ragged lengths."""
+import numpy as np
+import pytest
+import torch
+
+from asr_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N = lambda t: t.detach().float().cpu().numpy()
+
+
+def make(B, L, U, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B * L, 256, generator=g).bfloat16()
+    w = (torch.randn(V, 256, generator=g) * 0.15).bfloat16()
+    tg = torch.randint(1, V - 1, (B, U), generator=g)
+    if U > 6:
+        tg[0, U - 2:] = 0                         # a shorter target
+        tg[1 % B, 1] = tg[1 % B, 0]               # a repeated label
+        tg[0, 0], tg[0, 1], tg[0, 2] = 63, 64, min(V - 2, 127)      # labels on the 64-column chunk boundaries
+        tg[(B - 1), 3] = V - 2                    # the last label before the blank
+        tg[(B - 1), 4] = 1
+    if B > 2:
+        tg[2, :] = 0                              # an empty target: the table row holds the blank alone
+    il = torch.randint(max(2 * U + 2, L // 2), L + 1, (B,), generator=g)
+    il[0] = L
+    return x, w, tg, il
+
+
+@pytest.mark.parametrize("B,L,U,V", [(3, 300, 51, 4234), (2, 128, 7, 130), (5, 257, 50, 1000), (4, 200, 63, 700), (2, 1000, 20, 4234)])
+def test_vocab_proj_ctc_is_the_projection_plus_the_table_pass(B, L, U, V):
+    x, w, tg, il = make(B, L, U, V, B * L + U)
+    xd, wd, tgd, ild = x.to(DEV), w.to(DEV), tg.to(DEV), il.to(DEV)
+    assert ops.vocab_proj_ctc_ok(xd, wd, B, L, U)
+    logits16, loss, nll, st = ops.vocab_proj_ctc(xd, wd, tgd, ild, B, L)
+    # the forms it replaces, on the same operands
+    logits32, lse32 = ops.vocab_proj_lse(xd, wd)
+    loss_s, nll_s, st_s = ops.ctc_loss_fwd(logits32.view(B, L, V), ild, tgd, n_chunks=1)       # streams the f32 logits itself
+    assert logits16.dtype == torch.bfloat16 and logits16.shape == (B * L, V) and logits16.stride(0) == (V + 7) // 8 * 8
+    assert torch.equal(logits16, logits32.bfloat16())                       # the same fp32 accumulators, rounded once
+    pad = torch.as_strided(logits16, (B * L, logits16.stride(0) - V), (logits16.stride(0), 1), logits16.storage_offset() + V)
+    assert pad.numel() == 0 or float(pad.float().abs().max()) == 0.0
+    assert torch.equal(st.lse.view(-1), lse32)
+    # table rows of live frames: identical bits (the streaming form leaves frames past in_len unwritten)
+    for b in range(B):
+        n = int(il[b])
+        assert torch.equal(st.lp_ext[b, :n], st_s.lp_ext[b, :n]), b
+    np.testing.assert_array_equal(N(st.tgt_len), (tg != 0).sum(1).numpy())
+    assert torch.equal(nll, nll_s) and torch.equal(loss, loss_s)
+    # aten on the CPU from the f32 logits
+    lp = torch.log_softmax(logits32.float().cpu().double(), -1).view(B, L, V).transpose(0, 1)
+    tl = (tg != 0).sum(1)
+    ref = torch.nn.functional.ctc_loss(lp, tg, il, tl, blank=V - 1, reduction="none")
+    np.testing.assert_allclose(N(nll), ref.numpy(), rtol=1e-5, atol=1e-4)
+    # the gradient pass: bf16 logits image in, bf16 gradient image out - against the same pass on the f32 logits
+    one = torch.ones(1, device=DEV)
+    g16 = ops.ctc_loss_bwd(st, one, bf16=True)
+    g32 = ops.ctc_loss_bwd(st_s, one, bf16=True)
+    assert g16.dtype == torch.bfloat16 and g16.shape == (B, L, V)
+    a, c = g16.float(), g32.float()
+    # softmax of a bf16-rounded logit: exp(x (1 +- 2^-9)) - relative 0.4 % x |x| on that element, plus the image's own bf16 rounding
+    assert float((a - c).norm() / c.norm()) < 1.5e-2
+    assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max())
+    for b in range(B):
+        assert float(a[b, int(il[b]):].abs().max() if int(il[b]) < L else 0.0) == 0.0
+
+
+def test_vocab_proj_ctc_north_star_shape_matches_aten():
+    """(B 32, L 1000, U 51 incl. <eos>, V 4234): the S1 step's CTC branch; every utterance's nll against aten fp32 on the CPU."""
+    B, L, U, V = 32, 1000, 51, 4234
+    x, w, tg, il = make(B, L, U, V, 7)
+    il[1] = L
+    logits16, loss, nll, st = ops.vocab_proj_ctc(x.to(DEV), w.to(DEV), tg.to(DEV), il.to(DEV), B, L)
+    ref_logits = x.float() @ w.float().t()
+    lp = torch.log_softmax(ref_logits, -1).view(B, L, V).transpose(0, 1)
+    tl = (tg != 0).sum(1)
+    ref = torch.nn.functional.ctc_loss(lp, tg, il, tl, blank=V - 1, reduction="none")
+    np.testing.assert_allclose(N(nll), ref.numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(float(loss), float((ref / tl.clamp(min=1)).mean()), rtol=1e-5)
+    np.testing.assert_allclose(N(logits16), ref_logits.numpy(), atol=2e-2, rtol=8e-3)      # bf16 image of fp32 sums of exact bf16 products
+
+
+def test_shapes_the_one_launch_table_does_not_take_fall_back():
+    x = torch.randn(4 * 64, 256).bfloat16().to(DEV)
+    w = torch.randn(70, 256).bfloat16().to(DEV)
+    assert not ops.vocab_proj_ctc_ok(x, w, 4, 64, 7)            # L < 128: a block could span three utterances
+    x = torch.randn(2 * 4096, 256).bfloat16().to(DEV)
+    assert not ops.vocab_proj_ctc_ok(x, w, 2, 4096, 64)         # U + 1 > 64
+    assert ops.vocab_proj_ctc_ok(x, w, 2, 4096, 63)
