@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
     // the two lane halves hold disjoint parts of the frame's vocabulary
     const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sm, 32, 64);
     const float mm = fmaxf(mx, mo);
-    const float tot = sm * __expf(mx - mm) + so * __expf(mo - mm);
+    // (one explicit fma: left to the compiler, a * b + c * d contracts around either product and the two instantiations of this kernel
+    // picked different ones - a last-bit difference in lse between them)
+    const float tot = h == 0 ? __builtin_fmaf(sm, __expf(mx - mm), so * __expf(mo - mm)) : __builtin_fmaf(so, __expf(mo - mm), sm * __expf(mx - mm));
     const float lse = mm + logf(tot);
     if (h == 0 && m < a.M) a.lse[m] = lse;
     if constexpr (CTC) {

@@ -43,18 +43,20 @@ def test_vocab_proj_ctc_is_the_projection_plus_the_table_pass(B, L, U, V):
     logits16, loss, nll, st = ops.vocab_proj_ctc(xd, wd, tgd, ild, B, L)
     # the forms it replaces, on the same operands
     logits32, lse32 = ops.vocab_proj_lse(xd, wd)
-    loss_s, nll_s, st_s = ops.ctc_loss_fwd(logits32.view(B, L, V), ild, tgd, n_chunks=1)       # streams the f32 logits itself
+    loss_s, nll_s, st_s = ops.ctc_loss_fwd(logits32.view(B, L, V), ild, tgd, lse=lse32)        # label gather from the f32 logits + recursion
+    loss_t, nll_t, st_t = ops.ctc_loss_fwd(logits32.view(B, L, V), ild, tgd, n_chunks=1)       # streams the f32 logits itself (its own lse)
     assert logits16.dtype == torch.bfloat16 and logits16.shape == (B * L, V) and logits16.stride(0) == (V + 7) // 8 * 8
     assert torch.equal(logits16, logits32.bfloat16())                       # the same fp32 accumulators, rounded once
     pad = torch.as_strided(logits16, (B * L, logits16.stride(0) - V), (logits16.stride(0), 1), logits16.storage_offset() + V)
     assert pad.numel() == 0 or float(pad.float().abs().max()) == 0.0
     assert torch.equal(st.lse.view(-1), lse32)
-    # table rows of live frames: identical bits (the streaming form leaves frames past in_len unwritten)
+    # table rows of live frames: identical bits (the gather form leaves frames past in_len unwritten)
     for b in range(B):
         n = int(il[b])
         assert torch.equal(st.lp_ext[b, :n], st_s.lp_ext[b, :n]), b
     np.testing.assert_array_equal(N(st.tgt_len), (tg != 0).sum(1).numpy())
     assert torch.equal(nll, nll_s) and torch.equal(loss, loss_s)
+    np.testing.assert_allclose(N(nll), N(nll_t), rtol=2e-6)                  # (the streaming form sums the row's exponentials in another order)
     # aten on the CPU from the f32 logits
     lp = torch.log_softmax(logits32.float().cpu().double(), -1).view(B, L, V).transpose(0, 1)
     tl = (tg != 0).sum(1)

@@ -36,3 +36,21 @@ t_c2 = timeit(lambda: ops.ctc_loss_fwd(l3, il, tg, lse=lse))
 t_b2 = timeit(lambda: ops.ctc_loss_fwd(ops.vocab_proj_lse(x, w)[0].view(B, L, V), il, tg, lse=lse))
 print("projection + lse %.1f us (%.0f TF, %.2f TB/s written) | CTC forward from lse %.1f us (%.2f TB/s of the unfused 542 MB) | back to back %.1f us" % (
     t_v, 2.0 * M * V * 256 / t_v / 1e6, M * Vp * 4 / t_v / 1e6, t_c2, 4.0 * M * V / t_c2 / 1e6, t_b2))
+# round 5: bf16 logits + lse + the CTC table rows from the projection's own launch, recursion on the table; and both backward passes
+t_c3 = timeit(lambda: ops.vocab_proj_ctc(x, w, tg, il, B, L))
+one = torch.ones(1, device=dev)
+
+
+def fwd_bwd_new():
+    _, _, _, st = ops.vocab_proj_ctc(x, w, tg, il, B, L)
+    ops.ctc_loss_bwd(st, one, bf16=True)
+
+
+def fwd_bwd_old():
+    lg2, lse2 = ops.vocab_proj_lse(x, w)
+    _, _, st = ops.ctc_loss_fwd(lg2.view(B, L, V), il, tg, lse=lse2)
+    ops.ctc_loss_bwd(st, one, bf16=True)
+
+
+print("projection + lse + table (bf16 logits) + recursion %.1f us | with the gradient pass: %.1f us (round 4's form: %.1f us)" % (
+    t_c3, timeit(fwd_bwd_new), timeit(fwd_bwd_old)))
