@@ -1180,7 +1180,7 @@ extern "C" int asr_ctc_loss_mean_fwd(void* stream, const float* logits, int64_t 
 // exactly these values - half the write here, half the read in both of ctc_fc's backward GEMMs).  Rows are 16-byte aligned on
 // both sides (ldl % 4 == 0, ldg % 8 == 0, host-checked); columns V .. ldg-1 are written as zeros: ldg is chosen by the caller
 // so that the GEMM kernels can treat the rows as padded to their tile width.
-// LT = bf16_t: the logits are the bf16 image asr_vocab_proj_ctc wrote (ldl % 8 == 0; half the read).
+// LT = _Float16: the logits are the fp16 image asr_vocab_proj_ctc wrote (ldl % 8 == 0; half the read).
 template <typename LT>
 __global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const LT* __restrict__ logits, int64_t ldl, const int32_t* __restrict__ in_len,
                                                             const int64_t* __restrict__ targets, const int32_t* __restrict__ tgt_len,
@@ -1213,7 +1213,8 @@ __global__ __launch_bounds__(256) void ctc_grad_bf16_kernel(const LT* __restrict
         }
         __syncthreads();
         const float l = lse[row];
-        typedef typename std::conditional<std::is_same<LT, float>::value, f32x4, bf16x4>::type x4_t;
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+        typedef typename std::conditional<std::is_same<LT, float>::value, f32x4, f16x4>::type x4_t;
         const x4_t* x4 = reinterpret_cast<const x4_t*>(x);
         for (int i = tid; i < ng; i += 256) {
             const int c = i * 4;
@@ -1258,14 +1259,14 @@ extern "C" int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, 
                                grad_dtype, ldg, alpha2);
 }
 
-// logits_dtype = ASR_BF16: the bf16 logits image of asr_vocab_proj_ctc (bf16 gradient only; ldl % 8 == 0).
+// logits_dtype = ASR_F16: the fp16 logits image of asr_vocab_proj_ctc (bf16 gradient only; ldl % 8 == 0).
 extern "C" int asr_ctc_loss_bwd_ex(void* stream, const void* logits_v, int logits_dtype, int64_t ldl, const int32_t* in_len, const int64_t* targets, int B,
                                    int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
                                    const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
                                    float* alpha2) {
     const float* logits = static_cast<const float*>(logits_v);
-    ASR_REQUIRE(logits_dtype == ASR_F32 || (logits_dtype == ASR_BF16 && grad_dtype == ASR_BF16 && ldl % 8 == 0), ASR_ERR_ARG,
-                "ctc_bwd: bf16 logits need a bf16 gradient and ldl %% 8 == 0");
+    ASR_REQUIRE(logits_dtype == ASR_F32 || (logits_dtype == ASR_F16 && grad_dtype == ASR_BF16 && ldl % 8 == 0), ASR_ERR_ARG,
+                "ctc_bwd: fp16 logits need a bf16 gradient and ldl %% 8 == 0");
     ASR_REQUIRE(logits && in_len && targets && lse && lp_ext && alpha && nll && tgt_len && gout && grad, ASR_ERR_ARG,
                 "ctc_bwd: null pointer");
     ASR_REQUIRE(!alpha2 || asr_aligned(alpha2, 16), ASR_ERR_ALIGN, "ctc_bwd: alpha2 must be 16-byte aligned");
@@ -1287,8 +1288,8 @@ extern "C" int asr_ctc_loss_bwd_ex(void* stream, const void* logits_v, int logit
     int rb = (2048 + B - 1) / B;
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
-    if (grad_dtype == ASR_BF16 && logits_dtype == ASR_BF16)
-        hipLaunchKernelGGL(ctc_grad_bf16_kernel<bf16_t>, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, static_cast<const bf16_t*>(logits_v),
+    if (grad_dtype == ASR_BF16 && logits_dtype == ASR_F16)
+        hipLaunchKernelGGL(ctc_grad_bf16_kernel<_Float16>, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, static_cast<const _Float16*>(logits_v),
                            ldl, in_len, targets, tgt_len, B, L, V, Umax, blank, lse, alpha, gout, reinterpret_cast<bf16_t*>(grad), ldg, alpha2, lp_ext, nll);
     else if (grad_dtype == ASR_BF16)
         hipLaunchKernelGGL(ctc_grad_bf16_kernel<float>, dim3(rb, B), dim3(256), (size_t)(V + 4) * sizeof(float), s, logits, ldl, in_len, targets,

@@ -33,8 +33,8 @@ struct VocabArgs {
     float* lse;
     int M, V;
     int64_t ldl;
-    // CTC = true: bf16 logits + the CTC table rows
-    bf16_t* logits16;    // [M, ldl] bf16 (ldl % 8 == 0)
+    // CTC = true: fp16 logits + the CTC table rows
+    _Float16* logits16;  // [M, ldl] IEEE half (ldl % 8 == 0)
     float* lp_ext;       // [M, 128]: (x[label] - lse) log2 e of the extended label sequence, -inf beyond 2 U_b + 1 (ctc.hip's table)
     const int64_t* targets;      // [B, Umax]
     int B, L, Umax, blank;
@@ -42,8 +42,8 @@ struct VocabArgs {
 constexpr int GLC = 64;              // CTC: gathered logits per frame in LDS - columns 0 .. Umax - 1 the labels, column 63 the blank
 constexpr int VGLAB = VBM * GLC * 4; // 32 KiB
 
-// CTC = true (asr_vocab_proj_ctc): the logits leave as bf16 (the only later reader is the CTC gradient pass, whose output is a bf16
-// image anyway) and the CTC forward's table rows are produced HERE - every logit passes through the per-wave LDS tile in fp32 on
+// CTC = true (asr_vocab_proj_ctc): the logits leave as IEEE fp16 (their only later reader is the CTC gradient pass, which forms
+// exp(logit - lse): 11 significand bits keep that within 0.2 % at |logit| <= 8; bf16's 8 bits would put 1.6 % on the largest probabilities) and the CTC forward's table rows are produced HERE - every logit passes through the per-wave LDS tile in fp32 on
 // its way out, so the ~52 an utterance's extended label sequence needs are picked up there instead of being gathered from the 542 MB
 // in a launch of its own: per chunk a lane reads the tile entries of the labels that fall into the chunk (the utterance's labels
 // sorted by vocabulary index at kernel entry, one running pointer per lane) into a [128 frames][64] LDS table, and once the row's
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
             const unsigned o = col < (unsigned)a.ldl ? soff[k - 24] : 0x80000000u;
             if constexpr (CTC) {
                 const f32x4 f = __builtin_bit_cast(f32x4, outv[k - 24]);
-                const bf16x4 b4 = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                const f16x4 b4 = {(_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3]};      // round to nearest even
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b4), rsl, o, chunk * (VC * 2), 0);
             } else {
                 __builtin_amdgcn_raw_buffer_store_b128(outv[k - 24], rsl, o, chunk * (VC * 4), 0);
@@ -308,7 +309,7 @@ extern "C" int asr_vocab_proj_ctc(void* stream, const void* x16, const void* w16
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(w16, 16) && asr_aligned(logits16, 16) && asr_aligned(lp_ext, 16), ASR_ERR_ALIGN,
                 "asr_vocab_proj_ctc: 16-byte aligned buffers required");
     const int M = (int)M64;
-    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, nullptr, lse, M, V, ldl, (bf16_t*)logits16, lp_ext, targets, B, L, Umax, blank};
+    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, nullptr, lse, M, V, ldl, (_Float16*)logits16, lp_ext, targets, B, L, Umax, blank};
     hipLaunchKernelGGL(vocab_proj_lse_kernel<true>, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_vocab_proj_ctc");
     return 0;

@@ -1054,7 +1054,7 @@ def _vocab_proj(mod, key, weight, x, want_lse=False, ctc=None):
     Vp = (V + 7) // 8 * 8
     if (ctc is not None and _PRECISION == "bf16" and ops.FUSED_VOCAB_LSE and xa.shape[0] >= 4096 and
             ops.vocab_proj_ctc_ok(xa, w16, x.B, x.L, ctc[0].shape[1])):
-        # the training step's CTC branch: bf16 logits, row lse and the CTC table rows from ONE launch, then the recursion on the table
+        # the training step's CTC branch: fp16 logits, row lse and the CTC table rows from ONE launch, then the recursion on the table
         # (ctc = (targets, input lengths)) -> lse slot carries (loss, nll, state) instead of the row lse
         logits, c_loss, c_nll, c_st = ops.vocab_proj_ctc(xa, w16, ctc[0], ctc[1], x.B, x.L)
         lse = ("ctc", c_loss, c_nll, c_st)

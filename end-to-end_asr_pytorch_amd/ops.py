@@ -13,7 +13,7 @@ import torch
 
 from ._lib import NO_DROP, Dropout, check, lib
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 GEMM_RELU = 1
 
 
@@ -22,6 +22,8 @@ def dtype_code(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:      # (the CTC branch's logits image only)
+        return F16
     raise TypeError("asr_amd: unsupported dtype %s" % t.dtype)
 
 
@@ -611,8 +613,8 @@ def vocab_proj_ctc_ok(x16, w16, B, L, Umax):
 
 def vocab_proj_ctc(x16, w16, targets, in_len, B, L, blank=None):
     """The training step's CTC branch forward in two launches (asr_hip.h: asr_vocab_proj_ctc + asr_ctc_loss_fwd_table): the projection
-    writes bf16 logits, the rows' log-sum-exp and the CTC table rows; the alpha / beta recursion runs on the table.
-    -> (logits bf16 [B*L, V] view of rows padded to 8, loss [1], nll [B], state for ctc_loss_bwd)"""
+    writes fp16 logits, the rows' log-sum-exp and the CTC table rows; the alpha / beta recursion runs on the table.
+    -> (logits fp16 [B*L, V] view of rows padded to 8, loss [1], nll [B], state for ctc_loss_bwd)"""
     _req_cuda(x16, w16, targets)
     M, V = x16.shape[0], w16.shape[0]
     Umax = targets.shape[1]
@@ -622,7 +624,7 @@ def vocab_proj_ctc(x16, w16, targets, in_len, B, L, blank=None):
     st.targets = targets.to(torch.int64).contiguous()
     st.in_len = as_i32(in_len)
     st.blank = V - 1 if blank is None else blank
-    buf = torch.empty((M, Vp), device=dev, dtype=torch.bfloat16)
+    buf = torch.empty((M, Vp), device=dev, dtype=torch.float16)
     st.logits, st.ldl, st.B, st.L, st.V, st.Umax = buf.view(B, L, Vp)[:, :, :V], Vp, B, L, V, Umax
     S = lib().asr_ctc_workspace_stride(Umax)
     st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
@@ -706,7 +708,7 @@ def ctc_loss_bwd(st, gout, bf16=False):
     """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,Vp] buffer (rows 16-byte aligned so the gradient is directly a
     GEMM operand).  Consumes st.alpha.  bf16=True (a gradient that only feeds the projection's backward GEMMs, which run on bf16
     MFMA anyway): half the bytes, Vp = roundup(V, 128) so that both GEMMs take their LDS-DMA kernels, pad written by the kernel."""
-    if bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0 or st.logits.dtype == torch.bfloat16:
+    if bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0 or st.logits.dtype == torch.float16:
         Vp = (st.V + 127) // 128 * 128
         gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.bfloat16)
     else:

@@ -27,6 +27,7 @@ extern "C" {
 
 #define ASR_F32 0
 #define ASR_BF16 1
+#define ASR_F16 2      /* IEEE half: only the CTC branch's logits image (asr_vocab_proj_ctc -> asr_ctc_loss_bwd_ex) */
 
 #define ASR_ERR_ARG (-1)       /* null pointer / non-positive size */
 #define ASR_ERR_ALIGN (-2)     /* pointer or leading dimension not aligned as documented */
@@ -446,8 +447,9 @@ int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16, float* lo
 int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t ldl, const float* lse, const int32_t* in_len, const int64_t* targets,
                          int B, int L, int V, int Umax, int blank, float* lp_ext, float* alpha, float* nll, int32_t* tgt_len);
 /* The same projection for the training step's CTC branch (loss.py:41-43 behind transformer.py:148), with the logits never read back
- * for the forward: logits16 bf16 [B*L, ldl] (ldl % 8 == 0, pad columns zero) - their only later reader is asr_ctc_loss_bwd_ex, whose
- * output is a bf16 image anyway -, lse f32 [B*L], and lp_ext f32 [B*L, 128]: the CTC table rows asr_ctc_loss_fwd builds by a pass over
+ * for the forward: logits16 IEEE fp16 [B*L, ldl] (ldl % 8 == 0, pad columns zero) - their only later reader is asr_ctc_loss_bwd_ex, which
+ * takes softmax = exp(logit - lse) from them: fp16's 11-bit significand puts <= 0.2 % on a probability at |logit| <= 8 where bf16's 8
+ * bits put 1.6 %, more than the bf16 gradient image's own rounding -, lse f32 [B*L], and lp_ext f32 [B*L, 128]: the CTC table rows asr_ctc_loss_fwd builds by a pass over
  * the logits ((x[blank or label] - lse) log2 e per state of the utterance's extended label sequence, -inf beyond), taken here from
  * the fp32 accumulators as each 64-column chunk passes through LDS - bit-identical to that pass on f32 logits.  targets int64
  * [B, Umax] (0 = pad); L >= 128, Umax + 1 <= 64, d_model = 256.  asr_ctc_loss_fwd_table then runs the alpha / beta recursion on the
@@ -480,7 +482,7 @@ int asr_ctc_loss_bwd(void* stream, const float* logits, int64_t ldl, const int32
                      int B, int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
                      const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,
                      float* alpha2);
-/* ... with the logits' element type given: ASR_BF16 = the image asr_vocab_proj_ctc wrote (ldl % 8 == 0, bf16 gradient only). */
+/* ... with the logits' element type given: ASR_F16 = the image asr_vocab_proj_ctc wrote (ldl % 8 == 0, bf16 gradient only). */
 int asr_ctc_loss_bwd_ex(void* stream, const void* logits, int logits_dtype, int64_t ldl, const int32_t* in_len, const int64_t* targets,
                         int B, int L, int V, int Umax, int blank, const float* lse, const float* lp_ext, float* alpha,
                         const float* nll, const int32_t* tgt_len, const float* gout, void* grad, int grad_dtype, int64_t ldg,

@@ -1,10 +1,10 @@
-"""The training step's CTC branch forward as two launches (csrc/vocab.hip: asr_vocab_proj_ctc - ctc_fc's projection writing bf16
+"""The training step's CTC branch forward as two launches (csrc/vocab.hip: asr_vocab_proj_ctc - ctc_fc's projection writing fp16
 logits, the rows' log-sum-exp AND the CTC table rows picked out of the fp32 accumulators on their way through LDS; csrc/ctc.hip:
 asr_ctc_loss_fwd_table - the alpha / beta recursion on the finished table; transformer.py:119,148 + loss.py:41-43):
   * bit for bit against the forms it replaces on the same operands - the f32 projection with lse (asr_vocab_proj_lse) and the
     streaming CTC forward on those f32 logits: lse, every live table row, nll, loss;
   * against aten's F.log_softmax + F.ctc_loss on the CPU;
-  * the gradient pass on the bf16 logits image against the one on f32 logits;
+  * the gradient pass on the fp16 logits image against the one on f32 logits;
 with blocks that straddle utterances, labels on chunk boundaries, repeated labels, empty and full-length targets, ragged lengths."""
 import numpy as np
 import pytest
@@ -45,8 +45,8 @@ def test_vocab_proj_ctc_is_the_projection_plus_the_table_pass(B, L, U, V):
     logits32, lse32 = ops.vocab_proj_lse(xd, wd)
     loss_s, nll_s, st_s = ops.ctc_loss_fwd(logits32.view(B, L, V), ild, tgd, lse=lse32)        # label gather from the f32 logits + recursion
     loss_t, nll_t, st_t = ops.ctc_loss_fwd(logits32.view(B, L, V), ild, tgd, n_chunks=1)       # streams the f32 logits itself (its own lse)
-    assert logits16.dtype == torch.bfloat16 and logits16.shape == (B * L, V) and logits16.stride(0) == (V + 7) // 8 * 8
-    assert torch.equal(logits16, logits32.bfloat16())                       # the same fp32 accumulators, rounded once
+    assert logits16.dtype == torch.float16 and logits16.shape == (B * L, V) and logits16.stride(0) == (V + 7) // 8 * 8
+    assert torch.equal(logits16, logits32.half())                           # the same fp32 accumulators, rounded once (to nearest even)
     pad = torch.as_strided(logits16, (B * L, logits16.stride(0) - V), (logits16.stride(0), 1), logits16.storage_offset() + V)
     assert pad.numel() == 0 or float(pad.float().abs().max()) == 0.0
     assert torch.equal(st.lse.view(-1), lse32)
@@ -62,15 +62,16 @@ def test_vocab_proj_ctc_is_the_projection_plus_the_table_pass(B, L, U, V):
     tl = (tg != 0).sum(1)
     ref = torch.nn.functional.ctc_loss(lp, tg, il, tl, blank=V - 1, reduction="none")
     np.testing.assert_allclose(N(nll), ref.numpy(), rtol=1e-5, atol=1e-4)
-    # the gradient pass: bf16 logits image in, bf16 gradient image out - against the same pass on the f32 logits
+    # the gradient pass: fp16 logits image in, bf16 gradient image out - against the same pass on the f32 logits
     one = torch.ones(1, device=DEV)
     g16 = ops.ctc_loss_bwd(st, one, bf16=True)
     g32 = ops.ctc_loss_bwd(st_s, one, bf16=True)
     assert g16.dtype == torch.bfloat16 and g16.shape == (B, L, V)
     a, c = g16.float(), g32.float()
-    # softmax of a bf16-rounded logit: exp(x (1 +- 2^-9)) - relative 0.4 % x |x| on that element, plus the image's own bf16 rounding
-    assert float((a - c).norm() / c.norm()) < 1.5e-2
-    assert float((a - c).abs().max()) <= 2e-2 * float(c.abs().max())
+    # softmax of an fp16-rounded logit: exp(x +- ulp/2) = 0.2 % at |x| < 8 - under the bf16 image's own 0.4 % rounding: the two images
+    # differ by at most one bf16 ulp of the larger gradient entries (a bf16 logits image measured 2.4 % there: 1.6 % at |x| ~ 5)
+    assert float((a - c).norm() / c.norm()) < 4e-3
+    assert float((a - c).abs().max()) <= 6e-3 * float(c.abs().max())
     for b in range(B):
         assert float(a[b, int(il[b]):].abs().max() if int(il[b]) < L else 0.0) == 0.0
 
@@ -87,7 +88,7 @@ def test_vocab_proj_ctc_north_star_shape_matches_aten():
     ref = torch.nn.functional.ctc_loss(lp, tg, il, tl, blank=V - 1, reduction="none")
     np.testing.assert_allclose(N(nll), ref.numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(float(loss), float((ref / tl.clamp(min=1)).mean()), rtol=1e-5)
-    np.testing.assert_allclose(N(logits16), ref_logits.numpy(), atol=2e-2, rtol=8e-3)      # bf16 image of fp32 sums of exact bf16 products
+    np.testing.assert_allclose(N(logits16), ref_logits.numpy(), atol=2e-3, rtol=1e-3)      # fp16 image of fp32 sums of exact bf16 products
 
 
 def test_shapes_the_one_launch_table_does_not_take_fall_back():

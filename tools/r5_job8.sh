@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/r5job8
+mkdir -p $OUT
+export TMPDIR=/tmp
+T="timeout -k 5"
+$T 1200 python3 -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; echo "pytest rc $?" >> $OUT/pytest.log
+grep -E "passed|failed|FAILED|rc |^E  " $OUT/pytest.log | tail -15
+$T 200 python3 tools/bench_vocab.py 2>&1 | grep -v amdgpu
+for i in 1 2; do $T 300 python3 bench.py --brief --steps 40 --warmup 5 2>>$OUT/bench.err | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('S1', d['ms_per_step'], d['losses_last_step'], d['config']['launch_calibration_ms'])"; done
