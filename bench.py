@@ -360,7 +360,7 @@ def pmc_traffic(fam_kernel, prof_dir):
     return int(tot / n) if n else None
 
 
-FAMILY_KERNEL = {"vocab_proj_lse": "vocab_proj_lse_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_v2_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
+FAMILY_KERNEL = {"vocab_proj_ctc": "vocab_proj_ctc_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_v2_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
                  "attention_fwd": "attn_fwd_bf16_v4a_kernel", "attention_bwd_dq": "attn_bwd_dq_v4_kernel", "attention_bwd_dkv": "attn_bwd_dkv_v4_kernel",
                  "add_layernorm": "add_layernorm_fwd_kernel", "add_layernorm_bwd": "add_layernorm_bwd_kernel",
                  "ctc_loss_fwd": "ctc_fused_fwd_kernel", "ctc_loss_bwd": "ctc_grad_bf16_kernel", "proj_heads": "proj_heads_rows_kernel"}
@@ -369,7 +369,7 @@ FAMILY_KERNEL = {"vocab_proj_lse": "vocab_proj_lse_kernel", "ffn_fwd": "ffn_fwd_
 FAMILY_CSV_KERNELS = {"gemm_tn": ["gemm_tn_v2_kernel", "gemm_tn_v2_group_kernel", "tn_reduce_kernel", "tn_reduce_group_kernel", "gemm_tn_kernel"],
                       "ffn_fwd": ["ffn_fwd_kernel"], "ffn_bwd": ["ffn_bwd_kernel"], "attention_fwd": ["attn_fwd_bf16_v4a_kernel", "attn_fwd_bf16_v2_kernel"],
                       "attention_bwd_dq": ["attn_bwd_dq_v4_kernel", "attn_bwd_dq_kernel"], "attention_bwd_dkv": ["attn_bwd_dkv_v4_kernel", "attn_bwd_dkv_kernel"],
-                      "vocab_proj_lse": ["vocab_proj_lse_kernel"], "ctc_loss_fwd": ["ctc_fused_fwd_kernel", "ctc_gather_lse_kernel", "ctc_mitm_kernel"],
+                      "vocab_proj_ctc": ["vocab_proj_ctc_kernel"], "ctc_loss_fwd": ["ctc_fused_fwd_kernel", "ctc_mitm_kernel"],
                       "ctc_loss_bwd": ["ctc_grad_bf16_kernel", "ctc_grad_kernel", "ctc_mitm_kernel"]}
 
 
@@ -567,7 +567,7 @@ def main():
         from asr_amd import modules as _modules
         if args.per_op == "both":
             trainer.wgrad_stream = False
-            trainer.side_inline = True              # the CTC branch's own kernels (vocab_proj_lse, gather + recursion, gradient) on the launch stream
+            trainer.side_inline = True              # the CTC branch's own kernels (vocab_proj_ctc, recursion, gradient) on the launch stream
             _modules._MASK_PREFETCH = False
     if prof_in_step is not None and args.per_op == "in_step":
         prof = prof_in_step
@@ -657,7 +657,7 @@ def main():
             del da, xb_, out_
         ctc_k = [k for k in kernels if k["name"].startswith("ctc_loss_fwd")]
         ctc_b = [k for k in kernels if k["name"].startswith("ctc_loss_bwd")]
-        vp_k = [k for k in kernels if k["name"].startswith("vocab_proj_lse")]
+        vp_k = [k for k in kernels if k["name"].startswith("vocab_proj_ctc")]
         what, mname = what_name(args, train), model_name()
         Lc = CFG["T"] // 4 if CFG["n_conv_layers"] else CFG["T"]
         ctc_iso = ctc_standalone_ms() if (ctc_k and args.mode != "decode") else None
@@ -668,22 +668,20 @@ def main():
             def pick(profd, prefix):
                 r = [(n, v) for n, v in (profd or {}).items() if n.startswith(prefix)]
                 return (sum(v["ms"] for _, v in r) / max(1, sum(v["calls"] for _, v in r))) if r else None
-            grad_bytes = (2.0 if trainer is not None else 4.0) * CFG["B"] * Lc * CFG["vocab_size"]
             branch = {}
             for tag, profd in (("alone", prof), ("in_step", prof_in_step)):
-                vp, fw, bw = pick(profd, "vocab_proj_lse"), pick(profd, "ctc_loss_fwd"), pick(profd, "ctc_loss_bwd")
+                vp, fw, bw = pick(profd, "vocab_proj_ctc"), pick(profd, "ctc_loss_fwd"), pick(profd, "ctc_loss_bwd")
                 if fw is None:
                     continue
-                branch[tag] = {"vocab_proj_lse_ms": None if vp is None else round(vp, 4), "ctc_fwd_ms": round(fw, 4),
+                branch[tag] = {"vocab_proj_ctc_ms": None if vp is None else round(vp, 4), "ctc_recursion_ms": round(fw, 4),
                                "ctc_bwd_ms": None if bw is None else round(bw, 4),
-                               # forward priced on the unfused op's bytes (the B x L x V x 4 logits read once), SURVEY 8(d)
-                               "fwd_frac_of_hbm_peak": round(logit_bytes / (fw * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                               "fwd_bwd_GBps": (round((2 * logit_bytes + grad_bytes) / ((fw + bw) * 1e-3) / 1e9, 1) if bw else None)}
+                               "branch_fwd_bwd_ms": (round((vp or 0.0) + fw + (bw or 0.0), 4))}
             ctc_block = {
-                "form_in_step": ("the projection writes the logits AND their row log-sum-exp (vocab_proj_lse_kernel); the CTC forward behind it "
-                                 "gathers ~52 logits per frame and runs the alpha / beta chains (ctc_gather_lse_kernel + ctc_mitm_kernel); the "
-                                 "backward streams the logits once and writes the bf16 gradient image (ctc_mitm_kernel + ctc_grad_bf16_kernel) - "
-                                 "all on the trainer's side stream beside the decoder" if vp_k else
+                "form_in_step": ("ctc_fc's projection writes fp16 logits, their row log-sum-exp AND the CTC table rows (the ~52 logits per frame the "
+                                 "utterance's extended label sequence needs, picked out of the fp32 accumulators as they pass through LDS: "
+                                 "vocab_proj_ctc_kernel); the CTC forward is then the alpha / beta recursion on that table and never touches the "
+                                 "logits (ctc_mitm_kernel); the backward streams the fp16 logits once and writes the bf16 gradient image "
+                                 "(ctc_mitm_kernel + ctc_grad_bf16_kernel) - all on the trainer's side stream beside the decoder" if vp_k else
                                  "one launch: persistent pass workgroups stream the logits, the recursion waves consume the table rows as they arrive"),
                 "branch_ms_per_call": branch,
                 "ms_per_step_fwd": ctc_k[0]["ms_per_step"], "ms_per_step_bwd": (ctc_b[0]["ms_per_step"] if ctc_b else None),

@@ -102,8 +102,6 @@ SIGNATURES = {
     "asr_conv_sub1_bwd_w_workspace_floats": [],
     "asr_conv_sub0_bwd_w": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "asr_ctc_workspace_stride": [_i],
-    "asr_vocab_proj_lse": [_vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i],
-    "asr_ctc_loss_fwd_lse": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "asr_ctc_loss_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "asr_ctc_loss_mean_fwd": [_vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "asr_ctc_counter_words": [_i, _i, _i],

@@ -1044,44 +1044,6 @@ extern "C" int64_t asr_ctc_counter_words(int B, int L, int n_chunks) {
     return (int64_t)B * 2 * nc + 16;      // arrival counters + the pass workgroups' queue heads (8) + the finished-utterance count
 }
 
-// ---- forward from a known row log-sum-exp (asr_vocab_proj_lse took it while the projection's accumulators held the logits) ----
-// The table row of a frame is then a gather: the blank's and the utterance's labels' logits, minus lse, in base 2.  One wave per
-// frame, lane i owns the state pair (blank, label i) exactly as ctc_row_finish lays it out; ~52 four-byte reads per frame instead
-// of the frame's 17 KB.
-__global__ __launch_bounds__(256) void ctc_gather_lse_kernel(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ lse,
-                                                             const int32_t* __restrict__ in_len, const int64_t* __restrict__ targets, int L,
-                                                             int V, int Umax, int blank, int64_t M, float* __restrict__ lp_ext) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int b = (int)(row / L), t = (int)(row - (int64_t)b * L);
-    if (t >= in_len[b]) return;
-    int lab = lane < Umax ? (int)targets[(int64_t)b * Umax + lane] : 0;
-    const int Ub = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lab != 0));       // loss.py:40 targets.ne(0).sum(1)
-    lab = min(max(lab, 0), V - 1);
-    const float* x = logits + row * ldl;
-    const float l = lse[row];
-    const float vb = (x[blank] - l) * LOG2E;
-    const float vl = lane < Ub ? (x[lab] - l) * LOG2E : -INFINITY;
-    *reinterpret_cast<f32x2*>(lp_ext + row * 128 + 2 * lane) = f32x2{lane <= Ub ? vb : -INFINITY, vl};
-}
-
-extern "C" int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t ldl, const float* lse, const int32_t* in_len,
-                                    const int64_t* targets, int B, int L, int V, int Umax, int blank, float* lp_ext, float* alpha, float* nll,
-                                    int32_t* tgt_len) {
-    ASR_REQUIRE(logits && lse && in_len && targets && lp_ext && alpha && nll && tgt_len, ASR_ERR_ARG, "ctc_fwd_lse: null pointer");
-    ASR_REQUIRE(B > 0 && L > 0 && V > 1 && Umax > 0 && blank >= 0 && blank < V && ldl >= V, ASR_ERR_ARG, "ctc_fwd_lse: bad sizes");
-    ASR_REQUIRE(ctc_np(Umax) == 1, ASR_ERR_UNSUPPORTED, "ctc_fwd_lse: Umax = %d (one state pair per lane: U + 1 <= 64)", Umax);
-    ASR_REQUIRE(asr_aligned(lp_ext, 16) && asr_aligned(alpha, 16), ASR_ERR_ALIGN, "ctc_fwd_lse: workspaces must be 16-byte aligned");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t M = (int64_t)B * L;
-    hipLaunchKernelGGL(ctc_gather_lse_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, logits, ldl, lse, in_len, targets, L, V, Umax, blank, M,
-                       lp_ext);
-    launch_recursion<0>(s, lp_ext, in_len, targets, tgt_len, B, L, Umax, alpha, nll, 0, L, 1);
-    ASR_LAUNCH_CHECK("ctc_loss_fwd_lse");
-    return 0;
-}
-
 // ---- forward from finished table rows (asr_vocab_proj_ctc wrote them while the projection's logits passed through LDS): the two
 // half-length alpha / beta chains and the batch mean, nothing else - no pass over logits at all
 extern "C" int asr_ctc_loss_fwd_table(void* stream, const float* lp_ext, const int32_t* in_len, const int64_t* targets, int B, int L, int Umax,

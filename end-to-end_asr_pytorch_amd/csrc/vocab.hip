@@ -1,9 +1,11 @@
-// Vocabulary projection of the CTC branch with the row log-sum-exp taken while the logits are still in the accumulators
-// (src/transformer/transformer.py:119,148 `ctc_fc`, a bias-free Linear d_model -> V, + the `F.log_softmax` of loss.py:41):
-//   logits[m, v] = x[m, :] . W[v, :]   (f32, written once, the CTC backward and the caller read them)
+// Vocabulary projection of the training step's CTC branch (src/transformer/transformer.py:119,148 `ctc_fc`, a bias-free Linear
+// d_model -> V, + the `F.log_softmax` and the label gather of loss.py:41-43) - everything the CTC forward needs from the logits, taken
+// while they are still fp32 accumulators on their way out:
+//   logits[m, v] = x[m, :] . W[v, :]                  stored once, as IEEE fp16 (the CTC gradient pass reads them)
 //   lse[m]       = log sum_v exp(logits[m, v])
-// The CTC forward then never streams the 542 MB of logits (B 32 x L 1000 x V 4234) a second time: its table rows are a 103-entry
-// gather per frame (asr_ctc_loss_fwd_lse), the rest is the alpha / beta recursion.
+//   lp_ext[m, s] = (logits[m, label_s] - lse[m]) log2 e   for the 2 U + 1 states of the frame's utterance (ctc.hip's table rows)
+// The CTC forward then never touches the 542 MB of logits (B 32 x L 1000 x V 4234) at all: it is the alpha / beta recursion on the table
+// (asr_ctc_loss_fwd_table).
 //
 // Same decomposition as the fused feed-forward's first product (ffn.hip): a workgroup owns 128 frames, each wave 32 of them as the
 // MFMA's B operand held in registers (x^T, K = d_model = 256); the weight streams through LDS in chunks of 64 vocabulary rows
@@ -29,28 +31,25 @@ __device__ __forceinline__ int vswap23(int r) { return (r & ~12) | ((r & 4) << 1
 struct VocabArgs {
     const bf16_t* x16;
     const bf16_t* w;
-    float* logits;       // f32 logits [M, ldl]             (CTC = false)
     float* lse;
     int M, V;
     int64_t ldl;
-    // CTC = true: fp16 logits + the CTC table rows
     _Float16* logits16;  // [M, ldl] IEEE half (ldl % 8 == 0)
     float* lp_ext;       // [M, 128]: (x[label] - lse) log2 e of the extended label sequence, -inf beyond 2 U_b + 1 (ctc.hip's table)
     const int64_t* targets;      // [B, Umax]
     int B, L, Umax, blank;
 };
-constexpr int GLC = 64;              // CTC: gathered logits per frame in LDS - columns 0 .. Umax - 1 the labels, column 63 the blank
+constexpr int GLC = 64;              // gathered logits per frame in LDS - columns 0 .. Umax - 1 the labels, column 63 the blank
 constexpr int VGLAB = VBM * GLC * 4; // 32 KiB
 
-// CTC = true (asr_vocab_proj_ctc): the logits leave as IEEE fp16 (their only later reader is the CTC gradient pass, which forms
+// The logits leave as IEEE fp16 (their only later reader is the CTC gradient pass, which forms
 // exp(logit - lse): 11 significand bits keep that within 0.2 % at |logit| <= 8; bf16's 8 bits would put 1.6 % on the largest probabilities) and the CTC forward's table rows are produced HERE - every logit passes through the per-wave LDS tile in fp32 on
 // its way out, so the ~52 an utterance's extended label sequence needs are picked up there instead of being gathered from the 542 MB
 // in a launch of its own: per chunk a lane reads the tile entries of the labels that fall into the chunk (the utterance's labels
 // sorted by vocabulary index at kernel entry, one running pointer per lane) into a [128 frames][64] LDS table, and once the row's
 // log-sum-exp is known the workgroup writes its 128 table rows, 512 contiguous bytes each.  Same table bits as ctc.hip's gather.
-template <bool CTC>
-__global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * VWBUF + 4 * VTILE + (CTC ? VGLAB + 2 * 64 * 4 + 16 : 0)];
+__global__ __launch_bounds__(256, 1) void vocab_proj_ctc_kernel(const VocabArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * VWBUF + 4 * VTILE + VGLAB + 2 * 64 * 4 + 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* const tile = smem + 2 * VWBUF + wave * VTILE;
@@ -58,12 +57,12 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
     const int m = blockIdx.x * VBM + wave * 32 + r;
     const int mc = m < a.M ? m : a.M - 1;
     const int V = a.V, NCH = (V + VC - 1) / VC;
-    // ---- CTC: the (at most two) utterances this block's frames belong to, their labels sorted by vocabulary index -------------
+    // ---- the (at most two) utterances this block's frames belong to, their labels sorted by vocabulary index -------------
     float* const glab = reinterpret_cast<float*>(smem + 2 * VWBUF + 4 * VTILE);                    // [128][GLC]
     int* const skey = reinterpret_cast<int*>(smem + 2 * VWBUF + 4 * VTILE + VGLAB);               // [2][64]: vocab id << 8 | column
     int* const snum = skey + 128;                                                                   // [2]: entries (U_b + 1)
     int ub = 0, ptr = 0, nent = 0;
-    if constexpr (CTC) {
+    {
         const int b0 = (blockIdx.x * VBM) / a.L;
         if (tid < 128) {
             const int u = tid >> 6, t = tid & 63, b = b0 + u;
@@ -121,9 +120,8 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
 
     // the logits tile of a chunk in LDS: frame r's 64 values, 16-byte piece q (vocab 4q .. 4q + 3 of the chunk) in slot q ^ (r & 15);
     // written by the lane that owns frame r (pieces 2 (4t + 2s + h') ...), read back by 16 lanes per frame
-    constexpr unsigned EB = CTC ? 2u : 4u;      // bytes per stored logit
-    const auto rsl = CTC ? __builtin_amdgcn_make_buffer_rsrc(a.logits16, 0, (int)((int64_t)a.M * a.ldl * 2), 0x00020000)
-                         : __builtin_amdgcn_make_buffer_rsrc(a.logits, 0, (int)((int64_t)a.M * a.ldl * 4), 0x00020000);
+    constexpr unsigned EB = 2u;      // bytes per stored logit
+    const auto rsl = __builtin_amdgcn_make_buffer_rsrc(a.logits16, 0, (int)((int64_t)a.M * a.ldl * 2), 0x00020000);
     unsigned soff[8];      // read-back pass ps: frame 4 ps + (lane >> 4), piece lane & 15
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
             sm += __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[t][j], 1.4426950408889634f, nm2)) +
                   __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[t][j + 1], 1.4426950408889634f, nm2));
         }
-        if constexpr (CTC) {
+        {
             if (k == 9) {
                 // the chunk's tile is complete (steps 0..7, this wave's own LDS writes): pick up the labels that live in it.  The two
                 // lane halves of a frame walk the same sorted list and take alternate entries.
@@ -199,14 +197,10 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
             // columns at or past the row stride do not exist (the last chunk overhangs it): the range check drops them
             const unsigned col = (unsigned)chunk * VC + 4u * (lane & 15);
             const unsigned o = col < (unsigned)a.ldl ? soff[k - 24] : 0x80000000u;
-            if constexpr (CTC) {
-                const f32x4 f = __builtin_bit_cast(f32x4, outv[k - 24]);
-                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-                const f16x4 b4 = {(_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3]};      // round to nearest even
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b4), rsl, o, chunk * (VC * 2), 0);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128(outv[k - 24], rsl, o, chunk * (VC * 4), 0);
-            }
+            const f32x4 f = __builtin_bit_cast(f32x4, outv[k - 24]);
+            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+            const f16x4 b4 = {(_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3]};      // round to nearest even
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b4), rsl, o, chunk * (VC * 2), 0);
         }
         (void)nmx;
     };
@@ -259,12 +253,11 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
     // the two lane halves hold disjoint parts of the frame's vocabulary
     const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sm, 32, 64);
     const float mm = fmaxf(mx, mo);
-    // (one explicit fma: left to the compiler, a * b + c * d contracts around either product and the two instantiations of this kernel
-    // picked different ones - a last-bit difference in lse between them)
+    // (one explicit fma per lane half, the same expression in both: left to the compiler, a * b + c * d contracts around either product)
     const float tot = h == 0 ? __builtin_fmaf(sm, __expf(mx - mm), so * __expf(mo - mm)) : __builtin_fmaf(so, __expf(mo - mm), sm * __expf(mx - mm));
     const float lse = mm + logf(tot);
     if (h == 0 && m < a.M) a.lse[m] = lse;
-    if constexpr (CTC) {
+    {
         // table rows of this wave's 32 frames: state pair (2 lane, 2 lane + 1) = (blank, label `lane`) per lane, 512 bytes per frame
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's own glab writes)
         const int Sb = 2 * (nent - 1) + 1;                       // 2 U_b + 1 live states of the LANE's utterance (uniform per frame)
@@ -285,17 +278,6 @@ __global__ __launch_bounds__(256, 1) void vocab_proj_lse_kernel(const VocabArgs 
 
 }  // namespace
 
-extern "C" int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16, float* logits, int64_t ldl, float* lse, int M, int V, int d_model) {
-    ASR_REQUIRE(d_model == VD, -1, "asr_vocab_proj_lse: d_model = %d (built for 256)", d_model);
-    ASR_REQUIRE(x16 && w16 && logits && lse && M > 0 && V > 0 && ldl >= V && ldl % 4 == 0, -1, "asr_vocab_proj_lse: bad arguments");
-    ASR_REQUIRE((int64_t)M * ldl * 4 < (1ll << 31), -1, "asr_vocab_proj_lse: M * ldl out of range");
-    ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(w16, 16) && asr_aligned(logits, 16), -1, "asr_vocab_proj_lse: 16-byte aligned buffers required");
-    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, logits, lse, M, V, ldl, nullptr, nullptr, nullptr, 0, 0, 0, 0};
-    hipLaunchKernelGGL(vocab_proj_lse_kernel<false>, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
-    ASR_LAUNCH_CHECK("asr_vocab_proj_lse");
-    return 0;
-}
-
 extern "C" int asr_vocab_proj_ctc(void* stream, const void* x16, const void* w16, void* logits16, int64_t ldl, float* lse, float* lp_ext,
                                   const int64_t* targets, int B, int L, int V, int Umax, int blank, int d_model) {
     ASR_REQUIRE(d_model == VD, ASR_ERR_UNSUPPORTED, "asr_vocab_proj_ctc: d_model = %d (built for 256)", d_model);
@@ -309,8 +291,8 @@ extern "C" int asr_vocab_proj_ctc(void* stream, const void* x16, const void* w16
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(w16, 16) && asr_aligned(logits16, 16) && asr_aligned(lp_ext, 16), ASR_ERR_ALIGN,
                 "asr_vocab_proj_ctc: 16-byte aligned buffers required");
     const int M = (int)M64;
-    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, nullptr, lse, M, V, ldl, (_Float16*)logits16, lp_ext, targets, B, L, Umax, blank};
-    hipLaunchKernelGGL(vocab_proj_lse_kernel<true>, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
+    VocabArgs a{(const bf16_t*)x16, (const bf16_t*)w16, lse, M, V, ldl, (_Float16*)logits16, lp_ext, targets, B, L, Umax, blank};
+    hipLaunchKernelGGL(vocab_proj_ctc_kernel, dim3((M + VBM - 1) / VBM), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_vocab_proj_ctc");
     return 0;
 }

@@ -1040,26 +1040,23 @@ class DecoderLayer(nn.Module):
         return self.pos_ffn._impl(x, dec_len)
 
 
-def _vocab_proj(mod, key, weight, x, want_lse=False, ctc=None):
+def _vocab_proj(mod, key, weight, x, ctc=None):
     """logits = x . W^T (no bias).  On the tape the gradient arrives through `mod._grad_slots[key]["g"]`, filled by the
     trainer from the fused loss backward: a [.., V] view of a zero-padded buffer whose rows are 16-byte aligned.
-    want_lse: -> (logits, lse or None): the rows' log-sum-exp from the projection's own launch when the shape takes it
-    (ops.vocab_proj_lse: encoder-sized rows, d_model 256, bf16) - the CTC forward then does not stream the logits again."""
+    ctc = (targets, input lengths): the training step's CTC branch -> (logits, None or (loss, nll, state)): when the shape takes it
+    (ops.vocab_proj_ctc: encoder-sized rows, d_model 256, bf16 mode) the projection's own launch leaves fp16 logits, the rows'
+    log-sum-exp and the CTC table rows, and the alpha / beta recursion has already run on them."""
     w16 = mod._w(key, (weight,))
-    lse = None
+    done = None
     # rows padded to a multiple of 8 floats: every row 16-byte aligned -> the GEMM's full-cache-line vector epilogue applies to any
     # vocabulary size (V = 4234: 295 -> ~150 us for the [32000, V] CTC projection); the loss kernels take the row stride
     xa = x.mma()
     M, V = xa.shape[0], weight.shape[0]
     Vp = (V + 7) // 8 * 8
-    if (ctc is not None and _PRECISION == "bf16" and ops.FUSED_VOCAB_LSE and xa.shape[0] >= 4096 and
+    if (ctc is not None and _PRECISION == "bf16" and ops.FUSED_VOCAB_CTC and xa.shape[0] >= 4096 and
             ops.vocab_proj_ctc_ok(xa, w16, x.B, x.L, ctc[0].shape[1])):
-        # the training step's CTC branch: fp16 logits, row lse and the CTC table rows from ONE launch, then the recursion on the table
-        # (ctc = (targets, input lengths)) -> lse slot carries (loss, nll, state) instead of the row lse
         logits, c_loss, c_nll, c_st = ops.vocab_proj_ctc(xa, w16, ctc[0], ctc[1], x.B, x.L)
-        lse = ("ctc", c_loss, c_nll, c_st)
-    elif want_lse and _PRECISION == "bf16" and ops.vocab_proj_lse_ok(xa, w16):
-        logits, lse = ops.vocab_proj_lse(xa, w16)
+        done = (c_loss, c_nll, c_st)
     else:
         buf = torch.empty((M, Vp), device=xa.device, dtype=torch.float32)
         ops.gemm_nt_raw(xa, M, xa.shape[1], xa.shape[1], w16, None, out=buf, ldc=Vp)
@@ -1087,7 +1084,7 @@ def _vocab_proj(mod, key, weight, x, want_lse=False, ctc=None):
             slot["g"] = None
 
         _TAPE.push(bw, (weight,))
-    return (logits, lse) if want_lse else logits
+    return (logits, done) if ctc is not None else logits
 
 
 def _compact_targets(targets):

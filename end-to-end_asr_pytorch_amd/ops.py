@@ -581,26 +581,7 @@ def aux_stream(device, priority=0, slot=0):
     return _AUX[key]
 
 
-FUSED_VOCAB_LSE = True      # ctc_fc with the row log-sum-exp from its own launch (False: plain GEMM, the CTC forward streams the logits itself, +70 us)
-
-
-def vocab_proj_lse_ok(x16, w16):
-    return (FUSED_VOCAB_LSE and x16 is not None and x16.dtype == torch.bfloat16 and w16.dtype == torch.bfloat16 and x16.dim() == 2 and
-            x16.shape[1] == 256 and w16.shape[1] == 256 and x16.is_contiguous() and w16.is_contiguous() and x16.shape[0] >= 4096 and
-            x16.shape[0] * ((w16.shape[0] + 7) // 8 * 8) * 4 < 2 ** 31)
-
-
-def vocab_proj_lse(x16, w16):
-    """(logits f32 [M, V] view of rows padded to 8 floats, lse f32 [M]) = the CTC branch's projection with the row log-sum-exp from the
-    same launch (asr_hip.h: asr_vocab_proj_lse)."""
-    _req_cuda(x16, w16)
-    M, V = x16.shape[0], w16.shape[0]
-    Vp = (V + 7) // 8 * 8
-    buf = torch.empty((M, Vp), device=x16.device, dtype=torch.float32)
-    lse = torch.empty(M, device=x16.device, dtype=torch.float32)
-    with _timed("vocab_proj_lse[%dx%dx256]" % (M, V), 2.0 * M * V * 256):
-        check(lib().asr_vocab_proj_lse(_stream(), _p(x16), _p(w16), _p(buf), Vp, _p(lse), M, V, 256), "asr_vocab_proj_lse")
-    return buf[:, :V], lse
+FUSED_VOCAB_CTC = True      # the trainer's CTC branch: ctc_fc writing fp16 logits + lse + the CTC table rows in one launch (False: plain GEMM + the streaming CTC forward)
 
 
 def vocab_proj_ctc_ok(x16, w16, B, L, Umax):
@@ -633,7 +614,7 @@ def vocab_proj_ctc(x16, w16, targets, in_len, B, L, blank=None):
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
     loss = torch.empty(1, device=dev, dtype=torch.float32)
-    with _timed("vocab_proj_lse[%dx%dx256]" % (M, V), 2.0 * M * V * 256):
+    with _timed("vocab_proj_ctc[%dx%dx256]" % (M, V), 2.0 * M * V * 256):
         check(lib().asr_vocab_proj_ctc(_stream(), _p(x16), _p(w16), _p(buf), Vp, _p(st.lse), _p(st.lp_ext), _p(st.targets), B, L, V, Umax,
                                        st.blank, 256), "asr_vocab_proj_ctc")
     with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):      # (priced on the unfused op's bytes)
@@ -642,10 +623,9 @@ def vocab_proj_ctc(x16, w16, targets, in_len, B, L, blank=None):
     return buf[:, :V], loss, st.nll, st
 
 
-def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None, lse=None):
+def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None):
     """logits f32 [B,L,V] (last dim contiguous, rows may be strided), in_len int32 [B], targets int64 [B,Umax].
-    lse: the rows' log-sum-exp [B*L] when the producer of the logits has taken it already (vocab_proj_lse): the forward is then a
-    label gather + the recursion.  -> (loss scalar tensor [1], nll [B], state)"""
+    -> (loss scalar tensor [1], nll [B], state)"""
     _req_cuda(logits, in_len, targets)
     B, L, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(2) == 1 and logits.stride(0) == L * logits.stride(1)
@@ -657,19 +637,11 @@ def ctc_loss_fwd(logits, in_len, targets, blank=None, n_chunks=None, lse=None):
     st.targets = targets.to(torch.int64).contiguous()
     S = lib().asr_ctc_workspace_stride(Umax)   # opaque workspace row stride (asr_hip.h)
     dev = logits.device
-    st.lse = torch.empty((B, L), device=dev, dtype=torch.float32) if lse is None else lse.view(B, L)
+    st.lse = torch.empty((B, L), device=dev, dtype=torch.float32)
     st.lp_ext = torch.empty((B, L, S), device=dev, dtype=torch.float32)
     st.alpha = torch.empty((B, L + 2, S), device=dev, dtype=torch.float32)   # +2 rows: beta at the meeting point, arrival counters
     st.nll = torch.empty(B, device=dev, dtype=torch.float32)
     st.tgt_len = torch.empty(B, device=dev, dtype=torch.int32)
-    if lse is not None and Umax + 1 <= 64:
-        assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * L
-        with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):      # (priced on the unfused byte count)
-            check(lib().asr_ctc_loss_fwd_lse(_stream(), _p(logits), st.ldl, _p(st.lse), _p(st.in_len), _p(st.targets), B, L, V, Umax, st.blank,
-                                             _p(st.lp_ext), _p(st.alpha), _p(st.nll), _p(st.tgt_len)), "asr_ctc_loss_fwd_lse")
-        loss = torch.empty(1, device=dev, dtype=torch.float32)
-        check(lib().asr_ctc_mean(_stream(), _p(st.nll), _p(st.tgt_len), B, _p(loss)), "asr_ctc_mean")
-        return loss, st.nll, st
     nck = CTC_CHUNKS if n_chunks is None else n_chunks
     # arrival counters of the fused form from the step's zero arena when one is live (no memset node in front of the launch)
     counters = None

@@ -256,11 +256,11 @@ class Trainer:
         proxy = modules.Act(enc.f32, enc.b16, enc.B, enc.L)
         with torch.cuda.stream(aux):
             with modules.record() as side_tape:
-                logits, lse = modules._vocab_proj(model, "ctc", model.ctc_fc.weight, proxy, want_lse=True, ctc=(ctc_targets, lens))
-            if isinstance(lse, tuple):      # projection + table in one launch, recursion on the table (ops.vocab_proj_ctc)
-                _, ctc, nll, st = lse
+                logits, done = modules._vocab_proj(model, "ctc", model.ctc_fc.weight, proxy, ctc=(ctc_targets, lens))
+            if done is not None:      # projection + table rows in one launch, the recursion has run on the table (ops.vocab_proj_ctc)
+                ctc, nll, st = done
             else:
-                ctc, nll, st = ops.ctc_loss_fwd(logits.view(enc.B, enc.L, -1), ops.as_i32(lens, logits.device), ctc_targets, lse=lse)
+                ctc, nll, st = ops.ctc_loss_fwd(logits.view(enc.B, enc.L, -1), ops.as_i32(lens, logits.device), ctc_targets)
             model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, torch.ones(1, device=logits.device), bf16=(modules.get_precision() == "bf16"))
             side_tape.backward()
         self._side = {"ctc": ctc, "st": st}

@@ -438,16 +438,8 @@ int asr_conv_col2im_relu_f32(void* stream, const float* dcol, int ldc, const flo
  * (the last utterance to finish clears them), so ONE buffer per stream serves every call on that stream.
  * asr_ctc_loss_mean_fwd is the same call with the batch reduction of asr_ctc_mean folded in (loss.py:41-43 in one launch).
  */
-/* The CTC branch's vocabulary projection with the row log-sum-exp taken in the same launch (transformer.py:119,148 `ctc_fc`: Linear
- * d_model -> V without bias, d_model = 256; loss.py:41 `F.log_softmax`): logits f32 [M, V] (row stride ldl floats, a multiple of 4; pad
- * columns V .. ldl - 1 are written with zeros) = x16 [M, 256] . w16 [V, 256]^T and lse f32 [M] = log sum_v exp(logits[m, v]).
- * asr_ctc_loss_fwd_lse is asr_ctc_loss_fwd for logits whose row lse is known already: its table rows are a gather of the blank's and the
- * labels' logits per frame (the 17 KB frame is not read again), then the alpha / beta recursion; same workspaces, same outputs, U + 1 <= 64. */
-int asr_vocab_proj_lse(void* stream, const void* x16, const void* w16, float* logits, int64_t ldl, float* lse, int M, int V, int d_model);
-int asr_ctc_loss_fwd_lse(void* stream, const float* logits, int64_t ldl, const float* lse, const int32_t* in_len, const int64_t* targets,
-                         int B, int L, int V, int Umax, int blank, float* lp_ext, float* alpha, float* nll, int32_t* tgt_len);
-/* The same projection for the training step's CTC branch (loss.py:41-43 behind transformer.py:148), with the logits never read back
- * for the forward: logits16 IEEE fp16 [B*L, ldl] (ldl % 8 == 0, pad columns zero) - their only later reader is asr_ctc_loss_bwd_ex, which
+/* The CTC branch's vocabulary projection in the training step (transformer.py:119,148 `ctc_fc`: Linear d_model -> V without bias,
+ * d_model = 256; loss.py:41-43 behind it), with the logits never read back for the forward: logits = x16 [B*L, 256] . w16 [V, 256]^T, logits16 IEEE fp16 [B*L, ldl] (ldl % 8 == 0, pad columns zero) - their only later reader is asr_ctc_loss_bwd_ex, which
  * takes softmax = exp(logit - lse) from them: fp16's 11-bit significand puts <= 0.2 % on a probability at |logit| <= 8 where bf16's 8
  * bits put 1.6 %, more than the bf16 gradient image's own rounding -, lse f32 [B*L], and lp_ext f32 [B*L, 128]: the CTC table rows asr_ctc_loss_fwd builds by a pass over
  * the logits ((x[blank or label] - lse) log2 e per state of the utterance's extended label sequence, -inf beyond), taken here from

@@ -69,15 +69,16 @@ def test_ffn_fused_and_weight_gradients():
     _same(run)
 
 
-def test_vocab_projection_with_lse_and_ctc():
-    M, V = 8000, 4234
+def test_vocab_projection_with_lse_and_ctc_table():
+    B, L, V = 8, 1000, 4234
     g = torch.Generator().manual_seed(2)
-    x = torch.randn(M, 256, generator=g).bfloat16().to(DEV)
+    x = torch.randn(B * L, 256, generator=g).bfloat16().to(DEV)
     w = (torch.randn(V, 256, generator=g) * 0.05).bfloat16().to(DEV)
-    if not ops.vocab_proj_lse_ok(x, w):
-        pytest.skip("fused vocabulary projection not taken for this shape")
+    tg = torch.randint(1, V - 1, (B, 51), generator=g).to(DEV)
+    il = torch.full((B,), L, dtype=torch.int32, device=DEV)
+    assert ops.vocab_proj_ctc_ok(x, w, B, L, 51)
 
     def run():
-        logits, lse = ops.vocab_proj_lse(x, w)
-        return logits, lse
+        logits, loss, nll, st = ops.vocab_proj_ctc(x, w, tg, il, B, L)
+        return logits, st.lse, torch.nan_to_num(st.lp_ext, neginf=-1e30), nll      # (dead states are -inf by design)
     _same(run)
