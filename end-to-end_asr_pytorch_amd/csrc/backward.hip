@@ -348,7 +348,8 @@ constexpr int LNB_WAVES = 8;                  // waves per workgroup: 256 workgr
                                               // contended column atomics at the end (512 workgroups: ~8 us of a 31 us launch)
 constexpr int LNB_ROWS = LNB_WAVES * LNB_RPW;  // rows per workgroup
 
-// MAXJ = float4 column groups per lane: 1 for D <= 256 (the model dimension of every shipped config), 4 up to D = 1024.
+// MAXJ = float4 column groups per lane: 1 for D <= 256, 2 for D <= 512 (the reference's shipped width), 4 up to D = 1024 (that one
+// spills: 143 registers to scratch - D = 512 ran on it until round 5, 3x slower than its bytes allow).
 template <int MAXJ>
 __global__ __launch_bounds__(64 * LNB_WAVES) void add_layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -682,6 +683,9 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
+    else if (D <= 512)      // d_model = 512, the width every shipped recipe of the reference trains (egs/aishell/recipes/*.sh): no spills
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<2>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
     else
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, drop_y);
@@ -704,6 +708,9 @@ extern "C" int asr_add_layernorm_bwd_y(void* stream, const float* dy, const floa
     const asr_dropout_t none{0, 0, 0, nullptr};
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, y, rstd, rstd, gamma,
+                           row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, none, beta);
+    else if (D <= 512)
+        hipLaunchKernelGGL(add_layernorm_bwd_kernel<2>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, y, rstd, rstd, gamma,
                            row_len, ds, ds16, dgamma, dbeta, dbias, M, L, D, drop_x, none, beta);
     else
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<4>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, y, rstd, rstd, gamma,
