@@ -712,14 +712,7 @@ __global__ __launch_bounds__(256, 8) void ctc_fused_fwd_kernel(const float* __re
         // than the imbalance); the row by LDS-DMA into the idle ring with the next row's DMA in flight during the reduction (mean
         // workgroup 6 % faster, slowest 8 % slower: 151 against 141 us); the label gather issued behind the row's own loads (155 / 143).
         if (dbg & 32) return;      // (bit 5: timing experiment - the chains alone)
-        // items: chunk 0 is dealt ROW BY ROW (dbg bit 0 clear), every later chunk in groups of RPB rows.  The chains cannot take their first
-        // step before chunk 0 of their direction is complete, and every pass workgroup starts at once sharing the memory system
-        // equally: a workgroup's first item takes (its rows) x 2016 workgroups' worth of bandwidth - with 4-row items chunk 0 is
-        // complete ~30 us in, with 1-row items after a quarter of that, and nothing else about the walk changes (round 4 dealt the
-        // whole first ROUND row by row - every workgroup's first item, all chunks' locality gone: +17 us)
-        const int G = W / RPB, npass = gridDim.x - Bn;
-        const int G0 = (dbg & 1) ? G : W, RP0 = (dbg & 1) ? RPB : 1;
-        const int per0 = Bn * 2 * G0, total = per0 + (nchunks - 1) * Bn * 2 * G;
+        const int G = W / RPB, npass = gridDim.x - Bn, total = nchunks * Bn * 2 * G;
         const bool w0 = threadIdx.x < 64;
         // (dbg bit 1: the round-4 gather by a second global load of each label - A/B and the FETCH_SIZE attribution; bit 3: no gather, timing only)
         const bool stage = !(dbg & 2) && ctc_row_fits_regs(V) && (size_t)((V + 3) >> 2) * 16 + 32 <= sizeof(ring);
@@ -727,21 +720,17 @@ __global__ __launch_bounds__(256, 8) void ctc_fused_fwd_kernel(const float* __re
         int pending_count = 0;
         // (Round 5, measured and dropped: a head start for chunk 0 - the workgroups whose first item is not of chunk 0 sleeping 2..24 us so
         // that the chains' first chunk has the memory system to itself: 135 us without, 146 / 147 / 148 / 151 / 154 / 158 us with
-        // 2 / 4 / 6 / 12 / 16 / 24 us - the kernel simply ends that much later, the pass is what it waits for.)
+        // 2 / 4 / 6 / 12 / 16 / 24 us - the kernel simply ends that much later, the pass is what it waits for.  And chunk 0 alone dealt row by
+        // row, every later chunk in 4-row items as before: 151.6 against 146.9 us on the same box.)
         for (int gid = blockIdx.x - Bn; gid < total; gid += npass) {
-            int bid = gid, chunk = 0, Gc = G0, rp = RP0;
-            if (gid >= per0) {
-                bid -= per0;
-                chunk = 1 + bid / (Bn * 2 * G);
-                bid -= (chunk - 1) * (Bn * 2 * G);
-                Gc = G;
-                rp = RPB;
-            }
-            const int b = bid / (2 * Gc), gi = bid - b * 2 * Gc;
-            const int dirc = gi / Gc, g0 = (gi - dirc * Gc) * rp;
+            int bid = gid;
+            const int chunk = bid / (Bn * 2 * G);
+            bid -= chunk * (Bn * 2 * G);
+            const int b = bid / (2 * G), gi = bid - b * 2 * G;
+            const int dirc = gi / G, g0 = (gi - dirc * G) * RPB;
             const int Tb = min(in_len[b], L), mid = Tb >> 1;
             int count = 0;
-            for (int r = 0; r < rp; ++r) {               // frames only run out at the end of a direction
+            for (int r = 0; r < RPB; ++r) {              // frames only run out at the end of a direction
                 const int k = chunk * W + g0 + r;
                 const int t = dirc == 0 ? k : Tb - 1 - k;
                 count += (dirc == 0 ? (t <= mid && t < Tb) : (t > mid)) ? 1 : 0;
@@ -1093,8 +1082,7 @@ static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, con
     }
     // fused: ONE launch - pass workgroups publish table rows chunk by chunk (write-through stores + arrival counters in row L+1 of
     // the alpha workspace), recursion workgroups of the same grid consume them as they arrive
-    // ASR_AMD_CTC_DBG: timing / attribution builds of the launch (results invalid except bits 0, 1, 7): bit 0 chunk 0 in RPB-row items like
-    // every other chunk, bit 1 the labels gathered by a second global load
+    // ASR_AMD_CTC_DBG: timing / attribution builds of the launch (results invalid): bit 1 the labels gathered by a second global load
     // (round 4's form: FETCH_SIZE 705 MB against 562), bit 2 pass only, bit 3 no gather, bit 4 chains never wait, bit 5 chains only,
     // bit 7 workgroup end stamps (tools/ctc_timeline.py)
     constexpr int rpb = 4;          // table rows per pass workgroup and item (1 / 2 / 8: 151 / 147 / 154 us against 144)
@@ -1122,7 +1110,7 @@ static int ctc_loss_fwd_impl(void* stream, const float* logits, int64_t ldl, con
     // B recursion workgroups + persistent pass workgroups filling every remaining slot of the chip (7 or 8 per CU by the kernel's
     // LDS / register budget; more than fit would only queue)
     const int n_cu = ctc_fused_max_batch() / 2;      // (of the current device)
-    const int groups = B * 2 * ((dbg & 1) ? W / rpb : W) + (nc - 1) * B * 2 * (W / rpb);      // (the kernel's item count: chunk 0 row by row)
+    const int groups = nc * B * 2 * (W / rpb);
     int npass = n_cu * 8 - B;      // 8 per CU: the kernel's LDS (ring of 8 row pairs, 18.6 KB) and register budget (<= 64)
     if (npass > groups) npass = groups;
     if (npass < 1) npass = 1;
