@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU test suite + the default bench line (a correctness / regression check after a refactor)
 set -u
-OUT=gpurun_out/r5check
+OUT=gpurun_out/check
 mkdir -p $OUT
 export TMPDIR=/tmp
 T="timeout -k 5"
