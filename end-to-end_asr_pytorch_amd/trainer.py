@@ -476,7 +476,7 @@ class Trainer:
             # N > 1 steps are queued eagerly and all-reduced through torch.distributed
             return False
         m = self.model
-        return isinstance(m, (modules.CTC_Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"
+        return isinstance(m, (modules.Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"      # (every tape-recording family)
 
     def _sync_state(self, dev):
         """device step state <- host step counter (first use, or after eager steps / a checkpoint load moved it)"""
