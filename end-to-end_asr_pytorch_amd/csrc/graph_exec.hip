@@ -40,7 +40,7 @@ struct XNode {
 
 // Events between the executor's streams order work on ONE device: they need no system-scope fence.  A default HIP event performs one
 // when it is recorded (cache write-back and invalidation so that the host and other devices see the data) - measured ~6.5 us of
-// nothing between the recording kernel and the next kernel of its stream, 49 times per S1 step.  ASR_AMD_GRAPHX_SYSFENCE=1 restores it.
+// nothing between the recording kernel and the next kernel of its stream, 49 times per S1 step.  (`sysfence` below restores it.)
 unsigned graphx_event_flags() {
     constexpr bool sysfence = false;      // (true: HIP's default system-scope fence at every record, S1 replay +0.1-0.2 ms)
     // (hipEventReleaseToDevice instead: 12.06 against 11.99 ms; both flags together are rejected by the runtime)

@@ -432,7 +432,7 @@ extern "C" int asr_gemm_tn_ws_group(void* stream, int n, const asr_tn_problem_t*
     return asr_gemm_tn_ws_group_wgs(stream, n, pr, deterministic, 0);
 }
 
-// group_workgroups: the launch's workgroup budget, shared out by output tiles (0: ASR_AMD_TN_GROUP_WGS, default 128 = half the CUs for
+// group_workgroups: the launch's workgroup budget, shared out by output tiles (0: 128 = half the CUs for
 // a launch beside the main chain).  A problem never gets fewer workgroups than it has tiles: with budget <= total tiles every
 // problem runs UNSPLIT - one workgroup walks all M rows of its tile and writes dW itself, no slab, no reduce launch (the batched form
 // of a whole encoder layer's, or two layers', weight gradients: modules._wg).
@@ -458,7 +458,7 @@ extern "C" int asr_gemm_tn_ws_group_wgs(void* stream, int n, const asr_tn_proble
         TnArgs& a = g.p[i];
         int tiles;
         const int my_tiles = ((q.N + 127) / 128) * (q.K / 128);
-        // the grouped launch runs on the trainer's side stream beside the main chain: half the CUs (ASR_AMD_TN_GROUP_WGS; a slab
+        // the grouped launch runs on the trainer's side stream beside the main chain: half the CUs (a slab
         // workgroup takes a whole CU, see modules._WGRAD_SIDE_WGS)
         const int group_wgs = group_workgroups > 0 ? group_workgroups : 128;      // (96 / 160 / 192 / 256 / 64 on the side stream: S1 step +0.19 / -0.03 / -0.03 / +0.06 / +0.29 ms)
         int share = (int)((int64_t)group_wgs * my_tiles / total_tiles);

@@ -179,7 +179,7 @@ class Trainer:
         # collective nodes in the captured step even with one rank (a 1-rank RCCL communicator: the executor's all-reduce plumbing,
         # measurable on a 1-GPU box; tools/rccl_sanity.py, tests/test_gpu_graph.py)
         self.force_collective = bool(force_collective)
-        # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); ASR_AMD_OVERLAP_CTC=0 serialises it
+        # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); Trainer(overlap_ctc=False) serialises it
         self.overlap_ctc = True if overlap_ctc is None else bool(overlap_ctc)
         self.wgrad_stream = True     # weight-gradient GEMMs on a side stream (backward()); bench.py's kernel-alone pass sets it False
         self.lambda_qua = lambda_qua      # CIF models: loss = lambda_qua * qua + ctc + ce (solver.py:153, train.py:64)
