@@ -476,7 +476,8 @@ class Trainer:
             # N > 1 steps are queued eagerly and all-reduced through torch.distributed
             return False
         m = self.model
-        return isinstance(m, (modules.Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"      # (every tape-recording family)
+        # (the attention-only `Transformer` steps eagerly: its capture trips "operation not permitted when stream is capturing" - not chased)
+        return isinstance(m, (modules.CTC_Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"
 
     def _sync_state(self, dev):
         """device step state <- host step counter (first use, or after eager steps / a checkpoint load moved it)"""
