@@ -324,6 +324,12 @@ class Trainer:
                 pre = model.decoder._preprocess(targets, umax=max_target_len)
             model.decoder.__dict__["_pre_hint"] = (targets, pre, ev)
             model.__dict__["_ctc_hook"] = lambda enc, l: self._ctc_side_branch(enc, l, pre[1], ev)
+        # every other family with the reference's attention decoder (the attention-only Transformer; the joint models with the CTC branch
+        # inline): the loader's longest target goes to the decoder's target bookkeeping - no host read-back in the step, so it captures
+        dec_hint = (not side_ok and max_target_len is not None and targets.is_cuda and
+                    isinstance(getattr(model, "decoder", None), modules.Decoder) and not isinstance(model, modules.CIF_Model))
+        if dec_hint:
+            model.decoder.__dict__["_pre_hint"] = (targets, model.decoder._preprocess(targets, umax=max_target_len), None)
         cif_hint = isinstance(model, modules.CIF_Model) and max_target_len is not None
         if cif_hint:
             model.__dict__["_umax_hint"] = int(max_target_len)
@@ -334,6 +340,8 @@ class Trainer:
                 model.__dict__.pop("_umax_hint", None)
             if side_ok:
                 model.__dict__.pop("_ctc_hook", None)
+                model.decoder.__dict__.pop("_pre_hint", None)
+            if dec_hint:
                 model.decoder.__dict__.pop("_pre_hint", None)
 
     def _forward_loss(self, feats, lens, targets, noise):
@@ -476,8 +484,7 @@ class Trainer:
             # N > 1 steps are queued eagerly and all-reduced through torch.distributed
             return False
         m = self.model
-        # (the attention-only `Transformer` steps eagerly: its capture trips "operation not permitted when stream is capturing" - not chased)
-        return isinstance(m, (modules.CTC_Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"
+        return isinstance(m, (modules.Transformer, modules.CIF_Model)) and modules.get_precision() == "bf16"      # (every tape-recording family)
 
     def _sync_state(self, dev):
         """device step state <- host step counter (first use, or after eager steps / a checkpoint load moved it)"""

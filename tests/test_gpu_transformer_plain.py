@@ -137,3 +137,26 @@ def test_autograd_bridge_matches_the_trainer(golden_dir):
         got = dict(model.named_parameters())[name].grad.float().cpu().numpy()
         assert np.linalg.norm(got - ref) < 1.2e-1 * np.linalg.norm(ref), name      # (measured 0.6-7.6 %: tools/g17_bf16_err.py)
 
+
+
+def test_the_two_tuple_step_replays_from_a_graph(golden_dir):
+    """Trainer.step_graphed on the attention-only family (no CTC branch, so no side-branch fork / join in the captured step): the
+    replayed steps stay on the eager trajectory."""
+    z, sd, m_e = build(golden_dir, train=True)
+    _, _, m_g = build(golden_dir, train=True)
+    x, lens, tg = batch(z)
+    umax = int((tg != 0).sum(1).max())
+    asr_amd.set_precision("bf16")
+    te = asr_amd.Trainer(m_e, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    tg_ = asr_amd.Trainer(m_g, k=0.2, warmup_steps=50, label_smoothing=0.1)
+    le, lg = [], []
+    for i in range(8):
+        c, e = te.step(x, lens, tg, max_target_len=umax)
+        le.append(float(e))
+        c, e = tg_.step_graphed(x, lens, tg, max_target_len=umax)
+        lg.append(float(e))
+        assert float(c) == 0.0
+    assert tg_.graph_active(), tg_._graph_failed
+    np.testing.assert_allclose(np.array(lg), np.array(le), rtol=5e-3)
+    pe, pg = te.fp.flat.float().cpu().numpy(), tg_.fp.flat.float().cpu().numpy()
+    assert np.linalg.norm(pg - pe) / np.linalg.norm(pe) < 2e-3
