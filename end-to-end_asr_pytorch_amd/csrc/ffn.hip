@@ -177,12 +177,19 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     f32x4 res[32];      // the epilogue's residual rows, requested inside the LAST body
     const int m0 = blockIdx.x * FBM + wave * 32;
     typedef __attribute__((ext_vector_type(2))) short s16x2_t;
+    // FFN_ABL (build-time, timing only - results garbage; tools/abl_ffn.sh): 1 no fragment LDS reads (a register stands in), 2 no MFMAs
+    // in the loop, 4 no LDS-DMA of the weight chunks
+#ifndef FFN_ABL
+#define FFN_ABL 0
+#endif
     auto frag1 = [&](const unsigned char* w1, int k) {      // first product, MFMA k: k-step k >> 1, row tile k & 1
         const int ks = k >> 1, t = k & 1;
-        return *reinterpret_cast<const bf16x8*>(w1 + a1[ks & 7] + t * 16384 + (ks >> 3) * 256);
+        if constexpr ((FFN_ABL & 1) != 0) return xb[k & 15];
+        else return *reinterpret_cast<const bf16x8*>(w1 + a1[ks & 7] + t * 16384 + (ks >> 3) * 256);
     };
     auto frag2 = [&](const unsigned char* w2, int k) {      // second product, MFMA k: k-step k >> 3, row tile k & 7 of Y^T
-        return *reinterpret_cast<const bf16x8*>(w2 + a2[k >> 3] + (k & 7) * 4096);
+        if constexpr ((FFN_ABL & 1) != 0) return xb[(k + 3) & 15];
+        else return *reinterpret_cast<const bf16x8*>(w2 + a2[k >> 3] + (k & 7) * 4096);
     };
     auto init_s = [&](int chunk, f32x16 (&S)[2]) {
         const float* bb = b1s + chunk * FHC + 8 * h;
@@ -237,10 +244,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             FFN_STEP();
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
+                if constexpr ((FFN_ABL & 2) == 0) S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
+                else asm volatile("" : "+v"(A[k & 15]));
                 if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
                 else if (!FIRST) A[(k + 8) & 15] = frag2(w2, k + 8 - 32);
-                if (k < 16) {
+                if ((FFN_ABL & 4) == 0 && k < 16) {
                     if (k & 1) dma_w2(i & 1, i, k >> 1);
                     else dma_w1((i + 1) & 1, nxt, k >> 1);
                 }
@@ -255,7 +263,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             if constexpr (!FIRST) {
-                Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
+                if constexpr ((FFN_ABL & 2) == 0) Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
+                else asm volatile("" : "+v"(A[k & 15]));
                 if (k + 8 < 32) A[(k + 8) & 15] = frag2(w2, k + 8);
             }
             if constexpr (!LAST) {
