@@ -16,6 +16,10 @@ model = bench.build_model(asr_amd, dev, 0.1, train=True)
 asr_amd.manual_seed(1234)
 x, lens, tg = bench.make_batch(dev, seed=0)
 tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+from asr_amd import modules as _m
+for _k, _v in os.environ.items():      # MOD__CROSS_DKV_SIDE=0 -> modules._CROSS_DKV_SIDE = False (A/B of module constants)
+    if _k.startswith("MOD_"):
+        setattr(_m, _k[4:], bool(int(_v)))
 tr.side_inline = os.environ.get("SIDE_INLINE") == "1"      # the CTC branch queued on the launch stream itself (no overlap with the decoder)
 step = tr.step
 for _ in range(6):
