@@ -228,7 +228,6 @@ def _prefetch_attn_masks(sites, training, device):
 # gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
 _TAPE = None
 _DIRECT_CONV_BWD = True     # the conv layers' direct backward kernels (bf16); the patch-matrix route stays as the f32 parity path
-_CROSS_DKV_SIDE = True      # the decoder's cross-attention dK / dV kernels on the weight-gradient stream (MultiheadAttention._record_bw)
 _DECODE_FUSED = True      # one-launch sub-layers in the per-token decode steps (decode_blocks.hip)
 _IN_DECODE_STEP = False    # set while a per-token decode step is being queued / captured (rows = hypotheses, one position each)
 
@@ -524,15 +523,7 @@ class MultiheadAttention(_Cached):
                 else:
                     dkv = torch.empty((B * Lk, 2 * hd), device=ds.device, dtype=gdt)
                     dk_out, dv_out = dkv[:, :hd], dkv[:, hd:]
-                # cross attention with the keys / values projected for all layers at once (Decoder._cross_kv): dK / dV are read only after
-                # the last decoder layer's backward, the chain continues from dQ - their kernel goes to the weight-gradient stream
-                # (22 us x 6 layers off the decoder's latency-bound chain), which the joint K / V gradient GEMMs are ordered behind
-                side = _WGRAD["stream"] if (_CROSS_DKV_SIDE and _WGRAD is not None and dkv_pre is not None and _PRECISION == "bf16") else None
-                held = ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn, drop_bits=dbits,
-                                         dkv_stream=side)
-                if held is not None:
-                    _WGRAD["keep"].append(held)
-                    _WGRAD["dkv_side"] = True
+                ops.attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq, dk_out, dv_out, drop=dp_attn, drop_bits=dbits)
                 _wg(dq, xq.mma(), out=self.w_qs.weight.grad, accumulate=True, colsum=self.w_qs.bias.grad)
                 _acc(xq, ops.gemm_nn(dq, self._w("q", (self.w_qs.weight,)), addend=ds))
                 if dkv_pre is None:
@@ -1470,8 +1461,6 @@ class Decoder(_Cached):
 
         def bw():   # pushed before the layers -> runs after all of them have written their dK / dV columns
             dkv = box.pop("dkv")
-            if _WGRAD is not None and _WGRAD.pop("dkv_side", False):      # the layers' dK / dV kernels ran on the weight-gradient stream
-                ops.order_after(torch.cuda.current_stream(), _WGRAD["stream"])
             _wg(dkv, enc.mma(), out=_gcat(ws), accumulate=True, colsum=_gcat(bs))
             if enc.lazy_grad is not None:
                 enc.lazy_grad()      # (the CTC branch's gradient: it becomes this GEMM's addend)

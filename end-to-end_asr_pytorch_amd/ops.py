@@ -1053,12 +1053,9 @@ def add_layernorm_bwd(dy, s, mean, rstd, gamma, row_len, B, L, dgamma, dbeta, wa
     return ds, ds16
 
 
-def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out, drop=None, drop_bits=None, dkv_stream=None):
+def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out, dv_out, drop=None, drop_bits=None):
     """q [B,h,Lq,64], k/v [B,h,Lk,64] bf16; ctx, d_ctx token-major bf16 [B,Lq,h*64]; dq_out / dk_out / dv_out are bf16 views with
-    row stride (elements) dq_out.stride(0) / dk_out.stride(0) into token-major gradient buffers (last dim = h*64).
-    dkv_stream: queue the dK / dV kernel on that stream, behind the dQ kernel (which leaves it delta) - for a caller whose chain
-    continues from dQ alone (the decoder's cross attention: dK / dV are first read after the last decoder layer).  Returns the tensors
-    that kernel reads and this call would otherwise let go of: the caller keeps them until it has ordered itself behind that stream."""
+    row stride (elements) dq_out.stride(0) / dk_out.stride(0) into token-major gradient buffers (last dim = h*64)."""
     _req_cuda(q, k, v, ctx, d_ctx, lse)
     B, h, Lq, _ = q.shape
     Lk = k.shape[2]
@@ -1081,18 +1078,10 @@ def attention_bwd(q, k, v, ctx, d_ctx, lse, k_len, causal, scale, dq_out, dk_out
         check(lib().asr_attention_bwd_dq(_stream(), _p(q), _p(k), _p(v), _p(ctx), _p(d_ctx), _p(lse), _p(delta), _p(dq_out),
                                          dq_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, float(scale), _d(drop),
                                          _p(drop_bits)), "asr_attention_bwd_dq")
-    def dkv():
-        with _timed("attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, Lq, Lk), 6.0 * base):
-            check(lib().asr_attention_bwd_dkv(_stream(), _p(q), _p(k), _p(v), _p(d_ctx), _p(lse), _p(delta), _p(dk_out), _p(dv_out),
-                                              dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, _d(drop), _p(drop_bits)),
-                  "asr_attention_bwd_dkv")
-    if dkv_stream is None:
-        dkv()
-        return None
-    order_after(dkv_stream, torch.cuda.current_stream())
-    with torch.cuda.stream(dkv_stream):
-        dkv()
-    return (delta, d_ctx, drop_bits, q, k, v, lse)
+    with _timed("attention_bwd_dkv[B%d h%d %dx%d]" % (B, h, Lq, Lk), 6.0 * base):
+        check(lib().asr_attention_bwd_dkv(_stream(), _p(q), _p(k), _p(v), _p(d_ctx), _p(lse), _p(delta), _p(dk_out), _p(dv_out),
+                                          dk_out.stride(0), B, h, Lq, Lk, _p(k_len), 1 if causal else 0, _d(drop), _p(drop_bits)),
+              "asr_attention_bwd_dkv")
 
 
 def embed_bwd(ids, dy, demb, drop=None):
