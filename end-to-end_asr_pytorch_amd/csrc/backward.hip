@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const T* __restrict_
 #define LNB_RPW_ 2
 #endif
 constexpr int LNB_RPW = LNB_RPW_;             // rows per wave handled TOGETHER: all loads issued up front, reductions interleaved
+#ifndef LNB_MAX_BLOCKS
+#define LNB_MAX_BLOCKS 256
+#endif
 constexpr int LNB_WAVES = 8;                  // waves per workgroup: 256 workgroups x 8 waves fill the chip like 512 x 4 did, with half the
                                               // contended column atomics at the end (512 workgroups: ~8 us of a 31 us launch)
 constexpr int LNB_ROWS = LNB_WAVES * LNB_RPW;  // rows per workgroup
@@ -678,7 +681,7 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    constexpr int max_blocks = 256;      // persistent workgroups (192 .. 384 measured: +0.1 .. 0.8 ms per step either side)
+    constexpr int max_blocks = LNB_MAX_BLOCKS;      // persistent workgroups (192 .. 384 measured at D = 256: +0.1 .. 0.8 ms per step either side)
     if (blocks > max_blocks) blocks = max_blocks;
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
@@ -703,7 +706,7 @@ extern "C" int asr_add_layernorm_bwd_y(void* stream, const float* dy, const floa
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd_y: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    constexpr int max_blocks = 256;      // persistent workgroups (192 .. 384 measured: +0.1 .. 0.8 ms per step either side)
+    constexpr int max_blocks = LNB_MAX_BLOCKS;      // persistent workgroups (192 .. 384 measured at D = 256: +0.1 .. 0.8 ms per step either side)
     if (blocks > max_blocks) blocks = max_blocks;
     const asr_dropout_t none{0, 0, 0, nullptr};
     if (D <= 256)
