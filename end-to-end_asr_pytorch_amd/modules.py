@@ -1079,7 +1079,7 @@ def _vocab_proj(mod, key, weight, x, ctc=None):
                 g = buf[:, :V]
             Vp = g.stride(-2)
             g2 = torch.as_strided(g, (rows, V), (Vp, 1), g.storage_offset())
-            ops.gemm_tn(g2, x.mma(), out=weight.grad, accumulate=True)
+            _wg(g2, x.mma(), out=weight.grad, accumulate=True)      # (under the trainer's backward: with the decoder's other weight gradients, off the main chain)
             x.grad = ops.gemm_nn(g2, w16, addend=x.grad)
             slot["g"] = None
 
