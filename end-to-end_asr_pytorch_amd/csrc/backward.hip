@@ -681,7 +681,7 @@ extern "C" int asr_add_layernorm_bwd(void* stream, const float* dy, const float*
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    constexpr int max_blocks = LNB_MAX_BLOCKS;      // persistent workgroups (192 .. 384 measured at D = 256: +0.1 .. 0.8 ms per step either side)
+    constexpr int max_blocks = LNB_MAX_BLOCKS;      // persistent workgroups (tools/abl_lnb.sh, alone on the chip: 256 / 192 / 128 / 96 / 64 -> 23.7 / 24.3 / 28.8 / 33.4 / 46.1 us at [32000 x 256], 18.0 / 17.5 / 18.5 / 20.7 / 26.3 us at [10688 x 512])
     if (blocks > max_blocks) blocks = max_blocks;
     if (D <= 256)
         hipLaunchKernelGGL(add_layernorm_bwd_kernel<1>, dim3(blocks), dim3(64 * LNB_WAVES), 0, static_cast<hipStream_t>(stream), dy, s, mean, rstd, gamma,
@@ -706,7 +706,7 @@ extern "C" int asr_add_layernorm_bwd_y(void* stream, const float* dy, const floa
     ASR_REQUIRE(B > 0 && L > 0 && D > 0 && D <= 1024 && D % 4 == 0, ASR_ERR_UNSUPPORTED, "layernorm_bwd_y: D=%d", D);
     const int M = B * L;
     int blocks = (M + LNB_ROWS - 1) / LNB_ROWS;
-    constexpr int max_blocks = LNB_MAX_BLOCKS;      // persistent workgroups (192 .. 384 measured at D = 256: +0.1 .. 0.8 ms per step either side)
+    constexpr int max_blocks = LNB_MAX_BLOCKS;      // persistent workgroups (tools/abl_lnb.sh, alone on the chip: 256 / 192 / 128 / 96 / 64 -> 23.7 / 24.3 / 28.8 / 33.4 / 46.1 us at [32000 x 256], 18.0 / 17.5 / 18.5 / 20.7 / 26.3 us at [10688 x 512])
     if (blocks > max_blocks) blocks = max_blocks;
     const asr_dropout_t none{0, 0, 0, nullptr};
     if (D <= 256)
