@@ -118,3 +118,37 @@ def test_shapes_the_one_launch_table_does_not_take_fall_back():
     x = torch.randn(2 * 4096, 256).bfloat16().to(DEV)
     assert not ops.vocab_proj_ctc_ok(x, w, 2, 4096, 64)         # U + 1 > 64
     assert ops.vocab_proj_ctc_ok(x, w, 2, 4096, 63)
+
+
+def test_trainer_step_on_the_table_form_equals_the_streaming_form(monkeypatch):
+    """The whole CTC branch inside Trainer (side stream, projection + table, recursion, gradient pass on the fp16 image, ctc_fc's two
+    backward GEMMs, the join into the encoder's gradient) against the same step with the branch on the plain GEMM + streaming CTC
+    forward + f32-logits gradient pass: losses to 1e-5, ctc_fc's and the encoder's gradients to the bf16 images' rounding."""
+    import asr_amd
+    B, T, U, V = 8, 640, 20, 500
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, 80, generator=g).to(DEV)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    tg = torch.randint(4, V - 1, (B, U), generator=g)
+    tg[1, 12:] = 0
+    grads, losses = [], []
+    asr_amd.set_precision("bf16")
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_VOCAB_CTC", fused)
+        torch.manual_seed(11)
+        model = asr_amd.CTC_Transformer(asr_amd.Encoder(80, 2, 4, 256, 512, dropout=0.0),
+                                        asr_amd.Decoder(2, 3, V, 1, 4, 256, 512, dropout=0.0)).to(DEV).train()
+        tr = asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1)
+        tr.fp.grad.zero_()
+        ctc, ce, state = tr.forward_loss(x, lens.to(DEV), tg.to(DEV), max_target_len=U)
+        if fused:
+            assert tr._side is not None and tr._side["st"].logits.dtype == torch.float16      # the table form ran
+        tr.backward(state)
+        torch.cuda.synchronize()
+        losses.append((float(ctc), float(ce)))
+        grads.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters()})
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
+    for name in ("ctc_fc.weight", "encoder.layer_stack.1.pos_ffn.w_2.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight", "encoder.linear_in.weight"):
+        a, c = grads[0][name], grads[1][name]
+        assert float((a - c).norm() / c.norm()) < 1e-2, name
