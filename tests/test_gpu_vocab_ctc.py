@@ -35,7 +35,7 @@ def make(B, L, U, V, seed):
     return x, w, tg, il
 
 
-@pytest.mark.parametrize("B,L,U,V", [(3, 300, 51, 4234), (2, 128, 7, 130), (5, 257, 50, 1000), (4, 200, 63, 700), (2, 1000, 20, 4234)])
+@pytest.mark.parametrize("B,L,U,V", [(3, 300, 51, 4234), (2, 128, 7, 130), (5, 257, 50, 1000), (4, 200, 63, 700), (2, 1000, 20, 4234), (2, 130, 3, 70), (1, 129, 1, 64)])
 def test_vocab_proj_ctc_is_the_projection_plus_the_table_pass(B, L, U, V):
     x, w, tg, il = make(B, L, U, V, B * L + U)
     xd, wd, tgd, ild = x.to(DEV), w.to(DEV), tg.to(DEV), il.to(DEV)
