@@ -13,6 +13,11 @@ queue behind each other.  Two waves per SIMD issue different kinds side by side;
 operand (rows that left reference 0 pay a v_sub per score instead, rare), 4-fragment K / V buffers, ring slots as immediates (four
 steps per trip).
 
+Row sums, measured and kept as two v_add_f32 per pair (round 5, same box, eval / dropout at [32,4,1000,1000]): one v_pk_add_f32 per pair
+(16 fewer vector instructions per phase) 40.9 / 49.4 us against 39.6 / 46.8; the sums on the matrix pipe (a 2-pass 4x4x4 MFMA against a
+ones operand per four packed probabilities, no adds at all) 43.3 us: an MFMA holds the wave's in-order issue until the pipe takes it, so
+every extra one is a stall for the vector work queued behind it, and the packed add's longer dependent chain costs more than its slot saves.
+
 Structure: a wave owns 64 query rows as two 32-row blocks A and B.
   phase X (X = A, B alternating):  vector port: block X's tile -> p = exp2(s), row sums, bf16 packs;
                                    matrix pipe: the OTHER block's P.V of its previous tile (8 MFMAs), then K.Q^T of its next tile (8).
