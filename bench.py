@@ -65,6 +65,8 @@ def parse_args():
                     help="the per-op timing passes after the timed region: both = one with the step's side streams (in step) and one with "
                          "everything inlined on one stream (alone); in_step = only the first, so that EVERY step of the process ran with its "
                          "side streams - the run tools/profile_r5.sh puts under rocprofv3 for kernel_stats.csv")
+    ap.add_argument("--side-budget", type=int, default=-1,
+                    help="Trainer.side_budget: launch budget (CUs) of the CTC branch's backward on the side stream; 0 = full grids, -1 = the trainer's default")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the extra legs of the default 1-GPU run (S2, CIF_Model, greedy decode: BASELINE configs[2] / [3] and SURVEY 8(f)1)")
     return ap.parse_args()
@@ -449,6 +451,8 @@ def main():
 
     trainer = (asr_amd.Trainer(model, k=0.2, warmup_steps=4000, label_smoothing=0.1, **({"lambda_qua": 0.001} if CFG.get("cif") else {}))
                if train else None)
+    if trainer is not None and args.side_budget >= 0:
+        trainer.side_budget = args.side_budget
     use_graph = args.graph == 1 and trainer is not None
     auto_graph = args.graph < 0 and trainer is not None
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "asr_gemm_tn": [_vp, _vp, _i, _i64, _vp, _i, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i],
     "asr_debug_poison_lds": [_vp, _vp],
     "asr_set_deterministic": [_i],
+    "asr_launch_budget": [_i],
     "asr_streams_share_queue": [_vp, _vp, _vp],
     "asr_event_create": [_vp],
     "asr_stream_order_after": [_vp, _vp, _vp],

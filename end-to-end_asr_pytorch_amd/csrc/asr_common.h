@@ -34,6 +34,7 @@ int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const v
                             asr_dropout_t drop, const uint32_t* drop_bits);
 // collective.hip: the function of the bucket-ready marker node (graph_exec.hip turns such a node into an all-reduce call) and the call
 const void* asr_collective_marker_func();
+int asr_launch_budget_current();     // common.hip: asr_launch_budget (0 = none)
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
     do {                                  \

@@ -24,6 +24,11 @@ int asr_deterministic() {
     if (g_deterministic < 0) { const char* e = getenv("ASR_AMD_DETERMINISTIC"); g_deterministic = (e && atoi(e) != 0) ? 1 : 0; }
     return g_deterministic;
 }
+// launch budget (asr_hip.h: asr_launch_budget): per host thread, read by the launches named there
+static thread_local int g_launch_budget = 0;
+int asr_launch_budget_current() { return g_launch_budget; }
+extern "C" int asr_launch_budget(int cus) { const int old = g_launch_budget; g_launch_budget = cus > 0 ? cus : 0; return old; }
+
 extern "C" int asr_set_deterministic(int on) { const int old = asr_deterministic(); g_deterministic = on ? 1 : 0; return old; }
 
 // ---- test support: leave every CU's LDS full of bf16 / f32 NaN patterns -----------------------------------------------------------

@@ -1245,10 +1245,16 @@ extern "C" int asr_ctc_loss_bwd_ex(void* stream, const void* logits_v, int logit
     else
         launch_recursion<1>(s, lp_ext, in_len, targets, const_cast<int32_t*>(tgt_len), B, L, Umax, alpha, const_cast<float*>(nll), 0, L, 1);
     // ~2048 workgroups in flight (8 per CU: every wave slot).  In the training step this launch runs on the side stream beside the
-    // decoder's small kernels; leaving slots free for them (6 / 5 / 4 per CU, with and without the branch's GEMMs at one workgroup per
-    // CU) does not shorten the decoder segment - 2.51-2.53 ms either way, tools/step_segments.py: what the small kernels wait for is
-    // the memory system this branch saturates, not a place to run.
-    int rb = (2048 + B - 1) / B;
+    // decoder's small kernels, whose workgroups are fat - attention at 51 x 1000: eight waves of 162 registers + 128 KiB of LDS,
+    // gemm_ln_small: eight waves of 178 - and find no CU to start on while this launch holds every wave slot (tools/op_timeline.py,
+    // events, no profiler: cross attention 17.6 -> 154 us beside it).  Capping it at 6 / 5 / 4 workgroups per CU is not enough
+    // (4 x 40 registers leave a SIMD 352, gemm_ln_small needs 368; and ctc_fc's two GEMMs behind it starve the same kernels), which
+    // is what the 2.51-2.53 ms of those runs showed.  Under asr_launch_budget (trainer: 128): 3 workgroups per budgeted CU; with
+    // the two GEMMs budgeted as well no decoder kernel stalls any more and the segment is 2.41 -> 2.32 ms - the branch's work
+    // still shares the chip with the chain, it just no longer stops it.
+    const int budget = asr_launch_budget_current();      // (asr_hip.h: asr_launch_budget - 3 workgroups per budgeted CU)
+    const int wgs = budget > 0 && budget * 3 < 2048 ? budget * 3 : 2048;
+    int rb = (wgs + B - 1) / B;
     if (rb > L) rb = L;
     if (rb < 1) rb = 1;
     if (grad_dtype == ASR_BF16 && logits_dtype == ASR_F16)

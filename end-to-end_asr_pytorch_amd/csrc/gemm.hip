@@ -1130,7 +1130,8 @@ extern "C" int asr_gemm_nn(void* stream, const void* A, int a_dtype, int64_t lda
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, nwg = tiles_m * tiles_n;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a_dtype == ASR_BF16 && k_ok && N % 128 == 0 && ldb % 8 == 0 && asr_aligned(Bm, 16)) {
-        constexpr int max_wg = 512;   // 2 per CU, persistent
+        const int budget = asr_launch_budget_current();
+        const int max_wg = budget > 0 && budget < 512 ? budget : 512;   // 2 per CU, persistent (asr_launch_budget: fewer, beside latency-bound work)
         const int sp = pick_ksplit(epi, nwg, K);
         if (sp > 1) {
             if (!epi.c_is_zero)

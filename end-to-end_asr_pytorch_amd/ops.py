@@ -58,9 +58,24 @@ def _req_cuda(*ts):
 _PROF = None
 
 
-def profile_start():
-    global _PROF
+_PROF_SEQ = None
+
+
+def profile_start(sequence=False):
+    """sequence=True also keeps the bracketed calls in issue order (profile_sequence: a time line of one step, every stream)."""
+    global _PROF, _PROF_SEQ
     _PROF = {}
+    _PROF_SEQ = [] if sequence else None
+
+
+def profile_mark():
+    """a timing event on the current stream: the origin of profile_sequence's time axis"""
+    return _timer()
+
+
+def profile_sequence(origin):
+    """-> [(name, start_ms, duration_ms, stream)] in issue order; call before profile_stop, after a device synchronize."""
+    return [(n, _elapsed_ms(origin, a), _elapsed_ms(a, b), st) for n, a, b, st in (_PROF_SEQ or [])]
 
 
 LIGHT_TIMERS = True      # timing events without the system-scope fence (False: torch timing events, ~2 us more per bracketed op)
@@ -122,6 +137,8 @@ class _timed:
                 b = torch.cuda.Event(enable_timing=True)
                 b.record()
             _PROF.setdefault(self.name, []).append((self.a, b, self.work))
+            if _PROF_SEQ is not None:
+                _PROF_SEQ.append((self.name, self.a, b, _stream().value or 0))
         return False
 
 
@@ -910,6 +927,29 @@ def _gemm_tn_f32(a2d, b2d, out, accumulate, colsum_out):
     return out
 
 
+_BUDGET = 0
+
+
+class launch_budget:
+    """`with ops.launch_budget(cus):` - launches queued inside keep to `cus` CUs' worth of the chip (asr_hip.h: asr_launch_budget; the
+    weight-gradient GEMM takes it as its max_wgs).  For side-stream work beside a chain of small kernels; 0 = no budget."""
+
+    def __init__(self, cus):
+        self.cus = int(cus or 0)
+
+    def __enter__(self):
+        global _BUDGET
+        self.old_c, self.old_p = int(lib().asr_launch_budget(self.cus)), _BUDGET
+        _BUDGET = self.cus
+        return self
+
+    def __exit__(self, *exc):
+        global _BUDGET
+        lib().asr_launch_budget(self.old_c)
+        _BUDGET = self.old_p
+        return False
+
+
 def set_deterministic(on):
     """asr_set_deterministic: single-writer forms instead of float atomics in arrival order (forward split-K GEMMs, bias gradients)."""
     global DETERMINISTIC
@@ -951,6 +991,7 @@ def _tn_workspace(out, M, N, K, max_wgs, persistent=True):
 def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     """dW[N,K] = A[M,N]^T . B[M,K]  (f32 result).  A/B f32 or bf16; rows may be strided (padded buffers).
     colsum (f32 [N]) += column sums of A (the bias gradient) in the same pass."""
+    max_wgs = max_wgs or _BUDGET
     _req_cuda(a2d, b2d)
     M, N = a2d.shape
     K = b2d.shape[1]

@@ -181,6 +181,9 @@ class Trainer:
         self.force_collective = bool(force_collective)
         # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); Trainer(overlap_ctc=False) serialises it
         self.overlap_ctc = True if overlap_ctc is None else bool(overlap_ctc)
+        # launch budget of the branch's backward (ops.launch_budget: CTC gradient pass 3 x 128 workgroups, ctc_fc's two GEMMs 128 each):
+        # at full grids they starve the decoder's fat-workgroup kernels for 100-150 us apiece; 0 = none (tools/op_timeline.py)
+        self.side_budget = 128
         self.wgrad_stream = True     # weight-gradient GEMMs on a side stream (backward()); bench.py's kernel-alone pass sets it False
         self.lambda_qua = lambda_qua      # CIF models: loss = lambda_qua * qua + ctc + ce (solver.py:153, train.py:64)
         dev = next(model.parameters()).device
@@ -261,8 +264,9 @@ class Trainer:
                 ctc, nll, st = done
             else:
                 ctc, nll, st = ops.ctc_loss_fwd(logits.view(enc.B, enc.L, -1), ops.as_i32(lens, logits.device), ctc_targets)
-            model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, torch.ones(1, device=logits.device), bf16=(modules.get_precision() == "bf16"))
-            side_tape.backward()
+            with ops.launch_budget(self.side_budget if aux is not main else 0):
+                model._grad_slots["ctc"]["g"] = ops.ctc_loss_bwd(st, torch.ones(1, device=logits.device), bf16=(modules.get_precision() == "bf16"))
+                side_tape.backward()
         self._side = {"ctc": ctc, "st": st}
         params = (model.ctc_fc.weight,)
 

@@ -66,6 +66,14 @@ int asr_version(void);
  * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
  * (asr_gemm_tn_ws) is order-fixed in either mode.  Returns the previous setting. */
 int asr_set_deterministic(int on);
+/* Launch budget of the calling host thread (0 = none; returns the previous value).  A launch queued on a side stream beside a chain
+ * of small, latency-bound kernels must not fill the chip: a persistent GEMM workgroup holds its CU's registers / LDS for the whole
+ * launch, and a streaming kernel at eight waves per SIMD leaves no wave slot - the small kernels' workgroups then find no CU to
+ * start on until the side launch has drained (measured: the decoder's 12-18 us kernels took 100-150 us beside the CTC branch's
+ * gradient pass and ctc_fc's two backward GEMMs).  With a budget of `cus`, asr_gemm_nn's persistent grid is at most `cus`
+ * workgroups and asr_ctc_loss_bwd(_ex)'s gradient pass at most 3 * cus (three waves per SIMD when spread over the chip); asr_gemm_tn
+ * takes its share as its own max_workgroups argument.  Results do not depend on the budget. */
+int asr_launch_budget(int cus);
 /* Ordering between two streams of ONE device without the system-scope fence a default HIP event performs at every record (cache
  * write-back and invalidation: ~1-3 us of the recording stream's time per event, ~100 events per eagerly queued training step):
  * asr_stream_order_after records `event` (from asr_event_create) on earlier_stream and makes later_stream wait for it - everything

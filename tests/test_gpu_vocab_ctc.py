@@ -152,3 +152,27 @@ def test_trainer_step_on_the_table_form_equals_the_streaming_form(monkeypatch):
     for name in ("ctc_fc.weight", "encoder.layer_stack.1.pos_ffn.w_2.weight", "encoder.layer_stack.0.slf_attn.w_qs.weight", "encoder.linear_in.weight"):
         a, c = grads[0][name], grads[1][name]
         assert float((a - c).norm() / c.norm()) < 1e-2, name
+
+
+def test_launch_budget_changes_no_result():
+    """ops.launch_budget (asr_launch_budget): the CTC gradient pass on 3 x 40 workgroups gives the bits of the full grid; the persistent
+    data-gradient GEMM on 40 workgroups (split-K partial sums meet in atomics) and the weight-gradient GEMM (another split over the
+    rows) the same sums to fp32 rounding."""
+    B, L, U, V = 4, 300, 20, 1000
+    x, w, tg, il = make(B, L, U, V, 5)
+    xd, wd = x.to(DEV), w.to(DEV)
+    _, _, _, st = ops.vocab_proj_ctc(xd, wd, tg.to(DEV), il.to(DEV), B, L)
+    one = torch.ones(1, device=DEV)
+    g_full = ops.ctc_loss_bwd(st, one, bf16=True).clone()
+    g2 = torch.as_strided(g_full, (B * L, V), (g_full.stride(-2), 1), g_full.storage_offset())
+    dx_full = ops.gemm_nn(g2, wd).clone()
+    dw_full = ops.gemm_tn(g2, xd).clone()
+    with ops.launch_budget(40):
+        _, _, _, st_b = ops.vocab_proj_ctc(xd, wd, tg.to(DEV), il.to(DEV), B, L)
+        g_b = ops.ctc_loss_bwd(st_b, one, bf16=True)
+        dx_b = ops.gemm_nn(g2, wd)
+        dw_b = ops.gemm_tn(g2, xd)
+    assert int(ops.lib().asr_launch_budget(0)) == 0              # the context restored "none"
+    assert torch.equal(g_b, g_full)
+    np.testing.assert_allclose(N(dx_b), N(dx_full), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(N(dw_b), N(dw_full), rtol=1e-4, atol=1e-6)

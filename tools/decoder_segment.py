@@ -64,6 +64,19 @@ def main(d):
         for i in range(1, len(seg) - 1):
             s, e, q, n = seg[i]
             print("    +%8.1f us  %6.1f us  gap %5.1f  %s" % ((s - seg[0][1]) / 1e3, (e - s) / 1e3, (s - seg[i - 1][1]) / 1e3, short(n)))
+    if "--side" in sys.argv:          # the other queues' kernels on the same axis, and the main-queue kernels that ran > 3x their median beside them
+        print("  other queues (start, duration, queue):")
+        for s, e, q, n in sorted(other):
+            print("    +%8.1f us  %6.1f us  q%-3s %s" % ((s - seg[0][1]) / 1e3, (e - s) / 1e3, q, short(n)))
+        med = defaultdict(list)
+        for s, e, q, n in seg[1:-1]:
+            med[short(n)].append(e - s)
+        print("  main-queue kernels at > 3x their median, and what ran beside them:")
+        for s, e, q, n in seg[1:-1]:
+            m = sorted(med[short(n)])[len(med[short(n)]) // 2]
+            if e - s > 3 * m:
+                beside = [short(n2)[:40] for s2, e2, q2, n2 in other if s2 < e and e2 > s]
+                print("    +%8.1f us  %6.1f us (median %.1f)  %s   | %s" % ((s - seg[0][1]) / 1e3, (e - s) / 1e3, m / 1e3, short(n), ", ".join(beside)))
 
 
 if __name__ == "__main__":

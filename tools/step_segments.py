@@ -20,7 +20,10 @@ from asr_amd import modules as _m
 for _k, _v in os.environ.items():      # MOD__CROSS_DKV_SIDE=0 -> modules._CROSS_DKV_SIDE = False (A/B of module constants)
     if _k.startswith("MOD_"):
         setattr(_m, _k[4:], bool(int(_v)))
-tr.side_inline = os.environ.get("SIDE_INLINE") == "1"      # the CTC branch queued on the launch stream itself (no overlap with the decoder)
+tr.side_inline = os.environ.get("SIDE_INLINE") == "1"
+for _k, _v in os.environ.items():      # TR_SIDE_BUDGET=128 -> tr.side_budget = 128
+    if _k.startswith("TR_"):
+        setattr(tr, _k[3:].lower(), int(_v))      # the CTC branch queued on the launch stream itself (no overlap with the decoder)
 step = tr.step
 for _ in range(6):
     step(x, lens, tg, max_target_len=bench.CFG["U"])
