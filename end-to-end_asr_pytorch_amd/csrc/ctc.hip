@@ -1251,7 +1251,10 @@ extern "C" int asr_ctc_loss_bwd_ex(void* stream, const void* logits_v, int logit
     // (4 x 40 registers leave a SIMD 352, gemm_ln_small needs 368; and ctc_fc's two GEMMs behind it starve the same kernels), which
     // is what the 2.51-2.53 ms of those runs showed.  Under asr_launch_budget (trainer: 128): 3 workgroups per budgeted CU; with
     // the two GEMMs budgeted as well no decoder kernel stalls any more and the segment is 2.41 -> 2.32 ms - the branch's work
-    // still shares the chip with the chain, it just no longer stops it.
+    // still shares the chip with the chain, it just no longer stops it.  (A software-pipelined form of the pass - next row's logits
+    // and occupancies requested a row ahead, two correction vectors, two barriers per row - runs 546 -> 336 us under the budget, but at
+    // 69 registers instead of 38 three workgroups per CU leave a SIMD 296 registers and gemm_ln_small stalls again: segment and step
+    // unchanged; alone, at full grid, it is no faster with fp16 logits and 11 % slower with f32 ones.  Not kept.)
     const int budget = asr_launch_budget_current();      // (asr_hip.h: asr_launch_budget - 3 workgroups per budgeted CU)
     const int wgs = budget > 0 && budget * 3 < 2048 ? budget * 3 : 2048;
     int rb = (wgs + B - 1) / B;
