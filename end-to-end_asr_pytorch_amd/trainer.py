@@ -181,6 +181,10 @@ class Trainer:
         self.force_collective = bool(force_collective)
         # CTC branch on a side stream beside the decoder branch (see _ctc_side_branch); Trainer(overlap_ctc=False) serialises it
         self.overlap_ctc = True if overlap_ctc is None else bool(overlap_ctc)
+        # (Measured and not kept, round 5: the branch queued BEHIND the decoder's first launch - the K / V projection of all six layers over
+        # the encoder output, a chip-filling GEMM that shares the chip with the branch's own projection - decoder segment 2.32 -> 2.24-2.39 ms,
+        # step unchanged within the box's noise; that projection split into layer 0 on the launch stream and layers 1-5 on a side stream:
+        # segment + 0.12 ms, the small GEMM waits for the CUs the branch's projection holds.)
         # launch budget of the branch's backward (ops.launch_budget: CTC gradient pass 3 x 128 workgroups, ctc_fc's two GEMMs 128 each):
         # at full grids they starve the decoder's fat-workgroup kernels for 100-150 us apiece; 0 = none (tools/op_timeline.py)
         self.side_budget = 128
