@@ -73,3 +73,30 @@ def test_host_side_size_queries_need_no_gpu():
     assert L.asr_ffn_bits_words(130, 64) == 1 * 2 * 256                # rows padded to the 128-token block
     old = L.asr_set_deterministic(1)
     assert L.asr_set_deterministic(old) == 1
+
+
+def test_launch_budget_is_per_host_thread_and_restored_by_the_context():
+    """asr_launch_budget (asr_hip.h): thread-local state, the previous value comes back; ops.launch_budget restores it on exit, also on an
+    exception, and nests."""
+    import threading
+    from asr_amd import ops
+    L = _lib.lib()
+    assert L.asr_launch_budget(0) == 0
+    with ops.launch_budget(96):
+        assert L.asr_launch_budget(96) == 96 and ops._BUDGET == 96
+        with ops.launch_budget(0):                    # "no budget" inside a budgeted region
+            assert L.asr_launch_budget(0) == 0 and ops._BUDGET == 0
+        assert L.asr_launch_budget(96) == 96 and ops._BUDGET == 96
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(L.asr_launch_budget(0)))      # another host thread starts with none
+        t.start()
+        t.join()
+        assert seen == [0]
+    assert L.asr_launch_budget(0) == 0 and ops._BUDGET == 0
+    try:
+        with ops.launch_budget(64):
+            raise RuntimeError("x")
+    except RuntimeError:
+        pass
+    assert L.asr_launch_budget(0) == 0 and ops._BUDGET == 0
+    assert L.asr_launch_budget(-5) == 0 and L.asr_launch_budget(0) == 0      # negative = none
