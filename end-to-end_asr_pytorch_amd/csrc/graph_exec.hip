@@ -438,16 +438,20 @@ extern "C" int asr_graphx_launch(void* handle, void* stream) {
     const int rc = graphx_launch_nodes(g, main);
     if (rc != 0) {
         // A step with collective nodes that failed part-way is fatal for the JOB, not only for this rank: the peers have queued (or will
-        // queue) the matching ncclAllReduce calls and would wait for this rank forever.  Abort the communicator so that they fail fast
-        // with an asynchronous error (asr_rccl_comm_check) instead; the message of the original failure is kept.
+        // queue) the matching ncclAllReduce calls and would wait for this rank forever.  The communicator is BORROWED (its owner gave
+        // it to asr_graphx_set_collective): it is not freed here - the executor forgets it and returns ASR_ERR_COLLECTIVE_STEP, on which
+        // the owner aborts it (asr_rccl_comm_abort: peers fail fast with an asynchronous error) and drops its own handle.
+        bool collective_step = false;
         if (g->n_collective > 0 && g->comm) {
             const std::string first = asr_last_error();
-            (void)asr_rccl_comm_abort(g->comm);
             g->comm = nullptr;
-            asr_set_error("%s [the step's RCCL communicator was aborted: peers fail fast instead of waiting in an all-reduce this rank never joins]",
-                          first.c_str());
+            collective_step = true;
+            asr_set_error("%s [a step with RCCL all-reduce nodes failed part-way: abort the communicator (asr_rccl_comm_abort) so that peers fail "
+                          "fast instead of waiting in an all-reduce this rank never joins]", first.c_str());
         }
         for (size_t s = 1; s < g->streams.size(); ++s) (void)hipStreamSynchronize(g->streams[s]);
+        if (collective_step) return ASR_ERR_COLLECTIVE_STEP;
+        return rc;
     }
     return rc;
 }

@@ -8,6 +8,7 @@ import atexit
 import ctypes
 import weakref
 import os
+import threading
 
 import torch
 
@@ -634,7 +635,8 @@ def vocab_proj_ctc(x16, w16, targets, in_len, B, L, blank=None):
     with _timed("vocab_proj_ctc[%dx%dx256]" % (M, V), 2.0 * M * V * 256):
         check(lib().asr_vocab_proj_ctc(_stream(), _p(x16), _p(w16), _p(buf), Vp, _p(st.lse), _p(st.lp_ext), _p(st.targets), B, L, V, Umax,
                                        st.blank, 256), "asr_vocab_proj_ctc")
-    with _timed("ctc_loss_fwd[B%d L%d V%d U%d]" % (B, L, V, Umax), 4.0 * B * L * V):      # (priced on the unfused op's bytes)
+    # (the table form touches the table only: lp_ext read, alpha written - NOT the logits; its own name so no table prices it at 4 B L V)
+    with _timed("ctc_loss_fwd_table[B%d L%d S%d U%d]" % (B, L, S, Umax), 2.0 * 4.0 * B * L * S):
         check(lib().asr_ctc_loss_fwd_table(_stream(), _p(st.lp_ext), _p(st.in_len), _p(st.targets), B, L, Umax, _p(st.alpha), _p(st.nll),
                                            _p(st.tgt_len), _p(loss)), "asr_ctc_loss_fwd_table")
     return buf[:, :V], loss, st.nll, st
@@ -697,7 +699,10 @@ def ctc_loss_bwd(st, gout, bf16=False):
     """-> grad wrt logits as a [B,L,V] view of a zero-padded [B,L,Vp] buffer (rows 16-byte aligned so the gradient is directly a
     GEMM operand).  Consumes st.alpha.  bf16=True (a gradient that only feeds the projection's backward GEMMs, which run on bf16
     MFMA anyway): half the bytes, Vp = roundup(V, 128) so that both GEMMs take their LDS-DMA kernels, pad written by the kernel."""
-    if bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0 or st.logits.dtype == torch.float16:
+    fp16_in = st.logits.dtype == torch.float16
+    if fp16_in and not bf16:
+        raise ValueError("ctc_loss_bwd: an fp16 logits image (asr_vocab_proj_ctc) only has the bf16 gradient form - pass bf16=True")
+    if fp16_in or (bf16 and st.ldl % 4 == 0 and st.logits.data_ptr() % 16 == 0):
         Vp = (st.V + 127) // 128 * 128
         gbuf = torch.empty((st.B, st.L, Vp), device=st.logits.device, dtype=torch.bfloat16)
     else:
@@ -927,7 +932,11 @@ def _gemm_tn_f32(a2d, b2d, out, accumulate, colsum_out):
     return out
 
 
-_BUDGET = 0
+class _BudgetTLS(threading.local):      # per host thread, like the C side's thread_local (asr_launch_budget): one value drives both halves
+    cus = 0
+
+
+_BUDGET = _BudgetTLS()
 
 
 class launch_budget:
@@ -938,15 +947,13 @@ class launch_budget:
         self.cus = int(cus or 0)
 
     def __enter__(self):
-        global _BUDGET
-        self.old_c, self.old_p = int(lib().asr_launch_budget(self.cus)), _BUDGET
-        _BUDGET = self.cus
+        self.old_c, self.old_p = int(lib().asr_launch_budget(self.cus)), _BUDGET.cus
+        _BUDGET.cus = self.cus
         return self
 
     def __exit__(self, *exc):
-        global _BUDGET
         lib().asr_launch_budget(self.old_c)
-        _BUDGET = self.old_p
+        _BUDGET.cus = self.old_p
         return False
 
 
@@ -991,7 +998,7 @@ def _tn_workspace(out, M, N, K, max_wgs, persistent=True):
 def gemm_tn(a2d, b2d, out=None, accumulate=False, colsum=None, max_wgs=0):
     """dW[N,K] = A[M,N]^T . B[M,K]  (f32 result).  A/B f32 or bf16; rows may be strided (padded buffers).
     colsum (f32 [N]) += column sums of A (the bias gradient) in the same pass."""
-    max_wgs = max_wgs or _BUDGET
+    max_wgs = max_wgs or _BUDGET.cus
     _req_cuda(a2d, b2d)
     M, N = a2d.shape
     K = b2d.shape[1]
@@ -1558,6 +1565,9 @@ def rccl_load():
         _RCCL["loaded"] = True
 
 
+ERR_COLLECTIVE_STEP = -6      # asr_hip.h: ASR_ERR_COLLECTIVE_STEP
+
+
 class RcclComm:
     """An RCCL communicator owned by libasr_hip.so (not torch's): what the graph executor's collective nodes all-reduce through."""
 
@@ -1569,16 +1579,31 @@ class RcclComm:
         _req_cuda(t)
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise RuntimeError("RcclComm.all_reduce_: a contiguous float32 tensor is required")
+        self._live()
         check(lib().asr_rccl_all_reduce_f32(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), _stream()), "asr_rccl_all_reduce_f32")
         return t
 
     def check(self):
+        self._live()
         check(lib().asr_rccl_comm_check(self.handle), "asr_rccl_comm_check")
 
     def destroy(self):
         h, self.handle = self.handle, None
         if h:
             lib().asr_rccl_comm_destroy(h)
+
+    def abort(self):
+        """asr_rccl_comm_abort: tear down without waiting (peers get an asynchronous error); the handle is dropped and the object evicted
+        from the per-group cache, so neither the atexit teardown nor a later rccl_comm() touches the freed communicator."""
+        h, self.handle = self.handle, None
+        for k in [k for k, c in list(_RCCL["comms"].items()) if c is self]:
+            del _RCCL["comms"][k]
+        if h:
+            lib().asr_rccl_comm_abort(h)
+
+    def _live(self):
+        if not self.handle:
+            raise RuntimeError("RcclComm: this communicator was aborted or destroyed")
 
 
 def rccl_comm(group=None, device=None):
@@ -1684,6 +1709,8 @@ class GraphExec:
     def set_collective(self, comm=None, fn=None):
         """What the plan's collective nodes call: an RcclComm, or an asr_collective_fn callback (torch_collective_fn)."""
         self._comm, self._fn = comm, fn      # (kept alive with the executor)
+        if comm is not None:
+            comm._live()
         check(lib().asr_graphx_set_collective(self._h, comm.handle if comm is not None else None,
                                               ctypes.cast(fn, ctypes.c_void_p) if fn is not None else None, None), "asr_graphx_set_collective")
 
@@ -1693,6 +1720,13 @@ class GraphExec:
         if rc != 0 and fn is not None and fn.state["error"] is not None:
             err, fn.state["error"] = fn.state["error"], None
             raise err
+        if rc == ERR_COLLECTIVE_STEP:
+            # the executor has forgotten the communicator it borrowed; its owner (this side) aborts it and drops every reference
+            msg = lib().asr_last_error().decode(errors="replace")
+            comm, self._comm = getattr(self, "_comm", None), None
+            if comm is not None:
+                comm.abort()
+            raise RuntimeError("asr_graphx_launch failed (rc=%d): %s" % (rc, msg))
         check(rc, "asr_graphx_launch")
 
     def place_streams(self, clear=False):

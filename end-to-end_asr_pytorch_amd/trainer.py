@@ -464,9 +464,20 @@ class Trainer:
         try:
             ctc, ce, state = self.forward_loss(feats, lens, targets, noise=noise, max_target_len=max_target_len)
             self.backward(state)
+        except BaseException:
+            ops.ctc_reset_counters()      # an aborted step may leave the one-launch CTC forward's arrival counters non-zero
+            raise
         finally:
             ops.arena_release()
         return ctc, ce
+
+    def losses_finite(self, ctc, ce):
+        """Host read of a step's losses (a sync - call it where the losses are logged, solver.py:52-56): False for a non-finite value,
+        after forgetting the CTC forward's cached arrival counters (a bounded wait that gave up returns NaN and leaves them stale)."""
+        ok = bool(torch.isfinite(ctc).all()) and bool(torch.isfinite(ce).all())
+        if not ok:
+            ops.ctc_reset_counters()
+        return ok
 
     def step(self, feats, lens, targets, noise=None, max_target_len=None):
         """One full training step; returns (ctc_loss, ce_loss) tensors (no host sync when max_target_len is given)."""
@@ -526,7 +537,7 @@ class Trainer:
             # the captured data-parallel step; anything else has to say so loudly.
             raise RuntimeError("Trainer.step_graphed with world_size %d: the batch signature changed after the step was captured (%r -> %r). "
                                "The captured data-parallel step needs the same shapes and max_target_len on every rank and every step - "
-                               "bucket the loader to fixed shapes, or step eagerly (Trainer.step / ASR_AMD_GRAPH_DP=0)."
+                               "bucket the loader to fixed shapes, or step eagerly (Trainer.step; unset ASR_AMD_GRAPH_DP - eager is the default for world_size > 1)."
                                % (self.world, self._graph_key, key))
         if self._graph is None or self._graph_key != key:
             if self._eager_steps < 2:

@@ -61,6 +61,8 @@ int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, in
 #define ASR_GEMM_RELU 1u
 #define ASR_GEMM_C_IS_ZERO 4u   /* the caller's C is already all zeros: a split-K launch (few output tiles, long K) skips its zeroing kernel */
 
+/* ABI revision: 100 = rounds 1-4; 101 = asr_vocab_proj_lse and asr_ctc_loss_fwd_lse removed (asr_vocab_proj_ctc + asr_ctc_loss_fwd_table
+ * replace them), asr_launch_budget_current added.  A binder checks this before it resolves symbols. */
 int asr_version(void);
 /* Deterministic mode (also ASR_AMD_DETERMINISTIC=1 in the environment): the forward GEMMs stop splitting K across workgroups (float
  * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
@@ -223,8 +225,10 @@ int asr_graphx_destroy(void* handle);
  * calls asr_rccl_comm_create(id, nranks, rank) with its device current.  asr_rccl_all_reduce_f32 queues buf <- sum over ranks, in
  * place, on `stream`.  asr_rccl_comm_check returns the communicator's asynchronous error state (0 = healthy).  asr_rccl_comm_abort tears
  * a communicator down without waiting for outstanding collectives (peers see an asynchronous error instead of waiting forever);
- * asr_graphx_launch does that itself when a step with collective nodes fails part-way - such a failure is fatal for the job. */
+ * when asr_graphx_launch fails part-way through a step with collective nodes - fatal for the job - it returns ASR_ERR_COLLECTIVE_STEP and
+ * forgets the (borrowed) communicator: the OWNER then calls asr_rccl_comm_abort on it and drops its handle (ops.RcclComm.abort). */
 #define ASR_RCCL_ID_BYTES 128
+#define ASR_ERR_COLLECTIVE_STEP (-6)
 int asr_rccl_load(const char* path);
 int asr_rccl_version(int* version);
 int asr_rccl_unique_id(void* out_id);

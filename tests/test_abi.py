@@ -3,6 +3,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 import asr_amd
 from asr_amd import _lib
 
@@ -23,7 +25,7 @@ def test_library_builds_and_loads():
     path = asr_amd.build_library()
     assert os.path.exists(path)
     L = asr_amd.lib()
-    assert L.asr_version() >= 100
+    assert L.asr_version() >= 101
     assert L.asr_last_error() is not None
 
 
@@ -83,20 +85,43 @@ def test_launch_budget_is_per_host_thread_and_restored_by_the_context():
     L = _lib.lib()
     assert L.asr_launch_budget(0) == 0
     with ops.launch_budget(96):
-        assert L.asr_launch_budget(96) == 96 and ops._BUDGET == 96
+        assert L.asr_launch_budget(96) == 96 and ops._BUDGET.cus == 96
         with ops.launch_budget(0):                    # "no budget" inside a budgeted region
-            assert L.asr_launch_budget(0) == 0 and ops._BUDGET == 0
-        assert L.asr_launch_budget(96) == 96 and ops._BUDGET == 96
+            assert L.asr_launch_budget(0) == 0 and ops._BUDGET.cus == 0
+        assert L.asr_launch_budget(96) == 96 and ops._BUDGET.cus == 96
         seen = []
-        t = threading.Thread(target=lambda: seen.append(L.asr_launch_budget(0)))      # another host thread starts with none
+        t = threading.Thread(target=lambda: seen.append((L.asr_launch_budget(0), ops._BUDGET.cus)))      # another host thread starts with none, on both halves
         t.start()
         t.join()
-        assert seen == [0]
-    assert L.asr_launch_budget(0) == 0 and ops._BUDGET == 0
+        assert seen == [(0, 0)]
+    assert L.asr_launch_budget(0) == 0 and ops._BUDGET.cus == 0
     try:
         with ops.launch_budget(64):
             raise RuntimeError("x")
     except RuntimeError:
         pass
-    assert L.asr_launch_budget(0) == 0 and ops._BUDGET == 0
+    assert L.asr_launch_budget(0) == 0 and ops._BUDGET.cus == 0
     assert L.asr_launch_budget(-5) == 0 and L.asr_launch_budget(0) == 0      # negative = none
+
+
+def test_rccl_comm_abort_drops_the_handle_and_evicts_the_cache_entry():
+    """a communicator the graph executor borrowed is aborted by its OWNER (ops.RcclComm.abort) - the handle is dropped and the
+    per-group cache forgets it, so neither the atexit teardown nor a later rccl_comm() touches freed memory.  (No RCCL call is made here:
+    a null-library abort is a no-op in C; what is checked is the host-side ownership logic.)"""
+    from asr_amd import ops
+    c = ops.RcclComm(None, 1, 0)
+    class _Key:
+        pass
+    key = _Key()
+    ops._RCCL["comms"][key] = c
+    c.handle = 0          # "no communicator": abort must still evict
+    c.abort()
+    assert key not in ops._RCCL["comms"] and all(v is not c for v in ops._RCCL["comms"].values())
+    assert c.handle is None
+    with pytest.raises(RuntimeError, match="aborted or destroyed"):
+        c.check()
+    with pytest.raises(RuntimeError, match="aborted or destroyed"):
+        c._live()
+    assert ops.ERR_COLLECTIVE_STEP == -6
+    hdr = open(_lib.HEADER).read()
+    assert "#define ASR_ERR_COLLECTIVE_STEP (-6)" in hdr
