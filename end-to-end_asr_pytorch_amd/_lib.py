@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
-SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "vocab.hip", "graph_exec.hip", "collective.hip", "dgrad_rows.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "attention_bwd4.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
+SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "ffn2.hip", "vocab.hip", "graph_exec.hip", "collective.hip", "dgrad_rows.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "attention_bwd4.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
            "backward.hip", "wgrad.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
 EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")

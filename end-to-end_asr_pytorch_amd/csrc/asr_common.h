@@ -34,6 +34,10 @@ int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const v
                             asr_dropout_t drop, const uint32_t* drop_bits);
 // collective.hip: the function of the bucket-ready marker node (graph_exec.hip turns such a node into an all-reduce call) and the call
 const void* asr_collective_marker_func();
+// asr_ffn_fwd's launch (ffn2.hip; arguments checked by ffn.hip)
+int asr_ffn_fwd2_launch(hipStream_t stream, const void* x16, const float* x32, const void* w1, const float* b1, const void* w2, const float* b2,
+                        const float* gamma, const float* beta, const int32_t* row_len, void* hid_out, void* bits_out, float* s_out, float* y32,
+                        void* y16, float* mean_out, float* rstd_out, int M, int L, int d_ff, float eps, asr_dropout_t drop_x);
 int asr_launch_budget_current();     // common.hip: asr_launch_budget (0 = none)
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \
@@ -187,6 +191,13 @@ __device__ __forceinline__ u32x4 load128_asm(u32x4 rsrc, unsigned voff, unsigned
     u32x4 v;
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     return v;
+}
+// two 16-bit loads (same lane offset, two scalar offsets), zero-extended (no d16_hi form: with SRAM ECC a d16 load clears the other half)
+__device__ __forceinline__ u32x2 load16x2_asm(u32x4 rsrc, unsigned voff, unsigned soff_lo, unsigned soff_hi) {
+    uint32_t lo, hi;
+    asm volatile("s_nop 4\n\tbuffer_load_ushort %0, %2, %3, %4 offen\n\tbuffer_load_ushort %1, %2, %3, %5 offen"
+                 : "=&v"(lo), "=&v"(hi) : "v"(voff), "s"(rsrc), "s"(soff_lo), "s"(soff_hi) : "memory");
+    return u32x2{lo, hi};
 }
 __device__ __forceinline__ uint32_t load32_asm(u32x4 rsrc, unsigned voff, unsigned soff) {
     uint32_t v;

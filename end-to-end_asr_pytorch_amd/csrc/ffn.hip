@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
     u32x4 Hf[4];
     const auto rsh = __builtin_amdgcn_make_buffer_rsrc(a.dhid, 0, (int)((int64_t)a.M * dff * 2), 0x00020000);
     const u32x4 rsb = rsrc_words(a.bits, (unsigned)((int64_t)NC * 2 * a.Mp * 4));
-    const unsigned boff = ((unsigned)h * a.Mp + mc) * 4u;
+    const unsigned boff = ((unsigned)h * a.Mp + mc) * 2u;      // uint16 [chunk][tile t][lane half h][token]: ffn2.hip's mask image
     const unsigned hwr = (unsigned)(r * 128), hrd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));      // as in the forward
     unsigned hoff[4];
 #pragma unroll
@@ -558,10 +558,10 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
     auto frag2 = [&](const unsigned char* w1, int k) {      // second product, MFMA k: k-step k >> 3 (16 rows), row tile k & 7 of dX^T
         return tr_pair(w1 + a2[k & 3] + (k >> 3) * 8192 + ((k & 7) >> 2) * 256, 2048);
     };
-    // element e = 16 t + j of a lane's chunk: mask bit e >> 1 (e even) / 16 + (e >> 1) (e odd)
+    // element e = 16 t + j of a lane's chunk: the forward's uint16 of tile t (ffn2.hip) in half t of the word, bit j >> 1 (j even) / 8 + (j >> 1) (j odd)
     auto mask_pair = [&](const f32x16 (&S)[2], u32x4 (&Hn)[4], uint32_t word, int P) {
         const int t = P >> 3, p = P & 7;
-        const float lo = drop_and(S[t][2 * p], word, P), hi = drop_and(S[t][2 * p + 1], word, 16 + P);
+        const float lo = drop_and(S[t][2 * p], word, 16 * t + p), hi = drop_and(S[t][2 * p + 1], word, 16 * t + 8 + p);
         uint32_t pk;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(lo), "v"(hi));
         Hn[2 * t + (p >> 2)][p & 3] = pk;
@@ -574,8 +574,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
         asm volatile("" ::: "memory");                                                \
     } while (0)
 
-    auto body = [&](int i, uint32_t word_in, auto first_c, auto last_c) {
-        uint32_t word = word_in;
+    auto body = [&](int i, u32x2 word_in, auto first_c, auto last_c) {
+        uint32_t wlo = word_in[0], whi = word_in[1], word = 0;
         constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
         const unsigned char* w2 = w2s + (i & 1) * W2BUF;
         const unsigned char* w1 = w1s + ((i - 1) & 1) * W1BUF;
@@ -602,7 +602,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
                 if (!FIRST && k >= 24 && k < 28) Hout[k - 24] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 24) * 1024);
                 FFN_STEP();
             }
-            asm volatile("s_waitcnt vmcnt(16)" : "+v"(word));      // the mask word: older than this iteration's 16 DMA pieces
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(wlo), "+v"(whi));      // the two mask shorts: older than this iteration's 16 DMA pieces
+            word = wlo | (whi << 16);
             FFN_STEP();
         } else {
 #pragma unroll
@@ -634,17 +635,17 @@ __global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
         }
     };
     {
-        const uint32_t word = load32_asm(rsb, boff, 0);
+        const u32x2 word = load16x2_asm(rsb, boff, 0, 4u * a.Mp);
         body(0, word, std::true_type{}, std::false_type{});
         FFN_WAIT_STAGE(0);
     }
     for (int i = 1; i < NC; ++i) {
         // this chunk's mask word: issued BEFORE the iteration's LDS-DMA, waited for (vmcnt(16)) where the second product begins
-        const uint32_t word = load32_asm(rsb, boff, i * (2 * a.Mp * 4));
+        const u32x2 word = load16x2_asm(rsb, boff, i * (2 * a.Mp * 4), i * (2 * a.Mp * 4) + 4u * a.Mp);
         body(i, word, std::false_type{}, std::false_type{});
         FFN_WAIT_STAGE(4);
     }
-    body(NC, 0u, std::false_type{}, std::true_type{});
+    body(NC, u32x2{0u, 0u}, std::false_type{}, std::true_type{});
 #undef FFN_WAIT_STAGE
 #undef FFN_STEP
 
@@ -990,18 +991,10 @@ extern "C" int asr_ffn_fwd(void* stream, const void* x16, const float* x32, cons
     ASR_REQUIRE(asr_aligned(x16, 16) && asr_aligned(x32, 16) && asr_aligned(w1, 16) && asr_aligned(w2, 16) && asr_aligned(y32, 16) &&
                     asr_aligned(hid_out, 16) && asr_aligned(s_out, 16) && asr_aligned(y16, 8) && asr_aligned(b1, 16) && asr_aligned(b2, 16) &&
                     asr_aligned(gamma, 16) && asr_aligned(beta, 16), -1, "asr_ffn_fwd: 16-byte aligned buffers required");
-    const int M = (int)M64;
-    FfnFwdArgs a{(const bf16_t*)x16, x32, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gamma, beta, row_len, (bf16_t*)hid_out,
-                 (uint32_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x,
-                 0};
-    const dim3 grid((M + FBM - 1) / FBM), block(256);
-    const bool dr = drop_x.thr16 != 0;
-    if (hid_out && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
-    else if (hid_out) hipLaunchKernelGGL((ffn_fwd_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
-    else if (dr) hipLaunchKernelGGL((ffn_fwd_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((ffn_fwd_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
-    ASR_LAUNCH_CHECK("asr_ffn_fwd");
-    return 0;
+    ASR_REQUIRE(asr_aligned(bits_out, 4), -1, "asr_ffn_fwd: bits_out must be 4-byte aligned");
+    // the two-waves-per-SIMD form (ffn2.hip: generated loop + this sub-layer's epilogue)
+    return asr_ffn_fwd2_launch((hipStream_t)stream, x16, x32, w1, b1, w2, b2, gamma, beta, row_len, hid_out, bits_out, s_out, y32, y16, mean_out,
+                               rstd_out, (int)M64, L, d_ff, eps, drop_x);
 }
 
 extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,

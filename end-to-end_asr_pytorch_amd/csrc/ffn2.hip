@@ -1,0 +1,243 @@
+// Position-wise feed-forward sub-layer of an encoder layer at TWO waves per SIMD (d_model = 256): the forward launch.
+//   y = LayerNorm(dropout(relu(x W1^T + b1) W2^T + b2) + x) [* non_pad_mask]                    src/transformer/module.py:48-53, encoder.py:77
+// Same decomposition as ffn.hip (a workgroup owns 128 tokens and streams W1 / W2 in 64-unit chunks through LDS-DMA double buffers,
+// the hidden activation never makes a round trip through HBM), re-cut for eight waves: waves wv and wv + 4 share a SIMD and the 32
+// tokens of pair wv & 3; per chunk each takes a 32-unit half of the first product and a 128-row half of the second, the ReLU-ed halves
+// cross through a 4-KiB LDS tile per pair.  The loop is a generated instruction stream (tools/gen_ffn_fwd.py -> ffn_fwd2_asm.inc:
+// fixed registers, every LDS-DMA request / fragment read / ReLU slice placed in an MFMA gap); this file is its C++ frame:
+//   prologue  every lane-dependent address of the loop, computed here with ffn.hip's formulas and left in LDS (one dword per thread
+//             and parameter) - the asm block has no VGPR inputs, so the compiler's registers and the block's 176 + 64 never compete
+//   epilogue  bias + dropout + residual + LayerNorm + row mask over whole token rows read back from the pair's LDS tile
+//             (add_layernorm_fwd_kernel's arithmetic; outputs as asr_gemm_nt x 2 + asr_add_layernorm_fwd leave them)
+// Mask image (training, private between this launch and asr_ffn_bwd*): uint16 [chunk][half w][lane half h][token], bit p = unit 2 p of
+// the lane's 16 units of the half positive, bit 8 + p = unit 2 p + 1 (a lane's units: e = register index of the 32 x 32 accumulator).
+#include "asr_common.h"
+
+#include <stdlib.h>
+
+#include "ffn_fwd2_params.h"
+#ifndef FFN2_FWD_INC
+#define FFN2_FWD_INC "ffn_fwd2_asm.inc"
+#endif
+#include FFN2_FWD_INC
+
+namespace {
+
+constexpr int FBM = 128, FHC = 64, FD = 256;
+constexpr int W2RING = 65536, HXRING = 131072;
+constexpr int SMEM2 = 163840;       // W1 ring 2 x 32 KiB | W2 ring 2 x 32 KiB (first: the parameter area) | H tiles [2][4][4 KiB]
+
+__device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_perm<0xB1>(v);
+    v += dpp_perm<0x4E>(v);
+    v += dpp_perm<0x141>(v);
+    v += dpp_perm<0x140>(v);
+    const int iv = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
+}
+
+struct Ffn2Args {
+    const bf16_t* x16;
+    const float* x32;
+    const bf16_t* w1;
+    const float* b1;
+    const bf16_t* w2;
+    const float* b2;
+    const float* gamma;
+    const float* beta;
+    const int32_t* row_len;
+    bf16_t* hid;
+    uint16_t* bits;
+    float* s_out;
+    float* y32;
+    bf16_t* y16;
+    float* mean;
+    float* rstd;
+    int M, L, dff, Mp;
+    float eps;
+    asr_dropout_t drop;
+};
+
+template <bool TRAIN, bool DROP>
+__global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = wv & 3, w = wv >> 2;
+    const int r = lane & 31, h = lane >> 5;
+    const int mbase = blockIdx.x * FBM + 32 * p;
+    const int m = mbase + r;
+    const int mc = m < a.M ? m : a.M - 1;
+    const int dff = a.dff, NC = dff / FHC;
+    const unsigned smem0 = lds_addr_of(smem);
+    {
+        // ---- the loop's per-lane parameters (tools/gen_ffn_fwd.py: PARAMS), formulas of ffn.hip's images ----
+        unsigned* const P = reinterpret_cast<unsigned*>(smem + W2RING) + tid;
+        auto put = [&](int k, unsigned val) { P[k * 512] = val; };
+        const int ur = swap23(r), u15 = ur & 15;
+        // W1 chunk image [64 units][512 B]: 16-byte slot pc of row u holds chunk (pc & 16) | ((pc ^ u) & 15); this wave's units 32 w + ur
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) put(FFN2_P_A1_0 + kk, smem0 + (unsigned)(w * 16384 + ur * 512 + (((2 * kk + h) ^ u15) << 4)));
+        // W2 chunk image [256 d][128 B]: slot pc of row d holds chunk pc ^ ((d >> 1) & 7); this wave's rows 128 w + 32 ytl + r; k-step sg
+        auto a2 = [&](int sg) { return smem0 + (unsigned)(W2RING + w * 16384 + r * 128 + (((2 * sg + h) ^ ((r >> 1) & 7)) << 4)); };
+        put(FFN2_P_A2O_0, a2(2 * w));
+        put(FFN2_P_A2O_1, a2(2 * w + 1));
+        put(FFN2_P_A2P_0, a2(2 * (1 - w)));
+        put(FFN2_P_A2P_1, a2(2 * (1 - w) + 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pi = wv * 4 + j;
+            {
+                const int u = 2 * pi + (lane >> 5), pc = lane & 31;
+                put(FFN2_P_OFF1_0 + j, (unsigned)(u * FD * 2 + ((pc & 16) | ((pc ^ u) & 15)) * 16));
+            }
+            {
+                const int d = 8 * pi + (lane >> 3), pc = lane & 7;
+                put(FFN2_P_OFF2_0 + j, (unsigned)(d * dff * 2 + (pc ^ ((d >> 1) & 7)) * 16));
+            }
+        }
+        // the pair's H tile [32 tok][128 B], 16-byte slot s of token t at s ^ (t & 7): this lane writes units 32 w + 16 g + 8 h .. + 8 of
+        // its token (slot 4 w + 2 g + h), reads the partner's, and reads back whole rows (tokens 16 w + 8 ps + lane / 8) for the stores
+        const unsigned hx = smem0 + (unsigned)(HXRING + p * 4096);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            put(FFN2_P_HXW_0 + g, hx + (unsigned)(r * 128 + (((4 * w + 2 * g + h) ^ (r & 7)) << 4)));
+            put(FFN2_P_HXP_0 + g, hx + (unsigned)(r * 128 + (((4 * (1 - w) + 2 * g + h) ^ (r & 7)) << 4)));
+            const int tk = 16 * w + 8 * g + (lane >> 3), pc = lane & 7;
+            put(FFN2_P_HXR_0 + g, hx + (unsigned)(tk * 128 + ((pc ^ (tk & 7)) << 4)));
+            const int mt = mbase + tk;
+            put(FFN2_P_HOFF_0 + g, (TRAIN && mt < a.M) ? (unsigned)mt * (unsigned)dff * 2u + 16u * pc : 0x80000000u);
+        }
+        put(FFN2_P_BOFF, (TRAIN && m < a.M) ? ((unsigned)h * a.Mp + m) * 2u : 0x80000000u);
+        put(FFN2_P_BIOFF, (unsigned)(w * 128 + 32 * h));
+        put(FFN2_P_XOFF, (unsigned)mc * (FD * 2u) + 16u * h);
+    }
+    __syncthreads();
+    {
+        const uint64_t xb = (uint64_t)a.x16, w1b = (uint64_t)a.w1, w2b = (uint64_t)a.w2, b1b = (uint64_t)a.b1;
+        const uint64_t hb = (uint64_t)a.hid, bb = (uint64_t)a.bits;
+        const unsigned xbytes = (unsigned)a.M * (FD * 2u), wbytes = (unsigned)dff * (FD * 2u), b1bytes = (unsigned)dff * 4u;
+        const unsigned hbytes = TRAIN ? (unsigned)((int64_t)a.M * dff * 2) : 0u, bbytes = TRAIN ? (unsigned)((int64_t)NC * 4 * a.Mp * 2) : 0u;
+        const unsigned bstride = 8u * a.Mp, bsoff0 = (unsigned)w * 4u * a.Mp;
+        const unsigned w1dst = smem0 + (unsigned)wv * 4096u, w2dst = smem0 + W2RING + (unsigned)wv * 4096u;
+        const unsigned ybase = smem0 + (unsigned)(p * 32768 + w * 512), pbase = smem0 + W2RING + (unsigned)wv * 256u;
+#define FFN2_OPERANDS                                                                                                                     \
+    [xb] "s"(xb), [w1b] "s"(w1b), [w2b] "s"(w2b), [b1b] "s"(b1b), [hb] "s"(hb), [bb] "s"(bb), [xbytes] "s"(xbytes), [wbytes] "s"(wbytes), \
+        [b1bytes] "s"(b1bytes), [hbytes] "s"(hbytes), [bbytes] "s"(bbytes), [nc] "s"(NC), [bstride] "s"(bstride), [bsoff0] "s"(bsoff0),    \
+        [w1dst] "s"(w1dst), [w2dst] "s"(w2dst), [ybase] "s"(ybase), [pbase] "s"(pbase)
+        if constexpr (TRAIN) asm volatile(FFN2_FWD_ASM_TRAIN : : FFN2_OPERANDS : FFN2_FWD_ASM_CLOBBERS);
+        else asm volatile(FFN2_FWD_ASM_EVAL : : FFN2_OPERANDS : FFN2_FWD_ASM_CLOBBERS);
+#undef FFN2_OPERANDS
+    }
+    // ---- epilogue: v = dropout(Y + b2) + x, LayerNorm, row mask; this wave's 16 rows of the pair's tile [32 tok][256] f32 ----------------
+    const int m0 = mbase + 16 * w;
+    f32x4 res[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;
+        res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
+    }
+    uint32_t keepmask = 0xffffu;
+    const int m0c = m0 < a.M ? m0 : a.M - 1;
+    const int b_first = m0c / a.L, t_first = m0c - b_first * a.L;
+    if (a.row_len) {
+        keepmask = 0;
+        int bb = b_first, tt = t_first, len = a.row_len[bb];
+        for (int tr = 0; tr < 16; ++tr) {
+            keepmask |= (tt < len ? 1u : 0u) << tr;
+            if (++tt == a.L) {
+                tt = 0;
+                if (m0 + tr + 1 < a.M) len = a.row_len[++bb];
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned char* const tile = smem + p * 32768 + (16 * w) * 1024;
+    const asr_dropout_t drop = drop_resolve(a.drop);
+    const float sc = drop_scale(drop);
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * lane);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * lane), bt = *reinterpret_cast<const f32x4*>(a.beta + 4 * lane);
+    const auto rss = __builtin_amdgcn_make_buffer_rsrc(a.s_out, 0, a.s_out ? (int)((int64_t)a.M * FD * 4) : 0, 0x00020000);
+    const auto rsy = __builtin_amdgcn_make_buffer_rsrc(a.y32, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(a.y16, 0, a.y16 ? (int)((int64_t)a.M * FD * 2) : 0, 0x00020000);
+    const auto rsm = __builtin_amdgcn_make_buffer_rsrc(a.mean, 0, a.mean ? a.M * 4 : 0, 0x00020000);
+    const auto rsr = __builtin_amdgcn_make_buffer_rsrc(a.rstd, 0, a.rstd ? a.M * 4 : 0, 0x00020000);
+    int bb = b_first, tt = t_first;
+    uint32_t sub = DROP ? drop_subkey(drop, (uint32_t)bb) : 0u;
+    float mean_l = 0.f, rstd_l = 0.f;
+#pragma unroll
+    for (int tr0 = 0; tr0 < 16; tr0 += 8) {
+        f32x4 v[8];
+        float part[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tr = tr0 + j;       // (token 16 w + tr of the pair: its swizzle key is tr & 7)
+            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (j & 7)) << 4));
+            f32x4 wv4 = y + b2v;
+            if (DROP) {
+                wv4 = drop4(drop, sub, (uint32_t)tt, FD >> 1, (uint32_t)(4 * lane), wv4, sc);
+                if (++tt == a.L) {
+                    tt = 0;
+                    sub = drop_subkey(drop, (uint32_t)++bb);
+                }
+            }
+            v[j] = wv4 + res[tr];
+            part[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mean[j] = wave_sum_dpp(part[j]) * (1.f / FD);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 dl = v[j] - mean[j];
+            part[j] = (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(wave_sum_dpp(part[j]) * (1.f / FD) + a.eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tr = tr0 + j, row = m0 + tr;
+            const bool rv = row < a.M;
+            const unsigned o16 = rv ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u;
+            if (TRAIN) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rss, o16, 0, 0);
+                mean_l = lane == tr ? mean[j] : mean_l;
+                rstd_l = lane == tr ? rstd[j] : rstd_l;
+            }
+            f32x4 o = (v[j] - mean[j]) * rstd[j] * gm + bt;
+            if (!((keepmask >> tr) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, o16, 0, 0);
+            const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsz, rv ? (unsigned)row * (FD * 2u) + 8u * lane : 0x80000000u, 0, 0);
+        }
+    }
+    if (TRAIN) {
+        const unsigned o4 = (lane < 16 && m0 + lane < a.M) ? (unsigned)(m0 + lane) * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mean_l), rsm, o4, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rstd_l), rsr, o4, 0, 0);
+    }
+}
+
+}  // namespace
+
+// asr_ffn_fwd's launch (ffn.hip checks the arguments and calls here)
+int asr_ffn_fwd2_launch(hipStream_t stream, const void* x16, const float* x32, const void* w1, const float* b1, const void* w2, const float* b2,
+                        const float* gamma, const float* beta, const int32_t* row_len, void* hid_out, void* bits_out, float* s_out, float* y32,
+                        void* y16, float* mean_out, float* rstd_out, int M, int L, int d_ff, float eps, asr_dropout_t drop_x) {
+    Ffn2Args a{(const bf16_t*)x16, x32, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gamma, beta, row_len, (bf16_t*)hid_out,
+               (uint16_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x};
+    const dim3 grid((M + FBM - 1) / FBM), block(512);
+    const bool dr = drop_x.thr16 != 0;
+    if (hid_out && dr) hipLaunchKernelGGL((ffn_fwd2_kernel<true, true>), grid, block, 0, stream, a);
+    else if (hid_out) hipLaunchKernelGGL((ffn_fwd2_kernel<true, false>), grid, block, 0, stream, a);
+    else if (dr) hipLaunchKernelGGL((ffn_fwd2_kernel<false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((ffn_fwd2_kernel<false, false>), grid, block, 0, stream, a);
+    ASR_LAUNCH_CHECK("asr_ffn_fwd");
+    return 0;
+}
