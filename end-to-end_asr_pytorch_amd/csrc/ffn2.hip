@@ -13,6 +13,7 @@
 // the lane's 16 units of the half positive, bit 8 + p = unit 2 p + 1 (a lane's units: e = register index of the 32 x 32 accumulator).
 #include "asr_common.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "ffn_fwd2_params.h"
@@ -65,7 +66,7 @@ struct Ffn2Args {
 };
 
 template <bool TRAIN, bool DROP>
-__global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a) {
+__global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a0) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a) {
     const int r = lane & 31, h = lane >> 5;
     const int mbase = blockIdx.x * FBM + 32 * p;
     const int m = mbase + r;
-    const int mc = m < a.M ? m : a.M - 1;
-    const int dff = a.dff, NC = dff / FHC;
+    const int mc = m < a0.M ? m : a0.M - 1;
+    const int dff = a0.dff, NC = dff / FHC;
     const unsigned smem0 = lds_addr_of(smem);
     {
         // ---- the loop's per-lane parameters (tools/gen_ffn_fwd.py: PARAMS), formulas of ffn.hip's images ----
@@ -112,30 +113,28 @@ __global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a) {
             const int tk = 16 * w + 8 * g + (lane >> 3), pc = lane & 7;
             put(FFN2_P_HXR_0 + g, hx + (unsigned)(tk * 128 + ((pc ^ (tk & 7)) << 4)));
             const int mt = mbase + tk;
-            put(FFN2_P_HOFF_0 + g, (TRAIN && mt < a.M) ? (unsigned)mt * (unsigned)dff * 2u + 16u * pc : 0x80000000u);
+            put(FFN2_P_HOFF_0 + g, (TRAIN && mt < a0.M) ? (unsigned)mt * (unsigned)dff * 2u + 16u * pc : 0x80000000u);
         }
-        put(FFN2_P_BOFF, (TRAIN && m < a.M) ? ((unsigned)h * a.Mp + m) * 2u : 0x80000000u);
-        put(FFN2_P_BIOFF, (unsigned)(w * 128 + 32 * h));
+        put(FFN2_P_BOFF, (TRAIN && m < a0.M) ? ((unsigned)h * a0.Mp + m) * 2u : 0x80000000u);
         put(FFN2_P_XOFF, (unsigned)mc * (FD * 2u) + 16u * h);
     }
     __syncthreads();
     {
-        const uint64_t xb = (uint64_t)a.x16, w1b = (uint64_t)a.w1, w2b = (uint64_t)a.w2, b1b = (uint64_t)a.b1;
-        const uint64_t hb = (uint64_t)a.hid, bb = (uint64_t)a.bits;
-        const unsigned xbytes = (unsigned)a.M * (FD * 2u), wbytes = (unsigned)dff * (FD * 2u), b1bytes = (unsigned)dff * 4u;
-        const unsigned hbytes = TRAIN ? (unsigned)((int64_t)a.M * dff * 2) : 0u, bbytes = TRAIN ? (unsigned)((int64_t)NC * 4 * a.Mp * 2) : 0u;
-        const unsigned bstride = 8u * a.Mp, bsoff0 = (unsigned)w * 4u * a.Mp;
-        const unsigned w1dst = smem0 + (unsigned)wv * 4096u, w2dst = smem0 + W2RING + (unsigned)wv * 4096u;
-        const unsigned ybase = smem0 + (unsigned)(p * 32768 + w * 512), pbase = smem0 + W2RING + (unsigned)wv * 256u;
-#define FFN2_OPERANDS                                                                                                                     \
-    [xb] "s"(xb), [w1b] "s"(w1b), [w2b] "s"(w2b), [b1b] "s"(b1b), [hb] "s"(hb), [bb] "s"(bb), [xbytes] "s"(xbytes), [wbytes] "s"(wbytes), \
-        [b1bytes] "s"(b1bytes), [hbytes] "s"(hbytes), [bbytes] "s"(bbytes), [nc] "s"(NC), [bstride] "s"(bstride), [bsoff0] "s"(bsoff0),    \
-        [w1dst] "s"(w1dst), [w2dst] "s"(w2dst), [ybase] "s"(ybase), [pbase] "s"(pbase)
-        if constexpr (TRAIN) asm volatile(FFN2_FWD_ASM_TRAIN : : FFN2_OPERANDS : FFN2_FWD_ASM_CLOBBERS);
-        else asm volatile(FFN2_FWD_ASM_EVAL : : FFN2_OPERANDS : FFN2_FWD_ASM_CLOBBERS);
-#undef FFN2_OPERANDS
+        // the block reads the kernel's arguments itself (tools/gen_ffn_fwd.py: KA_*), so that its only inputs are three scalars
+        static_assert(offsetof(Ffn2Args, x16) == 0 && offsetof(Ffn2Args, w1) == 16 && offsetof(Ffn2Args, b1) == 24 && offsetof(Ffn2Args, w2) == 32 &&
+                          offsetof(Ffn2Args, hid) == 72 && offsetof(Ffn2Args, bits) == 80 && offsetof(Ffn2Args, M) == 128 &&
+                          offsetof(Ffn2Args, dff) == 136 && offsetof(Ffn2Args, Mp) == 140, "tools/gen_ffn_fwd.py reads Ffn2Args by offset");
+        const uint64_t ka = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+        if constexpr (TRAIN) asm volatile(FFN2_FWD_ASM_TRAIN : : [ka] "s"(ka), [wv] "s"(wv), [smem0] "s"(smem0) : FFN2_FWD_ASM_CLOBBERS);
+        else asm volatile(FFN2_FWD_ASM_EVAL : : [ka] "s"(ka), [wv] "s"(wv), [smem0] "s"(smem0) : FFN2_FWD_ASM_CLOBBERS);
     }
     // ---- epilogue: v = dropout(Y + b2) + x, LayerNorm, row mask; this wave's 16 rows of the pair's tile [32 tok][256] f32 ----------------
+    // (the arguments are read again from the kernel-argument segment: kept in scalar registers across the block they would have to be
+    // spilled - the block owns s20-s101)
+    typedef __attribute__((address_space(4))) const Ffn2Args* kernarg_ptr_t;
+    kernarg_ptr_t eap = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(eap));
+    __attribute__((address_space(4))) const Ffn2Args& a = *eap;
     const int m0 = mbase + 16 * w;
     f32x4 res[16];
 #pragma unroll
@@ -159,7 +158,9 @@ __global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a) {
     }
     __syncthreads();
     const unsigned char* const tile = smem + p * 32768 + (16 * w) * 1024;
-    const asr_dropout_t drop = drop_resolve(a.drop);
+    asr_dropout_t drop_arg;      // (field by field: the argument block lives in the constant address space)
+    drop_arg.thr16 = a.drop.thr16; drop_arg.key0 = a.drop.key0; drop_arg.key1 = a.drop.key1; drop_arg.salt = a.drop.salt;
+    const asr_dropout_t drop = drop_resolve(drop_arg);
     const float sc = drop_scale(drop);
     const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * lane);
     const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * lane), bt = *reinterpret_cast<const f32x4*>(a.beta + 4 * lane);

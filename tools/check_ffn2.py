@@ -56,7 +56,28 @@ def timeit(train, drop, n=30, dff=2048):
     print("ffn_fwd [32000 x 256 x %d] train %d drop %d: %.1f us = %.0f TF" % (dff, train, drop, best, 2 * 2.0 * 32000 * 256 * dff / best / 1e6), flush=True)
 
 
+def stamps():
+    """--stamps (a tools/gen_ffn_fwd.py --abl 64 build): cycles and 100-MHz ticks the loop took, per wave"""
+    B, L, dff = 32, 1000, 2048
+    x32, w1, b1, w2, b2, gam, bet, lens = _case(B, L, dff, seed=1)
+    args = (d(x32.bfloat16()), d(x32), d(w1), d(b1), d(w2), d(b2), d(gam), d(bet), B, L)
+    for _ in range(20):
+        hid = ops.ffn_fwd(*args, row_len=d(lens).int(), train=True, drop_x=ops.Dropout(THR, 5, 9))[0]
+    torch.cuda.synchronize()
+    w = hid.view(torch.int32).view(B * L, dff // 2)[:, :4].cpu().numpy().astype(np.int64) & 0xffffffff
+    w = w[::8]                      # one stamp per group of 8 rows (lanes with piece 0)
+    cyc = (w[:, 2] - w[:, 0]) & 0xffffffff
+    tick = (w[:, 3] - w[:, 1]) & 0xffffffff
+    ok = (tick > 0) & (tick < 100000)
+    cyc, tick = cyc[ok], tick[ok]
+    print("loop: cycles median %d (min %d max %d), 100-MHz ticks median %d -> %.2f us, clock %.2f GHz; per chunk %.0f cycles" %
+          (np.median(cyc), cyc.min(), cyc.max(), np.median(tick), np.median(tick) / 100.0, np.median(cyc) / np.median(tick) / 10.0, np.median(cyc) / (dff // 64)), flush=True)
+
+
 if __name__ == "__main__":
+    if "--stamps" in sys.argv:
+        stamps()
+        sys.exit(0)
     if "--time-only" not in sys.argv:
         for c in [(1, 5, 64, False), (4, 37, 128, False), (2, 128, 256, True), (5, 129, 512, True), (3, 100, 2048, True)]:
             check(*c)
