@@ -228,6 +228,7 @@ def _prefetch_attn_masks(sites, training, device):
 # gradients - all through the HIP kernels of backward.hip / attention_bwd.hip / gemm.hip.  Recording needs bf16 precision.
 _TAPE = None
 _DIRECT_CONV_BWD = True     # the conv layers' direct backward kernels (bf16); the patch-matrix route stays as the f32 parity path
+_CONV_F32 = 0               # 1: the conv front end (forward and backward) as an f32 island inside the bf16 step (tools/s2_grad_err.py)
 _DECODE_FUSED = True      # one-launch sub-layers in the per-token decode steps (decode_blocks.hip)
 _IN_DECODE_STEP = False    # set while a per-token decode step is being queued / captured (rows = hypotheses, one position each)
 
@@ -805,6 +806,9 @@ class Conv2dSubsample(_Cached):
         return m.weight, m.bias
 
     def _impl(self, feats, feat_lengths):
+        if _CONV_F32 and _PRECISION == "bf16":
+            with precision("f32"):
+                return self._impl(feats, feat_lengths)
         B, T, D = feats.shape
         n = self.n_layers
         F = self.d_conv_out
@@ -847,7 +851,12 @@ class Conv2dSubsample(_Cached):
         B, T, D = feats.shape
         convs = [getattr(self.conv, "subsample/conv{}".format(i)) for i in range(n)]
 
+        island = _PRECISION == "f32" and _CONV_F32
+
         def bw():
+            if island and _PRECISION == "bf16":
+                with precision("f32"):
+                    return bw()
             d_out = act.grad
             act.grad = None
             d = d_out.shape[1]
