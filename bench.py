@@ -67,6 +67,8 @@ def parse_args():
                          "side streams - the run tools/profile_r5.sh puts under rocprofv3 for kernel_stats.csv")
     ap.add_argument("--side-budget", type=int, default=-1,
                     help="Trainer.side_budget: launch budget (CUs) of the CTC branch's backward on the side stream; 0 = full grids, -1 = the trainer's default")
+    ap.add_argument("--trainer-set", action="append", default=[], metavar="NAME=INT",
+                    help="A/B runs: set a Trainer attribute (fused_ce=0, side_budget=96, ...) before the first step")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the extra legs of the default 1-GPU run (S2, CIF_Model, greedy decode: BASELINE configs[2] / [3] and SURVEY 8(f)1)")
     return ap.parse_args()
@@ -362,14 +364,14 @@ def pmc_traffic(fam_kernel, prof_dir):
     return int(tot / n) if n else None
 
 
-FAMILY_KERNEL = {"vocab_proj_ctc": "vocab_proj_ctc_kernel", "ffn_fwd": "ffn_fwd_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_v2_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
+FAMILY_KERNEL = {"vocab_proj_ctc": "vocab_proj_ctc_kernel", "ffn_fwd": "ffn_fwd2_kernel", "ffn_bwd": "ffn_bwd_kernel", "gemm_tn": "gemm_tn_v2_kernel", "gemm_nt": "gemm_nt_glds_kernel", "gemm_nn": "gemm_nn_tr_kernel",
                  "attention_fwd": "attn_fwd_bf16_v4a_kernel", "attention_bwd_dq": "attn_bwd_dq_v4_kernel", "attention_bwd_dkv": "attn_bwd_dkv_v4_kernel",
                  "add_layernorm": "add_layernorm_fwd_kernel", "add_layernorm_bwd": "add_layernorm_bwd_kernel",
                  "ctc_loss_fwd": "ctc_fused_fwd_kernel", "ctc_loss_fwd_table": "ctc_mitm_kernel", "ctc_loss_bwd": "ctc_grad_bf16_kernel", "proj_heads": "proj_heads_rows_kernel"}
 # every device kernel an op family launches, as rocprofv3's kernel_stats.csv names them (substring match): what tools/roofline_from_csv.py
 # sums to recompute a family's in-step rate from profiles/rN/bench_train_kernel_stats.csv
 FAMILY_CSV_KERNELS = {"gemm_tn": ["gemm_tn_v2_kernel", "gemm_tn_v2_group_kernel", "tn_reduce_kernel", "tn_reduce_group_kernel", "gemm_tn_kernel"],
-                      "ffn_fwd": ["ffn_fwd_kernel"], "ffn_bwd": ["ffn_bwd_kernel"], "attention_fwd": ["attn_fwd_bf16_v4a_kernel", "attn_fwd_bf16_v2_kernel"],
+                      "ffn_fwd": ["ffn_fwd2_kernel"], "ffn_bwd": ["ffn_bwd_kernel"], "attention_fwd": ["attn_fwd_bf16_v4a_kernel", "attn_fwd_bf16_v2_kernel"],
                       "attention_bwd_dq": ["attn_bwd_dq_v4_kernel", "attn_bwd_dq_kernel"], "attention_bwd_dkv": ["attn_bwd_dkv_v4_kernel", "attn_bwd_dkv_kernel"],
                       "vocab_proj_ctc": ["vocab_proj_ctc_kernel"], "ctc_loss_fwd": ["ctc_fused_fwd_kernel", "ctc_mitm_kernel"], "ctc_loss_fwd_table": ["ctc_mitm_kernel"],
                       "ctc_loss_bwd": ["ctc_grad_bf16_kernel", "ctc_grad_kernel", "ctc_mitm_kernel"]}
@@ -452,6 +454,10 @@ def main():
                if train else None)
     if trainer is not None and args.side_budget >= 0:
         trainer.side_budget = args.side_budget
+    for kv in (args.trainer_set if trainer is not None else []):
+        name, val = kv.split("=")
+        assert hasattr(trainer, name), "Trainer has no attribute %r" % name
+        setattr(trainer, name, type(getattr(trainer, name))(int(val)))
     use_graph = args.graph == 1 and trainer is not None
     auto_graph = args.graph < 0 and trainer is not None
 

@@ -1,19 +1,14 @@
-// Position-wise feed-forward sub-layer of an encoder layer as ONE forward launch and ONE data-gradient launch (d_model = 256):
-//   forward   y = LayerNorm(dropout(relu(x W1^T + b1) W2^T + b2) + x) [* non_pad_mask]      src/transformer/module.py:48-53, encoder.py:77
-//   backward  dH = (ds W2) * relu'(H),  dX = dH W1 + ds                                       (autograd of the same lines)
-// The [M, d_ff] hidden activation never makes a round trip through HBM inside either launch: a workgroup owns 128 tokens, keeps
-// their 256-wide rows in REGISTERS as MFMA B operands, and streams W1 / W2 in 64-unit chunks of the hidden dimension through a
-// double-buffered LDS image (LDS-DMA, every workgroup reads the same 2 MB of weights from its XCD's L2).  Per chunk and wave
-// (32 tokens, one wave per SIMD, the whole 512-register file):
-//   S^T[64 hidden x 32 tok]  = W1c . X^T             (v_mfma_f32_32x32x16_bf16, K = 256; accumulator starts at b1)
-//   H^T = relu(S^T) -> bf16 in the accumulator's own registers = the B operand of the second product (no LDS, no lane movement:
-//         rows of a 32x32 accumulator are the k index of the next MFMA; the hidden units are dealt to MFMA rows with bits 2 and 3
-//         of the row index swapped so that the k order the second product sees is the natural one)
-//   Y^T[256 x 32 tok]       += W2c . H^T             (K = 64)
-// The first product of chunk i and the second of chunk i - 1 share a loop iteration, so the MFMA pipe never waits for the ReLU.
-// Training also writes H once (bf16, for the weight gradient dW2 = ds^T H) and the ReLU mask as 1 bit per unit; the epilogue is
-// bias + dropout + residual + LayerNorm over the complete 256-wide row each lane pair holds (outputs: pre-norm sum, y32, y16, mean,
-// rstd - exactly what asr_gemm_nt x 2 + asr_add_layernorm_fwd leave).
+// Row-block kernels of the encoder layer at d_model = 256 (a workgroup owns 128 tokens, four waves x 32, one wave per SIMD; the tokens'
+// 256-wide rows sit in REGISTERS as MFMA B operands, the weights stream through 32-KiB LDS images by LDS-DMA):
+//   asr_ffn_bwd / asr_ffn_bwd_ln   the feed-forward sub-layer's data gradient in one launch   dH = (ds W2) * relu'(H),  dX = dH W1 + ds
+//                                  (autograd of src/transformer/module.py:48-53); per 64-unit chunk dH^T = (W2c^T . ds^T) * mask and
+//                                  dX^T += W1c^T . dH^T, dH written once (bf16, for the weight gradient dW1 = dH^T X)
+//   asr_proj_ln_fwd                attention.py:58-60: fc -> dropout -> + residual -> layer_norm
+//   asr_proj_heads (rows form)     attention.py:43-49: the head-major Q / K / V projections
+//   asr_ffn_fwd                    argument checks only - the forward launch is ffn2.hip (two waves per SIMD, generated loop); the mask image
+//                                  it leaves (uint16 [chunk][tile t][lane half h][token]) is read here by the data gradient
+// In every kernel the [M, d_ff] or [M, 3 d] intermediate never makes a round trip through HBM inside the launch, and rows leave as
+// whole 512-byte / 1-KiB lines through a per-wave LDS tile.
 #include "asr_common.h"
 
 #include <stdlib.h>
@@ -22,7 +17,7 @@
 namespace {
 
 #ifndef FFN_HID_POLICY
-#define FFN_HID_POLICY 0      // cache policy of the hidden-activation / hidden-gradient stores (A/B: 2 = non-temporal: forward 95 -> 89 us alone, the step unchanged)
+#define FFN_HID_POLICY 0      // cache policy of the hidden-gradient stores (A/B in round 3: 2 = non-temporal: the step unchanged)
 #endif
 constexpr int FBM = 128;      // tokens per workgroup (4 waves x 32)
 constexpr int FHC = 64;       // hidden units per chunk
@@ -31,15 +26,10 @@ constexpr int W1BUF = FHC * FD * 2;   // 32 KiB: [64 hidden][256 k] bf16, 512-by
 constexpr int W2BUF = FD * FHC * 2;   // 32 KiB: [256 d][64 hidden] bf16, 128-byte rows
 constexpr int FFN_MAX_DFF = 2048;
 constexpr int HST_BYTES = 4 * 4096;   // per wave: a chunk's H^T tile (32 tokens x 128 B) on its way to full-line stores
-constexpr int SMEM_BYTES = 2 * W1BUF + 2 * W2BUF + HST_BYTES + FFN_MAX_DFF * 4;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
-
-// mask word of one (token, lane half, chunk): bit P (P = 8 t + p) = unit 2P positive, bit 16 + P = unit 2P + 1 positive, where a lane's
-// 32 units of a chunk are numbered e = 16 t + j (t: 32-row tile, j: accumulator register)
-__device__ __forceinline__ int64_t bits_index(int chunk, int h, int Mp, int m) { return ((int64_t)(chunk * 2 + h)) * Mp + m; }
 
 // sum over the 64 lanes, the same value in every lane: four DPP adds inside the 16-lane rows, then the four row sums by v_readlane
 template <int CTRL> __device__ __forceinline__ float dpp_perm(float v) {
@@ -55,95 +45,61 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
            (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
-struct FfnFwdArgs {
-    const bf16_t* x16;
-    const float* x32;
-    const bf16_t* w1;
-    const float* b1;
-    const bf16_t* w2;
-    const float* b2;
+struct ProjLnArgs {
+    const bf16_t* x16;      // the attention context [M, 256] (h * d_v)
+    const float* x32;       // the residual: the layer's input
+    const bf16_t* w1;       // fc.weight [256][256]
+    const float* b2;        // fc.bias
     const float* gamma;
     const float* beta;
     const int32_t* row_len;
-    bf16_t* hid;
-    uint32_t* bits;
     float* s_out;
     float* y32;
     bf16_t* y16;
     float* mean;
     float* rstd;
-    int M, L, dff, Mp;
+    int M, L;
     float eps;
     asr_dropout_t drop;
-    int dbg;      // timing breakdowns only (tools build with it set): 1 = no epilogue
 };
 
-// PROJ: the attention sub-layer's tail at encoder size (attention.py:58-60: fc -> dropout -> + residual -> layer_norm) on the same
-// prologue and epilogue - w1 = the [256][256] output projection, no activation, no second product: the four 64-row chunks of the first
-// product ARE the 256 outputs of a token, x16 = the attention context, x32 = the residual (the layer's input), b2 = fc's bias.
-template <bool TRAIN, bool DROP, bool PROJ = false>
-__global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+// The attention sub-layer's tail at encoder size (attention.py:58-60: fc -> dropout -> + residual -> layer_norm): one product on the row-block
+// structure - a workgroup owns 128 tokens (4 waves x 32, rows in registers as MFMA B operands), the [256][256] output projection streams
+// through two 32-KiB LDS images as four 64-row chunks whose accumulators ARE the 256 outputs of a token, the epilogue is bias + dropout +
+// residual + LayerNorm + row mask over complete rows.  (The feed-forward sub-layer's forward, which this kernel was cut from, is ffn2.hip.)
+template <bool TRAIN, bool DROP>
+__global__ __launch_bounds__(256, 1) void proj_ln_kernel(const ProjLnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 32768];
     unsigned char* const w1s = smem;
-    unsigned char* const w2s = smem + 2 * W1BUF;
-    float* const b1s = reinterpret_cast<float*>(smem + 2 * W1BUF + 2 * W2BUF + HST_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* const hst = smem + 2 * W1BUF + 2 * W2BUF + wave * 4096;
     const int r = lane & 31, h = lane >> 5;
     const int m = blockIdx.x * FBM + wave * 32 + r;
-    const bool valid = m < a.M;
-    const int mc = valid ? m : a.M - 1;
-    const int dff = a.dff, NC = dff / FHC;
+    const int mc = m < a.M ? m : a.M - 1;
 
-    // ---- weight staging: buffer descriptors over the whole matrices, per-lane byte offsets fixed for the kernel's life --------------
-    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w1), 0, dff * FD * 2, 0x00020000);
-    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w2), 0, dff * FD * 2, 0x00020000);
-    unsigned off1[8], off2[8];
+    // ---- weight staging: a buffer descriptor over the matrix, per-lane byte offsets fixed for the kernel's life --------------------------
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.w1), 0, FD * FD * 2, 0x00020000);
+    unsigned off1[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int p = wave * 8 + k;
-        {   // W1 piece p: chunk rows 2p, 2p + 1 (512 B each); LDS slot pc of row u holds 16-byte chunk (pc & 16) | ((pc ^ u) & 15)
-            const int u = 2 * p + (lane >> 5), pc = lane & 31;
-            const int c = (pc & 16) | ((pc ^ u) & 15);
-            off1[k] = (unsigned)(u * FD * 2 + c * 16);
-        }
-        {   // W2 piece p: rows 8p .. 8p + 7 of the [256][64] chunk image (128 B each); slot pc of row d holds chunk pc ^ ((d >> 1) & 7)
-            const int d = 8 * p + (lane >> 3), pc = lane & 7;
-            const int c = pc ^ ((d >> 1) & 7);
-            off2[k] = (unsigned)(d * dff * 2 + c * 16);
-        }
+    for (int k = 0; k < 8; ++k) {       // piece p: chunk rows 2p, 2p + 1 (512 B each); LDS slot pc of row u holds 16-byte chunk (pc & 16) | ((pc ^ u) & 15)
+        const int p = wave * 8 + k, u = 2 * p + (lane >> 5), pc = lane & 31;
+        off1[k] = (unsigned)(u * FD * 2 + ((pc & 16) | ((pc ^ u) & 15)) * 16);
     }
-    // one 1-KiB piece (j = 0..7 of this wave's 8) of a chunk image; the loop deals the 16 pieces of an iteration over its first 16 steps
-    // (one every 4th step over the whole iteration, hidden stores behind the last of them: 101 vs 104 us train, 83 vs 82 us eval - no change),
-    // one behind each MFMA (an LDS-DMA instruction holds the wave's issue for tens of cycles: bunched in front of the MFMAs all of
-    // that time is exposed at one wave per SIMD)
     auto dma_w1 = [&](int buf, int chunk, int j) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_void*)(w1s + buf * W1BUF + (wave * 8 + j) * 1024), 16, off1[j], chunk * (FHC * FD * 2), 0, 0);
     };
-    auto dma_w2 = [&](int buf, int chunk, int j) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_void*)(w2s + buf * W2BUF + (wave * 8 + j) * 1024), 16, off2[j], chunk * (FHC * 2), 0, 0);
-    };
-
-    // ---- fragment read addresses -----------------------------------------------------------------------------------------------
-    const int ur = PROJ ? r : swap23(r);      // (PROJ: the accumulator rows are the outputs themselves, in natural order)
-    const int u15 = ur & 15;
-    unsigned a1[8], a2[4];
+    const int u15 = r & 15;      // (the accumulator rows are the outputs themselves, in natural order)
+    unsigned a1[8];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) a1[kk] = (unsigned)(ur * 512 + (((2 * kk + h) ^ u15) << 4));
-#pragma unroll
-    for (int sg = 0; sg < 4; ++sg) a2[sg] = (unsigned)(r * 128 + (((2 * sg + h) ^ ((r >> 1) & 7)) << 4));
+    for (int kk = 0; kk < 8; ++kk) a1[kk] = (unsigned)(r * 512 + (((2 * kk + h) ^ u15) << 4));
 
-    // ---- this lane's token as the first product's B operand: X[m][16 ks + 8 h .. + 8] --------------------------------------------
+    // ---- this lane's token as the product's B operand: ctx[m][16 ks + 8 h .. + 8] -----------------------------------------------------
     bf16x8 xb[16];
     {
         const bf16_t* xr = a.x16 + (int64_t)mc * FD + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(xr + 16 * ks);
     }
-    if (!PROJ)
-        for (int i = tid * 4; i < dff; i += 1024) *reinterpret_cast<f32x4*>(b1s + i) = *reinterpret_cast<const f32x4*>(a.b1 + i);
-
 #pragma unroll
     for (int j = 0; j < 8; ++j) dma_w1(0, 0, j);
     f32x16 Y[8];
@@ -154,144 +110,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    u32x4 Hf[4];        // H^T of the previous chunk as four k-steps of the second product's B operand
-    const auto rsh = __builtin_amdgcn_make_buffer_rsrc(a.hid, 0, TRAIN ? (int)((int64_t)a.M * dff * 2) : 0, 0x00020000);
-    const auto rsb = __builtin_amdgcn_make_buffer_rsrc(a.bits, 0, TRAIN ? (int)((int64_t)NC * 2 * a.Mp * 4) : 0, 0x00020000);
-    const unsigned boff = valid ? ((unsigned)h * a.Mp + m) * 4u : 0x80000000u;     // rows past M: an offset no later add brings back in range - the range check drops the store
-    // H leaves through LDS: a lane holds 16-byte pieces of ITS token's row (a store instruction would touch 32 rows, 32 bytes each);
-    // written to the wave's [32 tokens][128 B] tile (16-byte slot ^ (token & 7)) and read back 8 lanes per token, a store instruction
-    // covers 8 tokens x one full 128-byte line.  The tile of chunk i is flushed during iteration i + 1.
-    const unsigned hwr = (unsigned)(r * 128), hrd = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
-    unsigned hoff[4];
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int mt = blockIdx.x * FBM + wave * 32 + 8 * ps + (lane >> 3);
-        hoff[ps] = mt < a.M ? (unsigned)mt * (unsigned)dff * 2u + 16u * (lane & 7) : 0x80000000u;
-    }
-
-    // The loop body is pinned step by step (one MFMA per step, __builtin_amdgcn_sched_barrier(0) between steps - a wave issues in
-    // order, so whatever should run in an MFMA's shadow has to sit right behind it in the instruction stream):
-    //   steps  0..31  first product of chunk i:     MFMA k, then the LDS read of the fragment MFMA k + 8 will take (ring of 16)
-    //   steps 32..63  second product of chunk i-1:  MFMA, LDS read 8 ahead, and one slice of chunk i's ReLU / pack / mask work
-    bf16x8 A[16];
-    f32x4 res[32];      // the epilogue's residual rows, requested inside the LAST body
+    f32x4 res[32];      // the epilogue's residual rows (row layout: lane = 4 columns of a token row), requested beside the last chunk
     const int m0 = blockIdx.x * FBM + wave * 32;
-    typedef __attribute__((ext_vector_type(2))) short s16x2_t;
-    // FFN_ABL (build-time, timing only - results garbage; tools/abl_ffn.sh): 1 no fragment LDS reads (a register stands in), 2 no MFMAs
-    // in the loop, 4 no LDS-DMA of the weight chunks
-#ifndef FFN_ABL
-#define FFN_ABL 0
-#endif
-    auto frag1 = [&](const unsigned char* w1, int k) {      // first product, MFMA k: k-step k >> 1, row tile k & 1
+    auto frag1 = [&](const unsigned char* w1, int k) {      // MFMA k: k-step k >> 1, row tile k & 1
         const int ks = k >> 1, t = k & 1;
-        if constexpr ((FFN_ABL & 1) != 0) return xb[k & 15];
-        else return *reinterpret_cast<const bf16x8*>(w1 + a1[ks & 7] + t * 16384 + (ks >> 3) * 256);
+        return *reinterpret_cast<const bf16x8*>(w1 + a1[ks & 7] + t * 16384 + (ks >> 3) * 256);
     };
-    auto frag2 = [&](const unsigned char* w2, int k) {      // second product, MFMA k: k-step k >> 3, row tile k & 7 of Y^T
-        if constexpr ((FFN_ABL & 1) != 0) return xb[(k + 3) & 15];
-        else return *reinterpret_cast<const bf16x8*>(w2 + a2[k >> 3] + (k & 7) * 4096);
-    };
-    auto init_s = [&](int chunk, f32x16 (&S)[2]) {
-        const float* bb = b1s + chunk * FHC + 8 * h;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(bb + 32 * t), q1 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 4);
-            const f32x4 q2 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 16), q3 = *reinterpret_cast<const f32x4*>(bb + 32 * t + 20);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { S[t][j] = q0[j]; S[t][4 + j] = q1[j]; S[t][8 + j] = q2[j]; S[t][12 + j] = q3[j]; }
-        }
-    };
-    // ReLU + bf16 of one register pair (P = 8 t + p) on the packed pair as a signed 16-bit max (a negative bf16 is a negative int16):
-    // one instruction per pair and no canonicalising v_max in front of an fmaxf of MFMA results
-    auto relu_pair = [&](const f32x16 (&S)[2], u32x4 (&Hn)[4], int P) {
-        const int t = P >> 3, p = P & 7;
-        uint32_t pk;       // (no builtin for the two-source form; written as two casts the compiler emits two converts and a v_perm)
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(pk) : "v"(S[t][2 * p]), "v"(S[t][2 * p + 1]));
-        const s16x2_t rl = __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, pk), s16x2_t{0, 0});
-        Hn[2 * t + (p >> 2)][p & 3] = __builtin_bit_cast(uint32_t, rl);
-    };
-    auto mask_pair = [&](const u32x4 (&Hn)[4], uint32_t& word, int P) {      // bit 15 / 31 of w + 0x7fff7fff: that half of w is not zero
-        const int t = P >> 3, p = P & 7;
-        word = (word >> 1) | ((Hn[2 * t + (p >> 2)][p & 3] + 0x7fff7fffu) & 0x80008000u);
-        asm volatile("" : "+v"(word));      // keeps the three instructions in this step (pure arithmetic otherwise sinks to its one use)
-    };
-#define FFN_STEP() __builtin_amdgcn_sched_barrier(0)
-#define FFN_WAIT_STAGE(NST)                                                                                        \
-    do {                                                                                                           \
-        /* the LDS-DMA of this iteration is older than its NST stores (vmcnt retires in order): wait for it only */ \
-        /* (and every LDS read of the buffers the next iteration's DMA overwrites has returned) */                 \
-        if (TRAIN) asm volatile("s_waitcnt vmcnt(" #NST ") lgkmcnt(0)" ::: "memory");                  \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                           \
-        __builtin_amdgcn_s_barrier();                                                                              \
-        asm volatile("" ::: "memory");                                                                             \
-    } while (0)
-
-    // one iteration: FIRST = no second product yet (chunk 0), LAST = no first product any more (after the last chunk).
-    // VMEM order inside an iteration: 16 LDS-DMA pieces (steps 0..15: W1 of chunk i + 1, W2 of chunk i), THEN the stores (4 full-line
-    // stores of chunk i - 1's H tile, the mask word): the wait at the end leaves exactly the stores in flight.
-    auto body = [&](int i, auto first_c, auto last_c) {
-        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
-        const unsigned char* w1 = w1s + (i & 1) * W1BUF;
-        const unsigned char* w2 = w2s + ((i - 1) & 1) * W2BUF;
-        const int nxt = i + 1 < NC ? i + 1 : NC - 1;       // (the last chunk's iteration re-reads its own W1 into the free buffer: no branch)
-        f32x16 S[2];
-        u32x4 Hn[4], Hout[4];
-        uint32_t word = 0;
-        if constexpr (!LAST) {
-            init_s(i, S);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) A[k] = frag1(w1, k);
-            FFN_STEP();
-#pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                if constexpr ((FFN_ABL & 2) == 0) S[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], xb[k >> 1], S[k & 1], 0, 0, 0);
-                else asm volatile("" : "+v"(A[k & 15]));
-                if (k + 8 < 32) A[(k + 8) & 15] = frag1(w1, k + 8);
-                else if (!FIRST) A[(k + 8) & 15] = frag2(w2, k + 8 - 32);
-                if ((FFN_ABL & 4) == 0 && k < 16) {
-                    if (k & 1) dma_w2(i & 1, i, k >> 1);
-                    else dma_w1((i + 1) & 1, nxt, k >> 1);
-                }
-                if (TRAIN && !FIRST && k >= 24 && k < 28) Hout[k - 24] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 24) * 1024);
-                FFN_STEP();
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) A[k] = frag2(w2, k);
-            FFN_STEP();
-        }
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            if constexpr (!FIRST) {
-                if constexpr ((FFN_ABL & 2) == 0) Y[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[k & 15], __builtin_bit_cast(bf16x8, Hf[k >> 3]), Y[k & 7], 0, 0, 0);
-                else asm volatile("" : "+v"(A[k & 15]));
-                if (k + 8 < 32) A[(k + 8) & 15] = frag2(w2, k + 8);
-            }
-            if constexpr (!LAST) {
-                if ((k & 1) == 0) relu_pair(S, Hn, k >> 1);
-                else if (TRAIN) mask_pair(Hn, word, k >> 1);
-                if (TRAIN && !FIRST && (k & 7) == 0)       // chunk i - 1's tile (read back row-wise at steps 24..27): four full-line stores
-                    __builtin_amdgcn_raw_buffer_store_b128(Hout[k >> 3], rsh, hoff[k >> 3], (i - 1) * (FHC * 2), FFN_HID_POLICY);
-                if (TRAIN && (k & 7) == 7)
-                    *reinterpret_cast<u32x4*>(hst + hwr + ((((k >> 3) * 2 + h) ^ (r & 7)) << 4)) = Hn[k >> 3];
-            } else {
-                if (TRAIN && k >= 4 && k < 8) Hout[k - 4] = *reinterpret_cast<const u32x4*>(hst + hrd + (k - 4) * 1024);
-                if (TRAIN && k >= 16 && k < 20) __builtin_amdgcn_raw_buffer_store_b128(Hout[k - 16], rsh, hoff[k - 16], (i - 1) * (FHC * 2), FFN_HID_POLICY);
-                const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;       // the epilogue's residual row k (see below)
-                res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
-            }
-            FFN_STEP();
-        }
-        if constexpr (!LAST) {
-            if (TRAIN) __builtin_amdgcn_raw_buffer_store_b32(word, rsb, boff, i * (2 * a.Mp * 4), 0);
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg) Hf[sg] = Hn[sg];
-        }
-    };
-    // The epilogue's residual rows (row layout: lane = 4 columns of a token row, 32 rows per wave) are requested from inside the LAST
-    // body, one per MFMA step - a half-iteration + barrier ahead of their use, all 32 in flight at once.  (Fetched batch by batch
-    // inside the epilogue every batch paid an HBM round trip queued behind the previous batch's stores.)  The row-mask bits too:
-    // a load of row_len[b] per row in the epilogue was a dependent global load + wait per row, ~1000 cycles each.
+    // the row-mask bits (a load of row_len[b] per row in the epilogue was a dependent global load + wait per row, ~1000 cycles each)
     uint32_t keepmask = 0xffffffffu;
     const int m0c = m0 < a.M ? m0 : a.M - 1;
     const int b_first = m0c / a.L, t_first = m0c - b_first * a.L;      // (one division; rows advance from here)
@@ -306,59 +131,37 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(const FfnFwdArgs a) {
             }
         }
     }
-    if constexpr (PROJ) {
-        // four chunks of the projection through the two W1 buffers: 128 MFMAs, 2 us of a launch that is its epilogue
-        auto chunk = [&](auto C) {
-            constexpr int c = decltype(C)::value;
-            const unsigned char* w1 = w1s + (c & 1) * W1BUF;
-            if constexpr (c + 1 < 4) {
+    // four chunks of the projection through the two images: 128 MFMAs, 2 us of a launch that is its epilogue
+    auto chunk = [&](auto C) {
+        constexpr int c = decltype(C)::value;
+        const unsigned char* w1 = w1s + (c & 1) * W1BUF;
+        if constexpr (c + 1 < 4) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dma_w1((c + 1) & 1, c + 1, j);
-            } else {
+            for (int j = 0; j < 8; ++j) dma_w1((c + 1) & 1, c + 1, j);
+        } else {
 #pragma unroll
-                for (int k = 0; k < 32; ++k) {
-                    const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;
-                    res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
-                }
+            for (int k = 0; k < 32; ++k) {
+                const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;
+                res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
             }
+        }
 #pragma unroll
-            for (int k = 0; k < 32; ++k)
-                Y[2 * c + (k & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag1(w1, k), xb[k >> 1], Y[2 * c + (k & 1)], 0, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-        chunk(std::integral_constant<int, 0>{});
-        chunk(std::integral_constant<int, 1>{});
-        chunk(std::integral_constant<int, 2>{});
-        chunk(std::integral_constant<int, 3>{});
-    } else {
-    body(0, std::true_type{}, std::false_type{});
-    FFN_WAIT_STAGE(1);
-    for (int i = 1; i < NC; ++i) {
-        body(i, std::false_type{}, std::false_type{});
-        FFN_WAIT_STAGE(5);
-    }
-    body(NC, std::false_type{}, std::true_type{});
-    }
-#undef FFN_WAIT_STAGE
-#undef FFN_STEP
+        for (int k = 0; k < 32; ++k)
+            Y[2 * c + (k & 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag1(w1, k), xb[k >> 1], Y[2 * c + (k & 1)], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{});
 
-    if (a.dbg & 1) {
-        float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc += Y[t][j];
-        if (acc == 123.456f) a.y32[0] = acc;
-        return;
-    }
     // ---- epilogue: v = dropout(Y + b2) + x, LayerNorm, row mask --------------------------------------------------------------------
-    // A lane holds 128 values of ITS token (stores from here would touch 32 rows per instruction, 32 bytes each - measured 21 us of
-    // the eval launch, 40 us with the training outputs).  The weight images are free now: each wave parks its Y^T tile in 32 KiB of
-    // them ([32 tokens][256] f32, 16-byte piece p of token r in slot p ^ (r & 7): conflict-free both ways) and reads it back one
-    // token row per instruction - the residual load and the three stores are then whole 1-KiB / 512-byte rows, and the row
-    // arithmetic is add_layernorm_fwd_kernel's (lane = 4 columns of the row).
+    // A lane holds 128 values of ITS token (stores from here would touch 32 rows per instruction, 32 bytes each).  The weight images
+    // are free now: each wave parks its Y^T tile in 32 KiB of them ([32 tokens][256] f32, 16-byte piece p of token r in slot
+    // p ^ (r & 7): conflict-free both ways) and reads it back one token row per instruction - the three stores are then whole
+    // 1-KiB / 512-byte rows, and the row arithmetic is add_layernorm_fwd_kernel's (lane = 4 columns of the row).
     __syncthreads();
     unsigned char* const tile = smem + wave * 32768;
 #pragma unroll
@@ -1009,14 +812,14 @@ extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* res
                     asr_aligned(y16, 8) && asr_aligned(bias, 16) && asr_aligned(gamma, 16) && asr_aligned(beta, 16), -1,
                 "asr_proj_ln_fwd: 16-byte aligned buffers required");
     const int M = (int)M64;
-    FfnFwdArgs a{(const bf16_t*)ctx16, residual, (const bf16_t*)w, nullptr, nullptr, bias, gamma, beta, row_len, nullptr, nullptr, s_out, y32,
-                 (bf16_t*)y16, mean_out, rstd_out, M, L, FD, (M + FBM - 1) / FBM * FBM, eps, drop_x, 0};
+    ProjLnArgs a{(const bf16_t*)ctx16, residual, (const bf16_t*)w, bias, gamma, beta, row_len, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L,
+                 eps, drop_x};
     const dim3 grid((M + FBM - 1) / FBM), block(256);
     const bool dr = drop_x.thr16 != 0;
-    if (train && dr) hipLaunchKernelGGL((ffn_fwd_kernel<true, true, true>), grid, block, 0, (hipStream_t)stream, a);
-    else if (train) hipLaunchKernelGGL((ffn_fwd_kernel<true, false, true>), grid, block, 0, (hipStream_t)stream, a);
-    else if (dr) hipLaunchKernelGGL((ffn_fwd_kernel<false, true, true>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((ffn_fwd_kernel<false, false, true>), grid, block, 0, (hipStream_t)stream, a);
+    if (train && dr) hipLaunchKernelGGL((proj_ln_kernel<true, true>), grid, block, 0, (hipStream_t)stream, a);
+    else if (train) hipLaunchKernelGGL((proj_ln_kernel<true, false>), grid, block, 0, (hipStream_t)stream, a);
+    else if (dr) hipLaunchKernelGGL((proj_ln_kernel<false, true>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((proj_ln_kernel<false, false>), grid, block, 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_proj_ln_fwd");
     return 0;
 }

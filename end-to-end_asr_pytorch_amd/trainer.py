@@ -423,7 +423,12 @@ class Trainer:
 
     def _backward(self, tape, st, logits, tg1, lse, loss2, d_num):
         model = self.model
-        one = torch.ones(1, device=self.fp.flat.device)
+        one = self.__dict__.get("_one")      # (a constant: not a fill launch per step on the decoder's chain)
+        if one is None or one.device != self.fp.flat.device:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                one = torch.ones(1, device=self.fp.flat.device)
+            else:
+                one = self._one = torch.ones(1, device=self.fp.flat.device)
         with torch.no_grad():
             if logits is None:     # CTC_Model: the CTC loss is the whole objective
                 model.decoder._grad_slots["prj"]["g"] = ops.ctc_loss_bwd(st, one, bf16=(modules.get_precision() == "bf16"))

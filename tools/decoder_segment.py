@@ -36,8 +36,7 @@ def main(d):
             continue
         mq = max(perq, key=perq.get)
         main_k = [r for r in ks if r[2] == mq]
-        fwd = [i for i, r in enumerate(main_k) if "ffn_fwd_kernel<true, true, false>" in r[3] or "ffn_fwd_kernelILb1ELb1ELb0" in r[3] or
-               "ffn_fwd_kernel<true, false, false>" in r[3]]
+        fwd = [i for i, r in enumerate(main_k) if "ffn_fwd2_kernel" in r[3]]      # (the encoder's feed-forward forward: ffn2.hip)
         bwd = [i for i, r in enumerate(main_k) if "ffn_bwd_kernel" in r[3]]
         if len(fwd) >= 12 and bwd:
             break
