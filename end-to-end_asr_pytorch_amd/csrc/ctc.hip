@@ -808,7 +808,12 @@ __global__ __launch_bounds__(256, 8) void ctc_fused_fwd_kernel(const float* __re
         const int* arr_d = arrivals + (int64_t)b * arr_stride + d * nchunks;
         for (int c = 0; c * W <= klast_d; ++c) {
             const bool got = (dbg & 16) ? true : ctc_wait_rows(arr_d + c, min(c * W + W, klast_d + 1) - c * W);      // (bit 4: never wait - timing only)
-            if (lane == 0) avail_sh[d] = got ? c + 1 : -1;
+            if (lane == 0) {
+                avail_sh[d] = got ? c + 1 : -1;
+                // every arrival of this chunk has been counted: the word goes back to zero here (the caller's buffer is handed back
+                // zeroed without a pass over all B x 2 x chunks words by the last utterance, which sat at the very end of the launch)
+                if (got) __hip_atomic_store(const_cast<int*>(arr_d + c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (!got) break;
         }
     }
@@ -897,8 +902,11 @@ __global__ __launch_bounds__(256, 8) void ctc_fused_fwd_kernel(const float* __re
         }
     }
     // ---- the last utterance to finish closes the op: the batch mean (loss.py:41-43, what ctc_mean_kernel computes, same order) and the
-    // counters back to zero - every arrival has landed by then (each chain waited for all of its own), so a caller can keep ONE
-    // counter buffer per stream, zeroed once, and the op is one launch with no memset in front and no reduction kernel behind
+    // op's own finished-count back to zero; the arrival counters went back to zero one by one as their chunks were seen complete (the
+    // polling wavefronts), so a caller can keep ONE counter buffer per stream, zeroed once, and the op is one launch with no memset in
+    // front and no reduction kernel behind.  (Round 6, measured and dropped: the last quarter / eighth of the walk handed out by tickets
+    // from one agent-scope counter instead of equal static shares - 146 -> 171-174 us whatever the share; the pass workgroups' end times
+    // stay 45 us apart either way: they differ in speed by where they run, not in share.)
     if (stamp && lane == 0) stamp[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
     int last = 0;
     if (lane == 0) {
@@ -916,10 +924,6 @@ __global__ __launch_bounds__(256, 8) void ctc_fused_fwd_kernel(const float* __re
         }
         acc = wave_sum(acc);
         if (lane == 0) mean_loss[0] = acc / (float)Bn;
-    }
-    for (int i = lane; i < Bn * 2 * nchunks; i += 64) {
-        const int ub = i / (2 * nchunks);
-        __hip_atomic_store(arrivals + (int64_t)ub * arr_stride + (i - ub * 2 * nchunks), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0) __hip_atomic_store(extra + 8, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the queue heads reset themselves)
 }
