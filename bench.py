@@ -741,6 +741,8 @@ def main():
             "dtype": args.precision, "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": workload_name(args, train),
                        "global_batch": world * CFG["B"], "seq_len": CFG["T"], "parallelism": "dp%d" % world,
+                       # flat scalars the driver's record keeps: ranks counted by an all-reduce of ones (not by the environment), and its backend
+                       "rccl_ranks": (rccl_ranks["ranks"] if rccl_ranks else 1), "collective_backend": (rccl_ranks["backend"] if rccl_ranks else "none"),
                        "launch": launch_name(args, graphed, trainer),
                        "launch_calibration_ms": launch_timing,       # step_auto's own eager vs replay timing (4 steps each, during initialisation)
                        "settle_ms": [round(v, 3) for v in settle]},   # ms/step of the 5-step groups run until steady, before the W warm-up steps
