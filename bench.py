@@ -614,8 +614,8 @@ def main():
         peak = PEAK_HBM_GBS if dom["hbm"] else PEAK_MFMA_BF16_TFLOPS
         dom_in = fams_in.get(dom_name)
         ach_in = (dom_in["work"] / (dom_in["ms"] * 1e-3) / (1e9 if dom["hbm"] else 1e12)) if dom_in and dom_in["ms"] > 0 else None
-        prof_dir = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r5", "r4", "r3", "r2", "r1"))
-                         if os.path.exists(os.path.join(d, "pmc_traffic_train_s1.json"))), os.path.join(ROOT, "profiles", "r5"))
+        prof_dir = next((d for d in (os.path.join(ROOT, "profiles", r) for r in ("r6", "r5", "r4", "r3", "r2", "r1"))
+                         if os.path.exists(os.path.join(d, "pmc_traffic_train_s1.json"))), os.path.join(ROOT, "profiles", "r6"))
         traffic = pmc_traffic(FAMILY_KERNEL.get(dom_name, dom_name), prof_dir)
         roofline = dict(kernel="%s (%s, all shapes)" % (dom_name, FAMILY_KERNEL.get(dom_name, dom_name)),
                         bound="hbm" if dom["hbm"] else "mfma", achieved=round(ach, 2), peak=peak,
