@@ -99,12 +99,15 @@ def test_dropout_keys_match_the_oracle_restatement():
 
 
 @pytest.mark.parametrize("gen,inc", [("gen_attn_fwd4.py", "attention_fwd4_asm.inc"), ("gen_attn_bwd.py", "attention_bwd_asm.inc"),
-                                     ("gen_attn_bwd_dq.py", "attention_bwd_dq_asm.inc")])
+                                     ("gen_attn_bwd_dq.py", "attention_bwd_dq_asm.inc"), ("gen_ffn_fwd.py", "ffn_fwd2_asm.inc")])
 def test_generated_attention_streams_are_current(gen, inc):
-    """csrc/attention_*_asm.inc are the output of tools/gen_attn_*.py: an edit of one without the other must not go unnoticed."""
+    """csrc/attention_*_asm.inc and csrc/ffn_fwd2_asm.inc (+ ffn_fwd2_params.h) are the output of tools/gen_*.py: an edit of one without the
+    other must not go unnoticed."""
     import subprocess, sys, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "x.inc")
         subprocess.run([sys.executable, os.path.join(root, "tools", gen), "--out", out], check=True, stderr=subprocess.DEVNULL)
         assert open(out).read() == open(os.path.join(root, "end-to-end_asr_pytorch_amd", "csrc", inc)).read()
+        if gen == "gen_ffn_fwd.py":
+            assert open(os.path.join(d, "ffn_fwd2_params.h")).read() == open(os.path.join(root, "end-to-end_asr_pytorch_amd", "csrc", "ffn_fwd2_params.h")).read()

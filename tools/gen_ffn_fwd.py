@@ -130,10 +130,10 @@ def dma_piece(j, q):
     into buffer q.  -> (the M0 instruction, (the load, its address register)): one other instruction has to sit between the two."""
     if j < 4:
         m0 = "s_add_u32 m0, %s, 0x%x" % (s(S_W1DST), (q ^ 1) * 32768 + j * 1024)
-        ld = ("buffer_load_dwordx4 %s, %s, %s offen %s lds" % (v(OFF1 + j), s(S_W1RS, 4), s(S_W1SOFF), DMA_POLICY), V(OFF1 + j))
+        ld = ("buffer_load_dwordx4 %s, %s, %s offen%s lds" % (v(OFF1 + j), s(S_W1RS, 4), s(S_W1SOFF), (" " + DMA_POLICY) if DMA_POLICY else ""), V(OFF1 + j))
     else:
         m0 = "s_add_u32 m0, %s, 0x%x" % (s(S_W1DST), 0x10000 + q * 32768 + (j - 4) * 1024)
-        ld = ("buffer_load_dwordx4 %s, %s, %s offen %s lds" % (v(OFF2 + j - 4), s(S_W2RS, 4), s(S_W2SOFF), DMA_POLICY), V(OFF2 + j - 4))
+        ld = ("buffer_load_dwordx4 %s, %s, %s offen%s lds" % (v(OFF2 + j - 4), s(S_W2RS, 4), s(S_W2SOFF), (" " + DMA_POLICY) if DMA_POLICY else ""), V(OFF2 + j - 4))
     if ABL & 256:       # (timing probe: the same bytes into registers instead of LDS)
         off, rs, so = (OFF1 + j, S_W1RS, S_W1SOFF) if j < 4 else (OFF2 + j - 4, S_W2RS, S_W2SOFF)
         ld = ("buffer_load_dwordx4 %s, %s, %s, %s offen %s" % (v(HOUT + 4 * (j & 1), 4), v(off), s(rs, 4), s(so), DMA_POLICY), V(off))
