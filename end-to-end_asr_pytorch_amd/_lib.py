@@ -12,7 +12,10 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("ASR_AMD_LIB") or os.path.join(CSRC, "libasr_hip.so")     # (ASR_AMD_LIB: another build of the same ABI, for A/B runs)
 SOURCES = ["common.hip", "gemm.hip", "ffn.hip", "ffn2.hip", "vocab.hip", "graph_exec.hip", "collective.hip", "dgrad_rows.hip", "attention.hip", "attention_fwd4.hip", "attention_bwd.hip", "attention_bwd4.hip", "norm_embed.hip", "conv.hip", "ctc.hip", "ce.hip", "cif.hip",
            "backward.hip", "wgrad.hip", "fused_small.hip", "cif_train.hip", "decode.hip", "decode_blocks.hip", "input.hip"]
-EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"]}  # bit-exact CIF: product and sum rounded separately, like the reference
+EXTRA_FLAGS = {"cif.hip": ["-ffp-contract=off"],  # bit-exact CIF: product and sum rounded separately, like the reference
+               # ffn2.hip: the phase in front of the generated loop keeps its accumulators in VGPRs (the loop's block owns a0-a63 and the
+               # compiler places its own AGPRs behind them: 176 + 64 + 64 would not fit a wave at two per SIMD)
+               "ffn2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "asr_hip.h")
 
 _vp, _i, _i64, _f, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint
@@ -59,6 +62,8 @@ SIGNATURES = {
     "asr_graphx_collectives": [_vp, _vp, _vp],
     "asr_ffn_bits_words": [_i, _i],
     "asr_ffn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _dr],
+    "asr_attn_ffn_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _dr, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _vp, _i, _i, _i, _i, _f, _dr],
     "asr_proj_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _dr],
     "asr_ffn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i],
     "asr_dgrad_rows": [_vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i],

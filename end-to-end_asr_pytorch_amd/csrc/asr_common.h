@@ -35,9 +35,14 @@ int asr_attention_bwd_dq_v4(hipStream_t s, const void* q, const void* k, const v
 // collective.hip: the function of the bucket-ready marker node (graph_exec.hip turns such a node into an all-reduce call) and the call
 const void* asr_collective_marker_func();
 // asr_ffn_fwd's launch (ffn2.hip; arguments checked by ffn.hip)
+struct asr_ffn2_pre_t {      // asr_attn_ffn_fwd: the attention sub-layer's tail run in front of the feed-forward one (ffn2.hip, PRE)
+    const void* ctx16; const float* res32; const void* w; const float* bias; const float* gamma; const float* beta;
+    float* s_out; float* mean_out; float* rstd_out; float eps; asr_dropout_t drop_x;
+};
 int asr_ffn_fwd2_launch(hipStream_t stream, const void* x16, const float* x32, const void* w1, const float* b1, const void* w2, const float* b2,
                         const float* gamma, const float* beta, const int32_t* row_len, void* hid_out, void* bits_out, float* s_out, float* y32,
-                        void* y16, float* mean_out, float* rstd_out, int M, int L, int d_ff, float eps, asr_dropout_t drop_x);
+                        void* y16, float* mean_out, float* rstd_out, int M, int L, int d_ff, float eps, asr_dropout_t drop_x,
+                        const asr_ffn2_pre_t* pre = nullptr);
 int asr_launch_budget_current();     // common.hip: asr_launch_budget (0 = none)
 int asr_deterministic();     // common.hip: ASR_AMD_DETERMINISTIC / asr_set_deterministic
 #define ASR_REQUIRE(cond, code, ...)      \

@@ -800,6 +800,33 @@ extern "C" int asr_ffn_fwd(void* stream, const void* x16, const float* x32, cons
                                rstd_out, (int)M64, L, d_ff, eps, drop_x);
 }
 
+extern "C" int asr_attn_ffn_fwd(void* stream, const void* ctx16, const float* residual, const void* wo, const float* bo, const float* gamma0,
+                                const float* beta0, float eps0, asr_dropout_t drop0, float* s0_out, float* x32, void* x16, float* mean0_out,
+                                float* rstd0_out, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma,
+                                const float* beta, const int32_t* row_len, void* hid_out, void* bits_out, float* s_out, float* y32, void* y16,
+                                float* mean_out, float* rstd_out, int B, int L, int d_model, int d_ff, float eps, asr_dropout_t drop_x) {
+    const int64_t M64 = (int64_t)B * L;
+    ASR_REQUIRE(d_model == FD, -1, "asr_attn_ffn_fwd: d_model = %d (the fused sub-layers are built for 256)", d_model);
+    ASR_REQUIRE(d_ff >= FHC && d_ff % FHC == 0 && d_ff <= FFN_MAX_DFF, -1, "asr_attn_ffn_fwd: d_ff = %d (a multiple of 64 up to %d)", d_ff, FFN_MAX_DFF);
+    ASR_REQUIRE(M64 > 0 && M64 * d_ff * 2 < (1ll << 31), -1, "asr_attn_ffn_fwd: B * L out of range");
+    ASR_REQUIRE(ctx16 && residual && wo && bo && gamma0 && beta0 && x32 && x16 && w1 && b1 && w2 && b2 && gamma && beta && y32, -1,
+                "asr_attn_ffn_fwd: null argument");
+    ASR_REQUIRE((hid_out == nullptr) == (bits_out == nullptr), -1, "asr_attn_ffn_fwd: hid_out and bits_out come together (training) or not at all");
+    ASR_REQUIRE(hid_out || (!s_out && !mean_out && !rstd_out && !s0_out && !mean0_out && !rstd0_out), -1,
+                "asr_attn_ffn_fwd: s / mean / rstd are training outputs (pass hid_out and bits_out too)");
+    ASR_REQUIRE((drop0.thr16 != 0) == (drop_x.thr16 != 0), ASR_ERR_UNSUPPORTED, "asr_attn_ffn_fwd: both dropout sites active or neither");
+    ASR_REQUIRE(drop0.thr16 < 65536u && drop_x.thr16 < 65536u, ASR_ERR_ARG, "asr_attn_ffn_fwd: dropout thr16 must be < 65536");
+    ASR_REQUIRE(asr_aligned(ctx16, 16) && asr_aligned(residual, 16) && asr_aligned(wo, 16) && asr_aligned(bo, 16) && asr_aligned(gamma0, 16) &&
+                    asr_aligned(beta0, 16) && asr_aligned(s0_out, 16) && asr_aligned(x16, 16) && asr_aligned(x32, 16) && asr_aligned(w1, 16) &&
+                    asr_aligned(w2, 16) && asr_aligned(y32, 16) && asr_aligned(hid_out, 16) && asr_aligned(s_out, 16) && asr_aligned(y16, 8) &&
+                    asr_aligned(b1, 16) && asr_aligned(b2, 16) && asr_aligned(gamma, 16) && asr_aligned(beta, 16),
+                -1, "asr_attn_ffn_fwd: 16-byte aligned buffers required");
+    ASR_REQUIRE(asr_aligned(bits_out, 4), -1, "asr_attn_ffn_fwd: bits_out must be 4-byte aligned");
+    const asr_ffn2_pre_t pre{ctx16, residual, wo, bo, gamma0, beta0, s0_out, mean0_out, rstd0_out, eps0, drop0};
+    return asr_ffn_fwd2_launch((hipStream_t)stream, x16, x32, w1, b1, w2, b2, gamma, beta, row_len, hid_out, bits_out, s_out, y32, y16, mean_out,
+                               rstd_out, (int)M64, L, d_ff, eps, drop_x, &pre);
+}
+
 extern "C" int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,
                                const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16, float* mean_out,
                                float* rstd_out, int B, int L, int d_model, float eps, asr_dropout_t drop_x) {

@@ -63,11 +63,210 @@ struct Ffn2Args {
     int M, L, dff, Mp;
     float eps;
     asr_dropout_t drop;
+    // PRE (appended: tools/gen_ffn_fwd.py reads the fields above by offset): the attention sub-layer's tail in front of this one.  x16 / x32
+    // are then OUTPUTS of the launch's first phase (that sub-layer's y16 / y32) before they are this sub-layer's inputs.
+    const bf16_t* pre_ctx16;
+    const float* pre_res32;
+    const bf16_t* pre_w;
+    const float* pre_b;
+    const float* pre_gamma;
+    const float* pre_beta;
+    float* pre_s_out;
+    float* pre_mean;
+    float* pre_rstd;
+    float pre_eps;
+    asr_dropout_t pre_drop;
 };
 
+typedef __attribute__((address_space(3))) void lds_void2;
+
+// bias + dropout + residual + LayerNorm + row mask over 16 whole token rows read back from an LDS tile ([tokens][256] f32, 16-byte piece q
+// of token t in slot q ^ (t & 7)); lane = 4 columns of the row (add_layernorm_fwd_kernel's arithmetic).  m0: the first row's token index.
+// PREF: the fields of the phase in front (pre_*; its y32 / y16 are the launch's x32 / x16).  The arguments are read from the kernel-argument
+// segment where they are used (`a`: a laundered pointer to it) - kept in scalar registers from the top of the kernel they would have to
+// be spilled around the loop's block, which owns s20-s101.
+typedef __attribute__((address_space(4))) const Ffn2Args* kernarg_ptr_t;
+template <bool TRAIN, bool DROP, bool PREF>
+__device__ __forceinline__ void ln_rows16(const unsigned char* tile, const f32x4 (&res)[16], __attribute__((address_space(4))) const Ffn2Args& a, int m0,
+                                          int lane) {
+    const int M = a.M, L = a.L;
+    const int32_t* const row_len = a.row_len;
+    const float* const bias = PREF ? a.pre_b : a.b2;
+    const float* const gamma = PREF ? a.pre_gamma : a.gamma;
+    const float* const beta = PREF ? a.pre_beta : a.beta;
+    const float eps = PREF ? a.pre_eps : a.eps;
+    float* const s_out = PREF ? a.pre_s_out : a.s_out;
+    float* const y32 = PREF ? const_cast<float*>(a.x32) : a.y32;
+    bf16_t* const y16 = PREF ? const_cast<bf16_t*>(a.x16) : a.y16;
+    float* const mean_out = PREF ? a.pre_mean : a.mean;
+    float* const rstd_out = PREF ? a.pre_rstd : a.rstd;
+    asr_dropout_t drop_arg;      // (field by field: the argument block lives in the constant address space)
+    if (PREF) { drop_arg.thr16 = a.pre_drop.thr16; drop_arg.key0 = a.pre_drop.key0; drop_arg.key1 = a.pre_drop.key1; drop_arg.salt = a.pre_drop.salt; }
+    else { drop_arg.thr16 = a.drop.thr16; drop_arg.key0 = a.drop.key0; drop_arg.key1 = a.drop.key1; drop_arg.salt = a.drop.salt; }
+    uint32_t keepmask = 0xffffu;
+    const int m0c = m0 < M ? m0 : M - 1;
+    const int b_first = m0c / L, t_first = m0c - b_first * L;
+    if (row_len) {
+        keepmask = 0;
+        int bb = b_first, tt = t_first, len = row_len[bb];
+        for (int tr = 0; tr < 16; ++tr) {
+            keepmask |= (tt < len ? 1u : 0u) << tr;
+            if (++tt == L) {
+                tt = 0;
+                if (m0 + tr + 1 < M) len = row_len[++bb];
+            }
+        }
+    }
+    const asr_dropout_t drop = drop_resolve(drop_arg);
+    const float sc = drop_scale(drop);
+    const f32x4 b2v = *reinterpret_cast<const f32x4*>(bias + 4 * lane);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 4 * lane), bt = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
+    const auto rss = __builtin_amdgcn_make_buffer_rsrc(s_out, 0, s_out ? (int)((int64_t)M * FD * 4) : 0, 0x00020000);
+    const auto rsy = __builtin_amdgcn_make_buffer_rsrc(y32, 0, (int)((int64_t)M * FD * 4), 0x00020000);
+    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(y16, 0, y16 ? (int)((int64_t)M * FD * 2) : 0, 0x00020000);
+    int bb = b_first, tt = t_first;
+    uint32_t sub = DROP ? drop_subkey(drop, (uint32_t)bb) : 0u;
+    float mean_l = 0.f, rstd_l = 0.f;
+#pragma unroll
+    for (int tr0 = 0; tr0 < 16; tr0 += 8) {
+        f32x4 v[8];
+        float part[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tr = tr0 + j;       // (its swizzle key is tr & 7: m0 is a multiple of 16 inside the tile)
+            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (j & 7)) << 4));
+            f32x4 wv4 = y + b2v;
+            if (DROP) {
+                wv4 = drop4(drop, sub, (uint32_t)tt, FD >> 1, (uint32_t)(4 * lane), wv4, sc);
+                if (++tt == L) {
+                    tt = 0;
+                    sub = drop_subkey(drop, (uint32_t)++bb);
+                }
+            }
+            v[j] = wv4 + res[tr];
+            part[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+        float mean[8], rstd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mean[j] = wave_sum_dpp(part[j]) * (1.f / FD);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f32x4 dl = v[j] - mean[j];
+            part[j] = (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(wave_sum_dpp(part[j]) * (1.f / FD) + eps);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tr = tr0 + j, row = m0 + tr;
+            const bool rv = row < M;
+            const unsigned o16 = rv ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u;
+            if (TRAIN) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rss, o16, 0, 0);
+                mean_l = lane == tr ? mean[j] : mean_l;
+                rstd_l = lane == tr ? rstd[j] : rstd_l;
+            }
+            f32x4 o = (v[j] - mean[j]) * rstd[j] * gm + bt;
+            if (!((keepmask >> tr) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, o16, 0, 0);
+            const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsz, rv ? (unsigned)row * (FD * 2u) + 8u * lane : 0x80000000u, 0, 0);
+        }
+    }
+    if (TRAIN && lane < 16 && m0 + lane < M) {      // (plain stores: two buffer descriptors less in scalar registers beside the loop's block)
+        if (mean_out) mean_out[m0 + lane] = mean_l;
+        if (rstd_out) rstd_out[m0 + lane] = rstd_l;
+    }
+}
+
+// PRE: the attention sub-layer's tail (attention.py:58-60: fc -> dropout -> + residual -> layer_norm, encoder.py:77's row mask) runs in
+// front, on the same 128 tokens: wave (p, w) multiplies the pair's 32 context rows with output units 128 w .. + 127 of the [256][256]
+// projection (all four 32-KiB chunk images resident), the halves meet in the pair's LDS tile, each wave normalises 16 rows and writes
+// them as that sub-layer's outputs - x16 / x32 of the feed-forward phase, which reads them back (from L2) where the stand-alone launch
+// reads them from HBM.  One launch boundary, one prologue and one L2 write-back less per encoder layer.
+// The phase in front (PRE, see the kernel): every index is derived here from a thread index of its own, and the arguments are read
+// where they are used - nothing of this phase is meant to stay in registers across the loop's block.
 template <bool TRAIN, bool DROP>
+__device__ __forceinline__ void attn_tail_phase(unsigned char* smem, const Ffn2Args& a0) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = wv & 3, w = wv >> 2;
+    const int mbase = blockIdx.x * FBM + 32 * p;
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a0.pre_w), 0, FD * FD * 2, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {      // chunk image c: piece pi = rows 2 pi, 2 pi + 1 (512 B each); slot pc of row u holds 16-byte chunk (pc & 16) | ((pc ^ u) & 15)
+            const int pi = wv * 4 + j, u = 2 * pi + (lane >> 5), pc = lane & 31;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void2*)(smem + c * 32768 + pi * 1024), 16,
+                                                     (unsigned)(u * FD * 2 + ((pc & 16) | ((pc ^ u) & 15)) * 16), c * (FHC * FD * 2), 0, 0);
+        }
+    // wave (p, w): tokens 16 w .. + 15 of pair p against ALL 256 output units on v_mfma_f32_16x16x32_bf16 - the wave then holds
+    // complete rows of exactly the 16 tokens it normalises (at 32 x 32 the pair would split the units and hold 64 + 64 + 64
+    // registers of operand, accumulator and residual: more than a wave has at two per SIMD beside the loop's fixed 176 + 64)
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int m0 = mbase + 16 * w;
+    const int mr = m0 + r16 < a0.M ? m0 + r16 : a0.M - 1;
+    u32x4 xb[8];
+    {
+        const bf16_t* xr = a0.pre_ctx16 + (int64_t)mr * FD + 8 * q4;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xb[ks] = *reinterpret_cast<const u32x4*>(xr + 32 * ks);
+    }
+    f32x4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fragment of unit row u = 16 j + r16 (row u & 63 of chunk image u >> 6), k-step ks: the 16-byte piece pc = 4 ks + q4 of the row
+    unsigned fa[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int pc = 4 * ks + q4;
+        fa[ks] = (unsigned)(r16 * 512 + (((pc & 16) | ((pc ^ r16) & 15)) << 4));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {      // (rows 16 j .. + 15: row & 15 = r16 for every j, so one address set serves all sixteen tiles)
+        const unsigned char* wj = smem + (j >> 2) * 32768 + (j & 3) * (16 * 512);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) Mma<bf16_t>::run(*reinterpret_cast<const u32x4*>(wj + fa[ks]), xb[ks], acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the residual rows of this wave's 16 rows: requested here, landing under the tile hand-over
+    f32x4 res[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rowc = m0 + k < a0.M ? m0 + k : a0.M - 1;
+        res[k] = *reinterpret_cast<const f32x4*>(a0.pre_res32 + (int64_t)rowc * FD + 4 * lane);
+    }
+    __syncthreads();      // every wave is past its fragment reads: the images become the waves' row tiles
+    {
+        // lane (r16, q4) holds units 16 j + 4 q4 .. + 3 of token r16: 16-byte piece 4 j + q4 of the row, slot piece ^ (token & 7)
+        unsigned char* const trow = smem + p * 32768 + (16 * w + r16) * 1024;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) *reinterpret_cast<f32x4*>(trow + (((4 * j + q4) ^ (r16 & 7)) << 4)) = acc[j];
+    }
+    // (wave-private rows: written and read back by this wave only, LDS operations of a wave complete in order)
+    {
+        kernarg_ptr_t pap = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pap));
+        // (lane and m0 through a barrier of their own: the row offsets of this call are those of the epilogue's call, and what the
+        // compiler keeps of them across the loop's block - which owns v0-v175 - it parks in AGPRs beyond the block's 64)
+        int lane_p = lane, m0_p = m0;
+        asm volatile("" : "+v"(lane_p), "+s"(m0_p));
+        ln_rows16<TRAIN, DROP, true>(smem + p * 32768 + (16 * w) * 1024, res, *pap, m0_p, lane_p);
+    }
+    // the rows are this launch's own inputs from here on: written (acknowledged by L2) before any wave of the workgroup reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <bool TRAIN, bool DROP, bool PRE>
 __global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a0) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM2];
+    if constexpr (PRE) attn_tail_phase<TRAIN, DROP>(smem, a0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = wv & 3, w = wv >> 2;
@@ -131,7 +330,6 @@ __global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a0) {
     // ---- epilogue: v = dropout(Y + b2) + x, LayerNorm, row mask; this wave's 16 rows of the pair's tile [32 tok][256] f32 ----------------
     // (the arguments are read again from the kernel-argument segment: kept in scalar registers across the block they would have to be
     // spilled - the block owns s20-s101)
-    typedef __attribute__((address_space(4))) const Ffn2Args* kernarg_ptr_t;
     kernarg_ptr_t eap = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(eap));
     __attribute__((address_space(4))) const Ffn2Args& a = *eap;
@@ -142,103 +340,39 @@ __global__ __launch_bounds__(512, 1) void ffn_fwd2_kernel(const Ffn2Args a0) {
         const int rowc = m0 + k < a.M ? m0 + k : a.M - 1;
         res[k] = *reinterpret_cast<const f32x4*>(a.x32 + (int64_t)rowc * FD + 4 * lane);
     }
-    uint32_t keepmask = 0xffffu;
-    const int m0c = m0 < a.M ? m0 : a.M - 1;
-    const int b_first = m0c / a.L, t_first = m0c - b_first * a.L;
-    if (a.row_len) {
-        keepmask = 0;
-        int bb = b_first, tt = t_first, len = a.row_len[bb];
-        for (int tr = 0; tr < 16; ++tr) {
-            keepmask |= (tt < len ? 1u : 0u) << tr;
-            if (++tt == a.L) {
-                tt = 0;
-                if (m0 + tr + 1 < a.M) len = a.row_len[++bb];
-            }
-        }
-    }
     __syncthreads();
-    const unsigned char* const tile = smem + p * 32768 + (16 * w) * 1024;
-    asr_dropout_t drop_arg;      // (field by field: the argument block lives in the constant address space)
-    drop_arg.thr16 = a.drop.thr16; drop_arg.key0 = a.drop.key0; drop_arg.key1 = a.drop.key1; drop_arg.salt = a.drop.salt;
-    const asr_dropout_t drop = drop_resolve(drop_arg);
-    const float sc = drop_scale(drop);
-    const f32x4 b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * lane);
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + 4 * lane), bt = *reinterpret_cast<const f32x4*>(a.beta + 4 * lane);
-    const auto rss = __builtin_amdgcn_make_buffer_rsrc(a.s_out, 0, a.s_out ? (int)((int64_t)a.M * FD * 4) : 0, 0x00020000);
-    const auto rsy = __builtin_amdgcn_make_buffer_rsrc(a.y32, 0, (int)((int64_t)a.M * FD * 4), 0x00020000);
-    const auto rsz = __builtin_amdgcn_make_buffer_rsrc(a.y16, 0, a.y16 ? (int)((int64_t)a.M * FD * 2) : 0, 0x00020000);
-    const auto rsm = __builtin_amdgcn_make_buffer_rsrc(a.mean, 0, a.mean ? a.M * 4 : 0, 0x00020000);
-    const auto rsr = __builtin_amdgcn_make_buffer_rsrc(a.rstd, 0, a.rstd ? a.M * 4 : 0, 0x00020000);
-    int bb = b_first, tt = t_first;
-    uint32_t sub = DROP ? drop_subkey(drop, (uint32_t)bb) : 0u;
-    float mean_l = 0.f, rstd_l = 0.f;
-#pragma unroll
-    for (int tr0 = 0; tr0 < 16; tr0 += 8) {
-        f32x4 v[8];
-        float part[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int tr = tr0 + j;       // (token 16 w + tr of the pair: its swizzle key is tr & 7)
-            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + tr * 1024 + ((lane ^ (j & 7)) << 4));
-            f32x4 wv4 = y + b2v;
-            if (DROP) {
-                wv4 = drop4(drop, sub, (uint32_t)tt, FD >> 1, (uint32_t)(4 * lane), wv4, sc);
-                if (++tt == a.L) {
-                    tt = 0;
-                    sub = drop_subkey(drop, (uint32_t)++bb);
-                }
-            }
-            v[j] = wv4 + res[tr];
-            part[j] = (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        }
-        float mean[8], rstd[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mean[j] = wave_sum_dpp(part[j]) * (1.f / FD);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x4 dl = v[j] - mean[j];
-            part[j] = (dl[0] * dl[0] + dl[1] * dl[1]) + (dl[2] * dl[2] + dl[3] * dl[3]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(wave_sum_dpp(part[j]) * (1.f / FD) + a.eps);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int tr = tr0 + j, row = m0 + tr;
-            const bool rv = row < a.M;
-            const unsigned o16 = rv ? (unsigned)row * (FD * 4u) + 16u * lane : 0x80000000u;
-            if (TRAIN) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rss, o16, 0, 0);
-                mean_l = lane == tr ? mean[j] : mean_l;
-                rstd_l = lane == tr ? rstd[j] : rstd_l;
-            }
-            f32x4 o = (v[j] - mean[j]) * rstd[j] * gm + bt;
-            if (!((keepmask >> tr) & 1u)) o = f32x4{0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsy, o16, 0, 0);
-            const bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsz, rv ? (unsigned)row * (FD * 2u) + 8u * lane : 0x80000000u, 0, 0);
-        }
-    }
-    if (TRAIN) {
-        const unsigned o4 = (lane < 16 && m0 + lane < a.M) ? (unsigned)(m0 + lane) * 4u : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, mean_l), rsm, o4, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, rstd_l), rsr, o4, 0, 0);
-    }
+    ln_rows16<TRAIN, DROP, false>(smem + p * 32768 + (16 * w) * 1024, res, a, m0, lane);
 }
 
 }  // namespace
 
-// asr_ffn_fwd's launch (ffn.hip checks the arguments and calls here)
+// asr_ffn_fwd's launch (ffn.hip checks the arguments and calls here); pre != nullptr: asr_attn_ffn_fwd's
 int asr_ffn_fwd2_launch(hipStream_t stream, const void* x16, const float* x32, const void* w1, const float* b1, const void* w2, const float* b2,
                         const float* gamma, const float* beta, const int32_t* row_len, void* hid_out, void* bits_out, float* s_out, float* y32,
-                        void* y16, float* mean_out, float* rstd_out, int M, int L, int d_ff, float eps, asr_dropout_t drop_x) {
+                        void* y16, float* mean_out, float* rstd_out, int M, int L, int d_ff, float eps, asr_dropout_t drop_x, const asr_ffn2_pre_t* pre) {
     Ffn2Args a{(const bf16_t*)x16, x32, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, gamma, beta, row_len, (bf16_t*)hid_out,
-               (uint16_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x};
+               (uint16_t*)bits_out, s_out, y32, (bf16_t*)y16, mean_out, rstd_out, M, L, d_ff, (M + FBM - 1) / FBM * FBM, eps, drop_x,
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, asr_dropout_t{}};
+    if (pre) {
+        a.pre_ctx16 = (const bf16_t*)pre->ctx16; a.pre_res32 = pre->res32; a.pre_w = (const bf16_t*)pre->w; a.pre_b = pre->bias;
+        a.pre_gamma = pre->gamma; a.pre_beta = pre->beta; a.pre_s_out = pre->s_out; a.pre_mean = pre->mean_out; a.pre_rstd = pre->rstd_out;
+        a.pre_eps = pre->eps; a.pre_drop = pre->drop_x;
+    }
     const dim3 grid((M + FBM - 1) / FBM), block(512);
     const bool dr = drop_x.thr16 != 0;
-    if (hid_out && dr) hipLaunchKernelGGL((ffn_fwd2_kernel<true, true>), grid, block, 0, stream, a);
-    else if (hid_out) hipLaunchKernelGGL((ffn_fwd2_kernel<true, false>), grid, block, 0, stream, a);
-    else if (dr) hipLaunchKernelGGL((ffn_fwd2_kernel<false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((ffn_fwd2_kernel<false, false>), grid, block, 0, stream, a);
-    ASR_LAUNCH_CHECK("asr_ffn_fwd");
+#define FFN2_GO(T, D, P) hipLaunchKernelGGL((ffn_fwd2_kernel<T, D, P>), grid, block, 0, stream, a)
+    if (pre) {
+        if (hid_out && dr) FFN2_GO(true, true, true);
+        else if (hid_out) FFN2_GO(true, false, true);
+        else if (dr) FFN2_GO(false, true, true);
+        else FFN2_GO(false, false, true);
+    } else {
+        if (hid_out && dr) FFN2_GO(true, true, false);
+        else if (hid_out) FFN2_GO(true, false, false);
+        else if (dr) FFN2_GO(false, true, false);
+        else FFN2_GO(false, false, false);
+    }
+#undef FFN2_GO
+    ASR_LAUNCH_CHECK(pre ? "asr_attn_ffn_fwd" : "asr_ffn_fwd");
     return 0;
 }

@@ -430,8 +430,9 @@ class MultiheadAttention(_Cached):
         nn.init.xavier_normal_(self.fc.weight)
         self.dropout_rate = dropout
 
-    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None, attn_drop=None, q_pre=None):
+    def _impl(self, xq, xkv, k_len, causal, row_len, kv_pre=None, attn_drop=None, q_pre=None, tail=None):
         """xq: Act [B*Lq, d]; xkv: Act (same object for self-attention).  Returns Act.
+        tail(ctx2, wfc, dp_fc, rec) -> proj_ln's tuple or None: the caller's launch that takes this sub-layer's tail with it (EncoderLayer).
         kv_pre = (k, v, dkv) when the caller has already projected the keys / values (_CrossKV: one GEMM for all decoder layers);
         dkv() -> (dk, dv) views the backward writes into, the K/V weight and input gradients are then the caller's business."""
         h, B, Lq, Lk = self.n_head, xq.B, xq.L, xkv.L
@@ -465,6 +466,8 @@ class MultiheadAttention(_Cached):
             o, y32, y16, mean, rstd = ops.gemm_add_layernorm(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
                                                                    self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps,
                                                                    save_stats=rec, drop_x=dp_fc)
+        elif _PRECISION == "bf16" and ops.proj_ln_ok(ctx2, wfc, xq.f32.shape[1], B, Lq) and tail is not None and (fused := tail(ctx2, wfc, dp_fc, rec)) is not None:
+            o, y32, y16, mean, rstd = fused      # (this sub-layer's tail ran in the caller's launch: asr_attn_ffn_fwd)
         elif _PRECISION == "bf16" and ops.proj_ln_ok(ctx2, wfc, xq.f32.shape[1], B, Lq):      # the same at encoder size (csrc/ffn.hip, PROJ)
             o, y32, y16, mean, rstd = ops.proj_ln(ctx2, wfc, self._b("bfc", (self.fc.bias,)), xq.f32, self.layer_norm.weight,
                                                   self.layer_norm.bias, B, Lq, row_len=row_len, eps=self.layer_norm.eps, save_stats=rec,
@@ -610,7 +613,8 @@ class PositionwiseFeedForward(_Cached):
         self.layer_norm = nn.LayerNorm(d_model)
         self.dropout_rate = dropout
 
-    def _impl(self, x, row_len):
+    def _impl(self, x, row_len, drawn=False):
+        """drawn: this call's dropout descriptor when the caller has drawn it already (False: not drawn; None is a drawn 'inactive')"""
         hdt = _cdtype()
         rec = _TAPE is not None
         d_ff = self.w_1.weight.shape[0]
@@ -622,7 +626,7 @@ class PositionwiseFeedForward(_Cached):
                                       self.layer_norm.bias, self.layer_norm.eps)
             return Act(y32, y16, x.B, x.L)
         if _PRECISION == "bf16" and ops.ffn_fused_ok(x.b16, x.f32, self._w("w1", (self.w_1.weight,)), self._w("w2", (self.w_2.weight,)), x.B, x.L):
-            return self._impl_fused(x, row_len, rec)
+            return self._impl_fused(x, row_len, rec, drawn)
         # training: the ReLU mask travels to the backward as 1 sign bit per hidden unit (written by this GEMM's epilogue) - the
         # hidden gradient's GEMM then reads 8 MB instead of re-reading the 131 MB activation (S1 shape)
         use_bits = rec and _PRECISION == "bf16" and d_ff % 128 == 0 and x.mma().dtype == torch.bfloat16 and x.f32.shape[1] % 64 == 0
@@ -632,7 +636,7 @@ class PositionwiseFeedForward(_Cached):
                                  relu_bits_out=bits)
         else:
             hid = ops.gemm_nt(x.mma(), self._w("w1", (self.w_1.weight,)), self._b("b1", (self.w_1.bias,)), out_dtype=hdt, relu=True)
-        dp = _drop(self, "dropout")   # module.py:51
+        dp = _drop(self, "dropout") if drawn is False else drawn   # module.py:51
         w2m = self._w("w2", (self.w_2.weight,))
         if _PRECISION == "bf16" and ops.gemm_add_layernorm_ok(hid, w2m, x.f32.shape[1], x.B, x.L):       # projection + LayerNorm in one launch
             o, y32, y16, mean, rstd = ops.gemm_add_layernorm(hid, w2m, self._b("b2", (self.w_2.bias,)), x.f32, self.layer_norm.weight,
@@ -659,16 +663,21 @@ class PositionwiseFeedForward(_Cached):
             _TAPE.push(bw, (w1.weight, w1.bias, w2.weight, w2.bias, ln.weight, ln.bias))
         return y
 
-    def _impl_fused(self, x, row_len, rec):
+    def _impl_fused(self, x, row_len, rec, drawn=False):
         """Encoder-sized rows at d_model = 256: the sub-layer is ONE forward launch (asr_ffn_fwd: both products, bias, ReLU, dropout,
         residual, LayerNorm, row mask; the hidden activation is written once for the weight gradient, never read back in the forward)
         and ONE data-gradient launch (asr_ffn_bwd: dH and dX); the two weight gradients stay GEMMs over the stored H / dH."""
         ln, w1, w2 = self.layer_norm, self.w_1, self.w_2
         w1m, w2m = self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,))
-        dp = _drop(self, "dropout")   # module.py:51
-        hid, bits, o, y32, y16, mean, rstd = ops.ffn_fwd(x.b16, x.f32, w1m, self._b("b1", (w1.bias,)), w2m, self._b("b2", (w2.bias,)),
-                                                         ln.weight, ln.bias, x.B, x.L, row_len=row_len, eps=ln.eps, train=rec, drop_x=dp,
-                                                         save_s=not _LN_FROM_Y)
+        dp = _drop(self, "dropout") if drawn is False else drawn   # module.py:51
+        outs = ops.ffn_fwd(x.b16, x.f32, w1m, self._b("b1", (w1.bias,)), w2m, self._b("b2", (w2.bias,)), ln.weight, ln.bias, x.B, x.L,
+                           row_len=row_len, eps=ln.eps, train=rec, drop_x=dp, save_s=not _LN_FROM_Y)
+        return self._fused_finish(x, row_len, rec, dp, outs)
+
+    def _fused_finish(self, x, row_len, rec, dp, outs):
+        """the sub-layer's output Act and backward closure from asr_ffn_fwd's tensors (ops.ffn_fwd, or ops.attn_ffn_fwd's second tuple)"""
+        ln, w1, w2 = self.layer_norm, self.w_1, self.w_2
+        hid, bits, o, y32, y16, mean, rstd = outs
         y = Act(y32, y16, x.B, x.L)
         if rec:
             ln_in, ln_beta = (y32, ln.bias) if o is None else (o, None)
@@ -725,8 +734,31 @@ class EncoderLayer(nn.Module):
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
 
     def _impl(self, x, lens, causal=False, attn_drop=None):
-        x = self.slf_attn._impl(x, x, lens, causal, lens, attn_drop=attn_drop)   # `*= non_pad_mask` fused into the LN kernel
-        return self.pos_ffn._impl(x, lens)
+        att, ffn = self.slf_attn, self.pos_ffn
+        box = {}
+
+        def tail(ctx2, wfc, dp_fc, rec):
+            """the attention sub-layer's output projection + residual + LayerNorm and the whole feed-forward sub-layer in ONE launch
+            (asr_attn_ffn_fwd: both own the same 128-token row blocks) -> proj_ln's tuple; the feed-forward tensors wait in `box`"""
+            w1m, w2m = ffn._w("w1", (ffn.w_1.weight,)), ffn._w("w2", (ffn.w_2.weight,))
+            ffn_drops = bool(ffn.training and float(getattr(ffn, "dropout_rate", 0.0) or 0.0) > 0.0)
+            if not ops.attn_ffn_ok(ctx2, wfc, x.f32, w1m, w2m, x.B, x.L) or ffn_drops != (dp_fc is not None):
+                return None
+            dp = _drop(ffn, "dropout")   # module.py:51
+            if (dp is None) != (dp_fc is None):
+                box["dp"] = dp          # (drawn already: the separate launch below takes it)
+                return None
+            ln0, ln = att.layer_norm, ffn.layer_norm
+            pre, main = ops.attn_ffn_fwd(ctx2, wfc, att._b("bfc", (att.fc.bias,)), x.f32, ln0.weight, ln0.bias, w1m, ffn._b("b1", (ffn.w_1.bias,)),
+                                         w2m, ffn._b("b2", (ffn.w_2.bias,)), ln.weight, ln.bias, x.B, x.L, row_len=lens, eps0=ln0.eps,
+                                         eps=ln.eps, train=rec, drop0=dp_fc, drop_x=dp, save_s=not _LN_FROM_Y)
+            box["ffn"] = (dp, main)
+            return pre
+
+        y = att._impl(x, x, lens, causal, lens, attn_drop=attn_drop, tail=tail if _PRECISION == "bf16" else None)   # `*= non_pad_mask` fused into the LN kernel
+        if "ffn" in box:
+            return ffn._fused_finish(y, lens, _TAPE is not None, *box["ffn"])
+        return ffn._impl(y, lens, drawn=box.get("dp", False))
 
     def forward(self, enc_input, non_pad_mask=None, slf_attn_mask=None, lengths=None):
         if lengths is None and non_pad_mask is not None:

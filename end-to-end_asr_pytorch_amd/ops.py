@@ -384,6 +384,43 @@ def ffn_fwd(x16, x32, w1, b1, w2, b2, gamma, beta, B, L, row_len=None, eps=1e-5,
     return hid, bits, s_sum, y32, y16, mean, rstd
 
 
+ATTN_FFN_FUSED = os.environ.get("ASR_AMD_ATTN_FFN", "1") != "0"      # the attention sub-layer's tail and the feed-forward sub-layer of an encoder layer as ONE launch (asr_attn_ffn_fwd)
+
+
+def attn_ffn_ok(ctx2d, wo, x32, w1, w2, B, L):
+    """Shapes asr_attn_ffn_fwd takes: those of proj_ln AND of the fused feed-forward sub-layer."""
+    return (ATTN_FFN_FUSED and proj_ln_ok(ctx2d, wo, x32.shape[1], B, L) and
+            ffn_fused_ok(ctx2d, x32, w1, w2, B, L))
+
+
+def attn_ffn_fwd(ctx2d, wo, bo, residual, gamma0, beta0, w1, b1, w2, b2, gamma, beta, B, L, row_len=None, eps0=1e-5, eps=1e-5, train=False,
+                 drop0=None, drop_x=None, save_s=True):
+    """proj_ln + ffn_fwd in one launch (asr_hip.h: asr_attn_ffn_fwd) -> ((s0 or None, x32, x16, mean0, rstd0), ffn_fwd's tuple): the tensors of
+    the two calls it replaces, bit for bit."""
+    _req_cuda(ctx2d, wo, bo, residual, gamma0, beta0, w1, b1, w2, b2, gamma, beta, row_len)
+    M, dff, dev = B * L, w1.shape[0], residual.device
+    assert ctx2d.shape[0] == M and residual.is_contiguous()
+    f32, b16 = torch.float32, torch.bfloat16
+    s0 = torch.empty((M, 256), device=dev, dtype=f32) if (train and save_s) else None
+    x32 = torch.empty((M, 256), device=dev, dtype=f32)
+    x16 = torch.empty((M, 256), device=dev, dtype=b16)
+    mean0 = torch.empty(M, device=dev, dtype=f32) if train else None
+    rstd0 = torch.empty(M, device=dev, dtype=f32) if train else None
+    hid = torch.empty((M, dff), device=dev, dtype=b16) if train else None
+    bits = torch.empty((int(lib().asr_ffn_bits_words(M, dff)),), device=dev, dtype=torch.int32) if train else None
+    s_sum = torch.empty((M, 256), device=dev, dtype=f32) if (train and save_s) else None
+    y32 = torch.empty((M, 256), device=dev, dtype=f32)
+    y16 = torch.empty((M, 256), device=dev, dtype=b16)
+    mean = torch.empty(M, device=dev, dtype=f32) if train else None
+    rstd = torch.empty(M, device=dev, dtype=f32) if train else None
+    with _timed("attn_ffn_fwd[%dx256x%d]" % (M, dff), 4.0 * M * 256 * dff + 2.0 * M * 256 * 256):
+        check(lib().asr_attn_ffn_fwd(_stream(), _p(ctx2d), _p(residual), _p(wo), _p(bo), _p(gamma0), _p(beta0), float(eps0), _d(drop0), _p(s0),
+                                     _p(x32), _p(x16), _p(mean0), _p(rstd0), _p(w1), _p(b1), _p(w2), _p(b2), _p(gamma), _p(beta), _p(row_len),
+                                     _p(hid), _p(bits), _p(s_sum), _p(y32), _p(y16), _p(mean), _p(rstd), B, L, 256, dff, float(eps), _d(drop_x)),
+              "asr_attn_ffn_fwd")
+    return (s0, x32, x16, mean0, rstd0), (hid, bits, s_sum, y32, y16, mean, rstd)
+
+
 def ffn_bwd(ds16, ds32, w1, w2, bits):
     """(d_hid bf16 [M,d_ff], dx f32 [M,256]) = the sub-layer's data gradient in one launch (asr_hip.h: asr_ffn_bwd)."""
     _req_cuda(ds16, ds32, w1, w2, bits)

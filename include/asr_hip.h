@@ -270,6 +270,18 @@ int asr_ffn_fwd(void* stream, const void* x16, const float* x32, const void* w1,
 int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,
                     const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16, float* mean_out, float* rstd_out,
                     int B, int L, int d_model, float eps, asr_dropout_t drop_x);
+/* asr_proj_ln_fwd AND asr_ffn_fwd as ONE launch - the two row-wise sub-layer tails of an encoder layer behind its attention
+ * (encoder.py:74-77: `slf_attn`'s fc / dropout / residual / layer_norm, the row mask, then `pos_ffn`), d_model = 256:
+ *   x = LayerNorm0(dropout0(ctx16 . Wo^T + bo) + residual) [rows >= row_len zeroed]      -> x32 / x16 (OUTPUTS here), s0 / mean0 / rstd0
+ *   y = LayerNorm(dropout_x(relu(x . W1^T + b1) . W2^T + b2) + x) [rows >= row_len zeroed] -> everything asr_ffn_fwd writes
+ * Arguments as in the two entry points it replaces (s0_out may be NULL with mean0_out / rstd0_out given, like asr_proj_ln_fwd's);
+ * both dropout sites active or neither.  Results are those of the two launches, bit for bit: a workgroup owns the same 128 tokens in
+ * both phases and reads its own x rows back between them. */
+int asr_attn_ffn_fwd(void* stream, const void* ctx16, const float* residual, const void* wo, const float* bo, const float* gamma0,
+                     const float* beta0, float eps0, asr_dropout_t drop0, float* s0_out, float* x32, void* x16, float* mean0_out,
+                     float* rstd0_out, const void* w1, const float* b1, const void* w2, const float* b2, const float* gamma, const float* beta,
+                     const int32_t* row_len, void* hid_out, void* bits_out, float* s_out, float* y32, void* y16, float* mean_out,
+                     float* rstd_out, int B, int L, int d_model, int d_ff, float eps, asr_dropout_t drop_x);
 /* Data gradient of the same sub-layer in ONE launch (autograd of module.py:50-52 below the LayerNorm):
  *   dH = (ds16 . W2) * [h > 0]  (bits from asr_ffn_fwd);   dx = dH . W1 + ds32.
  * ds16 bf16 [M, 256]: the gradient wrt w_2's output (asr_add_layernorm_bwd's ds16); ds32 f32 [M, 256]: the gradient wrt the residual.

@@ -222,3 +222,36 @@ def test_ffn_bwd_with_the_layernorm_backward_folded_in(B, L, dff, drop):
         assert float(np.abs(N(ds_f)[pad]).max()) == 0.0                           # masked rows: no gradient
     for a, b in ((dg1, dg0), (db1, db0), (dbias1, dbias0)):
         np.testing.assert_allclose(N(a), N(b), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,L,dff,drop", [(4, 37, 128, False), (3, 100, 2048, True), (2, 128, 256, True), (1, 5, 64, False), (5, 129, 512, True),
+                                           (32, 250, 2048, True)])
+def test_attn_ffn_fwd_is_the_two_launches(B, L, dff, drop):
+    """asr_attn_ffn_fwd (the attention sub-layer's tail in front of the feed-forward sub-layer, one launch) against asr_proj_ln_fwd followed by
+    asr_ffn_fwd: every output tensor bit for bit, training and inference form, ragged lengths, partial last block."""
+    x32, w1, b1, w2, b2, gam, bet, lens = _case(B, L, dff, seed=B * 77 + L)
+    g = torch.Generator().manual_seed(B + L + dff)
+    M = B * L
+    ctx = torch.randn(M, 256, generator=g).bfloat16()
+    wo = (torch.randn(256, 256, generator=g) * 0.06).bfloat16()
+    bo = torch.randn(256, generator=g) * 0.2
+    g0 = torch.rand(256, generator=g) + 0.5
+    be0 = torch.randn(256, generator=g) * 0.3
+    d = lambda t: t.to(DEV).contiguous()
+    ctx, wo, bo, g0, be0, x32, w1, b1, w2, b2, gam, bet = [d(t) for t in (ctx, wo, bo, g0, be0, x32, w1, b1, w2, b2, gam, bet)]
+    rl = d(lens).int()
+    dr0 = ops.Dropout(THR, 11, 3) if drop else None
+    dr1 = ops.Dropout(THR, 5, 9) if drop else None
+    for train in (True, False):
+        for save_s in ((True, False) if train else (True,)):
+            s0, y0_32, y0_16, mean0, rstd0 = ops.proj_ln(ctx, wo, bo, x32, g0, be0, B, L, row_len=rl, save_stats=train, drop_x=dr0, save_s=save_s)
+            ref = ops.ffn_fwd(y0_16, y0_32, w1, b1, w2, b2, gam, bet, B, L, row_len=rl, train=train, drop_x=dr1, save_s=save_s)
+            pre, main = ops.attn_ffn_fwd(ctx, wo, bo, x32, g0, be0, w1, b1, w2, b2, gam, bet, B, L, row_len=rl, train=train, drop0=dr0, drop_x=dr1,
+                                         save_s=save_s)
+            for name, a_, b_ in list(zip(("s0", "x32", "x16", "mean0", "rstd0"), pre, (s0, y0_32, y0_16, mean0, rstd0))) + \
+                    list(zip(("hid", "bits", "s", "y32", "y16", "mean", "rstd"), main, ref)):
+                assert (a_ is None) == (b_ is None), name
+                if a_ is not None:
+                    if name == "bits":      # (words of rows past M are never written)
+                        continue
+                    assert torch.equal(a_, b_), "%s differs (train %s, save_s %s): max %g" % (name, train, save_s, float((a_.float() - b_.float()).abs().max()))
