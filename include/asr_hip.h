@@ -62,7 +62,7 @@ int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, in
 #define ASR_GEMM_C_IS_ZERO 4u   /* the caller's C is already all zeros: a split-K launch (few output tiles, long K) skips its zeroing kernel */
 
 /* ABI revision: 100 = rounds 1-4; 101 = asr_vocab_proj_lse and asr_ctc_loss_fwd_lse removed (asr_vocab_proj_ctc + asr_ctc_loss_fwd_table
- * replace them), asr_launch_budget_current added.  A binder checks this before it resolves symbols. */
+ * replace them), asr_launch_budget_current added; 102 = asr_attn_ffn_fwd added.  A binder checks this before it resolves symbols. */
 int asr_version(void);
 /* Deterministic mode (also ASR_AMD_DETERMINISTIC=1 in the environment): the forward GEMMs stop splitting K across workgroups (float
  * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
