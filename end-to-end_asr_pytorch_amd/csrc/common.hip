@@ -14,7 +14,7 @@ void asr_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int asr_version(void) { return 103; }   // 101: asr_vocab_proj_lse / asr_ctc_loss_fwd_lse removed (round 5), asr_launch_budget_current added; 102: asr_attn_ffn_fwd added; 103: asr_dgrad_rows_ffn_bwd_ln added
+extern "C" int asr_version(void) { return 102; }   // 101: asr_vocab_proj_lse / asr_ctc_loss_fwd_lse removed (round 5), asr_launch_budget_current added; 102: asr_attn_ffn_fwd added
 extern "C" const char* asr_last_error(void) { return g_err; }
 
 // deterministic mode: kernels that would otherwise combine partial results with float atomics in arrival order (the forward GEMMs'

@@ -14,8 +14,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-#include "dgrad_rows_body.h"
-
 namespace {
 
 #ifndef FFN_HID_POLICY
@@ -279,10 +277,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* p, int second_off
     return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
 }
 
-constexpr int FFN_BWD_SMEM = 2 * W1BUF + 2 * W2BUF + HST_BYTES;
-// (the launch's work as a function of (arguments, LDS): a kernel of its own below, and the second phase of dgrad_ffn_bwd_kernel)
 template <bool LNB>
-__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, unsigned char* const smem) {
+__global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * W1BUF + 2 * W2BUF + HST_BYTES];
     unsigned char* const w2s = smem;                    // first product's weights here
     unsigned char* const w1s = smem + 2 * W2BUF;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -560,27 +557,6 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& a, unsigned char*
             atomicAdd(dst + tid, v);
         }
     }
-}
-
-template <bool LNB>
-__global__ __launch_bounds__(256, 1) void ffn_bwd_kernel(const FfnBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FFN_BWD_SMEM];
-    ffn_bwd_body<LNB>(a, smem);
-}
-
-// asr_dgrad_rows_ln and asr_ffn_bwd_ln as ONE launch: the backward of an encoder layer's q / k / v projections (with the LayerNorm in front of
-// them folded in: dgrad_rows.hip, OUT_LNB) produces ds / ds16 of the feed-forward sub-layer BELOW - exactly the rows, workgroup by workgroup and
-// wave by wave, that this file's data gradient of that sub-layer takes as its operands.  Second phase behind the first: the 48 MB of ds + ds16
-// per layer are read back from the XCD's L2 by the workgroup that has just written them, not from HBM by a launch of its own.
-template <bool ADD>
-__global__ __launch_bounds__(256, 1) void dgrad_ffn_bwd_kernel(const RowsArgs ra, const FfnBwdArgs fa) {
-    static_assert(RSMEM == FFN_BWD_SMEM && RBM == FBM, "both phases own the same 128-row blocks and the same 144 KiB of LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[FFN_BWD_SMEM];
-    dgrad_rows_body<OUT_LNB, ADD>(ra, smem);
-    // the rows are the second phase's inputs: written (acknowledged by L2) before any wave reads them, and every wave is past the column sums
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    ffn_bwd_body<true>(fa, smem);
 }
 
 // ---- head-major projections on the same structure (attention.py:43-49: w_qs / w_ks / w_vs + view / permute / contiguous) ---------
@@ -911,43 +887,5 @@ extern "C" int asr_ffn_bwd_ln(void* stream, const void* ds16, const float* ds32,
     a.ds_out = ds_out; a.ds16_out = (bf16_t*)ds16_out; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias; a.drop_x = drop_x;
     hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3((M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, a);
     ASR_LAUNCH_CHECK("asr_ffn_bwd_ln");
-    return 0;
-}
-
-extern "C" int asr_dgrad_rows_ffn_bwd_ln(void* stream, const void* dy, int64_t ldy, const void* w, const float* addend, int B, int L, int K, int d_model,
-                                         const float* ln_s, const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta,
-                                         const int32_t* row_len, float* ds_out, void* ds16_out, float* dgamma, float* dbeta, float* dbias,
-                                         asr_dropout_t drop_x, const void* w1, const void* w2, const void* bits, void* dhid_out, int d_ff,
-                                         const float* ln2_s, const float* ln2_mean, const float* ln2_rstd, const float* ln2_gamma,
-                                         const float* ln2_beta, float* ds2_out, void* ds2_16_out, float* dgamma2, float* dbeta2, float* dbias2,
-                                         asr_dropout_t drop2_x) {
-    ASR_REQUIRE(B > 0 && L > 0, ASR_ERR_ARG, "asr_dgrad_rows_ffn_bwd_ln: bad B / L");
-    const int M = B * L;
-    ASR_REQUIRE(d_model == FD, -1, "asr_dgrad_rows_ffn_bwd_ln: d_model = %d (built for 256)", d_model);
-    ASR_REQUIRE(K >= RKC && K % RKC == 0, ASR_ERR_UNSUPPORTED, "asr_dgrad_rows_ffn_bwd_ln: K = %d (a multiple of 64)", K);
-    ASR_REQUIRE(ldy >= K && ldy % 8 == 0 && ((int64_t)(M - 1) * ldy + K) * 2 < (1ll << 32), ASR_ERR_ARG, "asr_dgrad_rows_ffn_bwd_ln: bad row stride");
-    ASR_REQUIRE(d_ff >= FHC && d_ff % FHC == 0 && d_ff <= FFN_MAX_DFF && (int64_t)M * d_ff * 2 < (1ll << 31), -1,
-                "asr_dgrad_rows_ffn_bwd_ln: d_ff = %d (a multiple of 64 up to %d) / B * L out of range", d_ff, FFN_MAX_DFF);
-    ASR_REQUIRE(dy && w && ln_s && (ln_mean || ln_beta) && ln_rstd && ln_gamma && ds_out && ds16_out && dgamma && dbeta && w1 && w2 && bits && dhid_out &&
-                    ln2_s && (ln2_mean || ln2_beta) && ln2_rstd && ln2_gamma && ds2_out && ds2_16_out && dgamma2 && dbeta2, ASR_ERR_ARG,
-                "asr_dgrad_rows_ffn_bwd_ln: null argument");
-    ASR_REQUIRE(asr_aligned(dy, 16) && asr_aligned(w, 16) && asr_aligned(ln_s, 16) && asr_aligned(ln_gamma, 16) && asr_aligned(ds_out, 16) &&
-                    asr_aligned(ds16_out, 16) && (!addend || asr_aligned(addend, 16)) && asr_aligned(w1, 16) && asr_aligned(w2, 16) &&
-                    asr_aligned(dhid_out, 16) && asr_aligned(ln2_s, 16) && asr_aligned(ln2_gamma, 16) && asr_aligned(ds2_out, 16) &&
-                    asr_aligned(ds2_16_out, 16), ASR_ERR_ALIGN, "asr_dgrad_rows_ffn_bwd_ln: 16-byte aligned buffers required");
-    RowsArgs ra{};
-    ra.dy = (const bf16_t*)dy; ra.w = (const bf16_t*)w; ra.addend = addend; ra.M = M; ra.K = K; ra.ldy = ldy;
-    ra.out32 = ds_out; ra.out16 = (bf16_t*)ds16_out;
-    ra.ln_s = ln_s; ra.ln_mean = ln_mean; ra.ln_rstd = ln_rstd; ra.ln_gamma = ln_gamma; ra.ln_beta = ln_beta; ra.row_len = row_len; ra.L = L;
-    ra.dgamma = dgamma; ra.dbeta = dbeta; ra.dbias = dbias; ra.drop_x = drop_x;
-    FfnBwdArgs fa{};
-    fa.ds16 = (const bf16_t*)ds16_out; fa.ds32 = ds_out; fa.w1 = (const bf16_t*)w1; fa.w2 = (const bf16_t*)w2; fa.bits = (const uint32_t*)bits;
-    fa.dhid = (bf16_t*)dhid_out; fa.dx = nullptr; fa.M = M; fa.dff = d_ff; fa.Mp = (M + FBM - 1) / FBM * FBM;
-    fa.ln_s = ln2_s; fa.ln_mean = ln2_mean; fa.ln_rstd = ln2_rstd; fa.ln_gamma = ln2_gamma; fa.ln_beta = ln2_beta; fa.row_len = row_len; fa.L = L;
-    fa.ds_out = ds2_out; fa.ds16_out = (bf16_t*)ds2_16_out; fa.dgamma = dgamma2; fa.dbeta = dbeta2; fa.dbias = dbias2; fa.drop_x = drop2_x;
-    const dim3 grid((M + FBM - 1) / FBM), block(256);
-    if (addend) hipLaunchKernelGGL(dgrad_ffn_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, ra, fa);
-    else hipLaunchKernelGGL(dgrad_ffn_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, ra, fa);
-    ASR_LAUNCH_CHECK("asr_dgrad_rows_ffn_bwd_ln");
     return 0;
 }

@@ -368,16 +368,13 @@ class _Cached(nn.Module):
 
 class Act:
     """An activation as it travels between kernels: fp32 master [M,D] (+ optional bf16 shadow for MFMA)."""
-    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q", "ln_ctx", "ln_done", "lazy_grad", "bw_plan", "bw_pre")
+    __slots__ = ("f32", "b16", "B", "L", "grad", "needs_grad", "next_q", "ln_ctx", "ln_done", "lazy_grad")
 
     def __init__(self, f32, b16, B, L):
         self.f32, self.b16, self.B, self.L, self.grad, self.needs_grad = f32, b16, B, L, None, False
         # a LayerNorm output whose ONLY reader may run that LayerNorm's backward in its own data-gradient launch (asr_ffn_bwd_ln):
         # ln_ctx = what the backward needs (set by the producer), ln_done = (ds, ds16) once a reader has done it
         self.ln_ctx = self.ln_done = None
-        # a feed-forward sub-layer's output: bw_plan() -> what its data-gradient launch needs (or None), so that the reader whose backward
-        # produces this Act's ds can run that launch as a second phase of its own (ops.gemm_nn_ln_ffn_bwd); bw_pre = its results then
-        self.bw_plan = self.bw_pre = None
         self.lazy_grad = None    # a callable that adds a gradient contribution computed elsewhere (the trainer's CTC side branch) into .grad
         self.next_q = None       # decode step: the next cross attention's projected queries, when the launch that made this produced them
 
@@ -519,18 +516,8 @@ class MultiheadAttention(_Cached):
                     # xq is a LayerNorm output that only this sub-layer read (encoder.py:74-77): its gradient goes through that
                     # LayerNorm's backward in the data-gradient launch itself (asr_dgrad_rows_ln) - no dx in memory, no launch of its own
                     p_s, p_mean, p_rstd, p_ln, p_len, p_bias, p_drop, p_beta = xq.ln_ctx
-                    plan = xq.bw_plan() if (xq.bw_plan is not None and ops.ROWS_FFN_BWD_FUSED) else None
-                    if plan is not None:
-                        # ... and the data gradient of the feed-forward sub-layer that produced xq as the launch's second phase
-                        # (asr_dgrad_rows_ffn_bwd_ln): its operands are the rows this launch writes
-                        f_w1, f_w2, f_bits, (q_s, q_mean, q_rstd, q_ln, q_len, q_bias, q_drop, q_beta) = plan
-                        r = ops.gemm_nn_ln_ffn_bwd(dqkv, wqkv, ds, B, Lq, p_s, p_mean, p_rstd, p_ln.weight, p_len, p_ln.weight.grad, p_ln.bias.grad,
-                                                   p_bias.grad, p_drop, p_beta, f_w1, f_w2, f_bits, q_s, q_mean, q_rstd, q_ln.weight,
-                                                   q_ln.weight.grad, q_ln.bias.grad, q_bias.grad, q_drop, q_beta)
-                        xq.ln_done, xq.bw_pre = (r[0], r[1]), (r[2], r[3], r[4])
-                    else:
-                        xq.ln_done = ops.gemm_nn_ln(dqkv, wqkv, ds, B, Lq, p_s, p_mean, p_rstd, p_ln.weight, p_len, p_ln.weight.grad,
-                                                    p_ln.bias.grad, dbias=p_bias.grad, drop_x=p_drop, ln_beta=p_beta)
+                    xq.ln_done = ops.gemm_nn_ln(dqkv, wqkv, ds, B, Lq, p_s, p_mean, p_rstd, p_ln.weight, p_len, p_ln.weight.grad,
+                                                p_ln.bias.grad, dbias=p_bias.grad, drop_x=p_drop, ln_beta=p_beta)
                 else:
                     _acc(xq, ops.gemm_nn(dqkv, wqkv, addend=ds))
             else:
@@ -696,15 +683,6 @@ class PositionwiseFeedForward(_Cached):
             ln_in, ln_beta = (y32, ln.bias) if o is None else (o, None)
             y.ln_ctx = (ln_in, mean, rstd, ln, row_len, w2.bias, dp, ln_beta)
 
-            def plan():
-                """for the reader whose backward launch produces this sub-layer's ds (MultiheadAttention._record_bw): the data gradient's
-                operands, when it is the folded form (below) that would run"""
-                if not (_FOLD_LN and x.ln_ctx is not None and x.grad is None and _PRECISION == "bf16"):
-                    return None
-                return self._w("w1", (w1.weight,)), self._w("w2", (w2.weight,)), bits, x.ln_ctx
-
-            y.bw_plan = plan
-
             def bw():
                 if y.ln_done is not None:      # the next layer's attention sub-layer ran this LayerNorm's backward in its data-gradient launch
                     ds, ds16 = y.ln_done
@@ -713,14 +691,8 @@ class PositionwiseFeedForward(_Cached):
                     ds, ds16 = _ln_bwd(y.grad, ln_in, mean, rstd, ln.weight, row_len, x.B, x.L, ln.weight.grad, ln.bias.grad,
                                           dbias=w2.bias.grad, drop_x=dp, beta=ln_beta)
                 y.grad = None
-                y.bw_plan = None
                 fold = _FOLD_LN and x.ln_ctx is not None and x.grad is None and _PRECISION == "bf16"
-                if y.bw_pre is not None:       # ... and this sub-layer's data gradient as that launch's second phase
-                    d_hid, p_ds, p_ds16 = y.bw_pre
-                    y.bw_pre = None
-                    x.ln_done = (p_ds, p_ds16)
-                    fold = True
-                elif fold:
+                if fold:
                     # x is a LayerNorm output that only this sub-layer read (encoder.py:74-76): dx goes through that LayerNorm's
                     # backward in ffn_bwd's epilogue instead of through memory and a launch of its own
                     p_s, p_mean, p_rstd, p_ln, p_len, p_bias, p_drop, p_beta = x.ln_ctx

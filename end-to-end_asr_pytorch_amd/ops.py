@@ -384,7 +384,7 @@ def ffn_fwd(x16, x32, w1, b1, w2, b2, gamma, beta, B, L, row_len=None, eps=1e-5,
     return hid, bits, s_sum, y32, y16, mean, rstd
 
 
-ATTN_FFN_FUSED = True      # the attention sub-layer's tail and the feed-forward sub-layer of an encoder layer as ONE launch (asr_attn_ffn_fwd)
+ATTN_FFN_FUSED = os.environ.get("ASR_AMD_ATTN_FFN", "1") != "0"      # the attention sub-layer's tail and the feed-forward sub-layer of an encoder layer as ONE launch (asr_attn_ffn_fwd)
 
 
 def attn_ffn_ok(ctx2d, wo, x32, w1, w2, B, L):
@@ -903,31 +903,6 @@ def gemm_nn_ln(a2d, w, addend, B, L, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, 
                                       _p(ln_gamma), _p(ln_beta), _p(row_len), _p(ds), _p(ds_b), _p(dgamma), _p(dbeta), _p(dbias), _d(drop_x)),
               "asr_dgrad_rows_ln")
     return ds, ds_b
-
-
-ROWS_FFN_BWD_FUSED = True      # gemm_nn_ln + ffn_bwd_ln as one launch (asr_dgrad_rows_ffn_bwd_ln)
-
-
-def gemm_nn_ln_ffn_bwd(a2d, w, addend, B, L, ln_s, ln_mean, ln_rstd, ln_gamma, row_len, dgamma, dbeta, dbias, drop_x, ln_beta, w1, w2, bits,
-                       ln2_s, ln2_mean, ln2_rstd, ln2_gamma, dgamma2, dbeta2, dbias2, drop2_x, ln2_beta):
-    """gemm_nn_ln(...) and, on its result, ffn_bwd_ln(...) in ONE launch (asr_hip.h: asr_dgrad_rows_ffn_bwd_ln)
-    -> (ds, ds16, d_hid, ds2, ds2_16): the tensors of the two calls."""
-    _req_cuda(a2d, w, addend, ln_s, ln_rstd, ln_gamma, dgamma, dbeta, w1, w2, bits, ln2_s, ln2_rstd, ln2_gamma, dgamma2, dbeta2)
-    M, K = a2d.shape
-    dff, dev = w1.shape[0], a2d.device
-    assert M == B * L and dgrad_rows_ok(a2d, w) and ln_s.is_contiguous() and ln2_s.is_contiguous() and (addend is None or addend.is_contiguous())
-    ds = torch.empty((M, 256), device=dev, dtype=torch.float32)
-    ds_b = torch.empty((M, 256), device=dev, dtype=torch.bfloat16)
-    d_hid = torch.empty((M, dff), device=dev, dtype=torch.bfloat16)
-    ds2 = torch.empty((M, 256), device=dev, dtype=torch.float32)
-    ds2_b = torch.empty((M, 256), device=dev, dtype=torch.bfloat16)
-    with _timed("gemm_nn_ffn_bwd[%dx256x%d+%d]" % (M, K, dff), 2.0 * M * 256 * K + 4.0 * M * 256 * dff):
-        check(lib().asr_dgrad_rows_ffn_bwd_ln(_stream(), _p(a2d), a2d.stride(0), _p(w), _p(addend), B, L, K, 256, _p(ln_s), _p(ln_mean), _p(ln_rstd),
-                                              _p(ln_gamma), _p(ln_beta), _p(row_len), _p(ds), _p(ds_b), _p(dgamma), _p(dbeta), _p(dbias), _d(drop_x),
-                                              _p(w1), _p(w2), _p(bits), _p(d_hid), dff, _p(ln2_s), _p(ln2_mean), _p(ln2_rstd), _p(ln2_gamma),
-                                              _p(ln2_beta), _p(ds2), _p(ds2_b), _p(dgamma2), _p(dbeta2), _p(dbias2), _d(drop2_x)),
-              "asr_dgrad_rows_ffn_bwd_ln")
-    return ds, ds_b, d_hid, ds2, ds2_b
 
 
 def gemm_nn(a2d, w, out_dtype=torch.float32, addend=None, relu_mask=None, lda=None, K=None, relu_bits=None):

@@ -62,7 +62,7 @@ int asr_dropout_apply(void* stream, const float* x, float* y, int N0, int N1, in
 #define ASR_GEMM_C_IS_ZERO 4u   /* the caller's C is already all zeros: a split-K launch (few output tiles, long K) skips its zeroing kernel */
 
 /* ABI revision: 100 = rounds 1-4; 101 = asr_vocab_proj_lse and asr_ctc_loss_fwd_lse removed (asr_vocab_proj_ctc + asr_ctc_loss_fwd_table
- * replace them), asr_launch_budget_current added; 102 = asr_attn_ffn_fwd added; 103 = asr_dgrad_rows_ffn_bwd_ln added.  A binder checks this before it resolves symbols. */
+ * replace them), asr_launch_budget_current added; 102 = asr_attn_ffn_fwd added.  A binder checks this before it resolves symbols. */
 int asr_version(void);
 /* Deterministic mode (also ASR_AMD_DETERMINISTIC=1 in the environment): the forward GEMMs stop splitting K across workgroups (float
  * atomics in arrival order) and the weight gradient's bias side product takes its single-writer form; the weight gradient itself
@@ -270,18 +270,6 @@ int asr_ffn_fwd(void* stream, const void* x16, const float* x32, const void* w1,
 int asr_proj_ln_fwd(void* stream, const void* ctx16, const float* residual, const void* w, const float* bias, const float* gamma,
                     const float* beta, const int32_t* row_len, float* s_out, float* y32, void* y16, float* mean_out, float* rstd_out,
                     int B, int L, int d_model, float eps, asr_dropout_t drop_x);
-/* asr_dgrad_rows_ln AND asr_ffn_bwd_ln as ONE launch - the backward of an encoder layer's q / k / v projections with the LayerNorm in front
- * of them folded in (that LayerNorm closes the feed-forward sub-layer of the layer below, encoder.py:74-77), followed by that sub-layer's data
- * gradient on the rows just produced: arguments 2-21 are asr_dgrad_rows_ln's (ds_out / ds16_out are OUTPUTS here and the second phase's
- * ds32 / ds16), the rest asr_ffn_bwd_ln's without its first two (ln2_* = the LayerNorm that produced the feed-forward sub-layer's input,
- * ds2_* / dgamma2 / dbeta2 / dbias2 / drop2_x its results and parameters).  Same 128-row blocks in both phases; results are those of the
- * two launches bit for bit (the column sums by float atomics as there). */
-int asr_dgrad_rows_ffn_bwd_ln(void* stream, const void* dy, int64_t ldy, const void* w, const float* addend, int B, int L, int K, int d_model,
-                              const float* ln_s, const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta,
-                              const int32_t* row_len, float* ds_out, void* ds16_out, float* dgamma, float* dbeta, float* dbias,
-                              asr_dropout_t drop_x, const void* w1, const void* w2, const void* bits, void* dhid_out, int d_ff,
-                              const float* ln2_s, const float* ln2_mean, const float* ln2_rstd, const float* ln2_gamma, const float* ln2_beta,
-                              float* ds2_out, void* ds2_16_out, float* dgamma2, float* dbeta2, float* dbias2, asr_dropout_t drop2_x);
 /* asr_proj_ln_fwd AND asr_ffn_fwd as ONE launch - the two row-wise sub-layer tails of an encoder layer behind its attention
  * (encoder.py:74-77: `slf_attn`'s fc / dropout / residual / layer_norm, the row mask, then `pos_ffn`), d_model = 256:
  *   x = LayerNorm0(dropout0(ctx16 . Wo^T + bo) + residual) [rows >= row_len zeroed]      -> x32 / x16 (OUTPUTS here), s0 / mean0 / rstd0

@@ -255,45 +255,3 @@ def test_attn_ffn_fwd_is_the_two_launches(B, L, dff, drop):
                     if name == "bits":      # (words of rows past M are never written)
                         continue
                     assert torch.equal(a_, b_), "%s differs (train %s, save_s %s): max %g" % (name, train, save_s, float((a_.float() - b_.float()).abs().max()))
-
-
-@pytest.mark.parametrize("B,L,dff,from_y", [(4, 37, 128, False), (3, 100, 2048, True), (1, 5, 64, True), (5, 129, 512, False), (32, 250, 2048, True)])
-def test_dgrad_rows_ffn_bwd_is_the_two_launches(B, L, dff, from_y, monkeypatch):
-    """asr_dgrad_rows_ffn_bwd_ln (q / k / v data gradient + LayerNorm backward, then the feed-forward sub-layer's data gradient + the
-    LayerNorm backward in front of it, one launch) against asr_dgrad_rows_ln followed by asr_ffn_bwd_ln: row outputs bit for bit, the
-    column sums (float atomics in arrival order in both forms) to rounding."""
-    monkeypatch.setattr(ops, "DGRAD_ROWS_MIN", 1)      # (the row-block kernels at every size: the wrapper's row threshold is a speed policy)
-    x32, w1, b1, w2, b2, gam, bet, lens = _case(B, L, dff, seed=B * 31 + L)
-    g = torch.Generator().manual_seed(B + 3 * L + dff)
-    M = B * L
-    d = lambda t: t.to(DEV).contiguous()
-    x32, w1, b1, w2, b2, gam, bet = [d(t) for t in (x32, w1, b1, w2, b2, gam, bet)]
-    rl = d(lens).int()
-    dr = ops.Dropout(THR, 5, 9)
-    # a forward of the feed-forward sub-layer for its mask image and LayerNorm state; x32 plays the attention sub-layer's LayerNorm output
-    hid, bits, s, y32, y16, mean, rstd = ops.ffn_fwd(x32.bfloat16(), x32, w1, b1, w2, b2, gam, bet, B, L, row_len=rl, train=True, drop_x=dr,
-                                                     save_s=not from_y)
-    ln_s, ln_beta = (y32, bet) if from_y else (s, None)
-    g0 = d(torch.rand(256, generator=g) + 0.5)
-    be0 = d(torch.randn(256, generator=g) * 0.3)
-    mean0 = x32.mean(-1).contiguous()
-    rstd0 = (1.0 / torch.sqrt(x32.var(-1, unbiased=False) + 1e-5)).contiguous()
-    ln2_s, ln2_beta = (x32 * g0 + be0, be0) if from_y else (x32, None)      # (any rows do: both forms read the same ones)
-    ln2_s = ln2_s.contiguous()
-    dqkv = d((torch.randn(M, 768, generator=g) * 0.05).bfloat16())
-    wqkv = d((torch.randn(768, 256, generator=g) * 0.06).bfloat16())
-    add = d(torch.randn(M, 256, generator=g) * 0.05)
-    dr0 = ops.Dropout(THR, 11, 3)
-
-    def grads():
-        return [torch.zeros(256, device=DEV) for _ in range(6)]
-    ga = grads()
-    ds, ds16 = ops.gemm_nn_ln(dqkv, wqkv, add, B, L, ln_s, mean, rstd, gam, rl, ga[0], ga[1], dbias=ga[2], drop_x=dr, ln_beta=ln_beta)
-    d_hid, ds2, ds2_16 = ops.ffn_bwd_ln(ds16, ds, w1, w2, bits, B, L, ln2_s, mean0, rstd0, g0, rl, ga[3], ga[4], dbias=ga[5], drop_x=dr0, ln_beta=ln2_beta)
-    gb = grads()
-    r = ops.gemm_nn_ln_ffn_bwd(dqkv, wqkv, add, B, L, ln_s, mean, rstd, gam, rl, gb[0], gb[1], gb[2], dr, ln_beta, w1, w2, bits, ln2_s, mean0, rstd0, g0,
-                               gb[3], gb[4], gb[5], dr0, ln2_beta)
-    for name, a_, b_ in zip(("ds", "ds16", "d_hid", "ds2", "ds2_16"), r, (ds, ds16, d_hid, ds2, ds2_16)):
-        assert torch.equal(a_, b_), "%s differs: max %g" % (name, float((a_.float() - b_.float()).abs().max()))
-    for name, a_, b_ in zip(("dgamma", "dbeta", "dbias", "dgamma2", "dbeta2", "dbias2"), gb, ga):
-        np.testing.assert_allclose(N(a_), N(b_), rtol=2e-4, atol=2e-4 * float(b_.abs().max() + 1e-6), err_msg=name)
