@@ -215,6 +215,14 @@ __device__ __forceinline__ void attn_tail_phase(unsigned char* smem, const Ffn2A
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xb[ks] = *reinterpret_cast<const u32x4*>(xr + 32 * ks);
     }
+    // the residual rows of this wave's 16 rows (row layout: lane = 4 columns): requested with everything else the phase reads - one HBM
+    // round trip for the weight images, the context rows and these (64 + 32 + 64 registers with the accumulators: inside a wave's 176)
+    f32x4 res[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int rowc = m0 + k < a0.M ? m0 + k : a0.M - 1;
+        res[k] = *reinterpret_cast<const f32x4*>(a0.pre_res32 + (int64_t)rowc * FD + 4 * lane);
+    }
     f32x4 acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -233,13 +241,6 @@ __device__ __forceinline__ void attn_tail_phase(unsigned char* smem, const Ffn2A
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) Mma<bf16_t>::run(*reinterpret_cast<const u32x4*>(wj + fa[ks]), xb[ks], acc[j]);
         __builtin_amdgcn_sched_barrier(0);
-    }
-    // the residual rows of this wave's 16 rows: requested here, landing under the tile hand-over
-    f32x4 res[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int rowc = m0 + k < a0.M ? m0 + k : a0.M - 1;
-        res[k] = *reinterpret_cast<const f32x4*>(a0.pre_res32 + (int64_t)rowc * FD + 4 * lane);
     }
     __syncthreads();      // every wave is past its fragment reads: the images become the waves' row tiles
     {
