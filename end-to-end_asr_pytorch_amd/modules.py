@@ -794,6 +794,10 @@ class Encoder(_Cached):
             need_dx = x_in.needs_grad
 
             def bw():
+                # the tape's last closure: the weight gradients still waiting for a grouped launch go to the side stream NOW, beside this
+                # closure's three launches - flushed at the end of the backward they ran alone, on half the chip, while Adam waited
+                # (tools/step_tail.py: main chain's last kernel -> Adam 136 -> 88 us; S1 - 0.02 ms, S2 - 0.02 ms, five pairs each)
+                flush_wgrads()
                 ds, ds16 = _ln_bwd(y0.grad, o, mean, rstd, ln.weight, None, B, L, ln.weight.grad, ln.bias.grad,
                                       dbias=lin.bias.grad, drop_y=dp)
                 y0.grad = None
