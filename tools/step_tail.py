@@ -35,6 +35,10 @@ def main():
     t_adam = rows[c][0]
     for s, e, n, q, st in rows[c - N:c + 1]:
         print("  q%s  start %9.1f us  end %9.1f us  dur %7.1f  %s" % (q, (s - t_adam) / 1e3, (e - t_adam) / 1e3, (e - s) / 1e3, short(n)))
+    print("the step's head (times from the end of the previous step's Adam):")
+    t_end = rows[c][1]
+    for s, e, n, q, st in rows[c + 1:c + 1 + N]:
+        print("  q%s  start %9.1f us  end %9.1f us  dur %7.1f  %s" % (q, (s - t_end) / 1e3, (e - t_end) / 1e3, (e - s) / 1e3, short(n)))
 
 
 if __name__ == "__main__":
